@@ -1,0 +1,83 @@
+/* CPU oracle: synthetic Atari-shaped vector environment — TEST INFRASTRUCTURE.
+ *
+ * Stands in for make_atari (reference agent0/common/atari_wrappers.py:59-69, gymnasium 0.28.1 + ale-py, neither
+ * present on the GPU box; SURVEY.md §8(d) "Synthetic inputs").  It honours the tuple/info contract that
+ * Actor.sample consumes (agent0/deepq/agent.py:55-62,85-88): obs (E,4,84,84) u8 frame stack, reward in {-1,0,1},
+ * terminal, truncated (never), info["life_loss"], and an episode-return record on terminal with the observation
+ * already auto-reset.  It is NOT Atari; it exists so throughput can be measured with inputs of the right shape.
+ * The device twin is agent0_amd/csrc/synth_env.hip and must match this file byte-for-byte.
+ *
+ *   frame(e,g)[y][x] = lit ? (h & 255) : 0,   h = mix(seed ^ mix(e*0x9E3779B1 + g) ^ ((y*84+x)*0x85EBCA77)),
+ *                      lit = ((h >> 8) & 3) == 0;  an 8x8 block of 255 at (by,bx) = ((3g+11e)%77, (5g+7e)%77)
+ *   draws (x0..x3) = philox4x32_10(ctr = (e, g, 0, 0x454E56), key = (seed_lo, seed_hi ^ rank))
+ *   reward   = x0%1000 < 50 ? -1 : x0%1000 < 100 ? +1 : 0          P = (0.05, 0.05, 0.90)
+ *   terminal = x1 % 500 == 0;  life_loss = !terminal && x2 % 200 == 0;  truncated = 0
+ *   obs'     = terminal ? 4 x frame(e,g) : shift(obs) + frame(e,g)
+ */
+#include <stdint.h>
+#include <string.h>
+
+void a0o_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]);
+
+#define A0O_H 84
+#define A0O_W 84
+#define A0O_PIX (A0O_H * A0O_W)
+
+static uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+void a0o_env_frame(uint32_t seed, uint32_t e, uint32_t g, uint8_t* out /* [84*84] */) {
+    uint32_t base = seed ^ mix32(e * 0x9E3779B1u + g);
+    uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    for (uint32_t y = 0; y < A0O_H; ++y)
+        for (uint32_t x = 0; x < A0O_W; ++x) {
+            uint32_t h = mix32(base ^ ((y * A0O_W + x) * 0x85EBCA77u));
+            uint8_t v = (((h >> 8) & 3u) == 0u) ? (uint8_t)(h & 255u) : 0;
+            if (y >= by && y < by + 8 && x >= bx && x < bx + 8) v = 255;
+            out[y * A0O_W + x] = v;
+        }
+}
+
+void a0o_env_reset(uint64_t seed, uint32_t rank, int64_t E, uint32_t* g, float* ep_ret, uint8_t* obs /* [E,4,84,84] */) {
+    (void)rank;
+    for (int64_t e = 0; e < E; ++e) {
+        g[e] = 0; ep_ret[e] = 0.0f;
+        uint8_t* o = obs + (size_t)e * 4 * A0O_PIX;
+        a0o_env_frame((uint32_t)seed, (uint32_t)e, 0, o);
+        for (int c = 1; c < 4; ++c) memcpy(o + c * A0O_PIX, o, A0O_PIX);
+    }
+}
+
+void a0o_env_step(uint64_t seed, uint32_t rank, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,
+                  const uint8_t* obs_in, uint8_t* obs_out, float* reward, uint8_t* terminal, uint8_t* truncated,
+                  uint8_t* life_loss, uint8_t* final_mask, float* final_ret) {
+    (void)action;
+    for (int64_t e = 0; e < E; ++e) {
+        uint32_t gg = g[e] + 1u;
+        g[e] = gg;
+        uint32_t ctr[4] = {(uint32_t)e, gg, 0u, 0x454E56u};
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ rank};
+        uint32_t x[4];
+        a0o_philox4x32_10(ctr, key, x);
+        uint32_t rw = x[0] % 1000u;
+        float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+        uint8_t term = (x[1] % 500u) == 0u;
+        uint8_t life = (!term) && ((x[2] % 200u) == 0u);
+        reward[e] = r; terminal[e] = term; truncated[e] = 0; life_loss[e] = life;
+        ep_ret[e] += r;
+        final_mask[e] = term; final_ret[e] = term ? ep_ret[e] : 0.0f;
+        if (term) ep_ret[e] = 0.0f;
+        const uint8_t* in = obs_in + (size_t)e * 4 * A0O_PIX;
+        uint8_t* out = obs_out + (size_t)e * 4 * A0O_PIX;
+        uint8_t fr[A0O_PIX];
+        a0o_env_frame((uint32_t)seed, (uint32_t)e, gg, fr);
+        if (term) {
+            for (int c = 0; c < 4; ++c) memcpy(out + c * A0O_PIX, fr, A0O_PIX);
+        } else {
+            memmove(out, in + A0O_PIX, 3 * A0O_PIX);
+            memcpy(out + 3 * A0O_PIX, fr, A0O_PIX);
+        }
+    }
+}
