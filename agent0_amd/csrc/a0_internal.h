@@ -1,0 +1,31 @@
+// Internal helpers shared by the .hip translation units: error plumbing for the C-ABI.
+#pragma once
+#include "../../include/agent0_hip.h"
+#include "a0_defs.h"
+
+#include <exception>
+#include <stdexcept>
+#include <string>
+
+int a0_fail(int code, const char* msg);          // records the thread-local message, returns code
+int a0_fail_hip(int hip_error, const char* what);
+
+struct a0_hip_error : std::runtime_error {
+    int err;
+    a0_hip_error(int e, const std::string& w) : std::runtime_error(w), err(e) {}
+};
+
+#define A0_STR2(x) #x
+#define A0_STR(x) A0_STR2(x)
+#define A0_HIP_THROW(expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t a0_e_ = (expr);                                                                          \
+        if (a0_e_ != hipSuccess) throw a0_hip_error((int)a0_e_, std::string(__FILE__ ":" A0_STR(__LINE__) ": ") + hipGetErrorString(a0_e_)); \
+    } while (0)
+
+#define A0_TRY try {
+#define A0_CATCH                                                   \
+    }                                                              \
+    catch (const a0_hip_error& e) { return a0_fail_hip(e.err, e.what()); } \
+    catch (const std::exception& e) { return a0_fail(A0_EINVAL, e.what()); } \
+    catch (...) { return a0_fail(A0_EINVAL, "unknown C++ exception"); }

@@ -1,0 +1,73 @@
+// Actor-side fused elementwise kernels: epsilon-greedy selection and the n-step return scan (gfx950).
+// Restates reference agent0/deepq/agent.py:25-39 (act) and agent.py:57-73 (done logic + n-step accumulation over a
+// deque(maxlen=n) that is never cleared, quirk Q9).  n-step sums are carried in fp64 like the reference's numpy
+// arrays and rounded to fp32 once, where the reference's Trainer casts them (trainer.py:88-90).
+#include "a0_internal.h"
+
+#pragma clang fp contract(off)
+
+// action = u > eps ? greedy : random;  qs_out[0] = mean_e qmax[e]   (single workgroup)
+__global__ __launch_bounds__(256) void a0_egreedy_kernel(const int* __restrict__ greedy, const int* __restrict__ rand_action, const float* __restrict__ u,
+                                                          float eps, int E, int* __restrict__ action, const float* __restrict__ qmax, float* __restrict__ qs_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        action[e] = (u[e] > eps) ? greedy[e] : rand_action[e];
+        if (qmax) s += qmax[e];
+    }
+    if (!qs_out) return;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) qs_out[0] = red[0] / (float)E;
+}
+
+extern "C" int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action, const float* qmax,
+                                float* qs_out, void* stream) {
+    if (!greedy || !rand_action || !u || !action || E < 1) return a0_fail(A0_EINVAL, "a0_actor_egreedy: bad argument");
+    hipLaunchKernelGGL(a0_egreedy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, greedy, rand_action, u, eps, E, action, qmax, qs_out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_egreedy");
+}
+
+// Ring of the last n (action, reward, done) per env; entry for step t lives at t % n.
+//   done_t = (terminal | life_loss) & ~truncated                      agent.py:57-62
+//   R = 0; D = 0; for k = newest .. oldest: D |= d_k; R = R*gamma*(1-d_k) + r_k      agent.py:64-69
+//   emitted action = action of the oldest entry                       agent.py:70-71
+// steps = number of env steps taken BEFORE this one (so this step is written at steps % n).
+__global__ void a0_nstep_kernel(int E, int n, long long steps, double gamma, const int* __restrict__ action, const float* __restrict__ reward,
+                                const float* __restrict__ terminal, const float* __restrict__ truncated, const float* __restrict__ life_loss,
+                                int* __restrict__ ring_act, float* __restrict__ ring_rew, float* __restrict__ ring_done,
+                                int* __restrict__ out_act, float* __restrict__ out_rew, float* __restrict__ out_done) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const bool done = ((terminal[e] != 0.f) || (life_loss && life_loss[e] != 0.f)) && !(truncated[e] != 0.f);
+    const int cur = (int)(steps % n);
+    ring_act[(long long)cur * E + e] = action[e];
+    ring_rew[(long long)cur * E + e] = reward[e];
+    ring_done[(long long)cur * E + e] = done ? 1.f : 0.f;
+    const long long have = steps + 1;
+    const int count = have < n ? (int)have : n;
+    double R = 0.0;
+    bool D = false;
+    for (int k = 0; k < count; ++k) {
+        const int idx = (int)(((steps - k) % n + n) % n);
+        const float dk = (k == 0) ? (done ? 1.f : 0.f) : ring_done[(long long)idx * E + e];
+        const float rk = (k == 0) ? reward[e] : ring_rew[(long long)idx * E + e];
+        D = D || (dk != 0.f);
+        R = R * gamma * (double)(1 - (dk != 0.f ? 1 : 0)) + (double)rk;
+    }
+    const int oldest = (int)(((steps - (count - 1)) % n + n) % n);
+    out_act[e] = (count == 1) ? action[e] : ring_act[(long long)oldest * E + e];
+    out_rew[e] = (float)R;
+    out_done[e] = D ? 1.f : 0.f;
+}
+
+extern "C" int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* action, const float* reward, const float* terminal,
+                              const float* truncated, const float* life_loss, int* ring_act, float* ring_rew, float* ring_done, int* out_act,
+                              float* out_rew, float* out_done, void* stream) {
+    if (E < 1 || n < 1 || steps < 0 || !action || !reward || !terminal || !truncated || !ring_act || !ring_rew || !ring_done || !out_act || !out_rew || !out_done)
+        return a0_fail(A0_EINVAL, "a0_actor_nstep: bad argument");
+    hipLaunchKernelGGL(a0_nstep_kernel, dim3((E + 127) / 128), dim3(128), 0, (hipStream_t)stream, E, n, steps, gamma, action, reward, terminal, truncated,
+                       life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_nstep");
+}

@@ -1,0 +1,154 @@
+// Implicit-GEMM kernel on the CDNA4 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// Why fp32 MFMA: the reference network runs in fp32 (agent0/deepq/model.py, no autocast) and the north star asks
+// for Q-values / TD losses within a tight tolerance; gfx950's f32-input MFMA is an exact k-ordered fmaf chain at
+// the fp32 vector peak (157 TFLOP/s), so parity is a few ulp while the convs still run on the matrix pipe.
+//
+// Tiling: 256 threads = 4 wave64s laid out WM x WN; each wave owns MT x NT accumulator blocks of 32x32, so the
+// block tile is BX = WM*MT*32 rows by BY = WN*NT*32 columns, BK = 32 deep.  Operands are gathered by the policies
+// in operands.h into k-major LDS tiles As[k][x], Bs[k][y]; a fragment read As[2s + (lane>>5)][x0 + (lane&31)] is
+// one conflict-free ds_read_b32 per 32x32x2 MFMA operand (the MFMA takes 64 cycles, so LDS is never the limit).
+// Global loads for tile t+1 are issued into registers before the MFMAs of tile t (register double buffering).
+#pragma once
+#include "operands.h"
+
+#if defined(__HIPCC__)
+
+typedef float a0_acc16 __attribute__((ext_vector_type(16)));
+
+template <class OP, int BX, int MODE = OP::MODE> struct a0_stager;
+
+template <class OP, int BX> struct a0_stager<OP, BX, A0_KC> {
+    static constexpr int R = BX / 32;
+    static constexpr int LD = BX + 1;
+    typename OP::Row rows[R];
+    a0_f4 v[R];
+    A0_D void init(const typename OP::Params& P, int x0, int X, int tid) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + (tid >> 3) + 32 * j, X);
+    }
+    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int, int, int tid) {
+        const int k = k0 + 4 * (tid & 7);
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = OP::load(P, rows[j], k, ke);
+    }
+    A0_D void commit(float* lds, int tid) const {
+        const int kk = 4 * (tid & 7);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = (tid >> 3) + 32 * j;
+            lds[(kk + 0) * LD + r] = v[j].x;
+            lds[(kk + 1) * LD + r] = v[j].y;
+            lds[(kk + 2) * LD + r] = v[j].z;
+            lds[(kk + 3) * LD + r] = v[j].w;
+        }
+    }
+};
+
+template <class OP, int BX> struct a0_stager<OP, BX, A0_XC> {
+    static constexpr int R = BX / 32;
+    static constexpr int LD = BX + 4;
+    static constexpr int Q = BX / 4;   // 16-byte groups per k row
+    a0_f4 v[R];
+    A0_D void init(const typename OP::Params&, int, int, int) {}
+    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int x0, int X, int tid) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int f = tid + 256 * j;
+            v[j] = OP::load(P, k0 + f / Q, x0 + 4 * (f % Q), ke, X);
+        }
+    }
+    A0_D void commit(float* lds, int tid) const {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int f = tid + 256 * j;
+            *(a0_f4*)&lds[(f / Q) * LD + 4 * (f % Q)] = v[j];
+        }
+    }
+};
+
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, typename OB::Params pb,
+                                                        typename EP::Params pe, int X, int Y, int K, int kchunk) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BK = 32;
+    constexpr int BX = WM * MT * 32;
+    constexpr int BY = WN * NT * 32;
+    typedef a0_stager<OA, BX> SA;
+    typedef a0_stager<OB, BY> SB;
+    constexpr int LDA = SA::LD, LDB = SB::LD;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int x0 = blockIdx.x * BX, y0 = blockIdx.y * BY;
+    const int kb = blockIdx.z * kchunk;
+    const int ke = (K < kb + kchunk) ? K : (kb + kchunk);
+
+    SA sa; SB sb;
+    sa.init(pa, x0, X, tid);
+    sb.init(pb, y0, Y, tid);
+
+    a0_acc16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kb < ke) { sa.fetch(pa, kb, ke, x0, X, tid); sb.fetch(pb, kb, ke, y0, Y, tid); }
+
+    const float* ap = As + (lane >> 5) * LDA + wm * (MT * 32) + (lane & 31);
+    const float* bp = Bs + (lane >> 5) * LDB + wn * (NT * 32) + (lane & 31);
+
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        __syncthreads();                 // every wave is done reading the previous tile
+        sa.commit(As, tid);
+        sb.commit(Bs, tid);
+        __syncthreads();
+        if (k0 + BK < ke) { sa.fetch(pa, k0 + BK, ke, x0, X, tid); sb.fetch(pb, k0 + BK, ke, y0, Y, tid); }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = ap[2 * s * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int z = blockIdx.z;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int y = y0 + wn * (NT * 32) + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (x < X && y < Y) EP::store(pe, x, y, acc[i][j][r], z);
+            }
+        }
+}
+
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+static inline hipError_t a0_igemm_launch(hipStream_t st, const typename OA::Params& pa, const typename OB::Params& pb,
+                                         const typename EP::Params& pe, int X, int Y, int K, int splits) {
+    constexpr int BX = WM * MT * 32, BY = WN * NT * 32;
+    if (splits < 1) splits = 1;
+    const int ktiles = (K + 31) / 32;
+    const int kchunk = ((ktiles + splits - 1) / splits) * 32;
+    dim3 grid((X + BX - 1) / BX, (Y + BY - 1) / BY, splits);
+    hipLaunchKernelGGL((a0_igemm_kernel<OA, OB, EP, WM, WN, MT, NT>), grid, dim3(256), 0, st, pa, pb, pe, X, Y, K, kchunk);
+    return hipGetLastError();
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,298 @@
+// Head epilogues and TD losses: dueling combine, greedy-action selection, DQN Huber, C51 projection +
+// cross-entropy, quantile-Huber (QR / IQN / FQF) — forward value and gradient w.r.t. the head output in one pass.
+// Restates reference agent0/deepq/agent.py:110-114, 173-190, 219-269, 273-293, 297-327 and the dueling / qval
+// arithmetic of agent0/deepq/model.py:123-131, 163-177, 190-192, 219-233, 253-257, 280-284.
+#include "a0_internal.h"
+
+A0_D float a0_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+A0_D float a0_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ dueling combine
+// raw [R][ld]: columns [0, A*T) advantage / plain q (action-major), [A*T, A*T+T) value stream when dueling.
+__global__ void a0_dueling_fwd_kernel(const float* __restrict__ raw, int ld, float* __restrict__ q, int R, int A, int T, int dueling) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)R * T) return;
+    const int r = (int)(i / T), t = (int)(i % T);
+    const float* x = raw + (long long)r * ld;
+    float* o = q + (long long)r * A * T;
+    if (!dueling) {
+        for (int a = 0; a < A; ++a) o[a * T + t] = x[a * T + t];
+        return;
+    }
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += x[a * T + t];
+    const float mean = s / (float)A;
+    const float v = x[A * T + t];
+    for (int a = 0; a < A; ++a) o[a * T + t] = v + (x[a * T + t] - mean);
+}
+
+__global__ void a0_dueling_bwd_kernel(const float* __restrict__ dq, float* __restrict__ draw, int ld, int R, int A, int T, int dueling) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)R * ld) return;
+    const int r = (int)(i / ld), c = (int)(i % ld);
+    const float* g = dq + (long long)r * A * T;
+    float out = 0.f;
+    if (c < A * T) {
+        out = g[c];
+        if (dueling) {
+            const int t = c % T;
+            float s = 0.f;
+            for (int a = 0; a < A; ++a) s += g[a * T + t];
+            out -= s / (float)A;
+        }
+    } else if (dueling && c < A * T + T) {
+        const int t = c - A * T;
+        float s = 0.f;
+        for (int a = 0; a < A; ++a) s += g[a * T + t];
+        out = s;
+    }
+    draw[i] = out;
+}
+
+extern "C" int a0_dueling_fwd(const float* raw, int ld, float* q, int R, int A, int T, int dueling, void* stream) {
+    if (!raw || !q || R < 1 || A < 1 || T < 1 || ld < A * T + (dueling ? T : 0)) return a0_fail(A0_EINVAL, "a0_dueling_fwd: bad argument");
+    long long n = (long long)R * T;
+    hipLaunchKernelGGL(a0_dueling_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, ld, q, R, A, T, dueling);
+    return a0_fail_hip((int)hipGetLastError(), "a0_dueling_fwd");
+}
+
+extern "C" int a0_dueling_bwd(const float* dq, float* draw, int ld, int R, int A, int T, int dueling, void* stream) {
+    if (!dq || !draw || R < 1 || A < 1 || T < 1 || ld < A * T + (dueling ? T : 0)) return a0_fail(A0_EINVAL, "a0_dueling_bwd: bad argument");
+    long long n = (long long)R * ld;
+    hipLaunchKernelGGL(a0_dueling_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dq, draw, ld, R, A, T, dueling);
+    return a0_fail_hip((int)hipGetLastError(), "a0_dueling_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ action values + argmax
+// One wave per sample.  x(b,a,t) = x[b*sb + a*sa + t*st].  mode: 0 identity (T=1), 1 mean over t (QR atoms / IQN taus),
+// 2 C51 expectation sum_t softmax_t * atoms[t], 3 FQF sum_t (tau[b][t+1]-tau[b][t]) * x.
+__global__ __launch_bounds__(64) void a0_select_action_kernel(const float* __restrict__ x, long long sb, long long sa, long long st,
+                                                               int B, int A, int T, int mode, const float* __restrict__ aux,
+                                                               int* __restrict__ a_star, float* __restrict__ qsel, float* __restrict__ qmax) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
+    float best = 0.f;
+    int besta = 0;
+    for (int a = 0; a < A; ++a) {
+        const float* p = x + (long long)b * sb + (long long)a * sa;
+        float v;
+        if (mode == 0) {
+            v = p[0];
+        } else if (mode == 1) {
+            float s = 0.f;
+            for (int t = lane; t < T; t += 64) s += p[(long long)t * st];
+            v = a0_wave_sum(s) / (float)T;
+        } else if (mode == 2) {
+            float mx = -INFINITY;
+            for (int t = lane; t < T; t += 64) mx = fmaxf(mx, p[(long long)t * st]);
+            mx = a0_wave_max(mx);
+            float se = 0.f, sz = 0.f;
+            for (int t = lane; t < T; t += 64) {
+                float e = expf(p[(long long)t * st] - mx);
+                se += e;
+                sz += e * aux[t];
+            }
+            se = a0_wave_sum(se);
+            sz = a0_wave_sum(sz);
+            v = sz / se;
+        } else {
+            const float* tau = aux + (long long)b * (T + 1);
+            float s = 0.f;
+            for (int t = lane; t < T; t += 64) s += (tau[t + 1] - tau[t]) * p[(long long)t * st];
+            v = a0_wave_sum(s);
+        }
+        if (qsel && lane == 0) qsel[(long long)b * A + a] = v;
+        if (a == 0 || v > best) { best = v; besta = a; }   // first maximum wins, like torch.argmax on CPU
+    }
+    if (lane == 0) {
+        if (a_star) a_star[b] = besta;
+        if (qmax) qmax[b] = best;
+    }
+}
+
+extern "C" int a0_select_action(const float* x, long long sb, long long sa, long long st, int B, int A, int T, int mode,
+                                const float* aux, int* a_star, float* qsel, float* qmax, void* stream) {
+    if (!x || B < 1 || A < 1 || T < 1 || mode < 0 || mode > 3 || ((mode == 2 || mode == 3) && !aux)) return a0_fail(A0_EINVAL, "a0_select_action: bad argument");
+    hipLaunchKernelGGL(a0_select_action_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, sb, sa, st, B, A, T, mode, aux, a_star, qsel, qmax);
+    return a0_fail_hip((int)hipGetLastError(), "a0_select_action");
+}
+
+// ------------------------------------------------------------------------------------------------ DQN
+// loss[b] = smooth_l1(q[b][a_b] - y_b), y_b = r + gamma_n*(1-d)*q_next[b][a*_b];  dq = w * clamp(q - y, -1, 1) at a_b.
+__global__ void a0_dqn_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next, int A, const int* __restrict__ act,
+                                   const int* __restrict__ a_star, const float* __restrict__ rew, const float* __restrict__ done,
+                                   const float* __restrict__ wgt, float gamma_n, int B, float* __restrict__ loss, float* __restrict__ dq,
+                                   int* __restrict__ nan_flag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float qn = q_next[(long long)b * A + a_star[b]];
+    const float y = rew[b] + (gamma_n * (1.f - done[b])) * qn;
+    const int a = act[b];
+    const float d = q[(long long)b * A + a] - y;
+    const float ad = fabsf(d);
+    const float l = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+    loss[b] = l;
+    if (l != l) atomicOr(nan_flag, 1);
+    const float g = wgt[b] * fminf(fmaxf(d, -1.f), 1.f);
+    for (int k = 0; k < A; ++k) dq[(long long)b * A + k] = (k == a) ? g : 0.f;
+}
+
+extern "C" int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
+                           const float* done, const float* wgt, float gamma_n, int B, float* loss, float* dq, int* nan_flag, void* stream) {
+    if (!q || !q_next || !act || !a_star || !rew || !done || !wgt || !loss || !dq || !nan_flag || B < 1 || A < 1) return a0_fail(A0_EINVAL, "a0_loss_dqn: bad argument");
+    hipLaunchKernelGGL(a0_dqn_loss_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, q, q_next, A, act, a_star, rew, done, wgt, gamma_n, B, loss, dq, nan_flag);
+    return a0_fail_hip((int)hipGetLastError(), "a0_loss_dqn");
+}
+
+// ------------------------------------------------------------------------------------------------ C51
+// One wave per sample, one lane per atom (T <= 64).  The projection is computed in gather form — bin j sums the
+// contributions of the atoms whose lo (then up) index equals j, in ascending atom order — which is the order the
+// reference's two index_add_ calls produce on the CPU, so the result is deterministic (quirk Q20 resolved).
+__global__ __launch_bounds__(64) void a0_c51_loss_kernel(const float* __restrict__ logits, const float* __restrict__ tgt_logits,
+                                                          int A, int T, const int* __restrict__ act, const int* __restrict__ a_star,
+                                                          const float* __restrict__ rew, const float* __restrict__ done,
+                                                          const float* __restrict__ wgt, const float* __restrict__ atoms,
+                                                          float gamma_n, float vmin, float vmax, float delta, int B,
+                                                          float* __restrict__ loss, float* __restrict__ dlogits, float* __restrict__ m_out,
+                                                          int* __restrict__ nan_flag) {
+    __shared__ int s_lo[64], s_up[64];
+    __shared__ float s_wl[64], s_wu[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool on = t < T;
+    // softmax of the target net's logits at the greedy next action
+    const float* tp = tgt_logits + ((long long)b * A + a_star[b]) * T;
+    const float xt = on ? tp[t] : -INFINITY;
+    const float mxt = a0_wave_max(xt);
+    const float et = on ? expf(xt - mxt) : 0.f;
+    const float p = et / a0_wave_sum(et);
+    // Bellman-shifted, clamped support and its fractional bin position
+    float tz = rew[b] + (gamma_n * (1.f - done[b])) * (on ? atoms[t] : 0.f);
+    tz = fminf(fmaxf(tz, vmin), vmax);
+    const float bp = (tz - vmin) / delta;
+    int lo = (int)floorf(bp), up = (int)ceilf(bp);
+    if (up > 0 && lo == up) lo -= 1;
+    if (lo < T - 1 && lo == up) up += 1;
+    s_lo[t] = on ? lo : -1;
+    s_up[t] = on ? up : -1;
+    s_wl[t] = p * ((float)up - bp);
+    s_wu[t] = p * (bp - (float)lo);
+    __syncthreads();
+    float m = 0.f;
+    if (on) {
+        for (int k = 0; k < T; ++k) if (s_lo[k] == t) m += s_wl[k];
+        for (int k = 0; k < T; ++k) if (s_up[k] == t) m += s_wu[k];
+    }
+    if (m_out && on) m_out[(long long)b * T + t] = m;
+    // cross entropy against the online net's log-softmax at the taken action
+    const int a = act[b];
+    const float* op = logits + ((long long)b * A + a) * T;
+    const float xo = on ? op[t] : -INFINITY;
+    const float mxo = a0_wave_max(xo);
+    const float eo = on ? expf(xo - mxo) : 0.f;
+    const float so = a0_wave_sum(eo);
+    const float logp = xo - mxo - logf(so);
+    const float l = -a0_wave_sum(on ? m * logp : 0.f);
+    const float msum = a0_wave_sum(m);
+    if (t == 0) {
+        loss[b] = l;
+        if (l != l) atomicOr(nan_flag, 1);
+    }
+    if (on) {
+        const float w = wgt[b];
+        const float g = w * ((eo / so) * msum - m);
+        for (int k = 0; k < A; ++k) dlogits[((long long)b * A + k) * T + t] = (k == a) ? g : 0.f;
+    }
+}
+
+extern "C" int a0_loss_c51(const float* logits, const float* tgt_logits, int A, int T, const int* act, const int* a_star,
+                           const float* rew, const float* done, const float* wgt, const float* atoms, float gamma_n,
+                           float vmin, float vmax, int B, float* loss, float* dlogits, float* m_out, int* nan_flag, void* stream) {
+    if (!logits || !tgt_logits || !act || !a_star || !rew || !done || !wgt || !atoms || !loss || !dlogits || !nan_flag || B < 1 || A < 1 || T < 2 || T > 64)
+        return a0_fail(A0_EINVAL, "a0_loss_c51: bad argument (2 <= num_atoms <= 64)");
+    const float delta = (float)(((double)vmax - (double)vmin) / (double)(T - 1));
+    hipLaunchKernelGGL(a0_c51_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, tgt_logits, A, T, act, a_star, rew, done, wgt,
+                       atoms, gamma_n, vmin, vmax, delta, B, loss, dlogits, m_out, nan_flag);
+    return a0_fail_hip((int)hipGetLastError(), "a0_loss_c51");
+}
+
+// ------------------------------------------------------------------------------------------------ quantile Huber
+// y[b][j] = r + gamma_n*(1-d) * qn(b, j, a*_b),  qn(b,j,a) = q_next[b*sb + j*sj + a*sa]
+__global__ void a0_quantile_target_kernel(const float* __restrict__ q_next, long long sb, long long sj, long long sa,
+                                          const int* __restrict__ a_star, const float* __restrict__ rew, const float* __restrict__ done,
+                                          float gamma_n, int B, int Nd, float* __restrict__ y) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * Nd) return;
+    const int b = (int)(i / Nd), j = (int)(i % Nd);
+    y[i] = rew[b] + (gamma_n * (1.f - done[b])) * q_next[(long long)b * sb + (long long)j * sj + (long long)a_star[b] * sa];
+}
+
+// One workgroup per sample; thread i owns online quantile i and sweeps the N' targets held in LDS, so the
+// B x N' x N pairwise tensor of the reference (agent.py:110-114) is never materialised.
+// q(b,i,a) = q[b*sb + i*si + a*sa]; taus[b*tb + i] (tb = 0: shared fixed midpoints).
+// dq gets w_b/N' * sum_j clamp(q_i - T_j, -1, 1) * |tau_i - 1{T_j < q_i}| at the taken action (dq pre-zeroed by caller).
+__global__ __launch_bounds__(256) void a0_quantile_huber_kernel(const float* __restrict__ q, long long sb, long long si, long long sa,
+                                                                 const float* __restrict__ y, const float* __restrict__ taus, long long tb,
+                                                                 const int* __restrict__ act, const float* __restrict__ wgt,
+                                                                 int B, int N, int Nd, float* __restrict__ loss, float* __restrict__ dq,
+                                                                 int* __restrict__ nan_flag) {
+    extern __shared__ float s_t[];       // Nd targets, then 4 partial sums
+    __shared__ float s_part[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < Nd; j += blockDim.x) s_t[j] = y[(long long)b * Nd + j];
+    __syncthreads();
+    const int a = act[b];
+    float total = 0.f;
+    for (int i = tid; i < N; i += blockDim.x) {
+        const long long qi_off = (long long)b * sb + (long long)i * si + (long long)a * sa;
+        const float qi = q[qi_off];
+        const float tau = taus[(long long)b * tb + i];
+        float al = 0.f, ag = 0.f;
+        for (int j = 0; j < Nd; ++j) {
+            const float tj = s_t[j];
+            const float d = qi - tj;
+            const float ad = fabsf(d);
+            const float h = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+            const float wq = fabsf(tau - ((tj < qi) ? 1.f : 0.f));
+            al += h * wq;
+            ag += fminf(fmaxf(d, -1.f), 1.f) * wq;
+        }
+        total += al;
+        dq[qi_off] = wgt[b] * ag / (float)Nd;
+    }
+    total = a0_wave_sum(total);
+    if ((tid & 63) == 0) s_part[tid >> 6] = total;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_part[w];
+        const float l = s / (float)Nd;
+        loss[b] = l;
+        if (l != l) atomicOr(nan_flag, 1);
+    }
+}
+
+extern "C" int a0_quantile_target(const float* q_next, long long sb, long long sj, long long sa, const int* a_star, const float* rew,
+                                  const float* done, float gamma_n, int B, int Nd, float* y, void* stream) {
+    if (!q_next || !a_star || !rew || !done || !y || B < 1 || Nd < 1) return a0_fail(A0_EINVAL, "a0_quantile_target: bad argument");
+    long long n = (long long)B * Nd;
+    hipLaunchKernelGGL(a0_quantile_target_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q_next, sb, sj, sa, a_star, rew, done, gamma_n, B, Nd, y);
+    return a0_fail_hip((int)hipGetLastError(), "a0_quantile_target");
+}
+
+extern "C" int a0_loss_quantile_huber(const float* q, long long sb, long long si, long long sa, const float* y, const float* taus,
+                                      long long tb, const int* act, const float* wgt, int B, int N, int Nd, float* loss, float* dq,
+                                      int* nan_flag, void* stream) {
+    if (!q || !y || !taus || !act || !wgt || !loss || !dq || !nan_flag || B < 1 || N < 1 || Nd < 1 || Nd > 8192) return a0_fail(A0_EINVAL, "a0_loss_quantile_huber: bad argument");
+    int threads = ((N + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    hipLaunchKernelGGL(a0_quantile_huber_kernel, dim3(B), dim3(threads), (size_t)Nd * sizeof(float), (hipStream_t)stream, q, sb, si, sa, y, taus, tb, act, wgt, B, N, Nd, loss, dq, nan_flag);
+    return a0_fail_hip((int)hipGetLastError(), "a0_loss_quantile_huber");
+}

@@ -1,0 +1,181 @@
+// Nature-CNN encoder + dense layers on gfx950: the HIP backend of net_impl.h plus the exported C entry points.
+// Replaces the ATen -> cuDNN/cuBLAS dispatches behind reference agent0/deepq/model.py:93-101 (ConvEncoder),
+// model.py:112-114 / 144-146 / 203-216 (dense layers of the heads) and their autograd backward (agent.py:153-155).
+#include "igemm.h"
+#include "a0_internal.h"
+#include "net_impl.h"
+
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__global__ void a0_reduce_slabs_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab,
+                                       float* __restrict__ out, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        float s = 0.f;
+        for (int z = 0; z < nslab; ++z) s += slabs[(long long)z * slab_stride + i];
+        out[i] = s;
+    }
+}
+
+__global__ void a0_reduce_bias_act_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab,
+                                          const float* __restrict__ bias, float* __restrict__ out, int rows, int N, int relu) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long count = (long long)rows * N;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        float s = 0.f;
+        for (int z = 0; z < nslab; ++z) s += slabs[(long long)z * slab_stride + i];
+        s += bias[i % N];
+        if (relu) s = (s < 0.f) ? 0.f : s;
+        out[i] = s;
+    }
+}
+
+// Bias gradient: db[n] = sum_m dY[m][n] — one block per (32 columns, row chunk), partials into the weight slabs.
+__global__ __launch_bounds__(256) void a0_colsum_kernel(const float* __restrict__ dy, int M, int N, int mchunk,
+                                                         float* __restrict__ out, long long slab_stride, long long bias_off) {
+    __shared__ float red[8][33];
+    const int n = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int r0 = threadIdx.x >> 5;
+    const int mb = blockIdx.y * mchunk;
+    const int me = (M < mb + mchunk) ? M : mb + mchunk;
+    float s = 0.f;
+    if (n < N)
+        for (int m = mb + r0; m < me; m += 8) s += dy[(long long)m * N + n];
+    red[r0][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x];
+        out[(long long)blockIdx.y * slab_stride + bias_off + n] = t;
+    }
+}
+
+static inline int a0_grid_for(long long count, int block = 256, int cap = 2048) {
+    long long g = (count + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+struct a0_hip_backend {
+    hipStream_t st;
+    template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+    void igemm(const typename OA::Params& pa, const typename OB::Params& pb, const typename EP::Params& pe, int X, int Y, int K, int splits) {
+        A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+    }
+    void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
+        hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3(a0_grid_for(count)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);
+        A0_HIP_THROW(hipGetLastError());
+    }
+    void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu) {
+        hipLaunchKernelGGL(a0_reduce_bias_act_kernel, dim3(a0_grid_for((long long)rows * N)), dim3(256), 0, st, slabs, slab_stride, nslab, bias, out, rows, N, relu);
+        A0_HIP_THROW(hipGetLastError());
+    }
+    void colsum(const float* dy, int M, int N, int mchunk, int splits, float* out, long long slab_stride, long long bias_off) {
+        hipLaunchKernelGGL(a0_colsum_kernel, dim3((N + 31) / 32, splits), dim3(256), 0, st, dy, M, N, mchunk, out, slab_stride, bias_off);
+        A0_HIP_THROW(hipGetLastError());
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ net object
+struct a0_net {
+    a0_net_core core;
+    std::vector<void*> owned;
+    ~a0_net() { for (void* p : owned) (void)hipFree(p); }
+    template <class T> const T* upload(const std::vector<T>& v) {
+        void* d = nullptr;
+        A0_HIP_THROW(hipMalloc(&d, v.size() * sizeof(T)));
+        owned.push_back(d);
+        A0_HIP_THROW(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return (const T*)d;
+    }
+};
+
+extern "C" int a0_net_create(const a0_net_desc* d, a0_net** out) {
+    A0_TRY
+    if (!d || !out) return a0_fail(A0_EINVAL, "a0_net_create: null argument");
+    a0_net* n = new a0_net();
+    if (!a0_net_core_init(n->core, d->C, d->H, d->W)) { delete n; return a0_fail(A0_EINVAL, "a0_net_create: observation too small for the 8/4, 4/2, 3/1 conv stack"); }
+    a0_net_tables t;
+    a0_net_build_tables(n->core, t);
+    try {
+        n->core.ktab1 = n->upload(t.ktab1); n->core.ktab2 = n->upload(t.ktab2); n->core.ktab3 = n->upload(t.ktab3);
+        n->core.ktab_d3 = n->upload(t.ktab_d3); n->core.ktab_d2 = n->upload(t.ktab_d2);
+        n->core.wtab_d3 = n->upload(t.wtab_d3);
+        for (int i = 0; i < 4; ++i) n->core.wtab_d2[i] = n->upload(t.wtab_d2[i]);
+    } catch (...) { delete n; throw; }
+    *out = n;
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_net_destroy(a0_net* n) { delete n; return A0_OK; }
+
+extern "C" int a0_net_geometry(const a0_net* n, int* out8) {
+    if (!n || !out8) return a0_fail(A0_EINVAL, "a0_net_geometry: null");
+    const a0_net_core& c = n->core;
+    out8[0] = c.H1; out8[1] = c.W1; out8[2] = c.H2; out8[3] = c.W2; out8[4] = c.H3; out8[5] = c.W3; out8[6] = c.feat; out8[7] = c.K1;
+    return A0_OK;
+}
+
+extern "C" int a0_net_encoder_fwd(const a0_net* n, const a0_encoder_weights* w, const a0_frames_arg* f, int B,
+                                  float* act1, float* act2, float* act3, void* stream) {
+    A0_TRY
+    if (!n || !w || !f || !f->frames || !act1 || !act2 || !act3 || B < 1) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd: bad argument");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_encoder_fwd_impl(bk, n->core, *w, *f, B, act1, act2, act3);
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" long long a0_dense_fwd_scratch(int R, int N, int K) { return a0_dense_fwd_scratch_impl(R, N, K); }
+
+extern "C" int a0_dense_fwd(const float* X, int ldx, const float* W, const float* b, float* Y, int R, int N, int K, int relu,
+                            float* scratch, void* stream) {
+    A0_TRY
+    if (!X || !W || !b || !Y || R < 1 || N < 4 || (N & 3) || (K & 3) || (ldx & 3)) return a0_fail(A0_EINVAL, "a0_dense_fwd: bad shape (N, K, ldx must be multiples of 4)");
+    if (a0_dense_fwd_scratch_impl(R, N, K) > 0 && !scratch) return a0_fail(A0_EINVAL, "a0_dense_fwd: split-K needs scratch");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_dense_fwd_impl(bk, X, ldx, W, b, Y, R, N, K, relu, scratch);
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K, void* stream) {
+    A0_TRY
+    if (!dY || !W || !dX || R < 1 || (N & 3) || (K & 3)) return a0_fail(A0_EINVAL, "a0_dense_dgrad: bad shape");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_dense_dgrad_impl(bk, dY, W, act_mask, dX, R, N, K);
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" long long a0_dense_wgrad_scratch(int R, int N, int K) { return a0_dense_wgrad_scratch_impl(R, N, K); }
+
+extern "C" int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad, int R, int N, int K, float* slabs, void* stream) {
+    A0_TRY
+    if (!dY || !X || !grad || R < 1 || (N & 3) || (K & 3) || (ldx & 3)) return a0_fail(A0_EINVAL, "a0_dense_wgrad: bad shape");
+    if (a0_dense_wgrad_scratch_impl(R, N, K) > 0 && !slabs) return a0_fail(A0_EINVAL, "a0_dense_wgrad: needs slab scratch");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_dense_wgrad_impl(bk, dY, X, ldx, grad, R, N, K, slabs);
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" long long a0_net_encoder_bwd_scratch(const a0_net* n, int B) { return n ? a0_encoder_bwd_scratch_impl(n->core, B) : 0; }
+
+extern "C" int a0_net_encoder_bwd(const a0_net* n, const a0_encoder_weights* w, const a0_frames_arg* f, int B,
+                                  const float* act1, const float* act2, const float* d3, float* d2, float* d1,
+                                  float* g1, float* g2, float* g3, float* slabs, void* stream) {
+    A0_TRY
+    if (!n || !w || !f || !f->frames || !act1 || !act2 || !d3 || !d2 || !d1 || !g1 || !g2 || !g3 || B < 1) return a0_fail(A0_EINVAL, "a0_net_encoder_bwd: null argument");
+    if (a0_encoder_bwd_scratch_impl(n->core, B) > 0 && !slabs) return a0_fail(A0_EINVAL, "a0_net_encoder_bwd: needs slab scratch");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_encoder_bwd_impl(bk, n->core, *w, *f, B, act1, act2, d3, d2, d1, g1, g2, g3, slabs);
+    return A0_OK;
+    A0_CATCH
+}

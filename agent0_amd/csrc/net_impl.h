@@ -1,0 +1,226 @@
+// Layer orchestration of the Nature CNN, written once against a "backend" that knows how to run one implicit GEMM
+// and three small reductions.  net.hip instantiates it with the HIP backend (real kernels); tests/host_emul.cpp
+// instantiates it with a CPU backend that evaluates the very same operand/epilogue policies in plain loops, so every
+// table, stride and geometry decision below is exercised by the CPU test-suite before it ever reaches a GPU.
+//
+// Backend concept:
+//   template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+//   void igemm(const OA::Params&, const OB::Params&, const EP::Params&, int X, int Y, int K, int splits);
+//   void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count);
+//   void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu);
+//   void colsum(const float* dy, int M, int N, int mchunk, int splits, float* out, long long slab_stride, long long bias_off);
+#pragma once
+#include "net_tables.h"
+#include "operands.h"
+#include "../../include/agent0_hip.h"
+
+// weight-gradient epilogue: slab z of the layer's [W | b] block
+struct EpiWgradSlab {
+    struct Params { float* out; long long slab_stride; int ld; };
+    A0_HD static void store(const Params& P, int x, int y, float v, int z) {
+        P.out[(long long)z * P.slab_stride + (long long)x * P.ld + y] = v;
+    }
+};
+
+static inline a0_frames_src a0_frames(const a0_net_core& n, const a0_frames_arg& f) {
+    a0_frames_src s;
+    s.frames = f.frames; s.slot = f.slot;
+    s.g.Hin = n.H; s.g.Win = n.W; s.g.C = n.C;
+    s.g.Hout = n.H1; s.g.Wout = n.W1; s.g.stride = 4; s.g.pad = 0; s.g.HWout = n.H1 * n.W1;
+    s.g.sample_stride = f.sample_stride;
+    s.chan_off = f.chan_off;
+    s.ktab = n.ktab1;
+    s.aligned4 = (n.W % 4 == 0) && (f.sample_stride % 4 == 0) && (f.chan_off % 4 == 0) && (((uintptr_t)f.frames) % 4 == 0);
+    return s;
+}
+
+static inline a0_act_src a0_act(const float* x, int Hin, int Win, int C, int Hout, int Wout, int stride, int pad, const a0_i4* ktab) {
+    a0_act_src s;
+    s.x = x; s.ktab = ktab;
+    s.g.Hin = Hin; s.g.Win = Win; s.g.C = C; s.g.Hout = Hout; s.g.Wout = Wout; s.g.stride = stride; s.g.pad = pad;
+    s.g.HWout = Hout * Wout; s.g.sample_stride = (long long)Hin * Win * C;
+    return s;
+}
+
+// ---- split heuristics (pure functions of the shapes, shared by the *_scratch queries)
+static inline int a0_fwd_splits(int gx, int gy, int K) {
+    int blocks = gx * gy, splits = 1;
+    if (blocks < 256) {
+        splits = 512 / blocks;
+        int maxs = (K / 32) / 2;
+        if (splits > maxs) splits = maxs;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    return splits;
+}
+
+static inline int a0_wgrad_splits(int gx, int gy, int R) {
+    int blocks = gx * gy, splits = 1;
+    if (blocks < 256) {
+        splits = (512 + blocks - 1) / blocks;
+        int maxs = (R + 63) / 64;
+        if (splits > maxs) splits = maxs;
+        if (splits > 256) splits = 256;
+        if (splits < 1) splits = 1;
+    }
+    return splits;
+}
+
+static inline int a0_chunk_rows(int R, int splits) { return (((R + 31) / 32 + splits - 1) / splits) * 32; }
+
+static inline long long a0_dense_fwd_scratch_impl(int R, int N, int K) {
+    int s = a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
+    return s > 1 ? (long long)s * R * N : 0;
+}
+
+static inline long long a0_dense_wgrad_scratch_impl(int R, int N, int K) {
+    int s = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
+    return s > 1 ? (long long)s * ((long long)N * K + N) : 0;
+}
+
+static inline long long a0_encoder_bwd_scratch_impl(const a0_net_core& n, int B) {
+    long long need = 0;
+    const int M[3] = {B * n.H1 * n.W1, B * n.H2 * n.W2, B * n.H3 * n.W3};
+    const int N[3] = {32, 64, 64};
+    const int K[3] = {n.K1, n.K2, n.K3};
+    for (int l = 0; l < 3; ++l) {
+        int s = a0_wgrad_splits(1, (K[l] + 127) / 128, M[l]);
+        long long v = (long long)s * ((long long)N[l] * K[l] + N[l]);
+        if (s > 1 && v > need) need = v;
+    }
+    return need;
+}
+
+// ------------------------------------------------------------------------------------------------ encoder forward
+template <class BK>
+static void a0_encoder_fwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_weights& w, const a0_frames_arg& f, int B,
+                                float* act1, float* act2, float* act3) {
+    {
+        a0_frames_src a = a0_frames(n, f);
+        a0_mat_src b{w.w1, n.K1};
+        EpiBiasAct::Params e{act1, w.b1, 32, 1};
+        bk.template igemm<OpFramesKC, OpMatKC, EpiBiasAct, 4, 1, 1, 1>(a, b, e, B * n.H1 * n.W1, 32, n.K1, 1);
+    }
+    {
+        a0_act_src a = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
+        a0_mat_src b{w.w2, n.K2};
+        EpiBiasAct::Params e{act2, w.b2, 64, 1};
+        bk.template igemm<OpActKC, OpMatKC, EpiBiasAct, 4, 1, 1, 2>(a, b, e, B * n.H2 * n.W2, 64, n.K2, 1);
+    }
+    {
+        a0_act_src a = a0_act(act2, n.H2, n.W2, 64, n.H3, n.W3, 1, 0, n.ktab3);
+        a0_mat_src b{w.w3, n.K3};
+        EpiBiasAct::Params e{act3, w.b3, 64, 1};
+        const int M = B * n.H3 * n.W3;
+        if (M <= 128 * 160)   // small batches (actor): 64-row tiles keep more CUs busy
+            bk.template igemm<OpActKC, OpMatKC, EpiBiasAct, 2, 2, 1, 1>(a, b, e, M, 64, n.K3, 1);
+        else
+            bk.template igemm<OpActKC, OpMatKC, EpiBiasAct, 4, 1, 1, 2>(a, b, e, M, 64, n.K3, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dense layers
+template <class BK>
+static void a0_dense_fwd_impl(BK& bk, const float* X, int ldx, const float* W, const float* b, float* Y, int R, int N, int K,
+                              int relu, float* scratch) {
+    a0_mat_src a{X, ldx};
+    a0_mat_src bw{W, K};
+    const int splits = a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
+    const bool narrow = (N <= 32);
+    if (splits == 1) {
+        EpiBiasAct::Params e{Y, b, N, relu};
+        if (narrow) bk.template igemm<OpMatKC, OpMatKC, EpiBiasAct, 4, 1, 1, 1>(a, bw, e, R, N, K, 1);
+        else bk.template igemm<OpMatKC, OpMatKC, EpiBiasAct, 4, 1, 1, 2>(a, bw, e, R, N, K, 1);
+    } else {
+        EpiSlab::Params e{scratch, (long long)R * N, N};
+        if (narrow) bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 1>(a, bw, e, R, N, K, splits);
+        else bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, e, R, N, K, splits);
+        bk.reduce_bias_act(scratch, (long long)R * N, splits, b, Y, R, N, relu);
+    }
+}
+
+template <class BK>
+static void a0_dense_dgrad_impl(BK& bk, const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K) {
+    a0_mat_src a{dY, N};
+    a0_mat_src bw{W, K};
+    if (act_mask) {
+        EpiMaskMat::Params e{dX, act_mask, K};
+        bk.template igemm<OpMatKC, OpMatXC, EpiMaskMat, 4, 1, 1, 2>(a, bw, e, R, K, N, 1);
+    } else {
+        EpiSlab::Params e{dX, 0, K};
+        bk.template igemm<OpMatKC, OpMatXC, EpiSlab, 4, 1, 1, 2>(a, bw, e, R, K, N, 1);
+    }
+}
+
+// shared tail of every weight gradient: bias column sums into the same slabs, then the slab reduction
+template <class BK>
+static void a0_finish_wgrad(BK& bk, const float* dY, int R, int N, long long wcount, float* grad, float* slabs, int splits) {
+    float* target = (splits > 1) ? slabs : grad;
+    const long long slab_stride = (splits > 1) ? (wcount + N) : 0;
+    bk.colsum(dY, R, N, a0_chunk_rows(R, splits), splits, target, slab_stride, wcount);
+    if (splits > 1) bk.reduce_slabs(slabs, slab_stride, splits, grad, wcount + N);
+}
+
+template <class BK>
+static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx, float* grad, int R, int N, int K, float* slabs) {
+    const int splits = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
+    const long long wcount = (long long)N * K;
+    a0_mat_src a{dY, N};
+    a0_mat_src b{X, ldx};
+    EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K};
+    bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
+    a0_finish_wgrad(bk, dY, R, N, wcount, grad, slabs, splits);
+}
+
+// ------------------------------------------------------------------------------------------------ encoder backward
+// d3 = dL/d(conv3 pre-activation) [B][H3][W3][64] (ReLU mask already applied by the fc1 data gradient).
+template <class BK>
+static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_weights& w, const a0_frames_arg& f, int B,
+                                const float* act1, const float* act2, const float* d3, float* d2, float* d1,
+                                float* g1, float* g2, float* g3, float* slabs) {
+    const int M3 = B * n.H3 * n.W3, M2 = B * n.H2 * n.W2, M1 = B * n.H1 * n.W1;
+    {   // conv3 weight gradient: dW3[64][K3] = sum_m d3[m][:]^T im2col(act2)[m][:]
+        const int splits = a0_wgrad_splits(1, (n.K3 + 127) / 128, M3);
+        const long long wc = 64LL * n.K3;
+        a0_mat_src a{d3, 64};
+        a0_act_src b = a0_act(act2, n.H2, n.W2, 64, n.H3, n.W3, 1, 0, n.ktab3);
+        EpiWgradSlab::Params e{splits > 1 ? slabs : g3, splits > 1 ? wc + 64 : 0, n.K3};
+        bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
+        a0_finish_wgrad(bk, d3, M3, 64, wc, g3, slabs, splits);
+    }
+    {   // conv3 data gradient -> d2 (masked by act2 > 0): gather form, 3x3 taps over d3 with pad 2
+        a0_act_src a = a0_act(d3, n.H3, n.W3, 64, n.H2, n.W2, 1, 2, n.ktab_d3);
+        a0_wtab_src b{w.w3, n.wtab_d3};
+        EpiDgrad::Params e{d2, act2, n.H2 * n.W2, n.W2, n.H2, n.W2, 64, 1, 0, 0, (long long)n.H2 * n.W2 * 64};
+        bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 2>(a, b, e, M2, 64, 9 * 64, 1);
+    }
+    {   // conv2 weight gradient
+        const int splits = a0_wgrad_splits(1, (n.K2 + 127) / 128, M2);
+        const long long wc = 64LL * n.K2;
+        a0_mat_src a{d2, 64};
+        a0_act_src b = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
+        EpiWgradSlab::Params e{splits > 1 ? slabs : g2, splits > 1 ? wc + 64 : 0, n.K2};
+        bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K2, M2, splits);
+        a0_finish_wgrad(bk, d2, M2, 64, wc, g2, slabs, splits);
+    }
+    // conv2 data gradient -> d1 (masked by act1 > 0): four stride phases, 2x2 taps over d2 with pad 1
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int Hv = (n.H1 - ph + 1) / 2, Wv = (n.W1 - pw + 1) / 2;
+            if (Hv < 1 || Wv < 1) continue;
+            a0_act_src a = a0_act(d2, n.H2, n.W2, 64, Hv, Wv, 1, 1, n.ktab_d2);
+            a0_wtab_src b{w.w2, n.wtab_d2[ph * 2 + pw]};
+            EpiDgrad::Params e{d1, act1, Hv * Wv, Wv, n.H1, n.W1, 32, 2, ph, pw, (long long)n.H1 * n.W1 * 32};
+            bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 1>(a, b, e, B * Hv * Wv, 32, 4 * 64, 1);
+        }
+    {   // conv1 weight gradient (the input is data: no data gradient)
+        const int splits = a0_wgrad_splits(1, (n.K1 + 127) / 128, M1);
+        const long long wc = 32LL * n.K1;
+        a0_mat_src a{d1, 32};
+        a0_frames_src b = a0_frames(n, f);
+        EpiWgradSlab::Params e{splits > 1 ? slabs : g1, splits > 1 ? wc + 32 : 0, n.K1};
+        bk.template igemm<OpMatXC, OpFramesXC, EpiWgradSlab, 1, 4, 1, 1>(a, b, e, 32, n.K1, M1, splits);
+        a0_finish_wgrad(bk, d1, M1, 32, wc, g1, slabs, splits);
+    }
+}

@@ -1,0 +1,198 @@
+// Optimizer, NaN guard and target-network sync over the flat parameter buffer (gfx950).
+// Restates reference agent0/deepq/agent.py:102-106 (Adam lr 5e-4, eps 1e-2/B), :333-338 (RMSprop for the FQF
+// fraction net), :152-158 (skip the step when any per-sample loss is NaN) and :160-161 (target <- online every
+// target_update_freq successful updates) without the two host syncs per update the reference pays (quirk Q14):
+// the NaN flag, the step counter and the "sync now" decision all live in a small device-side state block.
+#include "a0_internal.h"
+
+// state block (ints): see a0_learner_state in include/agent0_hip.h
+//   [0] nan_flag      set by the loss kernels (atomicOr) when a per-sample loss is NaN
+//   [1] update_steps  successful optimizer steps so far (reference BaseLearner.update_steps)
+//   [2] skipped       number of updates skipped because of NaN
+//   [3] skip_now      decision for the update in flight (1 = NaN seen, leave the parameters alone)
+//   [4] sync_now      1 if update_steps % target_update_freq == 0 after this update
+// scalars (floats): [0] step_size = lr / (1 - b1^t), [1] bc2_sqrt = sqrt(1 - b2^t)
+__global__ void a0_adam_prep_kernel(int* __restrict__ state, float* __restrict__ scal, double lr, double b1, double b2, int target_freq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int skip = state[0] != 0;
+    int steps = state[1];
+    if (!skip) steps += 1; else state[2] += 1;
+    const int t = steps > 0 ? steps : 1;
+    scal[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+    scal[1] = (float)sqrt(1.0 - pow(b2, (double)t));
+    state[1] = steps;
+    state[3] = skip;
+    state[4] = (target_freq > 0 && (steps % target_freq) == 0) ? 1 : 0;   // evaluated even after a skipped step, like the reference
+    state[0] = 0;
+}
+
+__global__ void a0_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               long long n, const int* __restrict__ state, const float* __restrict__ scal,
+                               float w1, float b2, float w2, float eps) {
+    if (state[3]) return;
+    const float step_size = scal[0], bc2_sqrt = scal[1];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * w1;
+        vi = vi * b2 + (w2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int a0_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars,
+                            double lr, double beta1, double beta2, double eps, int target_update_freq, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !state || !scalars || n < 1) return a0_fail(A0_EINVAL, "a0_adam_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+    return a0_fail_hip((int)hipGetLastError(), "a0_adam_step");
+}
+
+// RMSprop(lr, alpha, eps), no momentum, not centered (torch.optim.RMSprop defaults otherwise) — runs unconditionally,
+// like the reference's fqf_optimizer.step() which sits before the NaN guard (agent.py:139-148).
+__global__ void a0_rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long long n,
+                                  float lr, float alpha, float w, float eps, const float* __restrict__ clip_coef) {
+    const float c = clip_coef ? clip_coef[0] : 1.f;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float gi = g[i] * c;
+        float s = sq[i] * alpha + (w * gi) * gi;
+        sq[i] = s;
+        p[i] = p[i] - lr * (gi / (sqrtf(s) + eps));
+    }
+}
+
+// clip_coef[0] = min(1, max_norm / (||g|| + 1e-6))   (torch.nn.utils.clip_grad_norm_), single workgroup
+__global__ __launch_bounds__(256) void a0_clip_coef_kernel(const float* __restrict__ g, long long n, float max_norm, float* __restrict__ coef) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float c = max_norm / (sqrtf(red[0]) + 1e-6f);
+        coef[0] = c < 1.f ? c : 1.f;
+    }
+}
+
+extern "C" int a0_rmsprop_step(float* params, const float* grads, float* square_avg, long long n, double lr, double alpha, double eps,
+                               double max_grad_norm, float* clip_scratch, void* stream) {
+    if (!params || !grads || !square_avg || n < 1) return a0_fail(A0_EINVAL, "a0_rmsprop_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const float* coef = nullptr;
+    if (max_grad_norm > 0) {
+        if (!clip_scratch) return a0_fail(A0_EINVAL, "a0_rmsprop_step: clipping needs a 1-float scratch");
+        hipLaunchKernelGGL(a0_clip_coef_kernel, dim3(1), dim3(256), 0, st, grads, n, (float)max_grad_norm, clip_scratch);
+        coef = clip_scratch;
+    }
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, square_avg, n, (float)lr, (float)alpha,
+                       (float)(1.0 - alpha), (float)eps, coef);
+    return a0_fail_hip((int)hipGetLastError(), "a0_rmsprop_step");
+}
+
+// target <- online when state[4] says so (agent.py:160-161: deepcopy of the whole module, buffers included)
+__global__ void a0_target_sync_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, const int* __restrict__ state, int force) {
+    if (!force && !state[4]) return;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    const a0_f4* s4 = (const a0_f4*)src;
+    a0_f4* d4 = (a0_f4*)dst;
+    for (long long j = i; j < n4; j += stride) d4[j] = s4[j];
+    for (long long j = (n4 << 2) + i; j < n; j += stride) dst[j] = src[j];
+}
+
+extern "C" int a0_target_sync(float* target, const float* online, long long n, const int* state, int force, void* stream) {
+    if (!target || !online || n < 1 || (!force && !state)) return a0_fail(A0_EINVAL, "a0_target_sync: bad argument");
+    if ((((uintptr_t)target) | ((uintptr_t)online)) & 15) return a0_fail(A0_EINVAL, "a0_target_sync: buffers must be 16-byte aligned");
+    long long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(a0_target_sync_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, target, online, n, state, force);
+    return a0_fail_hip((int)hipGetLastError(), "a0_target_sync");
+}
+
+// ------------------------------------------------------------------------------------------------ NoisyNet
+// W = mu + sigma * (f(eps_out) x f(eps_in)),  b = mu_b + sigma_b * f(eps_b),  f(x) = sign(x) sqrt|x|
+// (reference agent0/deepq/model.py:54-62,73-87).  Blocks are [W (N*K) | b (N)]; one call handles the rows [r0, r1) that
+// belong to one NoisyLinear module (q_head and value_head share a packed block but have their own noise vectors).
+A0_D float a0_noise_f(float x) { return (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)) * sqrtf(fabsf(x)); }
+
+__global__ void a0_noisy_compose_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, float* __restrict__ eff, int N, int K,
+                                        int r0, int r1, const float* __restrict__ noise_in, const float* __restrict__ noise_out_w,
+                                        const float* __restrict__ noise_out_b) {
+    const long long rows = r1 - r0;
+    const long long total = rows * K + rows;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        long long off; float e;
+        if (i < rows * K) {
+            const int n = (int)(i / K), k = (int)(i % K);
+            off = (long long)(r0 + n) * K + k;
+            e = a0_noise_f(noise_out_w[n]) * a0_noise_f(noise_in[k]);
+        } else {
+            const int n = (int)(i - rows * K);
+            off = (long long)N * K + r0 + n;
+            e = a0_noise_f(noise_out_b[n]);
+        }
+        eff[off] = mu[off] + sigma[off] * e;
+    }
+}
+
+// gradient fan-out: the weight-gradient kernels write d(eff) into the mu block (d mu = d eff); d sigma = d eff * eps
+__global__ void a0_noisy_grad_sigma_kernel(const float* __restrict__ gmu, float* __restrict__ gsigma, int N, int K, int r0, int r1,
+                                           const float* __restrict__ noise_in, const float* __restrict__ noise_out_w,
+                                           const float* __restrict__ noise_out_b) {
+    const long long rows = r1 - r0;
+    const long long total = rows * K + rows;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        long long off; float e;
+        if (i < rows * K) {
+            const int n = (int)(i / K), k = (int)(i % K);
+            off = (long long)(r0 + n) * K + k;
+            e = a0_noise_f(noise_out_w[n]) * a0_noise_f(noise_in[k]);
+        } else {
+            const int n = (int)(i - rows * K);
+            off = (long long)N * K + r0 + n;
+            e = a0_noise_f(noise_out_b[n]);
+        }
+        gsigma[off] = gmu[off] * e;
+    }
+}
+
+extern "C" int a0_noisy_compose(const float* mu, const float* sigma, float* eff, int N, int K, int r0, int r1, const float* noise_in,
+                                const float* noise_out_w, const float* noise_out_b, void* stream) {
+    if (!mu || !sigma || !eff || !noise_in || !noise_out_w || !noise_out_b || N < 1 || K < 1 || r0 < 0 || r1 <= r0 || r1 > N) return a0_fail(A0_EINVAL, "a0_noisy_compose: bad argument");
+    long long total = (long long)(r1 - r0) * (K + 1), blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_noisy_compose_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mu, sigma, eff, N, K, r0, r1, noise_in, noise_out_w, noise_out_b);
+    return a0_fail_hip((int)hipGetLastError(), "a0_noisy_compose");
+}
+
+extern "C" int a0_noisy_grad_sigma(const float* gmu, float* gsigma, int N, int K, int r0, int r1, const float* noise_in,
+                                   const float* noise_out_w, const float* noise_out_b, void* stream) {
+    if (!gmu || !gsigma || !noise_in || !noise_out_w || !noise_out_b || N < 1 || K < 1 || r0 < 0 || r1 <= r0 || r1 > N) return a0_fail(A0_EINVAL, "a0_noisy_grad_sigma: bad argument");
+    long long total = (long long)(r1 - r0) * (K + 1), blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_noisy_grad_sigma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gmu, gsigma, N, K, r0, r1, noise_in, noise_out_w, noise_out_b);
+    return a0_fail_hip((int)hipGetLastError(), "a0_noisy_grad_sigma");
+}

@@ -1,0 +1,327 @@
+// HBM-resident replay: ring-buffer insert, indexed gather, flat-priority bookkeeping, importance weights,
+// uniform-permutation index generator, fp32 sum-tree (gfx950).
+//
+// Replaces reference agent0/deepq/replay.py:14-59 (deque of lz4 blobs + torch priority vector on the host),
+// the DataLoader/DataPrefetcher path of agent0/deepq/trainer.py:63-72 + agent0/common/utils.py:31-61 and the
+// importance-weight block trainer.py:91-96.  Frames are stored uncompressed exactly as the actor packs them
+// (agent.py:78-81): slot -> [8][H][W] u8 = st || st_next; 56 448 B per transition at 84x84, so 1 M transitions
+// = 56.4 GB of the 288 GB HBM.  Integer / index results are bit-exact against oracle/sumtree.c.
+#include "a0_internal.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------ insert / gather
+// One workgroup column per transition, 16 B per lane.  obs / obs_next: [n][obs_bytes] u8; ring slot (start+i) % cap.
+__global__ __launch_bounds__(256) void a0_replay_insert_kernel(uint8_t* __restrict__ frames, long long cap, int obs_bytes, long long start, int n,
+                                                                const uint8_t* __restrict__ obs, const uint8_t* __restrict__ obs_next,
+                                                                const int* __restrict__ act, const float* __restrict__ rew, const float* __restrict__ done,
+                                                                int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done) {
+    const int i = blockIdx.y;
+    const long long slot = (start + i) % cap;
+    const int q = obs_bytes >> 4;   // 16-byte groups per observation
+    const uint4* s0 = (const uint4*)(obs + (long long)i * obs_bytes);
+    const uint4* s1 = (const uint4*)(obs_next + (long long)i * obs_bytes);
+    uint4* d = (uint4*)(frames + slot * (2LL * obs_bytes));
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * q; j += gridDim.x * blockDim.x) d[j] = (j < q) ? s0[j] : s1[j - q];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        r_act[slot] = act[i];
+        r_rew[slot] = rew[i];
+        r_done[slot] = done[i];
+    }
+}
+
+extern "C" int a0_replay_insert(uint8_t* frames, long long cap, int obs_bytes, long long start_slot, int n, const uint8_t* obs, const uint8_t* obs_next,
+                                const int* act, const float* rew, const float* done, int* r_act, float* r_rew, float* r_done, void* stream) {
+    if (!frames || !obs || !obs_next || !act || !rew || !done || !r_act || !r_rew || !r_done || cap < 1 || n < 1 || n > cap || (obs_bytes & 15) || start_slot < 0)
+        return a0_fail(A0_EINVAL, "a0_replay_insert: bad argument (obs_bytes must be a multiple of 16)");
+    if ((((uintptr_t)frames) | ((uintptr_t)obs) | ((uintptr_t)obs_next)) & 15) return a0_fail(A0_EINVAL, "a0_replay_insert: buffers must be 16-byte aligned");
+    const int q2 = 2 * (obs_bytes >> 4);
+    int gx = (q2 + 255) / 256; if (gx > 8) gx = 8;
+    hipLaunchKernelGGL(a0_replay_insert_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, frames, cap, obs_bytes, start_slot % cap, n, obs, obs_next,
+                       act, rew, done, r_act, r_rew, r_done);
+    return a0_fail_hip((int)hipGetLastError(), "a0_replay_insert");
+}
+
+// logical deque index -> ring slot (reference deque(maxlen) semantics): slot = (head + idx % top) % cap
+__global__ void a0_replay_slots_kernel(const long long* __restrict__ idx, int B, long long top, long long head, long long cap, int* __restrict__ slot,
+                                       const int* __restrict__ r_act, const float* __restrict__ r_rew, const float* __restrict__ r_done,
+                                       const float* __restrict__ priority, int* __restrict__ act, float* __restrict__ rew, float* __restrict__ done,
+                                       float* __restrict__ prio, long long* __restrict__ idx_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const long long li = idx[b] % top;
+    const long long s = (head + li) % cap;
+    slot[b] = (int)s;
+    act[b] = r_act[s];
+    rew[b] = r_rew[s];
+    done[b] = r_done[s];
+    if (prio) prio[b] = priority ? priority[li] : 1.f;
+    if (idx_out) idx_out[b] = li;
+}
+
+extern "C" int a0_replay_lookup(const long long* idx, int B, long long top, long long head, long long cap, int* slot, const int* r_act,
+                                const float* r_rew, const float* r_done, const float* priority, int* act, float* rew, float* done, float* prio,
+                                long long* idx_out, void* stream) {
+    if (!idx || !slot || !r_act || !r_rew || !r_done || !act || !rew || !done || B < 1 || top < 1 || cap < top || cap > 2147483647LL) return a0_fail(A0_EINVAL, "a0_replay_lookup: bad argument");
+    hipLaunchKernelGGL(a0_replay_slots_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, idx, B, top, head, cap, slot, r_act, r_rew, r_done,
+                       priority, act, rew, done, prio, idx_out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_replay_lookup");
+}
+
+// out[b] = frames[slot[b]]  (row_bytes each, 16 B per lane, rows are contiguous so every load is a full line)
+__global__ __launch_bounds__(256) void a0_replay_gather_kernel(const uint8_t* __restrict__ frames, int row_bytes, const int* __restrict__ slot,
+                                                                uint8_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int q = row_bytes >> 4;
+    const uint4* s = (const uint4*)(frames + (long long)slot[b] * row_bytes);
+    uint4* d = (uint4*)(out + (long long)b * row_bytes);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) d[j] = s[j];
+}
+
+extern "C" int a0_replay_gather(const uint8_t* frames, int row_bytes, const int* slot, int B, uint8_t* out, void* stream) {
+    if (!frames || !slot || !out || B < 1 || (row_bytes & 15)) return a0_fail(A0_EINVAL, "a0_replay_gather: bad argument");
+    int gx = ((row_bytes >> 4) + 255) / 256; if (gx > 4) gx = 4;
+    hipLaunchKernelGGL(a0_replay_gather_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, frames, row_bytes, slot, out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_replay_gather");
+}
+
+// ------------------------------------------------------------------------------------------------ flat priority vector (reference semantics)
+__global__ void a0_fill_kernel(float* __restrict__ p, long long n, float v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+extern "C" int a0_fill_f32(float* p, long long n, float v, void* stream) {
+    if (!p || n < 1) return a0_fail(A0_EINVAL, "a0_fill_f32: bad argument");
+    long long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    return a0_fail_hip((int)hipGetLastError(), "a0_fill_f32");
+}
+
+A0_D float a0_prio_pow(float x, float alpha) { return (alpha == 0.5f) ? sqrtf(x) : powf(x, alpha); }   // torch lowers pow(0.5) to sqrt
+
+// priority[ids] = (loss + eps)^alpha in batch order (a later duplicate wins); max_p[0] = max(max_p, max loss)
+// pstate: [0] max_p (float).  Single workgroup so that the duplicate rule is deterministic.
+__global__ __launch_bounds__(1024) void a0_priority_update_kernel(float* __restrict__ priority, const long long* __restrict__ ids,
+                                                                   const float* __restrict__ loss, int B, float eps, float alpha,
+                                                                   float* __restrict__ pstate, const int* __restrict__ state) {
+    if (state && state[3]) return;   // the update was skipped (NaN): the reference would have raised here; we leave priorities alone
+    __shared__ float red[1024];
+    float mx = -INFINITY;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const long long id = ids[b];
+        bool last = true;
+        for (int c = b + 1; c < B; ++c) if (ids[c] == id) { last = false; break; }
+        const float l = loss[b];
+        if (last) priority[id] = a0_prio_pow(l + eps, alpha);
+        mx = fmaxf(mx, l);
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pstate[0] = fmaxf(pstate[0], red[0]);
+}
+
+extern "C" int a0_priority_update(float* priority, const long long* ids, const float* loss, int B, float eps, float alpha, float* pstate,
+                                  const int* state, void* stream) {
+    if (!priority || !ids || !loss || !pstate || B < 1) return a0_fail(A0_EINVAL, "a0_priority_update: bad argument");
+    hipLaunchKernelGGL(a0_priority_update_kernel, dim3(1), dim3(B >= 1024 ? 1024 : ((B + 63) / 64) * 64), 0, (hipStream_t)stream, priority, ids, loss, B, eps, alpha, pstate, state);
+    return a0_fail_hip((int)hipGetLastError(), "a0_priority_update");
+}
+
+// priority[-n:] = max_p ^ alpha  (the reference's tail write, replay.py:51-52, quirk Q1)
+__global__ void a0_priority_tail_kernel(float* __restrict__ priority, long long size, long long n, const float* __restrict__ pstate, float alpha) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    priority[size - n + i] = (float)pow((double)pstate[0], (double)alpha);   // python float ** float, then cast to fp32
+}
+
+extern "C" int a0_priority_tail(float* priority, long long size, long long n, const float* pstate, float alpha, void* stream) {
+    if (!priority || !pstate || n < 1 || n > size) return a0_fail(A0_EINVAL, "a0_priority_tail: bad argument");
+    hipLaunchKernelGGL(a0_priority_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, priority, size, n, pstate, alpha);
+    return a0_fail_hip((int)hipGetLastError(), "a0_priority_tail");
+}
+
+// sum of a float vector, deterministic two-level tree (fixed grid), result in out[0]
+__global__ __launch_bounds__(256) void a0_sum_stage1(const float* __restrict__ x, long long n, float* __restrict__ part) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void a0_sum_stage2(const float* __restrict__ part, int np, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+extern "C" int a0_sum_f32(const float* x, long long n, float* scratch256, float* out, void* stream) {
+    if (!x || !scratch256 || !out || n < 1) return a0_fail(A0_EINVAL, "a0_sum_f32: bad argument");
+    int blocks = (int)((n + 255) / 256); if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(a0_sum_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scratch256);
+    hipLaunchKernelGGL(a0_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch256, blocks, out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sum_f32");
+}
+
+// w = (top * p / sum)^(-beta);  w /= (max w + 1e-8)     (trainer.py:91-94).  Single workgroup.
+__global__ __launch_bounds__(1024) void a0_is_weights_kernel(const float* __restrict__ prio, int B, const float* __restrict__ psum, float top, float beta,
+                                                              float* __restrict__ w) {
+    __shared__ float red[1024];
+    const float total = psum[0];
+    float mx = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float probs = prio[b] / total;
+        const float v = powf(top * probs, -beta);
+        w[b] = v;
+        mx = fmaxf(mx, v);
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    const float denom = red[0] + 1e-8f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) w[b] = w[b] / denom;
+}
+
+extern "C" int a0_is_weights(const float* prio, int B, const float* psum, long long top, float beta, float* w, void* stream) {
+    if (!prio || !psum || !w || B < 1 || top < 1) return a0_fail(A0_EINVAL, "a0_is_weights: bad argument");
+    int threads = 64; while (threads < B && threads < 1024) threads <<= 1;
+    hipLaunchKernelGGL(a0_is_weights_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, prio, B, psum, (float)top, beta, w);
+    return a0_fail_hip((int)hipGetLastError(), "a0_is_weights");
+}
+
+// ------------------------------------------------------------------------------------------------ uniform permutation
+// 4-round Feistel bijection on [0, 2^(2h)) with cycle walking — must equal oracle/sumtree.c a0o_perm_index.
+A0_D uint32_t a0_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+__global__ void a0_perm_kernel(unsigned long long start, int count, unsigned long long n, uint32_t seed, long long* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    uint32_t h = 1;
+    while ((1ull << (2 * h)) < n) ++h;
+    const uint32_t mask = (uint32_t)((1ull << h) - 1);
+    unsigned long long x = start + (unsigned long long)k;
+    do {
+        uint32_t l = (uint32_t)(x >> h) & mask, r = (uint32_t)x & mask;
+        for (uint32_t round = 0; round < 4; ++round) {
+            const uint32_t f = a0_mix32(r ^ (seed + 0x9E3779B9u * (round + 1))) & mask;
+            const uint32_t nl = r, nr = l ^ f;
+            l = nl; r = nr;
+        }
+        x = ((unsigned long long)l << h) | r;
+    } while (x >= n);
+    out[k] = (long long)x;
+}
+
+extern "C" int a0_perm_batch(unsigned long long start, int count, unsigned long long n, unsigned int seed, long long* out, void* stream) {
+    if (!out || count < 1 || n < 1 || start + (unsigned long long)count > n) return a0_fail(A0_EINVAL, "a0_perm_batch: bad argument");
+    hipLaunchKernelGGL(a0_perm_kernel, dim3((count + 127) / 128), dim3(128), 0, (hipStream_t)stream, start, count, n, seed, out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_perm_batch");
+}
+
+// ------------------------------------------------------------------------------------------------ sum-tree
+// Contract: oracle/sumtree.c.  tree[1] root, leaf i at tree[cap2 + i]; ancestors recomputed as left + right.
+__global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict__ tree, long long cap2, const long long* __restrict__ idx,
+                                                               const float* __restrict__ val, int n) {
+    // single workgroup: leaves first (a later duplicate wins), then one level per barrier, bottom-up
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long long id = idx[i];
+        bool last = true;
+        for (int c = i + 1; c < n; ++c) if (idx[c] == id) { last = false; break; }
+        if (last) tree[cap2 + id] = val[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (long long span = cap2 >> 1; span >= 1; span >>= 1) {   // span = number of nodes on the level being recomputed
+        const int shift = __builtin_ctzll(cap2 / span);          // leaf -> ancestor on this level
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const long long p = (cap2 + idx[i]) >> shift;
+            tree[p] = tree[2 * p] + tree[2 * p + 1];             // identical value from every writer of p
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, void* stream) {
+    if (!tree || !idx || !val || n < 1 || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_set: cap2 must be a power of two");
+    int threads = 64; while (threads < n && threads < 1024) threads <<= 1;
+    hipLaunchKernelGGL(a0_sumtree_set_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, tree, cap2, idx, val, n);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set");
+}
+
+// transform-and-set used by the learner: val = (loss + eps)^alpha; also tracks max_p like a0_priority_update
+__global__ __launch_bounds__(1024) void a0_sumtree_prio_kernel(const float* __restrict__ loss, int n, float eps, float alpha, float* __restrict__ val,
+                                                                float* __restrict__ pstate) {
+    __shared__ float red[1024];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float l = loss[i]; val[i] = a0_prio_pow(l + eps, alpha); mx = fmaxf(mx, l); }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) pstate[0] = fmaxf(pstate[0], red[0]);
+}
+
+extern "C" int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, void* stream) {
+    if (!loss || !val || !pstate || n < 1) return a0_fail(A0_EINVAL, "a0_priority_from_loss: bad argument");
+    int threads = 64; while (threads < n && threads < 1024) threads <<= 1;
+    hipLaunchKernelGGL(a0_sumtree_prio_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, loss, n, eps, alpha, val, pstate);
+    return a0_fail_hip((int)hipGetLastError(), "a0_priority_from_loss");
+}
+
+// full rebuild, one launch per level (used after bulk fills)
+__global__ void a0_sumtree_level_kernel(float* __restrict__ tree, long long first, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const long long p = first + i;
+    tree[p] = tree[2 * p] + tree[2 * p + 1];
+}
+
+extern "C" int a0_sumtree_rebuild(float* tree, long long cap2, void* stream) {
+    if (!tree || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_rebuild: bad argument");
+    for (long long first = cap2 >> 1; first >= 1; first >>= 1)
+        hipLaunchKernelGGL(a0_sumtree_level_kernel, dim3((unsigned)((first + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tree, first, first);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_rebuild");
+}
+
+// stratified proportional sampling: u_k = (k + xi_k) * (total / B)
+__global__ void a0_sumtree_sample_kernel(const float* __restrict__ tree, long long cap2, const float* __restrict__ xi, int B,
+                                         long long* __restrict__ out_idx, float* __restrict__ out_p) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const float total = tree[1];
+    const float seg = total / (float)B;
+    float u = ((float)k + xi[k]) * seg;
+    long long n = 1;
+    while (n < cap2) {
+        const float left = tree[2 * n];
+        const float right = tree[2 * n + 1];
+        if (u < left || !(right > 0.0f)) {
+            n = 2 * n;
+        } else {
+            u -= left;
+            n = 2 * n + 1;
+        }
+    }
+    out_idx[k] = n - cap2;
+    out_p[k] = tree[n];
+}
+
+extern "C" int a0_sumtree_sample(const float* tree, long long cap2, const float* xi, int B, long long* out_idx, float* out_p, void* stream) {
+    if (!tree || !xi || !out_idx || !out_p || B < 1 || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_sample: bad argument");
+    hipLaunchKernelGGL(a0_sumtree_sample_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tree, cap2, xi, B, out_idx, out_p);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_sample");
+}

@@ -1,0 +1,83 @@
+// Device-resident synthetic Atari-shaped vector environment (gfx950).  Byte-exact twin of oracle/synth_env.c; see that
+// file for the definition.  Stands in for reference agent0/common/atari_wrappers.py:59-69 (gymnasium + ale-py are not
+// available on the GPU box); honours the obs/reward/terminal/truncated/life_loss/episode-return contract that
+// agent0/deepq/agent.py:55-62,85-88 consumes.  It is NOT Atari.
+#include "a0_internal.h"
+#include "philox.h"
+
+#pragma clang fp contract(off)
+
+#define A0_ENV_H 84
+#define A0_ENV_W 84
+#define A0_ENV_PIX (A0_ENV_H * A0_ENV_W)
+
+A0_D uint32_t a0_env_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix) {
+    const uint32_t y = pix / A0_ENV_W, x = pix - y * A0_ENV_W;
+    const uint32_t h = a0_env_mix32(base ^ (pix * 0x85EBCA77u));
+    uint8_t v = (((h >> 8) & 3u) == 0u) ? (uint8_t)(h & 255u) : (uint8_t)0;
+    if (y >= by && y < by + 8 && x >= bx && x < bx + 8) v = 255;
+    return v;
+}
+
+// grid (chunks, E); each thread produces 4 consecutive pixels of the new frame and moves the matching 4-byte groups
+// of the three older frames.  g = step index since reset (identical for every env: they step in lockstep).
+__global__ __launch_bounds__(256) void a0_env_step_kernel(unsigned long long seed, uint32_t rank, int E, uint32_t g, const uint8_t* __restrict__ obs_in,
+                                                           uint8_t* __restrict__ obs_out, float* __restrict__ ep_ret, float* __restrict__ reward,
+                                                           float* __restrict__ terminal, float* __restrict__ truncated, float* __restrict__ life_loss,
+                                                           float* __restrict__ final_mask, float* __restrict__ final_ret, int reset) {
+    const uint32_t e = blockIdx.y;
+    bool term = reset != 0;
+    if (!reset) {
+        const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)seed, (uint32_t)(seed >> 32) ^ rank);
+        term = (x.y % 500u) == 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const uint32_t rw = x.x % 1000u;
+            const float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+            const bool life = (!term) && ((x.z % 200u) == 0u);
+            reward[e] = r; terminal[e] = term ? 1.f : 0.f; truncated[e] = 0.f; life_loss[e] = life ? 1.f : 0.f;
+            const float ret = ep_ret[e] + r;
+            final_mask[e] = term ? 1.f : 0.f;
+            final_ret[e] = term ? ret : 0.f;
+            ep_ret[e] = term ? 0.f : ret;
+        }
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ep_ret[e] = 0.f;
+    }
+    const uint32_t base = (uint32_t)seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
+    const uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    const uint32_t* in4 = (const uint32_t*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
+    uint32_t* out4 = (uint32_t*)(obs_out + (size_t)e * 4 * A0_ENV_PIX);
+    const int q = A0_ENV_PIX / 4;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) {
+        const uint32_t p = 4u * (uint32_t)j;
+        const uint32_t nw = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
+                            ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
+        if (term) {
+            out4[j] = nw; out4[q + j] = nw; out4[2 * q + j] = nw; out4[3 * q + j] = nw;
+        } else {
+            out4[j] = in4[q + j]; out4[q + j] = in4[2 * q + j]; out4[2 * q + j] = in4[3 * q + j]; out4[3 * q + j] = nw;
+        }
+    }
+}
+
+extern "C" int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream) {
+    if (!obs || !ep_ret || E < 1) return a0_fail(A0_EINVAL, "a0_env_synth_reset: bad argument");
+    hipLaunchKernelGGL(a0_env_step_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, 0u, obs, obs, ep_ret,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1);
+    return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_reset");
+}
+
+extern "C" int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
+                                 float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
+                                 float* final_ret, void* stream) {
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !reward || !terminal || !truncated || !life_loss || !final_mask || !final_ret || E < 1)
+        return a0_fail(A0_EINVAL, "a0_env_synth_step: bad argument (obs_in and obs_out must differ)");
+    hipLaunchKernelGGL(a0_env_step_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal,
+                       truncated, life_loss, final_mask, final_ret, 0);
+    return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step");
+}

@@ -1,0 +1,366 @@
+"""Device-side network and learner: composes the HIP kernels (through ``ops``) into the forward passes, losses,
+backward passes and optimizer steps of the six reference learners.
+
+``ops`` is the only door to the GPU (agent0_amd.ops.HipOps).  The composition is written against that interface so
+the CPU test-suite can drive the very same code with an emulation backend (tests/cpu_ops.py) that runs the shared
+C++ layer orchestration on the host — the product itself never does that.
+
+Reference mapping (paths relative to the reference repo):
+  DeviceNet.forward / qvalues   agent0/deepq/model.py:323-330 + heads 123-131, 163-177, 190-192, 219-257, 268-284
+  DeviceLearner.update          agent0/deepq/agent.py:124-169 (BaseLearner.train) + train_step of each learner
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from .layout import Block, NetLayout
+
+MODE_IDENT, MODE_MEAN, MODE_C51, MODE_FQF = 0, 1, 2, 3
+
+
+class Workspace:
+    """Activations of one forward pass over ``B`` observations (``n_tau`` quantile samples each for IQN/FQF)."""
+
+    def __init__(self, ops, L: NetLayout, B: int, n_tau: int = 1, grads: bool = False):
+        self.B, self.n_tau = B, n_tau
+        R = B * n_tau if L.quantile else B
+        self.R = R
+        self.act1 = ops.empty(B * L.H1 * L.W1 * 32)
+        self.act2 = ops.empty(B * L.H2 * L.W2 * 64)
+        self.act3 = ops.empty(B * L.feat)
+        self.h = ops.empty(R * 512)
+        self.raw = ops.empty(R * L.Npad)
+        self.q = ops.empty(R * L.A * L.T)
+        if L.quantile:
+            self.cosx = ops.empty(R * L.num_cosines)
+            self.emb = ops.empty(R * L.feat)
+            self.x = ops.empty(R * L.feat)
+            self.taus = ops.empty(R)
+        if L.algo == "fqf":
+            self.frac_logits = ops.empty(B * L.Fpad)
+            self.tau_all = ops.empty(B * (L.F + 1))
+            self.tau_hat = ops.empty(B * L.F)
+        if grads:
+            self.dq = ops.zeros(R * L.A * L.T)
+            self.draw = ops.empty(R * L.Npad)
+            self.dh = ops.empty(R * 512)
+            self.d3 = ops.empty(B * L.feat)
+            self.d2 = ops.empty(B * L.H2 * L.W2 * 64)
+            self.d1 = ops.empty(B * L.H1 * L.W1 * 32)
+            if L.quantile:
+                self.dx = ops.empty(R * L.feat)
+                self.demb = ops.empty(R * L.feat)
+
+
+class DeviceNet:
+    """One set of network parameters on the device in the packed layout, plus forward-pass composition."""
+
+    def __init__(self, ops, L: NetLayout, net_handle):
+        self.ops, self.L, self.net = ops, L, net_handle
+        self.flat = ops.zeros(L.n_params_padded)
+        self.eff = ops.zeros(max(L.n_eff, 4)) if L.noisy else None
+        # noise vectors in KERNEL order (noise_in of first_dense permuted to (h,w,c))
+        self.noise: Dict[str, Dict[str, torch.Tensor]] = {}
+        for prefix, block, r0, r1, in_f in L.noise_modules:
+            self.noise[prefix] = {"noise_in": ops.zeros(in_f), "noise_out_weight": ops.zeros(r1 - r0), "noise_out_bias": ops.zeros(r1 - r0)}
+        self._scratch: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ weights
+    def block(self, name: str) -> Block:
+        return self.L.blocks[name]
+
+    def wb(self, name: str):
+        """(W, b) views of the EFFECTIVE weights of a dense layer (composed ones for NoisyNet)."""
+        if self.L.noisy and name in ("fc1", "head"):
+            blk, buf = self.L.eff[name], self.eff
+        else:
+            blk, buf = self.L.blocks[name], self.flat
+        return buf[blk.w], buf[blk.b]
+
+    def encoder_weights(self):
+        f, B = self.flat, self.L.blocks
+        return {"w1": f[B["conv1"].w], "b1": f[B["conv1"].b], "w2": f[B["conv2"].w], "b2": f[B["conv2"].b], "w3": f[B["conv3"].w], "b3": f[B["conv3"].b]}
+
+    def compose_noise(self):
+        """NoisyLinear.reset_noise's weight_epsilon/bias_epsilon + forward composition (model.py:54-62,78-83)."""
+        L = self.L
+        for prefix, block, r0, r1, in_f in L.noise_modules:
+            mu, sg, ef = L.blocks[block + ".mu"], L.blocks[block + ".sigma"], L.eff[block]
+            nz = self.noise[prefix]
+            self.ops.noisy_compose(self.flat[mu.all], self.flat[sg.all], self.eff[ef.all], mu.N, mu.K, r0, r1,
+                                   nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"])
+
+    def set_noise(self, prefix: str, noise_in, noise_out_weight, noise_out_bias):
+        """Install the three noise vectors of one NoisyLinear (reference order/layout; model.py:73-76)."""
+        nz = self.noise[prefix]
+        dev = self.flat.device
+        nz["noise_in"].copy_(self.L.noise_in_to_kernel(prefix, torch.as_tensor(noise_in, dtype=torch.float32).to(dev)))
+        nz["noise_out_weight"].copy_(torch.as_tensor(noise_out_weight, dtype=torch.float32).to(dev))
+        nz["noise_out_bias"].copy_(torch.as_tensor(noise_out_bias, dtype=torch.float32).to(dev))
+
+    def load_state_dict(self, sd):
+        """Reference-format state_dict (keys/shapes of agent0/deepq/model.py) -> packed device parameters."""
+        dev = self.flat.device
+        sd = {k: torch.as_tensor(v).to(dev) for k, v in sd.items()}
+        self.L.pack(sd, self.flat)
+        for prefix, *_ in self.L.noise_modules:
+            if f"{prefix}.noise_in" in sd:
+                self.set_noise(prefix, sd[f"{prefix}.noise_in"], sd[f"{prefix}.noise_out_weight"], sd[f"{prefix}.noise_out_bias"])
+        if self.L.noisy:
+            self.compose_noise()
+
+    def state_dict(self):
+        """Packed device parameters -> reference-format entries (trainables + NoisyNet buffers)."""
+        out = self.L.unpack(self.flat)
+        for prefix, *_ in self.L.noise_modules:
+            nz = self.noise[prefix]
+            nin = self.L.noise_in_from_kernel(prefix, nz["noise_in"]).clone()
+            f = lambda x: x.sign() * x.abs().sqrt()
+            out[f"{prefix}.weight_epsilon"] = torch.outer(f(nz["noise_out_weight"]), f(nin))
+            out[f"{prefix}.bias_epsilon"] = f(nz["noise_out_bias"])
+            out[f"{prefix}.noise_in"] = nin
+            out[f"{prefix}.noise_out_weight"] = nz["noise_out_weight"].clone()
+            out[f"{prefix}.noise_out_bias"] = nz["noise_out_bias"].clone()
+        return out
+
+    def scratch(self, n: int) -> Optional[torch.Tensor]:
+        if n <= 0:
+            return None
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = self.ops.empty(n)
+        return self._scratch
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, ws: Workspace, frames, slot, sample_stride, chan_off, B):
+        self.ops.encoder_fwd(self.net, self.encoder_weights(), frames, slot, sample_stride, chan_off, B, ws.act1, ws.act2, ws.act3)
+
+    def _dense(self, X, ldx, name, Y, R, relu):
+        W, b = self.wb(name)
+        blk = self.L.eff[name] if (self.L.noisy and name in ("fc1", "head")) else self.L.blocks[name]
+        N, K = blk.N, blk.K
+        self.ops.dense_fwd(X, ldx, W, b, Y, R, N, K, relu, self.scratch(self.ops.dense_fwd_scratch(R, N, K)))
+
+    def head(self, ws: Workspace, B, taus: Optional[torch.Tensor] = None, n_tau: int = 1, feat: Optional[torch.Tensor] = None):
+        """features -> q.  Dense algos: q [B][A][T].  Quantile algos: taus [B*n_tau] -> q [B][n_tau][A].
+        ``feat`` overrides ws.act3 (evaluating a head on another pass's features)."""
+        L, ops = self.L, self.ops
+        feat = ws.act3 if feat is None else feat
+        if not L.quantile:
+            self._dense(feat, L.feat, "fc1", ws.h, B, True)
+            self._dense(ws.h, 512, "head", ws.raw, B, False)
+            ops.dueling_fwd(ws.raw, L.Npad, ws.q, B, L.A, L.T, L.dueling)
+            return ws.q
+        R = B * n_tau
+        ops.cos_features(taus, ws.cosx, R, L.num_cosines)
+        self._dense(ws.cosx, L.num_cosines, "cos", ws.emb, R, True)
+        ops.hadamard_fwd(ws.emb, feat, ws.x, B, n_tau, L.feat)
+        self._dense(ws.x, L.feat, "fc1", ws.h, R, True)
+        self._dense(ws.h, 512, "head", ws.raw, R, False)
+        ops.dueling_fwd(ws.raw, L.Npad, ws.q, R, L.A, 1, L.dueling)
+        return ws.q
+
+    def fqf_taus(self, ws: Workspace, B):
+        """FQFHead.prop_taus (model.py:268-278): fraction net on (detached) features -> taus, tau_hats."""
+        L = self.L
+        self._dense(ws.act3, L.feat, "frac", ws.frac_logits, B, False)
+        self.ops.fqf_taus(ws.frac_logits, L.Fpad, ws.tau_all, ws.tau_hat, B, L.F)
+
+    def select(self, ws: Workspace, B, n_tau, a_star, qsel=None, qmax=None, atoms=None):
+        """argmax_a head.qval (greedy action) from the activations in ``ws``."""
+        L, ops = self.L, self.ops
+        if L.algo in ("dqn", "mdqn"):
+            ops.select_action(ws.q, L.A, 1, 1, B, L.A, 1, MODE_IDENT, None, a_star, qsel, qmax)
+        elif L.algo == "qr":
+            ops.select_action(ws.q, L.A * L.T, L.T, 1, B, L.A, L.T, MODE_MEAN, None, a_star, qsel, qmax)
+        elif L.algo == "c51":
+            ops.select_action(ws.q, L.A * L.T, L.T, 1, B, L.A, L.T, MODE_C51, atoms, a_star, qsel, qmax)
+        elif L.algo == "iqn":
+            ops.select_action(ws.q, n_tau * L.A, 1, L.A, B, L.A, n_tau, MODE_MEAN, None, a_star, qsel, qmax)
+        else:  # fqf: sum_i (tau_{i+1} - tau_i) q(tau_hat_i)
+            ops.select_action(ws.q, n_tau * L.A, 1, L.A, B, L.A, n_tau, MODE_FQF, ws.tau_all, a_star, qsel, qmax)
+
+
+class DeviceLearner:
+    """Online + target network, gradients, Adam / RMSprop state and the per-algorithm update."""
+
+    def __init__(self, ops, L: NetLayout, batch_size: int, *, discount=0.99, n_step=1, double_q=False, lr=5e-4,
+                 target_update_freq=500, vmin=-10.0, vmax=10.0, K=32, N=64, N_dash=64, max_grad_norm=-1.0, adam_eps=None):
+        self.ops, self.L, self.B = ops, L, batch_size
+        self.net = ops.net(L.C, L.H, L.W)
+        self.online = DeviceNet(ops, L, self.net)
+        self.target = DeviceNet(ops, L, self.net)
+        self.grads = ops.zeros(L.n_params_padded)
+        self.adam_m = ops.zeros(L.n_params_padded)
+        self.adam_v = ops.zeros(L.n_params_padded)
+        self.state = ops.zeros(8, dtype=torch.int32)
+        self.scalars = ops.zeros(4)
+        self.discount, self.n_step, self.double_q = discount, n_step, double_q
+        self.gamma_n = float(discount ** n_step)
+        self.lr, self.target_update_freq = lr, target_update_freq
+        self.adam_eps = (1e-2 / batch_size) if adam_eps is None else adam_eps
+        self.vmin, self.vmax = float(vmin), float(vmax)
+        self.K, self.N, self.N_dash = K, N, N_dash
+        self.max_grad_norm = max_grad_norm
+        B = batch_size
+        if L.quantile:
+            n_on = N if L.algo == "iqn" else L.F
+            n_tg = N_dash if L.algo == "iqn" else L.F
+            n_sel = K if L.algo == "iqn" else L.F
+            self.ws_o = Workspace(ops, L, B, n_on, grads=True)
+            self.ws_t = Workspace(ops, L, B, max(n_tg, n_sel))
+            self.ws_s = Workspace(ops, L, B, n_sel) if double_q else None
+            if L.algo == "fqf":
+                self.ws_f = Workspace(ops, L, B, L.F)        # q at taus[1:-1] for the fraction loss (F-1 used)
+                self.rms_sq = ops.zeros(L.blocks["frac"].size)
+                self.frac_loss = ops.empty(B)
+                self.dfrac_logits = ops.zeros(B * L.Fpad)
+                self.clip = ops.zeros(1)
+            self.y = ops.empty(B * n_tg)
+        else:
+            self.ws_o = Workspace(ops, L, B, grads=True)
+            self.ws_t = Workspace(ops, L, B)
+            self.ws_s = Workspace(ops, L, B) if double_q else None
+            if L.algo == "qr":
+                self.y = ops.empty(B * L.T)
+                self.qr_taus = ((2 * torch.arange(L.T, dtype=torch.float32) + 1) / (2.0 * L.T)).to(ops.device)
+            if L.algo == "mdqn":
+                self.ws_m = Workspace(ops, L, B)
+        if L.algo == "c51":
+            self.atoms = torch.linspace(self.vmin, self.vmax, L.T).to(ops.device)
+            self.m_proj = ops.empty(B * L.T)
+        self.a_star = ops.zeros(B, dtype=torch.int32)
+        self.loss = ops.empty(B)
+        n_slab = max(ops.encoder_bwd_scratch(self.net, B),
+                     ops.dense_wgrad_scratch(self.ws_o.R, L.Npad, 512), ops.dense_wgrad_scratch(self.ws_o.R, 512, L.feat),
+                     ops.dense_wgrad_scratch(self.ws_o.R, L.feat, L.num_cosines) if L.quantile else 0,
+                     ops.dense_wgrad_scratch(B, L.Fpad, L.feat) if L.algo == "fqf" else 0, 4)
+        self.slabs = ops.empty(n_slab)
+        self.obs_bytes = L.C * L.H * L.W
+
+    # ------------------------------------------------------------------ helpers
+    def sync_target(self, force=True):
+        self.ops.target_sync(self.target.flat, self.online.flat, self.L.n_params_padded, self.state, force)
+
+    def _grad(self, name: str) -> torch.Tensor:
+        L = self.L
+        key = name + ".mu" if (L.noisy and name in ("fc1", "head")) else name
+        return self.grads[L.blocks[key].all]
+
+    def _backward_trunk(self, ws: Workspace, frames, slot, stride, B):
+        """dq (w.r.t. the combined head output) -> every parameter gradient of the online net."""
+        L, ops, on = self.L, self.ops, self.online
+        R, T = ws.R, (1 if L.quantile else L.T)
+        ops.dueling_bwd(ws.dq, ws.draw, L.Npad, R, L.A, T, L.dueling)
+        Wh, _ = on.wb("head")
+        Wf, _ = on.wb("fc1")
+        ops.dense_wgrad(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512, self.slabs)
+        ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
+        if not L.quantile:
+            ops.dense_wgrad(ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat, self.slabs)
+            ops.dense_dgrad(ws.dh, Wf, ws.act3, ws.d3, R, 512, L.feat)
+        else:
+            n = ws.n_tau
+            ops.dense_wgrad(ws.dh, ws.x, L.feat, self._grad("fc1"), R, 512, L.feat, self.slabs)
+            ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
+            ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
+            ops.dense_wgrad(ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines, self.slabs)
+        ops.encoder_bwd(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1,
+                        self.grads[L.blocks["conv1"].all], self.grads[L.blocks["conv2"].all], self.grads[L.blocks["conv3"].all], self.slabs)
+        if L.noisy:
+            for prefix, block, r0, r1, in_f in L.noise_modules:
+                mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
+                nz = on.noise[prefix]
+                ops.noisy_grad_sigma(self.grads[mu.all], self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"])
+
+    # ------------------------------------------------------------------ the update
+    def update(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
+        """One BaseLearner.train step (agent.py:124-169) on a batch that stays on the device.
+
+        frames: u8 replay rows (st || st_next); slot: optional int32 row indices; act int32, rew/done/wgt fp32 [B].
+        rand (IQN only): [taus_K [B*K], taus_N' [B*N'], taus_N [B*N]] in the reference's draw order.
+        Returns the per-sample loss tensor (device) — and for FQF also the fraction loss.
+        """
+        L, ops, B = self.L, self.ops, self.B
+        on, tg = self.online, self.target
+        nxt = self.obs_bytes
+        if L.noisy:
+            on.compose_noise()
+            tg.compose_noise()
+        algo = L.algo
+        wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
+        frac = None
+        if algo in ("dqn", "c51", "qr"):
+            tg.encode(wt, frames, slot, sample_stride, nxt, B)
+            tg.head(wt, B)
+            if self.double_q:
+                on.encode(wsel, frames, slot, sample_stride, nxt, B)
+                on.head(wsel, B)
+                on.select(wsel, B, 1, self.a_star, atoms=getattr(self, "atoms", None))
+            else:
+                tg.select(wt, B, 1, self.a_star, atoms=getattr(self, "atoms", None))
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            on.head(wo, B)
+            if algo == "dqn":
+                ops.loss_dqn(wo.q, wt.q, L.A, act, self.a_star, rew, done, wgt, self.gamma_n, B, self.loss, wo.dq, self.state)
+            elif algo == "c51":
+                ops.loss_c51(wo.q, wt.q, L.A, L.T, act, self.a_star, rew, done, wgt, self.atoms, self.gamma_n, self.vmin, self.vmax, B,
+                             self.loss, wo.dq, self.m_proj, self.state)
+            else:
+                ops.quantile_target(wt.q, L.A * L.T, 1, L.T, self.a_star, rew, done, self.gamma_n, B, L.T, self.y)
+                wo.dq.zero_()
+                ops.loss_quantile_huber(wo.q, L.A * L.T, 1, L.T, self.y, self.qr_taus, 0, act, wgt, B, L.T, L.T, self.loss, wo.dq, self.state)
+        elif algo == "iqn":
+            t_sel, t_tgt, t_on = rand
+            K, Nd, N = self.K, self.N_dash, self.N
+            tg.encode(wt, frames, slot, sample_stride, nxt, B)
+            if self.double_q:
+                on.encode(wsel, frames, slot, sample_stride, nxt, B)
+                on.head(wsel, B, t_sel, K)
+                on.select(wsel, B, K, self.a_star)
+            else:
+                tg.head(wt, B, t_sel, K)
+                tg.select(wt, B, K, self.a_star)
+            tg.head(wt, B, t_tgt, Nd)
+            ops.quantile_target(wt.q, Nd * L.A, L.A, 1, self.a_star, rew, done, self.gamma_n, B, Nd, self.y)
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            on.head(wo, B, t_on, N)
+            wo.dq.zero_()
+            ops.loss_quantile_huber(wo.q, N * L.A, L.A, 1, self.y, t_on, N, act, wgt, B, N, Nd, self.loss, wo.dq, self.state)
+        elif algo == "fqf":
+            F = L.F
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            on.fqf_taus(wo, B)
+            on.head(wo, B, wo.tau_hat, F)
+            tg.encode(wt, frames, slot, sample_stride, nxt, B)
+            if self.double_q:
+                on.encode(wsel, frames, slot, sample_stride, nxt, B)
+                on.fqf_taus(wsel, B)
+                on.head(wsel, B, wsel.tau_hat, F)
+                on.select(wsel, B, F, self.a_star)
+            else:
+                tg.fqf_taus(wt, B)
+                tg.head(wt, B, wt.tau_hat, F)
+                tg.select(wt, B, F, self.a_star)
+            tg.head(wt, B, wo.tau_hat, F)           # quirk Q16: target evaluated at the ONLINE tau-hats
+            ops.quantile_target(wt.q, F * L.A, L.A, 1, self.a_star, rew, done, self.gamma_n, B, F, self.y)
+            wo.dq.zero_()
+            ops.loss_quantile_huber(wo.q, F * L.A, L.A, 1, self.y, wo.tau_hat, F, act, wgt, B, F, F, self.loss, wo.dq, self.state)
+            # fraction loss: q at the interior taus (no grad), its gradient w.r.t. the fraction logits, RMSprop
+            wf = self.ws_f
+            ops.fqf_inner_taus(wo.tau_all, wf.taus, B, F)                      # taus[:, 1:-1] -> [B][F-1]
+            on.head(wf, B, wf.taus, F - 1, feat=wo.act3)
+            ops.fqf_fraction_loss(wf.q, wo.q, wo.tau_all, act, wgt, B, F, L.A, L.Fpad, self.frac_loss, self.dfrac_logits, wo.frac_logits)
+            gfr = self.grads[L.blocks["frac"].all]
+            ops.dense_wgrad(self.dfrac_logits, wo.act3, L.feat, gfr, B, L.Fpad, L.feat, self.slabs)
+            blk = L.blocks["frac"]
+            ops.rmsprop_step(on.flat[blk.all], gfr, self.rms_sq, blk.size, self.lr / 2e4, 0.95, 1e-5, self.max_grad_norm, self.clip)
+            frac = self.frac_loss
+        else:
+            raise NotImplementedError(f"algo {algo} has no device learner yet")
+        self._backward_trunk(wo, frames, slot, sample_stride, B)
+        ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
+        self.sync_target(force=False)
+        return (self.loss, frac) if frac is not None else self.loss

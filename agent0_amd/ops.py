@@ -1,0 +1,318 @@
+"""Tensor-level wrappers over the C-ABI (one method per exported kernel group).
+
+Every method validates dtype / device / contiguity / size on the host before a
+pointer reaches a kernel, and launches on torch's current HIP stream.  The
+product code (agent0_amd.deepq.*) talks to the GPU only through this class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _abi
+from ._abi import A0Error, EncoderWeights, FramesArg, NetDesc, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: Optional[torch.Tensor], dtype, min_numel: int, name: str, optional: bool = False):
+    if t is None:
+        if optional:
+            return None
+        raise A0Error(f"{name}: tensor required")
+    if not t.is_cuda:
+        raise A0Error(f"{name}: expected a HIP device tensor (got {t.device}); agent0_amd has no CPU path")
+    if t.dtype != dtype:
+        raise A0Error(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise A0Error(f"{name}: must be contiguous")
+    if t.numel() < min_numel:
+        raise A0Error(f"{name}: needs >= {min_numel} elements, has {t.numel()}")
+    return t.data_ptr()
+
+
+class Net:
+    """a0_net handle: geometry + gather tables for one observation shape."""
+
+    def __init__(self, lib, C_, H, W):
+        self.lib = lib
+        self.h = C.c_void_p()
+        desc = NetDesc(C_, H, W)
+        check(lib.a0_net_create(C.addressof(desc), C.addressof(self.h)), "a0_net_create")
+        geo = (C.c_int * 8)()
+        check(lib.a0_net_geometry(self.h, C.addressof(geo)), "a0_net_geometry")
+        self.C, self.H, self.W = C_, H, W
+        self.H1, self.W1, self.H2, self.W2, self.H3, self.W3, self.feat, self.K1 = list(geo)
+        self.K2, self.K3 = 512, 576
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.a0_net_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self):
+        if not torch.cuda.is_available():
+            raise A0Error("agent0_amd needs an AMD GPU visible to PyTorch-ROCm (torch.cuda.is_available() is False)")
+        self.lib = _abi.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    # ------------------------------------------------------------------ allocation helpers
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def net(self, C_, H, W) -> Net:
+        return Net(self.lib, C_, H, W)
+
+    # ------------------------------------------------------------------ encoder
+    def _frames(self, net, frames, slot, sample_stride, chan_off, B):
+        hw = net.H * net.W
+        need_rows = B if slot is None else 1
+        fp = _req(frames, torch.uint8, need_rows * sample_stride if slot is None else chan_off + net.C * hw, "frames")
+        if chan_off + net.C * hw > sample_stride:
+            raise A0Error("frames: chan_off + C*H*W exceeds sample_stride")
+        sp = _req(slot, torch.int32, B, "slot", optional=True)
+        return FramesArg(fp, sp, sample_stride, chan_off)
+
+    @staticmethod
+    def _enc_w(w):
+        return EncoderWeights(*[w[k].data_ptr() for k in ("w1", "b1", "w2", "b2", "w3", "b3")])
+
+    def encoder_fwd(self, net, w, frames, slot, sample_stride, chan_off, B, act1, act2, act3):
+        fa = self._frames(net, frames, slot, sample_stride, chan_off, B)
+        ew = self._enc_w(w)
+        a1 = _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1")
+        a2 = _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2")
+        a3 = _req(act3, torch.float32, B * net.feat, "act3")
+        check(self.lib.a0_net_encoder_fwd(net.h, C.addressof(ew), C.addressof(fa), B, a1, a2, a3, _stream()), "a0_net_encoder_fwd")
+
+    def encoder_bwd_scratch(self, net, B) -> int:
+        return int(self.lib.a0_net_encoder_bwd_scratch(net.h, B))
+
+    def encoder_bwd(self, net, w, frames, slot, sample_stride, chan_off, B, act1, act2, d3, d2, d1, g1, g2, g3, slabs):
+        fa = self._frames(net, frames, slot, sample_stride, chan_off, B)
+        ew = self._enc_w(w)
+        need = self.encoder_bwd_scratch(net, B)
+        check(self.lib.a0_net_encoder_bwd(
+            net.h, C.addressof(ew), C.addressof(fa), B,
+            _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1"), _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2"),
+            _req(d3, torch.float32, B * net.feat, "d3"), _req(d2, torch.float32, B * net.H2 * net.W2 * 64, "d2"),
+            _req(d1, torch.float32, B * net.H1 * net.W1 * 32, "d1"),
+            _req(g1, torch.float32, 32 * net.K1 + 32, "g1"), _req(g2, torch.float32, 64 * net.K2 + 64, "g2"), _req(g3, torch.float32, 64 * net.K3 + 64, "g3"),
+            _req(slabs, torch.float32, need, "slabs", optional=(need == 0)), _stream()), "a0_net_encoder_bwd")
+
+    # ------------------------------------------------------------------ dense
+    def dense_fwd_scratch(self, R, N, K) -> int:
+        return int(self.lib.a0_dense_fwd_scratch(R, N, K))
+
+    def dense_wgrad_scratch(self, R, N, K) -> int:
+        return int(self.lib.a0_dense_wgrad_scratch(R, N, K))
+
+    def dense_fwd(self, X, ldx, W, b, Y, R, N, K, relu, scratch):
+        need = self.dense_fwd_scratch(R, N, K)
+        check(self.lib.a0_dense_fwd(_req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx, _req(W, torch.float32, N * K, "W"), _req(b, torch.float32, N, "b"),
+                                    _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu),
+                                    _req(scratch, torch.float32, need, "scratch", optional=(need == 0)), _stream()), "a0_dense_fwd")
+
+    def dense_dgrad(self, dY, W, mask, dX, R, N, K):
+        check(self.lib.a0_dense_dgrad(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"),
+                                      _req(mask, torch.float32, R * K, "mask", optional=True), _req(dX, torch.float32, R * K, "dX"), R, N, K, _stream()), "a0_dense_dgrad")
+
+    def dense_wgrad(self, dY, X, ldx, grad, R, N, K, slabs):
+        need = self.dense_wgrad_scratch(R, N, K)
+        check(self.lib.a0_dense_wgrad(_req(dY, torch.float32, R * N, "dY"), _req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx,
+                                      _req(grad, torch.float32, N * K + N, "grad"), R, N, K,
+                                      _req(slabs, torch.float32, need, "slabs", optional=(need == 0)), _stream()), "a0_dense_wgrad")
+
+    # ------------------------------------------------------------------ heads / losses
+    def dueling_fwd(self, raw, ld, q, R, A, T, dueling):
+        check(self.lib.a0_dueling_fwd(_req(raw, torch.float32, R * ld, "raw"), ld, _req(q, torch.float32, R * A * T, "q"), R, A, T, int(dueling), _stream()), "a0_dueling_fwd")
+
+    def dueling_bwd(self, dq, draw, ld, R, A, T, dueling):
+        check(self.lib.a0_dueling_bwd(_req(dq, torch.float32, R * A * T, "dq"), _req(draw, torch.float32, R * ld, "draw"), ld, R, A, T, int(dueling), _stream()), "a0_dueling_bwd")
+
+    def select_action(self, x, sb, sa, st, B, A, T, mode, aux, a_star, qsel, qmax):
+        span = (B - 1) * sb + (A - 1) * sa + (T - 1) * st + 1
+        check(self.lib.a0_select_action(_req(x, torch.float32, span, "x"), sb, sa, st, B, A, T, mode,
+                                        _req(aux, torch.float32, T if mode == 2 else (B * (T + 1) if mode == 3 else 0), "aux", optional=mode < 2),
+                                        _req(a_star, torch.int32, B, "a_star", optional=True), _req(qsel, torch.float32, B * A, "qsel", optional=True),
+                                        _req(qmax, torch.float32, B, "qmax", optional=True), _stream()), "a0_select_action")
+
+    def loss_dqn(self, q, q_next, A, act, a_star, rew, done, wgt, gamma_n, B, loss, dq, state):
+        check(self.lib.a0_loss_dqn(_req(q, torch.float32, B * A, "q"), _req(q_next, torch.float32, B * A, "q_next"), A, _req(act, torch.int32, B, "act"),
+                                   _req(a_star, torch.int32, B, "a_star"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                   _req(wgt, torch.float32, B, "wgt"), gamma_n, B, _req(loss, torch.float32, B, "loss"), _req(dq, torch.float32, B * A, "dq"),
+                                   _req(state, torch.int32, 8, "state"), _stream()), "a0_loss_dqn")
+
+    def loss_c51(self, logits, tgt_logits, A, T, act, a_star, rew, done, wgt, atoms, gamma_n, vmin, vmax, B, loss, dlogits, m_out, state):
+        check(self.lib.a0_loss_c51(_req(logits, torch.float32, B * A * T, "logits"), _req(tgt_logits, torch.float32, B * A * T, "tgt_logits"), A, T,
+                                   _req(act, torch.int32, B, "act"), _req(a_star, torch.int32, B, "a_star"), _req(rew, torch.float32, B, "rew"),
+                                   _req(done, torch.float32, B, "done"), _req(wgt, torch.float32, B, "wgt"), _req(atoms, torch.float32, T, "atoms"),
+                                   gamma_n, vmin, vmax, B, _req(loss, torch.float32, B, "loss"), _req(dlogits, torch.float32, B * A * T, "dlogits"),
+                                   _req(m_out, torch.float32, B * T, "m_out", optional=True), _req(state, torch.int32, 8, "state"), _stream()), "a0_loss_c51")
+
+    def quantile_target(self, q_next, sb, sj, sa, a_star, rew, done, gamma_n, B, Nd, y):
+        check(self.lib.a0_quantile_target(_req(q_next, torch.float32, (B - 1) * sb + (Nd - 1) * sj + 1, "q_next"), sb, sj, sa, _req(a_star, torch.int32, B, "a_star"),
+                                          _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"), gamma_n, B, Nd,
+                                          _req(y, torch.float32, B * Nd, "y"), _stream()), "a0_quantile_target")
+
+    def loss_quantile_huber(self, q, sb, si, sa, y, taus, tb, act, wgt, B, N, Nd, loss, dq, state):
+        span = (B - 1) * sb + (N - 1) * si + 1
+        check(self.lib.a0_loss_quantile_huber(_req(q, torch.float32, span, "q"), sb, si, sa, _req(y, torch.float32, B * Nd, "y"),
+                                              _req(taus, torch.float32, (B - 1) * tb + N, "taus"), tb, _req(act, torch.int32, B, "act"),
+                                              _req(wgt, torch.float32, B, "wgt"), B, N, Nd, _req(loss, torch.float32, B, "loss"),
+                                              _req(dq, torch.float32, span, "dq"), _req(state, torch.int32, 8, "state"), _stream()), "a0_loss_quantile_huber")
+
+    # ------------------------------------------------------------------ IQN / FQF
+    def cos_features(self, taus, out, R, D):
+        check(self.lib.a0_cos_features(_req(taus, torch.float32, R, "taus"), _req(out, torch.float32, R * D, "out"), R, D, _stream()), "a0_cos_features")
+
+    def hadamard_fwd(self, emb, feat, x, B, n, D):
+        check(self.lib.a0_hadamard_fwd(_req(emb, torch.float32, B * n * D, "emb"), _req(feat, torch.float32, B * D, "feat"), _req(x, torch.float32, B * n * D, "x"), B, n, D, _stream()), "a0_hadamard_fwd")
+
+    def hadamard_bwd(self, dx, emb, feat, demb, d3, B, n, D):
+        check(self.lib.a0_hadamard_bwd(_req(dx, torch.float32, B * n * D, "dx"), _req(emb, torch.float32, B * n * D, "emb"), _req(feat, torch.float32, B * D, "feat"),
+                                       _req(demb, torch.float32, B * n * D, "demb"), _req(d3, torch.float32, B * D, "d3"), B, n, D, _stream()), "a0_hadamard_bwd")
+
+    def fqf_taus(self, logits, ld, taus, tau_hat, B, F):
+        check(self.lib.a0_fqf_taus(_req(logits, torch.float32, B * ld, "logits"), ld, _req(taus, torch.float32, B * (F + 1), "taus"),
+                                   _req(tau_hat, torch.float32, B * F, "tau_hat"), B, F, _stream()), "a0_fqf_taus")
+
+    def fqf_inner_taus(self, taus, out, B, F):
+        check(self.lib.a0_fqf_inner_taus(_req(taus, torch.float32, B * (F + 1), "taus"), _req(out, torch.float32, B * (F - 1), "out"), B, F, _stream()), "a0_fqf_inner_taus")
+
+    def fqf_fraction_loss(self, q, qh, taus, act, wgt, B, F, A, ldl, loss, dlogits, logits):
+        check(self.lib.a0_fqf_fraction_loss(_req(q, torch.float32, B * (F - 1) * A, "q"), _req(qh, torch.float32, B * F * A, "qh"), _req(taus, torch.float32, B * (F + 1), "taus"),
+                                            _req(act, torch.int32, B, "act"), _req(wgt, torch.float32, B, "wgt"), B, F, A, ldl, _req(loss, torch.float32, B, "loss"),
+                                            _req(dlogits, torch.float32, B * ldl, "dlogits"), _req(logits, torch.float32, B * ldl, "logits"), _stream()), "a0_fqf_fraction_loss")
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq):
+        check(self.lib.a0_adam_step(_req(params, torch.float32, n, "params"), _req(grads, torch.float32, n, "grads"), _req(m, torch.float32, n, "m"),
+                                    _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
+                                    lr, b1, b2, eps, target_freq, _stream()), "a0_adam_step")
+
+    def rmsprop_step(self, params, grads, sq, n, lr, alpha, eps, max_grad_norm, clip_scratch):
+        check(self.lib.a0_rmsprop_step(_req(params, torch.float32, n, "params"), _req(grads, torch.float32, n, "grads"), _req(sq, torch.float32, n, "sq"), n,
+                                       lr, alpha, eps, max_grad_norm, _req(clip_scratch, torch.float32, 1, "clip_scratch", optional=True), _stream()), "a0_rmsprop_step")
+
+    def target_sync(self, target, online, n, state, force):
+        check(self.lib.a0_target_sync(_req(target, torch.float32, n, "target"), _req(online, torch.float32, n, "online"), n,
+                                      _req(state, torch.int32, 8, "state", optional=bool(force)), int(force), _stream()), "a0_target_sync")
+
+    def noisy_compose(self, mu, sigma, eff, N, K, r0, r1, noise_in, noise_out_w, noise_out_b):
+        check(self.lib.a0_noisy_compose(_req(mu, torch.float32, N * K + N, "mu"), _req(sigma, torch.float32, N * K + N, "sigma"), _req(eff, torch.float32, N * K + N, "eff"),
+                                        N, K, r0, r1, _req(noise_in, torch.float32, K, "noise_in"), _req(noise_out_w, torch.float32, r1 - r0, "noise_out_w"),
+                                        _req(noise_out_b, torch.float32, r1 - r0, "noise_out_b"), _stream()), "a0_noisy_compose")
+
+    def noisy_grad_sigma(self, gmu, gsigma, N, K, r0, r1, noise_in, noise_out_w, noise_out_b):
+        check(self.lib.a0_noisy_grad_sigma(_req(gmu, torch.float32, N * K + N, "gmu"), _req(gsigma, torch.float32, N * K + N, "gsigma"), N, K, r0, r1,
+                                           _req(noise_in, torch.float32, K, "noise_in"), _req(noise_out_w, torch.float32, r1 - r0, "noise_out_w"),
+                                           _req(noise_out_b, torch.float32, r1 - r0, "noise_out_b"), _stream()), "a0_noisy_grad_sigma")
+
+    # ------------------------------------------------------------------ replay
+    def replay_insert(self, frames, cap, obs_bytes, start_slot, n, obs, obs_next, act, rew, done, r_act, r_rew, r_done):
+        check(self.lib.a0_replay_insert(_req(frames, torch.uint8, cap * 2 * obs_bytes, "frames"), cap, obs_bytes, start_slot, n,
+                                        _req(obs, torch.uint8, n * obs_bytes, "obs"), _req(obs_next, torch.uint8, n * obs_bytes, "obs_next"),
+                                        _req(act, torch.int32, n, "act"), _req(rew, torch.float32, n, "rew"), _req(done, torch.float32, n, "done"),
+                                        _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
+                                        _stream()), "a0_replay_insert")
+
+    def replay_lookup(self, idx, B, top, head, cap, slot, r_act, r_rew, r_done, priority, act, rew, done, prio, idx_out):
+        check(self.lib.a0_replay_lookup(_req(idx, torch.int64, B, "idx"), B, top, head, cap, _req(slot, torch.int32, B, "slot"),
+                                        _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
+                                        _req(priority, torch.float32, top, "priority", optional=True), _req(act, torch.int32, B, "act"),
+                                        _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"), _req(prio, torch.float32, B, "prio", optional=True),
+                                        _req(idx_out, torch.int64, B, "idx_out", optional=True), _stream()), "a0_replay_lookup")
+
+    def replay_gather(self, frames, row_bytes, slot, B, out, rows_available):
+        check(self.lib.a0_replay_gather(_req(frames, torch.uint8, rows_available * row_bytes, "frames"), row_bytes, _req(slot, torch.int32, B, "slot"), B,
+                                        _req(out, torch.uint8, B * row_bytes, "out"), _stream()), "a0_replay_gather")
+
+    def fill_f32(self, p, n, v):
+        check(self.lib.a0_fill_f32(_req(p, torch.float32, n, "p"), n, v, _stream()), "a0_fill_f32")
+
+    def priority_update(self, priority, ids, loss, B, eps, alpha, pstate, state):
+        check(self.lib.a0_priority_update(_req(priority, torch.float32, 1, "priority"), _req(ids, torch.int64, B, "ids"), _req(loss, torch.float32, B, "loss"), B,
+                                          eps, alpha, _req(pstate, torch.float32, 1, "pstate"), _req(state, torch.int32, 8, "state", optional=True), _stream()), "a0_priority_update")
+
+    def priority_tail(self, priority, size, n, pstate, alpha):
+        check(self.lib.a0_priority_tail(_req(priority, torch.float32, size, "priority"), size, n, _req(pstate, torch.float32, 1, "pstate"), alpha, _stream()), "a0_priority_tail")
+
+    def sum_f32(self, x, n, scratch256, out):
+        check(self.lib.a0_sum_f32(_req(x, torch.float32, n, "x"), n, _req(scratch256, torch.float32, 256, "scratch256"), _req(out, torch.float32, 1, "out"), _stream()), "a0_sum_f32")
+
+    def is_weights(self, prio, B, psum, top, beta, w):
+        check(self.lib.a0_is_weights(_req(prio, torch.float32, B, "prio"), B, _req(psum, torch.float32, 1, "psum"), top, beta, _req(w, torch.float32, B, "w"), _stream()), "a0_is_weights")
+
+    def perm_batch(self, start, count, n, seed, out):
+        check(self.lib.a0_perm_batch(start, count, n, seed & 0xFFFFFFFF, _req(out, torch.int64, count, "out"), _stream()), "a0_perm_batch")
+
+    def sumtree_set(self, tree, cap2, idx, val, n):
+        check(self.lib.a0_sumtree_set(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(val, torch.float32, n, "val"), n, _stream()), "a0_sumtree_set")
+
+    def sumtree_rebuild(self, tree, cap2):
+        check(self.lib.a0_sumtree_rebuild(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _stream()), "a0_sumtree_rebuild")
+
+    def sumtree_sample(self, tree, cap2, xi, B, out_idx, out_p):
+        check(self.lib.a0_sumtree_sample(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(xi, torch.float32, B, "xi"), B,
+                                         _req(out_idx, torch.int64, B, "out_idx"), _req(out_p, torch.float32, B, "out_p"), _stream()), "a0_sumtree_sample")
+
+    def priority_from_loss(self, loss, n, eps, alpha, val, pstate):
+        check(self.lib.a0_priority_from_loss(_req(loss, torch.float32, n, "loss"), n, eps, alpha, _req(val, torch.float32, n, "val"), _req(pstate, torch.float32, 1, "pstate"), _stream()), "a0_priority_from_loss")
+
+    # ------------------------------------------------------------------ actor / rng / env
+    def actor_egreedy(self, greedy, rand_action, u, eps, E, action, qmax, qs_out):
+        check(self.lib.a0_actor_egreedy(_req(greedy, torch.int32, E, "greedy"), _req(rand_action, torch.int32, E, "rand_action"), _req(u, torch.float32, E, "u"), eps, E,
+                                        _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax", optional=True),
+                                        _req(qs_out, torch.float32, 1, "qs_out", optional=True), _stream()), "a0_actor_egreedy")
+
+    def actor_nstep(self, E, n, steps, gamma, action, reward, terminal, truncated, life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done):
+        check(self.lib.a0_actor_nstep(E, n, steps, gamma, _req(action, torch.int32, E, "action"), _req(reward, torch.float32, E, "reward"),
+                                      _req(terminal, torch.float32, E, "terminal"), _req(truncated, torch.float32, E, "truncated"),
+                                      _req(life_loss, torch.float32, E, "life_loss", optional=True), _req(ring_act, torch.int32, n * E, "ring_act"),
+                                      _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
+                                      _req(out_act, torch.int32, E, "out_act"), _req(out_rew, torch.float32, E, "out_rew"), _req(out_done, torch.float32, E, "out_done"),
+                                      _stream()), "a0_actor_nstep")
+
+    def rng_uniform(self, seed, stream_id, offset, out, n):
+        check(self.lib.a0_rng_uniform(seed, stream_id, offset, _req(out, torch.float32, n, "out"), n, _stream()), "a0_rng_uniform")
+
+    def rng_u32(self, seed, stream_id, offset, out, n):
+        check(self.lib.a0_rng_u32(seed, stream_id, offset, _req(out, torch.int32, n, "out"), n, _stream()), "a0_rng_u32")
+
+    def rng_randint(self, seed, stream_id, offset, hi, out, n):
+        check(self.lib.a0_rng_randint(seed, stream_id, offset, hi, _req(out, torch.int32, n, "out"), n, _stream()), "a0_rng_randint")
+
+    def rng_normal(self, seed, stream_id, offset, std, out, n):
+        check(self.lib.a0_rng_normal(seed, stream_id, offset, std, _req(out, torch.float32, n, "out"), n, _stream()), "a0_rng_normal")
+
+    def env_reset(self, seed, rank, E, obs, ep_ret):
+        check(self.lib.a0_env_synth_reset(seed, rank, E, _req(obs, torch.uint8, E * 4 * 84 * 84, "obs"), _req(ep_ret, torch.float32, E, "ep_ret"), _stream()), "a0_env_synth_reset")
+
+    def env_step(self, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal, truncated, life_loss, final_mask, final_ret):
+        n = E * 4 * 84 * 84
+        check(self.lib.a0_env_synth_step(seed, rank, E, g, _req(obs_in, torch.uint8, n, "obs_in"), _req(obs_out, torch.uint8, n, "obs_out"),
+                                         _req(ep_ret, torch.float32, E, "ep_ret"), _req(reward, torch.float32, E, "reward"), _req(terminal, torch.float32, E, "terminal"),
+                                         _req(truncated, torch.float32, E, "truncated"), _req(life_loss, torch.float32, E, "life_loss"),
+                                         _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), _stream()), "a0_env_synth_step")
+
+    def device_info(self):
+        cu = C.c_int()
+        mem = C.c_longlong()
+        name = C.create_string_buffer(64)
+        check(self.lib.a0_device_info(C.addressof(cu), C.addressof(mem), C.addressof(name)), "a0_device_info")
+        return cu.value, mem.value, name.value.decode()

@@ -1,0 +1,162 @@
+/* agent0_hip.h — C-ABI of libagent0_hip.so: the MI355X (gfx950) hot path of agent0's deepq actor-learner loop.
+ *
+ * The reference (zhoubin-me/agent0) is pure Python and defines no FFI; each entry point below names the reference
+ * code it replaces (paths relative to the reference repo).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.  Conventions:
+ *   - every function returns int: 0 = A0_OK, < 0 = error (A0_E*), message via a0_last_error() (thread-local);
+ *   - all pointers are DEVICE pointers unless a parameter is named host_*; buffers are owned by the caller and
+ *     only borrowed for the duration of the call (the library keeps no reference, a0_net tables excepted);
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous w.r.t. the host, never synchronise,
+ *     never allocate (except a0_net_create) and are safe to capture into a hipGraph;
+ *   - fp32 everywhere the reference is fp32; u8 frames; int32 actions/slots; int64 replay indices.
+ */
+#ifndef AGENT0_HIP_H
+#define AGENT0_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A0_ABI_VERSION 1
+
+const char* a0_last_error(void);
+int a0_abi_version(void);
+int a0_device_info(int* cu_count, long long* hbm_bytes, char* arch_name64);
+
+/* ---------------------------------------------------------------- network geometry (agent0/deepq/model.py:90-105) */
+typedef struct a0_net_desc {
+    int C, H, W;          /* observation shape, cfg.obs_shape (agent0/deepq/main.py:31) */
+} a0_net_desc;
+
+typedef struct a0_net a0_net;
+
+/* where a batch of u8 observations lives: frames[(slot ? slot[b] : b) * sample_stride + chan_off + c*H*W + y*W + x] */
+typedef struct a0_frames_arg {
+    const uint8_t* frames;
+    const int* slot;            /* optional gather indices (replay sample), NULL = dense batch */
+    long long sample_stride;    /* bytes between samples: 8*H*W for replay rows, 4*H*W for actor observations */
+    int chan_off;               /* 0 = st, 4*H*W = st_next half of a replay row (agent0/deepq/agent.py:132-135) */
+} a0_frames_arg;
+
+/* packed conv weights: w1 [32][C*8*8] in (c,kh,kw) order, w2 [64][4*4*32] and w3 [64][3*3*64] in (kh,kw,c) order */
+typedef struct a0_encoder_weights {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+} a0_encoder_weights;
+
+int a0_net_create(const a0_net_desc* desc, a0_net** out);
+int a0_net_destroy(a0_net* net);
+int a0_net_geometry(const a0_net* net, int* out8);  /* H1,W1,H2,W2,H3,W3,feat_dim,K1 */
+
+/* ConvEncoder.forward (model.py:104-105) with the uint8->fp32 /255 of agent.py:27 / agent.py:129-134 fused into conv1.
+ * Outputs are NHWC: act1 [B][H1][W1][32], act2 [B][H2][W2][64], act3 [B][H3][W3][64] (= features in (h,w,c) order). */
+int a0_net_encoder_fwd(const a0_net* net, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
+                       float* act1, float* act2, float* act3, void* stream);
+
+/* autograd backward of the encoder (agent.py:153-155).  d3 = dL/d(conv3 pre-activation), already ReLU-masked.
+ * g1,g2,g3 receive [dW | db] of each conv in the packed layout.  slabs: a0_net_encoder_bwd_scratch() floats. */
+long long a0_net_encoder_bwd_scratch(const a0_net* net, int B);
+int a0_net_encoder_bwd(const a0_net* net, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
+                       const float* act1, const float* act2, const float* d3, float* d2, float* d1,
+                       float* g1, float* g2, float* g3, float* slabs, void* stream);
+
+/* nn.Linear / NoisyLinear forward+backward (model.py:54-62,112-114): Y = act(X W^T + b), W [N][K] row-major.
+ * N, K, ldx multiples of 4.  scratch sizes from the *_scratch functions (0 => may pass NULL). */
+long long a0_dense_fwd_scratch(int R, int N, int K);
+int a0_dense_fwd(const float* X, int ldx, const float* W, const float* b, float* Y, int R, int N, int K, int relu,
+                 float* scratch, void* stream);
+int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K, void* stream);
+long long a0_dense_wgrad_scratch(int R, int N, int K);
+int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
+
+/* ---------------------------------------------------------------- heads and losses */
+/* dueling combine (model.py:127-130,168-172,228-231): raw [R][ld] = [A*T advantages | T values | pad] -> q [R][A][T] */
+int a0_dueling_fwd(const float* raw, int ld, float* q, int R, int A, int T, int dueling, void* stream);
+int a0_dueling_bwd(const float* dq, float* draw, int ld, int R, int A, int T, int dueling, void* stream);
+
+/* head.qval + argmax (model.py:133,176-177,190-192,253-257,280-284; agent.py:32,177-180,224-227,277-280).
+ * x(b,a,t) = x[b*sb + a*sa + t*st]; mode 0 identity, 1 mean over t, 2 C51 expectation (aux = atoms[T]),
+ * 3 FQF sum (tau[t+1]-tau[t]) x (aux = taus [B][T+1]).  Outputs optional. */
+int a0_select_action(const float* x, long long sb, long long sa, long long st, int B, int A, int T, int mode,
+                     const float* aux, int* a_star, float* qsel, float* qmax, void* stream);
+
+/* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
+int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
+                const float* done, const float* wgt, float gamma_n, int B, float* loss, float* dq, int* nan_flag, void* stream);
+/* C51Learner.train_step (agent.py:219-269): logits / tgt_logits [B][A][T]; m_out (optional) = projected target [B][T] */
+int a0_loss_c51(const float* logits, const float* tgt_logits, int A, int T, const int* act, const int* a_star,
+                const float* rew, const float* done, const float* wgt, const float* atoms, float gamma_n,
+                float vmin, float vmax, int B, float* loss, float* dlogits, float* m_out, int* nan_flag, void* stream);
+/* quantile target r + gamma^n (1-d) q_next[a*] (agent.py:281-286,313-318,358-364) and BaseLearner.huber_qr_loss
+ * (agent.py:110-114) with its gradient; strides let QR ([B][A][N]) and IQN/FQF ([B][N][A]) share the kernels. */
+int a0_quantile_target(const float* q_next, long long sb, long long sj, long long sa, const int* a_star, const float* rew,
+                       const float* done, float gamma_n, int B, int Nd, float* y, void* stream);
+int a0_loss_quantile_huber(const float* q, long long sb, long long si, long long sa, const float* y, const float* taus,
+                           long long tb, const int* act, const float* wgt, int B, int N, int Nd, float* loss, float* dq,
+                           int* nan_flag, void* stream);
+
+/* IQN / FQF head pieces (model.py:235-251, 268-278; agent.py:371-387) */
+int a0_cos_features(const float* taus, float* out, long long R, int D, void* stream);
+int a0_hadamard_fwd(const float* emb, const float* feat, float* x, int B, int n, int D, void* stream);
+int a0_hadamard_bwd(const float* dx, const float* emb, const float* feat, float* demb, float* d3, int B, int n, int D, void* stream);
+int a0_fqf_taus(const float* logits, int ld, float* taus, float* tau_hat, int B, int F, void* stream);
+int a0_fqf_inner_taus(const float* taus, float* out, int B, int F, void* stream);
+int a0_fqf_fraction_loss(const float* q, const float* qh, const float* taus, const int* act, const float* wgt, int B, int F, int A,
+                         int ldl, float* loss, float* dlogits, const float* logits, void* stream);
+
+/* ---------------------------------------------------------------- optimizer / target sync (agent.py:102-106,152-161,333-338) */
+/* state: int[8] device block: [0] nan flag (set by losses) [1] update_steps [2] skipped [3] skip_now [4] sync_now */
+int a0_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state,
+                 float* scalars2, double lr, double beta1, double beta2, double eps, int target_update_freq, void* stream);
+int a0_rmsprop_step(float* params, const float* grads, float* square_avg, long long n, double lr, double alpha, double eps,
+                    double max_grad_norm, float* clip_scratch, void* stream);
+int a0_target_sync(float* target, const float* online, long long n, const int* state, int force, void* stream);
+/* NoisyLinear.reset_noise / forward weight composition and its gradient fan-out (model.py:54-62,73-87) */
+int a0_noisy_compose(const float* mu, const float* sigma, float* eff, int N, int K, int r0, int r1, const float* noise_in,
+                     const float* noise_out_w, const float* noise_out_b, void* stream);
+int a0_noisy_grad_sigma(const float* gmu, float* gsigma, int N, int K, int r0, int r1, const float* noise_in,
+                        const float* noise_out_w, const float* noise_out_b, void* stream);
+
+/* ---------------------------------------------------------------- replay (agent0/deepq/replay.py:14-59, trainer.py:63-72,91-96) */
+int a0_replay_insert(uint8_t* frames, long long cap, int obs_bytes, long long start_slot, int n, const uint8_t* obs,
+                     const uint8_t* obs_next, const int* act, const float* rew, const float* done, int* r_act,
+                     float* r_rew, float* r_done, void* stream);
+int a0_replay_lookup(const long long* idx, int B, long long top, long long head, long long cap, int* slot, const int* r_act,
+                     const float* r_rew, const float* r_done, const float* priority, int* act, float* rew, float* done,
+                     float* prio, long long* idx_out, void* stream);
+int a0_replay_gather(const uint8_t* frames, int row_bytes, const int* slot, int B, uint8_t* out, void* stream);
+int a0_fill_f32(float* p, long long n, float v, void* stream);
+int a0_priority_update(float* priority, const long long* ids, const float* loss, int B, float eps, float alpha,
+                       float* pstate, const int* state, void* stream);
+int a0_priority_tail(float* priority, long long size, long long n, const float* pstate, float alpha, void* stream);
+int a0_sum_f32(const float* x, long long n, float* scratch256, float* out, void* stream);
+int a0_is_weights(const float* prio, int B, const float* psum, long long top, float beta, float* w, void* stream);
+int a0_perm_batch(unsigned long long start, int count, unsigned long long n, unsigned int seed, long long* out, void* stream);
+/* sum-tree (new component, contract in oracle/sumtree.c): tree float[2*cap2] */
+int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, void* stream);
+int a0_sumtree_rebuild(float* tree, long long cap2, void* stream);
+int a0_sumtree_sample(const float* tree, long long cap2, const float* xi, int B, long long* out_idx, float* out_p, void* stream);
+int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, void* stream);
+
+/* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */
+int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action,
+                     const float* qmax, float* qs_out, void* stream);
+int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* action, const float* reward, const float* terminal,
+                   const float* truncated, const float* life_loss, int* ring_act, float* ring_rew, float* ring_done,
+                   int* out_act, float* out_rew, float* out_done, void* stream);
+
+/* ---------------------------------------------------------------- device RNG + synthetic env (no reference counterpart) */
+int a0_rng_u32(unsigned long long seed, unsigned int stream_id, unsigned long long offset, unsigned int* out, long long n, void* stream);
+int a0_rng_uniform(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float* out, long long n, void* stream);
+int a0_rng_randint(unsigned long long seed, unsigned int stream_id, unsigned long long offset, int hi, int* out, long long n, void* stream);
+int a0_rng_normal(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float stdv, float* out, long long n, void* stream);
+int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream);
+int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
+                      float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
+                      float* final_ret, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGENT0_HIP_H */

@@ -1,0 +1,226 @@
+"""CPU: agent0_amd.deepq.engine (the product's layer composition) driven by the emulation backend, against the oracle.
+
+What this covers without a GPU: the packed parameter layout and its round trip to the reference state_dict, the
+gather tables / phase decomposition / split-K and slab logic of the shared C++ orchestration (net_impl.h via
+tests/host_emul.cpp), forward/backward wiring of every head (dueling, NoisyNet, IQN, FQF), loss-gradient formulas,
+Adam / RMSprop / NaN-skip / target-sync sequencing.  The MFMA tile code itself is only reachable on the GPU.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from recipe import NetSpec, SPECS
+from agent0_amd.deepq.engine import DeviceLearner, DeviceNet, Workspace
+from agent0_amd.deepq.layout import NetLayout
+from cpu_ops import CpuOps
+from oracle import learner as olearner, nets
+from oracle.losses import Hyper
+from util import assert_close, assert_mostly_close
+
+TINY = (4, 36, 36)
+CASES = {
+    "dqn": NetSpec("dqn", 4, obs_shape=TINY),
+    "dqn_duel": NetSpec("dqn", 5, dueling=True, obs_shape=TINY),
+    "c51": NetSpec("c51", 3, num_atoms=51, obs_shape=TINY),
+    "c51_duel_noisy": NetSpec("c51", 6, dueling=True, noisy=True, obs_shape=TINY),
+    "qr": NetSpec("qr", 3, num_atoms=200, obs_shape=TINY),
+    "qr_duel_noisy": NetSpec("qr", 2, dueling=True, noisy=True, num_atoms=200, obs_shape=TINY),
+    "iqn": NetSpec("iqn", 9, obs_shape=TINY),
+    "iqn_duel": NetSpec("iqn", 3, dueling=True, obs_shape=TINY),
+    "fqf": NetSpec("fqf", 4, obs_shape=TINY),
+    "dqn_noisy": NetSpec("dqn", 4, noisy=True, obs_shape=TINY),
+    "dqn_odd": NetSpec("dqn", 4, obs_shape=(4, 44, 52)),   # non-square, odd conv1 output (10x12 -> 4x5 -> 2x3)
+}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return CpuOps()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_layout_roundtrip(name):
+    spec = CASES[name]
+    L = NetLayout.from_spec(spec)
+    sd = {k: torch.from_numpy(v) for k, v in recipe.make_state_dict(spec, 5).items()}
+    flat = torch.zeros(L.n_params_padded)
+    L.pack(sd, flat)
+    back = L.unpack(flat)
+    train = [k for k in sd if not recipe.is_buffer(k)]
+    assert set(back) == set(train)
+    for k in train:
+        assert back[k].shape == sd[k].shape and torch.equal(back[k], sd[k]), k
+    # every float of the flat buffer is either a mapped parameter or zero padding
+    assert int((flat != 0).sum()) == sum(int((sd[k] != 0).sum()) for k in train)
+
+
+def noise_draws(spec, seed):
+    g = recipe.gen(seed)
+    L = NetLayout.from_spec(spec)
+    out = []
+    for prefix, block, r0, r1, in_f in L.noise_modules:
+        out += [(g.standard_normal(in_f) * 0.1).astype(np.float32), (g.standard_normal(r1 - r0) * 0.1).astype(np.float32),
+                (g.standard_normal(r1 - r0) * 0.1).astype(np.float32)]
+    return out
+
+
+def install_noise(net: DeviceNet, draws):
+    it = iter(draws)
+    for prefix, *_ in net.L.noise_modules:
+        net.set_noise(prefix, next(it), next(it), next(it))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_oracle(ops, name):
+    spec = CASES[name]
+    L = NetLayout.from_spec(spec)
+    B = 5
+    sd = recipe.make_state_dict(spec, 11)
+    p = olearner.to_params(sd)
+    net = DeviceNet(ops, L, ops.net(*spec.obs_shape))
+    net.load_state_dict(sd)
+    if spec.noisy:
+        dr = noise_draws(spec, 3)
+        install_noise(net, dr)
+        net.compose_noise()
+        it = iter(dr)
+        for prefix in nets.dense_prefixes(spec):
+            for leaf in ("noise_in", "noise_out_weight", "noise_out_bias"):
+                p[f"{prefix}.{leaf}"] = torch.from_numpy(next(it))
+            nets.compose_noise(p, prefix)
+    frames = torch.from_numpy(recipe.make_frames(B, 21, spec.obs_shape))
+    obs_bytes = int(np.prod(spec.obs_shape))
+    n_tau = 7 if L.quantile else 1
+    ws = Workspace(ops, L, B, n_tau if spec.algo != "fqf" else L.F)
+    net.encode(ws, frames.reshape(-1), None, 2 * obs_bytes, obs_bytes, B)      # st_next half
+    x = nets.normalize(frames[:, spec.obs_shape[0]:])
+    with torch.no_grad():
+        feat, (a1, a2, a3) = nets.encoder(p, x, return_all=True)
+    assert_close(ws.act1.view(B, L.H1, L.W1, 32).permute(0, 3, 1, 2), a1, 1e-5, 1e-6, "conv1")
+    assert_close(ws.act2.view(B, L.H2, L.W2, 64).permute(0, 3, 1, 2), a2, 1e-5, 1e-6, "conv2")
+    assert_close(ws.act3.view(B, L.H3, L.W3, 64).permute(0, 3, 1, 2), a3, 1e-5, 1e-6, "conv3")
+    a_star = torch.zeros(B, dtype=torch.int32)
+    qsel = torch.zeros(B * L.A)
+    with torch.no_grad():
+        if spec.algo == "iqn":
+            taus = torch.from_numpy(recipe.gen(9).random((B, n_tau, 1), dtype=np.float32))
+            q = net.head(ws, B, taus.reshape(-1).contiguous(), n_tau)
+            assert_close(q[: B * n_tau * L.A].view(B, n_tau, L.A), nets.head_iqn(p, spec, feat, taus), 2e-5, 2e-6, "iqn q")
+            net.select(ws, B, n_tau, a_star, qsel)
+            want = nets.head_iqn(p, spec, feat, taus).mean(1)
+        elif spec.algo == "fqf":
+            net.fqf_taus(ws, B)
+            t, th, _ = nets.fqf_prop_taus(p, spec, feat)
+            assert_close(ws.tau_all.view(B, L.F + 1), t[:, :, 0], 1e-5, 1e-6, "taus")
+            assert_close(ws.tau_hat.view(B, L.F), th[:, :, 0], 1e-5, 1e-6, "tau_hat")
+            q = net.head(ws, B, ws.tau_hat, L.F)
+            # cos(pi*64*tau) amplifies the 1e-7 differences of the two tau computations ~200x: compare at the SAME taus tightly
+            q2 = net.head(ws, B, th.reshape(-1).contiguous(), L.F).clone()
+            assert_close(q2[: B * L.F * L.A].view(B, L.F, L.A), nets.head_iqn(p, spec, feat, th), 2e-5, 2e-6, "fqf q_hat @ oracle taus")
+            q = net.head(ws, B, ws.tau_hat, L.F)
+            assert_close(q[: B * L.F * L.A].view(B, L.F, L.A), nets.head_iqn(p, spec, feat, th), 5e-4, 5e-5, "fqf q_hat")
+            net.select(ws, B, L.F, a_star, qsel)
+            want = nets.qval_from_feat(p, spec, feat)
+        else:
+            q = net.head(ws, B)
+            assert_close(q[: B * L.A * L.T].view(B, L.A, L.T).squeeze(-1) if L.T == 1 else q[: B * L.A * L.T].view(B, L.A, L.T),
+                         nets.forward(p, spec, x), 2e-5, 2e-6, "head out")
+            atoms = nets.c51_atoms(spec) if spec.algo == "c51" else None
+            net.select(ws, B, 1, a_star, qsel, atoms=atoms)
+            want = nets.qval(p, spec, x)
+    assert_close(qsel.view(B, L.A), want, *((5e-4, 5e-5) if spec.algo == "fqf" else (2e-5, 2e-6)), "qval")
+    assert torch.equal(a_star.long(), want.argmax(-1))
+
+
+def run_both(ops, name, B, double_q, n_step, steps=2, target_freq=2, resync=True):
+    spec = CASES[name]
+    L = NetLayout.from_spec(spec)
+    hp = Hyper(double_q=double_q, n_step=n_step, K=6, N=8, N_dash=5)
+    sd_o, sd_t = recipe.make_state_dict(spec, 11), recipe.make_state_dict(spec, 12)
+    ora = olearner.OracleLearner(spec, sd_o, sd_t, hp, batch_size=B, target_update_freq=target_freq)
+    dev = DeviceLearner(ops, L, B, n_step=n_step, double_q=double_q, target_update_freq=target_freq, K=hp.K, N=hp.N, N_dash=hp.N_dash)
+    dev.online.load_state_dict(sd_o)
+    dev.target.load_state_dict(sd_t)
+    obs_bytes = int(np.prod(spec.obs_shape))
+    results = []
+    for s in range(steps):
+        frames = recipe.make_frames(B, 61 + s, spec.obs_shape)
+        a, r, d, w = recipe.make_transitions(B, spec.action_dim, 62 + s)
+        rand_np = None
+        if spec.algo == "iqn":
+            g = recipe.gen(70 + s)
+            rand_np = [g.random((B, n, 1), dtype=np.float32) for n in (hp.K, hp.N_dash, hp.N)]
+        no = nt = None
+        if spec.noisy:
+            no, nt = noise_draws(spec, 80 + s), noise_draws(spec, 90 + s)
+            install_noise(dev.online, no)
+            install_noise(dev.target, nt)
+        res_o = ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B), rand=rand_np, noise_online=no, noise_target=nt)
+        out = dev.update(torch.from_numpy(frames).reshape(-1), None, 2 * obs_bytes, torch.from_numpy(a.astype(np.int32)), torch.from_numpy(r),
+                         torch.from_numpy(d.astype(np.float32)), torch.from_numpy(w),
+                         rand=None if rand_np is None else [torch.from_numpy(x.reshape(-1).copy()) for x in rand_np])
+        out = tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()      # device buffers are reused by the next update
+        got_p, got_t = dev.online.state_dict(), dev.target.state_dict()
+        results.append((res_o, out, {k: v.clone() for k, v in ora.last_grads.items()}, dev.grads.clone(), got_p, got_t,
+                        {k: v.detach().clone() for k, v in ora.po.items()}, {k: v.detach().clone() for k, v in ora.pt.items()}))
+        if resync:   # remove accumulated ulp-level drift so that every step is compared from identical parameters
+            dev.online.L.pack({k: v.detach() for k, v in ora.po.items()}, dev.online.flat)
+            dev.target.L.pack({k: v.detach() for k, v in ora.pt.items()}, dev.target.flat)
+    return spec, L, ora, dev, results
+
+
+TRAIN = [("dqn", 8, False, 1), ("dqn_duel", 8, True, 3), ("c51", 8, False, 1), ("c51_duel_noisy", 8, True, 3), ("qr", 6, False, 1),
+         ("qr_duel_noisy", 6, True, 1), ("iqn", 6, False, 1), ("iqn_duel", 6, True, 3), ("fqf", 6, False, 1), ("fqf", 6, True, 3),
+         ("dqn_noisy", 8, True, 1), ("dqn_odd", 8, True, 1)]
+
+
+@pytest.mark.parametrize("name,B,dq,n", TRAIN)
+def test_update_matches_oracle(ops, name, B, dq, n):
+    spec, L, ora, dev, results = run_both(ops, name, B, dq, n)
+    for s, (res_o, out, g_o, g_d, got, tgt, want_p, want_t) in enumerate(results):
+        loss_d, frac_d = (out if isinstance(out, tuple) else (out, None))
+        assert_close(loss_d[:B], res_o["q_loss"], *((1e-3, 1e-4) if spec.algo == "fqf" else (5e-5, 5e-6)), f"step {s} q_loss")
+        if frac_d is not None:
+            assert_close(frac_d[:B], res_o["fraction_loss"], 1e-3, 1e-4, f"step {s} fraction_loss")
+        # gradients, tensor by tensor, in the reference layout
+        g_ref = L.unpack(g_d)
+        for k, g in g_o.items():
+            if g is None:
+                continue
+            scale = float(g.abs().max()) + 1e-12
+            # FQF: q(tau) goes through cos(pi*64*tau), which amplifies the ulp-level differences of the two softmax/cumsum
+            # evaluations ~200x; its gradients are compared with a correspondingly wider (still tight) tolerance
+            if spec.algo == "fqf":
+                assert_mostly_close(g_ref[k] / scale, g / scale, 3e-2, 0.05, 0.15, f"step {s} grad {k}")
+            else:
+                assert_close(g_ref[k] / scale, g / scale, 0, 3e-5, f"step {s} grad {k}")
+        # parameters after this step's optimizer update (Adam normalises the step size: compare absolutely)
+        for src, ref, tag in ((got, want_p, "param"), (tgt, want_t, "target param")):
+            for k in nets.trainable_keys(ref):
+                if spec.algo == "fqf":
+                    assert_mostly_close(src[k], ref[k], 2e-5, 0.05, 1e-3, f"step {s} {tag} {k}")
+                else:
+                    assert_close(src[k], ref[k], 0, 2e-5, f"step {s} {tag} {k}")
+    assert int(dev.state[1]) == ora.update_steps == 2
+
+
+def test_nan_loss_skips_the_step(ops):
+    spec = CASES["dqn"]
+    L = NetLayout.from_spec(spec)
+    B = 4
+    dev = DeviceLearner(ops, L, B, target_update_freq=500)
+    sd = recipe.make_state_dict(spec, 11)
+    dev.online.load_state_dict(sd)
+    dev.target.load_state_dict(sd)
+    before = dev.online.flat.clone()
+    frames = torch.from_numpy(recipe.make_frames(B, 1, spec.obs_shape)).reshape(-1)
+    a, r, d, w = recipe.make_transitions(B, 4, 2)
+    r = r.copy(); r[1] = np.nan
+    dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), torch.from_numpy(a.astype(np.int32)), torch.from_numpy(r), torch.from_numpy(d.astype(np.float32)), torch.from_numpy(w))
+    assert torch.equal(before, dev.online.flat)            # parameters untouched (agent.py:152-158)
+    assert int(dev.state[1]) == 0 and int(dev.state[2]) == 1 and int(dev.state[0]) == 0
+    # quirk: update_steps % freq == 0 still triggers the target copy after a skipped step (agent.py:160-161)
+    assert torch.equal(dev.target.flat, dev.online.flat)

@@ -26,3 +26,20 @@ def assert_close(got, want, rtol, atol, what=""):
     if bad.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: {bad.sum()}/{bad.size} outside tol (rtol={rtol}, atol={atol}); worst at {i}: got {got[i]!r} want {want[i]!r}")
+
+
+def assert_mostly_close(got, want, atol, max_bad_frac, max_rel_l2, what=""):
+    """Robust comparison for chaotic paths (FQF: q(tau) runs through cos(pi*64*tau), so ulp-level differences in tau can
+    flip an isolated ReLU and change a handful of elements by O(1)): bounds the FRACTION of elements outside ``atol``
+    and the relative L2 error instead of the worst element."""
+    def _np(x):
+        if hasattr(x, "detach"):
+            x = x.detach().cpu().numpy()
+        return np.asarray(x, dtype=np.float64)
+
+    got, want = _np(got), _np(want)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    bad = np.abs(got - want) > atol
+    frac = bad.mean() if bad.size else 0.0
+    rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)
+    assert frac <= max_bad_frac and rel <= max_rel_l2, f"{what}: {bad.sum()}/{bad.size} elements outside {atol} (allowed {max_bad_frac:.3%}), rel-L2 {rel:.3e} (allowed {max_rel_l2})"
