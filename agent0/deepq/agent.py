@@ -1,0 +1,8 @@
+"""Alias of agent0_amd.deepq.agent (same public names as the reference's agent0/deepq/agent.py)."""
+from agent0_amd.deepq.agent import *  # noqa: F401,F403
+from agent0_amd.deepq import agent as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})
+
+if __name__ == "__main__" and hasattr(_impl, "main"):
+    _impl.main()

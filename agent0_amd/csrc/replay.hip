@@ -99,7 +99,9 @@ extern "C" int a0_fill_f32(float* p, long long n, float v, void* stream) {
     return a0_fail_hip((int)hipGetLastError(), "a0_fill_f32");
 }
 
-A0_D float a0_prio_pow(float x, float alpha) { return (alpha == 0.5f) ? sqrtf(x) : powf(x, alpha); }   // torch lowers pow(0.5) to sqrt
+// torch lowers pow(x, 0.5) to a correctly rounded sqrt; fp64 sqrt rounded to fp32 is correctly rounded too (53 >= 2*24 + 2),
+// whatever the device's v_sqrt_f32 does
+A0_D float a0_prio_pow(float x, float alpha) { return (alpha == 0.5f) ? (float)sqrt((double)x) : powf(x, alpha); }
 
 // priority[ids] = (loss + eps)^alpha in batch order (a later duplicate wins); max_p[0] = max(max_p, max loss)
 // pstate: [0] max_p (float).  Single workgroup so that the duplicate rule is deterministic.

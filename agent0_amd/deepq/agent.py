@@ -1,0 +1,223 @@
+"""``Actor`` and the six ``<Algo>Learner`` classes with the reference's names and call signatures, running on the device.
+
+Mirrors /root/reference agent0/deepq/agent.py: ``Actor`` (16-93: ``act``, ``reset``, ``sample``, ``close``),
+``BaseLearner`` (96-169: Adam(lr, eps=1e-2/B), ``train`` -> {"q_loss","fraction_loss","indices"}), and
+``DQNLearner`` / ``MDQNLearner`` / ``C51Learner`` / ``QRLearner`` / ``IQNLearner`` / ``FQFLearner`` (172-388), which
+``Trainer`` resolves by name (trainer.py:31-34).  Differences that follow from keeping everything in HBM:
+  * ``Actor.sample`` returns a ``TransitionBlock`` (slots already written into the replay ring) instead of a Python
+    list of lz4 blobs; episode returns and per-step mean max-Q come back as Python lists after ONE device->host copy;
+  * ``Learner.train`` accepts the reference's 6-tuple of tensors, or — on the hot path — ``train_batch`` takes ring
+    slots and never touches the host; losses are returned as device tensors (the reference's ``.cpu()`` copies and its
+    ``isnan().any()`` sync are gone, quirk Q14; the NaN-skip itself is kept, on the device).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from agent0_amd.common.atari_wrappers import make_atari
+from agent0_amd.common.utils import DeviceRng
+from .config import AlgoEnum, ExpConfig
+from .engine import DeviceLearner, Workspace
+from .model import DeepQNet, layout_from_cfg
+from .replay import ReplayDataset, TransitionBlock
+
+
+def _ops_from(cfg, ops=None):
+    if cfg.device.value != "cuda":
+        raise RuntimeError("agent0_amd runs on MI355X only: set device=cuda (no CPU fallback; see oracle/ for the CPU restatement used in tests)")
+    if ops is None:
+        from agent0_amd.ops import HipOps
+        ops = HipOps()
+    return ops
+
+
+class Actor:
+    def __init__(self, cfg: ExpConfig, model: Optional[DeepQNet] = None, replay: Optional[ReplayDataset] = None, ops=None, rank: int = 0, envs=None):
+        self.cfg = cfg
+        self.ops = ops = model.ops if model is not None else _ops_from(cfg, ops)
+        self.rng = DeviceRng(ops, cfg.seed, rank)
+        self.envs = envs if envs is not None else make_atari(cfg.env_id, cfg.actor.num_envs, seed=cfg.seed, rank=rank, ops=ops)
+        self.obs, _ = self.envs.reset()
+        self.model = model if model is not None else DeepQNet(cfg, ops=ops)
+        self.replay = replay
+        self.L = self.model.L
+        E = self.E = int(cfg.actor.num_envs)
+        self.n = int(cfg.learner.n_step_q)
+        self.steps = 0
+        self.obs_bytes = self.L.C * self.L.H * self.L.W
+        n_tau = self.L.F if self.L.algo == "fqf" else (cfg.learner.iqn.K if self.L.algo == "iqn" else 1)
+        self.n_tau = n_tau
+        self.ws = Workspace(ops, self.L, E, n_tau)
+        self.taus = ops.empty(E * n_tau) if self.L.algo == "iqn" else None
+        self.greedy, self.rand_a, self.action = ops.zeros(E, dtype=torch.int32), ops.zeros(E, dtype=torch.int32), ops.zeros(E, dtype=torch.int32)
+        self.u, self.qmax = ops.zeros(E), ops.zeros(E)
+        T = max(int(cfg.actor.sample_steps), int(cfg.actor.test_steps) if False else int(cfg.actor.sample_steps))
+        self.qs = ops.zeros(T)
+        self.stat_mask, self.stat_ret = ops.zeros(T * E), ops.zeros(T * E)
+        self.ring_act, self.ring_rew, self.ring_done = ops.zeros(self.n * E, dtype=torch.int32), ops.zeros(self.n * E), ops.zeros(self.n * E)
+        self.ring_obs = ops.zeros(self.n * E * self.obs_bytes, dtype=torch.uint8) if self.n > 1 else None
+        self.out_act, self.out_rew, self.out_done = ops.zeros(E, dtype=torch.int32), ops.zeros(E), ops.zeros(E)
+        self.atoms = self.model.head.atoms.reshape(-1).contiguous() if self.L.algo == "c51" else None
+        self._stage = None
+
+    # ------------------------------------------------------------------ agent.py:25-39
+    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor]):
+        L, ops, E, dev = self.L, self.ops, self.E, self.model._dev
+        dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E)
+        if L.algo == "fqf":
+            dev.fqf_taus(self.ws, E)
+            dev.head(self.ws, E, self.ws.tau_hat, L.F)
+        elif L.algo == "iqn":
+            self.rng.uniform(self.rng.STREAM_TAUS, self.taus, E * self.n_tau)
+            dev.head(self.ws, E, self.taus, self.n_tau)
+        else:
+            dev.head(self.ws, E)
+        dev.select(self.ws, E, self.n_tau, self.greedy, qmax=self.qmax, atoms=self.atoms)
+        self.rng.randint(self.rng.STREAM_EGREEDY_A, L.A, self.rand_a, E)       # draw order as the reference: randint, then rand
+        self.rng.uniform(self.rng.STREAM_EGREEDY_U, self.u, E)
+        ops.actor_egreedy(self.greedy, self.rand_a, self.u, float(epsilon), E, self.action, self.qmax, qs_slot)
+
+    def act(self, epsilon):
+        one = self.ops.zeros(1)
+        self._act_device(epsilon, one)
+        return self.action.cpu().numpy().astype(np.int64), float(one[0])
+
+    def reset(self):
+        self.obs, _ = self.envs.reset()
+
+    # ------------------------------------------------------------------ agent.py:44-90
+    def sample(self, epsilon, state_dict=None, test: bool = False):
+        cfg, ops, E = self.cfg, self.ops, self.E
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        T = int(cfg.actor.sample_steps)
+        bound = self.replay is not None and not test
+        if not bound and not test:
+            st = self._stage
+            if st is None or st["obs"].shape[0] != T * E:
+                st = self._stage = {"obs": ops.zeros(T * E, self.obs_bytes, dtype=torch.uint8), "obs_next": ops.zeros(T * E, self.obs_bytes, dtype=torch.uint8),
+                                    "act": ops.zeros(T * E, dtype=torch.int32), "rew": ops.zeros(T * E), "done": ops.zeros(T * E)}
+        start = self.replay.write_cursor() if bound else 0
+        frames_out = []
+        for t in range(T):
+            if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
+                self.model.reset_noise()
+            self._act_device(epsilon, self.qs[t:t + 1])
+            cur_obs = self.obs
+            if self.n > 1:
+                slot = self.steps % self.n
+                self.ring_obs[slot * E * self.obs_bytes:(slot + 1) * E * self.obs_bytes].copy_(cur_obs)
+            obs_next, reward, terminal, truncated, info = self.envs.step(self.action)
+            ops.actor_nstep(E, self.n, self.steps, float(cfg.learner.discount), self.action, reward, terminal, truncated, info.get("life_loss"),
+                            self.ring_act, self.ring_rew, self.ring_done, self.out_act, self.out_rew, self.out_done)
+            self.stat_mask[t * E:(t + 1) * E].copy_(info["final_mask"])
+            self.stat_ret[t * E:(t + 1) * E].copy_(info["final_ret"])
+            if self.n > 1:
+                count = min(self.steps + 1, self.n)
+                oldest = (self.steps - (count - 1)) % self.n
+                obs0 = self.ring_obs[oldest * E * self.obs_bytes:(oldest + 1) * E * self.obs_bytes]
+            else:
+                obs0 = cur_obs
+            self.steps += 1
+            if test:
+                frames_out.append(obs_next.view(E, self.L.C, self.L.H, self.L.W)[:4, -1:].cpu().numpy())
+            elif bound:
+                rp = self.replay
+                ops.replay_insert(rp.frames, rp.size, self.obs_bytes, (start + t * E) % rp.size, E, obs0, obs_next, self.out_act, self.out_rew, self.out_done,
+                                  rp.act, rp.rew, rp.done)
+            else:
+                sl = slice(t * E, (t + 1) * E)
+                st["obs"][sl].copy_(obs0.view(E, -1)); st["obs_next"][sl].copy_(obs_next.view(E, -1))
+                st["act"][sl].copy_(self.out_act); st["rew"][sl].copy_(self.out_rew); st["done"][sl].copy_(self.out_done)
+            self.obs = obs_next
+        # one device->host copy per rollout: mean max-Q per step and finished-episode returns, in the reference's order
+        qs = self.qs[:T].cpu().tolist()
+        mask = self.stat_mask[:T * E].cpu().numpy() != 0
+        rs = self.stat_ret[:T * E].cpu().numpy()[mask].tolist()
+        if test:
+            return frames_out, rs, qs
+        data = TransitionBlock(T * E, start=start) if bound else TransitionBlock(T * E, staged=st)
+        return data, rs, qs
+
+    def close(self):
+        self.envs.close()
+
+
+class BaseLearner:
+    def __init__(self, cfg: ExpConfig, ops=None):
+        self.cfg = cfg
+        self.ops = ops = _ops_from(cfg, ops)
+        lc = cfg.learner
+        L = layout_from_cfg(cfg)
+        if lc.algo == AlgoEnum.mdqn:
+            raise NotImplementedError("MDQNLearner: Munchausen-DQN is outside the dqn/c51/qr/iqn/fqf hot path of this build (SURVEY.md R11)")
+        self.engine = DeviceLearner(ops, L, int(lc.batch_size), discount=lc.discount, n_step=lc.n_step_q, double_q=lc.double_q, lr=lc.learning_rate,
+                                    target_update_freq=lc.target_update_freq, vmin=lc.c51.vmin, vmax=lc.c51.vmax, K=lc.iqn.K, N=lc.iqn.N, N_dash=lc.iqn.N_dash,
+                                    max_grad_norm=lc.max_grad_norm)
+        self.rng = DeviceRng(ops, cfg.seed + 15485863)
+        self.model = DeepQNet(cfg, ops=ops, dev_net=self.engine.online, rng=self.rng)
+        self.model_target = DeepQNet(cfg, ops=ops, dev_net=self.engine.target, rng=self.rng)
+        self.engine.sync_target(force=True)                 # model_target = deepcopy(model), agent.py:100
+        self.batch_indices = torch.arange(lc.batch_size, device=ops.device)
+        self.optimizer = self.engine                        # Adam state lives in the engine's flat buffers
+        B = int(lc.batch_size)
+        self._taus = [ops.empty(B * n) for n in (lc.iqn.K, lc.iqn.N_dash, lc.iqn.N)] if L.algo == "iqn" else None
+        self._ones = torch.ones(B, device=ops.device)
+
+    @property
+    def update_steps(self) -> int:
+        return int(self.engine.state[1])
+
+    # ------------------------------------------------------------------ hot path: batch addressed by ring slots
+    def train_batch(self, frames: torch.Tensor, slot: Optional[torch.Tensor], row_bytes: int, act, rew, done, weights):
+        cfg = self.cfg
+        if cfg.learner.noisy_net:
+            self.model.reset_noise()
+            self.model_target.reset_noise()
+        rand = None
+        if self._taus is not None:
+            for t in self._taus:
+                self.rng.uniform(self.rng.STREAM_TAUS, t, t.numel())
+            rand = self._taus
+        out = self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+        return out if isinstance(out, tuple) else (out, None)
+
+    # ------------------------------------------------------------------ reference signature (agent.py:124-169)
+    def train(self, data):
+        frames, actions, rewards, terminals, weights, indices = data
+        dev = self.ops.device
+        B = frames.shape[0]
+        u8 = frames.to(dev)
+        u8 = (u8 if u8.dtype == torch.uint8 else u8.round().clamp_(0, 255).to(torch.uint8)).reshape(-1).contiguous()
+        q_loss, f_loss = self.train_batch(u8, None, u8.numel() // B, actions.to(dev).to(torch.int32).contiguous(), rewards.to(dev).float().contiguous(),
+                                          terminals.to(dev).float().contiguous(), weights.to(dev).float().contiguous())
+        skipped = bool(self.engine.state[3])
+        return {"q_loss": None if skipped else q_loss[:B].clone(), "fraction_loss": None if f_loss is None else f_loss[:B].clone(),
+                "indices": indices.long()}
+
+
+class DQNLearner(BaseLearner):
+    pass
+
+
+class MDQNLearner(BaseLearner):
+    pass
+
+
+class C51Learner(BaseLearner):
+    pass
+
+
+class QRLearner(BaseLearner):
+    pass
+
+
+class IQNLearner(BaseLearner):
+    pass
+
+
+class FQFLearner(BaseLearner):
+    pass

@@ -239,6 +239,7 @@ class DeviceLearner:
                      ops.dense_wgrad_scratch(B, L.Fpad, L.feat) if L.algo == "fqf" else 0, 4)
         self.slabs = ops.empty(n_slab)
         self.obs_bytes = L.C * L.H * L.W
+        self.grad_hook = None       # data parallelism: callable(grads, state) run between backward and the optimizer (dist.GradAllReduce)
 
     # ------------------------------------------------------------------ helpers
     def sync_target(self, force=True):
@@ -361,6 +362,8 @@ class DeviceLearner:
         else:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
         self._backward_trunk(wo, frames, slot, sample_stride, B)
+        if self.grad_hook is not None:
+            self.grad_hook(self.grads, self.state)
         ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
         self.sync_target(force=False)
         return (self.loss, frac) if frac is not None else self.loss

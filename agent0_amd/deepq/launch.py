@@ -1,0 +1,61 @@
+"""``python -m agent0.deepq.launch [key=value ...]`` — multi-process entry point.
+
+The reference (agent0/deepq/launch.py:25-205) starts ``num_actors`` Launchpad CourierNodes plus one TrainerNode that
+ships the whole state_dict to an actor on every sample RPC and receives pickled lz4 transitions back (launch.py:30-97).
+dm-launchpad is not available (its wheel is a missing blob in the reference checkout) and that transport is the
+bottleneck this build removes: here one process per GPU runs actor + replay shard + learner on its own device and the
+replicas exchange only gradients (agent0_amd/deepq/dist.py).  ``num_actors`` maps to the number of ranks, capped by the
+GPUs present.  When started without a torch.distributed environment this module re-launches itself under
+``torch.distributed.run`` — as a CHILD process and before anything touches the GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+from .dist import GradAllReduce, env_world, init_process_group
+
+
+class TrainerNode:
+    """One data-parallel replica: reference TrainerNode + its ActorNodes collapsed onto one GPU."""
+
+    def __init__(self, cfg, rank: int, world: int):
+        from .trainer import Trainer
+
+        cfg.seed = cfg.seed + 1000003 * rank          # per-rank env / replay / exploration streams
+        self.trainer = Trainer(cfg, rank=rank)
+        eng = self.trainer.learner.engine
+        if world > 1:
+            eng.grad_hook = GradAllReduce(eng.L.n_adam)
+            eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)       # SUM-reduced gradients == one step on the global batch
+            # identical initial replicas: broadcast rank 0's parameters
+            import torch.distributed as dist
+            dist.broadcast(eng.online.flat, src=0)
+            eng.sync_target(force=True)
+
+    def run(self):
+        self.trainer.run()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if "WORLD_SIZE" not in os.environ:
+        import torch
+        from .config import parse_overrides
+
+        n_gpu = torch.cuda.device_count()             # does not initialise the GPU
+        world = max(1, min(parse_overrides(argv).num_actors, n_gpu))
+        if world > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                   "--master-port", os.environ.get("MASTER_PORT", "29511"), "-m", "agent0_amd.deepq.launch", *argv]
+            raise SystemExit(subprocess.call(cmd))
+    from .main import build_config
+
+    rank, local_rank, world = init_process_group()
+    cfg = build_config(argv)
+    TrainerNode(cfg, rank, world).run()
+
+
+if __name__ == "__main__":
+    main()

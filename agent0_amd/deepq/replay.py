@@ -1,0 +1,197 @@
+"""``ReplayDataset``: the reference's replay API over an HBM-resident ring buffer.
+
+Mirrors /root/reference agent0/deepq/replay.py:14-59 — ``extend``, ``__getitem__``, ``__len__``, ``update_priority`` and
+the attributes ``priority``, ``top``, ``beta``, ``max_p`` — but transitions never leave the GPU: frames are stored
+uncompressed as the actor packs them (st || st_next, agent.py:78-81; 56 448 B each at 84x84, so the default 1 M-entry
+buffer is 56.4 GB of the MI355X's 288 GB), and batches are produced by index kernels instead of a DataLoader
+(trainer.py:63-72).
+
+Sampling modes (``sample``):
+  uniform                     the reference's RandomSampler semantics — a fresh pseudo-random permutation of range(top)
+                              per epoch, batches of B, last batch never returned (utils.py:51-56) — as a Feistel bijection
+  prioritize, sumtree=False   reference-faithful: uniform sampling, priorities only feed importance weights, new
+                              priorities are written to the TAIL of the vector, sum over the whole capacity (Q1,Q2,Q7)
+  prioritize, sumtree=True    proportional stratified sampling from the fp32 sum-tree (contract: oracle/sumtree.c),
+                              importance weights (top * p/total)^-beta / max
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from agent0_amd.common.utils import DeviceRng, LinearSchedule
+from .config import ExpConfig, ReplayEnum
+
+
+@dataclass
+class TransitionBlock:
+    """What ``Actor.sample`` hands to ``ReplayDataset.extend``: transitions already written into ring slots
+    [start, start+count) by the actor (zero-copy), or staged in ``staged`` buffers when the actor has no replay bound."""
+    count: int
+    start: int = -1
+    staged: Optional[dict] = None
+
+    def __len__(self):
+        return self.count
+
+
+@dataclass
+class Batch:
+    idx: torch.Tensor        # int64 [B] logical indices (what update_priority takes)
+    slot: torch.Tensor       # int32 [B] ring slots
+    act: torch.Tensor
+    rew: torch.Tensor
+    done: torch.Tensor
+    prio: torch.Tensor
+    weights: torch.Tensor
+
+
+class ReplayDataset:
+    def __init__(self, cfg: ExpConfig, ops=None, rng: Optional[DeviceRng] = None):
+        if ops is None:
+            from agent0_amd.ops import HipOps
+            ops = HipOps()
+        self.cfg, self.ops = cfg, ops
+        self.size = int(cfg.replay.size)
+        C, H, W = (int(v) for v in cfg.obs_shape)
+        self.obs_bytes = C * H * W
+        self.row_bytes = 2 * self.obs_bytes
+        if self.obs_bytes % 16:
+            raise ValueError("observation byte size must be a multiple of 16")
+        self.frames = torch.empty(self.size * self.row_bytes, dtype=torch.uint8, device=ops.device)
+        self.act = ops.zeros(self.size, dtype=torch.int32)
+        self.rew = ops.zeros(self.size)
+        self.done = ops.zeros(self.size)
+        self.priority = torch.ones(self.size, device=ops.device)
+        self.top = 0
+        self.written = 0                      # transitions ever written (ring cursor = written % size)
+        self.prioritize = cfg.replay.policy == ReplayEnum.prioritize
+        self.use_sumtree = self.prioritize and bool(cfg.replay.sumtree)
+        self.rng = rng or DeviceRng(ops, cfg.seed + 104729)
+        B = int(cfg.learner.batch_size)
+        self.B = B
+        self._idx = ops.zeros(B, dtype=torch.int64)
+        self._slot = ops.zeros(B, dtype=torch.int32)
+        self._act, self._rew, self._done = ops.zeros(B, dtype=torch.int32), ops.zeros(B), ops.zeros(B)
+        self._prio, self._w = ops.zeros(B), torch.ones(B, device=ops.device)
+        self._idx_out = ops.zeros(B, dtype=torch.int64)
+        self._xi = ops.zeros(B)
+        self._psum, self._scratch = ops.zeros(1), ops.zeros(256)
+        self._pstate = torch.ones(1, device=ops.device)        # max_p on the device
+        self._epoch = None
+        if self.prioritize:
+            self.beta_schedule = LinearSchedule(cfg.replay.beta0, 1.0, cfg.trainer.total_steps)
+            self.beta = cfg.replay.beta0
+        if self.use_sumtree:
+            self.cap2 = 1
+            while self.cap2 < self.size:
+                self.cap2 <<= 1
+            self.tree = ops.zeros(2 * self.cap2)
+            self._new_idx = None
+            self._val = ops.zeros(max(B, 1))
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def max_p(self) -> float:
+        return float(self._pstate[0])
+
+    def __len__(self):
+        return self.top
+
+    @property
+    def head(self) -> int:
+        return self.written % self.size if self.written > self.size else 0
+
+    def write_cursor(self) -> int:
+        return self.written % self.size
+
+    # ------------------------------------------------------------------ insert
+    def extend(self, transitions):
+        """replay.py:45-53.  ``transitions`` is a TransitionBlock produced by the device Actor."""
+        if not isinstance(transitions, TransitionBlock):
+            raise TypeError("ReplayDataset.extend takes the TransitionBlock returned by Actor.sample (transitions stay on the device)")
+        n = transitions.count
+        if transitions.staged is not None:
+            s = transitions.staged
+            done_rows = 0
+            while done_rows < n:                      # staged blocks may be larger than the ring
+                k = min(n - done_rows, self.size)
+                sl = slice(done_rows, done_rows + k)
+                self.ops.replay_insert(self.frames, self.size, self.obs_bytes, self.write_cursor(), k, s["obs"][sl].reshape(-1), s["obs_next"][sl].reshape(-1),
+                                       s["act"][sl].contiguous(), s["rew"][sl].contiguous(), s["done"][sl].contiguous(), self.act, self.rew, self.done)
+                self.written += k
+                done_rows += k
+        else:
+            assert transitions.start == self.write_cursor(), "actor wrote to a stale ring position"
+            self.written += n
+        self.top = min(self.top + n, self.size)
+        if self.prioritize:
+            if self.use_sumtree:
+                start = (self.written - n) % self.size
+                idx = (torch.arange(n, device=self.ops.device, dtype=torch.int64) + start) % self.size
+                val = (self._pstate[0].double() ** self.cfg.replay.alpha).float().expand(n).contiguous()
+                for o in range(0, n, 1024):           # the set kernel handles up to one workgroup's worth per call
+                    k = min(1024, n - o)
+                    self.ops.sumtree_set(self.tree, self.cap2, idx[o:o + k].contiguous(), val[o:o + k].contiguous(), k)
+            else:
+                self.ops.priority_tail(self.priority, self.size, min(n, self.size), self._pstate, float(self.cfg.replay.alpha))
+            self.beta = self.beta_schedule(n)
+
+    # ------------------------------------------------------------------ host-side item access (API parity, slow path)
+    def __getitem__(self, idx: int):
+        idx = idx % self.top
+        slot = (self.head + idx) % self.size
+        row = self.frames[slot * self.row_bytes:(slot + 1) * self.row_bytes].cpu().numpy()
+        pr = self.tree[self.cap2 + slot] if self.use_sumtree else self.priority[idx]
+        return row, int(self.act[slot]), float(self.rew[slot]), bool(self.done[slot] != 0), pr.cpu(), idx
+
+    # ------------------------------------------------------------------ priorities
+    def update_priority(self, ids: torch.Tensor, priorities: torch.Tensor, state: Optional[torch.Tensor] = None):
+        """replay.py:55-59: priority[ids] = (loss + eps)^alpha; max_p = max(max_p, max loss)."""
+        rc = self.cfg.replay
+        B = ids.numel()
+        ids = ids.to(self.ops.device, torch.int64).contiguous()
+        pr = priorities.to(self.ops.device, torch.float32).contiguous()
+        if self.use_sumtree:
+            self.ops.priority_from_loss(pr, B, float(rc.eps), float(rc.alpha), self._val, self._pstate)
+            self.ops.sumtree_set(self.tree, self.cap2, ids, self._val, B)
+        else:
+            self.ops.priority_update(self.priority, ids, pr, B, float(rc.eps), float(rc.alpha), self._pstate, state)
+
+    # ------------------------------------------------------------------ sampling
+    def _next_uniform(self, B: int):
+        """DataLoader(shuffle=True) + DataPrefetcher semantics (trainer.py:63-72, utils.py:31-56)."""
+        ep = self._epoch
+        if ep is None or ep["pos"] + 1 >= ep["nb"]:
+            top = self.top
+            ep = {"top": top, "nb": (top + B - 1) // B, "pos": 0, "seed": self.rng.next_seed32(self.rng.STREAM_PERM)}
+            if ep["nb"] < 2:
+                raise RuntimeError("replay holds fewer than two batches: the reference's fetcher cannot return one either")
+            self._epoch = ep
+        start = ep["pos"] * B
+        ep["pos"] += 1
+        self.ops.perm_batch(start, B, ep["top"], ep["seed"], self._idx)
+
+    def sample(self, B: Optional[int] = None) -> Batch:
+        B = B or self.B
+        assert B == self.B
+        if self.use_sumtree:
+            self.rng.uniform(self.rng.STREAM_SUMTREE, self._xi, B)
+            self.ops.sumtree_sample(self.tree, self.cap2, self._xi, B, self._idx, self._prio)
+            # sum-tree leaves are addressed by ring slot: logical index == slot, no deque shift (head = 0)
+            self.ops.replay_lookup(self._idx, B, self.size, 0, self.size, self._slot, self.act, self.rew, self.done, None,
+                                   self._act, self._rew, self._done, None, self._idx_out)
+            self.ops.is_weights(self._prio, B, self.tree[1:2], self.top, float(self.beta), self._w)
+            idx = self._idx
+        else:
+            self._next_uniform(B)
+            self.ops.replay_lookup(self._idx, B, self.top, self.head, self.size, self._slot, self.act, self.rew, self.done,
+                                   self.priority if self.prioritize else None, self._act, self._rew, self._done, self._prio, self._idx_out)
+            if self.prioritize:
+                self.ops.sum_f32(self.priority, self.size, self._scratch, self._psum)
+                self.ops.is_weights(self._prio, B, self._psum, self.top, float(self.beta), self._w)
+            idx = self._idx_out
+        return Batch(idx, self._slot, self._act, self._rew, self._done, self._prio, self._w)

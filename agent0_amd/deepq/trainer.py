@@ -1,0 +1,182 @@
+"""``Trainer``: the reference's orchestration loop, unchanged in shape, with every tensor resident in HBM.
+
+Mirrors /root/reference agent0/deepq/trainer.py:19-189 — ``Trainer(cfg, use_lp=False)`` with ``run``, ``step``,
+``test``, ``logging``, ``final``, the epsilon schedule (46-50, eps(0) = 1 + min_eps as in the reference) and the result
+keys (111-118): frames, fraction_loss, loss, return_train, return_train_max, qmax, fps.
+Per iteration: ``actors[1].sample(eps)`` rolls ``sample_steps`` env steps and writes the transitions straight into the
+replay ring; ``step`` commits them and runs ``learner_steps`` updates (sample -> importance weights -> train ->
+priority update), all enqueued on one HIP stream with a single device->host read at the end for the loss means.
+wandb / tensorboard are used only if importable and enabled (neither ships in this image).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import agent as agents
+from .config import ExpConfig, ReplayEnum, to_dict
+from .replay import ReplayDataset
+from agent0_amd.common.atari_wrappers import make_atari
+from agent0_amd.common.utils import set_random_seed
+
+
+def epsilon_schedule(cfg: ExpConfig):
+    def fn(step):
+        if step > cfg.trainer.exploration_steps:
+            return cfg.actor.min_eps
+        return (1.0 - step / cfg.trainer.exploration_steps) + cfg.actor.min_eps
+    return fn
+
+
+class Trainer:
+    def __init__(self, cfg: ExpConfig, use_lp: bool = False, ops=None, rank: int = 0):
+        self.cfg, self.use_lp, self.rank = cfg, use_lp, rank
+        set_random_seed(cfg.seed)
+        if cfg.device.value != "cuda":
+            raise RuntimeError("agent0_amd runs on MI355X only: set device=cuda (no CPU fallback)")
+        if ops is None:
+            from agent0_amd.ops import HipOps
+            ops = HipOps()
+        self.ops = ops
+        dummy_env = make_atari(cfg.env_id, 1, ops=ops)
+        self.obs_shape = tuple(dummy_env.observation_space.shape[1:])
+        self.act_dim = int(dummy_env.action_space[0].n)
+        dummy_env.close()
+        if not cfg.obs_shape or len(tuple(cfg.obs_shape)) != 3:
+            cfg.obs_shape = self.obs_shape
+        if not cfg.action_dim:
+            cfg.action_dim = self.act_dim
+        try:
+            learner_cls = getattr(agents, f"{cfg.learner.algo.name.upper()}Learner")
+        except AttributeError:
+            raise NotImplementedError(f"No such learner for {cfg.learner.algo.name}")
+        self.learner = learner_cls(cfg, ops=ops)
+        self.replay = ReplayDataset(cfg, ops=ops)
+        if not use_lp:
+            # the reference builds a test actor [0] and a train actor [1] sharing the learner's model (trainer.py:41-44)
+            self.actors = [None, agents.Actor(cfg, self.learner.model, replay=self.replay, ops=ops, rank=rank)]
+        self.epsilon_fn = epsilon_schedule(cfg)
+        self.writer = None
+        self._wandb = None
+        if cfg.wandb:
+            try:
+                import wandb
+                wandb.init(project=cfg.name, config=to_dict(cfg))
+                self._wandb = wandb
+            except ImportError:
+                pass
+        if cfg.tb:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.writer = SummaryWriter(cfg.logdir)
+            except ImportError:
+                pass
+        self.logger = logging.getLogger("agent0")
+        try:
+            os.makedirs(cfg.logdir, exist_ok=True)
+            self.logger.addHandler(logging.FileHandler(os.path.join(cfg.logdir, "msg.log")))
+        except OSError:
+            pass
+        self.num_transitions = cfg.actor.sample_steps * cfg.actor.num_envs
+        self.Ls, self.Rs, self.RTs, self.Qs, self.FLs = [], [], [], [], []
+        self.frame_count = 0
+        L = int(cfg.learner.learner_steps)
+        self._loss_means = ops.zeros(max(L, 1))
+        self._floss_means = ops.zeros(max(L, 1))
+
+    # ------------------------------------------------------------------ trainer.py:74-119
+    def step(self, transitions, returns, qmax):
+        cfg = self.cfg
+        self.Qs.extend(qmax)
+        self.Rs.extend(returns)
+        self.replay.extend(transitions)
+        self.frame_count += self.num_transitions
+        n_upd = 0
+        has_frac = False
+        if len(self.replay) > cfg.trainer.training_start_steps:
+            rp = self.replay
+            for i in range(cfg.learner.learner_steps):
+                b = rp.sample()
+                q_loss, f_loss = self.learner.train_batch(rp.frames, b.slot, rp.row_bytes, b.act, b.rew, b.done, b.weights)
+                if cfg.replay.policy == ReplayEnum.prioritize:
+                    rp.update_priority(b.idx, q_loss, state=self.learner.engine.state)
+                self._loss_means[i] = q_loss.mean()
+                if f_loss is not None:
+                    self._floss_means[i] = f_loss.mean()
+                    has_frac = True
+                n_upd += 1
+        if n_upd:
+            self.Ls.extend(self._loss_means[:n_upd].cpu().tolist())        # the one device->host read of the update block
+            if has_frac:
+                self.FLs.extend(self._floss_means[:n_upd].cpu().tolist())
+        return dict(
+            frames=self.frame_count,
+            fraction_loss=np.mean(self.FLs[-20:]) if len(self.FLs) > 0 else None,
+            loss=np.mean(self.Ls[-20:]) if len(self.Ls) > 0 else None,
+            return_train=np.mean(self.Rs[-20:]) if len(self.Rs) > 0 else None,
+            return_train_max=np.max(self.Rs) if len(self.Rs) > 0 else None,
+            qmax=np.mean(self.Qs[-100:]) if len(self.Qs) > 0 else None,
+        )
+
+    # ------------------------------------------------------------------ trainer.py:121-156
+    def test(self):
+        cfg = self.cfg
+        if self.actors[0] is None:
+            self.actors[0] = agents.Actor(cfg, self.learner.model, replay=None, ops=self.ops, rank=self.rank + 1000)
+        rs = []
+        self.logger.info("Testing ... ")
+        self.actors[0].reset()
+        guard = 0
+        while len(rs) < cfg.trainer.test_episodes and guard < 200:
+            _, returns, _ = self.actors[0].sample(cfg.actor.test_eps, test=True)
+            rs.extend(returns)
+            guard += 1
+        self.RTs.extend(rs)
+        if rs:
+            if self.writer is not None:
+                self.writer.add_scalar("return_test", np.mean(rs), self.frame_count)
+                self.writer.add_scalar("return_test_max", np.max(self.RTs), self.frame_count)
+            if self._wandb is not None:
+                self._wandb.log({"return_test": np.mean(rs), "frame": self.frame_count})
+                self._wandb.log({"return_test_max": np.max(self.RTs), "frame": self.frame_count})
+            self.logger.info(f"TEST ---> Frames: {self.frame_count} | Return Avg: {np.mean(rs):.2f} Max: {np.max(rs)}")
+        return rs
+
+    def logging(self, result):
+        msg = ""
+        for k, v in result.items():
+            if v is None:
+                continue
+            if self.writer is not None:
+                self.writer.add_scalar(k, v, self.frame_count)
+            if self._wandb is not None:
+                self._wandb.log({k: v, "frame": self.frame_count})
+            if k in ["frames", "loss", "qmax", "fps"] or "return" in k:
+                msg += f"{k}: {v:.2f} | "
+        self.logger.info(msg)
+
+    def run_iteration(self):
+        """One pass of the loop body of trainer.py:176-182; returns the result dict including fps."""
+        tic = time.time()
+        epsilon = self.epsilon_fn(self.frame_count)
+        transitions, returns, qmax = self.actors[1].sample(epsilon)
+        result = self.step(transitions, returns, qmax)
+        torch.cuda.synchronize()
+        result.update(fps=self.num_transitions / (time.time() - tic))
+        return result
+
+    def run(self):
+        trainer_steps = self.cfg.trainer.total_steps // self.num_transitions + 1
+        for _ in range(trainer_steps):
+            self.logging(self.run_iteration())
+        self.final()
+
+    def final(self):
+        self.test()
+        for actor in self.actors:
+            if actor is not None:
+                actor.close()

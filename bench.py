@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: learner FPS of the deepq actor->replay->learner loop (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" is one Trainer iteration exactly as the reference times it (agent0/deepq/trainer.py:176-181):
+``sample_steps`` (80) vectorized env steps on ``num_envs`` (256) envs — Q-network forward, epsilon-greedy, env step,
+n-step, replay insert — followed by ``learner_steps`` (20) updates of batch 512 drawn from a FULL 1 M-transition HBM
+replay (BASELINE.json configs[1]: Breakout dqn, 256 envs, 1 M replay, batch 512).  value = agent steps (transitions
+written to replay) per second over all ranks == the reference's "FPS" (README.md:21-30, pre-frameskip); x4 for emulator
+frames.  Inputs are synthetic (device-resident env of the right shape, random-init network); nothing is skipped inside
+the timed region (forward, loss, backward, Adam, target sync, replay insert/sample, priority bookkeeping all run).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--algo", default="dqn")
+    ap.add_argument("--num-envs", type=int, default=256)
+    ap.add_argument("--replay-size", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--learner-steps", type=int, default=20)
+    ap.add_argument("--sample-steps", type=int, default=80)
+    ap.add_argument("--env", default="Breakout")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("overrides", nargs="*", help="extra key=value config overrides")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cfg):
+    """The CPU oracle (a port of the reference's algorithm, pinned by goldens) timed on this box's host cores on a
+    bounded sample of the same workload: actor forward on a 256-env batch and full updates at B=512, combined into the
+    time one Trainer iteration would take (sample_steps x act + learner_steps x update; env / lz4 / data-loader costs
+    the reference also pays are NOT included, so this flatters the CPU)."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import recipe
+    from oracle import learner as olearner, nets
+    from oracle.losses import Hyper
+
+    spec = recipe.NetSpec(cfg.learner.algo.name, cfg.action_dim, dueling=cfg.learner.dueling_head, noisy=False,
+                          num_atoms=cfg.learner.c51.num_atoms if cfg.learner.algo.name == "c51" else cfg.learner.qr.num_atoms)
+    if spec.algo in ("iqn", "fqf") or cfg.learner.noisy_net:
+        return None
+    B, E = args.batch, args.num_envs
+    sd = recipe.make_state_dict(spec, 1)
+    ora = olearner.OracleLearner(spec, sd, sd, Hyper(double_q=cfg.learner.double_q, n_step=cfg.learner.n_step_q), batch_size=B)
+    frames = recipe.make_frames(B, 3, spec.obs_shape)
+    a, r, d, w = recipe.make_transitions(B, spec.action_dim, 4)
+    ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B))        # warm-up
+    n_upd, t0 = 0, time.time()
+    while n_upd < 3 or time.time() - t0 < 6.0:
+        ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B))
+        n_upd += 1
+    t_upd = (time.time() - t0) / n_upd
+    obs = torch.from_numpy(recipe.make_frames(E, 5, spec.obs_shape)[:, :4].copy())
+    with torch.no_grad():
+        nets.qval(ora.po, spec, nets.normalize(obs))
+        n_act, t0 = 0, time.time()
+        while n_act < 5 or time.time() - t0 < 4.0:
+            nets.qval(ora.po, spec, nets.normalize(obs)).argmax(-1)
+            n_act += 1
+    t_act = (time.time() - t0) / n_act
+    t_iter = args.sample_steps * t_act + args.learner_steps * t_upd
+    return {"value": round(args.sample_steps * E / t_iter, 1), "unit": "env-frames/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_upd} oracle updates at B={B} ({t_upd*1e3:.1f} ms each) + {n_act} oracle actor forwards at E={E} ({t_act*1e3:.2f} ms each), "
+                      f"extrapolated to one iteration of {args.sample_steps} actor steps + {args.learner_steps} updates"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    from agent0_amd.deepq.dist import GradAllReduce, env_world, init_process_group
+
+    rank, local_rank, world = init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    from agent0_amd.common.atari_wrappers import ACTION_DIMS
+
+    cfg = parse_overrides([f"env_id={args.env}", f"learner.algo={args.algo}", f"actor.num_envs={args.num_envs}", f"replay.size={args.replay_size}",
+                           f"learner.batch_size={args.batch}", f"learner.learner_steps={args.learner_steps}", f"actor.sample_steps={args.sample_steps}",
+                           "wandb=false", "tb=false", f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}", *args.overrides])
+    cfg.obs_shape = (4, 84, 84)
+    cfg.action_dim = ACTION_DIMS.get(cfg.env_id, 18)
+    cfg.seed = cfg.seed + 1000003 * rank
+    tr = Trainer(cfg, rank=rank)
+    eng = tr.learner.engine
+    if world > 1:
+        import torch.distributed as dist
+        eng.grad_hook = GradAllReduce(eng.L.n_adam)
+        eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)
+        dist.broadcast(eng.online.flat, src=0)
+        eng.sync_target(force=True)
+
+    # ---- untimed: fill the replay ring to capacity with real rollouts (no learning), then warm up full iterations
+    per_iter = cfg.actor.sample_steps * cfg.actor.num_envs
+    start_steps = cfg.trainer.training_start_steps
+    cfg.trainer.training_start_steps = 1 << 62
+    t_fill = time.time()
+    while len(tr.replay) < cfg.replay.size:
+        tr.run_iteration()
+    torch.cuda.synchronize()
+    t_fill = time.time() - t_fill
+    cfg.trainer.training_start_steps = min(start_steps, cfg.replay.size - 1)
+    for _ in range(args.warmup):
+        tr.run_iteration()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.time()
+    last = None
+    for _ in range(args.steps):
+        last = tr.run_iteration()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank != 0:
+        return
+    value = world * per_iter * args.steps / dt
+    upd_per_s = world * cfg.learner.learner_steps * args.steps / dt
+    cu, hbm, arch = tr.ops.device_info()
+    out = {
+        "metric": "env-frames/sec (learner FPS: transitions collected and saved to replay per second with the learner running, pre-frameskip)",
+        "value": round(value, 1), "unit": "env-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{cfg.env_id} {cfg.learner.algo.name}, {cfg.actor.num_envs} vectorized envs x {cfg.actor.sample_steps} steps + "
+                               f"{cfg.learner.learner_steps} updates of batch {cfg.learner.batch_size} per iteration, {cfg.replay.size}-transition HBM replay "
+                               f"(full), obs 4x84x84 u8, per-rank shards, RCCL grad all-reduce" + ("" if world > 1 else " (inactive at 1 GPU)"),
+                   "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
+                   "replay_size": cfg.replay.size, "parallelism": f"dp{world}"},
+        "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
+        "device": arch, "replay_fill_s": round(t_fill, 2), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),
+    }
+    probe = getattr(tr.ops, "probe_report", None)
+    out["roofline"] = probe() if probe else None
+    out["cpu_baseline"] = None if (args.no_cpu_baseline) else cpu_baseline(args, cfg)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -73,8 +73,7 @@ def install_noise(net: DeviceNet, draws):
         net.set_noise(prefix, next(it), next(it), next(it))
 
 
-@pytest.mark.parametrize("name", list(CASES))
-def test_forward_matches_oracle(ops, name):
+def check_forward(ops, name):
     spec = CASES[name]
     L = NetLayout.from_spec(spec)
     B = 5
@@ -95,19 +94,19 @@ def test_forward_matches_oracle(ops, name):
     obs_bytes = int(np.prod(spec.obs_shape))
     n_tau = 7 if L.quantile else 1
     ws = Workspace(ops, L, B, n_tau if spec.algo != "fqf" else L.F)
-    net.encode(ws, frames.reshape(-1), None, 2 * obs_bytes, obs_bytes, B)      # st_next half
+    net.encode(ws, frames.reshape(-1).to(ops.device), None, 2 * obs_bytes, obs_bytes, B)      # st_next half
     x = nets.normalize(frames[:, spec.obs_shape[0]:])
     with torch.no_grad():
         feat, (a1, a2, a3) = nets.encoder(p, x, return_all=True)
     assert_close(ws.act1.view(B, L.H1, L.W1, 32).permute(0, 3, 1, 2), a1, 1e-5, 1e-6, "conv1")
     assert_close(ws.act2.view(B, L.H2, L.W2, 64).permute(0, 3, 1, 2), a2, 1e-5, 1e-6, "conv2")
     assert_close(ws.act3.view(B, L.H3, L.W3, 64).permute(0, 3, 1, 2), a3, 1e-5, 1e-6, "conv3")
-    a_star = torch.zeros(B, dtype=torch.int32)
-    qsel = torch.zeros(B * L.A)
+    a_star = ops.zeros(B, dtype=torch.int32)
+    qsel = ops.zeros(B * L.A)
     with torch.no_grad():
         if spec.algo == "iqn":
             taus = torch.from_numpy(recipe.gen(9).random((B, n_tau, 1), dtype=np.float32))
-            q = net.head(ws, B, taus.reshape(-1).contiguous(), n_tau)
+            q = net.head(ws, B, taus.reshape(-1).contiguous().to(ops.device), n_tau)
             assert_close(q[: B * n_tau * L.A].view(B, n_tau, L.A), nets.head_iqn(p, spec, feat, taus), 2e-5, 2e-6, "iqn q")
             net.select(ws, B, n_tau, a_star, qsel)
             want = nets.head_iqn(p, spec, feat, taus).mean(1)
@@ -118,7 +117,7 @@ def test_forward_matches_oracle(ops, name):
             assert_close(ws.tau_hat.view(B, L.F), th[:, :, 0], 1e-5, 1e-6, "tau_hat")
             q = net.head(ws, B, ws.tau_hat, L.F)
             # cos(pi*64*tau) amplifies the 1e-7 differences of the two tau computations ~200x: compare at the SAME taus tightly
-            q2 = net.head(ws, B, th.reshape(-1).contiguous(), L.F).clone()
+            q2 = net.head(ws, B, th.reshape(-1).contiguous().to(ops.device), L.F).clone()
             assert_close(q2[: B * L.F * L.A].view(B, L.F, L.A), nets.head_iqn(p, spec, feat, th), 2e-5, 2e-6, "fqf q_hat @ oracle taus")
             q = net.head(ws, B, ws.tau_hat, L.F)
             assert_close(q[: B * L.F * L.A].view(B, L.F, L.A), nets.head_iqn(p, spec, feat, th), 5e-4, 5e-5, "fqf q_hat")
@@ -128,11 +127,16 @@ def test_forward_matches_oracle(ops, name):
             q = net.head(ws, B)
             assert_close(q[: B * L.A * L.T].view(B, L.A, L.T).squeeze(-1) if L.T == 1 else q[: B * L.A * L.T].view(B, L.A, L.T),
                          nets.forward(p, spec, x), 2e-5, 2e-6, "head out")
-            atoms = nets.c51_atoms(spec) if spec.algo == "c51" else None
+            atoms = nets.c51_atoms(spec).to(ops.device) if spec.algo == "c51" else None
             net.select(ws, B, 1, a_star, qsel, atoms=atoms)
             want = nets.qval(p, spec, x)
     assert_close(qsel.view(B, L.A), want, *((5e-4, 5e-5) if spec.algo == "fqf" else (2e-5, 2e-6)), "qval")
-    assert torch.equal(a_star.long(), want.argmax(-1))
+    assert torch.equal(a_star.long().cpu(), want.argmax(-1))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_oracle(ops, name):
+    check_forward(ops, name)
 
 
 def run_both(ops, name, B, double_q, n_step, steps=2, target_freq=2, resync=True):
@@ -159,9 +163,10 @@ def run_both(ops, name, B, double_q, n_step, steps=2, target_freq=2, resync=True
             install_noise(dev.online, no)
             install_noise(dev.target, nt)
         res_o = ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B), rand=rand_np, noise_online=no, noise_target=nt)
-        out = dev.update(torch.from_numpy(frames).reshape(-1), None, 2 * obs_bytes, torch.from_numpy(a.astype(np.int32)), torch.from_numpy(r),
-                         torch.from_numpy(d.astype(np.float32)), torch.from_numpy(w),
-                         rand=None if rand_np is None else [torch.from_numpy(x.reshape(-1).copy()) for x in rand_np])
+        D = lambda t: t.to(ops.device)
+        out = dev.update(D(torch.from_numpy(frames).reshape(-1)), None, 2 * obs_bytes, D(torch.from_numpy(a.astype(np.int32))), D(torch.from_numpy(r)),
+                         D(torch.from_numpy(d.astype(np.float32))), D(torch.from_numpy(w)),
+                         rand=None if rand_np is None else [D(torch.from_numpy(x.reshape(-1).copy())) for x in rand_np])
         out = tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()      # device buffers are reused by the next update
         got_p, got_t = dev.online.state_dict(), dev.target.state_dict()
         results.append((res_o, out, {k: v.clone() for k, v in ora.last_grads.items()}, dev.grads.clone(), got_p, got_t,
@@ -177,8 +182,7 @@ TRAIN = [("dqn", 8, False, 1), ("dqn_duel", 8, True, 3), ("c51", 8, False, 1), (
          ("dqn_noisy", 8, True, 1), ("dqn_odd", 8, True, 1)]
 
 
-@pytest.mark.parametrize("name,B,dq,n", TRAIN)
-def test_update_matches_oracle(ops, name, B, dq, n):
+def check_update(ops, name, B, dq, n):
     spec, L, ora, dev, results = run_both(ops, name, B, dq, n)
     for s, (res_o, out, g_o, g_d, got, tgt, want_p, want_t) in enumerate(results):
         loss_d, frac_d = (out if isinstance(out, tuple) else (out, None))
@@ -207,7 +211,12 @@ def test_update_matches_oracle(ops, name, B, dq, n):
     assert int(dev.state[1]) == ora.update_steps == 2
 
 
-def test_nan_loss_skips_the_step(ops):
+@pytest.mark.parametrize("name,B,dq,n", TRAIN)
+def test_update_matches_oracle(ops, name, B, dq, n):
+    check_update(ops, name, B, dq, n)
+
+
+def check_nan_skip(ops):
     spec = CASES["dqn"]
     L = NetLayout.from_spec(spec)
     B = 4
@@ -216,11 +225,16 @@ def test_nan_loss_skips_the_step(ops):
     dev.online.load_state_dict(sd)
     dev.target.load_state_dict(sd)
     before = dev.online.flat.clone()
-    frames = torch.from_numpy(recipe.make_frames(B, 1, spec.obs_shape)).reshape(-1)
+    D = lambda t: t.to(ops.device)
+    frames = D(torch.from_numpy(recipe.make_frames(B, 1, spec.obs_shape)).reshape(-1))
     a, r, d, w = recipe.make_transitions(B, 4, 2)
     r = r.copy(); r[1] = np.nan
-    dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), torch.from_numpy(a.astype(np.int32)), torch.from_numpy(r), torch.from_numpy(d.astype(np.float32)), torch.from_numpy(w))
+    dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), D(torch.from_numpy(a.astype(np.int32))), D(torch.from_numpy(r)), D(torch.from_numpy(d.astype(np.float32))), D(torch.from_numpy(w)))
     assert torch.equal(before, dev.online.flat)            # parameters untouched (agent.py:152-158)
     assert int(dev.state[1]) == 0 and int(dev.state[2]) == 1 and int(dev.state[0]) == 0
     # quirk: update_steps % freq == 0 still triggers the target copy after a skipped step (agent.py:160-161)
     assert torch.equal(dev.target.flat, dev.online.flat)
+
+
+def test_nan_loss_skips_the_step(ops):
+    check_nan_skip(ops)

@@ -1,0 +1,136 @@
+"""GPU (MI355X): the HIP kernels, called through the C-ABI, against the CPU oracle and the reference goldens.
+
+Same checks as tests/test_engine_emul.py but on the real library (fp32 MFMA tile kernel included), plus full-size
+cases pinned by fixtures generated from the reference itself (tests/golden/g3_*, g6_*).
+Tolerances: the MFMA accumulates a k-ordered fp32 fmaf chain, torch CPU uses blocked/vectorised sums, so results agree
+to a few fp32 ulp of the accumulated magnitude: rtol 5e-5 / atol 5e-6 on losses and Q-values (stated per assert).
+"""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from recipe import SPECS
+import test_engine_emul as E
+from util import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from agent0_amd.ops import HipOps
+    ops = HipOps()
+    cu, mem, arch = ops.device_info()
+    assert "gfx950" in arch, f"these kernels are built for gfx950 only, found {arch}"
+    return ops
+
+
+@pytest.mark.parametrize("name", list(E.CASES))
+def test_forward(hip, name):
+    E.check_forward(hip, name)
+
+
+@pytest.mark.parametrize("name,B,dq,n", E.TRAIN)
+def test_update(hip, name, B, dq, n):
+    E.check_update(hip, name, B, dq, n)
+
+
+def test_nan_skip(hip):
+    E.check_nan_skip(hip)
+
+
+# ----------------------------------------------------------------------------- full geometry, reference goldens
+def _device_learner(hip, spec, B, dq, n, **kw):
+    from agent0_amd.deepq.engine import DeviceLearner
+    from agent0_amd.deepq.layout import NetLayout
+    L = NetLayout.from_spec(spec)
+    dev = DeviceLearner(hip, L, B, n_step=n, double_q=dq, **kw)
+    dev.online.load_state_dict(recipe.make_state_dict(spec, 11))
+    dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
+    return L, dev
+
+
+def _batch(hip, spec, B, seed_f, seed_t):
+    frames = recipe.make_frames(B, seed_f, spec.obs_shape)
+    a, r, d, w = recipe.make_transitions(B, spec.action_dim, seed_t)
+    D = lambda x: torch.from_numpy(x).to(hip.device)
+    return D(frames.reshape(-1)), D(a.astype(np.int32)), D(r), D(d.astype(np.float32)), D(w)
+
+
+G3_GPU = ["dqn_b8_dq0_n1", "dqn_b8_dq1_n3", "dqn_duel_b8_dq1_n1", "c51_b8_dq0_n1", "c51_b8_dq1_n3", "qr_b8_dq0_n1", "qr_duel_b8_dq1_n3",
+          "dqn_b512_dq0_n1", "c51_b512_dq1_n3"]
+
+
+@pytest.mark.parametrize("case", G3_GPU)
+def test_golden_losses(hip, case):
+    """Per-sample TD losses of the reference learners (fixture group G3) reproduced by the HIP path."""
+    name, b, dq, n = case.rsplit("_", 3)
+    B, dq, n = int(b[1:]), bool(int(dq[2:])), int(n[1:])
+    spec = SPECS[name]
+    g = golden(f"g3_{case}")
+    L, dev = _device_learner(hip, spec, B, dq, n)
+    frames, a, r, d, w = _batch(hip, spec, B, 31, 32)
+    w = torch.ones_like(w)
+    loss = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w)
+    assert_close(loss[:B], g["loss"], 5e-5, 5e-6, "per-sample loss vs reference")
+
+
+def test_golden_train_step_b512(hip):
+    """One full reference train() at B=512 (fixture G6): loss and post-Adam parameter fingerprints."""
+    spec = SPECS["dqn"]
+    g = golden("g6_dqn_b512_dq0_n1")
+    B = 512
+    L, dev = _device_learner(hip, spec, B, False, 1, target_update_freq=2)
+    frames, a, r, d, w = _batch(hip, spec, B, 61, 62)
+    loss = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w)
+    assert_close(loss[:B], g["s0::q_loss"], 5e-5, 5e-6, "q_loss")
+    grads = L.unpack(dev.grads)
+    params = dev.online.state_dict()
+    for k in g.files:
+        parts = k.split("::")
+        if parts[0] != "s0" or len(parts) < 3:
+            continue
+        if parts[1] == "grad":
+            want, got = g[k], recipe.checksum(grads[parts[2]].cpu().numpy())
+            assert abs(got[1] - want[1]) <= 3e-4 * max(want[1], 1e-6), (k, got[1], want[1])
+        elif parts[1] == "param":
+            want, got = g[k], recipe.checksum(params[parts[2]].cpu().numpy())
+            assert abs(got[1] - want[1]) <= 1e-5 * max(want[1], 1e-6), (k, got[1], want[1])
+            assert np.all(np.abs(got[2:] - want[2:]) <= 5e-5 + 1e-4 * np.abs(want[2:])), (k, got[2:], want[2:])
+
+
+def test_gather_fused_equals_dense_batch(hip):
+    """Reading the batch through replay slot indices (gather fused into conv1) == running on the gathered copy."""
+    spec = SPECS["dqn"]
+    B, cap = 16, 40
+    L, dev = _device_learner(hip, spec, B, False, 1)
+    L2, dev2 = _device_learner(hip, spec, B, False, 1)
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(cap, -1).contiguous()
+    slot = torch.from_numpy(recipe.gen(6).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+    _, a, r, d, w = _batch(hip, spec, B, 1, 2)
+    row = ring.shape[1]
+    dense = torch.empty(B * row, dtype=torch.uint8, device=hip.device)
+    hip.replay_gather(ring.reshape(-1), row, slot, B, dense, cap)
+    assert torch.equal(dense.view(B, row), ring[slot.long()])
+    l1 = dev.update(ring.reshape(-1), slot, row, a, r, d, w).clone()
+    l2 = dev2.update(dense, None, row, a, r, d, w).clone()
+    assert torch.equal(l1, l2) and torch.equal(dev.grads, dev2.grads) and torch.equal(dev.online.flat, dev2.online.flat)
+
+
+def test_update_is_deterministic(hip):
+    spec = SPECS["c51_duel_noisy"]
+    B = 32
+    outs = []
+    for _ in range(2):
+        L, dev = _device_learner(hip, spec, B, True, 3)
+        frames, a, r, d, w = _batch(hip, spec, B, 3, 4)
+        for net, seed in ((dev.online, 1), (dev.target, 2)):
+            gg = recipe.gen(seed)
+            for prefix, block, r0, r1, in_f in L.noise_modules:
+                net.set_noise(prefix, gg.standard_normal(in_f).astype(np.float32) * 0.1, gg.standard_normal(r1 - r0).astype(np.float32) * 0.1,
+                              gg.standard_normal(r1 - r0).astype(np.float32) * 0.1)
+        dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w)
+        outs.append((dev.loss.clone(), dev.grads.clone(), dev.online.flat.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y), "bit-identical results across runs (no atomics anywhere on the path)"

@@ -1,0 +1,206 @@
+"""GPU (MI355X): replay / sum-tree / permutation / RNG / synthetic env / actor kernels against the C and numpy oracle.
+Integer, byte and index results are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import core
+from oracle import actor as oactor
+from oracle import replay as oreplay
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from agent0_amd.ops import HipOps
+    return HipOps()
+
+
+def D(hip, x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
+
+
+@pytest.mark.parametrize("size", [1, 5, 24, 1000, 100000])
+def test_sumtree_bit_exact(hip, size):
+    g = recipe.gen(size)
+    t = core.SumTree(size)
+    tree = hip.zeros(2 * t.cap2)
+    for rnd in range(5):
+        n = int(g.integers(1, min(size, 512) + 1))
+        idx = g.integers(0, size, n)
+        val = g.uniform(0.0, 3.0, n).astype(np.float32)
+        if rnd == 2:
+            val[: n // 2] = 0
+        t.set(idx, val)
+        hip.sumtree_set(tree, t.cap2, D(hip, idx.astype(np.int64)), D(hip, val), n)
+        assert np.array_equal(tree.cpu().numpy(), t.tree), "tree bytes after set"
+        B = 64
+        xi = g.random(B).astype(np.float32)
+        want_i, want_p = t.sample(xi)
+        out_i, out_p = hip.zeros(B, dtype=torch.int64), hip.zeros(B)
+        hip.sumtree_sample(tree, t.cap2, D(hip, xi), B, out_i, out_p)
+        assert np.array_equal(out_i.cpu().numpy(), want_i) and np.array_equal(out_p.cpu().numpy(), want_p)
+    # bulk fill + rebuild
+    leaves = g.uniform(0.01, 1.0, size).astype(np.float32)
+    t.tree[t.cap2:t.cap2 + size] = leaves
+    t.rebuild()
+    tree[t.cap2:t.cap2 + size] = D(hip, leaves)
+    hip.sumtree_rebuild(tree, t.cap2)
+    assert np.array_equal(tree.cpu().numpy(), t.tree)
+
+
+def test_sumtree_full_size_properties(hip):
+    """1 M leaves (BASELINE config 2): internal nodes are exactly left+right; sampled leaves are live; sampling is sorted by stratum."""
+    size = 1_000_000
+    cap2 = 1 << 20
+    g = recipe.gen(1)
+    tree = hip.zeros(2 * cap2)
+    tree[cap2:cap2 + size] = D(hip, np.sqrt(g.uniform(0.01, 1.0, size)).astype(np.float32))
+    hip.sumtree_rebuild(tree, cap2)
+    idx = g.integers(0, size, 512)
+    val = g.uniform(0, 2, 512).astype(np.float32)
+    hip.sumtree_set(tree, cap2, D(hip, idx.astype(np.int64)), D(hip, val), 512)
+    tc = tree.cpu().numpy()
+    p = np.arange(1, cap2)
+    assert np.array_equal(tc[p], tc[2 * p] + tc[2 * p + 1])
+    out_i, out_p = hip.zeros(512, dtype=torch.int64), hip.zeros(512)
+    hip.sumtree_sample(tree, cap2, D(hip, g.random(512).astype(np.float32)), 512, out_i, out_p)
+    oi = out_i.cpu().numpy()
+    assert oi.min() >= 0 and oi.max() < size and np.all(np.diff(oi) >= 0) and np.all(out_p.cpu().numpy() > 0)
+    assert np.array_equal(out_p.cpu().numpy(), tc[cap2 + oi])
+
+
+@pytest.mark.parametrize("n", [1, 7, 512, 100001, 1_000_000])
+def test_perm_bit_exact(hip, n):
+    count = min(n, 4096)
+    start = 0 if n <= 4096 else n - count - 3
+    out = hip.zeros(count, dtype=torch.int64)
+    hip.perm_batch(start, count, n, 1234, out)
+    assert np.array_equal(out.cpu().numpy(), core.perm_batch(start, count, n, 1234))
+
+
+def test_rng_streams(hip):
+    n = 10007
+    u32 = hip.zeros(n, dtype=torch.int32)
+    hip.rng_u32(42, 7, 5, u32, n)
+    assert np.array_equal(u32.cpu().numpy().view(np.uint32), core.rng_u32(42, 7, 5, n))
+    u = hip.zeros(n)
+    hip.rng_uniform((1 << 40) + 3, 9, 1 << 33, u, n)
+    assert np.array_equal(u.cpu().numpy(), core.rng_uniform((1 << 40) + 3, 9, 1 << 33, n))
+    z = hip.zeros(n)
+    hip.rng_normal(3, 1, 11, 0.1, z, n)
+    assert_close(z, core.rng_normal(3, 1, 11, 0.1, n), 1e-4, 1e-6, "Box-Muller normals (transcendental rounding only)")
+    ri = hip.zeros(n, dtype=torch.int32)
+    hip.rng_randint(8, 2, 0, 18, ri, n)
+    assert np.array_equal(ri.cpu().numpy(), (core.rng_u32(8, 2, 0, n) % 18).astype(np.int32))
+
+
+def test_synth_env_bytes(hip):
+    E = 5
+    env = core.SynthVecEnv(E, seed=42, rank=3)
+    obs_c, _ = env.reset()
+    obs = [hip.zeros(E * 4 * 84 * 84, dtype=torch.uint8), hip.zeros(E * 4 * 84 * 84, dtype=torch.uint8)]
+    ep = hip.zeros(E)
+    f = [hip.zeros(E) for _ in range(6)]
+    hip.env_reset(42, 3, E, obs[0], ep)
+    assert np.array_equal(obs[0].cpu().numpy().reshape(E, 4, 84, 84), obs_c)
+    n_term = 0
+    for t in range(1, 1200):
+        o, r, term, trunc, info = env.step(np.zeros(E))
+        hip.env_step(42, 3, E, t, obs[(t - 1) % 2], obs[t % 2], ep, *f)
+        if t < 40 or term.any():
+            assert np.array_equal(obs[t % 2].cpu().numpy().reshape(E, 4, 84, 84), o), f"obs at step {t}"
+        assert np.array_equal(f[0].cpu().numpy(), r.astype(np.float32))
+        assert np.array_equal(f[1].cpu().numpy() != 0, term) and not f[2].cpu().numpy().any()
+        assert np.array_equal(f[3].cpu().numpy() != 0, info["life_loss"])
+        if term.any():
+            n_term += int(term.sum())
+            fr = np.array([info["final_info"][i]["episode"]["r"][0] if term[i] else 0.0 for i in range(E)], dtype=np.float32)
+            assert np.array_equal(f[5].cpu().numpy(), fr) and np.array_equal(f[4].cpu().numpy() != 0, term)
+    assert n_term > 0
+    assert np.array_equal(ep.cpu().numpy(), env.ep_ret)
+
+
+@pytest.mark.parametrize("n_step", [1, 3])
+def test_actor_nstep_and_egreedy(hip, n_step):
+    E, T, A = 6, 25, 4
+    g = recipe.gen(n_step)
+    from collections import deque
+    tracker = deque(maxlen=n_step)
+    ring_a, ring_r, ring_d = hip.zeros(n_step * E, dtype=torch.int32), hip.zeros(n_step * E), hip.zeros(n_step * E)
+    oa, orr, od = hip.zeros(E, dtype=torch.int32), hip.zeros(E), hip.zeros(E)
+    for t in range(T):
+        action = g.integers(0, A, E)
+        reward = g.choice([-1.0, 0.0, 1.0], E)
+        term, trunc, life = g.random(E) < 0.2, g.random(E) < 0.1, g.random(E) < 0.2
+        done = np.logical_and(np.logical_or(term, life), np.logical_not(trunc))
+        tracker.append((None, action, reward, done))
+        R, Dn = oactor.nstep_scan(tracker, 0.99)
+        hip.actor_nstep(E, n_step, t, 0.99, D(hip, action.astype(np.int32)), D(hip, reward.astype(np.float32)), D(hip, term.astype(np.float32)),
+                        D(hip, trunc.astype(np.float32)), D(hip, life.astype(np.float32)), ring_a, ring_r, ring_d, oa, orr, od)
+        assert np.array_equal(oa.cpu().numpy(), tracker[0][1].astype(np.int32))
+        assert np.array_equal(orr.cpu().numpy(), R.astype(np.float32)), "fp64 n-step sum rounded once to fp32"
+        assert np.array_equal(od.cpu().numpy() != 0, Dn)
+    greedy, rnd, u = g.integers(0, A, E), g.integers(0, A, E), g.random(E)
+    qmax = g.standard_normal(E).astype(np.float32)
+    act, qs = hip.zeros(E, dtype=torch.int32), hip.zeros(1)
+    hip.actor_egreedy(D(hip, greedy.astype(np.int32)), D(hip, rnd.astype(np.int32)), D(hip, u.astype(np.float32)), 0.3, E, act, D(hip, qmax), qs)
+    want, _ = oactor.egreedy(np.eye(A)[greedy], rnd, u.astype(np.float32), np.float32(0.3))
+    assert np.array_equal(act.cpu().numpy(), want.astype(np.int32))
+    assert_close(qs, [qmax.mean()], 1e-6, 1e-7, "mean max-Q")
+
+
+def test_replay_insert_lookup_gather_priorities(hip):
+    cap, E, ob = 24, 4, 4 * 84 * 84
+    frames = hip.zeros(cap * 2 * ob, dtype=torch.uint8)
+    r_act, r_rew, r_done = hip.zeros(cap, dtype=torch.int32), hip.zeros(cap), hip.zeros(cap)
+    ref = oreplay.ReferenceReplay(cap, True, total_steps=1000)
+    prio = hip.zeros(cap); hip.fill_f32(prio, cap, 1.0)
+    pstate = hip.zeros(1); hip.fill_f32(pstate, 1, 1.0)
+    g = recipe.gen(8)
+    written, uid = 0, 0
+    store = {}
+    for it in range(9):
+        obs = g.integers(0, 256, (E, ob), dtype=np.uint8)
+        nxt = g.integers(0, 256, (E, ob), dtype=np.uint8)
+        a = g.integers(0, 4, E).astype(np.int32); r = g.choice([-1.0, 0.0, 1.0], E).astype(np.float32); d = (g.random(E) < 0.3).astype(np.float32)
+        hip.replay_insert(frames, cap, ob, written % cap, E, D(hip, obs), D(hip, nxt), D(hip, a), D(hip, r), D(hip, d), r_act, r_rew, r_done)
+        trans = []
+        for i in range(E):
+            store[uid] = (np.concatenate((obs[i], nxt[i])), a[i], r[i], d[i])
+            trans.append((uid, a[i], r[i], d[i])); uid += 1
+        ref.extend(trans)
+        hip.priority_tail(prio, cap, E, pstate, 0.5)
+        written += E
+        top = min(written, cap); head = written % cap if written > cap else 0
+        assert head == ref.head and top == ref.top
+        B = 6
+        idx = g.integers(0, 1000, B)
+        slot, act, rew, done, pr, io = hip.zeros(B, dtype=torch.int32), hip.zeros(B, dtype=torch.int32), hip.zeros(B), hip.zeros(B), hip.zeros(B), hip.zeros(B, dtype=torch.int64)
+        hip.replay_lookup(D(hip, idx.astype(np.int64)), B, top, head, cap, slot, r_act, r_rew, r_done, prio, act, rew, done, pr, io)
+        out = hip.zeros(B * 2 * ob, dtype=torch.uint8)
+        hip.replay_gather(frames, 2 * ob, slot, B, out, cap)
+        got_rows = out.cpu().numpy().reshape(B, -1)
+        for b in range(B):
+            u, at, rt, dt, p, i2 = ref[int(idx[b])]
+            assert np.array_equal(got_rows[b], store[u][0]) and int(act[b]) == at and float(rew[b]) == rt and float(done[b]) == dt
+            assert int(io[b]) == i2 and abs(float(pr[b]) - float(p)) <= 1.2e-7 * float(p)
+        if it % 2 == 1:
+            ids = g.integers(0, top, 5); ids[1] = ids[0]
+            losses = g.uniform(0, 3, 5).astype(np.float32)
+            # oracle: torch indexed assignment with duplicates keeps the LAST write on CPU
+            ref.update_priority(ids, losses)
+            hip.priority_update(prio, D(hip, ids.astype(np.int64)), D(hip, losses), 5, 0.01, 0.5, pstate, None)
+        # fp: the device computes the IEEE-correct sqrt; torch's CPU pow(x, 0.5) is a vectorised (Sleef) sqrt that is
+        # occasionally 1 ulp off, so priorities are compared to 1 ulp and untouched slots exactly
+        assert_close(prio, ref.priority, 1.2e-7, 0, f"priority vector after iteration {it}")
+        assert np.array_equal(prio.cpu().numpy() == 1.0, ref.priority == 1.0)
+        assert float(pstate[0]) == np.float32(ref.max_p)
+        sc, ps, w = hip.zeros(256), hip.zeros(1), hip.zeros(B)
+        hip.sum_f32(prio, cap, sc, ps)
+        hip.is_weights(pr, B, ps, top, 0.5, w)
+        want = oreplay.is_weights(pr.cpu().numpy(), float(torch.from_numpy(ref.priority).sum()), top, 0.5)
+        assert_close(w, want, 2e-6, 1e-7, "importance weights")

@@ -1,0 +1,133 @@
+"""GPU (MI355X): the product's Python classes end to end — Actor rollout parity against the oracle actor on the same
+synthetic env and the same random draws, replay contents, Trainer iterations for every algorithm family."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import actor as oactor
+from oracle import core, learner as olearner, nets
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cfg(algo="dqn", E=4, **kw):
+    from agent0_amd.deepq.config import parse_overrides
+    cfg = parse_overrides([f"learner.algo={algo}", f"actor.num_envs={E}", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"] + [f"{k}={v}" for k, v in kw.items()])
+    cfg.obs_shape = (4, 84, 84)
+    cfg.action_dim = 4
+    return cfg
+
+
+@pytest.mark.parametrize("n_step", [1, 3])
+def test_actor_rollout_matches_oracle(n_step):
+    from agent0_amd.deepq.agent import Actor
+    from agent0_amd.deepq.model import DeepQNet
+    from agent0_amd.deepq.replay import ReplayDataset
+    from agent0_amd.common.utils import DeviceRng
+
+    E, T = 4, 12
+    cfg = make_cfg("dqn", E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 64, "learner.batch_size": 8})
+    model = DeepQNet(cfg)
+    spec = recipe.NetSpec("dqn", 4)
+    sd = recipe.make_state_dict(spec, 11)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    replay = ReplayDataset(cfg, ops=model.ops)
+    actor = Actor(cfg, model, replay=replay, rank=0)
+    # oracle twin: same env definition, same Philox draws (stream ids / offsets as DeviceRng assigns them)
+    seed64 = (cfg.seed & 0xFFFFFFFF)
+    step_no = [0]
+
+    def draw(E_):
+        off = step_no[0] * ((E_ + 3) // 4) * 4
+        step_no[0] += 1
+        a = (core.rng_u32(seed64, DeviceRng.STREAM_EGREEDY_A, off, E_) % 4).astype(np.int64)
+        u = core.rng_uniform(seed64, DeviceRng.STREAM_EGREEDY_U, off, E_)
+        return a, u
+
+    env = core.SynthVecEnv(E, seed=cfg.seed, rank=0)
+    ora = oactor.OracleActor(env, olearner.to_params(sd), spec, n_step=n_step, sample_steps=6, draw=draw)
+    eps = np.float32(0.35)
+    for call in range(2):
+        data, rs, qs = actor.sample(float(eps))
+        replay.extend(data)
+        odata, ors, oqs = ora.sample(eps)
+        assert_close(qs, oqs, 5e-5, 5e-6, "mean max-Q per step")
+        assert rs == [float(x) for x in ors]
+        n = len(odata)
+        base = call * n
+        rows = replay.frames.view(replay.size, -1)[base:base + n].cpu().numpy()
+        for i, (fr, at, rt, dt) in enumerate(odata):
+            assert np.array_equal(rows[i], fr.reshape(-1)), f"transition {base + i}: packed st||st_next bytes"
+            assert int(replay.act[base + i]) == int(at) and float(replay.rew[base + i]) == np.float32(rt) and bool(replay.done[base + i] != 0) == bool(dt)
+    assert len(replay) == 2 * 6 * E and replay.top == 48
+
+
+ALGOS = [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3}),
+         ("c51", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.noisy_net": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
+         ("c51", {"replay.policy": "prioritize", "replay.sumtree": "false"}), ("qr", {}), ("iqr", {"learner.double_q": "true"}), ("fqf", {})]
+
+
+@pytest.mark.parametrize("algo,extra", ALGOS)
+def test_trainer_iterations(algo, extra):
+    from agent0_amd.deepq.trainer import Trainer
+    cfg = make_cfg(algo, 8, **{"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 3,
+                                "trainer.training_start_steps": 100, "learner.target_update_freq": 4, **extra})
+    tr = Trainer(cfg)
+    flat0 = tr.learner.engine.online.flat.clone()
+    res = None
+    for it in range(7):
+        res = tr.run_iteration()
+    assert res["frames"] == 7 * 80 and len(tr.replay) == 400 and tr.replay.written == 560
+    assert res["loss"] is not None and np.isfinite(res["loss"]) and res["fps"] > 0 and np.isfinite(res["qmax"])
+    if algo == "fqf":
+        assert np.isfinite(res["fraction_loss"])
+    eng = tr.learner.engine
+    n_updates = 5 * 3            # training starts once len(replay) > 100, i.e. from the 2nd iteration... (80 -> 160 > 100)
+    assert tr.learner.update_steps == 6 * 3 and int(eng.state[2]) == 0
+    assert not torch.equal(flat0, eng.online.flat) and torch.isfinite(eng.online.flat).all()
+    if cfg.replay.policy.name == "prioritize":
+        if cfg.replay.sumtree:
+            t = tr.replay.tree.cpu().numpy(); c2 = tr.replay.cap2
+            p = np.arange(1, c2)
+            assert np.array_equal(t[p], t[2 * p] + t[2 * p + 1]) and t[1] > 0
+        else:
+            assert float(tr.replay.priority.min()) > 0 and tr.replay.max_p >= 1.0
+        assert 0.4 <= tr.replay.beta <= 1.0
+    sd = tr.learner.model.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    # reference-signature train(): the 6-tuple of float tensors (trainer.py:88-97)
+    B = 32
+    fr = torch.from_numpy(recipe.make_frames(B, 3)).reshape(B, -1).float()
+    a, r, d, w = recipe.make_transitions(B, 4, 4)
+    out = tr.learner.train((fr, torch.from_numpy(a).float(), torch.from_numpy(r), torch.from_numpy(d).float(), torch.from_numpy(w), torch.arange(B).float()))
+    assert out["q_loss"].shape == (B,) and out["indices"].dtype == torch.int64
+
+
+def test_model_api_matches_reference_shapes():
+    from agent0_amd.deepq.model import DeepQNet
+    x = torch.from_numpy(recipe.make_frames(3, 1)[:, :4].copy()).float().div(255.0)
+    for name in ("dqn", "c51", "qr", "iqn", "fqf"):
+        spec = recipe.SPECS[name]
+        cfg = make_cfg(name if name != "iqn" else "iqn", 4)
+        cfg.action_dim = spec.action_dim
+        m = DeepQNet(cfg)
+        sd = recipe.make_state_dict(spec, 11)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        got = m.state_dict()
+        for k, v in sd.items():
+            if not recipe.is_buffer(k):
+                assert torch.equal(got[k].cpu(), torch.from_numpy(v)), k       # state_dict round trip through the packed device layout
+        p = olearner.to_params(sd)
+        with torch.no_grad():
+            if name in ("dqn", "c51", "qr"):
+                assert_close(m(x), nets.forward(p, spec, x), 5e-5, 5e-6, f"{name} forward")
+                assert_close(m.qval(x), nets.qval(p, spec, x), 5e-5, 5e-6, f"{name} qval")
+            elif name == "iqn":
+                q, taus = m(x, n=8)
+                assert q.shape == (3, 8, spec.action_dim) and taus.shape == (3, 8, 1)
+                assert_close(q, nets.head_iqn(p, spec, nets.encoder(p, x), taus.cpu()), 5e-5, 5e-6, "iqn forward at the drawn taus")
+            else:
+                assert_close(m.qval(x), nets.qval(p, spec, x), 1e-3, 1e-4, "fqf qval")
+        assert len(list(m.params())) == len([k for k in sd if not recipe.is_buffer(k) and "fraction" not in k])
