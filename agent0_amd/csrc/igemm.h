@@ -22,25 +22,30 @@ template <class OP, int BX> struct a0_stager<OP, BX, A0_KC> {
     static constexpr int R = BX / 32;
     static constexpr int LD = BX + 1;
     typename OP::Row rows[R];
-    a0_f4 v[R];
-    A0_D void init(const typename OP::Params& P, int x0, int X, int tid) {
+    typename OP::KInfo ki;        // gather-table entry of the tile about to be fetched (loaded one tile ahead)
+    typename OP::Raw raw[R];
+    unsigned okmask;
+    A0_D void init(const typename OP::Params& P, int x0, int X, int kb, int ke, int tid) {
 #pragma unroll
         for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + (tid >> 3) + 32 * j, X);
+        ki = OP::kinfo(P, kb + 4 * (tid & 7), ke);
     }
-    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int, int, int tid) {
-        const int k = k0 + 4 * (tid & 7);
+    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int tid) {
+        okmask = 0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = OP::load(P, rows[j], k, ke);
+        for (int j = 0; j < R; ++j) { bool ok; raw[j] = OP::load(P, rows[j], ki, ok); okmask |= ok ? (1u << j) : 0u; }
+        ki = OP::kinfo(P, k0 + 32 + 4 * (tid & 7), ke);     // for the NEXT fetch; its latency hides behind this tile's MFMAs
     }
     A0_D void commit(float* lds, int tid) const {
         const int kk = 4 * (tid & 7);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int r = (tid >> 3) + 32 * j;
-            lds[(kk + 0) * LD + r] = v[j].x;
-            lds[(kk + 1) * LD + r] = v[j].y;
-            lds[(kk + 2) * LD + r] = v[j].z;
-            lds[(kk + 3) * LD + r] = v[j].w;
+            const a0_f4 v = OP::finish(raw[j], (okmask >> j) & 1u);
+            lds[(kk + 0) * LD + r] = v.x;
+            lds[(kk + 1) * LD + r] = v.y;
+            lds[(kk + 2) * LD + r] = v.z;
+            lds[(kk + 3) * LD + r] = v.w;
         }
     }
 };
@@ -49,20 +54,23 @@ template <class OP, int BX> struct a0_stager<OP, BX, A0_XC> {
     static constexpr int R = BX / 32;
     static constexpr int LD = BX + 4;
     static constexpr int Q = BX / 4;   // 16-byte groups per k row
-    a0_f4 v[R];
-    A0_D void init(const typename OP::Params&, int, int, int) {}
-    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int x0, int X, int tid) {
+    typename OP::XInfo xi[R];
+    typename OP::Raw raw[R];
+    unsigned okmask;
+    A0_D void init(const typename OP::Params& P, int x0, int X, int, int, int tid) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int f = tid + 256 * j;
-            v[j] = OP::load(P, k0 + f / Q, x0 + 4 * (f % Q), ke, X);
-        }
+        for (int j = 0; j < R; ++j) xi[j] = OP::xinfo(P, x0 + 4 * ((tid + 256 * j) % Q), X);
+    }
+    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int tid) {
+        okmask = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { bool ok; raw[j] = OP::load(P, k0 + (tid + 256 * j) / Q, ke, xi[j], ok); okmask |= ok ? (1u << j) : 0u; }
     }
     A0_D void commit(float* lds, int tid) const {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int f = tid + 256 * j;
-            *(a0_f4*)&lds[(f / Q) * LD + 4 * (f % Q)] = v[j];
+            *(a0_f4*)&lds[(f / Q) * LD + 4 * (f % Q)] = OP::finish(raw[j], (okmask >> j) & 1u);
         }
     }
 };
@@ -87,8 +95,8 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
     const int ke = (K < kb + kchunk) ? K : (kb + kchunk);
 
     SA sa; SB sb;
-    sa.init(pa, x0, X, tid);
-    sb.init(pb, y0, Y, tid);
+    sa.init(pa, x0, X, kb, ke, tid);
+    sb.init(pb, y0, Y, kb, ke, tid);
 
     a0_acc16 acc[MT][NT];
 #pragma unroll
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kb < ke) { sa.fetch(pa, kb, ke, x0, X, tid); sb.fetch(pb, kb, ke, y0, Y, tid); }
+    if (kb < ke) { sa.fetch(pa, kb, ke, tid); sb.fetch(pb, kb, ke, tid); }
 
     const float* ap = As + (lane >> 5) * LDA + wm * (MT * 32) + (lane & 31);
     const float* bp = Bs + (lane >> 5) * LDB + wn * (NT * 32) + (lane & 31);
@@ -108,19 +116,27 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
         sa.commit(As, tid);
         sb.commit(Bs, tid);
         __syncthreads();
-        if (k0 + BK < ke) { sa.fetch(pa, k0 + BK, ke, x0, X, tid); sb.fetch(pb, k0 + BK, ke, y0, Y, tid); }
+        if (k0 + BK < ke) { sa.fetch(pa, k0 + BK, ke, tid); sb.fetch(pb, k0 + BK, ke, tid); }
+        // fragment reads run one k-step ahead of the MFMAs that consume them
+        float a[2][MT], b[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float a[MT], b[NT];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = ap[2 * s * LDA + i * 32];
+                for (int i = 0; i < MT; ++i) a[nxt][i] = ap[2 * (s + 1) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * LDB + j * 32];
+                for (int j = 0; j < NT; ++j) b[nxt][j] = bp[2 * (s + 1) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
     }
 

@@ -14,6 +14,15 @@
 
 enum { A0_KC = 0, A0_XC = 1 };
 
+// Policy interface (all loads are BRANCH-FREE: an invalid element reads a safe in-bounds address and is then zeroed, so
+// the compiler can issue every load of a tile back to back behind one wait instead of a wait per conditional load):
+//   KC:  Row   row(P, x, X)            per-row state, computed once per workgroup (the row set of a thread never changes)
+//        KInfo kinfo(P, k, Kend)       per-k state (gather-table entry), fetched one tile AHEAD of its use
+//        Raw   load(P, row, kinfo, ok) raw bits + validity; nothing may CONSUME the bits here, or the wave would wait for the
+//        f4    finish(raw, ok)         load before the tile's MFMAs instead of after them: zero-fill / u8->fp32 happen at commit
+//   XC:  XInfo xinfo(P, x, X)          per-column state, computed once (a thread's columns never change)
+//        Raw   load(P, k, Kend, xinfo, ok);  f4 finish(raw, ok)
+//
 // ------------------------------------------------------------------------------------------------ u8 frames, conv1
 // Frames are stored as the actor packs them (reference agent.py:78-81): [slot][8][H][W] u8 = st || st_next.
 // The uint8 -> fp32 /255 normalisation of agent.py:27 / agent.py:129-134 is fused into this load (true division).
@@ -26,17 +35,18 @@ struct a0_frames_src {
     int aligned4;             // 1 if every 4-byte group is 4-byte aligned (W % 4 == 0, stride % 4 == 0)
 };
 
-A0_HD a0_f4 a0_u8x4_to_f4(const uint8_t* p, int aligned4) {
+A0_HD uint32_t a0_u8x4_load(const uint8_t* p, int aligned4) {
+    if (aligned4) return *(const uint32_t*)p;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+A0_HD a0_f4 a0_u8x4_to_f4(uint32_t w, bool valid) {
+    if (!valid) w = 0;
     a0_f4 v;
-    if (aligned4) {
-        uint32_t w = *(const uint32_t*)p;
-        v.x = (float)(w & 255u) / 255.0f;
-        v.y = (float)((w >> 8) & 255u) / 255.0f;
-        v.z = (float)((w >> 16) & 255u) / 255.0f;
-        v.w = (float)(w >> 24) / 255.0f;
-    } else {
-        v.x = (float)p[0] / 255.0f; v.y = (float)p[1] / 255.0f; v.z = (float)p[2] / 255.0f; v.w = (float)p[3] / 255.0f;
-    }
+    v.x = (float)(w & 255u) / 255.0f;
+    v.y = (float)((w >> 8) & 255u) / 255.0f;
+    v.z = (float)((w >> 16) & 255u) / 255.0f;
+    v.w = (float)(w >> 24) / 255.0f;
     return v;
 }
 
@@ -52,23 +62,35 @@ A0_HD const uint8_t* a0_frames_row(const a0_frames_src& P, int m) {
 struct OpFramesKC {
     static constexpr int MODE = A0_KC;
     typedef a0_frames_src Params;
-    struct Row { const uint8_t* p; };
+    struct Row { const uint8_t* p; bool ok; };
+    struct KInfo { int off; bool ok; };
     A0_HD static Row row(const Params& P, int m, int M) {
-        Row r; r.p = (m < M) ? a0_frames_row(P, m) : nullptr; return r;
+        Row r; r.ok = m < M; r.p = a0_frames_row(P, r.ok ? m : 0); return r;
     }
-    A0_HD static a0_f4 load(const Params& P, const Row& r, int k, int Kend) {
-        if (!r.p || k >= Kend) return a0_zero4();
-        return a0_u8x4_to_f4(r.p + P.ktab[k >> 2].x, P.aligned4);
+    A0_HD static KInfo kinfo(const Params& P, int k, int Kend) {
+        KInfo ki; ki.ok = k < Kend; ki.off = P.ktab[ki.ok ? (k >> 2) : 0].x; return ki;
     }
+    typedef uint32_t Raw;
+    A0_HD static Raw load(const Params& P, const Row& r, const KInfo& ki, bool& ok) {
+        ok = r.ok && ki.ok;
+        return a0_u8x4_load(r.p + ki.off, P.aligned4);
+    }
+    A0_HD static a0_f4 finish(Raw w, bool ok) { return a0_u8x4_to_f4(w, ok); }
 };
 
 struct OpFramesXC {   // wgrad of conv1: reduction index = im2col row m, x = patch element
     static constexpr int MODE = A0_XC;
     typedef a0_frames_src Params;
-    A0_HD static a0_f4 load(const Params& P, int m, int x, int Mend, int X) {
-        if (m >= Mend || x >= X) return a0_zero4();
-        return a0_u8x4_to_f4(a0_frames_row(P, m) + P.ktab[x >> 2].x, P.aligned4);
+    struct XInfo { int off; bool ok; };
+    A0_HD static XInfo xinfo(const Params& P, int x, int X) {
+        XInfo xi; xi.ok = x < X; xi.off = P.ktab[xi.ok ? (x >> 2) : 0].x; return xi;
     }
+    typedef uint32_t Raw;
+    A0_HD static Raw load(const Params& P, int m, int Mend, const XInfo& xi, bool& ok) {
+        ok = xi.ok && m < Mend;
+        return a0_u8x4_load(a0_frames_row(P, ok ? m : 0) + xi.off, P.aligned4);
+    }
+    A0_HD static a0_f4 finish(Raw w, bool ok) { return a0_u8x4_to_f4(w, ok); }
 };
 
 // ------------------------------------------------------------------------------------------------ fp32 NHWC activations
@@ -78,48 +100,56 @@ struct a0_act_src {
     const a0_i4* ktab;        // [K/4]: {element offset (kh*Win + kw)*C + c, kh, kw, 0}
 };
 
-struct a0_act_row { const float* p; int h0, w0; };
+struct a0_act_row { long long base; int h0, w0; bool ok; };
 
-A0_HD a0_act_row a0_act_rowdesc(const a0_act_src& P, int m) {
+A0_HD a0_act_row a0_act_rowdesc(const a0_act_src& P, int m, bool ok) {
     a0_act_row r;
+    if (!ok) m = 0;
     int b = m / P.g.HWout;
     int rem = m - b * P.g.HWout;
     int oh = rem / P.g.Wout;
     int ow = rem - oh * P.g.Wout;
     r.h0 = oh * P.g.stride - P.g.pad;
     r.w0 = ow * P.g.stride - P.g.pad;
-    r.p = P.x + (long long)b * P.g.sample_stride + ((long long)r.h0 * P.g.Win + r.w0) * P.g.C;
+    r.base = (long long)b * P.g.sample_stride + ((long long)r.h0 * P.g.Win + r.w0) * P.g.C;
+    r.ok = ok;
     return r;
 }
 
-A0_HD a0_f4 a0_act_fetch(const a0_act_src& P, const a0_act_row& r, int k) {
-    a0_i4 t = P.ktab[k >> 2];
-    int h = r.h0 + t.y, w = r.w0 + t.z;
-    if ((unsigned)h >= (unsigned)P.g.Hin || (unsigned)w >= (unsigned)P.g.Win) return a0_zero4();
-    return *(const a0_f4*)(r.p + t.x);
+A0_HD a0_f4 a0_act_fetch(const a0_act_src& P, const a0_act_row& r, const a0_i4& t, bool kok, bool& ok) {
+    const int h = r.h0 + t.y, w = r.w0 + t.z;
+    ok = r.ok && kok && (unsigned)h < (unsigned)P.g.Hin && (unsigned)w < (unsigned)P.g.Win;
+    return *(const a0_f4*)(P.x + (ok ? r.base + t.x : 0));
 }
+
+A0_HD a0_f4 a0_f4_select(a0_f4 v, bool ok) { if (!ok) v = a0_zero4(); return v; }
 
 struct OpActKC {
     static constexpr int MODE = A0_KC;
     typedef a0_act_src Params;
     typedef a0_act_row Row;
-    A0_HD static Row row(const Params& P, int m, int M) {
-        if (m >= M) { Row r; r.p = nullptr; r.h0 = 0; r.w0 = 0; return r; }
-        return a0_act_rowdesc(P, m);
+    struct KInfo { a0_i4 t; bool ok; };
+    A0_HD static Row row(const Params& P, int m, int M) { return a0_act_rowdesc(P, m, m < M); }
+    A0_HD static KInfo kinfo(const Params& P, int k, int Kend) {
+        KInfo ki; ki.ok = k < Kend; ki.t = P.ktab[ki.ok ? (k >> 2) : 0]; return ki;
     }
-    A0_HD static a0_f4 load(const Params& P, const Row& r, int k, int Kend) {
-        if (!r.p || k >= Kend) return a0_zero4();
-        return a0_act_fetch(P, r, k);
-    }
+    typedef a0_f4 Raw;
+    A0_HD static Raw load(const Params& P, const Row& r, const KInfo& ki, bool& ok) { return a0_act_fetch(P, r, ki.t, ki.ok, ok); }
+    A0_HD static a0_f4 finish(Raw v, bool ok) { return a0_f4_select(v, ok); }
 };
 
 struct OpActXC {
     static constexpr int MODE = A0_XC;
     typedef a0_act_src Params;
-    A0_HD static a0_f4 load(const Params& P, int m, int x, int Mend, int X) {
-        if (m >= Mend || x >= X) return a0_zero4();
-        return a0_act_fetch(P, a0_act_rowdesc(P, m), x);
+    struct XInfo { a0_i4 t; bool ok; };
+    A0_HD static XInfo xinfo(const Params& P, int x, int X) {
+        XInfo xi; xi.ok = x < X; xi.t = P.ktab[xi.ok ? (x >> 2) : 0]; return xi;
     }
+    typedef a0_f4 Raw;
+    A0_HD static Raw load(const Params& P, int m, int Mend, const XInfo& xi, bool& ok) {
+        return a0_act_fetch(P, a0_act_rowdesc(P, m, m < Mend), xi.t, xi.ok, ok);
+    }
+    A0_HD static a0_f4 finish(Raw v, bool ok) { return a0_f4_select(v, ok); }
 };
 
 // ------------------------------------------------------------------------------------------------ dense row-major
@@ -128,21 +158,29 @@ struct a0_mat_src { const float* x; int ld; };
 struct OpMatKC {      // X[row][k], k contiguous
     static constexpr int MODE = A0_KC;
     typedef a0_mat_src Params;
-    struct Row { const float* p; };
-    A0_HD static Row row(const Params& P, int r, int R) { Row o; o.p = (r < R) ? P.x + (long long)r * P.ld : nullptr; return o; }
-    A0_HD static a0_f4 load(const Params&, const Row& r, int k, int Kend) {
-        if (!r.p || k >= Kend) return a0_zero4();
-        return *(const a0_f4*)(r.p + k);
+    struct Row { const float* p; bool ok; };
+    struct KInfo { int k; bool ok; };
+    A0_HD static Row row(const Params& P, int r, int R) { Row o; o.ok = r < R; o.p = P.x + (o.ok ? (long long)r * P.ld : 0); return o; }
+    A0_HD static KInfo kinfo(const Params&, int k, int Kend) { KInfo ki; ki.ok = k < Kend; ki.k = ki.ok ? k : 0; return ki; }
+    typedef a0_f4 Raw;
+    A0_HD static Raw load(const Params&, const Row& r, const KInfo& ki, bool& ok) {
+        ok = r.ok && ki.ok;
+        return *(const a0_f4*)(r.p + ki.k);
     }
+    A0_HD static a0_f4 finish(Raw v, bool ok) { return a0_f4_select(v, ok); }
 };
 
 struct OpMatXC {      // X[k][x], x contiguous
     static constexpr int MODE = A0_XC;
     typedef a0_mat_src Params;
-    A0_HD static a0_f4 load(const Params& P, int k, int x, int Kend, int X) {
-        if (k >= Kend || x >= X) return a0_zero4();
-        return *(const a0_f4*)(P.x + (long long)k * P.ld + x);
+    struct XInfo { int x; bool ok; };
+    A0_HD static XInfo xinfo(const Params&, int x, int X) { XInfo xi; xi.ok = x < X; xi.x = xi.ok ? x : 0; return xi; }
+    typedef a0_f4 Raw;
+    A0_HD static Raw load(const Params& P, int k, int Kend, const XInfo& xi, bool& ok) {
+        ok = xi.ok && k < Kend;
+        return *(const a0_f4*)(P.x + (ok ? (long long)k * P.ld : 0) + xi.x);
     }
+    A0_HD static a0_f4 finish(Raw v, bool ok) { return a0_f4_select(v, ok); }
 };
 
 // weights seen by a data-gradient GEMM: B(k = (tap, oc), y = c) = W[oc][kh(tap)][kw(tap)][c]
@@ -151,10 +189,14 @@ struct a0_wtab_src { const float* w; const int* wtab; };   // wtab[k] = element 
 struct OpWtabXC {
     static constexpr int MODE = A0_XC;
     typedef a0_wtab_src Params;
-    A0_HD static a0_f4 load(const Params& P, int k, int x, int Kend, int X) {
-        if (k >= Kend || x >= X) return a0_zero4();
-        return *(const a0_f4*)(P.w + P.wtab[k] + x);
+    struct XInfo { int x; bool ok; };
+    A0_HD static XInfo xinfo(const Params&, int x, int X) { XInfo xi; xi.ok = x < X; xi.x = xi.ok ? x : 0; return xi; }
+    typedef a0_f4 Raw;
+    A0_HD static Raw load(const Params& P, int k, int Kend, const XInfo& xi, bool& ok) {
+        ok = xi.ok && k < Kend;
+        return *(const a0_f4*)(P.w + P.wtab[ok ? k : 0] + xi.x);
     }
+    A0_HD static a0_f4 finish(Raw v, bool ok) { return a0_f4_select(v, ok); }
 };
 
 // ------------------------------------------------------------------------------------------------ epilogues

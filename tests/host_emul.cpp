@@ -19,7 +19,7 @@ template <class OP> struct fetcher<OP, A0_KC> {   // element (x, k) for k in [kb
         for (int x = 0; x < X; ++x) {
             typename OP::Row r = OP::row(P, x, X);
             for (int k = kb; k < ke; k += 4) {
-                a0_f4 v = OP::load(P, r, k, ke);
+                bool ok; typename OP::Raw raw = OP::load(P, r, OP::kinfo(P, k, ke), ok); a0_f4 v = OP::finish(raw, ok);
                 float* o = &out[(size_t)x * kc + (k - kb)];
                 o[0] = v.x; if (k + 1 < ke) o[1] = v.y; if (k + 2 < ke) o[2] = v.z; if (k + 3 < ke) o[3] = v.w;
             }
@@ -30,14 +30,16 @@ template <class OP> struct fetcher<OP, A0_XC> {
     static void fill(const typename OP::Params& P, int X, int kb, int ke, std::vector<float>& out) {
         const int kc = ke - kb;
         out.assign((size_t)X * kc, 0.f);
-        for (int k = kb; k < ke; ++k)
-            for (int x = 0; x < X; x += 4) {
-                a0_f4 v = OP::load(P, k, x, ke, X);
+        for (int x = 0; x < X; x += 4) {
+            typename OP::XInfo xi = OP::xinfo(P, x, X);
+            for (int k = kb; k < ke; ++k) {
+                bool ok; typename OP::Raw raw = OP::load(P, k, ke, xi, ok); a0_f4 v = OP::finish(raw, ok);
                 out[(size_t)x * kc + (k - kb)] = v.x;
                 if (x + 1 < X) out[(size_t)(x + 1) * kc + (k - kb)] = v.y;
                 if (x + 2 < X) out[(size_t)(x + 2) * kc + (k - kb)] = v.z;
                 if (x + 3 < X) out[(size_t)(x + 3) * kc + (k - kb)] = v.w;
             }
+        }
     }
 };
 
