@@ -23,25 +23,24 @@ template <class OP, int BX> struct a0_stager<OP, BX, A0_KC> {
     static constexpr int LD = BX + 1;
     typename OP::Row rows[R];
     typename OP::KInfo ki;        // gather-table entry of the tile about to be fetched (loaded one tile ahead)
-    typename OP::Raw raw[R];
-    unsigned okmask;
+    struct Slot { typename OP::Raw raw[R]; unsigned okmask; };
     A0_D void init(const typename OP::Params& P, int x0, int X, int kb, int ke, int tid) {
 #pragma unroll
         for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + (tid >> 3) + 32 * j, X);
         ki = OP::kinfo(P, kb + 4 * (tid & 7), ke);
     }
-    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int tid) {
-        okmask = 0;
+    A0_D void fetch(const typename OP::Params& P, Slot& s, int k0, int ke, int tid) {
+        s.okmask = 0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) { bool ok; raw[j] = OP::load(P, rows[j], ki, ok); okmask |= ok ? (1u << j) : 0u; }
+        for (int j = 0; j < R; ++j) { bool ok; s.raw[j] = OP::load(P, rows[j], ki, ok); s.okmask |= ok ? (1u << j) : 0u; }
         ki = OP::kinfo(P, k0 + 32 + 4 * (tid & 7), ke);     // for the NEXT fetch; its latency hides behind this tile's MFMAs
     }
-    A0_D void commit(float* lds, int tid) const {
+    A0_D void commit(const Slot& s, float* lds, int tid) const {
         const int kk = 4 * (tid & 7);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int r = (tid >> 3) + 32 * j;
-            const a0_f4 v = OP::finish(raw[j], (okmask >> j) & 1u);
+            const a0_f4 v = OP::finish(s.raw[j], (s.okmask >> j) & 1u);
             lds[(kk + 0) * LD + r] = v.x;
             lds[(kk + 1) * LD + r] = v.y;
             lds[(kk + 2) * LD + r] = v.z;
@@ -55,22 +54,21 @@ template <class OP, int BX> struct a0_stager<OP, BX, A0_XC> {
     static constexpr int LD = BX + 4;
     static constexpr int Q = BX / 4;   // 16-byte groups per k row
     typename OP::XInfo xi[R];
-    typename OP::Raw raw[R];
-    unsigned okmask;
+    struct Slot { typename OP::Raw raw[R]; unsigned okmask; };
     A0_D void init(const typename OP::Params& P, int x0, int X, int, int, int tid) {
 #pragma unroll
         for (int j = 0; j < R; ++j) xi[j] = OP::xinfo(P, x0 + 4 * ((tid + 256 * j) % Q), X);
     }
-    A0_D void fetch(const typename OP::Params& P, int k0, int ke, int tid) {
-        okmask = 0;
+    A0_D void fetch(const typename OP::Params& P, Slot& s, int k0, int ke, int tid) {
+        s.okmask = 0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) { bool ok; raw[j] = OP::load(P, k0 + (tid + 256 * j) / Q, ke, xi[j], ok); okmask |= ok ? (1u << j) : 0u; }
+        for (int j = 0; j < R; ++j) { bool ok; s.raw[j] = OP::load(P, k0 + (tid + 256 * j) / Q, ke, xi[j], ok); s.okmask |= ok ? (1u << j) : 0u; }
     }
-    A0_D void commit(float* lds, int tid) const {
+    A0_D void commit(const Slot& s, float* lds, int tid) const {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int f = tid + 256 * j;
-            *(a0_f4*)&lds[(f / Q) * LD + 4 * (f % Q)] = OP::finish(raw[j], (okmask >> j) & 1u);
+            *(a0_f4*)&lds[(f / Q) * LD + 4 * (f % Q)] = OP::finish(s.raw[j], (s.okmask >> j) & 1u);
         }
     }
 };
@@ -106,17 +104,17 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kb < ke) { sa.fetch(pa, kb, ke, tid); sb.fetch(pb, kb, ke, tid); }
+    // Two tiles of global loads stay in flight: tile t+2 is requested right after tile t has been committed to LDS, so
+    // its latency is covered by the MFMAs of tiles t and t+1 (one tile of cover is not enough at 1-3 waves per SIMD).
+    typename SA::Slot sa0, sa1;
+    typename SB::Slot sb0, sb1;
+    if (kb < ke) { sa.fetch(pa, sa0, kb, ke, tid); sb.fetch(pb, sb0, kb, ke, tid); }
+    if (kb + BK < ke) { sa.fetch(pa, sa1, kb + BK, ke, tid); sb.fetch(pb, sb1, kb + BK, ke, tid); }
 
     const float* ap = As + (lane >> 5) * LDA + wm * (MT * 32) + (lane & 31);
     const float* bp = Bs + (lane >> 5) * LDB + wn * (NT * 32) + (lane & 31);
 
-    for (int k0 = kb; k0 < ke; k0 += BK) {
-        __syncthreads();                 // every wave is done reading the previous tile
-        sa.commit(As, tid);
-        sb.commit(Bs, tid);
-        __syncthreads();
-        if (k0 + BK < ke) { sa.fetch(pa, k0 + BK, ke, tid); sb.fetch(pb, k0 + BK, ke, tid); }
+    auto mma_tile = [&]() {
         // fragment reads run one k-step ahead of the MFMAs that consume them
         float a[2][MT], b[2][NT];
 #pragma unroll
@@ -138,6 +136,22 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
+        __syncthreads();                 // every wave is done reading the previous tile
+        sa.commit(sa0, As, tid);
+        sb.commit(sb0, Bs, tid);
+        __syncthreads();
+        if (k0 + 2 * BK < ke) { sa.fetch(pa, sa0, k0 + 2 * BK, ke, tid); sb.fetch(pb, sb0, k0 + 2 * BK, ke, tid); }
+        mma_tile();
+        if (k0 + BK >= ke) break;
+        __syncthreads();
+        sa.commit(sa1, As, tid);
+        sb.commit(sb1, Bs, tid);
+        __syncthreads();
+        if (k0 + 3 * BK < ke) { sa.fetch(pa, sa1, k0 + 3 * BK, ke, tid); sb.fetch(pb, sb1, k0 + 3 * BK, ke, tid); }
+        mma_tile();
     }
 
     // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)

@@ -61,11 +61,60 @@ static inline int a0_grid_for(long long count, int block = 256, int cap = 2048) 
     return (int)g;
 }
 
+// ------------------------------------------------------------------------------------------------ profiler probe
+// bench.py brackets every launch of ONE tagged GEMM with HIP events on the stream the kernel runs on, so that its
+// average duration (and hence achieved FLOP/s against the fp32 MFMA roofline) is measured live inside the timed region.
+struct a0_probe_t {
+    int tag = 0;
+    std::vector<hipEvent_t> ev;     // pairs: start, stop
+    size_t used = 0;
+    double flops = 0.0;
+};
+static a0_probe_t g_probe;
+
+extern "C" int a0_probe_begin(int tag, int max_launches) {
+    A0_TRY
+    for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);
+    g_probe.ev.clear();
+    g_probe.used = 0; g_probe.flops = 0.0; g_probe.tag = 0;
+    if (tag <= 0 || max_launches <= 0) return A0_OK;
+    g_probe.ev.resize(2 * (size_t)max_launches);
+    for (auto& e : g_probe.ev) A0_HIP_THROW(hipEventCreate(&e));
+    g_probe.tag = tag;
+    return A0_OK;
+    A0_CATCH
+}
+
+// host_out3: [launches, total milliseconds, total algorithmic FLOP]; synchronises on the recorded events
+extern "C" int a0_probe_end(double* host_out3) {
+    A0_TRY
+    if (!host_out3) return a0_fail(A0_EINVAL, "a0_probe_end: null");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_probe.used; i += 2) {
+        A0_HIP_THROW(hipEventSynchronize(g_probe.ev[i + 1]));
+        float t = 0.f;
+        A0_HIP_THROW(hipEventElapsedTime(&t, g_probe.ev[i], g_probe.ev[i + 1]));
+        ms += t;
+    }
+    host_out3[0] = (double)(g_probe.used / 2); host_out3[1] = ms; host_out3[2] = g_probe.flops;
+    g_probe.tag = 0;
+    return A0_OK;
+    A0_CATCH
+}
+
 struct a0_hip_backend {
     hipStream_t st;
+    int tag = 0;
     template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
     void igemm(const typename OA::Params& pa, const typename OB::Params& pb, const typename EP::Params& pe, int X, int Y, int K, int splits) {
+        const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
+        if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
         A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+        if (probe) {
+            A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
+            g_probe.used += 2;
+            g_probe.flops += 2.0 * (double)X * (double)Y * (double)K;
+        }
     }
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
         hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3(a0_grid_for(count)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);

@@ -14,6 +14,10 @@
 #include "operands.h"
 #include "../../include/agent0_hip.h"
 
+// layer tags: set on the backend before each GEMM so a profiler probe can single out one kernel (bench.py roofline)
+enum { A0_TAG_NONE = 0, A0_TAG_CONV1_FWD = 1, A0_TAG_CONV2_FWD = 2, A0_TAG_CONV3_FWD = 3, A0_TAG_DENSE_FWD = 4, A0_TAG_DENSE_DGRAD = 5,
+       A0_TAG_DENSE_WGRAD = 6, A0_TAG_CONV3_WGRAD = 7, A0_TAG_CONV3_DGRAD = 8, A0_TAG_CONV2_WGRAD = 9, A0_TAG_CONV2_DGRAD = 10, A0_TAG_CONV1_WGRAD = 11 };
+
 // weight-gradient epilogue: slab z of the layer's [W | b] block
 struct EpiWgradSlab {
     struct Params { float* out; long long slab_stride; int ld; };
@@ -100,12 +104,14 @@ static void a0_encoder_fwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_frames_src a = a0_frames(n, f);
         a0_mat_src b{w.w1, n.K1};
         EpiBiasAct::Params e{act1, w.b1, 32, 1};
+        bk.tag = A0_TAG_CONV1_FWD;
         bk.template igemm<OpFramesKC, OpMatKC, EpiBiasAct, 4, 1, 1, 1>(a, b, e, B * n.H1 * n.W1, 32, n.K1, 1);
     }
     {
         a0_act_src a = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
         a0_mat_src b{w.w2, n.K2};
         EpiBiasAct::Params e{act2, w.b2, 64, 1};
+        bk.tag = A0_TAG_CONV2_FWD;
         bk.template igemm<OpActKC, OpMatKC, EpiBiasAct, 4, 1, 1, 2>(a, b, e, B * n.H2 * n.W2, 64, n.K2, 1);
     }
     {
@@ -113,6 +119,7 @@ static void a0_encoder_fwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_mat_src b{w.w3, n.K3};
         EpiBiasAct::Params e{act3, w.b3, 64, 1};
         const int M = B * n.H3 * n.W3;
+        bk.tag = A0_TAG_CONV3_FWD;
         if (M <= 128 * 160)   // small batches (actor): 64-row tiles keep more CUs busy
             bk.template igemm<OpActKC, OpMatKC, EpiBiasAct, 2, 2, 1, 1>(a, b, e, M, 64, n.K3, 1);
         else
@@ -128,6 +135,7 @@ static void a0_dense_fwd_impl(BK& bk, const float* X, int ldx, const float* W, c
     a0_mat_src bw{W, K};
     const int splits = a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
     const bool narrow = (N <= 32);
+    bk.tag = A0_TAG_DENSE_FWD;
     if (splits == 1) {
         EpiBiasAct::Params e{Y, b, N, relu};
         if (narrow) bk.template igemm<OpMatKC, OpMatKC, EpiBiasAct, 4, 1, 1, 1>(a, bw, e, R, N, K, 1);
@@ -144,6 +152,7 @@ template <class BK>
 static void a0_dense_dgrad_impl(BK& bk, const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K) {
     a0_mat_src a{dY, N};
     a0_mat_src bw{W, K};
+    bk.tag = A0_TAG_DENSE_DGRAD;
     if (act_mask) {
         EpiMaskMat::Params e{dX, act_mask, K};
         bk.template igemm<OpMatKC, OpMatXC, EpiMaskMat, 4, 1, 1, 2>(a, bw, e, R, K, N, 1);
@@ -169,6 +178,7 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
     a0_mat_src a{dY, N};
     a0_mat_src b{X, ldx};
     EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K};
+    bk.tag = A0_TAG_DENSE_WGRAD;
     bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
     a0_finish_wgrad(bk, dY, R, N, wcount, grad, slabs, splits);
 }
@@ -186,6 +196,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_mat_src a{d3, 64};
         a0_act_src b = a0_act(act2, n.H2, n.W2, 64, n.H3, n.W3, 1, 0, n.ktab3);
         EpiWgradSlab::Params e{splits > 1 ? slabs : g3, splits > 1 ? wc + 64 : 0, n.K3};
+        bk.tag = A0_TAG_CONV3_WGRAD;
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
         a0_finish_wgrad(bk, d3, M3, 64, wc, g3, slabs, splits);
     }
@@ -193,6 +204,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_act_src a = a0_act(d3, n.H3, n.W3, 64, n.H2, n.W2, 1, 2, n.ktab_d3);
         a0_wtab_src b{w.w3, n.wtab_d3};
         EpiDgrad::Params e{d2, act2, n.H2 * n.W2, n.W2, n.H2, n.W2, 64, 1, 0, 0, (long long)n.H2 * n.W2 * 64};
+        bk.tag = A0_TAG_CONV3_DGRAD;
         bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 2>(a, b, e, M2, 64, 9 * 64, 1);
     }
     {   // conv2 weight gradient
@@ -201,6 +213,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_mat_src a{d2, 64};
         a0_act_src b = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
         EpiWgradSlab::Params e{splits > 1 ? slabs : g2, splits > 1 ? wc + 64 : 0, n.K2};
+        bk.tag = A0_TAG_CONV2_WGRAD;
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K2, M2, splits);
         a0_finish_wgrad(bk, d2, M2, 64, wc, g2, slabs, splits);
     }
@@ -212,6 +225,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
             a0_act_src a = a0_act(d2, n.H2, n.W2, 64, Hv, Wv, 1, 1, n.ktab_d2);
             a0_wtab_src b{w.w2, n.wtab_d2[ph * 2 + pw]};
             EpiDgrad::Params e{d1, act1, Hv * Wv, Wv, n.H1, n.W1, 32, 2, ph, pw, (long long)n.H1 * n.W1 * 32};
+            bk.tag = A0_TAG_CONV2_DGRAD;
             bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 1>(a, b, e, B * Hv * Wv, 32, 4 * 64, 1);
         }
     {   // conv1 weight gradient (the input is data: no data gradient)
@@ -220,6 +234,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_mat_src a{d1, 32};
         a0_frames_src b = a0_frames(n, f);
         EpiWgradSlab::Params e{splits > 1 ? slabs : g1, splits > 1 ? wc + 32 : 0, n.K1};
+        bk.tag = A0_TAG_CONV1_WGRAD;
         bk.template igemm<OpMatXC, OpFramesXC, EpiWgradSlab, 1, 4, 1, 1>(a, b, e, 32, n.K1, M1, splits);
         a0_finish_wgrad(bk, d1, M1, 32, wc, g1, slabs, splits);
     }

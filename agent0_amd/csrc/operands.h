@@ -40,13 +40,27 @@ A0_HD uint32_t a0_u8x4_load(const uint8_t* p, int aligned4) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
+// x / 255.0f for an integer 0 <= x <= 255, correctly rounded (== the fp32 division of the reference, checked exhaustively
+// in tests/test_oracle_core.py) in three instructions: one Newton correction of x * fl(1/255)
+A0_HD float a0_div255(float x) {
+    const float r = 1.0f / 255.0f;
+    const float q0 = x * r;
+#if defined(__HIPCC__)
+    const float e = __builtin_fmaf(-q0, 255.0f, x);
+    return __builtin_fmaf(e, r, q0);
+#else
+    const float e = __builtin_fmaf(-q0, 255.0f, x);
+    return __builtin_fmaf(e, r, q0);
+#endif
+}
+
 A0_HD a0_f4 a0_u8x4_to_f4(uint32_t w, bool valid) {
     if (!valid) w = 0;
     a0_f4 v;
-    v.x = (float)(w & 255u) / 255.0f;
-    v.y = (float)((w >> 8) & 255u) / 255.0f;
-    v.z = (float)((w >> 16) & 255u) / 255.0f;
-    v.w = (float)(w >> 24) / 255.0f;
+    v.x = a0_div255((float)(w & 255u));
+    v.y = a0_div255((float)((w >> 8) & 255u));
+    v.z = a0_div255((float)((w >> 16) & 255u));
+    v.w = a0_div255((float)(w >> 24));
     return v;
 }
 

@@ -310,6 +310,19 @@ class HipOps:
                                          _req(truncated, torch.float32, E, "truncated"), _req(life_loss, torch.float32, E, "life_loss"),
                                          _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), _stream()), "a0_env_synth_step")
 
+    # ------------------------------------------------------------------ measurement
+    PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
+                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11}
+
+    def probe_begin(self, name: str, max_launches: int = 8192):
+        self._probe_name = name
+        check(self.lib.a0_probe_begin(self.PROBE_TAGS[name], max_launches), "a0_probe_begin")
+
+    def probe_end(self):
+        out = (C.c_double * 3)()
+        check(self.lib.a0_probe_end(C.addressof(out)), "a0_probe_end")
+        return {"kernel": self._probe_name, "launches": int(out[0]), "ms": float(out[1]), "flop": float(out[2])}
+
     def device_info(self):
         cu = C.c_int()
         mem = C.c_longlong()

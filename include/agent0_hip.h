@@ -70,6 +70,12 @@ int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float
 long long a0_dense_wgrad_scratch(int R, int N, int K);
 int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
 
+/* measurement hook for bench.py: HIP events around every launch of the GEMM tagged `tag` (1 conv1 fwd, 2 conv2 fwd, 3 conv3 fwd,
+ * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad), recorded on the
+ * launch stream.  a0_probe_end writes host_out3 = {launches, total ms, total algorithmic FLOP (2*M*N*K)}. */
+int a0_probe_begin(int tag, int max_launches);
+int a0_probe_end(double* host_out3);
+
 /* ---------------------------------------------------------------- heads and losses */
 /* dueling combine (model.py:127-130,168-172,228-231): raw [R][ld] = [A*T advantages | T values | pad] -> q [R][A][T] */
 int a0_dueling_fwd(const float* raw, int ld, float* q, int R, int A, int T, int dueling, void* stream);

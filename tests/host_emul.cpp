@@ -44,6 +44,7 @@ template <class OP> struct fetcher<OP, A0_XC> {
 };
 
 struct host_backend {
+    int tag = 0;
     template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
     void igemm(const typename OA::Params& pa, const typename OB::Params& pb, const typename EP::Params& pe, int X, int Y, int K, int splits) {
         if (splits < 1) splits = 1;

@@ -1,0 +1,131 @@
+"""CPU: the C-ABI library loads and exports every symbol include/agent0_hip.h declares (no compute without a GPU); host-side
+logic of the product (config overrides, schedules, layout maths); isolation of the oracle from the product path."""
+import ast
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from agent0_amd import _abi
+    protos = _abi.parse_header()
+    names = [n for _, n, _ in protos]
+    assert len(names) == len(set(names)) and len(names) >= 55
+    assert os.path.exists(_abi.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    missing = [n for n in names if n not in exported]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    lib = _abi.load()                       # dlopen + argtypes for every prototype; works without a GPU
+    assert lib.a0_abi_version() == 1
+    # argument validation happens before any HIP call, so it is testable here
+    assert lib.a0_dense_fwd(None, 4, None, None, None, 1, 4, 4, 0, None, None) == -1
+    assert "a0_dense_fwd" in _abi.last_error()
+    assert lib.a0_sumtree_set(None, 3, None, None, 1, None) == -1 and "power of two" in _abi.last_error()
+
+
+def test_gfx950_code_object_only():
+    from agent0_amd import _abi
+    blob = open(_abi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob and b"sm_" not in blob
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from agent0_amd._abi import A0Error
+    from agent0_amd.ops import HipOps
+    with pytest.raises(A0Error, match="needs an AMD GPU"):
+        HipOps()
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    cfg = parse_overrides(["device=cpu", "wandb=false", "tb=false"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Trainer(cfg)
+
+
+def test_config_overrides_and_aliases():
+    from agent0_amd.deepq import config as C
+    cfg = C.parse_overrides(["env_id=Enduro", "learner.algo=iqr", "learner.double_q=true", "learner.dueling_head=True", "learner.noisy_net=1",
+                             "learner.n_step_q=3", "replay.policy=prioritize", "actor.num_envs=256", "replay.size=1000000", "device=cuda",
+                             "wandb=false", "tb=false", "trainer.total_steps=1e6", "learner.c51.vmax=20", "learner.iqn.N=32", "seed=7"])
+    assert cfg.env_id == "Enduro" and cfg.learner.algo is C.AlgoEnum.iqn and cfg.learner.double_q and cfg.learner.dueling_head and cfg.learner.noisy_net
+    assert cfg.learner.n_step_q == 3 and cfg.replay.policy is C.ReplayEnum.prioritize and cfg.actor.num_envs == 256 and cfg.replay.size == 10**6
+    assert cfg.trainer.total_steps == 10**6 and cfg.learner.c51.vmax == 20.0 and cfg.learner.iqn.N == 32 and cfg.seed == 7 and not cfg.wandb
+    with pytest.raises(KeyError):
+        C.parse_overrides(["learner.nope=1"])
+    with pytest.raises(ValueError):
+        C.parse_overrides(["learner.algo=sarsa"])
+    # reference defaults, field for field (agent0/deepq/config.py:72-145)
+    d = C.ExpConfig()
+    assert (d.learner.discount, d.learner.batch_size, d.learner.learning_rate, d.learner.target_update_freq, d.learner.learner_steps) == (0.99, 512, 5e-4, 500, 20)
+    assert (d.trainer.total_steps, d.trainer.training_start_steps, d.trainer.exploration_steps) == (10**7, 10**5, 10**6)
+    assert (d.actor.num_envs, d.actor.sample_steps, d.actor.min_eps, d.actor.test_eps) == (16, 80, 0.01, 0.001)
+    assert (d.replay.size, d.replay.beta0, d.replay.alpha, d.replay.eps) == (10**6, 0.4, 0.5, 0.01)
+    assert (d.learner.iqn.K, d.learner.iqn.N, d.learner.iqn.N_dash, d.learner.iqn.num_cosines, d.learner.iqn.F) == (32, 64, 64, 64, 32)
+    assert d.num_actors == 3 and d.seed == 42 and d.env_id == "Breakout"
+    rt = C.from_dict(C.to_dict(cfg))
+    assert C.to_dict(rt) == C.to_dict(cfg)
+
+
+def test_schedules_match_golden():
+    from agent0_amd.common.utils import LinearSchedule
+    from agent0_amd.deepq.config import ExpConfig
+    from agent0_amd.deepq.trainer import epsilon_schedule
+    from util import golden
+    g = golden("g9_schedules")
+    s = LinearSchedule(0.4, 1.0, 1e7)
+    assert np.array_equal(np.array([s(1280) for _ in range(6)]), g["lin_a"])
+    s = LinearSchedule(1.0, 0.1, 10)
+    assert np.array_equal(np.array([s() for _ in range(14)]), g["lin_c"])
+    eps = epsilon_schedule(ExpConfig())
+    assert np.array_equal(np.array([eps(int(t)) for t in g["eps_steps"]]), g["eps"])
+
+
+def _imports(path):
+    tree = ast.parse(open(path).read(), path)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            for a in node.names:
+                yield a.name
+        elif isinstance(node, ast.ImportFrom) and node.module:
+            yield ("." * node.level) + node.module
+
+
+def test_product_never_imports_the_oracle_or_the_emulation():
+    bad = []
+    for pkg in ("agent0_amd", "agent0"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith(".py"):
+                    p = os.path.join(dirpath, f)
+                    src = open(p).read()
+                    for mod in _imports(p):
+                        if mod.split(".")[0] in ("oracle", "cpu_ops", "tests", "recipe"):
+                            bad.append((p, mod))
+                    assert "liba0oracle" not in src and "host_emul" not in src, p
+    assert not bad, f"product code must not import test infrastructure: {bad}"
+    # nothing at run time reads the reference tree
+    for rel in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(ROOT, rel)).read()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "agent0_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "sys.path.insert(0, \"/root/reference\")" not in src and "import_reference" not in src
+
+
+def test_u8_division_shortcut_is_exact():
+    """x/255 via one Newton correction (operands.h a0_div255) equals the fp32 division for every byte value."""
+    x = np.arange(256, dtype=np.float32)
+    r = np.float32(1.0) / np.float32(255.0)
+    q0 = x * r
+    e = np.float32(x.astype(np.float64) - q0.astype(np.float64) * 255.0)          # fma(-q0, 255, x): exact in fp64, then one rounding
+    q = (q0.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
+    assert np.array_equal(q, x / np.float32(255.0))
