@@ -60,6 +60,10 @@ class DeviceRng:
     def normal(self, stream: int, std: float, out: torch.Tensor, n: int):
         self.ops.rng_normal(self.seed, stream, self._advance(stream, n), std, out, n)
 
+    def reserve(self, stream: int, n: int) -> int:
+        """Claims ``n`` draws of ``stream`` for a kernel that generates them itself; returns their offset."""
+        return self._advance(stream, n)
+
     def next_seed32(self, stream: int) -> int:
         off = self._advance(stream, 4)
         return (self.seed * 0x9E3779B1 + off * 0x85EBCA77 + stream) & 0xFFFFFFFF

@@ -3,6 +3,7 @@
 // deque(maxlen=n) that is never cleared, quirk Q9).  n-step sums are carried in fp64 like the reference's numpy
 // arrays and rounded to fp32 once, where the reference's Trainer casts them (trainer.py:88-90).
 #include "a0_internal.h"
+#include "philox.h"
 
 #pragma clang fp contract(off)
 
@@ -27,6 +28,33 @@ extern "C" int a0_actor_egreedy(const int* greedy, const int* rand_action, const
     if (!greedy || !rand_action || !u || !action || E < 1) return a0_fail(A0_EINVAL, "a0_actor_egreedy: bad argument");
     hipLaunchKernelGGL(a0_egreedy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, greedy, rand_action, u, eps, E, action, qmax, qs_out);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_egreedy");
+}
+
+// Same selection with the two draws generated in-kernel from the Philox streams (element e of stream_a / stream_u at the
+// given offsets — identical values to a0_rng_randint + a0_rng_uniform followed by a0_actor_egreedy, in one launch).
+__global__ __launch_bounds__(256) void a0_egreedy_rng_kernel(const int* __restrict__ greedy, unsigned long long seed, uint32_t stream_a, uint32_t stream_u,
+                                                              unsigned long long off_a, unsigned long long off_u, int A, float eps, int E,
+                                                              int* __restrict__ action, const float* __restrict__ qmax, float* __restrict__ qs_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const int ra = (int)(a0_philox_word(seed, stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
+        const float u = (float)(a0_philox_word(seed, stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
+        action[e] = (u > eps) ? greedy[e] : ra;
+        if (qmax) s += qmax[e];
+    }
+    if (!qs_out) return;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) qs_out[0] = red[0] / (float)E;
+}
+
+extern "C" int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                    unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out, void* stream) {
+    if (!greedy || !action || E < 1 || A < 1) return a0_fail(A0_EINVAL, "a0_actor_egreedy_rng: bad argument");
+    hipLaunchKernelGGL(a0_egreedy_rng_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, greedy, seed, stream_a, stream_u, off_a, off_u, A, eps, E, action, qmax, qs_out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_egreedy_rng");
 }
 
 // Ring of the last n (action, reward, done) per env; entry for step t lives at t % n.

@@ -8,14 +8,23 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------ small kernels
-__global__ void a0_reduce_slabs_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab,
-                                       float* __restrict__ out, long long count) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < count; i += stride) {
-        float s = 0.f;
-        for (int z = 0; z < nslab; ++z) s += slabs[(long long)z * slab_stride + i];
-        out[i] = s;
+// out[i] = sum_z slabs[z][i].  One workgroup per 32 consecutive outputs; its 8 row-groups stride over z and are combined in a
+// fixed order through LDS, so the sum is deterministic and 8 slab rows are in flight per output column.
+__global__ __launch_bounds__(256) void a0_reduce_slabs_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab,
+                                                               float* __restrict__ out, long long count) {
+    __shared__ float red[8][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (i < count)
+        for (int z = g; z < nslab; z += 8) s += slabs[(long long)z * slab_stride + i];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][c];
+        out[i] = t;
     }
 }
 
@@ -117,7 +126,7 @@ struct a0_hip_backend {
         }
     }
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
-        hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3(a0_grid_for(count)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);
+        hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);
         A0_HIP_THROW(hipGetLastError());
     }
     void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu) {

@@ -66,7 +66,7 @@ class Actor:
     # ------------------------------------------------------------------ agent.py:25-39
     def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor]):
         L, ops, E, dev = self.L, self.ops, self.E, self.model._dev
-        dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E)
+        dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E, keep=False)
         if L.algo == "fqf":
             dev.fqf_taus(self.ws, E)
             dev.head(self.ws, E, self.ws.tau_hat, L.F)
@@ -76,9 +76,11 @@ class Actor:
         else:
             dev.head(self.ws, E)
         dev.select(self.ws, E, self.n_tau, self.greedy, qmax=self.qmax, atoms=self.atoms)
-        self.rng.randint(self.rng.STREAM_EGREEDY_A, L.A, self.rand_a, E)       # draw order as the reference: randint, then rand
-        self.rng.uniform(self.rng.STREAM_EGREEDY_U, self.u, E)
-        ops.actor_egreedy(self.greedy, self.rand_a, self.u, float(epsilon), E, self.action, self.qmax, qs_slot)
+        # the reference draws randint(0, A, E) and then rand(E) (agent.py:29-36): both come from their own Philox stream, generated
+        # inside the selection kernel
+        rng = self.rng
+        ops.actor_egreedy_rng(self.greedy, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U, rng.reserve(rng.STREAM_EGREEDY_A, E),
+                              rng.reserve(rng.STREAM_EGREEDY_U, E), L.A, float(epsilon), E, self.action, self.qmax, qs_slot)
 
     def act(self, epsilon):
         one = self.ops.zeros(1)
@@ -110,11 +112,9 @@ class Actor:
             if self.n > 1:
                 slot = self.steps % self.n
                 self.ring_obs[slot * E * self.obs_bytes:(slot + 1) * E * self.obs_bytes].copy_(cur_obs)
-            obs_next, reward, terminal, truncated, info = self.envs.step(self.action)
+            obs_next, reward, terminal, truncated, info = self.envs.step(self.action, final_mask=self.stat_mask[t * E:(t + 1) * E], final_ret=self.stat_ret[t * E:(t + 1) * E])
             ops.actor_nstep(E, self.n, self.steps, float(cfg.learner.discount), self.action, reward, terminal, truncated, info.get("life_loss"),
                             self.ring_act, self.ring_rew, self.ring_done, self.out_act, self.out_rew, self.out_done)
-            self.stat_mask[t * E:(t + 1) * E].copy_(info["final_mask"])
-            self.stat_ret[t * E:(t + 1) * E].copy_(info["final_ret"])
             if self.n > 1:
                 count = min(self.steps + 1, self.n)
                 oldest = (self.steps - (count - 1)) % self.n

@@ -67,6 +67,13 @@ class DeviceNet:
         for prefix, block, r0, r1, in_f in L.noise_modules:
             self.noise[prefix] = {"noise_in": ops.zeros(in_f), "noise_out_weight": ops.zeros(r1 - r0), "noise_out_bias": ops.zeros(r1 - r0)}
         self._scratch: Optional[torch.Tensor] = None
+        # fused per-observation encoder (encoder_fused.hip): needs k-major copies of the conv weights, refreshed when they change
+        self.fused = bool(ops.fused_supported(L.C, L.H, L.W))
+        self.wt = ops.zeros(ops.conv_wt_floats(L.C)) if self.fused else None
+
+    def refresh_wt(self):
+        if self.fused:
+            self.ops.conv_wt_refresh(self.encoder_weights(), self.L.C, self.wt)
 
     # ------------------------------------------------------------------ weights
     def block(self, name: str) -> Block:
@@ -106,6 +113,7 @@ class DeviceNet:
         dev = self.flat.device
         sd = {k: torch.as_tensor(v).to(dev) for k, v in sd.items()}
         self.L.pack(sd, self.flat)
+        self.refresh_wt()
         for prefix, *_ in self.L.noise_modules:
             if f"{prefix}.noise_in" in sd:
                 self.set_noise(prefix, sd[f"{prefix}.noise_in"], sd[f"{prefix}.noise_out_weight"], sd[f"{prefix}.noise_out_bias"])
@@ -134,8 +142,13 @@ class DeviceNet:
         return self._scratch
 
     # ------------------------------------------------------------------ forward
-    def encode(self, ws: Workspace, frames, slot, sample_stride, chan_off, B):
-        self.ops.encoder_fwd(self.net, self.encoder_weights(), frames, slot, sample_stride, chan_off, B, ws.act1, ws.act2, ws.act3)
+    def encode(self, ws: Workspace, frames, slot, sample_stride, chan_off, B, keep: bool = True):
+        """frames -> act3 (and act1/act2 when ``keep``: only a pass that is differentiated needs them in HBM)."""
+        if self.fused:
+            self.ops.encoder_fwd_fused(self.net, self.wt, self.encoder_weights(), frames, slot, sample_stride, chan_off, B,
+                                       ws.act1 if keep else None, ws.act2 if keep else None, ws.act3)
+        else:
+            self.ops.encoder_fwd(self.net, self.encoder_weights(), frames, slot, sample_stride, chan_off, B, ws.act1, ws.act2, ws.act3)
 
     def _dense(self, X, ldx, name, Y, R, relu):
         W, b = self.wb(name)
@@ -244,6 +257,7 @@ class DeviceLearner:
     # ------------------------------------------------------------------ helpers
     def sync_target(self, force=True):
         self.ops.target_sync(self.target.flat, self.online.flat, self.L.n_params_padded, self.state, force)
+        self.target.refresh_wt()
 
     def _grad(self, name: str) -> torch.Tensor:
         L = self.L
@@ -294,10 +308,10 @@ class DeviceLearner:
         wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
         frac = None
         if algo in ("dqn", "c51", "qr"):
-            tg.encode(wt, frames, slot, sample_stride, nxt, B)
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             tg.head(wt, B)
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B)
+                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 on.head(wsel, B)
                 on.select(wsel, B, 1, self.a_star, atoms=getattr(self, "atoms", None))
             else:
@@ -316,9 +330,9 @@ class DeviceLearner:
         elif algo == "iqn":
             t_sel, t_tgt, t_on = rand
             K, Nd, N = self.K, self.N_dash, self.N
-            tg.encode(wt, frames, slot, sample_stride, nxt, B)
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B)
+                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 on.head(wsel, B, t_sel, K)
                 on.select(wsel, B, K, self.a_star)
             else:
@@ -335,9 +349,9 @@ class DeviceLearner:
             on.encode(wo, frames, slot, sample_stride, 0, B)
             on.fqf_taus(wo, B)
             on.head(wo, B, wo.tau_hat, F)
-            tg.encode(wt, frames, slot, sample_stride, nxt, B)
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B)
+                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 on.fqf_taus(wsel, B)
                 on.head(wsel, B, wsel.tau_hat, F)
                 on.select(wsel, B, F, self.a_star)
@@ -365,5 +379,6 @@ class DeviceLearner:
         if self.grad_hook is not None:
             self.grad_hook(self.grads, self.state)
         ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
+        on.refresh_wt()
         self.sync_target(force=False)
         return (self.loss, frac) if frac is not None else self.loss

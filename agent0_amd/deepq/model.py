@@ -202,7 +202,7 @@ class DeepQNet(nn.Module):
         obs_bytes = L.C * L.H * L.W
         if L.algo == "fqf":
             ws = self._workspace(B, L.F)
-            dev.encode(ws, u8.reshape(-1), None, obs_bytes, 0, B)
+            dev.encode(ws, u8.reshape(-1), None, obs_bytes, 0, B, keep=False)
             dev.fqf_taus(ws, B)
             dev.head(ws, B, ws.tau_hat, L.F)
             return ws, B, L.F, ws.tau_hat
@@ -210,11 +210,11 @@ class DeepQNet(nn.Module):
             n = taus.shape[1] if taus is not None else (n or self.cfg.learner.iqn.K)
             ws = self._workspace(B, n)
             t = self._taus(B, n, taus)
-            dev.encode(ws, u8.reshape(-1), None, obs_bytes, 0, B)
+            dev.encode(ws, u8.reshape(-1), None, obs_bytes, 0, B, keep=False)
             dev.head(ws, B, t, n)
             return ws, B, n, t
         ws = self._workspace(B, 1)
-        dev.encode(ws, u8.reshape(-1), None, obs_bytes, 0, B)
+        dev.encode(ws, u8.reshape(-1), None, obs_bytes, 0, B, keep=False)
         dev.head(ws, B)
         return ws, B, 1, None
 

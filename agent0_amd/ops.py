@@ -99,6 +99,24 @@ class HipOps:
         a3 = _req(act3, torch.float32, B * net.feat, "act3")
         check(self.lib.a0_net_encoder_fwd(net.h, C.addressof(ew), C.addressof(fa), B, a1, a2, a3, _stream()), "a0_net_encoder_fwd")
 
+    def fused_supported(self, C_, H, W) -> bool:
+        return bool(self.lib.a0_net_encoder_fused_supported(C_, H, W))
+
+    def conv_wt_floats(self, C_) -> int:
+        return int(self.lib.a0_net_conv_wt_floats(C_))
+
+    def conv_wt_refresh(self, w, C_, wt):
+        ew = self._enc_w(w)
+        check(self.lib.a0_net_conv_wt_refresh(C.addressof(ew), C_, _req(wt, torch.float32, self.conv_wt_floats(C_), "wt"), _stream()), "a0_net_conv_wt_refresh")
+
+    def encoder_fwd_fused(self, net, wt, w, frames, slot, sample_stride, chan_off, B, act1, act2, act3):
+        fa = self._frames(net, frames, slot, sample_stride, chan_off, B)
+        ew = self._enc_w(w)
+        check(self.lib.a0_net_encoder_fwd_fused(net.C, net.H, net.W, _req(wt, torch.float32, self.conv_wt_floats(net.C), "wt"), C.addressof(ew), C.addressof(fa), B,
+                                                _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1", optional=True),
+                                                _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2", optional=True),
+                                                _req(act3, torch.float32, B * net.feat, "act3"), _stream()), "a0_net_encoder_fwd_fused")
+
     def encoder_bwd_scratch(self, net, B) -> int:
         return int(self.lib.a0_net_encoder_bwd_scratch(net.h, B))
 
@@ -279,6 +297,11 @@ class HipOps:
         check(self.lib.a0_actor_egreedy(_req(greedy, torch.int32, E, "greedy"), _req(rand_action, torch.int32, E, "rand_action"), _req(u, torch.float32, E, "u"), eps, E,
                                         _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax", optional=True),
                                         _req(qs_out, torch.float32, 1, "qs_out", optional=True), _stream()), "a0_actor_egreedy")
+
+    def actor_egreedy_rng(self, greedy, seed, stream_a, stream_u, off_a, off_u, A, eps, E, action, qmax, qs_out):
+        check(self.lib.a0_actor_egreedy_rng(_req(greedy, torch.int32, E, "greedy"), seed, stream_a, stream_u, off_a, off_u, A, eps, E,
+                                            _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax", optional=True),
+                                            _req(qs_out, torch.float32, 1, "qs_out", optional=True), _stream()), "a0_actor_egreedy_rng")
 
     def actor_nstep(self, E, n, steps, gamma, action, reward, terminal, truncated, life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done):
         check(self.lib.a0_actor_nstep(E, n, steps, gamma, _req(action, torch.int32, E, "action"), _req(reward, torch.float32, E, "reward"),

@@ -54,6 +54,15 @@ int a0_net_geometry(const a0_net* net, int* out8);  /* H1,W1,H2,W2,H3,W3,feat_di
 int a0_net_encoder_fwd(const a0_net* net, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
                        float* act1, float* act2, float* act3, void* stream);
 
+/* Fused variant of a0_net_encoder_fwd: one workgroup per observation, activations resident in LDS, bit-identical outputs.
+ * wt = k-major copies of the three conv weight matrices (a0_net_conv_wt_floats(C) floats, refreshed by a0_net_conv_wt_refresh
+ * whenever the packed weights change); act1 / act2 may be NULL when no backward pass follows. */
+int a0_net_encoder_fused_supported(int C, int H, int W);
+long long a0_net_conv_wt_floats(int C);
+int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream);
+int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
+                             float* act1, float* act2, float* act3, void* stream);
+
 /* autograd backward of the encoder (agent.py:153-155).  d3 = dL/d(conv3 pre-activation), already ReLU-masked.
  * g1,g2,g3 receive [dW | db] of each conv in the packed layout.  slabs: a0_net_encoder_bwd_scratch() floats. */
 long long a0_net_encoder_bwd_scratch(const a0_net* net, int B);
@@ -148,6 +157,9 @@ int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, floa
 /* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */
 int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action,
                      const float* qmax, float* qs_out, void* stream);
+/* the same with both draws generated in-kernel from Philox streams (bit-identical to a0_rng_randint + a0_rng_uniform + a0_actor_egreedy) */
+int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                         unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out, void* stream);
 int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* action, const float* reward, const float* terminal,
                    const float* truncated, const float* life_loss, int* ring_act, float* ring_rew, float* ring_done,
                    int* out_act, float* out_rew, float* out_done, void* stream);

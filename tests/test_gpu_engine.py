@@ -134,3 +134,31 @@ def test_update_is_deterministic(hip):
         outs.append((dev.loss.clone(), dev.grads.clone(), dev.online.flat.clone()))
     for x, y in zip(*outs):
         assert torch.equal(x, y), "bit-identical results across runs (no atomics anywhere on the path)"
+
+
+@pytest.mark.parametrize("shape,B", [((4, 84, 84), 37), ((4, 36, 36), 5), ((4, 44, 52), 9), ((4, 84, 84), 300)])
+def test_fused_encoder_bit_identical(hip, shape, B):
+    """encoder_fused.hip (one workgroup per observation, activations in LDS) == the three implicit GEMMs, bit for bit,
+    including the replay-slot gather, the st_next half and the optional act1/act2 outputs."""
+    from agent0_amd.deepq.engine import DeviceNet, Workspace
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec("dqn", 4, obs_shape=shape)
+    L = NetLayout.from_spec(spec)
+    assert hip.fused_supported(*shape)
+    net = DeviceNet(hip, L, hip.net(*shape))
+    net.load_state_dict(recipe.make_state_dict(spec, 11))
+    cap = B + 11
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, shape)).to(hip.device).reshape(-1).contiguous()
+    slot = torch.from_numpy(recipe.gen(6).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+    ob = int(np.prod(shape))
+    a, b = Workspace(hip, L, B), Workspace(hip, L, B)
+    for w in (a, b):
+        for t in (w.act1, w.act2, w.act3):
+            t.fill_(float("nan"))
+    hip.encoder_fwd(net.net, net.encoder_weights(), ring, slot, 2 * ob, ob, B, a.act1, a.act2, a.act3)
+    hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), ring, slot, 2 * ob, ob, B, b.act1, b.act2, b.act3)
+    assert torch.equal(a.act1, b.act1) and torch.equal(a.act2, b.act2) and torch.equal(a.act3, b.act3)
+    c = Workspace(hip, L, B)
+    c.act3.fill_(float("nan"))
+    hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), ring, slot, 2 * ob, ob, B, None, None, c.act3)
+    assert torch.equal(a.act3, c.act3)
