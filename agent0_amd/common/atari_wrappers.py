@@ -57,7 +57,7 @@ class DeviceSynthVecEnv:
         self.ops.env_reset(self.seed, self.rank, self.E, self._obs[0], self.ep_ret)
         return self._obs[0], {}
 
-    def step(self, action: torch.Tensor, final_mask: Optional[torch.Tensor] = None, final_ret: Optional[torch.Tensor] = None):
+    def step(self, action: torch.Tensor, final_mask: Optional[torch.Tensor] = None, final_ret: Optional[torch.Tensor] = None, ctrl: Optional[torch.Tensor] = None):
         """``final_mask`` / ``final_ret``: optional caller buffers for the finished-episode record of this step (the gymnasium
         ``info["final_info"]`` / ``info["_final_info"]`` pair, agent.py:85-88)."""
         self.g += 1
@@ -65,7 +65,7 @@ class DeviceSynthVecEnv:
         fm = self.final_mask if final_mask is None else final_mask
         fr = self.final_ret if final_ret is None else final_ret
         self.ops.env_step(self.seed, self.rank, self.E, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, self.reward,
-                          self.terminal, self.truncated, self.life_loss, fm, fr)
+                          self.terminal, self.truncated, self.life_loss, fm, fr, ctrl)
         self._cur = nxt
         info = {"life_loss": self.life_loss, "final_mask": fm, "final_ret": fr}
         return self._obs[nxt], self.reward, self.terminal, self.truncated, info

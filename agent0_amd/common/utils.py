@@ -41,10 +41,13 @@ class DeviceRng:
 
     STREAM_EGREEDY_U, STREAM_EGREEDY_A, STREAM_TAUS, STREAM_NOISE, STREAM_SUMTREE, STREAM_PERM = 1, 2, 3, 4, 5, 6
 
+    CTRL_INDEX = {3: 5, 4: 6}      # STREAM_TAUS -> A0_CTRL_RNG_TAUS, STREAM_NOISE -> A0_CTRL_RNG_NOISE (include/agent0_hip.h)
+
     def __init__(self, ops, seed: int, rank: int = 0):
         self.ops = ops
         self.seed = (int(seed) & 0xFFFFFFFF) | ((int(rank) & 0xFFFF) << 32)
         self.offsets = {}
+        self.ctrl = None      # device int64[8]: when set, taus / noise fills add ctrl[idx] to their offset (hipGraph replay, see Actor)
 
     def _advance(self, stream: int, n: int) -> int:
         off = self.offsets.get(stream, 0)
@@ -52,13 +55,19 @@ class DeviceRng:
         return off
 
     def uniform(self, stream: int, out: torch.Tensor, n: int):
-        self.ops.rng_uniform(self.seed, stream, self._advance(stream, n), out, n)
+        if self.ctrl is not None and stream in self.CTRL_INDEX:
+            self.ops.rng_uniform_ctrl(self.seed, stream, self._advance(stream, n), out, n, self.ctrl, self.CTRL_INDEX[stream])
+        else:
+            self.ops.rng_uniform(self.seed, stream, self._advance(stream, n), out, n)
 
     def randint(self, stream: int, hi: int, out: torch.Tensor, n: int):
         self.ops.rng_randint(self.seed, stream, self._advance(stream, n), hi, out, n)
 
     def normal(self, stream: int, std: float, out: torch.Tensor, n: int):
-        self.ops.rng_normal(self.seed, stream, self._advance(stream, n), std, out, n)
+        if self.ctrl is not None and stream in self.CTRL_INDEX:
+            self.ops.rng_normal_ctrl(self.seed, stream, self._advance(stream, n), std, out, n, self.ctrl, self.CTRL_INDEX[stream])
+        else:
+            self.ops.rng_normal(self.seed, stream, self._advance(stream, n), std, out, n)
 
     def reserve(self, stream: int, n: int) -> int:
         """Claims ``n`` draws of ``stream`` for a kernel that generates them itself; returns their offset."""

@@ -29,3 +29,10 @@ struct a0_hip_error : std::runtime_error {
     catch (const a0_hip_error& e) { return a0_fail_hip(e.err, e.what()); } \
     catch (const std::exception& e) { return a0_fail(A0_EINVAL, e.what()); } \
     catch (...) { return a0_fail(A0_EINVAL, "unknown C++ exception"); }
+
+// profiler probe (net.hip): HIP events around launches tagged `tag`
+#if defined(__HIPCC__)
+bool a0_probe_start(int tag, hipStream_t st);
+void a0_probe_stop(hipStream_t st, double flops);
+#endif
+#define A0_TAG_ENCODER_FUSED 12

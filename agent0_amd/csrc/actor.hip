@@ -34,8 +34,11 @@ extern "C" int a0_actor_egreedy(const int* greedy, const int* rand_action, const
 // given offsets — identical values to a0_rng_randint + a0_rng_uniform followed by a0_actor_egreedy, in one launch).
 __global__ __launch_bounds__(256) void a0_egreedy_rng_kernel(const int* __restrict__ greedy, unsigned long long seed, uint32_t stream_a, uint32_t stream_u,
                                                               unsigned long long off_a, unsigned long long off_u, int A, float eps, int E,
-                                                              int* __restrict__ action, const float* __restrict__ qmax, float* __restrict__ qs_out) {
+                                                              int* __restrict__ action, const float* __restrict__ qmax, float* __restrict__ qs_out,
+                                                              const long long* __restrict__ ctrl, const float* __restrict__ eps_ptr) {
     __shared__ float red[256];
+    if (ctrl) { off_a += (unsigned long long)ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)ctrl[A0_CTRL_RNG_UNIFORM]; }
+    if (eps_ptr) eps = eps_ptr[0];
     float s = 0.f;
     for (int e = threadIdx.x; e < E; e += 256) {
         const int ra = (int)(a0_philox_word(seed, stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
@@ -51,9 +54,10 @@ __global__ __launch_bounds__(256) void a0_egreedy_rng_kernel(const int* __restri
 }
 
 extern "C" int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
-                                    unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out, void* stream) {
+                                    unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out,
+                                    const long long* ctrl, const float* eps_ptr, void* stream) {
     if (!greedy || !action || E < 1 || A < 1) return a0_fail(A0_EINVAL, "a0_actor_egreedy_rng: bad argument");
-    hipLaunchKernelGGL(a0_egreedy_rng_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, greedy, seed, stream_a, stream_u, off_a, off_u, A, eps, E, action, qmax, qs_out);
+    hipLaunchKernelGGL(a0_egreedy_rng_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, greedy, seed, stream_a, stream_u, off_a, off_u, A, eps, E, action, qmax, qs_out, ctrl, eps_ptr);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_egreedy_rng");
 }
 
@@ -65,9 +69,10 @@ extern "C" int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, 
 __global__ void a0_nstep_kernel(int E, int n, long long steps, double gamma, const int* __restrict__ action, const float* __restrict__ reward,
                                 const float* __restrict__ terminal, const float* __restrict__ truncated, const float* __restrict__ life_loss,
                                 int* __restrict__ ring_act, float* __restrict__ ring_rew, float* __restrict__ ring_done,
-                                int* __restrict__ out_act, float* __restrict__ out_rew, float* __restrict__ out_done) {
+                                int* __restrict__ out_act, float* __restrict__ out_rew, float* __restrict__ out_done, const long long* __restrict__ ctrl) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
+    if (ctrl) steps += ctrl[A0_CTRL_ACTOR_STEPS];
     const bool done = ((terminal[e] != 0.f) || (life_loss && life_loss[e] != 0.f)) && !(truncated[e] != 0.f);
     const int cur = (int)(steps % n);
     ring_act[(long long)cur * E + e] = action[e];
@@ -92,10 +97,10 @@ __global__ void a0_nstep_kernel(int E, int n, long long steps, double gamma, con
 
 extern "C" int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* action, const float* reward, const float* terminal,
                               const float* truncated, const float* life_loss, int* ring_act, float* ring_rew, float* ring_done, int* out_act,
-                              float* out_rew, float* out_done, void* stream) {
+                              float* out_rew, float* out_done, const long long* ctrl, void* stream) {
     if (E < 1 || n < 1 || steps < 0 || !action || !reward || !terminal || !truncated || !ring_act || !ring_rew || !ring_done || !out_act || !out_rew || !out_done)
         return a0_fail(A0_EINVAL, "a0_actor_nstep: bad argument");
     hipLaunchKernelGGL(a0_nstep_kernel, dim3((E + 127) / 128), dim3(128), 0, (hipStream_t)stream, E, n, steps, gamma, action, reward, terminal, truncated,
-                       life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done);
+                       life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done, ctrl);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_nstep");
 }

@@ -81,6 +81,17 @@ struct a0_probe_t {
 };
 static a0_probe_t g_probe;
 
+// used by encoder_fused.hip: returns true if this launch is being probed (start event recorded)
+bool a0_probe_start(int tag, hipStream_t st) {
+    if (g_probe.tag == 0 || g_probe.tag != tag || g_probe.used + 2 > g_probe.ev.size()) return false;
+    return hipEventRecord(g_probe.ev[g_probe.used], st) == hipSuccess;
+}
+void a0_probe_stop(hipStream_t st, double flops) {
+    (void)hipEventRecord(g_probe.ev[g_probe.used + 1], st);
+    g_probe.used += 2;
+    g_probe.flops += flops;
+}
+
 extern "C" int a0_probe_begin(int tag, int max_launches) {
     A0_TRY
     for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);

@@ -15,8 +15,10 @@
 __global__ __launch_bounds__(256) void a0_replay_insert_kernel(uint8_t* __restrict__ frames, long long cap, int obs_bytes, long long start, int n,
                                                                 const uint8_t* __restrict__ obs, const uint8_t* __restrict__ obs_next,
                                                                 const int* __restrict__ act, const float* __restrict__ rew, const float* __restrict__ done,
-                                                                int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done) {
+                                                                int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done,
+                                                                const long long* __restrict__ ctrl) {
     const int i = blockIdx.y;
+    if (ctrl) start += ctrl[A0_CTRL_REPLAY_SLOT];
     const long long slot = (start + i) % cap;
     const int q = obs_bytes >> 4;   // 16-byte groups per observation
     const uint4* s0 = (const uint4*)(obs + (long long)i * obs_bytes);
@@ -31,14 +33,15 @@ __global__ __launch_bounds__(256) void a0_replay_insert_kernel(uint8_t* __restri
 }
 
 extern "C" int a0_replay_insert(uint8_t* frames, long long cap, int obs_bytes, long long start_slot, int n, const uint8_t* obs, const uint8_t* obs_next,
-                                const int* act, const float* rew, const float* done, int* r_act, float* r_rew, float* r_done, void* stream) {
+                                const int* act, const float* rew, const float* done, int* r_act, float* r_rew, float* r_done, const long long* ctrl,
+                                void* stream) {
     if (!frames || !obs || !obs_next || !act || !rew || !done || !r_act || !r_rew || !r_done || cap < 1 || n < 1 || n > cap || (obs_bytes & 15) || start_slot < 0)
         return a0_fail(A0_EINVAL, "a0_replay_insert: bad argument (obs_bytes must be a multiple of 16)");
     if ((((uintptr_t)frames) | ((uintptr_t)obs) | ((uintptr_t)obs_next)) & 15) return a0_fail(A0_EINVAL, "a0_replay_insert: buffers must be 16-byte aligned");
     const int q2 = 2 * (obs_bytes >> 4);
     int gx = (q2 + 255) / 256; if (gx > 8) gx = 8;
     hipLaunchKernelGGL(a0_replay_insert_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, frames, cap, obs_bytes, start_slot % cap, n, obs, obs_next,
-                       act, rew, done, r_act, r_rew, r_done);
+                       act, rew, done, r_act, r_rew, r_done, ctrl);
     return a0_fail_hip((int)hipGetLastError(), "a0_replay_insert");
 }
 

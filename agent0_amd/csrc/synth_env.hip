@@ -29,7 +29,9 @@ A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix)
 __global__ __launch_bounds__(256) void a0_env_step_kernel(unsigned long long seed, uint32_t rank, int E, uint32_t g, const uint8_t* __restrict__ obs_in,
                                                            uint8_t* __restrict__ obs_out, float* __restrict__ ep_ret, float* __restrict__ reward,
                                                            float* __restrict__ terminal, float* __restrict__ truncated, float* __restrict__ life_loss,
-                                                           float* __restrict__ final_mask, float* __restrict__ final_ret, int reset) {
+                                                           float* __restrict__ final_mask, float* __restrict__ final_ret, int reset,
+                                                           const long long* __restrict__ ctrl) {
+    if (ctrl) g += (uint32_t)ctrl[A0_CTRL_ENV_STEP];
     const uint32_t e = blockIdx.y;
     bool term = reset != 0;
     if (!reset) {
@@ -68,16 +70,16 @@ __global__ __launch_bounds__(256) void a0_env_step_kernel(unsigned long long see
 extern "C" int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream) {
     if (!obs || !ep_ret || E < 1) return a0_fail(A0_EINVAL, "a0_env_synth_reset: bad argument");
     hipLaunchKernelGGL(a0_env_step_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, 0u, obs, obs, ep_ret,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1, (const long long*)nullptr);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_reset");
 }
 
 extern "C" int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
                                  float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
-                                 float* final_ret, void* stream) {
+                                 float* final_ret, const long long* ctrl, void* stream) {
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !reward || !terminal || !truncated || !life_loss || !final_mask || !final_ret || E < 1)
         return a0_fail(A0_EINVAL, "a0_env_synth_step: bad argument (obs_in and obs_out must differ)");
     hipLaunchKernelGGL(a0_env_step_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal,
-                       truncated, life_loss, final_mask, final_ret, 0);
+                       truncated, life_loss, final_mask, final_ret, 0, ctrl);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step");
 }

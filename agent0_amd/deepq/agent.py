@@ -58,13 +58,23 @@ class Actor:
         self.qs = ops.zeros(T)
         self.stat_mask, self.stat_ret = ops.zeros(T * E), ops.zeros(T * E)
         self.ring_act, self.ring_rew, self.ring_done = ops.zeros(self.n * E, dtype=torch.int32), ops.zeros(self.n * E), ops.zeros(self.n * E)
-        self.ring_obs = ops.zeros(self.n * E * self.obs_bytes, dtype=torch.uint8) if self.n > 1 else None
+        # observation ring for n-step: holds the last n observations; its length divides sample_steps when possible so that the
+        # slot pattern of a rollout repeats (required for hipGraph replay)
+        T_ = int(cfg.actor.sample_steps)
+        self.ring_len = next((r for r in range(self.n, 2 * self.n + 1) if T_ % r == 0), self.n)
+        self.ring_obs = ops.zeros(self.ring_len * E * self.obs_bytes, dtype=torch.uint8) if self.n > 1 else None
+        self.use_graph = True
+        self._graph, self._graph_warm = None, 0
+        self.ctrl = ops.zeros(8, dtype=torch.int64)
+        self.eps_dev = ops.zeros(1)
+        self._ctrl_host = torch.zeros(8, dtype=torch.int64).pin_memory()
+        self._eps_host = torch.zeros(1).pin_memory()
         self.out_act, self.out_rew, self.out_done = ops.zeros(E, dtype=torch.int32), ops.zeros(E), ops.zeros(E)
         self.atoms = self.model.head.atoms.reshape(-1).contiguous() if self.L.algo == "c51" else None
         self._stage = None
 
     # ------------------------------------------------------------------ agent.py:25-39
-    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor]):
+    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None):
         L, ops, E, dev = self.L, self.ops, self.E, self.model._dev
         dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E, keep=False)
         if L.algo == "fqf":
@@ -80,7 +90,7 @@ class Actor:
         # inside the selection kernel
         rng = self.rng
         ops.actor_egreedy_rng(self.greedy, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U, rng.reserve(rng.STREAM_EGREEDY_A, E),
-                              rng.reserve(rng.STREAM_EGREEDY_U, E), L.A, float(epsilon), E, self.action, self.qmax, qs_slot)
+                              rng.reserve(rng.STREAM_EGREEDY_U, E), L.A, float(epsilon), E, self.action, self.qmax, qs_slot, ctrl, eps_ptr)
 
     def act(self, epsilon):
         one = self.ops.zeros(1)
@@ -91,33 +101,25 @@ class Actor:
         self.obs, _ = self.envs.reset()
 
     # ------------------------------------------------------------------ agent.py:44-90
-    def sample(self, epsilon, state_dict=None, test: bool = False):
+    def _rollout(self, epsilon, T, start, bound, test, stage, frames_out, ctrl=None, eps_ptr=None):
+        """The body of Actor.sample's loop (agent.py:48-88), every step enqueued on the stream without touching the host."""
         cfg, ops, E = self.cfg, self.ops, self.E
-        if state_dict is not None:
-            self.model.load_state_dict(state_dict)
-        T = int(cfg.actor.sample_steps)
-        bound = self.replay is not None and not test
-        if not bound and not test:
-            st = self._stage
-            if st is None or st["obs"].shape[0] != T * E:
-                st = self._stage = {"obs": ops.zeros(T * E, self.obs_bytes, dtype=torch.uint8), "obs_next": ops.zeros(T * E, self.obs_bytes, dtype=torch.uint8),
-                                    "act": ops.zeros(T * E, dtype=torch.int32), "rew": ops.zeros(T * E), "done": ops.zeros(T * E)}
-        start = self.replay.write_cursor() if bound else 0
-        frames_out = []
+        R = self.ring_len
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
-                self.model.reset_noise()
-            self._act_device(epsilon, self.qs[t:t + 1])
+                self.model.reset_noise(rng=self.rng)
+            self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr)
             cur_obs = self.obs
             if self.n > 1:
-                slot = self.steps % self.n
+                slot = self.steps % R
                 self.ring_obs[slot * E * self.obs_bytes:(slot + 1) * E * self.obs_bytes].copy_(cur_obs)
-            obs_next, reward, terminal, truncated, info = self.envs.step(self.action, final_mask=self.stat_mask[t * E:(t + 1) * E], final_ret=self.stat_ret[t * E:(t + 1) * E])
+            obs_next, reward, terminal, truncated, info = self.envs.step(self.action, final_mask=self.stat_mask[t * E:(t + 1) * E],
+                                                                         final_ret=self.stat_ret[t * E:(t + 1) * E], ctrl=ctrl)
             ops.actor_nstep(E, self.n, self.steps, float(cfg.learner.discount), self.action, reward, terminal, truncated, info.get("life_loss"),
-                            self.ring_act, self.ring_rew, self.ring_done, self.out_act, self.out_rew, self.out_done)
+                            self.ring_act, self.ring_rew, self.ring_done, self.out_act, self.out_rew, self.out_done, ctrl)
             if self.n > 1:
                 count = min(self.steps + 1, self.n)
-                oldest = (self.steps - (count - 1)) % self.n
+                oldest = (self.steps - (count - 1)) % R
                 obs0 = self.ring_obs[oldest * E * self.obs_bytes:(oldest + 1) * E * self.obs_bytes]
             else:
                 obs0 = cur_obs
@@ -127,12 +129,80 @@ class Actor:
             elif bound:
                 rp = self.replay
                 ops.replay_insert(rp.frames, rp.size, self.obs_bytes, (start + t * E) % rp.size, E, obs0, obs_next, self.out_act, self.out_rew, self.out_done,
-                                  rp.act, rp.rew, rp.done)
+                                  rp.act, rp.rew, rp.done, ctrl)
             else:
                 sl = slice(t * E, (t + 1) * E)
-                st["obs"][sl].copy_(obs0.view(E, -1)); st["obs_next"][sl].copy_(obs_next.view(E, -1))
-                st["act"][sl].copy_(self.out_act); st["rew"][sl].copy_(self.out_rew); st["done"][sl].copy_(self.out_done)
+                stage["obs"][sl].copy_(obs0.view(E, -1)); stage["obs_next"][sl].copy_(obs_next.view(E, -1))
+                stage["act"][sl].copy_(self.out_act); stage["rew"][sl].copy_(self.out_rew); stage["done"][sl].copy_(self.out_done)
             self.obs = obs_next
+
+    def _graph_eligible(self, T, bound, test, state_dict) -> bool:
+        cfg = self.cfg
+        return (self.use_graph and bound and not test and state_dict is None and T % 2 == 0 and hasattr(self.envs, "_cur")
+                and (not cfg.learner.noisy_net or T % cfg.learner.reset_noise_freq == 0) and (self.n == 1 or T % self.ring_len == 0))
+
+    def _snapshot(self):
+        rng = self.rng
+        return {"g": self.envs.g, "steps": self.steps, "slot": self.replay.write_cursor(), "rng": dict(rng.offsets), "cur": self.envs._cur}
+
+    def _rollout_graphed(self, epsilon, T, start):
+        """One hipGraph launch per rollout: the 80 x ~10 launches are captured once; counters that keep advancing (env step, n-step
+        index, Philox offsets, replay cursor) reach the kernels through a device control block, epsilon through a device scalar."""
+        rng, rp = self.rng, self.replay
+        if self._graph is None:
+            if self._graph_warm < 2:                     # eager first: lazy allocations (workspaces, scratch) happen here
+                self._graph_warm += 1
+                self._rollout(epsilon, T, start, True, False, None, None)
+                return
+            self._ctrl_host.zero_(); self.ctrl.zero_(); self._eps_host[0] = float(epsilon); self.eps_dev.copy_(self._eps_host)
+            rng.ctrl = self.ctrl
+            base = self._snapshot()
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                self._rollout(epsilon, T, start, True, False, None, None, ctrl=self.ctrl, eps_ptr=self.eps_dev)
+            after = self._snapshot()
+            assert after["cur"] == base["cur"]
+            self._graph = (graph, base, {k: after["rng"].get(k, 0) - base["rng"].get(k, 0) for k in after["rng"]})
+            graph.replay()                               # capture only records; this is the rollout itself
+            return
+        graph, base, rng_adv = self._graph
+        assert self.envs._cur == base["cur"]
+        h = self._ctrl_host
+        h[0] = self.envs.g - base["g"]
+        h[1] = self.steps - base["steps"]
+        h[2] = rng.offsets.get(rng.STREAM_EGREEDY_A, 0) - base["rng"].get(rng.STREAM_EGREEDY_A, 0)
+        h[3] = rng.offsets.get(rng.STREAM_EGREEDY_U, 0) - base["rng"].get(rng.STREAM_EGREEDY_U, 0)
+        h[4] = (start - base["slot"]) % rp.size
+        h[5] = rng.offsets.get(rng.STREAM_TAUS, 0) - base["rng"].get(rng.STREAM_TAUS, 0)
+        h[6] = rng.offsets.get(rng.STREAM_NOISE, 0) - base["rng"].get(rng.STREAM_NOISE, 0)
+        self._eps_host[0] = float(epsilon)
+        self.ctrl.copy_(h, non_blocking=True)
+        self.eps_dev.copy_(self._eps_host, non_blocking=True)
+        graph.replay()
+        self.envs.g += T
+        self.steps += T
+        for k, v in rng_adv.items():
+            rng.offsets[k] = rng.offsets.get(k, 0) + v
+
+    def sample(self, epsilon, state_dict=None, test: bool = False):
+        cfg, ops, E = self.cfg, self.ops, self.E
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        T = int(cfg.actor.sample_steps)
+        bound = self.replay is not None and not test
+        st = None
+        if not bound and not test:
+            st = self._stage
+            if st is None or st["obs"].shape[0] != T * E:
+                st = self._stage = {"obs": ops.zeros(T * E, self.obs_bytes, dtype=torch.uint8), "obs_next": ops.zeros(T * E, self.obs_bytes, dtype=torch.uint8),
+                                    "act": ops.zeros(T * E, dtype=torch.int32), "rew": ops.zeros(T * E), "done": ops.zeros(T * E)}
+        start = self.replay.write_cursor() if bound else 0
+        frames_out = []
+        if self._graph_eligible(T, bound, test, state_dict):
+            self._rollout_graphed(epsilon, T, start)
+        else:
+            self._rollout(epsilon, T, start, bound, test, st, frames_out)
         # one device->host copy per rollout: mean max-Q per step and finished-episode returns, in the reference's order
         qs = self.qs[:T].cpu().tolist()
         mask = self.stat_mask[:T * E].cpu().numpy() != 0
@@ -166,6 +236,8 @@ class BaseLearner:
         B = int(lc.batch_size)
         self._taus = [ops.empty(B * n) for n in (lc.iqn.K, lc.iqn.N_dash, lc.iqn.N)] if L.algo == "iqn" else None
         self._ones = torch.ones(B, device=ops.device)
+        self.use_graph = True
+        self._graphs, self._graph_warm = {}, {}
 
     @property
     def update_steps(self) -> int:
@@ -182,8 +254,27 @@ class BaseLearner:
             for t in self._taus:
                 self.rng.uniform(self.rng.STREAM_TAUS, t, t.numel())
             rand = self._taus
-        out = self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+        out = self._update(frames, slot, row_bytes, act, rew, done, weights, rand)
         return out if isinstance(out, tuple) else (out, None)
+
+    def _update(self, frames, slot, row_bytes, act, rew, done, weights, rand):
+        """engine.update, replayed from a hipGraph when the caller keeps handing in the same device buffers (the Trainer's hot
+        loop does: the replay's persistent batch tensors).  One graph launch replaces ~45 kernel launches from Python."""
+        if not self.use_graph or self.engine.grad_hook is not None:
+            return self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+        key = (frames.data_ptr(), None if slot is None else slot.data_ptr(), row_bytes, act.data_ptr(), rew.data_ptr(), done.data_ptr(), weights.data_ptr())
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4 or self._graph_warm.get(key, 0) < 2:       # two eager runs first: every lazy allocation has happened
+                self._graph_warm[key] = self._graph_warm.get(key, 0) + 1
+                return self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                out = self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+            g = self._graphs[key] = (graph, out)          # capturing records the launches without running them
+        g[0].replay()
+        return g[1]
 
     # ------------------------------------------------------------------ reference signature (agent.py:124-169)
     def train(self, data):

@@ -159,17 +159,19 @@ class DeepQNet(nn.Module):
         return chain(v for k, v in self.named_parameters() if "fraction" not in k)
 
     # ------------------------------------------------------------------ noise
-    def reset_noise(self):
+    def reset_noise(self, rng=None):
         """NoisyLinear.reset_noise for every noisy layer (model.py:73-83,335-338): N(0, 0.1^2) draws on the device."""
         if not self.L.noisy:
             return
-        if self._rng is None:
-            from agent0_amd.common.utils import DeviceRng
-            self._rng = DeviceRng(self.ops, self.cfg.seed + 7919)
+        if rng is None:
+            if self._rng is None:
+                from agent0_amd.common.utils import DeviceRng
+                self._rng = DeviceRng(self.ops, self.cfg.seed + 7919)
+            rng = self._rng
         for prefix, *_ in self.L.noise_modules:
             nz = self._dev.noise[prefix]
             for leaf in ("noise_in", "noise_out_weight", "noise_out_bias"):
-                self._rng.normal(self._rng.STREAM_NOISE, 0.1, nz[leaf], nz[leaf].numel())
+                rng.normal(rng.STREAM_NOISE, 0.1, nz[leaf], nz[leaf].numel())
         self._dev.compose_noise()
 
     # ------------------------------------------------------------------ forward

@@ -242,12 +242,12 @@ class HipOps:
                                            _req(noise_out_b, torch.float32, r1 - r0, "noise_out_b"), _stream()), "a0_noisy_grad_sigma")
 
     # ------------------------------------------------------------------ replay
-    def replay_insert(self, frames, cap, obs_bytes, start_slot, n, obs, obs_next, act, rew, done, r_act, r_rew, r_done):
+    def replay_insert(self, frames, cap, obs_bytes, start_slot, n, obs, obs_next, act, rew, done, r_act, r_rew, r_done, ctrl=None):
         check(self.lib.a0_replay_insert(_req(frames, torch.uint8, cap * 2 * obs_bytes, "frames"), cap, obs_bytes, start_slot, n,
                                         _req(obs, torch.uint8, n * obs_bytes, "obs"), _req(obs_next, torch.uint8, n * obs_bytes, "obs_next"),
                                         _req(act, torch.int32, n, "act"), _req(rew, torch.float32, n, "rew"), _req(done, torch.float32, n, "done"),
                                         _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
-                                        _stream()), "a0_replay_insert")
+                                        _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_replay_insert")
 
     def replay_lookup(self, idx, B, top, head, cap, slot, r_act, r_rew, r_done, priority, act, rew, done, prio, idx_out):
         check(self.lib.a0_replay_lookup(_req(idx, torch.int64, B, "idx"), B, top, head, cap, _req(slot, torch.int32, B, "slot"),
@@ -298,21 +298,28 @@ class HipOps:
                                         _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax", optional=True),
                                         _req(qs_out, torch.float32, 1, "qs_out", optional=True), _stream()), "a0_actor_egreedy")
 
-    def actor_egreedy_rng(self, greedy, seed, stream_a, stream_u, off_a, off_u, A, eps, E, action, qmax, qs_out):
+    def actor_egreedy_rng(self, greedy, seed, stream_a, stream_u, off_a, off_u, A, eps, E, action, qmax, qs_out, ctrl=None, eps_ptr=None):
         check(self.lib.a0_actor_egreedy_rng(_req(greedy, torch.int32, E, "greedy"), seed, stream_a, stream_u, off_a, off_u, A, eps, E,
                                             _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax", optional=True),
-                                            _req(qs_out, torch.float32, 1, "qs_out", optional=True), _stream()), "a0_actor_egreedy_rng")
+                                            _req(qs_out, torch.float32, 1, "qs_out", optional=True), _req(ctrl, torch.int64, 8, "ctrl", optional=True),
+                                            _req(eps_ptr, torch.float32, 1, "eps_ptr", optional=True), _stream()), "a0_actor_egreedy_rng")
 
-    def actor_nstep(self, E, n, steps, gamma, action, reward, terminal, truncated, life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done):
+    def actor_nstep(self, E, n, steps, gamma, action, reward, terminal, truncated, life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done, ctrl=None):
         check(self.lib.a0_actor_nstep(E, n, steps, gamma, _req(action, torch.int32, E, "action"), _req(reward, torch.float32, E, "reward"),
                                       _req(terminal, torch.float32, E, "terminal"), _req(truncated, torch.float32, E, "truncated"),
                                       _req(life_loss, torch.float32, E, "life_loss", optional=True), _req(ring_act, torch.int32, n * E, "ring_act"),
                                       _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
                                       _req(out_act, torch.int32, E, "out_act"), _req(out_rew, torch.float32, E, "out_rew"), _req(out_done, torch.float32, E, "out_done"),
-                                      _stream()), "a0_actor_nstep")
+                                      _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_actor_nstep")
 
     def rng_uniform(self, seed, stream_id, offset, out, n):
         check(self.lib.a0_rng_uniform(seed, stream_id, offset, _req(out, torch.float32, n, "out"), n, _stream()), "a0_rng_uniform")
+
+    def rng_uniform_ctrl(self, seed, stream_id, offset, out, n, ctrl, ctrl_idx):
+        check(self.lib.a0_rng_uniform_ctrl(seed, stream_id, offset, _req(out, torch.float32, n, "out"), n, _req(ctrl, torch.int64, 8, "ctrl"), ctrl_idx, _stream()), "a0_rng_uniform_ctrl")
+
+    def rng_normal_ctrl(self, seed, stream_id, offset, std, out, n, ctrl, ctrl_idx):
+        check(self.lib.a0_rng_normal_ctrl(seed, stream_id, offset, std, _req(out, torch.float32, n, "out"), n, _req(ctrl, torch.int64, 8, "ctrl"), ctrl_idx, _stream()), "a0_rng_normal_ctrl")
 
     def rng_u32(self, seed, stream_id, offset, out, n):
         check(self.lib.a0_rng_u32(seed, stream_id, offset, _req(out, torch.int32, n, "out"), n, _stream()), "a0_rng_u32")
@@ -326,16 +333,17 @@ class HipOps:
     def env_reset(self, seed, rank, E, obs, ep_ret):
         check(self.lib.a0_env_synth_reset(seed, rank, E, _req(obs, torch.uint8, E * 4 * 84 * 84, "obs"), _req(ep_ret, torch.float32, E, "ep_ret"), _stream()), "a0_env_synth_reset")
 
-    def env_step(self, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal, truncated, life_loss, final_mask, final_ret):
+    def env_step(self, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal, truncated, life_loss, final_mask, final_ret, ctrl=None):
         n = E * 4 * 84 * 84
         check(self.lib.a0_env_synth_step(seed, rank, E, g, _req(obs_in, torch.uint8, n, "obs_in"), _req(obs_out, torch.uint8, n, "obs_out"),
                                          _req(ep_ret, torch.float32, E, "ep_ret"), _req(reward, torch.float32, E, "reward"), _req(terminal, torch.float32, E, "terminal"),
                                          _req(truncated, torch.float32, E, "truncated"), _req(life_loss, torch.float32, E, "life_loss"),
-                                         _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), _stream()), "a0_env_synth_step")
+                                         _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"),
+                                         _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_env_synth_step")
 
     # ------------------------------------------------------------------ measurement
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
-                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11}
+                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12}
 
     def probe_begin(self, name: str, max_launches: int = 8192):
         self._probe_name = name

@@ -21,6 +21,17 @@ extern "C" {
 
 #define A0_ABI_VERSION 1
 
+/* Control block (device int64[A0_CTRL_WORDS], optional): lets a sequence of launches be captured ONCE into a hipGraph and replayed
+ * while counters keep advancing — each kernel adds ctrl[index] to the corresponding immediate argument.  NULL = no adjustment. */
+#define A0_CTRL_ENV_STEP 0      /* a0_env_synth_step: g            */
+#define A0_CTRL_ACTOR_STEPS 1   /* a0_actor_nstep: steps           */
+#define A0_CTRL_RNG_ACTION 2    /* a0_actor_egreedy_rng: off_a     */
+#define A0_CTRL_RNG_UNIFORM 3   /* a0_actor_egreedy_rng: off_u     */
+#define A0_CTRL_REPLAY_SLOT 4   /* a0_replay_insert: start_slot    */
+#define A0_CTRL_RNG_TAUS 5      /* a0_rng_uniform_ctrl (IQN taus)  */
+#define A0_CTRL_RNG_NOISE 6     /* a0_rng_normal_ctrl (NoisyNet)   */
+#define A0_CTRL_WORDS 8
+
 const char* a0_last_error(void);
 int a0_abi_version(void);
 int a0_device_info(int* cu_count, long long* hbm_bytes, char* arch_name64);
@@ -80,7 +91,7 @@ long long a0_dense_wgrad_scratch(int R, int N, int K);
 int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
 
 /* measurement hook for bench.py: HIP events around every launch of the GEMM tagged `tag` (1 conv1 fwd, 2 conv2 fwd, 3 conv3 fwd,
- * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad), recorded on the
+ * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad, 12 fused encoder), recorded on the
  * launch stream.  a0_probe_end writes host_out3 = {launches, total ms, total algorithmic FLOP (2*M*N*K)}. */
 int a0_probe_begin(int tag, int max_launches);
 int a0_probe_end(double* host_out3);
@@ -136,7 +147,7 @@ int a0_noisy_grad_sigma(const float* gmu, float* gsigma, int N, int K, int r0, i
 /* ---------------------------------------------------------------- replay (agent0/deepq/replay.py:14-59, trainer.py:63-72,91-96) */
 int a0_replay_insert(uint8_t* frames, long long cap, int obs_bytes, long long start_slot, int n, const uint8_t* obs,
                      const uint8_t* obs_next, const int* act, const float* rew, const float* done, int* r_act,
-                     float* r_rew, float* r_done, void* stream);
+                     float* r_rew, float* r_done, const long long* ctrl, void* stream);
 int a0_replay_lookup(const long long* idx, int B, long long top, long long head, long long cap, int* slot, const int* r_act,
                      const float* r_rew, const float* r_done, const float* priority, int* act, float* rew, float* done,
                      float* prio, long long* idx_out, void* stream);
@@ -159,20 +170,25 @@ int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, 
                      const float* qmax, float* qs_out, void* stream);
 /* the same with both draws generated in-kernel from Philox streams (bit-identical to a0_rng_randint + a0_rng_uniform + a0_actor_egreedy) */
 int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
-                         unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out, void* stream);
+                         unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out,
+                         const long long* ctrl, const float* eps_ptr, void* stream);
 int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* action, const float* reward, const float* terminal,
                    const float* truncated, const float* life_loss, int* ring_act, float* ring_rew, float* ring_done,
-                   int* out_act, float* out_rew, float* out_done, void* stream);
+                   int* out_act, float* out_rew, float* out_done, const long long* ctrl, void* stream);
 
 /* ---------------------------------------------------------------- device RNG + synthetic env (no reference counterpart) */
 int a0_rng_u32(unsigned long long seed, unsigned int stream_id, unsigned long long offset, unsigned int* out, long long n, void* stream);
 int a0_rng_uniform(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float* out, long long n, void* stream);
 int a0_rng_randint(unsigned long long seed, unsigned int stream_id, unsigned long long offset, int hi, int* out, long long n, void* stream);
 int a0_rng_normal(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float stdv, float* out, long long n, void* stream);
+int a0_rng_uniform_ctrl(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float* out, long long n, const long long* ctrl,
+                        int ctrl_idx, void* stream);
+int a0_rng_normal_ctrl(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float stdv, float* out, long long n,
+                       const long long* ctrl, int ctrl_idx, void* stream);
 int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream);
 int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
                       float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
-                      float* final_ret, void* stream);
+                      float* final_ret, const long long* ctrl, void* stream);
 
 #ifdef __cplusplus
 }

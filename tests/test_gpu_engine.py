@@ -137,9 +137,10 @@ def test_update_is_deterministic(hip):
 
 
 @pytest.mark.parametrize("shape,B", [((4, 84, 84), 37), ((4, 36, 36), 5), ((4, 44, 52), 9), ((4, 84, 84), 300)])
-def test_fused_encoder_bit_identical(hip, shape, B):
-    """encoder_fused.hip (one workgroup per observation, activations in LDS) == the three implicit GEMMs, bit for bit,
-    including the replay-slot gather, the st_next half and the optional act1/act2 outputs."""
+def test_fused_encoder_matches_unfused(hip, shape, B):
+    """encoder_fused.hip (one workgroup per observation, activations in LDS) vs the three implicit GEMMs, including the replay-slot
+    gather, the st_next half and the optional act1/act2 outputs.  The fused conv1 multiplies raw bytes by w/255 instead of
+    (x/255) by w — same two roundings per term — so the comparison is to fp32 rounding (rtol 2e-6 of the activation scale)."""
     from agent0_amd.deepq.engine import DeviceNet, Workspace
     from agent0_amd.deepq.layout import NetLayout
     spec = recipe.NetSpec("dqn", 4, obs_shape=shape)
@@ -157,8 +158,11 @@ def test_fused_encoder_bit_identical(hip, shape, B):
             t.fill_(float("nan"))
     hip.encoder_fwd(net.net, net.encoder_weights(), ring, slot, 2 * ob, ob, B, a.act1, a.act2, a.act3)
     hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), ring, slot, 2 * ob, ob, B, b.act1, b.act2, b.act3)
-    assert torch.equal(a.act1, b.act1) and torch.equal(a.act2, b.act2) and torch.equal(a.act3, b.act3)
+    for x, y, name in ((a.act1, b.act1, "act1"), (a.act2, b.act2, "act2"), (a.act3, b.act3, "act3")):
+        assert torch.isfinite(y).all()
+        assert_close(y, x, 2e-6, 2e-6 * float(x.abs().max()), name)
+        assert torch.equal(x == 0, y == 0) or float(((x == 0) != (y == 0)).float().mean()) < 1e-4, f"{name}: ReLU pattern"
     c = Workspace(hip, L, B)
     c.act3.fill_(float("nan"))
     hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), ring, slot, 2 * ob, ob, B, None, None, c.act3)
-    assert torch.equal(a.act3, c.act3)
+    assert torch.equal(b.act3, c.act3)

@@ -28,7 +28,7 @@ def test_actor_rollout_matches_oracle(n_step):
     from agent0_amd.common.utils import DeviceRng
 
     E, T = 4, 12
-    cfg = make_cfg("dqn", E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 64, "learner.batch_size": 8})
+    cfg = make_cfg("dqn", E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8})
     model = DeepQNet(cfg)
     spec = recipe.NetSpec("dqn", 4)
     sd = recipe.make_state_dict(spec, 11)
@@ -49,7 +49,7 @@ def test_actor_rollout_matches_oracle(n_step):
     env = core.SynthVecEnv(E, seed=cfg.seed, rank=0)
     ora = oactor.OracleActor(env, olearner.to_params(sd), spec, n_step=n_step, sample_steps=6, draw=draw)
     eps = np.float32(0.35)
-    for call in range(2):
+    for call in range(6):           # calls 0-1 run eagerly, call 2 captures the rollout into a hipGraph, calls 3-5 replay it
         data, rs, qs = actor.sample(float(eps))
         replay.extend(data)
         odata, ors, oqs = ora.sample(eps)
@@ -61,7 +61,8 @@ def test_actor_rollout_matches_oracle(n_step):
         for i, (fr, at, rt, dt) in enumerate(odata):
             assert np.array_equal(rows[i], fr.reshape(-1)), f"transition {base + i}: packed st||st_next bytes"
             assert int(replay.act[base + i]) == int(at) and float(replay.rew[base + i]) == np.float32(rt) and bool(replay.done[base + i] != 0) == bool(dt)
-    assert len(replay) == 2 * 6 * E and replay.top == 48
+    assert actor._graph is not None, "the rollout should have been captured"
+    assert len(replay) == 6 * 6 * E and replay.top == 144
 
 
 ALGOS = [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3}),
