@@ -32,6 +32,7 @@ class TrainerNode:
             # identical initial replicas: broadcast rank 0's parameters
             import torch.distributed as dist
             dist.broadcast(eng.online.flat, src=0)
+            eng.online.refresh_wt()
             eng.sync_target(force=True)
 
     def run(self):

@@ -112,6 +112,7 @@ def main():
         eng.grad_hook = GradAllReduce(eng.L.n_adam)
         eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)
         dist.broadcast(eng.online.flat, src=0)
+        eng.online.refresh_wt()
         eng.sync_target(force=True)
 
     # ---- untimed: fill the replay ring to capacity with real rollouts (no learning), then warm up full iterations
@@ -150,14 +151,16 @@ def main():
     # bracket every launch of that kernel on its stream (events cannot be read out of a replayed graph).  Not part of `value`.
     probe_kernel = os.environ.get("A0_PROBE", "encoder_fused")
     pr = None
-    if rank == 0 and probe_kernel != "none":
+    if probe_kernel != "none":           # every rank repeats the iterations (they contain the gradient all-reduce); rank 0 records
         tr.learner.use_graph = False
         tr.actors[1].use_graph = False
-        tr.ops.probe_begin(probe_kernel, 64 + args.steps * (cfg.actor.sample_steps + 8 * cfg.learner.learner_steps))
+        if rank == 0:
+            tr.ops.probe_begin(probe_kernel, 64 + args.steps * (cfg.actor.sample_steps + 8 * cfg.learner.learner_steps))
         for _ in range(args.steps):
             tr.run_iteration()
         torch.cuda.synchronize()
-        pr = tr.ops.probe_end()
+        if rank == 0:
+            pr = tr.ops.probe_end()
     # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
     # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
     replay_gbps = None
@@ -176,6 +179,9 @@ def main():
     if world > 1:
         barrier()
     if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
         return
     value = world * per_iter * args.steps / dt
     upd_per_s = world * cfg.learner.learner_steps * args.steps / dt
@@ -205,8 +211,11 @@ def main():
                 "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off",
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
     out["roofline"] = roof
-    out["cpu_baseline"] = None if (args.no_cpu_baseline) else cpu_baseline(args, cfg)
+    out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args, cfg)     # rank 0 at N=1 only
     print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

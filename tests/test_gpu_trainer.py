@@ -132,3 +132,38 @@ def test_model_api_matches_reference_shapes():
             else:
                 assert_close(m.qval(x), nets.qval(p, spec, x), 1e-3, 1e-4, "fqf qval")
         assert len(list(m.params())) == len([k for k in sd if not recipe.is_buffer(k) and "fraction" not in k])
+
+
+def test_rccl_collectives_on_the_flat_buffers():
+    """The exact collectives the data-parallel path issues (SUM on the fp32 gradient buffer, MAX on the int32 NaN flag, broadcast of
+    the parameters, barrier) through RCCL — single rank here (one GPU per box); world_size 2 is covered on CPU/gloo."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        from agent0_amd.deepq.trainer import Trainer
+        cfg = make_cfg("dqn", 8, **{"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 2,
+                                    "trainer.training_start_steps": 50})
+        tr = Trainer(cfg)
+        eng = tr.learner.engine
+        calls = []
+
+        def hook(grads, state):
+            g0 = grads[: eng.L.n_adam].clone()
+            dist.all_reduce(grads[: eng.L.n_adam], op=dist.ReduceOp.SUM)
+            dist.all_reduce(state[0:1], op=dist.ReduceOp.MAX)
+            calls.append(bool(torch.equal(g0, grads[: eng.L.n_adam])))
+
+        eng.grad_hook = hook
+        dist.broadcast(eng.online.flat, src=0)
+        eng.online.refresh_wt(); eng.sync_target(force=True)
+        for _ in range(3):
+            res = tr.run_iteration()
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert len(calls) == 6 and all(calls) and np.isfinite(res["loss"]) and tr.learner.update_steps == 6
+    finally:
+        dist.destroy_process_group()
