@@ -152,6 +152,48 @@ extern "C" int a0_loss_dqn(const float* q, const float* q_next, int A, const int
     return a0_fail_hip((int)hipGetLastError(), "a0_loss_dqn");
 }
 
+// ------------------------------------------------------------------------------------------------ Munchausen DQN
+// MDQNLearner.train_step (reference agent.py:194-215, log_softmax_stable 116-119), per sample:
+//   lp(x)  = z - tau * logsumexp(z / tau),  z = x - max(x)
+//   v_next = sum_a softmax(q')_a * (q'_a - lp(q')_a)            (softmax at temperature 1, as the reference has it)
+//   y      = r + tau * clamp(lp(q_tgt(obs))[a], lo, 0) + gamma_n * (1 - d) * v_next        (alpha is unused in the reference, Q17)
+__global__ void a0_mdqn_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next, const float* __restrict__ q_cur_tgt, int A,
+                                    const int* __restrict__ act, const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ wgt,
+                                    float gamma_n, float tau, float lo, int B, float* __restrict__ loss, float* __restrict__ dq, int* __restrict__ nan_flag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* qn = q_next + (long long)b * A;
+    const float* qc = q_cur_tgt + (long long)b * A;
+    float mx = qn[0], mc = qc[0];
+    for (int k = 1; k < A; ++k) { mx = fmaxf(mx, qn[k]); mc = fmaxf(mc, qc[k]); }
+    float se_t = 0.f, se_1 = 0.f, sc_t = 0.f;
+    for (int k = 0; k < A; ++k) { se_t += expf((qn[k] - mx) / tau); se_1 += expf(qn[k] - mx); sc_t += expf((qc[k] - mc) / tau); }
+    const float lse_t = logf(se_t), lsc_t = logf(sc_t);
+    float v_next = 0.f;
+    for (int k = 0; k < A; ++k) {
+        const float lp = (qn[k] - mx) - tau * lse_t;
+        v_next += (expf(qn[k] - mx) / se_1) * (qn[k] - lp);
+    }
+    const int a = act[b];
+    float add_on = (qc[a] - mc) - tau * lsc_t;
+    add_on = fminf(fmaxf(add_on, lo), 0.f);
+    const float y = rew[b] + tau * add_on + (gamma_n * (1.f - done[b])) * v_next;
+    const float d = q[(long long)b * A + a] - y;
+    const float ad = fabsf(d);
+    const float l = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+    loss[b] = l;
+    if (l != l) atomicOr(nan_flag, 1);
+    const float g = wgt[b] * fminf(fmaxf(d, -1.f), 1.f);
+    for (int k = 0; k < A; ++k) dq[(long long)b * A + k] = (k == a) ? g : 0.f;
+}
+
+extern "C" int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,
+                            const float* wgt, float gamma_n, float tau, float lo, int B, float* loss, float* dq, int* nan_flag, void* stream) {
+    if (!q || !q_next || !q_cur_tgt || !act || !rew || !done || !wgt || !loss || !dq || !nan_flag || B < 1 || A < 1 || !(tau > 0.f)) return a0_fail(A0_EINVAL, "a0_loss_mdqn: bad argument");
+    hipLaunchKernelGGL(a0_mdqn_loss_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, q, q_next, q_cur_tgt, A, act, rew, done, wgt, gamma_n, tau, lo, B, loss, dq, nan_flag);
+    return a0_fail_hip((int)hipGetLastError(), "a0_loss_mdqn");
+}
+
 // ------------------------------------------------------------------------------------------------ C51
 // One wave per sample, one lane per atom (T <= 64).  The projection is computed in gather form — bin j sums the
 // contributions of the atoms whose lo (then up) index equals j, in ascending atom order — which is the order the

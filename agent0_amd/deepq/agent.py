@@ -222,11 +222,9 @@ class BaseLearner:
         self.ops = ops = _ops_from(cfg, ops)
         lc = cfg.learner
         L = layout_from_cfg(cfg)
-        if lc.algo == AlgoEnum.mdqn:
-            raise NotImplementedError("MDQNLearner: Munchausen-DQN is outside the dqn/c51/qr/iqn/fqf hot path of this build (SURVEY.md R11)")
         self.engine = DeviceLearner(ops, L, int(lc.batch_size), discount=lc.discount, n_step=lc.n_step_q, double_q=lc.double_q, lr=lc.learning_rate,
                                     target_update_freq=lc.target_update_freq, vmin=lc.c51.vmin, vmax=lc.c51.vmax, K=lc.iqn.K, N=lc.iqn.N, N_dash=lc.iqn.N_dash,
-                                    max_grad_norm=lc.max_grad_norm)
+                                    max_grad_norm=lc.max_grad_norm, mdqn_tau=lc.mdqn.tau, mdqn_lo=lc.mdqn.lo)
         self.rng = DeviceRng(ops, cfg.seed + 15485863)
         self.model = DeepQNet(cfg, ops=ops, dev_net=self.engine.online, rng=self.rng)
         self.model_target = DeepQNet(cfg, ops=ops, dev_net=self.engine.target, rng=self.rng)

@@ -11,6 +11,8 @@ Additions (all default to the reference's behaviour being available):
                    samples uniformly and only re-weights (quirks Q1/Q2/Q7 of SURVEY.md).
   learner.algo     accepts ``iqr`` (README spelling) as an alias of ``iqn`` (quirk Q10).
   device           ``cuda`` is the only supported device: this build has no CPU path (it raises instead).
+  checkpoint       path of a checkpoint written by ``Trainer.save_checkpoint``; read when ``mode`` is ``finetune`` (resume training)
+                   or ``play`` (evaluate only) — the reference declares those modes (config.py:26-29) but never implements them.
 """
 from __future__ import annotations
 
@@ -154,6 +156,7 @@ class ExpConfig:
     logdir: str = "logs"
     wandb: bool = True
     tb: bool = True
+    checkpoint: str = ""
     learner: LearnerConfig = field(default_factory=LearnerConfig)
     trainer: TrainerConfig = field(default_factory=TrainerConfig)
     actor: ActorConfig = field(default_factory=ActorConfig)

@@ -200,7 +200,8 @@ class DeviceLearner:
     """Online + target network, gradients, Adam / RMSprop state and the per-algorithm update."""
 
     def __init__(self, ops, L: NetLayout, batch_size: int, *, discount=0.99, n_step=1, double_q=False, lr=5e-4,
-                 target_update_freq=500, vmin=-10.0, vmax=10.0, K=32, N=64, N_dash=64, max_grad_norm=-1.0, adam_eps=None):
+                 target_update_freq=500, vmin=-10.0, vmax=10.0, K=32, N=64, N_dash=64, max_grad_norm=-1.0, adam_eps=None,
+                 mdqn_tau=0.03, mdqn_lo=-1.0):
         self.ops, self.L, self.B = ops, L, batch_size
         self.net = ops.net(L.C, L.H, L.W)
         self.online = DeviceNet(ops, L, self.net)
@@ -217,6 +218,7 @@ class DeviceLearner:
         self.vmin, self.vmax = float(vmin), float(vmax)
         self.K, self.N, self.N_dash = K, N, N_dash
         self.max_grad_norm = max_grad_norm
+        self.mdqn_tau, self.mdqn_lo = float(mdqn_tau), float(mdqn_lo)
         B = batch_size
         if L.quantile:
             n_on = N if L.algo == "iqn" else L.F
@@ -307,7 +309,16 @@ class DeviceLearner:
         algo = L.algo
         wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
         frac = None
-        if algo in ("dqn", "c51", "qr"):
+        if algo == "mdqn":
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+            tg.head(wt, B)
+            wm = self.ws_m
+            tg.encode(wm, frames, slot, sample_stride, 0, B, keep=False)        # target net on the CURRENT observation (agent.py:202-204)
+            tg.head(wm, B)
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            on.head(wo, B)
+            ops.loss_mdqn(wo.q, wt.q, wm.q, L.A, act, rew, done, wgt, self.gamma_n, self.mdqn_tau, self.mdqn_lo, B, self.loss, wo.dq, self.state)
+        elif algo in ("dqn", "c51", "qr"):
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             tg.head(wt, B)
             if self.double_q:

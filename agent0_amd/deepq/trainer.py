@@ -88,6 +88,33 @@ class Trainer:
         self._loss_means = ops.zeros(max(L, 1))
         self._floss_means = ops.zeros(max(L, 1))
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def save_checkpoint(self, path: str):
+        """Weights under the reference's state_dict keys (loadable by the reference's DeepQNet) + optimizer and counters."""
+        eng = self.learner.engine
+        blob = {"model": {k: v.cpu() for k, v in self.learner.model.state_dict().items()},
+                "model_target": {k: v.cpu() for k, v in self.learner.model_target.state_dict().items()},
+                "adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(), "state": eng.state.cpu(), "frame_count": self.frame_count,
+                "algo": self.cfg.learner.algo.name, "obs_shape": tuple(self.cfg.obs_shape), "action_dim": int(self.cfg.action_dim)}
+        if hasattr(eng, "rms_sq"):
+            blob["rms_sq"] = eng.rms_sq.cpu()
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(blob, path)
+        return path
+
+    def load_checkpoint(self, path: str, weights_only: bool = False):
+        blob = torch.load(path, map_location="cpu", weights_only=False)
+        if blob.get("algo") not in (None, self.cfg.learner.algo.name) or int(blob.get("action_dim", self.cfg.action_dim)) != int(self.cfg.action_dim):
+            raise ValueError(f"checkpoint {path} was written for {blob.get('algo')} / {blob.get('action_dim')} actions")
+        self.learner.model.load_state_dict(blob["model"])
+        self.learner.model_target.load_state_dict(blob.get("model_target", blob["model"]))
+        if not weights_only and "adam_m" in blob:
+            eng = self.learner.engine
+            eng.adam_m.copy_(blob["adam_m"]); eng.adam_v.copy_(blob["adam_v"]); eng.state.copy_(blob["state"])
+            if "rms_sq" in blob and hasattr(eng, "rms_sq"):
+                eng.rms_sq.copy_(blob["rms_sq"])
+            self.frame_count = int(blob.get("frame_count", 0))
+
     # ------------------------------------------------------------------ trainer.py:74-119
     def step(self, transitions, returns, qmax):
         cfg = self.cfg
@@ -170,12 +197,25 @@ class Trainer:
         return result
 
     def run(self):
-        trainer_steps = self.cfg.trainer.total_steps // self.num_transitions + 1
+        cfg = self.cfg
+        if cfg.mode.name in ("finetune", "play"):
+            if not cfg.checkpoint:
+                raise ValueError(f"mode={cfg.mode.name} needs checkpoint=<path>")
+            self.load_checkpoint(cfg.checkpoint, weights_only=(cfg.mode.name == "play"))
+        if cfg.mode.name == "play":
+            return self.final(save=False)
+        remaining = max(cfg.trainer.total_steps - self.frame_count, 0)
+        trainer_steps = remaining // self.num_transitions + 1
         for _ in range(trainer_steps):
             self.logging(self.run_iteration())
         self.final()
 
-    def final(self):
+    def final(self, save: bool = True):
+        if save:
+            try:
+                self.save_checkpoint(os.path.join(self.cfg.logdir, "final.pth"))
+            except OSError:
+                pass
         self.test()
         for actor in self.actors:
             if actor is not None:

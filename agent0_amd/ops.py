@@ -175,6 +175,12 @@ class HipOps:
                                    _req(wgt, torch.float32, B, "wgt"), gamma_n, B, _req(loss, torch.float32, B, "loss"), _req(dq, torch.float32, B * A, "dq"),
                                    _req(state, torch.int32, 8, "state"), _stream()), "a0_loss_dqn")
 
+    def loss_mdqn(self, q, q_next, q_cur_tgt, A, act, rew, done, wgt, gamma_n, tau, lo, B, loss, dq, state):
+        check(self.lib.a0_loss_mdqn(_req(q, torch.float32, B * A, "q"), _req(q_next, torch.float32, B * A, "q_next"), _req(q_cur_tgt, torch.float32, B * A, "q_cur_tgt"), A,
+                                    _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                    _req(wgt, torch.float32, B, "wgt"), gamma_n, tau, lo, B, _req(loss, torch.float32, B, "loss"), _req(dq, torch.float32, B * A, "dq"),
+                                    _req(state, torch.int32, 8, "state"), _stream()), "a0_loss_mdqn")
+
     def loss_c51(self, logits, tgt_logits, A, T, act, a_star, rew, done, wgt, atoms, gamma_n, vmin, vmax, B, loss, dlogits, m_out, state):
         check(self.lib.a0_loss_c51(_req(logits, torch.float32, B * A * T, "logits"), _req(tgt_logits, torch.float32, B * A * T, "tgt_logits"), A, T,
                                    _req(act, torch.int32, B, "act"), _req(a_star, torch.int32, B, "a_star"), _req(rew, torch.float32, B, "rew"),

@@ -110,6 +110,9 @@ int a0_select_action(const float* x, long long sb, long long sa, long long st, i
 /* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
 int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
                 const float* done, const float* wgt, float gamma_n, int B, float* loss, float* dq, int* nan_flag, void* stream);
+/* MDQNLearner.train_step (agent.py:194-215): q_next = target(next_obs), q_cur_tgt = target(obs), both [B][A] */
+int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,
+                 const float* wgt, float gamma_n, float tau, float lo, int B, float* loss, float* dq, int* nan_flag, void* stream);
 /* C51Learner.train_step (agent.py:219-269): logits / tgt_logits [B][A][T]; m_out (optional) = projected target [B][T] */
 int a0_loss_c51(const float* logits, const float* tgt_logits, int A, int T, const int* act, const int* a_star,
                 const float* rew, const float* done, const float* wgt, const float* atoms, float gamma_n,

@@ -176,6 +176,23 @@ class CpuOps:
         dq[: B * A] = g.reshape(-1)
         self._flag_nan(l, state)
 
+    def loss_mdqn(self, q, q_next, q_cur_tgt, A, act, rew, done, wgt, gamma_n, tau, lo, B, loss, dq, state):
+        ar = torch.arange(B)
+        def lp(x):
+            z = x - x.max(-1, keepdim=True)[0]
+            return z - tau * torch.logsumexp(z / tau, -1, keepdim=True)
+        qn, qc = q_next[: B * A].view(B, A), q_cur_tgt[: B * A].view(B, A)
+        v_next = (qn.softmax(-1) * (qn - lp(qn))).sum(-1)
+        add_on = lp(qc)[ar, act[:B].long()].clamp(lo, 0)
+        y = rew[:B] + tau * add_on + (gamma_n * (1 - done[:B])) * v_next
+        d = q[: B * A].view(B, A)[ar, act[:B].long()] - y
+        l = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
+        loss[:B] = l
+        g = torch.zeros(B, A)
+        g[ar, act[:B].long()] = wgt[:B] * d.clamp(-1, 1)
+        dq[: B * A] = g.reshape(-1)
+        self._flag_nan(l, state)
+
     def loss_c51(self, logits, tgt_logits, A, T, act, a_star, rew, done, wgt, atoms, gamma_n, vmin, vmax, B, loss, dlogits, m_out, state):
         ar = torch.arange(B)
         p = tgt_logits[: B * A * T].view(B, A, T)[ar, a_star[:B].long()].softmax(-1)

@@ -32,6 +32,7 @@ CASES = {
     "iqn_duel": NetSpec("iqn", 3, dueling=True, obs_shape=TINY),
     "fqf": NetSpec("fqf", 4, obs_shape=TINY),
     "dqn_noisy": NetSpec("dqn", 4, noisy=True, obs_shape=TINY),
+    "mdqn": NetSpec("mdqn", 5, obs_shape=TINY),
     "dqn_odd": NetSpec("dqn", 4, obs_shape=(4, 44, 52)),   # non-square, odd conv1 output (10x12 -> 4x5 -> 2x3)
 }
 
@@ -179,7 +180,7 @@ def run_both(ops, name, B, double_q, n_step, steps=2, target_freq=2, resync=True
 
 TRAIN = [("dqn", 8, False, 1), ("dqn_duel", 8, True, 3), ("c51", 8, False, 1), ("c51_duel_noisy", 8, True, 3), ("qr", 6, False, 1),
          ("qr_duel_noisy", 6, True, 1), ("iqn", 6, False, 1), ("iqn_duel", 6, True, 3), ("fqf", 6, False, 1), ("fqf", 6, True, 3),
-         ("dqn_noisy", 8, True, 1), ("dqn_odd", 8, True, 1)]
+         ("dqn_noisy", 8, True, 1), ("dqn_odd", 8, True, 1), ("mdqn", 8, False, 3)]
 
 
 def check_update(ops, name, B, dq, n):

@@ -67,7 +67,8 @@ def test_actor_rollout_matches_oracle(n_step):
 
 ALGOS = [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3}),
          ("c51", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.noisy_net": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
-         ("c51", {"replay.policy": "prioritize", "replay.sumtree": "false"}), ("qr", {}), ("iqr", {"learner.double_q": "true"}), ("fqf", {})]
+         ("c51", {"replay.policy": "prioritize", "replay.sumtree": "false"}), ("qr", {}), ("iqr", {"learner.double_q": "true"}), ("fqf", {}),
+         ("mdqn", {"learner.n_step_q": 3})]
 
 
 @pytest.mark.parametrize("algo,extra", ALGOS)
@@ -167,3 +168,60 @@ def test_rccl_collectives_on_the_flat_buffers():
         assert len(calls) == 6 and all(calls) and np.isfinite(res["loss"]) and tr.learner.update_steps == 6
     finally:
         dist.destroy_process_group()
+
+
+def test_checkpoint_roundtrip_and_modes(tmp_path):
+    """N3: save -> load restores weights (reference state_dict keys), optimizer state and counters; mode=play evaluates only."""
+    from agent0_amd.deepq.trainer import Trainer
+    base = {"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 2, "trainer.training_start_steps": 50,
+            "logdir": str(tmp_path / "run")}
+    tr = Trainer(make_cfg("c51", 8, **{**base, "learner.dueling_head": "true"}))
+    for _ in range(3):
+        tr.run_iteration()
+    path = tr.save_checkpoint(str(tmp_path / "ck.pth"))
+    blob = torch.load(path, weights_only=False)
+    assert set(blob["model"]) == set(recipe.state_dict_shapes(recipe.NetSpec("c51", 4, dueling=True))), "reference key names"
+    tr2 = Trainer(make_cfg("c51", 8, **{**base, "learner.dueling_head": "true", "seed": 7}))
+    assert not torch.equal(tr2.learner.engine.online.flat, tr.learner.engine.online.flat)
+    tr2.load_checkpoint(path)
+    e1, e2 = tr.learner.engine, tr2.learner.engine
+    assert torch.equal(e1.online.flat, e2.online.flat) and torch.equal(e1.target.flat, e2.target.flat)
+    assert torch.equal(e1.adam_m, e2.adam_m) and torch.equal(e1.adam_v, e2.adam_v) and torch.equal(e1.state, e2.state) and tr2.frame_count == tr.frame_count
+    x = torch.from_numpy(recipe.make_frames(3, 1)[:, :4].copy())
+    assert torch.equal(tr.learner.model.qval(x), tr2.learner.model.qval(x))
+    # play mode: loads the weights, runs evaluation episodes, trains nothing
+    cfg = make_cfg("c51", 8, **{**base, "learner.dueling_head": "true", "mode": "play", "checkpoint": path, "trainer.test_episodes": 1})
+    tr3 = Trainer(cfg)
+    tr3.run()
+    assert tr3.learner.update_steps == 0 and torch.equal(tr3.learner.engine.online.flat, e1.online.flat)
+
+
+def test_host_env_adapter_matches_device_env():
+    """N1: a HOST vector env behind HostVecEnvAdapter feeds the same device pipeline.  Using the oracle's CPU twin of the synthetic
+    env as the host env, the replay contents must equal those produced with the device-resident env, byte for byte."""
+    from agent0_amd.common.atari_wrappers import HostVecEnvAdapter
+    from agent0_amd.deepq.agent import Actor
+    from agent0_amd.deepq.model import DeepQNet
+    from agent0_amd.deepq.replay import ReplayDataset
+    E = 4
+    outs = []
+    for host in (False, True):
+        cfg = make_cfg("dqn", E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 128, "learner.batch_size": 8})
+        model = DeepQNet(cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec("dqn", 4), 11).items()})
+        replay = ReplayDataset(cfg, ops=model.ops)
+        envs = None
+        if host:
+            henv = core.SynthVecEnv(E, seed=cfg.seed, rank=0)
+            henv.observation_space = type("S", (), {"shape": (E, 4, 84, 84)})()
+            envs = HostVecEnvAdapter(henv, E, ops=model.ops, action_dim=4)
+        actor = Actor(cfg, model, replay=replay, rank=0, envs=envs)
+        rs_all = []
+        for _ in range(3):
+            data, rs, qs = actor.sample(0.3)
+            replay.extend(data)
+            rs_all += rs
+        outs.append((replay.frames[: 72 * replay.row_bytes].clone(), replay.act[:72].clone(), replay.rew[:72].clone(), replay.done[:72].clone(), rs_all))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4]
