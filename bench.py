@@ -201,9 +201,18 @@ def main():
         "replay_sample_GBps": None if replay_gbps is None else round(replay_gbps, 1), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),
     }
     roof = None
+    traffic = None
+    try:      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["per_launch"]
+        n_act, n_lrn = cfg.actor.sample_steps, 2 * cfg.learner.learner_steps
+        traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["512"]["hbm_bytes"]) / (n_act + n_lrn))
+    except Exception:
+        pass
     if pr is not None and pr["launches"] and pr["ms"] > 0:
         achieved = pr["flop"] / (pr["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": None,
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json; "
+                                "algorithmic minimum 10.7 MB (256 obs) / 21.2 MB (512 obs)",
                 "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation, fp32 v_mfma_f32_16x16x4_f32, u8 input, activations in LDS)"
                           if pr["kernel"] == "encoder_fused" else f"a0_igemm_kernel<{pr['kernel']}>",
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
