@@ -330,3 +330,80 @@ extern "C" int a0_sumtree_sample(const float* tree, long long cap2, const float*
     hipLaunchKernelGGL(a0_sumtree_sample_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tree, cap2, xi, B, out_idx, out_p);
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_sample");
 }
+
+
+// ------------------------------------------------------------------------------------------------ fused sample + gather
+// One launch draws the batch indices AND copies the rows: workgroup column b computes its own index (mode 0: Feistel permutation
+// element start + b of the current epoch, reference DataLoader semantics; mode 1: stratified sum-tree descent with xi[b]), maps it to
+// a ring slot, writes the per-sample metadata and streams the 2*obs_bytes row with 16 B per lane.  Same results as
+// a0_perm_batch / a0_sumtree_sample + a0_replay_lookup + a0_replay_gather (checked in tests/test_gpu_kernels.py).
+__global__ __launch_bounds__(256) void a0_sample_gather_kernel(int mode, unsigned long long start, unsigned long long n_perm, uint32_t seed,
+                                                                const float* __restrict__ tree, long long cap2, const float* __restrict__ xi,
+                                                                long long top, long long head, long long cap, const uint8_t* __restrict__ frames, int row_bytes,
+                                                                const int* __restrict__ r_act, const float* __restrict__ r_rew, const float* __restrict__ r_done,
+                                                                const float* __restrict__ priority, int B, uint8_t* __restrict__ out, long long* __restrict__ idx_out,
+                                                                int* __restrict__ slot_out, int* __restrict__ act, float* __restrict__ rew, float* __restrict__ done,
+                                                                float* __restrict__ prio) {
+    __shared__ long long s_slot;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        long long li, slot;
+        float p = 1.f;
+        if (mode == 0) {
+            uint32_t h = 1;
+            while ((1ull << (2 * h)) < n_perm) ++h;
+            const uint32_t mask = (uint32_t)((1ull << h) - 1);
+            unsigned long long x = start + (unsigned long long)b;
+            do {
+                uint32_t l = (uint32_t)(x >> h) & mask, r = (uint32_t)x & mask;
+                for (uint32_t round = 0; round < 4; ++round) {
+                    const uint32_t f = a0_mix32(r ^ (seed + 0x9E3779B9u * (round + 1))) & mask;
+                    const uint32_t nl = r, nr = l ^ f;
+                    l = nl; r = nr;
+                }
+                x = ((unsigned long long)l << h) | r;
+            } while (x >= n_perm);
+            li = (long long)(x % (unsigned long long)top);
+            slot = (head + li) % cap;
+            if (priority) p = priority[li];
+        } else {
+            const float total = tree[1];
+            const float seg = total / (float)B;
+            float u = ((float)b + xi[b]) * seg;
+            long long n = 1;
+            while (n < cap2) {
+                const float left = tree[2 * n];
+                const float right = tree[2 * n + 1];
+                if (u < left || !(right > 0.0f)) { n = 2 * n; } else { u -= left; n = 2 * n + 1; }
+            }
+            li = n - cap2;
+            slot = li;
+            p = tree[n];
+        }
+        s_slot = slot;
+        if (blockIdx.x == 0) {
+            idx_out[b] = li; slot_out[b] = (int)slot; act[b] = r_act[slot]; rew[b] = r_rew[slot]; done[b] = r_done[slot];
+            if (prio) prio[b] = p;
+        }
+    }
+    __syncthreads();
+    const int q = row_bytes >> 4;
+    const uint4* s = (const uint4*)(frames + s_slot * row_bytes);
+    uint4* d = (uint4*)(out + (long long)b * row_bytes);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) d[j] = s[j];
+}
+
+extern "C" int a0_replay_sample_gather(int mode, unsigned long long start, unsigned long long n_perm, unsigned int seed, const float* tree, long long cap2,
+                                       const float* xi, long long top, long long head, long long cap, const uint8_t* frames, int row_bytes, const int* r_act,
+                                       const float* r_rew, const float* r_done, const float* priority, int B, uint8_t* out, long long* idx_out, int* slot_out,
+                                       int* act, float* rew, float* done, float* prio, void* stream) {
+    if (!frames || !r_act || !r_rew || !r_done || !out || !idx_out || !slot_out || !act || !rew || !done || B < 1 || (row_bytes & 15) || top < 1 || cap < top)
+        return a0_fail(A0_EINVAL, "a0_replay_sample_gather: bad argument");
+    if (mode == 0 && (n_perm < 1 || start + (unsigned long long)B > n_perm)) return a0_fail(A0_EINVAL, "a0_replay_sample_gather: permutation window out of range");
+    if (mode == 1 && (!tree || !xi || cap2 < 1 || (cap2 & (cap2 - 1)))) return a0_fail(A0_EINVAL, "a0_replay_sample_gather: sum-tree arguments");
+    if (mode != 0 && mode != 1) return a0_fail(A0_EINVAL, "a0_replay_sample_gather: mode");
+    int gx = ((row_bytes >> 4) + 255) / 256; if (gx > 4) gx = 4;
+    hipLaunchKernelGGL(a0_sample_gather_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, mode, start, n_perm, seed, tree, cap2, xi, top, head, cap, frames,
+                       row_bytes, r_act, r_rew, r_done, priority, B, out, idx_out, slot_out, act, rew, done, prio);
+    return a0_fail_hip((int)hipGetLastError(), "a0_replay_sample_gather");
+}

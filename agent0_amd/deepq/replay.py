@@ -175,6 +175,32 @@ class ReplayDataset:
         ep["pos"] += 1
         self.ops.perm_batch(start, B, ep["top"], ep["seed"], self._idx)
 
+    def sample_gathered(self, out_rows: torch.Tensor) -> Batch:
+        """``sample()`` plus a dense copy of the sampled rows into ``out_rows`` [B * row_bytes] in ONE launch — the device counterpart of a
+        DataLoader batch (trainer.py:63-72, replay.py:32-37).  The learner does not need the copy (conv1 reads ring rows through the slot
+        index); this is the API for callers that want the batch materialised, and what bench.py times as 'replay sample GB/s'."""
+        B = self.B
+        if self.use_sumtree:
+            self.rng.uniform(self.rng.STREAM_SUMTREE, self._xi, B)
+            self.ops.replay_sample_gather(1, 0, 0, 0, self.tree, self.cap2, self._xi, self.size, 0, self.size, self.frames, self.row_bytes, self.act, self.rew, self.done,
+                                          None, B, out_rows, self._idx_out, self._slot, self._act, self._rew, self._done, self._prio)
+            self.ops.is_weights(self._prio, B, self.tree[1:2], self.top, float(self.beta), self._w)
+        else:
+            ep = self._epoch
+            if ep is None or ep["pos"] + 1 >= ep["nb"]:
+                self._next_uniform(B)           # opens a new epoch (and draws its first batch into _idx, unused here)
+                ep = self._epoch
+                ep["pos"] = 0
+            start = ep["pos"] * B
+            ep["pos"] += 1
+            self.ops.replay_sample_gather(0, start, ep["top"], ep["seed"], None, 1, None, self.top, self.head, self.size, self.frames, self.row_bytes, self.act, self.rew,
+                                          self.done, self.priority if self.prioritize else None, B, out_rows, self._idx_out, self._slot, self._act, self._rew, self._done,
+                                          self._prio)
+            if self.prioritize:
+                self.ops.sum_f32(self.priority, self.size, self._scratch, self._psum)
+                self.ops.is_weights(self._prio, B, self._psum, self.top, float(self.beta), self._w)
+        return Batch(self._idx_out, self._slot, self._act, self._rew, self._done, self._prio, self._w)
+
     def sample(self, B: Optional[int] = None) -> Batch:
         B = B or self.B
         assert B == self.B

@@ -266,6 +266,16 @@ class HipOps:
         check(self.lib.a0_replay_gather(_req(frames, torch.uint8, rows_available * row_bytes, "frames"), row_bytes, _req(slot, torch.int32, B, "slot"), B,
                                         _req(out, torch.uint8, B * row_bytes, "out"), _stream()), "a0_replay_gather")
 
+    def replay_sample_gather(self, mode, start, n_perm, seed, tree, cap2, xi, top, head, cap, frames, row_bytes, r_act, r_rew, r_done, priority, B, out,
+                             idx_out, slot_out, act, rew, done, prio):
+        check(self.lib.a0_replay_sample_gather(mode, start, n_perm, seed & 0xFFFFFFFF, _req(tree, torch.float32, 2 * cap2, "tree", optional=(mode == 0)), cap2,
+                                               _req(xi, torch.float32, B, "xi", optional=(mode == 0)), top, head, cap, _req(frames, torch.uint8, cap * row_bytes, "frames"),
+                                               row_bytes, _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"),
+                                               _req(r_done, torch.float32, cap, "r_done"), _req(priority, torch.float32, top, "priority", optional=True), B,
+                                               _req(out, torch.uint8, B * row_bytes, "out"), _req(idx_out, torch.int64, B, "idx_out"), _req(slot_out, torch.int32, B, "slot_out"),
+                                               _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                               _req(prio, torch.float32, B, "prio", optional=True), _stream()), "a0_replay_sample_gather")
+
     def fill_f32(self, p, n, v):
         check(self.lib.a0_fill_f32(_req(p, torch.float32, n, "p"), n, v, _stream()), "a0_fill_f32")
 

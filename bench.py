@@ -168,12 +168,12 @@ def main():
         rp = tr.replay
         out_rows = torch.empty(rp.B * rp.row_bytes, dtype=torch.uint8, device="cuda")
         for _ in range(3):
-            b = rp.sample(); tr.ops.replay_gather(rp.frames, rp.row_bytes, b.slot, rp.B, out_rows, rp.size)
+            rp.sample_gathered(out_rows)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_rep = 50
+        n_rep = 100
         torch.cuda.synchronize(); e0.record()
         for _ in range(n_rep):
-            b = rp.sample(); tr.ops.replay_gather(rp.frames, rp.row_bytes, b.slot, rp.B, out_rows, rp.size)
+            rp.sample_gathered(out_rows)          # index generation + metadata + 28.9 MB row gather, one launch
         e1.record(); torch.cuda.synchronize()
         replay_gbps = rp.B * rp.row_bytes * n_rep / (e0.elapsed_time(e1) * 1e-3) / 1e9
     if world > 1:

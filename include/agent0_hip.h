@@ -155,6 +155,12 @@ int a0_replay_lookup(const long long* idx, int B, long long top, long long head,
                      const float* r_rew, const float* r_done, const float* priority, int* act, float* rew, float* done,
                      float* prio, long long* idx_out, void* stream);
 int a0_replay_gather(const uint8_t* frames, int row_bytes, const int* slot, int B, uint8_t* out, void* stream);
+/* index generation + metadata lookup + row gather in ONE launch (trainer.py:63-72 + replay.py:32-37): mode 0 = element start+b of the
+ * epoch's Feistel permutation of [0, n_perm), mode 1 = stratified sum-tree draw with xi[b] */
+int a0_replay_sample_gather(int mode, unsigned long long start, unsigned long long n_perm, unsigned int seed, const float* tree, long long cap2,
+                            const float* xi, long long top, long long head, long long cap, const uint8_t* frames, int row_bytes, const int* r_act,
+                            const float* r_rew, const float* r_done, const float* priority, int B, uint8_t* out, long long* idx_out, int* slot_out,
+                            int* act, float* rew, float* done, float* prio, void* stream);
 int a0_fill_f32(float* p, long long n, float v, void* stream);
 int a0_priority_update(float* priority, const long long* ids, const float* loss, int B, float eps, float alpha,
                        float* pstate, const int* state, void* stream);

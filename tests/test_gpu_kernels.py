@@ -204,3 +204,36 @@ def test_replay_insert_lookup_gather_priorities(hip):
         hip.is_weights(pr, B, ps, top, 0.5, w)
         want = oreplay.is_weights(pr.cpu().numpy(), float(torch.from_numpy(ref.priority).sum()), top, 0.5)
         assert_close(w, want, 2e-6, 1e-7, "importance weights")
+
+
+@pytest.mark.parametrize("prioritize,sumtree", [(False, False), (True, False), (True, True)])
+def test_fused_sample_gather_equals_separate_kernels(prioritize, sumtree):
+    """a0_replay_sample_gather == (a0_perm_batch | a0_sumtree_sample) + a0_replay_lookup + a0_replay_gather, bit for bit."""
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.replay import ReplayDataset, TransitionBlock
+    over = ["replay.size=300", "learner.batch_size=64", "wandb=false", "tb=false"]
+    if prioritize:
+        over += ["replay.policy=prioritize", f"replay.sumtree={str(sumtree).lower()}"]
+    reps = []
+    for _ in range(2):
+        cfg = parse_overrides(over)
+        cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
+        rp = ReplayDataset(cfg)
+        g = recipe.gen(3)
+        n = 420                        # wraps the ring: head != 0
+        st = {"obs": torch.from_numpy(g.integers(0, 256, (n, rp.obs_bytes), dtype=np.uint8)).cuda(), "obs_next": torch.from_numpy(g.integers(0, 256, (n, rp.obs_bytes), dtype=np.uint8)).cuda(),
+              "act": torch.from_numpy(g.integers(0, 4, n).astype(np.int32)).cuda(), "rew": torch.from_numpy(g.standard_normal(n).astype(np.float32)).cuda(),
+              "done": torch.from_numpy((g.random(n) < 0.2).astype(np.float32)).cuda()}
+        rp.extend(TransitionBlock(n, staged=st))
+        if prioritize:
+            rp.update_priority(torch.from_numpy(g.integers(0, 300, 64)).cuda(), torch.from_numpy(g.uniform(0, 3, 64).astype(np.float32)).cuda())
+        reps.append(rp)
+    a, b = reps
+    rows = torch.empty(64 * a.row_bytes, dtype=torch.uint8, device="cuda")
+    for it in range(6):
+        ba = a.sample_gathered(rows)
+        bb = b.sample()
+        ref = torch.empty_like(rows)
+        b.ops.replay_gather(b.frames, b.row_bytes, bb.slot, 64, ref, b.size)
+        assert torch.equal(ba.slot, bb.slot) and torch.equal(ba.idx, bb.idx) and torch.equal(rows, ref)
+        assert torch.equal(ba.act, bb.act) and torch.equal(ba.rew, bb.rew) and torch.equal(ba.done, bb.done) and torch.equal(ba.weights, bb.weights)
