@@ -22,7 +22,7 @@ from agent0_amd.common.utils import DeviceRng
 from .config import AlgoEnum, ExpConfig
 from .engine import DeviceLearner, Workspace
 from .model import DeepQNet, layout_from_cfg
-from .replay import ReplayDataset, TransitionBlock
+from .replay import ReplayDataset, StageRing, TransitionBlock
 
 
 def _ops_from(cfg, ops=None):
@@ -186,8 +186,16 @@ class Actor:
             rng.offsets[k] = rng.offsets.get(k, 0) + v
 
     def sample(self, epsilon, state_dict=None, test: bool = False):
+        return self.sample_finish(self.sample_async(epsilon, state_dict, test))
+
+    def sample_async(self, epsilon, state_dict=None, test: bool = False):
+        """Enqueue one rollout on the current stream and return without waiting for it (the device counterpart of
+        ``actor.futures.sample(...)``, launch.py:34-36); ``sample_finish`` collects the result."""
         cfg, ops, E = self.cfg, self.ops, self.E
-        if state_dict is not None:
+        if isinstance(state_dict, DeepQNet):
+            self.model._dev.copy_from(state_dict._dev)          # device-to-device weight snapshot
+            state_dict = None
+        elif state_dict is not None:
             self.model.load_state_dict(state_dict)
         T = int(cfg.actor.sample_steps)
         bound = self.replay is not None and not test
@@ -203,13 +211,24 @@ class Actor:
             self._rollout_graphed(epsilon, T, start)
         else:
             self._rollout(epsilon, T, start, bound, test, st, frames_out)
+        done_ev = torch.cuda.Event()
+        done_ev.record()
+        return (T, bound, test, st, start, frames_out, done_ev)
+
+    def sample_finish(self, pending):
+        T, bound, test, st, start, frames_out, done_ev = pending
+        E = self.E
+        done_ev.synchronize()
         # one device->host copy per rollout: mean max-Q per step and finished-episode returns, in the reference's order
         qs = self.qs[:T].cpu().tolist()
         mask = self.stat_mask[:T * E].cpu().numpy() != 0
         rs = self.stat_ret[:T * E].cpu().numpy()[mask].tolist()
         if test:
             return frames_out, rs, qs
-        data = TransitionBlock(T * E, start=start) if bound else TransitionBlock(T * E, staged=st)
+        if bound:
+            data = TransitionBlock(T * E, start=start, source=self.replay if isinstance(self.replay, StageRing) else None)
+        else:
+            data = TransitionBlock(T * E, staged=st)
         return data, rs, qs
 
     def close(self):

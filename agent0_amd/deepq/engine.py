@@ -75,6 +75,18 @@ class DeviceNet:
         if self.fused:
             self.ops.conv_wt_refresh(self.encoder_weights(), self.L.C, self.wt)
 
+    def copy_from(self, other: "DeviceNet"):
+        """Device-to-device snapshot of another DeviceNet of the same layout: parameters, k-major conv copies, NoisyNet noise
+        vectors and composed weights.  This is what replaces shipping ``state_dict()`` to an actor (launch.py:34-36,58-62)."""
+        self.flat.copy_(other.flat)
+        if self.wt is not None:
+            self.wt.copy_(other.wt)
+        if self.eff is not None:
+            self.eff.copy_(other.eff)
+        for prefix, nz in self.noise.items():
+            for k, v in nz.items():
+                v.copy_(other.noise[prefix][k])
+
     # ------------------------------------------------------------------ weights
     def block(self, name: str) -> Block:
         return self.L.blocks[name]

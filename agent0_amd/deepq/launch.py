@@ -4,7 +4,9 @@ The reference (agent0/deepq/launch.py:25-205) starts ``num_actors`` Launchpad Co
 ships the whole state_dict to an actor on every sample RPC and receives pickled lz4 transitions back (launch.py:30-97).
 dm-launchpad is not available (its wheel is a missing blob in the reference checkout) and that transport is the
 bottleneck this build removes: here one process per GPU runs actor + replay shard + learner on its own device and the
-replicas exchange only gradients (agent0_amd/deepq/dist.py).  ``num_actors`` maps to the number of ranks, capped by the
+replicas exchange only gradients (agent0_amd/deepq/dist.py).  What the reference gets from Launchpad — rollouts running WHILE the
+learner updates, with the weights as they were when the rollout was issued (launch.py:34-36,44-63) — is kept: the actor owns a
+device-to-device snapshot of the network and rolls out on a second HIP stream into a stage ring (Trainer(use_lp=True)).  ``num_actors`` maps to the number of ranks, capped by the
 GPUs present.  When started without a torch.distributed environment this module re-launches itself under
 ``torch.distributed.run`` — as a CHILD process and before anything touches the GPU.
 """
@@ -24,7 +26,7 @@ class TrainerNode:
         from .trainer import Trainer
 
         cfg.seed = cfg.seed + 1000003 * rank          # per-rank env / replay / exploration streams
-        self.trainer = Trainer(cfg, rank=rank)
+        self.trainer = Trainer(cfg, use_lp=True, rank=rank)          # asynchronous actor on its own stream, weight snapshots
         eng = self.trainer.learner.engine
         if world > 1:
             eng.grad_hook = GradAllReduce(eng.L.n_adam)

@@ -33,6 +33,7 @@ class TransitionBlock:
     count: int
     start: int = -1
     staged: Optional[dict] = None
+    source: Optional["StageRing"] = None      # rows [start, start+count) of a StageRing (asynchronous actors, launch mode)
 
     def __len__(self):
         return self.count
@@ -47,6 +48,24 @@ class Batch:
     done: torch.Tensor
     prio: torch.Tensor
     weights: torch.Tensor
+
+
+class StageRing:
+    """A small ring in the replay's row format that an asynchronous actor writes while the learner samples the main ring.
+
+    The reference's remote actors return their transitions and the trainer ``extend``s the replay between update blocks
+    (launch.py:58-63), so a rollout in flight never touches entries the learner can sample.  Here the in-flight rollout lands in this
+    stage (two rollouts deep, so the next one can start while the previous one is being committed) and ``ReplayDataset.extend`` moves
+    the rows into the main ring with device-to-device copies."""
+
+    def __init__(self, ops, rows: int, obs_bytes: int):
+        self.size, self.obs_bytes, self.row_bytes = int(rows), obs_bytes, 2 * obs_bytes
+        self.frames = torch.empty(self.size * self.row_bytes, dtype=torch.uint8, device=ops.device)
+        self.act, self.rew, self.done = ops.zeros(self.size, dtype=torch.int32), ops.zeros(self.size), ops.zeros(self.size)
+        self.written = 0
+
+    def write_cursor(self) -> int:
+        return self.written % self.size
 
 
 class ReplayDataset:
@@ -114,7 +133,19 @@ class ReplayDataset:
         if not isinstance(transitions, TransitionBlock):
             raise TypeError("ReplayDataset.extend takes the TransitionBlock returned by Actor.sample (transitions stay on the device)")
         n = transitions.count
-        if transitions.staged is not None:
+        if transitions.source is not None:
+            src, done_rows = transitions.source, 0
+            assert src.row_bytes == self.row_bytes and transitions.start + n <= src.size and n <= self.size
+            dst_f, src_f = self.frames.view(self.size, self.row_bytes), src.frames.view(src.size, src.row_bytes)
+            while done_rows < n:                      # at most two pieces: the main ring may wrap
+                c = self.write_cursor()
+                k = min(n - done_rows, self.size - c)
+                a = transitions.start + done_rows
+                dst_f[c:c + k].copy_(src_f[a:a + k])
+                self.act[c:c + k].copy_(src.act[a:a + k]); self.rew[c:c + k].copy_(src.rew[a:a + k]); self.done[c:c + k].copy_(src.done[a:a + k])
+                self.written += k
+                done_rows += k
+        elif transitions.staged is not None:
             s = transitions.staged
             done_rows = 0
             while done_rows < n:                      # staged blocks may be larger than the ring

@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--sample-steps", type=int, default=80)
     ap.add_argument("--env", default="Breakout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--entry", choices=("main", "launch"), default="main",
+                    help="main: agent0.deepq.main schedule (rollout, then update block, strictly alternating); launch: agent0.deepq.launch schedule "
+                         "(next rollout with a weight snapshot on a second stream while the update block runs)")
     ap.add_argument("overrides", nargs="*", help="extra key=value config overrides")
     return ap.parse_args()
 
@@ -105,7 +108,7 @@ def main():
     cfg.obs_shape = (4, 84, 84)
     cfg.action_dim = ACTION_DIMS.get(cfg.env_id, 18)
     cfg.seed = cfg.seed + 1000003 * rank
-    tr = Trainer(cfg, rank=rank)
+    tr = Trainer(cfg, use_lp=(args.entry == "launch"), rank=rank)
     eng = tr.learner.engine
     if world > 1:
         import torch.distributed as dist
@@ -154,6 +157,8 @@ def main():
     if probe_kernel != "none":           # every rank repeats the iterations (they contain the gradient all-reduce); rank 0 records
         tr.learner.use_graph = False
         tr.actors[1].use_graph = False
+        if args.entry == "launch":
+            tr.overlap = False               # kernel timing without a second stream competing for the CUs
         if rank == 0:
             tr.ops.probe_begin(probe_kernel, 64 + args.steps * (cfg.actor.sample_steps + 8 * cfg.learner.learner_steps))
         for _ in range(args.steps):
@@ -195,7 +200,7 @@ def main():
                                f"{cfg.learner.learner_steps} updates of batch {cfg.learner.batch_size} per iteration, {cfg.replay.size}-transition HBM replay "
                                f"(full), obs 4x84x84 u8, per-rank shards, RCCL grad all-reduce" + ("" if world > 1 else " (inactive at 1 GPU)"),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
-                   "replay_size": cfg.replay.size, "parallelism": f"dp{world}"},
+                   "replay_size": cfg.replay.size, "parallelism": f"dp{world}", "entry": f"agent0.deepq.{args.entry}"},
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),
         "replay_sample_GBps": None if replay_gbps is None else round(replay_gbps, 1), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),

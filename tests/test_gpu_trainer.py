@@ -225,3 +225,43 @@ def test_host_env_adapter_matches_device_env():
     for a, b in zip(outs[0][:4], outs[1][:4]):
         assert torch.equal(a, b)
     assert outs[0][4] == outs[1][4]
+
+
+@pytest.mark.parametrize("algo,extra", [("dqn", []), ("c51", ["learner.noisy_net=true", "learner.n_step_q=3", "replay.policy=prioritize"])])
+def test_launch_mode_overlap_is_race_free(algo, extra):
+    """Trainer(use_lp=True) — the launch.py schedule: rollout k+1 with a weight snapshot runs on a second stream while the update block
+    consumes rollout k.  Issuing the same work on ONE stream must give bit-identical parameters, replay contents and statistics."""
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    res = []
+    for overlap in (True, False):
+        cfg = parse_overrides([f"learner.algo={algo}", "actor.num_envs=16", "actor.sample_steps=12", "learner.batch_size=32", "learner.learner_steps=3", "replay.size=500",
+                               "trainer.training_start_steps=100", "learner.target_update_freq=4", "wandb=false", "tb=false", "logdir=/tmp/a0_lp"] + extra)
+        tr = Trainer(cfg, use_lp=True)
+        tr.overlap = overlap
+        out = [tr.run_iteration() for _ in range(7)]            # wraps the 500-slot ring, captures + replays the graphs
+        torch.cuda.synchronize()
+        res.append((tr.learner.engine.online.flat.clone(), tr.replay.frames.clone(), tr.replay.act.clone(), tr.replay.rew.clone(), [o["loss"] for o in out],
+                    [o["qmax"] for o in out], tr.frame_count, tr.actors[1].model._dev.flat.clone()))
+    a, b = res
+    assert a[6] == b[6] == 7 * 16 * 12
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[7], b[7])
+    assert a[4] == b[4] and a[5] == b[5]
+    assert a[4][-1] is not None and not torch.equal(a[0], a[7])      # training happened; the actor's copy is one update block behind
+
+
+def test_launch_mode_uses_stale_weights_like_the_reference():
+    """launch.py:58-63 issues the next rollout BEFORE the update block: rollout k+1 acts with the weights after block k-1.  Check that the
+    actor's snapshot equals the learner's parameters as they were when the rollout was issued."""
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    cfg = parse_overrides(["actor.num_envs=16", "actor.sample_steps=12", "learner.batch_size=32", "learner.learner_steps=2", "replay.size=2000",
+                           "trainer.training_start_steps=100", "wandb=false", "tb=false", "logdir=/tmp/a0_lp"])
+    tr = Trainer(cfg, use_lp=True)
+    for _ in range(3):
+        tr.run_iteration()
+    before = tr.learner.engine.online.flat.clone()
+    tr.run_iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.actors[1].model._dev.flat, before)
+    assert not torch.equal(tr.learner.engine.online.flat, before)
