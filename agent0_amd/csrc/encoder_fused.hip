@@ -4,14 +4,18 @@
 // Replaces ConvEncoder.forward (reference agent0/deepq/model.py:93-105) plus the uint8 -> fp32 /255 in front of it
 // (agent.py:27, agent.py:129-134) for the shapes the actor-learner loop uses.  Why: as three separate implicit GEMMs the
 // actor's 256-observation forward launches 162-800 workgroups per layer and is latency-bound (profiles/r01); here every
-// CU owns one observation (28 KB u8 -> LDS once), reads its im2col operands straight out of LDS with computed addresses
-// (no staging pass, no HBM round trip for act1/act2) and only streams the shared weights (k-major copies, L2-resident)
-// through a double-buffered 32-deep LDS tile.  The MFMA is v_mfma_f32_16x16x4_f32: 16-row tiles fit M = 400 / 81 / 49
-// rows with little padding and split evenly over the eight waves.  conv2 / conv3 are the same k-ascending fp32 fmaf chains as in
-// igemm.h.  conv1 feeds the RAW byte values to the MFMA and folds the reference's x/255 into the weight copy (w/255): its inner
-// loop is instruction-issue bound and the exact three-instruction division per operand element cost more than the MFMA itself;
-// sum_k x_k*fl(w_k/255) and sum_k fl(x_k/255)*w_k carry the same two roundings per term, so the result agrees with the unfused
-// path (and the reference) to fp32 rounding — tests/test_gpu_engine.py::test_fused_encoder_matches_unfused, rtol 2e-6.
+// CU owns one observation (28 KB u8 -> LDS once) and reads its im2col A operands straight out of LDS with computed addresses
+// (no staging pass, no HBM round trip for act1/act2).  The B operands (the weights, shared by every workgroup and L2-resident)
+// never touch LDS: a0_conv_wt_kernel lays them out in MFMA-fragment order so that each lane streams ITS fragment values with
+// one 16-byte global load per 16 k, through a register ring several chunks deep.  There is therefore no barrier and no
+// s_waitcnt vmcnt(0) anywhere inside a convolution's k loop — the eight waves drift apart and keep the matrix pipe shared —
+// only one barrier per layer, when its output lands in LDS.
+// The MFMA is v_mfma_f32_16x16x4_f32: 16-row tiles fit M = 400 / 81 / 49 rows with little padding and split evenly over the
+// eight waves.  conv2 / conv3 are the same k-ascending fp32 fmaf chains as in igemm.h.  conv1 feeds the RAW byte values to the
+// MFMA and folds the reference's x/255 into the weight copy (w/255): its inner loop is instruction-issue bound and the exact
+// three-instruction division per operand element cost more than the MFMA itself; sum_k x_k*fl(w_k/255) and sum_k fl(x_k/255)*w_k
+// carry the same two roundings per term, so the result agrees with the unfused path (and the reference) to fp32 rounding —
+// tests/test_gpu_engine.py::test_fused_encoder_matches_unfused, rtol 2e-6.
 #include "a0_internal.h"
 #include "net_tables.h"
 #include "operands.h"
@@ -27,57 +31,101 @@ struct a0_fused_args {
     float *act1, *act2, *act3;           // act1/act2 optional (needed only when a backward pass follows)
     int B;
     int C, H, W, H1, W1, H2, W2, H3, W3;
-    int off_act1, off_act2, off_bs;      // float offsets of the LDS regions behind the u8 observation
-    int stage_mask;                      // diagnostics only (A0_FUSED_STAGES env): bit i enables conv(i+1); 7 = everything
+    int off_act1, off_act2, off_end;     // float offsets of the LDS regions behind the u8 observation
+    int rp1, rp2;                        // LDS row pitches (floats) of act1 / act2, padded so that A-fragment reads are bank-conflict free
 };
 
 // Eight waves per workgroup = two per SIMD: while one wave waits for its LDS operands the other keeps the matrix pipe busy.
 constexpr int A0_FUSED_WAVES = 8;
 constexpr int A0_FUSED_THREADS = 64 * A0_FUSED_WAVES;
-constexpr int A0_P1 = 33;   // LDS pixel pitch of act1 (32 channels + 1: 2*33 = 66 = 2 mod 32 -> conflict-free stride-2 row reads)
-constexpr int A0_P2 = 65;   // LDS pixel pitch of act2 (64 channels + 1)
+// LDS layout of the activations: [row][pixel][channel] with pixel pitch P and row pitch RP.  An A-fragment read (ds_read_b32) is served
+// in two groups of 32 lanes = 16 consecutive output positions m x 2 adjacent k; it is conflict-free when position m lands on bank
+// 2m (mod 32).  conv2 reads act1 at stride 2: 2*P1 = 66 = 2 (mod 32) along a row, and the row pitch is padded until
+// 2*RP1 = 2*W2 (mod 32), so stepping to the next output row continues the sequence; conv3 (stride 1): P2 = 66, RP2 = 2*W3 (mod 32).
+constexpr int A0_P1 = 33;
+constexpr int A0_P2 = 66;
 
-// ---- A-operand fetchers: element (row m, k = 32*kt + 4*s + q) of the im2col matrix, read directly from LDS.
-// address = row(m) + tile_off(kt) + step_off(s) + q: the tile part is added once per 32-deep tile, the step part is a
+// ---- A-operand fetchers: element (row m, k = 16*c + 4*j + q) of the im2col matrix, read directly from LDS.
+// address = row(m) + chunk_off(c) + step_off(j) + q: the chunk part is added once per 16-deep chunk, the step part is a
 // compile-time constant that folds into the DS instruction's immediate offset (WC > 0: width known at compile time).
 template <int WC> struct AF1 {   // conv1 8x8/4 over the u8 observation [C][H][W]; k = c*64 + kh*8 + kw
     const uint8_t* obs; int HW, W, W1;
     A0_D int width() const { return WC > 0 ? WC : W; }
     A0_D int row(int m) const { const int oh = m / W1, ow = m - oh * W1; return (4 * oh) * width() + 4 * ow; }
-    A0_D int tile_off(int kt) const { return (kt >> 1) * HW + 4 * (kt & 1) * width(); }
-    A0_D int step_off(int s) const { return (s >> 1) * width() + 4 * (s & 1); }
-    // raw byte value 0..255: the 1/255 of the reference's normalisation (agent.py:27,132) is folded into the k-major weight copy
-    A0_D float fetch(int addr) const { return (float)obs[addr]; }
+    A0_D int chunk_off(int c) const { return (c >> 2) * HW + 2 * (c & 3) * width(); }
+    A0_D int step_off(int j) const { return (j >> 1) * width() + 4 * (j & 1); }
+    // raw byte value 0..255: the 1/255 of the reference's normalisation (agent.py:27,132) is folded into the k-major weight copy.
+    // The ring keeps the byte as loaded; the conversion happens next to the MFMA that consumes it (a convert placed behind the
+    // read would wait for it on the spot and undo the prefetch).
+    typedef uint32_t Raw;
+    A0_D Raw load(int addr) const { return obs[addr]; }
+    static A0_D float value(Raw r) { return (float)r; }
 };
-struct AF2 {   // conv2 4x4/2 over act1 [H1][W1][P1]; k = (kh*4 + kw)*32 + c
-    const float* act; int W1, W2;
-    A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return ((2 * oh) * W1 + 2 * ow) * A0_P1; }
-    A0_D int tile_off(int kt) const { return ((kt >> 2) * W1 + (kt & 3)) * A0_P1; }
+struct AF2 {   // conv2 4x4/2 over act1 [H1][RP1]; k = (kh*4 + kw)*32 + c
+    const float* act; int RP1, W2;
+    A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return (2 * oh) * RP1 + 2 * ow * A0_P1; }
+    A0_D int chunk_off(int c) const { const int cell = c >> 1; return (cell >> 2) * RP1 + (cell & 3) * A0_P1 + 16 * (c & 1); }
     A0_D int step_off(int s) const { return 4 * s; }
-    A0_D float fetch(int addr) const { return act[addr]; }
+    typedef float Raw;
+    A0_D Raw load(int addr) const { return act[addr]; }
+    static A0_D float value(Raw r) { return r; }
 };
-struct AF3 {   // conv3 3x3/1 over act2 [H2][W2][P2]; k = (kh*3 + kw)*64 + c
-    const float* act; int W2, W3;
-    A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return (oh * W2 + ow) * A0_P2; }
-    A0_D int tile_off(int kt) const { const int kk = kt >> 1; return ((kk / 3) * W2 + (kk % 3)) * A0_P2 + (kt & 1) * 32; }
+struct AF3 {   // conv3 3x3/1 over act2 [H2][RP2]; k = (kh*3 + kw)*64 + c
+    const float* act; int RP2, W3;
+    A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return oh * RP2 + ow * A0_P2; }
+    A0_D int chunk_off(int c) const { const int cell = c >> 2; return (cell / 3) * RP2 + (cell % 3) * A0_P2 + 16 * (c & 3); }
     A0_D int step_off(int s) const { return 4 * s; }
-    A0_D float fetch(int addr) const { return act[addr]; }
+    typedef float Raw;
+    A0_D Raw load(int addr) const { return act[addr]; }
+    static A0_D float value(Raw r) { return r; }
 };
 
-// One convolution: C[M x N] = relu(A[M x K] * Wt[K x N] + bias), A read through AF.  Waves: WN along N, 4/WN along M; a wave
-// owns MBW 16-row blocks (interleaved) x NBW 16-column blocks.  (8 waves: conv1 2 x 4, conv2 / conv3 4 x 2.)
-template <int N, int WN, int MBW, class AF>
-A0_D void a0_conv_stage(const AF& af, int M, int K, const float* __restrict__ wt, const float* __restrict__ bias, float* Bs,
-                        float* out_lds, int out_pitch, float* __restrict__ out_glb) {
-    constexpr int NB = N / 16, NBW = NB / WN, WMG = A0_FUSED_WAVES / WN, NS = N + 16;
-    constexpr int WF4 = N * 32 / 4;             // float4 of one weight tile
-    constexpr int WREG = (WF4 + A0_FUSED_THREADS - 1) / A0_FUSED_THREADS;
-    static_assert(NBW >= 1, "tile shape");
+// ---- B operands.  Packed layout of one layer (a0_conv_wt_kernel): float index ((c*N + n)*4 + q)*4 + j holds W[n][k = 16c + 4j + q],
+// i.e. lane (n, q) of the MFMA B fragment finds the values of the four steps j of chunk c in one aligned float4, and a wave's
+// sixteen columns x four q of a chunk are 1 KB contiguous.
+template <int N, int WN, int R>
+struct a0_wring {
+    static constexpr int NBW = N / 16 / WN;
+    a0_f4 v[R][NBW];
+    const float* base;            // this lane's float4 of chunk 0, column block 0
+    int nch;
+    A0_D void init(const float* wp, int K) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int n = (wave % WN) * (NBW * 16) + (lane & 15), q = lane >> 4;
+        base = wp + (n * 4 + q) * 4;
+        nch = K >> 4;
+    }
+    A0_D void fill(int slot, int c) {
+        c = c < nch ? c : nch - 1;                     // past the end: re-read the last chunk (never consumed), keeps the loop branch-free
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) v[slot][j] = *(const a0_f4*)(base + (long long)c * (N * 16) + j * 256);
+    }
+    A0_D void prologue() {
+#pragma unroll
+        for (int u = 0; u < R; ++u) fill(u, u);
+    }
+};
+A0_D float a0_f4_get(const a0_f4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+// One convolution: C[M x N] = relu(A[M x K] * W^T + bias), A read through AF from LDS, B from the register ring.  Waves: WN along
+// N, 8/WN along M; a wave owns MBW 16-row blocks (interleaved) x NBW 16-column blocks.  (conv1 2 x 4 waves, conv2 / conv3 4 x 2.)
+// The k loop is one software pipeline over all K/4 MFMA steps: the LDS operands of step g + PD are requested before the MFMAs of
+// step g are issued (register ring of PD + 1 slots); chunk c + R of the weights is requested as soon as chunk c has been consumed.
+// Everything is branch-free (16-row blocks beyond M recompute row 0 and are never stored) and pinned with sched_barriers — left
+// alone, the scheduler sinks every prefetch down to its first use.  `between` runs after the last MFMA and before the epilogue:
+// the caller issues the next layer's weight prologue there, so its L2 latency hides behind the epilogue and the barrier.
+// Output: row m = (oh, ow) of an OW-wide image goes to out_lds[oh*out_rp + ow*out_pitch + n] (OWC > 0: width known at compile time) and /
+// or to out_glb[m*N + n].
+template <int N, int WN, int MBW, int PD, int R, int OWC, class AF, class Between>
+A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, const float* __restrict__ bias, float* out_lds, int out_pitch, int out_rp,
+                        int out_w, float* __restrict__ out_glb, Between&& between) {
+    constexpr int NB = N / 16, NBW = NB / WN, WMG = A0_FUSED_WAVES / WN, RS = PD + 1;
+    static_assert(NBW >= 1 && (4 % RS) == 0, "tile shape");
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the per-block skips below become scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wmg = wave / WN;
     const int q = lane >> 4, r16 = lane & 15;
-    const int MB = (M + 15) >> 4, KT = K >> 5;
+    const int MB = (M + 15) >> 4, NCH = K >> 4;      // NCH is a multiple of R for every supported shape (checked on the host)
 
     int rows[MBW];
 #pragma unroll
@@ -91,58 +139,46 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, const float* __restrict__ wt
 #pragma unroll
         for (int j = 0; j < NBW; ++j) acc[i][j] = a0_acc4{0.f, 0.f, 0.f, 0.f};
 
-    // weight tile kt: rows k = 32*kt .. +31 of Wt, N floats each, copied as float4 into Bs[buf][k][NS]
-    a0_f4 wreg[WREG];
-    auto wload = [&](int kt) {
+    float bv[NBW];                                    // bias now: a load in the epilogue would wait for the next layer's weight prologue
 #pragma unroll
-        for (int j = 0; j < WREG; ++j) {
-            const int f = tid + A0_FUSED_THREADS * j;
-            if (f < WF4) wreg[j] = *(const a0_f4*)(wt + (long long)(32 * kt + f / (N / 4)) * N + 4 * (f % (N / 4)));
-        }
+    for (int j = 0; j < NBW; ++j) bv[j] = bias[(wn * NBW + j) * 16 + r16];
+    typename AF::Raw a[RS][MBW];
+    auto fetch = [&](int slot, int ao, int j) {
+#pragma unroll
+        for (int i = 0; i < MBW; ++i) a[slot][i] = af.load(rows[i] + ao + af.step_off(j));
     };
-    auto wstore = [&](int buf) {
+    {
+        const int ao = af.chunk_off(0);
 #pragma unroll
-        for (int j = 0; j < WREG; ++j) {
-            const int f = tid + A0_FUSED_THREADS * j;
-            if (f < WF4) *(a0_f4*)&Bs[buf * 32 * NS + (f / (N / 4)) * NS + 4 * (f % (N / 4))] = wreg[j];
-        }
-    };
-    wload(0);
-    wstore(0);
-    __syncthreads();
-    int buf = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) wload(kt + 1);
-        const float* bb = Bs + buf * 32 * NS + q * NS + wn * (NBW * 16) + r16;
-        // operands of k-step s+1 are read from LDS while the MFMAs of step s run; no branch inside (16-row blocks beyond M
-        // recompute row 0 and are never stored), so the compiler is free to keep all MBW + NBW reads in flight
-        float a[2][MBW], b[2][NBW];
-        int rk[MBW];
-        const int toff = af.tile_off(kt);
-#pragma unroll
-        for (int i = 0; i < MBW; ++i) rk[i] = rows[i] + toff;
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) b[0][j] = bb[j * 16];
-#pragma unroll
-        for (int i = 0; i < MBW; ++i) a[0][i] = af.fetch(rk[i] + af.step_off(0));
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < 8) {
-#pragma unroll
-                for (int j = 0; j < NBW; ++j) b[nxt][j] = bb[4 * (s + 1) * NS + j * 16];
-#pragma unroll
-                for (int i = 0; i < MBW; ++i) a[nxt][i] = af.fetch(rk[i] + af.step_off(s + 1));
-            }
-#pragma unroll
-            for (int i = 0; i < MBW; ++i)
-#pragma unroll
-                for (int j = 0; j < NBW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < KT) wstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+        for (int p = 0; p < PD; ++p) fetch(p, ao, p);
     }
+    // Drain vmcnt once, here: the ring's R prologue loads were issued together (one latency) and the previous layer's activation
+    // stores may still be in flight.  gfx9 counts loads and stores in the same counter and lets them complete out of order, so
+    // with a store pending the compiler must answer every later "is chunk c here?" with vmcnt(0) — which would also wait for the
+    // R-1 younger refills.  From an empty counter on, only in-order loads are pending and the waits inside the loop are counted.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+    for (int cb = 0; cb < NCH; cb += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int c = cb + u;
+            const int ao_c = af.chunk_off(c), ao_n = af.chunk_off(c + 1 < NCH ? c + 1 : c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j + PD < 4) fetch((j + PD) % RS, ao_c, j + PD);
+                else fetch((j + PD) % RS, ao_n, j + PD - 4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NBW; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF::value(a[j % RS][i]), a0_f4_get(ring.v[u][jn], j), acc[i][jn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ring.fill(u, c + R);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    between();
     // C/D layout of v_mfma_f32_16x16x4_f32: column = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
@@ -151,14 +187,16 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, const float* __restrict__ wt
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
                 const int n = (wn * NBW + j) * 16 + r16;
-                const float bv = bias[n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mb * 16 + 4 * q + r;
                     if (m < M) {
-                        float v = acc[i][j][r] + bv;
+                        float v = acc[i][j][r] + bv[j];
                         v = (v < 0.f) ? 0.f : v;
-                        if (out_lds) out_lds[m * out_pitch + n] = v;
+                        if (out_lds) {
+                            const int ow_ = OWC > 0 ? OWC : out_w, oh = m / ow_;
+                            out_lds[oh * out_rp + (m - oh * ow_) * out_pitch + n] = v;
+                        }
                         if (out_glb) out_glb[(long long)m * N + n] = v;
                     }
                 }
@@ -168,6 +206,9 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, const float* __restrict__ wt
     __syncthreads();
 }
 
+// Register-ring depths (16-k chunks in flight per wave): >= 2 us of MFMA work ahead of every weight load.
+constexpr int A0_R1 = 4, A0_R2 = 8, A0_R3 = 12;
+
 template <int MBW1, int MBW2, int MBW3, int WC>
 __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_fused_args P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -175,9 +216,15 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_f
     float* fl = (float*)smem;
     float* act1 = fl + P.off_act1;
     float* act2 = fl + P.off_act2;
-    float* Bs = fl + P.off_bs;
     const int obs_bytes = P.C * P.H * P.W;
     const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
+    a0_wring<32, 2, A0_R1> ring1;
+    a0_wring<64, 4, A0_R2> ring2;
+    a0_wring<64, 4, A0_R3> ring3;
+    ring1.init(P.wt1, P.C * 64);
+    ring2.init(P.wt2, 512);
+    ring3.init(P.wt3, 576);
+    ring1.prologue();
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
         // ---- observation -> LDS (16 B per lane)
         const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
@@ -185,23 +232,34 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_f
         for (int i = threadIdx.x; i < (obs_bytes >> 4); i += A0_FUSED_THREADS) ((uint4*)obs)[i] = src[i];
         __syncthreads();
         AF1<WC> f1{obs, P.H * P.W, P.W, P.W1};
-        if (P.stage_mask & 1) a0_conv_stage<32, 2, MBW1, AF1<WC>>(f1, M1, P.C * 64, P.wt1, P.b1, Bs, act1, A0_P1, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr);
-        AF2 f2{act1, P.W1, P.W2};
-        if (P.stage_mask & 2) a0_conv_stage<64, 4, MBW2, AF2>(f2, M2, 512, P.wt2, P.b2, Bs, act2, A0_P2, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr);
-        AF3 f3{act2, P.W2, P.W3};
-        if (P.stage_mask & 4) a0_conv_stage<64, 4, MBW3, AF3>(f3, M3, 576, P.wt3, P.b3, Bs, nullptr, 0, P.act3 + (long long)b * M3 * 64);
+        constexpr int OW1 = WC == 84 ? 20 : 0, OW2 = WC == 84 ? 9 : 0;      // output widths of conv1 / conv2 when the input is 84 wide
+        float* g1 = P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr;
+        // conv1's 16-row blocks do not divide evenly over the four M groups (25 blocks: 7 + 6 + 6 + 6): groups that own one block less
+        // run the MBW1 - 1 instantiation instead of recomputing a dummy block (same barrier count on both paths)
+        const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
+        if (MBW1 > 1 && wmg1 + (MBW1 - 1) * 4 >= ((M1 + 15) >> 4))
+            a0_conv_stage<32, 2, (MBW1 > 1 ? MBW1 - 1 : 1), 1, A0_R1, OW1>(f1, M1, P.C * 64, ring1, P.b1, act1, A0_P1, P.rp1, P.W1, g1, [&] { ring2.prologue(); });
+        else
+            a0_conv_stage<32, 2, MBW1, 1, A0_R1, OW1>(f1, M1, P.C * 64, ring1, P.b1, act1, A0_P1, P.rp1, P.W1, g1, [&] { ring2.prologue(); });
+        AF2 f2{act1, P.rp1, P.W2};
+        a0_conv_stage<64, 4, MBW2, 3, A0_R2, OW2>(f2, M2, 512, ring2, P.b2, act2, A0_P2, P.rp2, P.W2, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, [&] { ring3.prologue(); });
+        AF3 f3{act2, P.rp2, P.W3};
+        a0_conv_stage<64, 4, MBW3, 3, A0_R3, 0>(f3, M3, 576, ring3, P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, [&] { ring1.prologue(); });
     }
 }
 
-// ---- k-major weight copies: wt1 [K1][32] (pre-divided by 255), wt2 [512][64], wt3 [576][64] from the packed [N][K] blocks
+// ---- fragment-major weight copies (layout: see a0_wring): conv1 (pre-divided by 255), conv2, conv3 from the packed [N][K] blocks
 __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
     const int n1 = 32 * K1, n2 = 64 * 512, n3 = 64 * 576;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n1) { const int k = i / 32, n = i % 32; wt[i] = w1[n * K1 + k] / 255.0f; return; }   // conv1 reads raw bytes: fold the /255 here
-    i -= n1;
-    if (i < n2) { const int k = i / 64, n = i % 64; wt[n1 + i] = w2[n * 512 + k]; return; }
-    i -= n2;
-    if (i < n3) { const int k = i / 64, n = i % 64; wt[n1 + n2 + i] = w3[n * 576 + k]; }
+    const float* w; int N, K; float* dst = wt + i;
+    if (i < n1) { w = w1; N = 32; K = K1; }
+    else if (i < n1 + n2) { i -= n1; w = w2; N = 64; K = 512; }
+    else if (i < n1 + n2 + n3) { i -= n1 + n2; w = w3; N = 64; K = 576; }
+    else return;
+    const int j = i & 3, q = (i >> 2) & 3, n = (i >> 4) % N, c = (i >> 4) / N;
+    const float v = w[n * K + 16 * c + 4 * j + q];
+    *dst = (w == w1) ? v / 255.0f : v;          // conv1 reads raw bytes: the /255 of the reference's normalisation is folded in here
 }
 
 extern "C" long long a0_net_conv_wt_floats(int C) { return 32LL * C * 64 + 64LL * 512 + 64LL * 576; }
@@ -218,13 +276,18 @@ static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_b
     if (!a0_net_core_init(n, C, H, W)) return false;
     const int M1 = n.H1 * n.W1, M2 = n.H2 * n.W2, M3 = n.H3 * n.W3;
     if (M1 > 7 * 4 * 16 || M2 > 4 * 2 * 16 || M3 > 2 * 2 * 16) return false;        // tile capacity of the three stages
+    if ((C * 4) % A0_R1) return false;                                                  // conv1 chunks (K1/16 = 4C) must fill whole ring turns
     const int obs_bytes = C * H * W;
     if (obs_bytes % 16) return false;
     P.C = C; P.H = H; P.W = W; P.H1 = n.H1; P.W1 = n.W1; P.H2 = n.H2; P.W2 = n.W2; P.H3 = n.H3; P.W3 = n.W3;
+    P.rp1 = n.W1 * A0_P1;
+    while ((P.rp1 - n.W2) & 15) ++P.rp1;                   // 2*RP1 = 2*W2 (mod 32)
+    P.rp2 = n.W2 * A0_P2;
+    while ((P.rp2 - 2 * n.W3) & 31) ++P.rp2;               // RP2 = 2*W3 (mod 32)
     P.off_act1 = obs_bytes / 4;
-    P.off_act2 = P.off_act1 + ((M1 * A0_P1 + 3) & ~3);
-    P.off_bs = P.off_act2 + ((M2 * A0_P2 + 3) & ~3);
-    lds_bytes = (size_t)(P.off_bs + 2 * 32 * (64 + 16)) * 4;
+    P.off_act2 = P.off_act1 + ((n.H1 * P.rp1 + 3) & ~3);
+    P.off_end = P.off_act2 + ((n.H2 * P.rp2 + 3) & ~3);
+    lds_bytes = (size_t)P.off_end * 4;
     return lds_bytes <= 160 * 1024;
 }
 
@@ -246,8 +309,6 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     P.wt1 = wt; P.wt2 = wt + 32LL * C * 64; P.wt3 = P.wt2 + 64LL * 512;
     P.b1 = w->b1; P.b2 = w->b2; P.b3 = w->b3;
     P.act1 = act1; P.act2 = act2; P.act3 = act3; P.B = B;
-    static const int stage_mask = getenv("A0_FUSED_STAGES") ? atoi(getenv("A0_FUSED_STAGES")) : 7;
-    P.stage_mask = stage_mask;
     // 16-row blocks per wave: conv1 ceil(MB1/4), conv2 ceil(MB2/2), conv3 ceil(MB3/2); exact for 84x84, generous otherwise
     const int mb1 = (P.H1 * P.W1 + 15) / 16, mb2 = (P.H2 * P.W2 + 15) / 16, mb3 = (P.H3 * P.W3 + 15) / 16;
     const bool standard = ((mb1 + 3) / 4 == 7) && ((mb2 + 1) / 2 == 3) && ((mb3 + 1) / 2 == 2) && W == 84;
