@@ -214,6 +214,131 @@ extern "C" int a0_dense_fwd(const float* X, int ldx, const float* W, const float
     A0_CATCH
 }
 
+// ------------------------------------------------------------------------------------------------ fused actor tail (dqn / mdqn)
+// Everything between the conv features and the chosen action of Actor.act (reference agent.py:25-39 with model.py:108-131 behind
+// it), for scalar-valued heads: fc1 runs as the usual split-K implicit GEMM, but its slabs are consumed directly by ONE kernel that
+// finishes fc1 (slab sum + bias + ReLU), evaluates the q head (A or A+1 rows of 512), applies the dueling combine, takes the first
+// maximum and makes the epsilon-greedy draw from the actor's Philox streams.  One wave per environment; replaces six launches
+// (reduce, head GEMM, reduce, dueling, select, egreedy) on the actor's critical path.
+#include "philox.h"
+__global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2, int A, int dueling, int E,
+                                                             unsigned long long seed, uint32_t stream_a, uint32_t stream_u, unsigned long long off_a,
+                                                             unsigned long long off_u, float eps, const long long* __restrict__ ctrl,
+                                                             const float* __restrict__ eps_ptr, int* __restrict__ action, float* __restrict__ qmax) {
+    __shared__ float raw[4][64];
+    extern __shared__ float w2s[];                       // the head's A(+1) rows of 512, staged once per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    const int NQ = A + (dueling ? 1 : 0);
+    for (int i = threadIdx.x; i < NQ * 128; i += 256) ((a0_f4*)w2s)[i] = ((const a0_f4*)W2)[i];
+    const int er = e < E ? e : E - 1;
+    // fc1: h[k] = relu(b1[k] + sum_z slab_z[e][k]) in slab order (bit-identical to a0_reduce_bias_act_kernel); lane holds k = lane + 64 i.
+    // All eight columns of a slab are requested before any is added, four slabs per trip: the loads overlap instead of queueing.
+    float h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = 0.f;
+    const float* sp = slabs + (long long)er * 512 + lane;
+    int z = 0;
+    for (; z + 4 <= nslab; z += 4) {
+        float t[4][8];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[zz][i] = sp[(long long)(z + zz) * slab_stride + 64 * i];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] += t[zz][i];
+    }
+    for (; z < nslab; ++z) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = sp[(long long)z * slab_stride + 64 * i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] += t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float sv = h[i] + b1[lane + 64 * i];
+        h[i] = sv < 0.f ? 0.f : sv;
+    }
+    __syncthreads();
+    if (e >= E) return;
+    for (int a = 0; a < NQ; ++a) {
+        const float* w = w2s + a * 512;
+        float sa = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sa = fmaf(h[i], w[lane + 64 * i], sa);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
+        if (lane == 0) raw[wave][a] = sa + b2[a];
+    }
+    if (lane != 0) return;
+    float mean = 0.f, v = 0.f;
+    if (dueling) {
+        float t = 0.f;
+        for (int a = 0; a < A; ++a) t += raw[wave][a];
+        mean = t / (float)A;
+        v = raw[wave][A];
+    }
+    float best = 0.f;
+    int besta = 0;
+    for (int a = 0; a < A; ++a) {
+        const float q = dueling ? v + (raw[wave][a] - mean) : raw[wave][a];
+        if (a == 0 || q > best) { best = q; besta = a; }
+    }
+    if (ctrl) { off_a += (unsigned long long)ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)ctrl[A0_CTRL_RNG_UNIFORM]; }
+    if (eps_ptr) eps = eps_ptr[0];
+    const int ra = (int)(a0_philox_word(seed, stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
+    const float u = (float)(a0_philox_word(seed, stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
+    action[e] = (u > eps) ? besta : ra;
+    qmax[e] = best;
+}
+
+extern "C" long long a0_actor_qhead_scratch(int E, int K) {
+    const int splits = a0_fwd_splits((E + 127) / 128, (512 + 63) / 64, K);
+    return (long long)splits * E * 512;
+}
+
+extern "C" int a0_actor_qhead(const float* feat, int E, int K, const float* W1, const float* b1, const float* W2, const float* b2, int A, int dueling,
+                              float* scratch, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                              unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax, void* stream) {
+    A0_TRY
+    if (!feat || !W1 || !b1 || !W2 || !b2 || !scratch || !action || !qmax || E < 1 || K < 4 || (K & 3) || A < 1 || A + (dueling ? 1 : 0) > 24)
+        return a0_fail(A0_EINVAL, "a0_actor_qhead: bad argument (A + dueling <= 24: the head rows are staged in 48 KB of LDS)");
+    a0_hip_backend bk{(hipStream_t)stream};
+    const int splits = a0_fwd_splits((E + 127) / 128, (512 + 63) / 64, K);
+    a0_mat_src a{feat, K};
+    a0_mat_src bw{W1, K};
+    EpiSlab::Params ep{scratch, (long long)E * 512, 512};
+    bk.tag = A0_TAG_DENSE_FWD;
+    bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, ep, E, 512, K, splits);
+    hipLaunchKernelGGL(a0_actor_qhead_kernel, dim3((E + 3) / 4), dim3(256), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, scratch, (long long)E * 512, splits, b1, W2, b2, A, dueling, E,
+                       seed, stream_a, stream_u, off_a, off_u, eps, ctrl, eps_ptr, action, qmax);
+    A0_HIP_THROW(hipGetLastError());
+    return A0_OK;
+    A0_CATCH
+}
+
+// out[t] = mean_e x[t][e]: the per-step mean max-Q of a rollout (agent.py:38,88), all T steps in one launch
+__global__ __launch_bounds__(256) void a0_mean_rows_kernel(const float* __restrict__ x, int E, float* __restrict__ out) {
+    __shared__ float red[256];
+    const float* p = x + (long long)blockIdx.x * E;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) s += p[e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (float)E;
+}
+
+extern "C" int a0_mean_rows(const float* x, int T, int E, float* out, void* stream) {
+    if (!x || !out || T < 1 || E < 1) return a0_fail(A0_EINVAL, "a0_mean_rows: bad argument");
+    hipLaunchKernelGGL(a0_mean_rows_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, x, E, out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_mean_rows");
+}
+
 extern "C" int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K, void* stream) {
     A0_TRY
     if (!dY || !W || !dX || R < 1 || (N & 3) || (K & 3)) return a0_fail(A0_EINVAL, "a0_dense_dgrad: bad shape");

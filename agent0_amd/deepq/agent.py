@@ -56,6 +56,10 @@ class Actor:
         self.u, self.qmax = ops.zeros(E), ops.zeros(E)
         T = max(int(cfg.actor.sample_steps), int(cfg.actor.test_steps) if False else int(cfg.actor.sample_steps))
         self.qs = ops.zeros(T)
+        # scalar heads take the fused tail (fc1 slabs -> q -> dueling -> argmax -> epsilon-greedy in one kernel, a0_actor_qhead)
+        self.fused_tail = self.L.algo in ("dqn", "mdqn") and self.L.feat % 4 == 0 and self.L.A + (1 if self.L.dueling else 0) <= 24
+        self.qmax_all = ops.zeros(T * E) if self.fused_tail else None
+        self._qh_scratch = ops.empty(ops.actor_qhead_scratch(E, self.L.feat)) if self.fused_tail else None
         self.stat_mask, self.stat_ret = ops.zeros(T * E), ops.zeros(T * E)
         self.ring_act, self.ring_rew, self.ring_done = ops.zeros(self.n * E, dtype=torch.int32), ops.zeros(self.n * E), ops.zeros(self.n * E)
         # observation ring for n-step: holds the last n observations; its length divides sample_steps when possible so that the
@@ -74,9 +78,16 @@ class Actor:
         self._stage = None
 
     # ------------------------------------------------------------------ agent.py:25-39
-    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None):
+    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None, t: int = 0):
         L, ops, E, dev = self.L, self.ops, self.E, self.model._dev
         dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E, keep=False)
+        if self.fused_tail:
+            rng = self.rng
+            (W1, b1), (W2, b2) = dev.wb("fc1"), dev.wb("head")
+            ops.actor_qhead(self.ws.act3, E, L.feat, W1, b1, W2, b2, L.A, L.dueling, self._qh_scratch, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
+                            rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action,
+                            self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+            return
         if L.algo == "fqf":
             dev.fqf_taus(self.ws, E)
             dev.head(self.ws, E, self.ws.tau_hat, L.F)
@@ -95,6 +106,8 @@ class Actor:
     def act(self, epsilon):
         one = self.ops.zeros(1)
         self._act_device(epsilon, one)
+        if self.fused_tail:
+            self.ops.mean_rows(self.qmax_all, 1, self.E, one)
         return self.action.cpu().numpy().astype(np.int64), float(one[0])
 
     def reset(self):
@@ -108,7 +121,7 @@ class Actor:
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
                 self.model.reset_noise(rng=self.rng)
-            self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr)
+            self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t)
             cur_obs = self.obs
             if self.n > 1:
                 slot = self.steps % R
@@ -135,6 +148,8 @@ class Actor:
                 stage["obs"][sl].copy_(obs0.view(E, -1)); stage["obs_next"][sl].copy_(obs_next.view(E, -1))
                 stage["act"][sl].copy_(self.out_act); stage["rew"][sl].copy_(self.out_rew); stage["done"][sl].copy_(self.out_done)
             self.obs = obs_next
+        if self.fused_tail:
+            ops.mean_rows(self.qmax_all, T, E, self.qs)          # per-step mean max-Q (agent.py:38,88), all steps at once
 
     def _graph_eligible(self, T, bound, test, state_dict) -> bool:
         cfg = self.cfg

@@ -276,6 +276,20 @@ class HipOps:
                                                _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
                                                _req(prio, torch.float32, B, "prio", optional=True), _stream()), "a0_replay_sample_gather")
 
+    def actor_qhead_scratch(self, E, K) -> int:
+        return int(self.lib.a0_actor_qhead_scratch(E, K))
+
+    def actor_qhead(self, feat, E, K, W1, b1, W2, b2, A, dueling, scratch, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl=None, eps_ptr=None):
+        nq = A + (1 if dueling else 0)
+        check(self.lib.a0_actor_qhead(_req(feat, torch.float32, E * K, "feat"), E, K, _req(W1, torch.float32, 512 * K, "W1"), _req(b1, torch.float32, 512, "b1"),
+                                      _req(W2, torch.float32, nq * 512, "W2"), _req(b2, torch.float32, nq, "b2"), A, int(dueling),
+                                      _req(scratch, torch.float32, self.actor_qhead_scratch(E, K), "scratch"), seed, stream_a, stream_u, off_a, off_u, float(eps),
+                                      _req(ctrl, torch.int64, 8, "ctrl", optional=True), _req(eps_ptr, torch.float32, 1, "eps_ptr", optional=True),
+                                      _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax"), _stream()), "a0_actor_qhead")
+
+    def mean_rows(self, x, T, E, out):
+        check(self.lib.a0_mean_rows(_req(x, torch.float32, T * E, "x"), T, E, _req(out, torch.float32, T, "out"), _stream()), "a0_mean_rows")
+
     def fill_f32(self, p, n, v):
         check(self.lib.a0_fill_f32(_req(p, torch.float32, n, "p"), n, v, _stream()), "a0_fill_f32")
 

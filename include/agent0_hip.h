@@ -177,6 +177,16 @@ int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, floa
 /* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */
 int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action,
                      const float* qmax, float* qs_out, void* stream);
+/* Fused actor tail for scalar heads (dqn / mdqn), Actor.act (agent.py:25-39) after the encoder: fc1 (split-K GEMM into `scratch`,
+ * a0_actor_qhead_scratch(E, K) floats) + bias + ReLU, q head (W2 [A(+1)][512], b2), dueling combine (model.py:123-131), first-max
+ * argmax, epsilon-greedy draw from the Philox streams (same draws as a0_actor_egreedy_rng).  qmax[e] = max_a q(e, a). */
+long long a0_actor_qhead_scratch(int E, int K);
+int a0_actor_qhead(const float* feat, int E, int K, const float* W1, const float* b1, const float* W2, const float* b2, int A, int dueling,
+                   float* scratch, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                   unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax, void* stream);
+/* out[t] = mean over e of x[t][e] (per-step mean max-Q of a rollout, agent.py:38,88) */
+int a0_mean_rows(const float* x, int T, int E, float* out, void* stream);
+
 /* the same with both draws generated in-kernel from Philox streams (bit-identical to a0_rng_randint + a0_rng_uniform + a0_actor_egreedy) */
 int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
                          unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out,
