@@ -111,6 +111,20 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
     if (kb < ke) { sa.fetch(pa, sa0, kb, ke, tid); sb.fetch(pb, sb0, kb, ke, tid); }
     if (kb + BK < ke) { sa.fetch(pa, sa1, kb + BK, ke, tid); sb.fetch(pb, sb1, kb + BK, ke, tid); }
 
+    // EP::ROWSUM_A (weight gradients): row sums of the A tiles, accumulated from LDS by the blockIdx.y == 0 column of workgroups.
+    // Thread (g, xr) adds rows kk = g, g + G, ... of column xr of every tile; the G partial sums meet in LDS after the k loop.
+    constexpr int RS_G = 256 / BX;
+    float rowsum = 0.f;
+    auto rowsum_tile = [&]() {
+        if constexpr (EP::ROWSUM_A) {
+            if (blockIdx.y == 0) {
+                const int xr = tid % BX, g = tid / BX;
+#pragma unroll
+                for (int kk = 0; kk < BK / RS_G; ++kk) rowsum += As[(g + kk * RS_G) * LDA + xr];
+            }
+        }
+    };
+
     const float* ap = As + (lane >> 5) * LDA + wm * (MT * 32) + (lane & 31);
     const float* bp = Bs + (lane >> 5) * LDB + wn * (NT * 32) + (lane & 31);
 
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
         sb.commit(sb0, Bs, tid);
         __syncthreads();
         if (k0 + 2 * BK < ke) { sa.fetch(pa, sa0, k0 + 2 * BK, ke, tid); sb.fetch(pb, sb0, k0 + 2 * BK, ke, tid); }
+        rowsum_tile();
         mma_tile();
         if (k0 + BK >= ke) break;
         __syncthreads();
@@ -151,7 +166,21 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
         sb.commit(sb1, Bs, tid);
         __syncthreads();
         if (k0 + 3 * BK < ke) { sa.fetch(pa, sa1, k0 + 3 * BK, ke, tid); sb.fetch(pb, sb1, k0 + 3 * BK, ke, tid); }
+        rowsum_tile();
         mma_tile();
+    }
+    if constexpr (EP::ROWSUM_A) {
+        if (blockIdx.y == 0) {
+            __syncthreads();                 // As is free: every wave has left the k loop
+            As[tid] = rowsum;
+            __syncthreads();
+            if (tid < BX && x0 + tid < X) {
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < RS_G; ++g) t += As[g * BX + tid];
+                EP::store_rowsum(pe, x0 + tid, t, blockIdx.z);
+            }
+        }
     }
 
     // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)

@@ -42,27 +42,6 @@ __global__ void a0_reduce_bias_act_kernel(const float* __restrict__ slabs, long 
     }
 }
 
-// Bias gradient: db[n] = sum_m dY[m][n] — one block per (32 columns, row chunk), partials into the weight slabs.
-__global__ __launch_bounds__(256) void a0_colsum_kernel(const float* __restrict__ dy, int M, int N, int mchunk,
-                                                         float* __restrict__ out, long long slab_stride, long long bias_off) {
-    __shared__ float red[8][33];
-    const int n = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int r0 = threadIdx.x >> 5;
-    const int mb = blockIdx.y * mchunk;
-    const int me = (M < mb + mchunk) ? M : mb + mchunk;
-    float s = 0.f;
-    if (n < N)
-        for (int m = mb + r0; m < me; m += 8) s += dy[(long long)m * N + n];
-    red[r0][threadIdx.x & 31] = s;
-    __syncthreads();
-    if (threadIdx.x < 32 && n < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x];
-        out[(long long)blockIdx.y * slab_stride + bias_off + n] = t;
-    }
-}
-
 static inline int a0_grid_for(long long count, int block = 256, int cap = 2048) {
     long long g = (count + block - 1) / block;
     if (g > cap) g = cap;
@@ -142,10 +121,6 @@ struct a0_hip_backend {
     }
     void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu) {
         hipLaunchKernelGGL(a0_reduce_bias_act_kernel, dim3(a0_grid_for((long long)rows * N)), dim3(256), 0, st, slabs, slab_stride, nslab, bias, out, rows, N, relu);
-        A0_HIP_THROW(hipGetLastError());
-    }
-    void colsum(const float* dy, int M, int N, int mchunk, int splits, float* out, long long slab_stride, long long bias_off) {
-        hipLaunchKernelGGL(a0_colsum_kernel, dim3((N + 31) / 32, splits), dim3(256), 0, st, dy, M, N, mchunk, out, slab_stride, bias_off);
         A0_HIP_THROW(hipGetLastError());
     }
 };

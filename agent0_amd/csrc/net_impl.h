@@ -8,7 +8,6 @@
 //   void igemm(const OA::Params&, const OB::Params&, const EP::Params&, int X, int Y, int K, int splits);
 //   void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count);
 //   void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu);
-//   void colsum(const float* dy, int M, int N, int mchunk, int splits, float* out, long long slab_stride, long long bias_off);
 #pragma once
 #include "net_tables.h"
 #include "operands.h"
@@ -18,9 +17,13 @@
 enum { A0_TAG_NONE = 0, A0_TAG_CONV1_FWD = 1, A0_TAG_CONV2_FWD = 2, A0_TAG_CONV3_FWD = 3, A0_TAG_DENSE_FWD = 4, A0_TAG_DENSE_DGRAD = 5,
        A0_TAG_DENSE_WGRAD = 6, A0_TAG_CONV3_WGRAD = 7, A0_TAG_CONV3_DGRAD = 8, A0_TAG_CONV2_WGRAD = 9, A0_TAG_CONV2_DGRAD = 10, A0_TAG_CONV1_WGRAD = 11 };
 
-// weight-gradient epilogue: slab z of the layer's [W | b] block
+// weight-gradient epilogue: slab z of the layer's [W | b] block.  ROWSUM_A: the GEMM's A operand is dY^T, so the sums of its rows
+// over the k range of the split ARE the bias gradient; the kernel produces them as a by-product (from the LDS tiles it stages
+// anyway) and stores them at out[z*slab_stride + bias_off + x] — no separate column-sum pass over dY.
 struct EpiWgradSlab {
-    struct Params { float* out; long long slab_stride; int ld; };
+    static constexpr bool ROWSUM_A = true;
+    struct Params { float* out; long long slab_stride; int ld; long long bias_off; };
+    A0_HD static void store_rowsum(const Params& P, int x, float v, int z) { P.out[(long long)z * P.slab_stride + P.bias_off + x] = v; }
     A0_HD static void store(const Params& P, int x, int y, float v, int z) {
         P.out[(long long)z * P.slab_stride + (long long)x * P.ld + y] = v;
     }
@@ -162,13 +165,10 @@ static void a0_dense_dgrad_impl(BK& bk, const float* dY, const float* W, const f
     }
 }
 
-// shared tail of every weight gradient: bias column sums into the same slabs, then the slab reduction
+// shared tail of every weight gradient: the slab reduction (weights and the bias row sums the GEMM left behind them)
 template <class BK>
-static void a0_finish_wgrad(BK& bk, const float* dY, int R, int N, long long wcount, float* grad, float* slabs, int splits) {
-    float* target = (splits > 1) ? slabs : grad;
-    const long long slab_stride = (splits > 1) ? (wcount + N) : 0;
-    bk.colsum(dY, R, N, a0_chunk_rows(R, splits), splits, target, slab_stride, wcount);
-    if (splits > 1) bk.reduce_slabs(slabs, slab_stride, splits, grad, wcount + N);
+static void a0_finish_wgrad(BK& bk, int N, long long wcount, float* grad, float* slabs, int splits) {
+    if (splits > 1) bk.reduce_slabs(slabs, wcount + N, splits, grad, wcount + N);
 }
 
 template <class BK>
@@ -177,10 +177,10 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
     const long long wcount = (long long)N * K;
     a0_mat_src a{dY, N};
     a0_mat_src b{X, ldx};
-    EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K};
+    EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K, wcount};
     bk.tag = A0_TAG_DENSE_WGRAD;
     bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
-    a0_finish_wgrad(bk, dY, R, N, wcount, grad, slabs, splits);
+    a0_finish_wgrad(bk, N, wcount, grad, slabs, splits);
 }
 
 // ------------------------------------------------------------------------------------------------ encoder backward
@@ -195,10 +195,10 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         const long long wc = 64LL * n.K3;
         a0_mat_src a{d3, 64};
         a0_act_src b = a0_act(act2, n.H2, n.W2, 64, n.H3, n.W3, 1, 0, n.ktab3);
-        EpiWgradSlab::Params e{splits > 1 ? slabs : g3, splits > 1 ? wc + 64 : 0, n.K3};
+        EpiWgradSlab::Params e{splits > 1 ? slabs : g3, splits > 1 ? wc + 64 : 0, n.K3, wc};
         bk.tag = A0_TAG_CONV3_WGRAD;
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
-        a0_finish_wgrad(bk, d3, M3, 64, wc, g3, slabs, splits);
+        a0_finish_wgrad(bk, 64, wc, g3, slabs, splits);
     }
     {   // conv3 data gradient -> d2 (masked by act2 > 0): gather form, 3x3 taps over d3 with pad 2
         a0_act_src a = a0_act(d3, n.H3, n.W3, 64, n.H2, n.W2, 1, 2, n.ktab_d3);
@@ -212,10 +212,10 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         const long long wc = 64LL * n.K2;
         a0_mat_src a{d2, 64};
         a0_act_src b = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
-        EpiWgradSlab::Params e{splits > 1 ? slabs : g2, splits > 1 ? wc + 64 : 0, n.K2};
+        EpiWgradSlab::Params e{splits > 1 ? slabs : g2, splits > 1 ? wc + 64 : 0, n.K2, wc};
         bk.tag = A0_TAG_CONV2_WGRAD;
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K2, M2, splits);
-        a0_finish_wgrad(bk, d2, M2, 64, wc, g2, slabs, splits);
+        a0_finish_wgrad(bk, 64, wc, g2, slabs, splits);
     }
     // conv2 data gradient -> d1 (masked by act1 > 0): four stride phases, 2x2 taps over d2 with pad 1
     for (int ph = 0; ph < 2; ++ph)
@@ -233,9 +233,9 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         const long long wc = 32LL * n.K1;
         a0_mat_src a{d1, 32};
         a0_frames_src b = a0_frames(n, f);
-        EpiWgradSlab::Params e{splits > 1 ? slabs : g1, splits > 1 ? wc + 32 : 0, n.K1};
+        EpiWgradSlab::Params e{splits > 1 ? slabs : g1, splits > 1 ? wc + 32 : 0, n.K1, wc};
         bk.tag = A0_TAG_CONV1_WGRAD;
         bk.template igemm<OpMatXC, OpFramesXC, EpiWgradSlab, 1, 4, 1, 1>(a, b, e, 32, n.K1, M1, splits);
-        a0_finish_wgrad(bk, d1, M1, 32, wc, g1, slabs, splits);
+        a0_finish_wgrad(bk, 32, wc, g1, slabs, splits);
     }
 }

@@ -216,6 +216,7 @@ struct OpWtabXC {
 // ------------------------------------------------------------------------------------------------ epilogues
 // store(params, x, y, value, z): x = GEMM row, y = GEMM column, z = blockIdx.z (split / slab index)
 struct EpiBiasAct {            // y = act(v + bias[y]);  relu keeps NaN like torch.relu
+    static constexpr bool ROWSUM_A = false;
     struct Params { float* out; const float* bias; int ld; int relu; };
     A0_HD static void store(const Params& P, int x, int y, float v, int) {
         v += P.bias[y];
@@ -225,6 +226,7 @@ struct EpiBiasAct {            // y = act(v + bias[y]);  relu keeps NaN like tor
 };
 
 struct EpiSlab {               // raw partial sums, one slab per z (split-K forward, weight gradients)
+    static constexpr bool ROWSUM_A = false;
     struct Params { float* out; long long slab_stride; int ld; };
     A0_HD static void store(const Params& P, int x, int y, float v, int z) {
         P.out[(long long)z * P.slab_stride + (long long)x * P.ld + y] = v;
@@ -232,6 +234,7 @@ struct EpiSlab {               // raw partial sums, one slab per z (split-K forw
 };
 
 struct EpiDgrad {              // scatter-free data gradient: row x = (b, h2, w2) of one stride phase
+    static constexpr bool ROWSUM_A = false;
     struct Params {
         float* dx; const float* act;   // act = forward output of the layer below (ReLU mask), same layout as dx
         int HWv, Wv;                   // rows per sample / width of this phase's virtual output
@@ -252,6 +255,7 @@ struct EpiDgrad {              // scatter-free data gradient: row x = (b, h2, w2
 };
 
 struct EpiMaskMat {            // dX[x][y] = act[x][y] > 0 ? v : 0   (dense layers)
+    static constexpr bool ROWSUM_A = false;
     struct Params { float* dx; const float* act; int ld; };
     A0_HD static void store(const Params& P, int x, int y, float v, int) {
         long long i = (long long)x * P.ld + y;

@@ -62,6 +62,12 @@ struct host_backend {
                     for (int k = 0; k < kc; ++k) acc = std::fmaf(A[(size_t)x * kc + k], Bm[(size_t)y * kc + k], acc);
                     EP::store(pe, x, y, acc, z);
                 }
+            if constexpr (EP::ROWSUM_A)
+                for (int x = 0; x < X; ++x) {
+                    float t = 0.f;
+                    for (int k = 0; k < kc; ++k) t += A[(size_t)x * kc + k];
+                    EP::store_rowsum(pe, x, t, z);
+                }
         }
     }
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
@@ -78,16 +84,6 @@ struct host_backend {
             s += bias[i % N];
             if (relu) s = (s < 0.f) ? 0.f : s;
             out[i] = s;
-        }
-    }
-    void colsum(const float* dy, int M, int N, int mchunk, int splits, float* out, long long slab_stride, long long bias_off) {
-        for (int z = 0; z < splits; ++z) {
-            const int mb = z * mchunk, me = (M < mb + mchunk) ? M : mb + mchunk;
-            for (int n = 0; n < N; ++n) {
-                float s = 0.f;
-                for (int m = mb; m < me; ++m) s += dy[(long long)m * N + n];
-                out[(long long)z * slab_stride + bias_off + n] = s;
-            }
         }
     }
 };
