@@ -36,3 +36,4 @@ bool a0_probe_start(int tag, hipStream_t st);
 void a0_probe_stop(hipStream_t st, double flops);
 #endif
 #define A0_TAG_ENCODER_FUSED 12
+#define A0_TAG_ENCODER_DGRAD_FUSED 13

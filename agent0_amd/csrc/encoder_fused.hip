@@ -107,18 +107,47 @@ struct a0_wring {
 };
 A0_D float a0_f4_get(const a0_f4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-// One convolution: C[M x N] = relu(A[M x K] * W^T + bias), A read through AF from LDS, B from the register ring.  Waves: WN along
+// ---- epilogue policies.  Values an epilogue needs from global memory (bias, ReLU masks) are requested at the START of the layer:
+// a load issued in the epilogue would wait behind the next layer's weight prologue.
+template <int OWC>
+struct EpiFwd {                 // y = relu(acc + bias[n]) -> LDS image [oh][ow][n] (pitch / row pitch) and / or global [m][n]
+    static constexpr bool PER_ELEM = false;
+    const float* bias; float* lds; int pitch, rp, ow; float* glb; int N;
+    A0_D float pre_col(int n) const { return bias[n]; }
+    A0_D float pre_elem(int, int) const { return 0.f; }
+    A0_D void emit(int m, int n, float acc, float pre) const {
+        float v = acc + pre;
+        v = (v < 0.f) ? 0.f : v;
+        if (lds) {
+            const int w_ = OWC > 0 ? OWC : ow, oh = m / w_;
+            lds[oh * rp + (m - oh * w_) * pitch + n] = v;
+        }
+        if (glb) glb[(long long)m * N + n] = v;
+    }
+};
+template <int OW, int S>
+struct EpiBwd {                 // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, ow*S + pw) of a Wfull-wide NHWC image; optional padded LDS image
+    static constexpr bool PER_ELEM = true;
+    const float* mask; float* dst; float* lds; int pitch, rp, Wfull, ph, pw, N;
+    A0_D long long gi(int m, int n) const { const int oh = m / OW, ow = m - oh * OW; return (long long)((oh * S + ph) * Wfull + ow * S + pw) * N + n; }
+    A0_D float pre_col(int) const { return 0.f; }
+    A0_D float pre_elem(int m, int n) const { return mask[gi(m, n)]; }
+    A0_D void emit(int m, int n, float acc, float pre) const {
+        const float v = pre > 0.f ? acc : 0.f;
+        dst[gi(m, n)] = v;
+        if (lds) { const int oh = m / OW; lds[oh * rp + (m - oh * OW) * pitch + n] = v; }
+    }
+};
+
+// One convolution-shaped GEMM: C[M x N] = A[M x K] * B, A read through AF from LDS, B from the register ring.  Waves: WN along
 // N, 8/WN along M; a wave owns MBW 16-row blocks (interleaved) x NBW 16-column blocks.  (conv1 2 x 4 waves, conv2 / conv3 4 x 2.)
 // The k loop is one software pipeline over all K/4 MFMA steps: the LDS operands of step g + PD are requested before the MFMAs of
 // step g are issued (register ring of PD + 1 slots); chunk c + R of the weights is requested as soon as chunk c has been consumed.
 // Everything is branch-free (16-row blocks beyond M recompute row 0 and are never stored) and pinned with sched_barriers — left
 // alone, the scheduler sinks every prefetch down to its first use.  `between` runs after the last MFMA and before the epilogue:
 // the caller issues the next layer's weight prologue there, so its L2 latency hides behind the epilogue and the barrier.
-// Output: row m = (oh, ow) of an OW-wide image goes to out_lds[oh*out_rp + ow*out_pitch + n] (OWC > 0: width known at compile time) and /
-// or to out_glb[m*N + n].
-template <int N, int WN, int MBW, int PD, int R, int OWC, class AF, class Between>
-A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, const float* __restrict__ bias, float* out_lds, int out_pitch, int out_rp,
-                        int out_w, float* __restrict__ out_glb, Between&& between) {
+template <int N, int WN, int MBW, int PD, int R, class AF, class EPI, class Between>
+A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, const EPI& epi, Between&& between) {
     constexpr int NB = N / 16, NBW = NB / WN, WMG = A0_FUSED_WAVES / WN, RS = PD + 1;
     static_assert(NBW >= 1 && (4 % RS) == 0, "tile shape");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -139,9 +168,21 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
 #pragma unroll
         for (int j = 0; j < NBW; ++j) acc[i][j] = a0_acc4{0.f, 0.f, 0.f, 0.f};
 
-    float bv[NBW];                                    // bias now: a load in the epilogue would wait for the next layer's weight prologue
+    float pc[NBW], pe[EPI::PER_ELEM ? MBW : 1][NBW][4];
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) bv[j] = bias[(wn * NBW + j) * 16 + r16];
+    for (int j = 0; j < NBW; ++j) {
+        const int n = (wn * NBW + j) * 16 + r16;
+        pc[j] = epi.pre_col(n);
+        if (EPI::PER_ELEM) {
+#pragma unroll
+            for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = (wmg + i * WMG) * 16 + 4 * q + r;
+                    pe[EPI::PER_ELEM ? i : 0][j][r] = epi.pre_elem(m < M ? m : M - 1, n);
+                }
+        }
+    }
     typename AF::Raw a[RS][MBW];
     auto fetch = [&](int slot, int ao, int j) {
 #pragma unroll
@@ -190,15 +231,7 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mb * 16 + 4 * q + r;
-                    if (m < M) {
-                        float v = acc[i][j][r] + bv[j];
-                        v = (v < 0.f) ? 0.f : v;
-                        if (out_lds) {
-                            const int ow_ = OWC > 0 ? OWC : out_w, oh = m / ow_;
-                            out_lds[oh * out_rp + (m - oh * ow_) * out_pitch + n] = v;
-                        }
-                        if (out_glb) out_glb[(long long)m * N + n] = v;
-                    }
+                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pe[EPI::PER_ELEM ? i : 0][j][r] : pc[j]);
                 }
             }
         }
@@ -233,36 +266,123 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_f
         __syncthreads();
         AF1<WC> f1{obs, P.H * P.W, P.W, P.W1};
         constexpr int OW1 = WC == 84 ? 20 : 0, OW2 = WC == 84 ? 9 : 0;      // output widths of conv1 / conv2 when the input is 84 wide
-        float* g1 = P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr;
+        const EpiFwd<OW1> e1{P.b1, act1, A0_P1, P.rp1, P.W1, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
         // conv1's 16-row blocks do not divide evenly over the four M groups (25 blocks: 7 + 6 + 6 + 6): groups that own one block less
         // run the MBW1 - 1 instantiation instead of recomputing a dummy block (same barrier count on both paths)
         const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
         if (MBW1 > 1 && wmg1 + (MBW1 - 1) * 4 >= ((M1 + 15) >> 4))
-            a0_conv_stage<32, 2, (MBW1 > 1 ? MBW1 - 1 : 1), 1, A0_R1, OW1>(f1, M1, P.C * 64, ring1, P.b1, act1, A0_P1, P.rp1, P.W1, g1, [&] { ring2.prologue(); });
+            a0_conv_stage<32, 2, (MBW1 > 1 ? MBW1 - 1 : 1), 1, A0_R1>(f1, M1, P.C * 64, ring1, e1, [&] { ring2.prologue(); });
         else
-            a0_conv_stage<32, 2, MBW1, 1, A0_R1, OW1>(f1, M1, P.C * 64, ring1, P.b1, act1, A0_P1, P.rp1, P.W1, g1, [&] { ring2.prologue(); });
+            a0_conv_stage<32, 2, MBW1, 1, A0_R1>(f1, M1, P.C * 64, ring1, e1, [&] { ring2.prologue(); });
         AF2 f2{act1, P.rp1, P.W2};
-        a0_conv_stage<64, 4, MBW2, 3, A0_R2, OW2>(f2, M2, 512, ring2, P.b2, act2, A0_P2, P.rp2, P.W2, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, [&] { ring3.prologue(); });
+        const EpiFwd<OW2> e2{P.b2, act2, A0_P2, P.rp2, P.W2, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
+        a0_conv_stage<64, 4, MBW2, 3, A0_R2>(f2, M2, 512, ring2, e2, [&] { ring3.prologue(); });
         AF3 f3{act2, P.rp2, P.W3};
-        a0_conv_stage<64, 4, MBW3, 3, A0_R3, 0>(f3, M3, 576, ring3, P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, [&] { ring1.prologue(); });
+        const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
+        a0_conv_stage<64, 4, MBW3, 3, A0_R3>(f3, M3, 576, ring3, e3, [&] { ring1.prologue(); });
     }
 }
 
-// ---- fragment-major weight copies (layout: see a0_wring): conv1 (pre-divided by 255), conv2, conv3 from the packed [N][K] blocks
-__global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
-    const int n1 = 32 * K1, n2 = 64 * 512, n3 = 64 * 576;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float* w; int N, K; float* dst = wt + i;
-    if (i < n1) { w = w1; N = 32; K = K1; }
-    else if (i < n1 + n2) { i -= n1; w = w2; N = 64; K = 512; }
-    else if (i < n1 + n2 + n3) { i -= n1 + n2; w = w3; N = 64; K = 576; }
-    else return;
-    const int j = i & 3, q = (i >> 2) & 3, n = (i >> 4) % N, c = (i >> 4) / N;
-    const float v = w[n * K + 16 * c + 4 * j + q];
-    *dst = (w == w1) ? v / 255.0f : v;          // conv1 reads raw bytes: the /255 of the reference's normalisation is folded in here
+// ------------------------------------------------------------------------------------------------ fused data gradients
+// conv3 and conv2 data gradients of one observation back to back (84x84 geometry: d3 7x7x64 -> d2 9x9x64 -> d1 20x20x32), the
+// counterpart of autograd's conv backward-data for ConvEncoder (reference model.py:93-105, called from agent.py:136-141).  Both are
+// written as stride-1 "gather" convolutions over ZERO-PADDED LDS images, so a0_conv_stage runs them unchanged:
+//   d2[h][w][ci] = sum_{kh',kw',co} d3pad[h + kh'][w + kw'][co] * W3[co][ci][2 - kh'][2 - kw']                 (pad 2, 3x3 taps)
+//   d1[2h2+ph][2w2+pw][ci] = sum_{a',b',co} d2pad[h2 + a'][w2 + b'][co] * W2[co][ci][ph + 2(1-a')][pw + 2(1-b')]   (pad 1, 2x2 taps)
+// the second once per stride phase (ph, pw).  The ReLU masks (act2 > 0, act1 > 0) come from the forward activations in HBM; d2 and d1
+// go to HBM for the weight-gradient GEMMs, d2 also stays in LDS for the four phases.  66 KB of LDS: two workgroups per CU.
+struct a0_dgrad_args {
+    const float *d3, *act1, *act2;
+    float *d2, *d1;
+    const float *wd3, *wd2;          // fragment-major copies (a0_conv_wt_kernel): [576][64] and 4 x [256][32]
+    int B, rpa, rpb;                 // row pitches of the two padded 11 x 11 x 64 LDS images
+};
+struct AFD3 {   // 3x3 taps over d3pad [11][rpa]; k = (kh'*3 + kw')*64 + co; output 9 wide
+    const float* img; int RP;
+    A0_D int row(int m) const { const int oh = m / 9, ow = m - oh * 9; return oh * RP + ow * A0_P2; }
+    A0_D int chunk_off(int c) const { const int cell = c >> 2; return (cell / 3) * RP + (cell % 3) * A0_P2 + 16 * (c & 3); }
+    A0_D int step_off(int j) const { return 4 * j; }
+    typedef float Raw;
+    A0_D Raw load(int addr) const { return img[addr]; }
+    static A0_D float value(Raw r) { return r; }
+};
+struct AFD2 {   // 2x2 taps over d2pad [11][rpb]; k = (a'*2 + b')*64 + co; output 10 wide
+    const float* img; int RP;
+    A0_D int row(int m) const { const int oh = m / 10, ow = m - oh * 10; return oh * RP + ow * A0_P2; }
+    A0_D int chunk_off(int c) const { const int cell = c >> 2; return (cell >> 1) * RP + (cell & 1) * A0_P2 + 16 * (c & 3); }
+    A0_D int step_off(int j) const { return 4 * j; }
+    typedef float Raw;
+    A0_D Raw load(int addr) const { return img[addr]; }
+    static A0_D float value(Raw r) { return r; }
+};
+constexpr int A0_RD3 = 6, A0_RD2 = 4;
+
+__global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kernel(a0_dgrad_args P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* imgA = (float*)smem;                 // d3, padded by 2
+    float* imgB = imgA + 11 * P.rpa;            // d2, padded by 1 (last row / column unused)
+    for (int i = threadIdx.x; i < 11 * (P.rpa + P.rpb); i += A0_FUSED_THREADS) imgA[i] = 0.f;     // borders stay zero for the whole launch
+    a0_wring<64, 4, A0_RD3> ring3;
+    a0_wring<32, 2, A0_RD2> ringp[2];
+    ring3.init(P.wd3, 576);
+    ring3.prologue();
+    __syncthreads();
+    for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+        const a0_f4* src = (const a0_f4*)(P.d3 + (long long)b * 49 * 64);
+        for (int i = threadIdx.x; i < 49 * 16; i += A0_FUSED_THREADS) {
+            const a0_f4 v = src[i];
+            const int pos = i >> 4, c4 = (i & 15) * 4, h = pos / 7, w = pos - h * 7;
+            float* d = imgA + (h + 2) * P.rpa + (w + 2) * A0_P2 + c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        AFD3 f3{imgA, P.rpa};
+        const EpiBwd<9, 1> e3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, imgB + P.rpb + A0_P2, A0_P2, P.rpb, 9, 0, 0, 64};
+        a0_conv_stage<64, 4, 3, 3, A0_RD3>(f3, 81, 576, ring3, e3, [&] { ringp[0].init(P.wd2, 256); ringp[0].prologue(); });
+        AFD2 f2{imgB, P.rpb};
+        const float* m1 = P.act1 + (long long)b * 400 * 32;
+        float* o1 = P.d1 + (long long)b * 400 * 32;
+        const EpiBwd<10, 2> p00{m1, o1, nullptr, 0, 0, 20, 0, 0, 32}, p01{m1, o1, nullptr, 0, 0, 20, 0, 1, 32}, p10{m1, o1, nullptr, 0, 0, 20, 1, 0, 32},
+            p11{m1, o1, nullptr, 0, 0, 20, 1, 1, 32};
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[0], p00, [&] { ringp[1].init(P.wd2 + 1 * 8192, 256); ringp[1].prologue(); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[1], p01, [&] { ringp[0].init(P.wd2 + 2 * 8192, 256); ringp[0].prologue(); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[0], p10, [&] { ringp[1].init(P.wd2 + 3 * 8192, 256); ringp[1].prologue(); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[1], p11, [&] { ring3.prologue(); });
+    }
 }
 
-extern "C" long long a0_net_conv_wt_floats(int C) { return 32LL * C * 64 + 64LL * 512 + 64LL * 576; }
+// ---- fragment-major weight copies (layout: see a0_wring) from the packed [N][K] blocks: conv1 (pre-divided by 255), conv2, conv3 for
+// the forward pass, then the flipped / phase-split matrices of the data gradients: wd3 [576][64], wd2 4 x [256][32]
+__global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
+    const int n1 = 32 * K1, n2 = 64 * 512, n3 = 64 * 576, n4 = 64 * 576, n5 = 4 * 32 * 256;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float* dst = wt + i;
+    int N, seg;
+    if (i < n1) { seg = 1; N = 32; }
+    else if ((i -= n1) < n2) { seg = 2; N = 64; }
+    else if ((i -= n2) < n3) { seg = 3; N = 64; }
+    else if ((i -= n3) < n4) { seg = 4; N = 64; }
+    else if ((i -= n4) < n5) { seg = 5; N = 32; }
+    else return;
+    const int phase = seg == 5 ? i / 8192 : 0;
+    if (seg == 5) i -= phase * 8192;
+    const int j = i & 3, q = (i >> 2) & 3, n = (i >> 4) % N, c = (i >> 4) / N;
+    const int k = 16 * c + 4 * j + q;
+    float v;
+    if (seg == 1) v = w1[n * K1 + k] / 255.0f;        // conv1 reads raw bytes: the /255 of the reference's normalisation is folded in here
+    else if (seg == 2) v = w2[n * 512 + k];
+    else if (seg == 3) v = w3[n * 576 + k];
+    else if (seg == 4) {                               // k = (kh'*3 + kw')*64 + co, n = ci: W3[co][2-kh'][2-kw'][ci]
+        const int cell = k >> 6, co = k & 63, kh = 2 - cell / 3, kw = 2 - cell % 3;
+        v = w3[co * 576 + (kh * 3 + kw) * 64 + n];
+    } else {                                           // k = (a'*2 + b')*64 + co, n = ci: W2[co][ph + 2(1-a')][pw + 2(1-b')][ci]
+        const int cell = k >> 6, co = k & 63, kh = (phase >> 1) + 2 * (1 - (cell >> 1)), kw = (phase & 1) + 2 * (1 - (cell & 1));
+        v = w2[co * 512 + (kh * 4 + kw) * 32 + n];
+    }
+    *dst = v;
+}
+
+extern "C" long long a0_net_conv_wt_floats(int C) { return 32LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; }
 
 extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream) {
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh: bad argument");
@@ -325,6 +445,34 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
         const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
         a0_probe_stop((hipStream_t)stream, per_obs * B);
     }
+    A0_HIP_THROW(hipGetLastError());
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_net_encoder_dgrad_fused_supported(int C, int H, int W) { return (C >= 1 && H == 84 && W == 84) ? 1 : 0; }
+
+// d3 [B][7][7][64] (ReLU-masked) -> d2 [B][9][9][64], d1 [B][20][20][32], masked by act2 / act1 > 0; wt from a0_net_conv_wt_refresh.
+extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, const float* d3, const float* act1, const float* act2, int B, float* d2,
+                                          float* d1, void* stream) {
+    A0_TRY
+    if (!wt || !d3 || !act1 || !act2 || !d2 || !d1 || B < 1) return a0_fail(A0_EINVAL, "a0_net_encoder_dgrad_fused: bad argument");
+    if (!a0_net_encoder_dgrad_fused_supported(C, H, W)) return a0_fail(A0_EINVAL, "a0_net_encoder_dgrad_fused: 84x84 observations only");
+    a0_dgrad_args P;
+    P.d3 = d3; P.act1 = act1; P.act2 = act2; P.d2 = d2; P.d1 = d1; P.B = B;
+    P.wd3 = wt + 32LL * C * 64 + 64LL * 512 + 64LL * 576;
+    P.wd2 = P.wd3 + 64LL * 576;
+    P.rpa = 11 * A0_P2; while ((P.rpa - 2 * 9) & 31) ++P.rpa;      // conflict-free A reads: RP = 2 * (output width) (mod 32)
+    P.rpb = 11 * A0_P2; while ((P.rpb - 2 * 10) & 31) ++P.rpb;
+    const size_t lds = (size_t)11 * (P.rpa + P.rpb) * 4;
+    static bool configured = false;
+    if (!configured) {
+        A0_HIP_THROW(hipFuncSetAttribute((const void*)a0_encoder_dgrad_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const bool probed = a0_probe_start(A0_TAG_ENCODER_DGRAD_FUSED, (hipStream_t)stream);
+    hipLaunchKernelGGL(a0_encoder_dgrad_fused_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    if (probed) a0_probe_stop((hipStream_t)stream, 2.0 * (81.0 * 64 * 576 + 400.0 * 32 * 256) * B);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
     A0_CATCH

@@ -144,11 +144,13 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
 #pragma unroll
                 for (int j = 0; j < NT; ++j) b[nxt][j] = bp[2 * (s + 1) * LDB + j * 32];
             }
+            __builtin_amdgcn_sched_barrier(0);       // keep the reads of step s+1 ahead of the MFMAs of step s (the scheduler sinks them otherwise)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 

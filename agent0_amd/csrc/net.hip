@@ -335,6 +335,17 @@ extern "C" int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* g
     A0_CATCH
 }
 
+extern "C" int a0_net_encoder_wgrad(const a0_net* n, const a0_encoder_weights* w, const a0_frames_arg* f, int B, const float* act1, const float* act2,
+                                    const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, void* stream) {
+    A0_TRY
+    if (!n || !w || !f || !f->frames || !act1 || !act2 || !d3 || !d2 || !d1 || !g1 || !g2 || !g3 || B < 1) return a0_fail(A0_EINVAL, "a0_net_encoder_wgrad: null argument");
+    if (a0_encoder_bwd_scratch_impl(n->core, B) > 0 && !slabs) return a0_fail(A0_EINVAL, "a0_net_encoder_wgrad: needs slab scratch");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_encoder_bwd_impl(bk, n->core, *w, *f, B, act1, act2, d3, const_cast<float*>(d2), const_cast<float*>(d1), g1, g2, g3, slabs, false);
+    return A0_OK;
+    A0_CATCH
+}
+
 extern "C" long long a0_net_encoder_bwd_scratch(const a0_net* n, int B) { return n ? a0_encoder_bwd_scratch_impl(n->core, B) : 0; }
 
 extern "C" int a0_net_encoder_bwd(const a0_net* n, const a0_encoder_weights* w, const a0_frames_arg* f, int B,

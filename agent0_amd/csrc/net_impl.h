@@ -188,7 +188,8 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
 template <class BK>
 static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_weights& w, const a0_frames_arg& f, int B,
                                 const float* act1, const float* act2, const float* d3, float* d2, float* d1,
-                                float* g1, float* g2, float* g3, float* slabs) {
+                                float* g1, float* g2, float* g3, float* slabs, bool with_dgrad = true) {
+    // with_dgrad == false: d2 / d1 already hold the data gradients (a0_net_encoder_dgrad_fused); only the weight gradients run
     const int M3 = B * n.H3 * n.W3, M2 = B * n.H2 * n.W2, M1 = B * n.H1 * n.W1;
     {   // conv3 weight gradient: dW3[64][K3] = sum_m d3[m][:]^T im2col(act2)[m][:]
         const int splits = a0_wgrad_splits(1, (n.K3 + 127) / 128, M3);
@@ -200,7 +201,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
         a0_finish_wgrad(bk, 64, wc, g3, slabs, splits);
     }
-    {   // conv3 data gradient -> d2 (masked by act2 > 0): gather form, 3x3 taps over d3 with pad 2
+    if (with_dgrad) {   // conv3 data gradient -> d2 (masked by act2 > 0): gather form, 3x3 taps over d3 with pad 2
         a0_act_src a = a0_act(d3, n.H3, n.W3, 64, n.H2, n.W2, 1, 2, n.ktab_d3);
         a0_wtab_src b{w.w3, n.wtab_d3};
         EpiDgrad::Params e{d2, act2, n.H2 * n.W2, n.W2, n.H2, n.W2, 64, 1, 0, 0, (long long)n.H2 * n.W2 * 64};
@@ -218,7 +219,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_finish_wgrad(bk, 64, wc, g2, slabs, splits);
     }
     // conv2 data gradient -> d1 (masked by act1 > 0): four stride phases, 2x2 taps over d2 with pad 1
-    for (int ph = 0; ph < 2; ++ph)
+    for (int ph = 0; ph < 2 && with_dgrad; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             const int Hv = (n.H1 - ph + 1) / 2, Wv = (n.W1 - pw + 1) / 2;
             if (Hv < 1 || Wv < 1) continue;

@@ -69,6 +69,7 @@ class DeviceNet:
         self._scratch: Optional[torch.Tensor] = None
         # fused per-observation encoder (encoder_fused.hip): needs k-major copies of the conv weights, refreshed when they change
         self.fused = bool(ops.fused_supported(L.C, L.H, L.W))
+        self.fused_dgrad = self.fused and bool(ops.dgrad_fused_supported(L.C, L.H, L.W))
         self.wt = ops.zeros(ops.conv_wt_floats(L.C)) if self.fused else None
 
     def refresh_wt(self):
@@ -296,8 +297,13 @@ class DeviceLearner:
             ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
             ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
             ops.dense_wgrad(ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines, self.slabs)
-        ops.encoder_bwd(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1,
-                        self.grads[L.blocks["conv1"].all], self.grads[L.blocks["conv2"].all], self.grads[L.blocks["conv3"].all], self.slabs)
+        g1, g2, g3 = self.grads[L.blocks["conv1"].all], self.grads[L.blocks["conv2"].all], self.grads[L.blocks["conv3"].all]
+        if on.fused and on.fused_dgrad:
+            # both data gradients per observation in one kernel (LDS-resident d2), then the three weight-gradient GEMMs
+            ops.encoder_dgrad_fused(self.net, on.wt, ws.d3, ws.act1, ws.act2, B, ws.d2, ws.d1)
+            ops.encoder_wgrad(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
+        else:
+            ops.encoder_bwd(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
         if L.noisy:
             for prefix, block, r0, r1, in_f in L.noise_modules:
                 mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]

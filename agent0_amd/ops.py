@@ -132,6 +132,28 @@ class HipOps:
             _req(g1, torch.float32, 32 * net.K1 + 32, "g1"), _req(g2, torch.float32, 64 * net.K2 + 64, "g2"), _req(g3, torch.float32, 64 * net.K3 + 64, "g3"),
             _req(slabs, torch.float32, need, "slabs", optional=(need == 0)), _stream()), "a0_net_encoder_bwd")
 
+    def dgrad_fused_supported(self, C_, H, W) -> bool:
+        return bool(self.lib.a0_net_encoder_dgrad_fused_supported(C_, H, W))
+
+    def encoder_dgrad_fused(self, net, wt, d3, act1, act2, B, d2, d1):
+        check(self.lib.a0_net_encoder_dgrad_fused(net.C, net.H, net.W, _req(wt, torch.float32, self.conv_wt_floats(net.C), "wt"),
+                                                  _req(d3, torch.float32, B * net.feat, "d3"), _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1"),
+                                                  _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2"), B,
+                                                  _req(d2, torch.float32, B * net.H2 * net.W2 * 64, "d2"), _req(d1, torch.float32, B * net.H1 * net.W1 * 32, "d1"),
+                                                  _stream()), "a0_net_encoder_dgrad_fused")
+
+    def encoder_wgrad(self, net, w, frames, slot, sample_stride, chan_off, B, act1, act2, d3, d2, d1, g1, g2, g3, slabs):
+        fa = self._frames(net, frames, slot, sample_stride, chan_off, B)
+        ew = self._enc_w(w)
+        need = self.encoder_bwd_scratch(net, B)
+        check(self.lib.a0_net_encoder_wgrad(
+            net.h, C.addressof(ew), C.addressof(fa), B,
+            _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1"), _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2"),
+            _req(d3, torch.float32, B * net.feat, "d3"), _req(d2, torch.float32, B * net.H2 * net.W2 * 64, "d2"),
+            _req(d1, torch.float32, B * net.H1 * net.W1 * 32, "d1"),
+            _req(g1, torch.float32, 32 * net.K1 + 32, "g1"), _req(g2, torch.float32, 64 * net.K2 + 64, "g2"), _req(g3, torch.float32, 64 * net.K3 + 64, "g3"),
+            _req(slabs, torch.float32, need, "slabs", optional=(need == 0)), _stream()), "a0_net_encoder_wgrad")
+
     # ------------------------------------------------------------------ dense
     def dense_fwd_scratch(self, R, N, K) -> int:
         return int(self.lib.a0_dense_fwd_scratch(R, N, K))
@@ -373,7 +395,7 @@ class HipOps:
 
     # ------------------------------------------------------------------ measurement
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
-                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12}
+                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}
 
     def probe_begin(self, name: str, max_launches: int = 8192):
         self._probe_name = name

@@ -74,12 +74,23 @@ int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* 
 int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
                              float* act1, float* act2, float* act3, void* stream);
 
+/* Fused conv3 + conv2 data gradients per observation (84x84 geometry), the backward-data half of ConvEncoder (model.py:93-105 under
+ * autograd, agent.py:136-141): d3 [B][7][7][64] -> d2 [B][9][9][64] and d1 [B][20][20][32], masked by act2 / act1 > 0.  wt = the
+ * buffer a0_net_conv_wt_refresh fills (it also holds the flipped / phase-split weight matrices this kernel streams). */
+int a0_net_encoder_dgrad_fused_supported(int C, int H, int W);
+int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, const float* d3, const float* act1, const float* act2, int B, float* d2,
+                               float* d1, void* stream);
+
 /* autograd backward of the encoder (agent.py:153-155).  d3 = dL/d(conv3 pre-activation), already ReLU-masked.
  * g1,g2,g3 receive [dW | db] of each conv in the packed layout.  slabs: a0_net_encoder_bwd_scratch() floats. */
 long long a0_net_encoder_bwd_scratch(const a0_net* net, int B);
 int a0_net_encoder_bwd(const a0_net* net, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
                        const float* act1, const float* act2, const float* d3, float* d2, float* d1,
                        float* g1, float* g2, float* g3, float* slabs, void* stream);
+
+/* the three weight-gradient GEMMs of a0_net_encoder_bwd alone: d2 / d1 are inputs (from a0_net_encoder_dgrad_fused) */
+int a0_net_encoder_wgrad(const a0_net* net, const a0_encoder_weights* w, const a0_frames_arg* frames, int B, const float* act1, const float* act2,
+                         const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, void* stream);
 
 /* nn.Linear / NoisyLinear forward+backward (model.py:54-62,112-114): Y = act(X W^T + b), W [N][K] row-major.
  * N, K, ldx multiples of 4.  scratch sizes from the *_scratch functions (0 => may pass NULL). */

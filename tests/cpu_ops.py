@@ -93,6 +93,9 @@ class CpuOps:
         fa, ew = self._fa(frames, slot, sample_stride, chan_off), self._ew(w)
         self.lib.emul_encoder_fwd(net.h, C.addressof(ew), C.addressof(fa), B, _p(act1), _p(act2), _p(act3))
 
+    def dgrad_fused_supported(self, C_, H, W):
+        return False
+
     def fused_supported(self, C_, H, W):
         return False           # the fused encoder exists only as a HIP kernel; the emulation runs the unfused orchestration
 

@@ -166,3 +166,38 @@ def test_fused_encoder_matches_unfused(hip, shape, B):
     c.act3.fill_(float("nan"))
     hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), ring, slot, 2 * ob, ob, B, None, None, c.act3)
     assert torch.equal(b.act3, c.act3)
+
+
+def test_fused_dgrad_matches_unfused():
+    """a0_net_encoder_dgrad_fused (both conv data gradients per observation, LDS-resident d2) against the implicit-GEMM path of
+    a0_net_encoder_bwd on the same inputs: same taps and masks, different summation order -> fp32 rounding (rtol 2e-5 of the scale)."""
+    from agent0_amd.ops import HipOps
+    from agent0_amd.deepq.engine import DeviceNet, Workspace
+    from agent0_amd.deepq.layout import NetLayout
+    hip = HipOps()
+    spec = recipe.NetSpec("dqn", 4)
+    L = NetLayout.from_spec(spec)
+    net = DeviceNet(hip, L, hip.net(4, 84, 84))
+    net.load_state_dict(recipe.make_state_dict(spec, 5))
+    assert net.fused_dgrad
+    for B in (3, 64):
+        g = recipe.gen(B)
+        frames = torch.from_numpy(g.integers(0, 256, B * 28224, dtype=np.uint8)).cuda()
+        ws = Workspace(hip, L, B, grads=True)
+        net.encode(ws, frames, None, 28224, 0, B, keep=True)
+        d3 = torch.from_numpy(g.standard_normal(B * L.feat).astype(np.float32)).cuda() * (ws.act3 > 0)
+        ws.d3.copy_(d3)
+        grads = hip.zeros(L.n_params_padded)
+        slabs = hip.empty(max(hip.encoder_bwd_scratch(net.net, B), 4))
+        g1, g2, g3 = grads[L.blocks["conv1"].all], grads[L.blocks["conv2"].all], grads[L.blocks["conv3"].all]
+        hip.encoder_bwd(net.net, net.encoder_weights(), frames, None, 28224, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, slabs)
+        ref2, ref1, refg = ws.d2.clone(), ws.d1.clone(), grads.clone()
+        ws.d2.fill_(7.0); ws.d1.fill_(7.0); grads.zero_()
+        hip.encoder_dgrad_fused(net.net, net.wt, ws.d3, ws.act1, ws.act2, B, ws.d2, ws.d1)
+        hip.encoder_wgrad(net.net, net.encoder_weights(), frames, None, 28224, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, slabs)
+        torch.cuda.synchronize()
+        for name, got, ref in (("d2", ws.d2, ref2), ("d1", ws.d1, ref1), ("grads", grads, refg)):
+            scale = float(ref.abs().max())
+            err = float((got - ref).abs().max())
+            assert err <= 2e-5 * scale, (name, B, err, scale)
+        assert torch.equal(ws.d2 == 0, ref2 == 0) or float(((ws.d2 == 0) != (ref2 == 0)).float().mean()) < 1e-4
