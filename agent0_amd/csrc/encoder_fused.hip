@@ -10,12 +10,15 @@
 // one 16-byte global load per 16 k, through a register ring several chunks deep.  There is therefore no barrier and no
 // s_waitcnt vmcnt(0) anywhere inside a convolution's k loop — the eight waves drift apart and keep the matrix pipe shared —
 // only one barrier per layer, when its output lands in LDS.
-// The MFMA is v_mfma_f32_16x16x4_f32: 16-row tiles fit M = 400 / 81 / 49 rows with little padding and split evenly over the
-// eight waves.  conv2 / conv3 are the same k-ascending fp32 fmaf chains as in igemm.h.  conv1 feeds the RAW byte values to the
-// MFMA and folds the reference's x/255 into the weight copy (w/255): its inner loop is instruction-issue bound and the exact
-// three-instruction division per operand element cost more than the MFMA itself; sum_k x_k*fl(w_k/255) and sum_k fl(x_k/255)*w_k
-// carry the same two roundings per term, so the result agrees with the unfused path (and the reference) to fp32 rounding —
-// tests/test_gpu_engine.py::test_fused_encoder_matches_unfused, rtol 2e-6.
+// conv2 / conv3 use v_mfma_f32_16x16x4_f32 (16-row tiles fit M = 81 / 49 rows with little padding and split evenly over the eight
+// waves) and are the same k-ascending fp32 fmaf chains as in igemm.h.
+// conv1 multiplies BYTES by fp32 weights, and both factors can be fed to the 16x-faster bf16 matrix pipe without giving up a bit:
+// a byte 0..255 is exact in bf16 (8 significant bits), the reference's x/255 is folded into the weight (w' = fl(w/255), same two
+// roundings per term as fl(x/255)*w), and w' is split EXACTLY into three bf16 terms w' = hi + mid + lo (8 + 8 + 8 mantissa bits,
+// a0_conv_wt_kernel).  Every product byte * term is exact in fp32, so three v_mfma_f32_16x16x32_bf16 per 32 k accumulate the same
+// real number as the fp32 chain, in fp32 accumulators (measured against fp64: 6.0e-8 vs 7.9e-8 for the fmaf chain,
+// tools/check_bf16x3.hip) at 48 instead of 256 matrix-pipe cycles.  The result agrees with the unfused path (and the reference) to
+// fp32 rounding — tests/test_gpu_engine.py::test_fused_encoder_matches_unfused, rtol 2e-6.
 #include "a0_internal.h"
 #include "net_tables.h"
 #include "operands.h"
@@ -48,19 +51,6 @@ constexpr int A0_P2 = 66;
 // ---- A-operand fetchers: element (row m, k = 16*c + 4*j + q) of the im2col matrix, read directly from LDS.
 // address = row(m) + chunk_off(c) + step_off(j) + q: the chunk part is added once per 16-deep chunk, the step part is a
 // compile-time constant that folds into the DS instruction's immediate offset (WC > 0: width known at compile time).
-template <int WC> struct AF1 {   // conv1 8x8/4 over the u8 observation [C][H][W]; k = c*64 + kh*8 + kw
-    const uint8_t* obs; int HW, W, W1;
-    A0_D int width() const { return WC > 0 ? WC : W; }
-    A0_D int row(int m) const { const int oh = m / W1, ow = m - oh * W1; return (4 * oh) * width() + 4 * ow; }
-    A0_D int chunk_off(int c) const { return (c >> 2) * HW + 2 * (c & 3) * width(); }
-    A0_D int step_off(int j) const { return (j >> 1) * width() + 4 * (j & 1); }
-    // raw byte value 0..255: the 1/255 of the reference's normalisation (agent.py:27,132) is folded into the k-major weight copy.
-    // The ring keeps the byte as loaded; the conversion happens next to the MFMA that consumes it (a convert placed behind the
-    // read would wait for it on the spot and undo the prefetch).
-    typedef uint32_t Raw;
-    A0_D Raw load(int addr) const { return obs[addr]; }
-    static A0_D float value(Raw r) { return (float)r; }
-};
 struct AF2 {   // conv2 4x4/2 over act1 [H1][RP1]; k = (kh*4 + kw)*32 + c
     const float* act; int RP1, W2;
     A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return (2 * oh) * RP1 + 2 * ow * A0_P1; }
@@ -88,21 +78,25 @@ struct a0_wring {
     static constexpr int NBW = N / 16 / WN;
     a0_f4 v[R][NBW];
     const float* base;            // this lane's float4 of chunk 0, column block 0
-    int nch;
+    const float* p;               // next chunk to request: the ring only ever walks forward, one running pointer instead of R addresses
+    int nch, left;
     A0_D void init(const float* wp, int K) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int n = (wave % WN) * (NBW * 16) + (lane & 15), q = lane >> 4;
         base = wp + (n * 4 + q) * 4;
         nch = K >> 4;
     }
-    A0_D void fill(int slot, int c) {
-        c = c < nch ? c : nch - 1;                     // past the end: re-read the last chunk (never consumed), keeps the loop branch-free
+    A0_D void fill(int slot) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) v[slot][j] = *(const a0_f4*)(base + (long long)c * (N * 16) + j * 256);
+        for (int j = 0; j < NBW; ++j) v[slot][j] = *(const a0_f4*)(p + j * 256);
+        const bool more = left > 1;                    // past the end: re-read the last chunk (never consumed), keeps the loop branch-free
+        p += more ? N * 16 : 0;
+        left -= more ? 1 : 0;
     }
     A0_D void prologue() {
+        p = base; left = nch;
 #pragma unroll
-        for (int u = 0; u < R; ++u) fill(u, u);
+        for (int u = 0; u < R; ++u) fill(u);
     }
 };
 A0_D float a0_f4_get(const a0_f4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
@@ -122,20 +116,63 @@ struct EpiFwd {                 // y = relu(acc + bias[n]) -> LDS image [oh][ow]
             const int w_ = OWC > 0 ? OWC : ow, oh = m / w_;
             lds[oh * rp + (m - oh * w_) * pitch + n] = v;
         }
-        if (glb) glb[(long long)m * N + n] = v;
+        if (glb) glb[(unsigned)(m * N + n)] = v;      // per-observation base (uniform) + 32-bit offset: no 64-bit address per element
+    }
+    // rows m0 .. m0+3 (m0 a multiple of 4) of one accumulator: when the image width is a multiple of 4 they sit in one image row
+    static constexpr bool ROW4 = OWC > 0 && (OWC % 4) == 0;
+    A0_D void emit4(int m0, int n, const a0_acc4& acc, float pre) const {
+        constexpr int OWD = OWC > 0 ? OWC : 1;
+        const int oh = m0 / OWD, ow0 = m0 - oh * OWD;
+        float* l = lds ? lds + oh * rp + ow0 * pitch + n : nullptr;
+        const unsigned go = (unsigned)(m0 * N + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[r] + pre;
+            v = (v < 0.f) ? 0.f : v;
+            if (l) l[r * pitch] = v;
+            if (glb) glb[go + (unsigned)(r * N)] = v;
+        }
     }
 };
 template <int OW, int S>
 struct EpiBwd {                 // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, ow*S + pw) of a Wfull-wide NHWC image; optional padded LDS image
     static constexpr bool PER_ELEM = true;
+    static constexpr bool ROW4 = false;
+    A0_D void emit4(int, int, const a0_acc4&, float) const {}
     const float* mask; float* dst; float* lds; int pitch, rp, Wfull, ph, pw, N;
-    A0_D long long gi(int m, int n) const { const int oh = m / OW, ow = m - oh * OW; return (long long)((oh * S + ph) * Wfull + ow * S + pw) * N + n; }
+    A0_D unsigned gi(int m, int n) const { const int oh = m / OW, ow = m - oh * OW; return (unsigned)(((oh * S + ph) * Wfull + ow * S + pw) * N + n); }
     A0_D float pre_col(int) const { return 0.f; }
     A0_D float pre_elem(int m, int n) const { return mask[gi(m, n)]; }
     A0_D void emit(int m, int n, float acc, float pre) const {
         const float v = pre > 0.f ? acc : 0.f;
         dst[gi(m, n)] = v;
         if (lds) { const int oh = m / OW; lds[oh * rp + (m - oh * OW) * pitch + n] = v; }
+    }
+};
+
+// What a layer's epilogue needs from global memory, in the wave's tile layout.  Loaded well ahead of the layer (kernel start, or the
+// previous layer's `between` slot) so that its latency is never waited for on its own.
+template <int N, int WN, int MBW, class EPI>
+struct a0_pre {
+    static constexpr int NBW = N / 16 / WN, WMG = A0_FUSED_WAVES / WN;
+    float pc[NBW], pe[EPI::PER_ELEM ? MBW : 1][NBW][4];
+    A0_D void load(const EPI& epi, int M) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wn = wave % WN, wmg = wave / WN, q = lane >> 4, r16 = lane & 15;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int n = (wn * NBW + j) * 16 + r16;
+            pc[j] = epi.pre_col(n);
+            if (EPI::PER_ELEM) {
+#pragma unroll
+                for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = (wmg + i * WMG) * 16 + 4 * q + r;
+                        pe[EPI::PER_ELEM ? i : 0][j][r] = epi.pre_elem(m < M ? m : M - 1, n);
+                    }
+            }
+        }
     }
 };
 
@@ -146,8 +183,9 @@ struct EpiBwd {                 // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, 
 // Everything is branch-free (16-row blocks beyond M recompute row 0 and are never stored) and pinned with sched_barriers — left
 // alone, the scheduler sinks every prefetch down to its first use.  `between` runs after the last MFMA and before the epilogue:
 // the caller issues the next layer's weight prologue there, so its L2 latency hides behind the epilogue and the barrier.
-template <int N, int WN, int MBW, int PD, int R, class AF, class EPI, class Between>
-A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, const EPI& epi, Between&& between) {
+template <int N, int WN, int MBW, int PD, int R, int MBWP, class AF, class EPI, class Between>
+A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, const EPI& epi, const a0_pre<N, WN, MBWP, EPI>& pre, Between&& between) {
+    static_assert(MBWP >= MBW, "prefetched epilogue values cover the wave's blocks");
     constexpr int NB = N / 16, NBW = NB / WN, WMG = A0_FUSED_WAVES / WN, RS = PD + 1;
     static_assert(NBW >= 1 && (4 % RS) == 0, "tile shape");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -168,21 +206,6 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
 #pragma unroll
         for (int j = 0; j < NBW; ++j) acc[i][j] = a0_acc4{0.f, 0.f, 0.f, 0.f};
 
-    float pc[NBW], pe[EPI::PER_ELEM ? MBW : 1][NBW][4];
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const int n = (wn * NBW + j) * 16 + r16;
-        pc[j] = epi.pre_col(n);
-        if (EPI::PER_ELEM) {
-#pragma unroll
-            for (int i = 0; i < MBW; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = (wmg + i * WMG) * 16 + 4 * q + r;
-                    pe[EPI::PER_ELEM ? i : 0][j][r] = epi.pre_elem(m < M ? m : M - 1, n);
-                }
-        }
-    }
     typename AF::Raw a[RS][MBW];
     auto fetch = [&](int slot, int ao, int j) {
 #pragma unroll
@@ -198,6 +221,7 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
     // with a store pending the compiler must answer every later "is chunk c here?" with vmcnt(0) — which would also wait for the
     // R-1 younger refills.  From an empty counter on, only in-order loads are pending and the waits inside the loop are counted.
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+#pragma unroll 1      // rolled on purpose: unrolled, every refill address becomes a hoisted 64-bit loop invariant (70 register pairs)
     for (int cb = 0; cb < NCH; cb += R) {
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -215,7 +239,7 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF::value(a[j % RS][i]), a0_f4_get(ring.v[u][jn], j), acc[i][jn], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            ring.fill(u, c + R);
+            ring.fill(u);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -231,7 +255,114 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mb * 16 + 4 * q + r;
-                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pe[EPI::PER_ELEM ? i : 0][j][r] : pc[j]);
+                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j][r] : pre.pc[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 on the bf16 pipe
+typedef __bf16 a0_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t a0_u32x4 __attribute__((ext_vector_type(4)));
+
+// conv1 weights: three exact bf16 terms of fl(w/255), fragment-major: uint4 index ((t*32 + n)*4 + q)*3 + s holds the eight k =
+// 32t + 8q .. + 7 of output channel n, term s — the B fragment of lane (n, q) for MFMA step t; a lane's three terms are adjacent.
+template <int R>
+struct a0_wring1 {
+    uint4 v[R][3];
+    const uint4* base;
+    const uint4* p;
+    int nst, left;
+    A0_D void init(const float* wp, int C) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        base = (const uint4*)wp + (((wave % 2) * 16 + (lane & 15)) * 4 + (lane >> 4)) * 3;
+        nst = 2 * C;
+    }
+    A0_D void fill(int slot) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) v[slot][s] = p[s];
+        const bool more = left > 1;
+        p += more ? 3 * 128 : 0;
+        left -= more ? 1 : 0;
+    }
+    A0_D void prologue() {
+        p = base; left = nst;
+#pragma unroll
+        for (int u = 0; u < R; ++u) fill(u);
+    }
+};
+
+// conv1 8x8/4 over the bf16 image [C][H][W] in LDS.  One MFMA step = 32 k = kernel rows kh = 4(t&1) + q (q = lane >> 4), all eight
+// kw, of channel t >> 1: the A fragment of lane (row m, q) is the 8 consecutive pixels img[c][4oh + kh][4ow .. 4ow + 7] (16 bytes,
+// 8-byte aligned: two ds_read_b64).  Waves: 2 along N x 4 along M, MBW 16-row blocks each; same pipeline discipline as a0_conv_stage.
+template <int MBW, int R, int WC, int MBWP, class EPI, class Between>
+A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0_wring1<R>& ring, const EPI& epi, const a0_pre<32, 2, MBWP, EPI>& pre,
+                         Between&& between) {
+    static_assert((R % 2) == 0 && MBWP >= MBW, "ring shape");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % 2, wmg = wave / 2;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int W = WC > 0 ? WC : Wrt;
+    const int MB = (M + 15) >> 4, NST = ring.nst;
+    int rows[MBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        int m = (wmg + i * 4) * 16 + r16;
+        m = m < M ? m : 0;
+        const int oh = m / W1, ow = m - oh * W1;
+        rows[i] = (4 * oh + q) * W + 4 * ow;
+    }
+    a0_acc4 acc[MBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) acc[i] = a0_acc4{0.f, 0.f, 0.f, 0.f};
+    uint2 a[2][MBW][2];
+    auto fetch = [&](int slot, int off) {
+#pragma unroll
+        for (int i = 0; i < MBW; ++i) {
+            a[slot][i][0] = *(const uint2*)(img + rows[i] + off);
+            a[slot][i][1] = *(const uint2*)(img + rows[i] + off + 4);
+        }
+    };
+    fetch(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see a0_conv_stage
+#pragma unroll 1
+    for (int tb = 0; tb < NST; tb += R) {
+        const int base = (tb >> 1) * HW;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const bool last = tb + u + 1 >= NST;     // past the end: re-read the current step (never consumed)
+            const int un = u + 1;
+            fetch(un & 1, last ? base + (u >> 1) * HW + (u & 1) * 4 * W : base + (un >> 1) * HW + (un & 1) * 4 * W);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < MBW; ++i) {
+                    const a0_u32x4 av = {a[u & 1][i][0].x, a[u & 1][i][0].y, a[u & 1][i][1].x, a[u & 1][i][1].y};
+                    const a0_u32x4 bv = {ring.v[u][s].x, ring.v[u][s].y, ring.v[u][s].z, ring.v[u][s].w};
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            ring.fill(u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    between();
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        const int mb = wmg + i * 4;
+        if (mb < MB) {
+            const int n = wn * 16 + r16;
+            if (EPI::ROW4 && mb * 16 + 16 <= M) {
+                epi.emit4(mb * 16 + 4 * q, n, acc[i], pre.pc[0]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb * 16 + 4 * q + r;
+                    if (m < M) epi.emit(m, n, acc[i][r], pre.pc[0]);
                 }
             }
         }
@@ -240,46 +371,77 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
 }
 
 // Register-ring depths (16-k chunks in flight per wave): >= 2 us of MFMA work ahead of every weight load.
-constexpr int A0_R1 = 4, A0_R2 = 8, A0_R3 = 12;
+constexpr int A0_R1 = 4, A0_R2 = 4, A0_R3 = 6;     // conv1: 32-k steps (three 16-byte terms each); conv2 / conv3: 16-k chunks
 
 template <int MBW1, int MBW2, int MBW3, int WC>
 __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_fused_args P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint8_t* obs = smem;
+    uint16_t* img = (uint16_t*)smem;            // the observation as bf16 (exact for bytes), [C][H][W]
     float* fl = (float*)smem;
     float* act1 = fl + P.off_act1;
     float* act2 = fl + P.off_act2;
     const int obs_bytes = P.C * P.H * P.W;
     const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
-    a0_wring<32, 2, A0_R1> ring1;
+    a0_wring1<A0_R1> ring1;
     a0_wring<64, 4, A0_R2> ring2;
     a0_wring<64, 4, A0_R3> ring3;
-    ring1.init(P.wt1, P.C * 64);
+    ring1.init(P.wt1, P.C);
     ring2.init(P.wt2, 512);
     ring3.init(P.wt3, 576);
     ring1.prologue();
+    constexpr int OW1 = WC == 84 ? 20 : 0, OW2 = WC == 84 ? 9 : 0;      // output widths of conv1 / conv2 when the input is 84 wide
+    a0_pre<32, 2, MBW1, EpiFwd<OW1>> pre1;
+    a0_pre<64, 4, MBW2, EpiFwd<OW2>> pre2;
+    a0_pre<64, 4, MBW3, EpiFwd<0>> pre3;
+    pre1.load(EpiFwd<OW1>{P.b1, nullptr, 0, 0, 1, nullptr, 32}, M1);   // biases: once per launch, ahead of everything
+    pre2.load(EpiFwd<OW2>{P.b2, nullptr, 0, 0, 1, nullptr, 64}, M2);
+    pre3.load(EpiFwd<0>{P.b3, nullptr, 0, 0, 1, nullptr, 64}, M3);
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
-        // ---- observation -> LDS (16 B per lane)
+        // ---- observation -> LDS as bf16: 16 bytes in, 32 bytes out per lane and trip; (float)byte is exact and its low 16 bits are zero
         const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
         const uint4* src = (const uint4*)(P.frames + s * P.sample_stride + P.chan_off);
-        for (int i = threadIdx.x; i < (obs_bytes >> 4); i += A0_FUSED_THREADS) ((uint4*)obs)[i] = src[i];
+        // (all of a lane's loads are requested before the first is converted: one HBM latency per observation, not one per trip)
+        constexpr int TRIPS = 4;
+        const int n16 = obs_bytes >> 4;
+        for (int i0 = threadIdx.x; i0 < n16; i0 += TRIPS * A0_FUSED_THREADS) {
+            uint4 v[TRIPS];
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                const int i = i0 + j * A0_FUSED_THREADS;
+                v[j] = src[i < n16 ? i : n16 - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                int i = i0 + j * A0_FUSED_THREADS;
+                i = i < n16 ? i : n16 - 1;                 // lanes past the end redo the last group (same bytes, same address): no branch
+                const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t f0 = __float_as_uint((float)(w[k] & 0xffu)), f1 = __float_as_uint((float)((w[k] >> 8) & 0xffu));
+                    const uint32_t f2 = __float_as_uint((float)((w[k] >> 16) & 0xffu)), f3 = __float_as_uint((float)(w[k] >> 24));
+                    o[2 * k] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);          // high halves of f0 (low) and f1 (high)
+                    o[2 * k + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+                }
+                ((uint4*)img)[2 * i] = uint4{o[0], o[1], o[2], o[3]};
+                ((uint4*)img)[2 * i + 1] = uint4{o[4], o[5], o[6], o[7]};
+            }
+        }
         __syncthreads();
-        AF1<WC> f1{obs, P.H * P.W, P.W, P.W1};
-        constexpr int OW1 = WC == 84 ? 20 : 0, OW2 = WC == 84 ? 9 : 0;      // output widths of conv1 / conv2 when the input is 84 wide
         const EpiFwd<OW1> e1{P.b1, act1, A0_P1, P.rp1, P.W1, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
         // conv1's 16-row blocks do not divide evenly over the four M groups (25 blocks: 7 + 6 + 6 + 6): groups that own one block less
         // run the MBW1 - 1 instantiation instead of recomputing a dummy block (same barrier count on both paths)
         const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
         if (MBW1 > 1 && wmg1 + (MBW1 - 1) * 4 >= ((M1 + 15) >> 4))
-            a0_conv_stage<32, 2, (MBW1 > 1 ? MBW1 - 1 : 1), 1, A0_R1>(f1, M1, P.C * 64, ring1, e1, [&] { ring2.prologue(); });
+            a0_conv1_stage<(MBW1 > 1 ? MBW1 - 1 : 1), A0_R1, WC>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
-            a0_conv_stage<32, 2, MBW1, 1, A0_R1>(f1, M1, P.C * 64, ring1, e1, [&] { ring2.prologue(); });
+            a0_conv1_stage<MBW1, A0_R1, WC>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         AF2 f2{act1, P.rp1, P.W2};
         const EpiFwd<OW2> e2{P.b2, act2, A0_P2, P.rp2, P.W2, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
-        a0_conv_stage<64, 4, MBW2, 3, A0_R2>(f2, M2, 512, ring2, e2, [&] { ring3.prologue(); });
+        a0_conv_stage<64, 4, MBW2, 3, A0_R2>(f2, M2, 512, ring2, e2, pre2, [&] { ring3.prologue(); });
         AF3 f3{act2, P.rp2, P.W3};
         const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
-        a0_conv_stage<64, 4, MBW3, 3, A0_R3>(f3, M3, 576, ring3, e3, [&] { ring1.prologue(); });
+        a0_conv_stage<64, 4, MBW3, 3, A0_R3>(f3, M3, 576, ring3, e3, pre3, [&] { ring1.prologue(); });
     }
 }
 
@@ -326,6 +488,13 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kerne
     a0_wring<32, 2, A0_RD2> ringp[2];
     ring3.init(P.wd3, 576);
     ring3.prologue();
+    typedef EpiBwd<9, 1> E3;
+    typedef EpiBwd<10, 2> E2;
+    a0_pre<64, 4, 3, E3> pre3;
+    a0_pre<32, 2, 2, E2> prep[2];
+    auto epi3 = [&](int b) { return E3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, imgB + P.rpb + A0_P2, A0_P2, P.rpb, 9, 0, 0, 64}; };
+    auto epi2 = [&](int b, int ph, int pw) { return E2{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, nullptr, 0, 0, 20, ph, pw, 32}; };
+    if ((int)blockIdx.x < P.B) pre3.load(epi3(blockIdx.x), 81);
     __syncthreads();
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
         const a0_f4* src = (const a0_f4*)(P.d3 + (long long)b * 49 * 64);
@@ -337,29 +506,44 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kerne
         }
         __syncthreads();
         AFD3 f3{imgA, P.rpa};
-        const EpiBwd<9, 1> e3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, imgB + P.rpb + A0_P2, A0_P2, P.rpb, 9, 0, 0, 64};
-        a0_conv_stage<64, 4, 3, 3, A0_RD3>(f3, 81, 576, ring3, e3, [&] { ringp[0].init(P.wd2, 256); ringp[0].prologue(); });
         AFD2 f2{imgB, P.rpb};
-        const float* m1 = P.act1 + (long long)b * 400 * 32;
-        float* o1 = P.d1 + (long long)b * 400 * 32;
-        const EpiBwd<10, 2> p00{m1, o1, nullptr, 0, 0, 20, 0, 0, 32}, p01{m1, o1, nullptr, 0, 0, 20, 0, 1, 32}, p10{m1, o1, nullptr, 0, 0, 20, 1, 0, 32},
-            p11{m1, o1, nullptr, 0, 0, 20, 1, 1, 32};
-        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[0], p00, [&] { ringp[1].init(P.wd2 + 1 * 8192, 256); ringp[1].prologue(); });
-        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[1], p01, [&] { ringp[0].init(P.wd2 + 2 * 8192, 256); ringp[0].prologue(); });
-        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[0], p10, [&] { ringp[1].init(P.wd2 + 3 * 8192, 256); ringp[1].prologue(); });
-        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[1], p11, [&] { ring3.prologue(); });
+        const int bn = b + gridDim.x < P.B ? b + gridDim.x : b;       // next observation of this workgroup (its masks are prefetched in the last slot)
+        // each `between` slot requests the NEXT layer's weights and ReLU masks before this layer's epilogue runs
+        a0_conv_stage<64, 4, 3, 3, A0_RD3>(f3, 81, 576, ring3, epi3(b), pre3, [&] { ringp[0].init(P.wd2, 256); ringp[0].prologue(); prep[0].load(epi2(b, 0, 0), 100); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[0], epi2(b, 0, 0), prep[0], [&] { ringp[1].init(P.wd2 + 1 * 8192, 256); ringp[1].prologue(); prep[1].load(epi2(b, 0, 1), 100); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[1], epi2(b, 0, 1), prep[1], [&] { ringp[0].init(P.wd2 + 2 * 8192, 256); ringp[0].prologue(); prep[0].load(epi2(b, 1, 0), 100); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[0], epi2(b, 1, 0), prep[0], [&] { ringp[1].init(P.wd2 + 3 * 8192, 256); ringp[1].prologue(); prep[1].load(epi2(b, 1, 1), 100); });
+        a0_conv_stage<32, 2, 2, 3, A0_RD2>(f2, 100, 256, ringp[1], epi2(b, 1, 1), prep[1], [&] { ring3.prologue(); pre3.load(epi3(bn), 81); });
     }
 }
 
-// ---- fragment-major weight copies (layout: see a0_wring) from the packed [N][K] blocks: conv1 (pre-divided by 255), conv2, conv3 for
-// the forward pass, then the flipped / phase-split matrices of the data gradients: wd3 [576][64], wd2 4 x [256][32]
+// ---- weight copies for the fused kernels, from the packed [N][K] blocks (layouts: a0_wring1 / a0_wring):
+//   seg 1  conv1: fl(w/255) split exactly into three bf16 terms, 16-byte fragments ((t*32 + n)*4 + q)*3 + s   (12 C KB)
+//   seg 2,3 conv2, conv3 fragment-major fp32;  seg 4,5 the flipped / phase-split matrices of the data gradients (wd3 [576][64], wd2 4 x [256][32])
+A0_HD uint32_t a0_bf16_trunc(float f) { return __float_as_uint(f) >> 16; }
+A0_HD float a0_bf16_up(uint32_t h) { return __uint_as_float(h << 16); }
 __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
-    const int n1 = 32 * K1, n2 = 64 * 512, n3 = 64 * 576, n4 = 64 * 576, n5 = 4 * 32 * 256;
+    const int n1 = 48 * K1, n2 = 64 * 512, n3 = 64 * 576, n4 = 64 * 576, n5 = 4 * 32 * 256;      // n1: 32 channels x K1 x 3 terms x 2 bytes, in floats
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     float* dst = wt + i;
+    if (i < n1) {      // one dword = two consecutive k of one (t, s, n, q) fragment
+        const int pair = i & 3, f = i >> 2, s = f % 3, q = (f / 3) & 3, n = (f / 12) & 31, t = f / 384;
+        uint32_t out = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 32 * t + 8 * q + 2 * pair + h;
+            const float w = w1[n * K1 + k] / 255.0f;          // conv1 multiplies raw bytes: the reference's /255 is folded in here
+            const uint32_t hi = a0_bf16_trunc(w);
+            const float r1 = w - a0_bf16_up(hi);              // exact
+            const uint32_t mid = a0_bf16_trunc(r1);
+            const float r2 = r1 - a0_bf16_up(mid);            // exact, at most 8 significant bits left
+            const uint32_t lo = a0_bf16_trunc(r2);
+            out |= (s == 0 ? hi : s == 1 ? mid : lo) << (16 * h);
+        }
+        *(uint32_t*)dst = out;
+        return;
+    }
     int N, seg;
-    if (i < n1) { seg = 1; N = 32; }
-    else if ((i -= n1) < n2) { seg = 2; N = 64; }
+    if ((i -= n1) < n2) { seg = 2; N = 64; }
     else if ((i -= n2) < n3) { seg = 3; N = 64; }
     else if ((i -= n3) < n4) { seg = 4; N = 64; }
     else if ((i -= n4) < n5) { seg = 5; N = 32; }
@@ -369,8 +553,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
     const int j = i & 3, q = (i >> 2) & 3, n = (i >> 4) % N, c = (i >> 4) / N;
     const int k = 16 * c + 4 * j + q;
     float v;
-    if (seg == 1) v = w1[n * K1 + k] / 255.0f;        // conv1 reads raw bytes: the /255 of the reference's normalisation is folded in here
-    else if (seg == 2) v = w2[n * 512 + k];
+    if (seg == 2) v = w2[n * 512 + k];
     else if (seg == 3) v = w3[n * 576 + k];
     else if (seg == 4) {                               // k = (kh'*3 + kw')*64 + co, n = ci: W3[co][2-kh'][2-kw'][ci]
         const int cell = k >> 6, co = k & 63, kh = 2 - cell / 3, kw = 2 - cell % 3;
@@ -382,7 +565,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
     *dst = v;
 }
 
-extern "C" long long a0_net_conv_wt_floats(int C) { return 32LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; }
+extern "C" long long a0_net_conv_wt_floats(int C) { return 48LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; }
 
 extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream) {
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh: bad argument");
@@ -396,7 +579,7 @@ static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_b
     if (!a0_net_core_init(n, C, H, W)) return false;
     const int M1 = n.H1 * n.W1, M2 = n.H2 * n.W2, M3 = n.H3 * n.W3;
     if (M1 > 7 * 4 * 16 || M2 > 4 * 2 * 16 || M3 > 2 * 2 * 16) return false;        // tile capacity of the three stages
-    if ((C * 4) % A0_R1) return false;                                                  // conv1 chunks (K1/16 = 4C) must fill whole ring turns
+    if ((C * 2) % A0_R1 || (W & 3)) return false;                                       // conv1 steps (K1/32 = 2C) fill whole ring turns; 8-byte aligned bf16 rows
     const int obs_bytes = C * H * W;
     if (obs_bytes % 16) return false;
     P.C = C; P.H = H; P.W = W; P.H1 = n.H1; P.W1 = n.W1; P.H2 = n.H2; P.W2 = n.W2; P.H3 = n.H3; P.W3 = n.W3;
@@ -404,7 +587,7 @@ static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_b
     while ((P.rp1 - n.W2) & 15) ++P.rp1;                   // 2*RP1 = 2*W2 (mod 32)
     P.rp2 = n.W2 * A0_P2;
     while ((P.rp2 - 2 * n.W3) & 31) ++P.rp2;               // RP2 = 2*W3 (mod 32)
-    P.off_act1 = obs_bytes / 4;
+    P.off_act1 = obs_bytes / 2;                            // the bf16 image takes 2 bytes per pixel
     P.off_act2 = P.off_act1 + ((n.H1 * P.rp1 + 3) & ~3);
     P.off_end = P.off_act2 + ((n.H2 * P.rp2 + 3) & ~3);
     lds_bytes = (size_t)P.off_end * 4;
@@ -426,7 +609,7 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     if (!a0_fused_layout(C, H, W, P, lds)) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused: observation shape not supported by the fused kernel");
     if ((f->sample_stride % 16) || (f->chan_off % 16) || (((uintptr_t)f->frames) % 16)) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused: frames must be 16-byte aligned");
     P.frames = f->frames; P.slot = f->slot; P.sample_stride = f->sample_stride; P.chan_off = f->chan_off;
-    P.wt1 = wt; P.wt2 = wt + 32LL * C * 64; P.wt3 = P.wt2 + 64LL * 512;
+    P.wt1 = wt; P.wt2 = wt + 48LL * C * 64; P.wt3 = P.wt2 + 64LL * 512;
     P.b1 = w->b1; P.b2 = w->b2; P.b3 = w->b3;
     P.act1 = act1; P.act2 = act2; P.act3 = act3; P.B = B;
     // 16-row blocks per wave: conv1 ceil(MB1/4), conv2 ceil(MB2/2), conv3 ceil(MB3/2); exact for 84x84, generous otherwise
@@ -460,7 +643,7 @@ extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, 
     if (!a0_net_encoder_dgrad_fused_supported(C, H, W)) return a0_fail(A0_EINVAL, "a0_net_encoder_dgrad_fused: 84x84 observations only");
     a0_dgrad_args P;
     P.d3 = d3; P.act1 = act1; P.act2 = act2; P.d2 = d2; P.d1 = d1; P.B = B;
-    P.wd3 = wt + 32LL * C * 64 + 64LL * 512 + 64LL * 576;
+    P.wd3 = wt + 48LL * C * 64 + 64LL * 512 + 64LL * 576;
     P.wd2 = P.wd3 + 64LL * 576;
     P.rpa = 11 * A0_P2; while ((P.rpa - 2 * 9) & 31) ++P.rpa;      // conflict-free A reads: RP = 2 * (output width) (mod 32)
     P.rpb = 11 * A0_P2; while ((P.rpb - 2 * 10) & 31) ++P.rpb;

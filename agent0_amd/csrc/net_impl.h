@@ -9,6 +9,7 @@
 //   void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count);
 //   void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu);
 #pragma once
+#include <cstdlib>
 #include "net_tables.h"
 #include "operands.h"
 #include "../../include/agent0_hip.h"
@@ -51,6 +52,8 @@ static inline a0_act_src a0_act(const float* x, int Hin, int Win, int C, int Hou
 
 // ---- split heuristics (pure functions of the shapes, shared by the *_scratch queries)
 static inline int a0_fwd_splits(int gx, int gy, int K) {
+    static const int forced = getenv("A0_FWD_SPLITS") ? atoi(getenv("A0_FWD_SPLITS")) : 0;     // tuning aid
+    if (forced > 0) return forced;
     int blocks = gx * gy, splits = 1;
     if (blocks < 256) {
         splits = 512 / blocks;
