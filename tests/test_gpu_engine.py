@@ -201,3 +201,49 @@ def test_fused_dgrad_matches_unfused():
             err = float((got - ref).abs().max())
             assert err <= 2e-5 * scale, (name, B, err, scale)
         assert torch.equal(ws.d2 == 0, ref2 == 0) or float(((ws.d2 == 0) != (ref2 == 0)).float().mean()) < 1e-4
+
+
+def test_conv1_bf16_split_is_exact_and_fp32_accurate():
+    """conv1 of the fused encoder runs on the bf16 matrix pipe.  (1) The three bf16 terms a0_conv_wt_kernel stores for every weight add up
+    to fl(w/255) EXACTLY (bit for bit), so with bytes exact in bf16 every product is exact in fp32.  (2) The layer's output is as close
+    to an fp64 evaluation as the fp32 fmaf chain of the unfused kernel (both within 2e-6 of the scale)."""
+    from agent0_amd.ops import HipOps
+    from agent0_amd.deepq.engine import DeviceNet, Workspace
+    from agent0_amd.deepq.layout import NetLayout
+    hip = HipOps()
+    spec = recipe.NetSpec("dqn", 4)
+    L = NetLayout.from_spec(spec)
+    net = DeviceNet(hip, L, hip.net(4, 84, 84))
+    sd = recipe.make_state_dict(spec, 9)
+    net.load_state_dict(sd)
+    # ---- (1) exact split: uint4 fragment ((t*32 + n)*4 + q)*3 + s holds k = 32t + 8q .. +7 of channel n, term s
+    K1 = 256
+    raw = net.wt[:48 * K1].view(torch.int32).cpu().numpy().view(np.uint16).reshape(8, 32, 4, 3, 8)       # [t][n][q][s][8]
+    terms = (raw.astype(np.uint32) << 16).view(np.float32)                                                # bf16 -> fp32, exact
+    total = (terms[:, :, :, 0].astype(np.float64) + terms[:, :, :, 1].astype(np.float64) + terms[:, :, :, 2].astype(np.float64))
+    got = np.transpose(total, (1, 0, 2, 3)).reshape(32, K1)                                               # [n][k = 32t + 8q + j]
+    w1 = net.encoder_weights()["w1"].cpu().numpy().reshape(32, K1)
+    want = (w1 / np.float32(255.0)).astype(np.float32)
+    assert np.array_equal(got.astype(np.float32), want) and np.array_equal(got, want.astype(np.float64))
+    # ---- (2) accuracy against fp64
+    B = 2
+    g = recipe.gen(77)
+    frames_np = g.integers(0, 256, (B, 4, 84, 84), dtype=np.uint8)
+    frames = torch.from_numpy(frames_np.reshape(-1)).cuda()
+    ws_f, ws_u = Workspace(hip, L, B), Workspace(hip, L, B)
+    hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), frames, None, 28224, 0, B, ws_f.act1, ws_f.act2, ws_f.act3)
+    hip.encoder_fwd(net.net, net.encoder_weights(), frames, None, 28224, 0, B, ws_u.act1, ws_u.act2, ws_u.act3)
+    w = np.asarray(sd["encoder.convs.0.weight"], dtype=np.float64)        # [32][4][8][8]
+    bias = np.asarray(sd["encoder.convs.0.bias"], dtype=np.float64)
+    x = frames_np.astype(np.float64) / 255.0
+    ref = np.zeros((B, 20, 20, 32))
+    for oh in range(20):
+        for ow in range(20):
+            patch = x[:, :, 4 * oh:4 * oh + 8, 4 * ow:4 * ow + 8].reshape(B, -1)
+            ref[:, oh, ow, :] = patch @ w.reshape(32, -1).T + bias
+    ref = np.maximum(ref, 0.0).reshape(-1)
+    scale = np.abs(ref).max()
+    e_f = np.abs(ws_f.act1.cpu().numpy().astype(np.float64) - ref).max()
+    e_u = np.abs(ws_u.act1.cpu().numpy().astype(np.float64) - ref).max()
+    assert e_f <= 2e-6 * scale and e_u <= 2e-6 * scale, (e_f, e_u, scale)
+    assert e_f <= 2.0 * e_u + 1e-7 * scale, (e_f, e_u)
