@@ -135,6 +135,9 @@ class Trainer:
         has_frac = False
         if len(self.replay) > cfg.trainer.training_start_steps:
             rp = self.replay
+            if self._loss_means.numel() < cfg.learner.learner_steps:       # learner_steps changed after construction
+                self._loss_means = self.ops.zeros(cfg.learner.learner_steps)
+                self._floss_means = self.ops.zeros(cfg.learner.learner_steps)
             for i in range(cfg.learner.learner_steps):
                 b = rp.sample()
                 q_loss, f_loss = self.learner.train_batch(rp.frames, b.slot, rp.row_bytes, b.act, b.rew, b.done, b.weights)

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--sample-steps", type=int, default=80)
     ap.add_argument("--env", default="Breakout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ratio320", action="store_true", help="skip the extra learner_steps=320 measurement")
     ap.add_argument("--entry", choices=("main", "launch"), default="main",
                     help="main: agent0.deepq.main schedule (rollout, then update block, strictly alternating); launch: agent0.deepq.launch schedule "
                          "(next rollout with a weight snapshot on a second stream while the update block runs)")
@@ -166,6 +167,25 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             pr = tr.ops.probe_end()
+    # ---- the same metric at the reference's update:data ratio for 256 envs (learner_steps = 320 instead of 20)
+    ratio320 = None
+    if world == 1 and not args.no_ratio320:
+        tr.learner.use_graph = True
+        tr.actors[1].use_graph = True
+        if args.entry == "launch":
+            tr.overlap = True
+        keep_L = cfg.learner.learner_steps
+        cfg.learner.learner_steps = 320
+        tr.run_iteration()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(3):
+            tr.run_iteration()
+        torch.cuda.synchronize()
+        d1 = (time.time() - t1) / 3
+        cfg.learner.learner_steps = keep_L
+        ratio320 = {"learner_steps": 320, "value": round(per_iter / d1, 1), "unit": "env-frames/sec", "ms_per_step": round(1e3 * d1, 2),
+                    "updates_per_sec": round(320 / d1, 1)}
     # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
     # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
     replay_gbps = None
@@ -203,6 +223,7 @@ def main():
                    "replay_size": cfg.replay.size, "parallelism": f"dp{world}", "entry": f"agent0.deepq.{args.entry}"},
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),
+        "at_reference_update_ratio": ratio320,
         "replay_sample_GBps": None if replay_gbps is None else round(replay_gbps, 1), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),
     }
     roof = None
