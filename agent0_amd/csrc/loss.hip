@@ -152,6 +152,115 @@ extern "C" int a0_loss_dqn(const float* q, const float* q_next, int A, const int
     return a0_fail_hip((int)hipGetLastError(), "a0_loss_dqn");
 }
 
+// ------------------------------------------------------------------------------------------------ DQN: heads + loss + head gradient
+// Everything between the fc1 activations and the gradient w.r.t. the raw head outputs of DQNLearner.train_step (reference
+// agent.py:173-190 with model.py:108-131 behind it) in one kernel, one wave per sample: q head of the online net on h(s), of the
+// target net on h'(s') and — double-Q — of the online net on h(s'); dueling combine; first-max argmax; smooth-L1 against
+// y = r + gamma^n (1-d) q'(s', a*); dq; dueling backward into draw [B][ld].  Replaces nine launches (2 x (GEMM, reduce, dueling),
+// select, loss, dueling backward) that together move a few hundred kilobytes.
+__global__ __launch_bounds__(256) void a0_dqn_head_loss_kernel(const float* __restrict__ h_on, const float* __restrict__ h_tg, const float* __restrict__ h_sel,
+                                                               const float* __restrict__ W_on, const float* __restrict__ b_on, const float* __restrict__ W_tg,
+                                                               const float* __restrict__ b_tg, int A, int dueling, int ld, const int* __restrict__ act,
+                                                               const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ wgt,
+                                                               float gamma_n, int B, float* __restrict__ loss, float* __restrict__ q_on_out,
+                                                               float* __restrict__ q_tg_out, float* __restrict__ draw, int* __restrict__ nan_flag) {
+    extern __shared__ float wsm[];                 // [online rows | target rows], NQ x 512 each
+    __shared__ float raw[4][3][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NQ = A + (dueling ? 1 : 0);
+    for (int i = threadIdx.x; i < NQ * 128; i += 256) { ((a0_f4*)wsm)[i] = ((const a0_f4*)W_on)[i]; ((a0_f4*)wsm)[NQ * 128 + i] = ((const a0_f4*)W_tg)[i]; }
+    const int b = blockIdx.x * 4 + wave;
+    const int br = b < B ? b : B - 1;
+    float ho[8], ht[8], hs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ho[i] = h_on[(long long)br * 512 + lane + 64 * i];
+        ht[i] = h_tg[(long long)br * 512 + lane + 64 * i];
+        hs[i] = h_sel ? h_sel[(long long)br * 512 + lane + 64 * i] : 0.f;
+    }
+    __syncthreads();
+    if (b >= B) return;
+    for (int a = 0; a < NQ; ++a) {
+        const float* wo = wsm + a * 512;
+        const float* wt = wsm + (NQ + a) * 512;
+        float so = 0.f, st = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float w1 = wo[lane + 64 * i];
+            so = fmaf(ho[i], w1, so);
+            ss = fmaf(hs[i], w1, ss);
+            st = fmaf(ht[i], wt[lane + 64 * i], st);
+        }
+        so = a0_wave_sum(so); st = a0_wave_sum(st); ss = a0_wave_sum(ss);
+        if (lane == 0) { raw[wave][0][a] = so + b_on[a]; raw[wave][1][a] = st + b_tg[a]; raw[wave][2][a] = ss + b_on[a]; }
+    }
+    if (lane != 0) return;
+    const int nsel = h_sel ? 2 : 1;
+    float mean[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+    if (dueling)
+        for (int s3 = 0; s3 < 3; ++s3) {
+            float t = 0.f;
+            for (int a = 0; a < A; ++a) t += raw[wave][s3][a];
+            mean[s3] = t / (float)A;
+            v[s3] = raw[wave][s3][A];
+        }
+    auto q = [&](int s3, int a) { return dueling ? v[s3] + (raw[wave][s3][a] - mean[s3]) : raw[wave][s3][a]; };
+    float best = 0.f;
+    int a_star = 0;
+    for (int a = 0; a < A; ++a) {
+        const float x = q(nsel, a);
+        if (a == 0 || x > best) { best = x; a_star = a; }       // first maximum wins, like torch.argmax on CPU
+        q_on_out[(long long)b * A + a] = q(0, a);
+        if (q_tg_out) q_tg_out[(long long)b * A + a] = q(1, a);
+    }
+    const float qn = q(1, a_star);
+    const float y = rew[b] + (gamma_n * (1.f - done[b])) * qn;
+    const int ab = act[b];
+    const float d = q(0, ab) - y;
+    const float ad = fabsf(d);
+    const float l = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+    loss[b] = l;
+    if (l != l) atomicOr(nan_flag, 1);
+    const float g = wgt[b] * fminf(fmaxf(d, -1.f), 1.f);
+    // dueling backward of dq = g * e_ab (a0_dueling_bwd_kernel): advantage column c gets dq[c] - sum(dq)/A, the value column sum(dq)
+    float* o = draw + (long long)b * ld;
+    for (int c = 0; c < ld; ++c) {
+        float out = 0.f;
+        if (c < A) {
+            out = (c == ab) ? g : 0.f;
+            if (dueling) {
+                float s = 0.f;
+                for (int a = 0; a < A; ++a) s += (a == ab) ? g : 0.f;
+                out -= s / (float)A;
+            }
+        } else if (dueling && c == A) {
+            float s = 0.f;
+            for (int a = 0; a < A; ++a) s += (a == ab) ? g : 0.f;
+            out = s;
+        }
+        o[c] = out;
+    }
+}
+
+extern "C" int a0_dqn_head_loss(const float* h_on, const float* h_tg, const float* h_sel, const float* W_on, const float* b_on, const float* W_tg,
+                                const float* b_tg, int A, int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt,
+                                float gamma_n, int B, float* loss, float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream) {
+    const int NQ = A + (dueling ? 1 : 0);
+    if (!h_on || !h_tg || !W_on || !b_on || !W_tg || !b_tg || !act || !rew || !done || !wgt || !loss || !q_on_out || !draw || !nan_flag || B < 1 || A < 1 || NQ > 24 ||
+        ld < NQ)
+        return a0_fail(A0_EINVAL, "a0_dqn_head_loss: bad argument (A + dueling <= 24)");
+    const size_t lds = (size_t)2 * NQ * 512 * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_dqn_head_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_dqn_head_loss: LDS");
+        configured = lds;
+    }
+    hipLaunchKernelGGL(a0_dqn_head_loss_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, h_on, h_tg, h_sel, W_on, b_on, W_tg, b_tg, A, dueling, ld, act,
+                       rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag);
+    return a0_fail_hip((int)hipGetLastError(), "a0_dqn_head_loss");
+}
+
 // ------------------------------------------------------------------------------------------------ Munchausen DQN
 // MDQNLearner.train_step (reference agent.py:194-215, log_softmax_stable 116-119), per sample:
 //   lp(x)  = z - tau * logsumexp(z / tau),  z = x - max(x)

@@ -188,6 +188,10 @@ class DeviceNet:
         ops.dueling_fwd(ws.raw, L.Npad, ws.q, R, L.A, 1, L.dueling)
         return ws.q
 
+    def fc1(self, ws: Workspace, B):
+        """features -> relu(fc1) only (the fused DQN head kernel takes it from there)."""
+        self._dense(ws.act3, self.L.feat, "fc1", ws.h, B, True)
+
     def fqf_taus(self, ws: Workspace, B):
         """FQFHead.prop_taus (model.py:268-278): fraction net on (detached) features -> taus, tau_hats."""
         L = self.L
@@ -279,11 +283,12 @@ class DeviceLearner:
         key = name + ".mu" if (L.noisy and name in ("fc1", "head")) else name
         return self.grads[L.blocks[key].all]
 
-    def _backward_trunk(self, ws: Workspace, frames, slot, stride, B):
+    def _backward_trunk(self, ws: Workspace, frames, slot, stride, B, have_draw: bool = False):
         """dq (w.r.t. the combined head output) -> every parameter gradient of the online net."""
         L, ops, on = self.L, self.ops, self.online
         R, T = ws.R, (1 if L.quantile else L.T)
-        ops.dueling_bwd(ws.dq, ws.draw, L.Npad, R, L.A, T, L.dueling)
+        if not have_draw:
+            ops.dueling_bwd(ws.dq, ws.draw, L.Npad, R, L.A, T, L.dueling)
         Wh, _ = on.wb("head")
         Wf, _ = on.wb("fc1")
         ops.dense_wgrad(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512, self.slabs)
@@ -327,6 +332,7 @@ class DeviceLearner:
         algo = L.algo
         wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
         frac = None
+        have_draw = False
         if algo == "mdqn":
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             tg.head(wt, B)
@@ -336,6 +342,19 @@ class DeviceLearner:
             on.encode(wo, frames, slot, sample_stride, 0, B)
             on.head(wo, B)
             ops.loss_mdqn(wo.q, wt.q, wm.q, L.A, act, rew, done, wgt, self.gamma_n, self.mdqn_tau, self.mdqn_lo, B, self.loss, wo.dq, self.state)
+        elif algo == "dqn" and getattr(ops, "fused_dqn_head", False) and L.A + (1 if L.dueling else 0) <= 24:
+            # heads, loss and head gradient in one kernel (a0_dqn_head_loss); only fc1 runs as a GEMM
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+            tg.fc1(wt, B)
+            if self.double_q:
+                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
+                on.fc1(wsel, B)
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            on.fc1(wo, B)
+            (Wo, bo), (Wt, bt) = on.wb("head"), tg.wb("head")
+            ops.dqn_head_loss(wo.h, wt.h, wsel.h if self.double_q else None, Wo, bo, Wt, bt, L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B,
+                              self.loss, wo.q, wt.q, wo.draw, self.state)
+            have_draw = True
         elif algo in ("dqn", "c51", "qr"):
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             tg.head(wt, B)
@@ -404,7 +423,7 @@ class DeviceLearner:
             frac = self.frac_loss
         else:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
-        self._backward_trunk(wo, frames, slot, sample_stride, B)
+        self._backward_trunk(wo, frames, slot, sample_stride, B, have_draw)
         if self.grad_hook is not None:
             self.grad_hook(self.grads, self.state)
         ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)

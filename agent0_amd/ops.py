@@ -298,6 +298,18 @@ class HipOps:
                                                _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
                                                _req(prio, torch.float32, B, "prio", optional=True), _stream()), "a0_replay_sample_gather")
 
+    fused_dqn_head = True
+
+    def dqn_head_loss(self, h_on, h_tg, h_sel, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg, draw, state):
+        nq = A + (1 if dueling else 0)
+        check(self.lib.a0_dqn_head_loss(_req(h_on, torch.float32, B * 512, "h_on"), _req(h_tg, torch.float32, B * 512, "h_tg"),
+                                        _req(h_sel, torch.float32, B * 512, "h_sel", optional=True), _req(W_on, torch.float32, nq * 512, "W_on"),
+                                        _req(b_on, torch.float32, nq, "b_on"), _req(W_tg, torch.float32, nq * 512, "W_tg"), _req(b_tg, torch.float32, nq, "b_tg"),
+                                        A, int(dueling), ld, _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                        _req(wgt, torch.float32, B, "wgt"), float(gamma_n), B, _req(loss, torch.float32, B, "loss"),
+                                        _req(q_on, torch.float32, B * A, "q_on"), _req(q_tg, torch.float32, B * A, "q_tg", optional=True),
+                                        _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"), _stream()), "a0_dqn_head_loss")
+
     def actor_qhead_scratch(self, E, K) -> int:
         return int(self.lib.a0_actor_qhead_scratch(E, K))
 

@@ -121,6 +121,13 @@ int a0_select_action(const float* x, long long sb, long long sa, long long st, i
 /* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
 int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
                 const float* done, const float* wgt, float gamma_n, int B, float* loss, float* dq, int* nan_flag, void* stream);
+/* DQNLearner.train_step (agent.py:173-190) from the fc1 activations on, one launch: q heads (online on h(s), target on h'(s'), online on
+ * h(s') when h_sel != NULL = double-Q), dueling combine (model.py:123-131), argmax, smooth-L1 loss, and the gradient w.r.t. the raw head
+ * outputs draw [B][ld] (dueling backward applied).  W_* [A(+1)][512] + b_*; q_on_out [B][A] (q_tg_out optional) for inspection. */
+int a0_dqn_head_loss(const float* h_on, const float* h_tg, const float* h_sel, const float* W_on, const float* b_on, const float* W_tg,
+                     const float* b_tg, int A, int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt,
+                     float gamma_n, int B, float* loss, float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream);
+
 /* MDQNLearner.train_step (agent.py:194-215): q_next = target(next_obs), q_cur_tgt = target(obs), both [B][A] */
 int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,
                  const float* wgt, float gamma_n, float tau, float lo, int B, float* loss, float* dq, int* nan_flag, void* stream);
