@@ -290,23 +290,34 @@ class BaseLearner:
         return out if isinstance(out, tuple) else (out, None)
 
     def _update(self, frames, slot, row_bytes, act, rew, done, weights, rand):
-        """engine.update, replayed from a hipGraph when the caller keeps handing in the same device buffers (the Trainer's hot
-        loop does: the replay's persistent batch tensors).  One graph launch replaces ~45 kernel launches from Python."""
-        if not self.use_graph or self.engine.grad_hook is not None:
-            return self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
-        key = (frames.data_ptr(), None if slot is None else slot.data_ptr(), row_bytes, act.data_ptr(), rew.data_ptr(), done.data_ptr(), weights.data_ptr())
+        """engine.update, replayed from hipGraphs when the caller keeps handing in the same device buffers (the Trainer's hot loop
+        does: the replay's persistent batch tensors).  Two graphs — forward+backward (~35 kernels) and optimizer step — so that the
+        data-parallel gradient all-reduce (RCCL, not captured) sits between two graph launches instead of forcing ~45 eager ones."""
+        eng = self.engine
+        if not self.use_graph:
+            return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+        hooked = eng.grad_hook is not None
+        key = (frames.data_ptr(), None if slot is None else slot.data_ptr(), row_bytes, act.data_ptr(), rew.data_ptr(), done.data_ptr(), weights.data_ptr(), hooked)
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 4 or self._graph_warm.get(key, 0) < 2:       # two eager runs first: every lazy allocation has happened
                 self._graph_warm[key] = self._graph_warm.get(key, 0) + 1
-                return self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
-            graph = torch.cuda.CUDAGraph()
+                return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+            g_fb, g_apply = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if hooked else None)
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                out = self.engine.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
-            g = self._graphs[key] = (graph, out)          # capturing records the launches without running them
+            with torch.cuda.graph(g_fb):
+                out = eng.forward_backward(frames, slot, row_bytes, act, rew, done, weights, rand)
+                if not hooked:
+                    eng.apply()                                   # no exchange step: the whole update is one graph
+            if hooked:
+                with torch.cuda.graph(g_apply):
+                    eng.apply()
+            g = self._graphs[key] = (g_fb, g_apply, out)          # capturing records the launches without running them
         g[0].replay()
-        return g[1]
+        if g[1] is not None:
+            eng.grad_hook(eng.grads, eng.state)
+            g[1].replay()
+        return g[2]
 
     # ------------------------------------------------------------------ reference signature (agent.py:124-169)
     def train(self, data):

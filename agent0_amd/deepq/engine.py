@@ -317,7 +317,24 @@ class DeviceLearner:
 
     # ------------------------------------------------------------------ the update
     def update(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
-        """One BaseLearner.train step (agent.py:124-169) on a batch that stays on the device.
+        """One BaseLearner.train step (agent.py:124-169) on a batch that stays on the device: forward + backward, the data-parallel
+        gradient exchange when a ``grad_hook`` is installed, optimizer step."""
+        out = self.forward_backward(frames, slot, sample_stride, act, rew, done, wgt, rand)
+        if self.grad_hook is not None:
+            self.grad_hook(self.grads, self.state)
+        self.apply()
+        return out
+
+    def apply(self):
+        """Adam on the flat buffer (NaN-skip and step counter on the device), refresh of the fused kernels' weight copies, target sync."""
+        L, ops, on = self.L, self.ops, self.online
+        ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
+        on.refresh_wt()
+        self.sync_target(force=False)
+
+    def forward_backward(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
+        """Losses and every parameter gradient (into ``self.grads``); no parameter is modified (FQF's fraction net aside, which the
+        reference also steps separately, agent.py:140-147).
 
         frames: u8 replay rows (st || st_next); slot: optional int32 row indices; act int32, rew/done/wgt fp32 [B].
         rand (IQN only): [taus_K [B*K], taus_N' [B*N'], taus_N [B*N]] in the reference's draw order.
@@ -424,9 +441,4 @@ class DeviceLearner:
         else:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
         self._backward_trunk(wo, frames, slot, sample_stride, B, have_draw)
-        if self.grad_hook is not None:
-            self.grad_hook(self.grads, self.state)
-        ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
-        on.refresh_wt()
-        self.sync_target(force=False)
         return (self.loss, frac) if frac is not None else self.loss

@@ -265,3 +265,27 @@ def test_launch_mode_uses_stale_weights_like_the_reference():
     torch.cuda.synchronize()
     assert torch.equal(tr.actors[1].model._dev.flat, before)
     assert not torch.equal(tr.learner.engine.online.flat, before)
+
+
+def test_graphed_update_with_a_gradient_hook_matches_eager():
+    """Data parallelism installs a grad_hook (RCCL all-reduce) between backward and Adam.  The learner then replays two hipGraphs around
+    the eager hook; the result must equal the fully eager update bit for bit (the hook here scales the gradients, so skipping or
+    misplacing it would show)."""
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    res = []
+    for use_graph in (True, False):
+        cfg = parse_overrides(["actor.num_envs=16", "actor.sample_steps=12", "learner.batch_size=32", "learner.learner_steps=3", "replay.size=1000",
+                               "trainer.training_start_steps=100", "wandb=false", "tb=false", "logdir=/tmp/a0_hook"])
+        tr = Trainer(cfg)
+        tr.learner.use_graph = use_graph
+        calls = []
+        def hook(grads, state, calls=calls):
+            grads.mul_(0.5)
+            calls.append(1)
+        tr.learner.engine.grad_hook = hook
+        for _ in range(6):
+            tr.run_iteration()
+        torch.cuda.synchronize()
+        res.append((tr.learner.engine.online.flat.clone(), len(calls), tr.learner.update_steps))
+    assert res[0][1] == res[1][1] == res[0][2] and torch.equal(res[0][0], res[1][0])
