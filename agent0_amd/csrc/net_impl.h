@@ -56,7 +56,7 @@ static inline int a0_fwd_splits(int gx, int gy, int K) {
     if (forced > 0) return forced;
     int blocks = gx * gy, splits = 1;
     if (blocks < 256) {
-        splits = 512 / blocks;
+        splits = 256 / blocks;          // one workgroup per CU: measured best for fc1 at 256 / 512 rows (tools/ubench_dense.py)
         int maxs = (K / 32) / 2;
         if (splits > maxs) splits = maxs;
         if (splits > 32) splits = 32;
