@@ -66,9 +66,10 @@ static inline int a0_fwd_splits(int gx, int gy, int K) {
 }
 
 static inline int a0_wgrad_splits(int gx, int gy, int R) {
+    static const int target = getenv("A0_WGRAD_TARGET") ? atoi(getenv("A0_WGRAD_TARGET")) : 512;     // tuning aid
     int blocks = gx * gy, splits = 1;
     if (blocks < 256) {
-        splits = (512 + blocks - 1) / blocks;
+        splits = (target + blocks - 1) / blocks;
         int maxs = (R + 63) / 64;
         if (splits > maxs) splits = maxs;
         if (splits > 256) splits = 256;
