@@ -162,7 +162,11 @@ static void a0_dense_dgrad_impl(BK& bk, const float* dY, const float* W, const f
     bk.tag = A0_TAG_DENSE_DGRAD;
     if (act_mask) {
         EpiMaskMat::Params e{dX, act_mask, K};
-        bk.template igemm<OpMatKC, OpMatXC, EpiMaskMat, 4, 1, 1, 2>(a, bw, e, R, K, N, 1);
+        static const int var = getenv("A0_DGRAD_VARIANT") ? atoi(getenv("A0_DGRAD_VARIANT")) : 0;      // tuning aid
+        const long long blocks = (long long)((R + 127) / 128) * ((K + 63) / 64);
+        if (var == 1 || (var == 0 && blocks < 256)) bk.template igemm<OpMatKC, OpMatXC, EpiMaskMat, 2, 2, 1, 1>(a, bw, e, R, K, N, 1);   // 64x64 tiles: twice the workgroups
+        else if (var == 2) bk.template igemm<OpMatKC, OpMatXC, EpiMaskMat, 4, 1, 1, 1>(a, bw, e, R, K, N, 1);
+        else bk.template igemm<OpMatKC, OpMatXC, EpiMaskMat, 4, 1, 1, 2>(a, bw, e, R, K, N, 1);
     } else {
         EpiSlab::Params e{dX, 0, K};
         bk.template igemm<OpMatKC, OpMatXC, EpiSlab, 4, 1, 1, 2>(a, bw, e, R, K, N, 1);
@@ -177,12 +181,20 @@ static void a0_finish_wgrad(BK& bk, int N, long long wcount, float* grad, float*
 
 template <class BK>
 static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx, float* grad, int R, int N, int K, float* slabs) {
-    const int splits = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
     const long long wcount = (long long)N * K;
     a0_mat_src a{dY, N};
     a0_mat_src b{X, ldx};
-    EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K, wcount};
     bk.tag = A0_TAG_DENSE_WGRAD;
+    static const int var = getenv("A0_WGRAD_VARIANT") ? atoi(getenv("A0_WGRAD_VARIANT")) : 0;      // tuning aid
+    const long long blocks64 = (long long)((N + 63) / 64) * ((K + 63) / 64);
+    if (var == 1 && blocks64 >= 256) {
+        // experiment (A0_WGRAD_VARIANT=1): 64x64 output tiles without a reduction split — measured slower than 64x128 tiles + 3 slabs for fc1
+        EpiWgradSlab::Params e{grad, 0, K, wcount};
+        bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>(a, b, e, N, K, R, 1);
+        return;
+    }
+    const int splits = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
+    EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K, wcount};
     bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
     a0_finish_wgrad(bk, N, wcount, grad, slabs, splits);
 }
