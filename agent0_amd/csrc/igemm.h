@@ -8,7 +8,7 @@
 // block tile is BX = WM*MT*32 rows by BY = WN*NT*32 columns, BK = 32 deep.  Operands are gathered by the policies
 // in operands.h into k-major LDS tiles As[k][x], Bs[k][y]; a fragment read As[2s + (lane>>5)][x0 + (lane&31)] is
 // one conflict-free ds_read_b32 per 32x32x2 MFMA operand (the MFMA takes 64 cycles, so LDS is never the limit).
-// Global loads for tile t+1 are issued into registers before the MFMAs of tile t (register double buffering).
+// Two tiles of global loads are in flight in registers; the LDS tiles are double-buffered (one barrier per 32 k).
 #pragma once
 #include "operands.h"
 
@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
     typedef a0_stager<OA, BX> SA;
     typedef a0_stager<OB, BY> SB;
     constexpr int LDA = SA::LD, LDB = SB::LD;
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    // two LDS buffers per operand: tile t+1 is written while tile t is being multiplied, one barrier per tile
+    __shared__ __attribute__((aligned(16))) float As[2 * BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -115,20 +116,22 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
     // Thread (g, xr) adds rows kk = g, g + G, ... of column xr of every tile; the G partial sums meet in LDS after the k loop.
     constexpr int RS_G = 256 / BX;
     float rowsum = 0.f;
-    auto rowsum_tile = [&]() {
+    auto rowsum_tile = [&](int buf) {
         if constexpr (EP::ROWSUM_A) {
             if (blockIdx.y == 0) {
                 const int xr = tid % BX, g = tid / BX;
 #pragma unroll
-                for (int kk = 0; kk < BK / RS_G; ++kk) rowsum += As[(g + kk * RS_G) * LDA + xr];
+                for (int kk = 0; kk < BK / RS_G; ++kk) rowsum += As[buf * BK * LDA + (g + kk * RS_G) * LDA + xr];
             }
         }
     };
 
-    const float* ap = As + (lane >> 5) * LDA + wm * (MT * 32) + (lane & 31);
-    const float* bp = Bs + (lane >> 5) * LDB + wn * (NT * 32) + (lane & 31);
+    const float* ap0 = As + (lane >> 5) * LDA + wm * (MT * 32) + (lane & 31);
+    const float* bp0 = Bs + (lane >> 5) * LDB + wn * (NT * 32) + (lane & 31);
 
-    auto mma_tile = [&]() {
+    auto mma_tile = [&](int buf) {
+        const float* ap = ap0 + buf * BK * LDA;
+        const float* bp = bp0 + buf * BK * LDB;
         // fragment reads run one k-step ahead of the MFMAs that consume them
         float a[2][MT], b[2][NT];
 #pragma unroll
@@ -154,26 +157,36 @@ __global__ __launch_bounds__(256) void a0_igemm_kernel(typename OA::Params pa, t
         }
     };
 
-    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
-        __syncthreads();                 // every wave is done reading the previous tile
+    // Pipeline: registers hold tiles t+1 and t+2 (global loads in flight), LDS buffer t&1 holds tile t.  In iteration t the waves
+    // first move tile t+1 from registers into the OTHER buffer (its last readers finished before the barrier that ended iteration
+    // t-1), request tile t+3 into the freed registers, then multiply tile t; one barrier closes the iteration.
+    if (kb < ke) {
         sa.commit(sa0, As, tid);
         sb.commit(sb0, Bs, tid);
+        if (kb + 2 * BK < ke) { sa.fetch(pa, sa0, kb + 2 * BK, ke, tid); sb.fetch(pb, sb0, kb + 2 * BK, ke, tid); }
+    }
+    __syncthreads();
+    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
+        if (k0 + BK < ke) {
+            sa.commit(sa1, As + BK * LDA, tid);
+            sb.commit(sb1, Bs + BK * LDB, tid);
+            if (k0 + 3 * BK < ke) { sa.fetch(pa, sa1, k0 + 3 * BK, ke, tid); sb.fetch(pb, sb1, k0 + 3 * BK, ke, tid); }
+        }
+        rowsum_tile(0);
+        mma_tile(0);
         __syncthreads();
-        if (k0 + 2 * BK < ke) { sa.fetch(pa, sa0, k0 + 2 * BK, ke, tid); sb.fetch(pb, sb0, k0 + 2 * BK, ke, tid); }
-        rowsum_tile();
-        mma_tile();
         if (k0 + BK >= ke) break;
+        if (k0 + 2 * BK < ke) {
+            sa.commit(sa0, As, tid);
+            sb.commit(sb0, Bs, tid);
+            if (k0 + 4 * BK < ke) { sa.fetch(pa, sa0, k0 + 4 * BK, ke, tid); sb.fetch(pb, sb0, k0 + 4 * BK, ke, tid); }
+        }
+        rowsum_tile(1);
+        mma_tile(1);
         __syncthreads();
-        sa.commit(sa1, As, tid);
-        sb.commit(sb1, Bs, tid);
-        __syncthreads();
-        if (k0 + 3 * BK < ke) { sa.fetch(pa, sa1, k0 + 3 * BK, ke, tid); sb.fetch(pb, sb1, k0 + 3 * BK, ke, tid); }
-        rowsum_tile();
-        mma_tile();
     }
     if constexpr (EP::ROWSUM_A) {
-        if (blockIdx.y == 0) {
-            __syncthreads();                 // As is free: every wave has left the k loop
+        if (blockIdx.y == 0) {               // As is free: the loop ends with a barrier
             As[tid] = rowsum;
             __syncthreads();
             if (tid < BX && x0 + tid < X) {
