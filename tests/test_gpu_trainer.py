@@ -20,21 +20,24 @@ def make_cfg(algo="dqn", E=4, **kw):
     return cfg
 
 
-@pytest.mark.parametrize("n_step", [1, 3])
-def test_actor_rollout_matches_oracle(n_step):
+@pytest.mark.parametrize("n_step,spec_name", [(1, "dqn"), (3, "dqn"), (1, "dqn_duel"), (3, "c51"), (1, "qr")])
+def test_actor_rollout_matches_oracle(n_step, spec_name):
+    """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the generic head + select + egreedy kernels."""
     from agent0_amd.deepq.agent import Actor
     from agent0_amd.deepq.model import DeepQNet
     from agent0_amd.deepq.replay import ReplayDataset
     from agent0_amd.common.utils import DeviceRng
 
     E, T = 4, 12
-    cfg = make_cfg("dqn", E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8})
+    spec = recipe.SPECS[spec_name]
+    cfg = make_cfg(spec.algo, E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8,
+                                     "learner.dueling_head": str(bool(spec.dueling)).lower(), **({"learner.qr.num_atoms": spec.num_atoms} if spec.algo == "qr" else {})})
     model = DeepQNet(cfg)
-    spec = recipe.NetSpec("dqn", 4)
     sd = recipe.make_state_dict(spec, 11)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     replay = ReplayDataset(cfg, ops=model.ops)
     actor = Actor(cfg, model, replay=replay, rank=0)
+    assert actor.fused_tail == (spec.algo == "dqn")
     # oracle twin: same env definition, same Philox draws (stream ids / offsets as DeviceRng assigns them)
     seed64 = (cfg.seed & 0xFFFFFFFF)
     step_no = [0]
