@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--env", default="Breakout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ratio320", action="store_true", help="skip the extra learner_steps=320 measurement")
+    ap.add_argument("--no-other-entry", action="store_true", help="skip the extra measurement of the other entry point's schedule")
     ap.add_argument("--entry", choices=("main", "launch"), default="main",
                     help="main: agent0.deepq.main schedule (rollout, then update block, strictly alternating); launch: agent0.deepq.launch schedule "
                          "(next rollout with a weight snapshot on a second stream while the update block runs)")
@@ -186,6 +187,27 @@ def main():
         cfg.learner.learner_steps = keep_L
         ratio320 = {"learner_steps": 320, "value": round(per_iter / d1, 1), "unit": "env-frames/sec", "ms_per_step": round(1e3 * d1, 2),
                     "updates_per_sec": round(320 / d1, 1)}
+    # ---- the other entry point's schedule on the same workload (second trainer, own full replay), so that one bench line carries both
+    other = None
+    if world == 1 and not args.no_other_entry:
+        import copy
+        cfg2 = copy.deepcopy(cfg)
+        cfg2.trainer.training_start_steps = 1 << 62
+        tr2 = Trainer(cfg2, use_lp=(args.entry != "launch"), rank=rank)
+        while len(tr2.replay) < cfg2.replay.size:
+            tr2.run_iteration()
+        cfg2.trainer.training_start_steps = min(start_steps, cfg2.replay.size - 1)
+        for _ in range(max(args.warmup, 3)):          # eager runs, then graph capture
+            tr2.run_iteration()
+        torch.cuda.synchronize()
+        t2 = time.time()
+        for _ in range(args.steps):
+            tr2.run_iteration()
+        torch.cuda.synchronize()
+        d2 = (time.time() - t2) / args.steps
+        other = {"entry": "agent0.deepq." + ("main" if args.entry == "launch" else "launch"), "value": round(per_iter / d2, 1), "unit": "env-frames/sec",
+                 "ms_per_step": round(1e3 * d2, 3), "steps": args.steps}
+        del tr2
     # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
     # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
     replay_gbps = None
@@ -223,7 +245,7 @@ def main():
                    "replay_size": cfg.replay.size, "parallelism": f"dp{world}", "entry": f"agent0.deepq.{args.entry}"},
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),
-        "at_reference_update_ratio": ratio320,
+        "at_reference_update_ratio": ratio320, "other_entry": other,
         "replay_sample_GBps": None if replay_gbps is None else round(replay_gbps, 1), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),
     }
     roof = None

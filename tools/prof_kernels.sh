@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-A0_PROBE=none rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_k -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --replay-size 100000 > gpurun_out/prof_k.log 2>&1
+A0_PROBE=none rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_k -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/prof_k.log 2>&1
 f=$(ls gpurun_out/prof_k/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

@@ -3,10 +3,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r01
 python3 bench.py > gpurun_out/r01/bench.json 2> gpurun_out/r01/bench.err
-python3 bench.py --entry launch --no-cpu-baseline > gpurun_out/r01/bench_launch.json 2> gpurun_out/r01/bench_launch.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01/prof -- python3 bench.py --no-cpu-baseline > gpurun_out/r01/prof.log 2>&1
-A0_PROBE=none rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --replay-size 100000 > gpurun_out/r01/pmc_fetch.log 2>&1
-A0_PROBE=none rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --replay-size 100000 > gpurun_out/r01/pmc_write.log 2>&1
+python3 bench.py --entry launch --no-cpu-baseline --no-other-entry > gpurun_out/r01/bench_launch.json 2> gpurun_out/r01/bench_launch.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01/prof -- python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry > gpurun_out/r01/prof.log 2>&1
+A0_PROBE=none rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/r01/pmc_fetch.log 2>&1
+A0_PROBE=none rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/r01/pmc_write.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json
 out = {}
