@@ -33,6 +33,8 @@ struct a0_hip_error : std::runtime_error {
 // profiler probe (net.hip): HIP events around launches tagged `tag`
 #if defined(__HIPCC__)
 bool a0_probe_start(int tag, hipStream_t st);
+// conv1_wgrad.hip: per-observation conv1 weight gradient on the bf16 pipe; returns the slab count (0 = unsupported shape)
+int a0_conv1_wgrad_fused_launch(const a0_frames_arg* f, int C, int H, int W, int B, const float* d1, float* slabs, hipStream_t st);
 void a0_probe_stop(hipStream_t st, double flops);
 #endif
 #define A0_TAG_ENCODER_FUSED 12

@@ -115,6 +115,19 @@ struct a0_hip_backend {
             g_probe.flops += 2.0 * (double)X * (double)Y * (double)K;
         }
     }
+    int conv1_wgrad_fused(const a0_net_core& n, const a0_frames_arg& f, int B, const float* d1, float* slabs) {
+        static const bool off = getenv("A0_NO_CONV1_WGRAD_FUSED") != nullptr;
+        if (off || !slabs) return 0;
+        const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
+        if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
+        const int g = a0_conv1_wgrad_fused_launch(&f, n.C, n.H, n.W, B, d1, slabs, st);
+        if (probe && g > 0) {
+            A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
+            g_probe.used += 2;
+            g_probe.flops += 2.0 * 32.0 * (double)n.K1 * (double)B * n.H1 * n.W1;
+        }
+        return g;
+    }
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
         hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);
         A0_HIP_THROW(hipGetLastError());

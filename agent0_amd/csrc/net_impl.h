@@ -246,8 +246,14 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
             bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 1>(a, b, e, B * Hv * Wv, 32, 4 * 64, 1);
         }
     {   // conv1 weight gradient (the input is data: no data gradient)
-        const int splits = a0_wgrad_splits(1, (n.K1 + 127) / 128, M1);
         const long long wc = 32LL * n.K1;
+        bk.tag = A0_TAG_CONV1_WGRAD;
+        const int fused_slabs = bk.conv1_wgrad_fused(n, f, B, d1, slabs);       // 84x84x4: per-observation kernel on the bf16 pipe
+        if (fused_slabs > 0) {
+            bk.reduce_slabs(slabs, wc + 32, fused_slabs, g1, wc + 32);
+            return;
+        }
+        const int splits = a0_wgrad_splits(1, (n.K1 + 127) / 128, M1);
         a0_mat_src a{d1, 32};
         a0_frames_src b = a0_frames(n, f);
         EpiWgradSlab::Params e{splits > 1 ? slabs : g1, splits > 1 ? wc + 32 : 0, n.K1, wc};
