@@ -67,58 +67,73 @@ __global__ __launch_bounds__(A0W_THREADS) void a0_conv1_wgrad_fused_kernel(a0_c1
         for (int t = 0; t < 2; ++t) acc[i][t] = a0w_acc4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;                                                    // bias partial of column n = tid % 32 over this thread's position groups
     __syncthreads();
+    // raw global data of one observation, held in registers: requested for observation b + gridDim.x BEFORE the MFMA loop of
+    // observation b, so the HBM latency of the next observation hides behind the matrix work of the current one
+    constexpr int NDW = 4 * 84 * 21, TR = (NDW + A0W_THREADS - 1) / A0W_THREADS;      // 7056 dwords of pixels, 14 per thread
+    constexpr int GT = (A0W_GROUPS + A0W_THREADS / 32 - 1) / (A0W_THREADS / 32);      // 4 position groups per thread
+    uint32_t w[TR];
+    float v[GT][8];
+    auto load_raw = [&](int b) {
+        const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
+        const uint32_t* src = (const uint32_t*)(P.frames + s * P.sample_stride + P.chan_off);
+#pragma unroll
+        for (int j = 0; j < TR; ++j) { const int i = tid + j * A0W_THREADS; w[j] = src[i < NDW ? i : NDW - 1]; }
+        const float* g = P.d1 + (long long)b * 400 * 32 + (tid & 31);
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            int G = (tid >> 5) + t * (A0W_THREADS / 32);
+            G = G < A0W_GROUPS ? G : A0W_GROUPS - 1;
+            const int oh = G / 3, ow0 = 8 * (G - 3 * oh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int m = oh * 20 + ow0 + j; v[t][j] = g[(m < 400 ? m : 399) * 32]; }       // pads are zeroed at use
+        }
+    };
+    load_raw(blockIdx.x);
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
         // ---- observation -> phase planes: one dword = 4 horizontally adjacent pixels = the four kw%4 planes at one (row, col)
-        {
-            const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
-            const uint32_t* src = (const uint32_t*)(P.frames + s * P.sample_stride + P.chan_off);
-            constexpr int NDW = 4 * 84 * 21, TR = (NDW + A0W_THREADS - 1) / A0W_THREADS;      // 7056 dwords, 14 trips
-            uint32_t w[TR];
 #pragma unroll
-            for (int j = 0; j < TR; ++j) { const int i = tid + j * A0W_THREADS; w[j] = src[i < NDW ? i : NDW - 1]; }
-#pragma unroll
-            for (int j = 0; j < TR; ++j) {
-                int i = tid + j * A0W_THREADS;
-                i = i < NDW ? i : NDW - 1;
-                const int c = i / (84 * 21), rem = i - c * (84 * 21), y = rem / 21, xc = rem - y * 21;
-                uint16_t* d = Xp + ((c * 4 + (y & 3)) * 4) * A0W_XP_PLANE + (y >> 2) * A0W_XP_ROW + xc;
-                d[0 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)(w[j] & 0xffu)) >> 16);
-                d[1 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)((w[j] >> 8) & 0xffu)) >> 16);
-                d[2 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)((w[j] >> 16) & 0xffu)) >> 16);
-                d[3 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)(w[j] >> 24)) >> 16);
-            }
+        for (int j = 0; j < TR; ++j) {
+            int i = tid + j * A0W_THREADS;
+            i = i < NDW ? i : NDW - 1;             // threads past the end redo the last dword (same value, same address)
+            const int c = i / (84 * 21), rem = i - c * (84 * 21), y = rem / 21, xc = rem - y * 21;
+            uint16_t* d = Xp + ((c * 4 + (y & 3)) * 4) * A0W_XP_PLANE + (y >> 2) * A0W_XP_ROW + xc;
+            d[0 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)(w[j] & 0xffu)) >> 16);
+            d[1 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)((w[j] >> 8) & 0xffu)) >> 16);
+            d[2 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)((w[j] >> 16) & 0xffu)) >> 16);
+            d[3 * A0W_XP_PLANE] = (uint16_t)(__float_as_uint((float)(w[j] >> 24)) >> 16);
         }
         // ---- d1 -> three exact bf16 terms, transposed: item (n, G) = 8 positions of one row for one channel
         {
-            const float* g = P.d1 + (long long)b * 400 * 32;
             const int n = tid & 31;
-            for (int G = tid >> 5; G < A0W_GROUPS; G += A0W_THREADS / 32) {
-                const int oh = G / 3, ow0 = 8 * (G - 3 * oh);
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (ow0 + j < 20) ? g[((oh * 20 + ow0 + j) < 400 ? (oh * 20 + ow0 + j) : 399) * 32 + n] : 0.f;
-                uint32_t t0[4], t1[4], t2[4];
+            for (int t = 0; t < GT; ++t) {
+                const int G = (tid >> 5) + t * (A0W_THREADS / 32);
+                if (G < A0W_GROUPS) {
+                    const int oh = G / 3, ow0 = 8 * (G - 3 * oh);
+                    uint32_t t0[4], t1[4], t2[4];
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    uint32_t h[2], m[2], l[2];
+                    for (int j = 0; j < 8; j += 2) {
+                        uint32_t h[2], m[2], l[2];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const float x = (ow0 + j + e < 20) ? v[j + e] : 0.f;
-                        bsum += x;
-                        h[e] = a0w_trunc(x);
-                        const float r1 = x - a0w_up(h[e]);
-                        m[e] = a0w_trunc(r1);
-                        l[e] = a0w_trunc(r1 - a0w_up(m[e]));
+                        for (int e = 0; e < 2; ++e) {
+                            const float x = (ow0 + j + e < 20) ? v[t][j + e] : 0.f;
+                            bsum += x;
+                            h[e] = a0w_trunc(x);
+                            const float r1 = x - a0w_up(h[e]);
+                            m[e] = a0w_trunc(r1);
+                            l[e] = a0w_trunc(r1 - a0w_up(m[e]));
+                        }
+                        t0[j >> 1] = h[0] | (h[1] << 16); t1[j >> 1] = m[0] | (m[1] << 16); t2[j >> 1] = l[0] | (l[1] << 16);
                     }
-                    t0[j >> 1] = h[0] | (h[1] << 16); t1[j >> 1] = m[0] | (m[1] << 16); t2[j >> 1] = l[0] | (l[1] << 16);
+                    uint16_t* d = T + n * A0W_T_PITCH + 8 * G;
+                    *(uint4*)(d) = uint4{t0[0], t0[1], t0[2], t0[3]};
+                    *(uint4*)(d + A0W_T_TERM) = uint4{t1[0], t1[1], t1[2], t1[3]};
+                    *(uint4*)(d + 2 * A0W_T_TERM) = uint4{t2[0], t2[1], t2[2], t2[3]};
                 }
-                uint16_t* d = T + n * A0W_T_PITCH + 8 * G;
-                *(uint4*)(d) = uint4{t0[0], t0[1], t0[2], t0[3]};
-                *(uint4*)(d + A0W_T_TERM) = uint4{t1[0], t1[1], t1[2], t1[3]};
-                *(uint4*)(d + 2 * A0W_T_TERM) = uint4{t2[0], t2[1], t2[2], t2[3]};
             }
         }
         __syncthreads();
+        if (b + (int)gridDim.x < P.B) load_raw(b + gridDim.x);
         // ---- 15 MFMA steps of 32 positions: A = d1 terms (2 channel blocks), B = two taps blocks; lane group q owns position group 4*st + q
         {
             const uint16_t* ap = T + r16 * A0W_T_PITCH + 8 * q;
