@@ -29,7 +29,8 @@ typedef float a0_acc4 __attribute__((ext_vector_type(4)));
 
 struct a0_fused_args {
     const uint8_t* frames; const int* slot; long long sample_stride; int chan_off;
-    const float *wt1, *wt2, *wt3;        // k-major weights [K][N]
+    const float *wt1, *wt2, *wt3;        // fragment-major weight copies (a0_conv_wt_kernel)
+    const float *wx2, *wx3;              // conv2 / conv3 as three exact bf16 terms (split-operand path)
     const float *b1, *b2, *b3;
     float *act1, *act2, *act3;           // act1/act2 optional (needed only when a backward pass follows)
     int B;
@@ -370,11 +371,227 @@ A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------ conv2 / conv3 on the bf16 pipe ("x9")
+// fp32 x fp32 products without rounding an operand: BOTH factors are split exactly into three bf16 terms (a = a0 + a1 + a2, 8 + 8 + 8
+// mantissa bits; the activations by the producing layer's epilogue, the weights by a0_conv_wt_kernel), every cross product ai * bj is
+// exact in fp32, and nine v_mfma_f32_16x16x32_bf16 per 32 k (144 matrix-pipe cycles) replace eight v_mfma_f32_16x16x4_f32 (256).
+// The sum is accumulated in fp32 like the fmaf chain; against fp64 it is as close (tools/check_bf16x9.hip: 4.8e-7 vs 3.3e-7 of the
+// scale at K = 512).  Activations live in LDS as three bf16 planes [term][pixel][channels + 8]; a lane's A fragment is the 8
+// consecutive channels 8q .. 8q+7 of one pixel: one aligned 16-byte read per term.
+template <int N, int WN, int R>
+struct a0_wring9 {          // uint4 index ((t*N + n)*4 + q)*3 + s: the eight k = 32t + 8q .. +7 of output channel n, term s
+    static constexpr int NBW = N / 16 / WN;
+    uint4 v[R][NBW][3];
+    const uint4* base;
+    const uint4* p;
+    int nst, left;
+    A0_D void init(const float* wp, int K) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        base = (const uint4*)wp + (((wave % WN) * (NBW * 16) + (lane & 15)) * 4 + (lane >> 4)) * 3;
+        nst = K >> 5;
+    }
+    A0_D void fill(int slot) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) v[slot][j][s] = p[j * 192 + s];
+        const bool more = left > 1;
+        p += more ? N * 12 : 0;
+        left -= more ? 1 : 0;
+    }
+    A0_D void prologue() {
+        p = base; left = nst;
+#pragma unroll
+        for (int u = 0; u < R; ++u) fill(u);
+    }
+};
+struct AF2X {   // conv2 4x4/2 over act1 planes [pixel = h*W1 + w][P]; MFMA step = tap (kh, kw), all 32 channels
+    const uint16_t* planes; int term, W1, W2, P;
+    A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return ((2 * oh) * W1 + 2 * ow) * P; }
+    A0_D int step_off(int st) const { return ((st >> 2) * W1 + (st & 3)) * P; }
+};
+struct AF3X {   // conv3 3x3/1 over act2 planes [pixel][P]; MFMA step = half (32 channels) of tap st >> 1
+    const uint16_t* planes; int term, W2, W3, P;
+    A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return (oh * W2 + ow) * P; }
+    A0_D int step_off(int st) const { const int tap = st >> 1; return ((tap / 3) * W2 + tap % 3) * P + 32 * (st & 1); }
+};
+template <int OWC>
+struct EpiFwdX {            // y = relu(acc + bias[n]) -> three bf16 planes in LDS [term][m][P] (+ fp32 to global [m][N])
+    static constexpr bool PER_ELEM = false;
+    static constexpr bool ROW4 = false;
+    const float* bias; uint16_t* planes; int term, P; float* glb; int N;
+    A0_D float pre_col(int n) const { return bias[n]; }
+    A0_D float pre_elem(int, int) const { return 0.f; }
+    A0_D void emit4(int, int, const a0_acc4&, float) const {}
+    A0_D void emit(int m, int n, float acc, float pre) const {
+        float v = acc + pre;
+        v = (v < 0.f) ? 0.f : v;
+        if (glb) glb[(unsigned)(m * N + n)] = v;
+        const uint32_t h = __float_as_uint(v) >> 16;
+        const float r1 = v - __uint_as_float(h << 16);
+        const uint32_t mi = __float_as_uint(r1) >> 16;
+        const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mi << 16)) >> 16;
+        uint16_t* d = planes + m * P + n;
+        d[0] = (uint16_t)h; d[term] = (uint16_t)mi; d[2 * term] = (uint16_t)lo;
+    }
+};
+
+template <int N, int WN, int MBW, int R, int MBWP, class AFX, class EPI, class Between>
+A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, const EPI& epi, const a0_pre<N, WN, MBWP, EPI>& pre, Between&& between) {
+    constexpr int NB = N / 16, NBW = NB / WN, WMG = A0_FUSED_WAVES / WN;
+    static_assert(NBW >= 1 && (R % 2) == 0 && MBWP >= MBW, "tile shape");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wmg = wave / WN;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int MB = (M + 15) >> 4, NST = ring.nst;       // NST is a multiple of R for every supported shape
+    int rows[MBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        const int m = (wmg + i * WMG) * 16 + r16;
+        rows[i] = af.row(m < M ? m : 0) + 8 * q;
+    }
+    a0_acc4 acc[MBW][NBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = a0_acc4{0.f, 0.f, 0.f, 0.f};
+    uint4 a[2][MBW][3];
+    auto fetch = [&](int slot, int off) {
+#pragma unroll
+        for (int i = 0; i < MBW; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[slot][i][t] = *(const uint4*)(af.planes + t * af.term + rows[i] + off);
+    };
+    fetch(0, af.step_off(0));
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see a0_conv_stage
+#pragma unroll 1
+    for (int tb = 0; tb < NST; tb += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int nxt = tb + u + 1;
+            fetch((u + 1) & 1, af.step_off(nxt < NST ? nxt : NST - 1));          // past the end: re-read the last step (never consumed)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+                    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < NBW; ++jn) {
+                            const a0_u32x4 av = {a[u & 1][i][ta].x, a[u & 1][i][ta].y, a[u & 1][i][ta].z, a[u & 1][i][ta].w};
+                            const a0_u32x4 bv = {ring.v[u][jn][tw].x, ring.v[u][jn][tw].y, ring.v[u][jn][tw].z, ring.v[u][jn][tw].w};
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i][jn], 0, 0, 0);
+                        }
+            __builtin_amdgcn_sched_barrier(0);
+            ring.fill(u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    between();
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        const int mb = wmg + i * WMG;
+        if (mb < MB) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const int n = (wn * NBW + j) * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb * 16 + 4 * q + r;
+                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j][r] : pre.pc[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+constexpr int A0_P1X = 40, A0_P2X = 72;       // pixel pitches (bf16 elements) of the act1 / act2 term planes: channels + 8
+constexpr int A0_RX2 = 4, A0_RX3 = 6;         // 32-k steps of split weights in flight
+
 // Register-ring depths (16-k chunks in flight per wave): >= 2 us of MFMA work ahead of every weight load.
 constexpr int A0_R1 = 4, A0_R2 = 4, A0_R3 = 6;     // conv1: 32-k steps (three 16-byte terms each); conv2 / conv3: 16-k chunks
 
-template <int MBW1, int MBW2, int MBW3, int WC>
+template <int MBW1, int MBW2, int MBW3, int WC, bool X9>
+__global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_fused_args P);
+
+// Split-operand variant (84 x 84 geometry): all three layers on the bf16 pipe.  LDS: bf16 image [0, 56 448), act1 term planes behind it;
+// the act2 term planes reuse the image's bytes (the image is dead once conv1 has finished).
+template <int MBW1, int MBW2, int MBW3>
+A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* img = (uint16_t*)smem;
+    const int obs_bytes = P.C * P.H * P.W;
+    const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
+    uint16_t* a1p = (uint16_t*)(smem + 2 * obs_bytes);
+    uint16_t* a2p = (uint16_t*)smem;
+    const int term1 = M1 * A0_P1X, term2 = M2 * A0_P2X;
+    a0_wring1<A0_R1> ring1;
+    a0_wring9<64, 4, A0_RX2> ring2;
+    a0_wring9<64, 4, A0_RX3> ring3;
+    ring1.init(P.wt1, P.C);
+    ring2.init(P.wx2, 512);
+    ring3.init(P.wx3, 576);
+    ring1.prologue();
+    a0_pre<32, 2, MBW1, EpiFwdX<0>> pre1;
+    a0_pre<64, 4, MBW2, EpiFwdX<0>> pre2;
+    a0_pre<64, 4, MBW3, EpiFwd<0>> pre3;
+    pre1.load(EpiFwdX<0>{P.b1, nullptr, 0, 0, nullptr, 32}, M1);
+    pre2.load(EpiFwdX<0>{P.b2, nullptr, 0, 0, nullptr, 64}, M2);
+    pre3.load(EpiFwd<0>{P.b3, nullptr, 0, 0, 1, nullptr, 64}, M3);
+    // the pad channels (32..39 / 64..71) of the term planes are never read; nothing to initialise
+    for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+        const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
+        const uint4* src = (const uint4*)(P.frames + s * P.sample_stride + P.chan_off);
+        constexpr int TRIPS = 4;
+        const int n16 = obs_bytes >> 4;
+        for (int i0 = threadIdx.x; i0 < n16; i0 += TRIPS * A0_FUSED_THREADS) {
+            uint4 v[TRIPS];
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                const int i = i0 + j * A0_FUSED_THREADS;
+                v[j] = src[i < n16 ? i : n16 - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                int i = i0 + j * A0_FUSED_THREADS;
+                i = i < n16 ? i : n16 - 1;
+                const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t f0 = __float_as_uint((float)(w[k] & 0xffu)), f1 = __float_as_uint((float)((w[k] >> 8) & 0xffu));
+                    const uint32_t f2 = __float_as_uint((float)((w[k] >> 16) & 0xffu)), f3 = __float_as_uint((float)(w[k] >> 24));
+                    o[2 * k] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+                    o[2 * k + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+                }
+                ((uint4*)img)[2 * i] = uint4{o[0], o[1], o[2], o[3]};
+                ((uint4*)img)[2 * i + 1] = uint4{o[4], o[5], o[6], o[7]};
+            }
+        }
+        __syncthreads();
+        const EpiFwdX<0> e1{P.b1, a1p, term1, A0_P1X, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
+        const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
+        if (MBW1 > 1 && wmg1 + (MBW1 - 1) * 4 >= ((M1 + 15) >> 4))
+            a0_conv1_stage<(MBW1 > 1 ? MBW1 - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
+        else
+            a0_conv1_stage<MBW1, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
+        const AF2X f2{a1p, term1, P.W1, P.W2, A0_P1X};
+        const EpiFwdX<0> e2{P.b2, a2p, term2, A0_P2X, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
+        a0_conv_stage_x9<64, 4, MBW2, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+        const AF3X f3{a2p, term2, P.W2, P.W3, A0_P2X};
+        const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
+        a0_conv_stage_x9<64, 4, MBW3, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
+    }
+}
+
+template <int MBW1, int MBW2, int MBW3, int WC, bool X9>
 __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_fused_args P) {
+    if constexpr (X9) {
+        a0_encoder_fused_x9_body<MBW1, MBW2, MBW3>(P);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* img = (uint16_t*)smem;            // the observation as bf16 (exact for bytes), [C][H][W]
     float* fl = (float*)smem;
@@ -520,10 +737,12 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kerne
 // ---- weight copies for the fused kernels, from the packed [N][K] blocks (layouts: a0_wring1 / a0_wring):
 //   seg 1  conv1: fl(w/255) split exactly into three bf16 terms, 16-byte fragments ((t*32 + n)*4 + q)*3 + s   (12 C KB)
 //   seg 2,3 conv2, conv3 fragment-major fp32;  seg 4,5 the flipped / phase-split matrices of the data gradients (wd3 [576][64], wd2 4 x [256][32])
+//   seg 6,7 conv2, conv3 as three exact bf16 terms (a0_wring9 layout) for the split-operand forward path
 A0_HD uint32_t a0_bf16_trunc(float f) { return __float_as_uint(f) >> 16; }
 A0_HD float a0_bf16_up(uint32_t h) { return __uint_as_float(h << 16); }
 __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
     const int n1 = 48 * K1, n2 = 64 * 512, n3 = 64 * 576, n4 = 64 * 576, n5 = 4 * 32 * 256;      // n1: 32 channels x K1 x 3 terms x 2 bytes, in floats
+    const int n6 = 96 * 512, n7 = 96 * 576;                                                       // conv2 / conv3 as three bf16 terms: 64 x K x 3 x 2 bytes
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     float* dst = wt + i;
     if (i < n1) {      // one dword = two consecutive k of one (t, s, n, q) fragment
@@ -542,8 +761,30 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
         *(uint32_t*)dst = out;
         return;
     }
+    i -= n1;
+    {   // seg 6 / 7: exact three-term bf16 split of conv2 / conv3, same fragment layout as seg 1 with 64 output channels
+        const int j6 = i - (n2 + n3 + n4 + n5);
+        if (j6 >= 0) {
+            if (j6 >= n6 + n7) return;
+            const bool c3 = j6 >= n6;
+            const int jj = c3 ? j6 - n6 : j6, K = c3 ? 576 : 512;
+            const float* wsrc = c3 ? w3 : w2;
+            const int pair = jj & 3, f = jj >> 2, s = f % 3, q = (f / 3) & 3, n = (f / 12) & 63, t = f / 768;
+            uint32_t out = 0;
+            for (int h = 0; h < 2; ++h) {
+                const float w = wsrc[n * K + 32 * t + 8 * q + 2 * pair + h];
+                const uint32_t hi = a0_bf16_trunc(w);
+                const float r1 = w - a0_bf16_up(hi);
+                const uint32_t mid = a0_bf16_trunc(r1);
+                const uint32_t lo = a0_bf16_trunc(r1 - a0_bf16_up(mid));
+                out |= (s == 0 ? hi : s == 1 ? mid : lo) << (16 * h);
+            }
+            *(uint32_t*)dst = out;
+            return;
+        }
+    }
     int N, seg;
-    if ((i -= n1) < n2) { seg = 2; N = 64; }
+    if (i < n2) { seg = 2; N = 64; }
     else if ((i -= n2) < n3) { seg = 3; N = 64; }
     else if ((i -= n3) < n4) { seg = 4; N = 64; }
     else if ((i -= n4) < n5) { seg = 5; N = 32; }
@@ -565,7 +806,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
     *dst = v;
 }
 
-extern "C" long long a0_net_conv_wt_floats(int C) { return 48LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; }
+extern "C" long long a0_net_conv_wt_floats(int C) { return 48LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256 + 96LL * 512 + 96LL * 576; }
 
 extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream) {
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh: bad argument");
@@ -610,20 +851,28 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     if ((f->sample_stride % 16) || (f->chan_off % 16) || (((uintptr_t)f->frames) % 16)) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused: frames must be 16-byte aligned");
     P.frames = f->frames; P.slot = f->slot; P.sample_stride = f->sample_stride; P.chan_off = f->chan_off;
     P.wt1 = wt; P.wt2 = wt + 48LL * C * 64; P.wt3 = P.wt2 + 64LL * 512;
+    P.wx2 = P.wt3 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; P.wx3 = P.wx2 + 96LL * 512;      // behind the data-gradient copies
     P.b1 = w->b1; P.b2 = w->b2; P.b3 = w->b3;
     P.act1 = act1; P.act2 = act2; P.act3 = act3; P.B = B;
     // 16-row blocks per wave: conv1 ceil(MB1/4), conv2 ceil(MB2/2), conv3 ceil(MB3/2); exact for 84x84, generous otherwise
     const int mb1 = (P.H1 * P.W1 + 15) / 16, mb2 = (P.H2 * P.W2 + 15) / 16, mb3 = (P.H3 * P.W3 + 15) / 16;
     const bool standard = ((mb1 + 3) / 4 == 7) && ((mb2 + 1) / 2 == 3) && ((mb3 + 1) / 2 == 2) && W == 84;
-    static size_t configured[2] = {0, 0};
-    const void* fn = standard ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84> : (const void*)a0_encoder_fused_kernel<7, 4, 2, 0>;
-    if (lds > configured[standard]) {
+    // three instantiations: split-operand (all layers on the bf16 pipe; 84x84, C = 4), fp32 conv2/conv3 for 84-wide inputs, generic
+    static const bool no_x9 = getenv("A0_NO_X9") != nullptr;
+    const bool x9 = standard && H == 84 && C == 4 && !no_x9;
+    const int which = x9 ? 2 : (standard ? 1 : 0);
+    if (x9) lds = (size_t)2 * C * H * W + (size_t)3 * P.H1 * P.W1 * A0_P1X * 2;       // image + act1 term planes (act2 planes reuse the image)
+    static size_t configured[3] = {0, 0, 0};
+    const void* fn = which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
+                   : which == 1 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, false> : (const void*)a0_encoder_fused_kernel<7, 4, 2, 0, false>;
+    if (lds > configured[which]) {
         A0_HIP_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[standard] = lds;
+        configured[which] = lds;
     }
     const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
-    if (standard) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 4, 2, 0>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    else if (which == 1) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 4, 2, 0, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     if (probed) {   // algorithmic FLOP of the three convolutions: 2 * (M1*32*K1 + M2*64*512 + M3*64*576) per observation
         const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
         a0_probe_stop((hipStream_t)stream, per_obs * B);
