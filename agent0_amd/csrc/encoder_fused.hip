@@ -405,13 +405,17 @@ struct a0_wring9 {          // uint4 index ((t*N + n)*4 + q)*3 + s: the eight k 
         for (int u = 0; u < R; ++u) fill(u);
     }
 };
+template <int TERM>
 struct AF2X {   // conv2 4x4/2 over act1 planes [pixel = h*W1 + w][P]; MFMA step = tap (kh, kw), all 32 channels
-    const uint16_t* planes; int term, W1, W2, P;
+    static constexpr int term = TERM;       // elements per term plane: compile-time, so the three term reads of a fragment differ only in the DS immediate
+    const uint16_t* planes; int W1, W2, P;
     A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return ((2 * oh) * W1 + 2 * ow) * P; }
     A0_D int step_off(int st) const { return ((st >> 2) * W1 + (st & 3)) * P; }
 };
+template <int TERM>
 struct AF3X {   // conv3 3x3/1 over act2 planes [pixel][P]; MFMA step = half (32 channels) of tap st >> 1
-    const uint16_t* planes; int term, W2, W3, P;
+    static constexpr int term = TERM;
+    const uint16_t* planes; int W2, W3, P;
     A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return (oh * W2 + ow) * P; }
     A0_D int step_off(int st) const { const int tap = st >> 1; return ((tap / 3) * W2 + tap % 3) * P + 32 * (st & 1); }
 };
@@ -461,7 +465,7 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
 #pragma unroll
         for (int i = 0; i < MBW; ++i)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[slot][i][t] = *(const uint4*)(af.planes + t * af.term + rows[i] + off);
+            for (int t = 0; t < 3; ++t) a[slot][i][t] = *(const uint4*)(af.planes + rows[i] + off + t * AFX::term);
     };
     fetch(0, af.step_off(0));
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see a0_conv_stage
@@ -507,7 +511,7 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
     }
     __syncthreads();
 }
-constexpr int A0_P1X = 40, A0_P2X = 72;       // pixel pitches (bf16 elements) of the act1 / act2 term planes: channels + 8
+constexpr int A0_P1X = 40, A0_P2X = 80;       // pixel pitches (bf16 elements) of the act1 / act2 term planes: channels + 8
 constexpr int A0_RX2 = 4, A0_RX3 = 6;         // 32-k steps of split weights in flight
 
 // Register-ring depths (16-k chunks in flight per wave): >= 2 us of MFMA work ahead of every weight load.
@@ -577,10 +581,10 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
             a0_conv1_stage<(MBW1 > 1 ? MBW1 - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
             a0_conv1_stage<MBW1, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
-        const AF2X f2{a1p, term1, P.W1, P.W2, A0_P1X};
+        const AF2X<400 * A0_P1X> f2{a1p, P.W1, P.W2, A0_P1X};
         const EpiFwdX<0> e2{P.b2, a2p, term2, A0_P2X, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
         a0_conv_stage_x9<64, 4, MBW2, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
-        const AF3X f3{a2p, term2, P.W2, P.W3, A0_P2X};
+        const AF3X<81 * A0_P2X> f3{a2p, P.W2, P.W3, A0_P2X};
         const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
         a0_conv_stage_x9<64, 4, MBW3, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
     }
