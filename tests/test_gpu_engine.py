@@ -225,6 +225,15 @@ def test_conv1_bf16_split_is_exact_and_fp32_accurate():
     w1 = net.encoder_weights()["w1"].cpu().numpy().reshape(32, K1)
     want = (w1 / np.float32(255.0)).astype(np.float32)
     assert np.array_equal(got.astype(np.float32), want) and np.array_equal(got, want.astype(np.float64))
+    # conv2 / conv3 (split-operand path): same exactness for the weight terms, fragment layout [t][n][q][s][8] with 64 channels
+    off = 48 * K1 + 64 * 512 + 64 * 576 + 64 * 576 + 4 * 32 * 256
+    for name, K, length in (("w2", 512, 96 * 512), ("w3", 576, 96 * 576)):
+        raw = net.wt[off:off + length].view(torch.int32).cpu().numpy().view(np.uint16).reshape(K // 32, 64, 4, 3, 8)
+        terms = (raw.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        got = np.transpose(terms[:, :, :, 0] + terms[:, :, :, 1] + terms[:, :, :, 2], (1, 0, 2, 3)).reshape(64, K)
+        want = net.encoder_weights()[name].cpu().numpy().reshape(64, K)
+        assert np.array_equal(got, want.astype(np.float64)), name
+        off += length
     # ---- (2) accuracy against fp64
     B = 2
     g = recipe.gen(77)
@@ -247,3 +256,23 @@ def test_conv1_bf16_split_is_exact_and_fp32_accurate():
     e_u = np.abs(ws_u.act1.cpu().numpy().astype(np.float64) - ref).max()
     assert e_f <= 2e-6 * scale and e_u <= 2e-6 * scale, (e_f, e_u, scale)
     assert e_f <= 2.0 * e_u + 1e-7 * scale, (e_f, e_u)
+    # the whole encoder (conv2 / conv3 with both operands split) against an fp64 evaluation of the three layers
+    def conv64(x, w, bias, stride):      # x [B][C][H][W] float64, w [N][C][kh][kw]
+        Bn, C_, H_, W_ = x.shape
+        N_, _, kh, kw = w.shape
+        Ho, Wo = (H_ - kh) // stride + 1, (W_ - kw) // stride + 1
+        out = np.zeros((Bn, N_, Ho, Wo))
+        wm = w.reshape(N_, -1).T
+        for i in range(Ho):
+            for j in range(Wo):
+                out[:, :, i, j] = x[:, :, i * stride:i * stride + kh, j * stride:j * stride + kw].reshape(Bn, -1) @ wm + bias
+        return np.maximum(out, 0.0)
+    w2, b2 = (np.asarray(sd[f"encoder.convs.2.{k}"], dtype=np.float64) for k in ("weight", "bias"))
+    w3, b3 = (np.asarray(sd[f"encoder.convs.4.{k}"], dtype=np.float64) for k in ("weight", "bias"))
+    y3 = conv64(conv64(conv64(x, w, bias, 4), w2, b2, 2), w3, b3, 1)                   # [B][64][7][7]
+    ref3 = np.transpose(y3, (0, 2, 3, 1)).reshape(-1)                                   # NHWC like act3
+    s3 = np.abs(ref3).max()
+    e3_f = np.abs(ws_f.act3.cpu().numpy().astype(np.float64) - ref3).max()
+    e3_u = np.abs(ws_u.act3.cpu().numpy().astype(np.float64) - ref3).max()
+    assert e3_f <= 3e-6 * s3 and e3_u <= 3e-6 * s3, (e3_f, e3_u, s3)
+    assert e3_f <= 3.0 * e3_u + 2e-7 * s3, (e3_f, e3_u)
