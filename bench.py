@@ -168,6 +168,21 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             pr = tr.ops.probe_end()
+    # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
+    # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
+    replay_gbps = None
+    if rank == 0:
+        rp = tr.replay
+        out_rows = torch.empty(rp.B * rp.row_bytes, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            rp.sample_gathered(out_rows)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_rep = 100
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(n_rep):
+            rp.sample_gathered(out_rows)          # index generation + metadata + 28.9 MB row gather, one launch
+        e1.record(); torch.cuda.synchronize()
+        replay_gbps = rp.B * rp.row_bytes * n_rep / (e0.elapsed_time(e1) * 1e-3) / 1e9
     # ---- the same metric at the reference's update:data ratio for 256 envs (learner_steps = 320 instead of 20)
     ratio320 = None
     if world == 1 and not args.no_ratio320:
@@ -208,21 +223,6 @@ def main():
         other = {"entry": "agent0.deepq." + ("main" if args.entry == "launch" else "launch"), "value": round(per_iter / d2, 1), "unit": "env-frames/sec",
                  "ms_per_step": round(1e3 * d2, 3), "steps": args.steps}
         del tr2
-    # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
-    # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
-    replay_gbps = None
-    if rank == 0:
-        rp = tr.replay
-        out_rows = torch.empty(rp.B * rp.row_bytes, dtype=torch.uint8, device="cuda")
-        for _ in range(3):
-            rp.sample_gathered(out_rows)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_rep = 100
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(n_rep):
-            rp.sample_gathered(out_rows)          # index generation + metadata + 28.9 MB row gather, one launch
-        e1.record(); torch.cuda.synchronize()
-        replay_gbps = rp.B * rp.row_bytes * n_rep / (e0.elapsed_time(e1) * 1e-3) / 1e9
     if world > 1:
         barrier()
     if rank != 0:
