@@ -260,10 +260,10 @@ def main():
         achieved = pr["flop"] / (pr["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json; "
-                                "algorithmic minimum 10.8 MB (256 obs) / 21.2 MB (512 obs); the learner's online pass also stores act1/act2 for the backward pass",
+                                "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB (512 obs); the learner's online pass also stores act1/act2 for the backward pass",
                 "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation; u8 input, activations in LDS, weights streamed through registers; "
-                          "conv1 on v_mfma_f32_16x16x32_bf16 with bytes x an exact three-term bf16 split of the fp32 weights, conv2/conv3 on v_mfma_f32_16x16x4_f32; "
-                          "FLOPs counted once, peak = fp32 MFMA)"
+                          "all layers on v_mfma_f32_16x16x32_bf16 with operands split exactly into bf16 terms (bytes x 3 weight terms; 3 activation x 3 weight terms), fp32 accumulation; "
+                          "FLOPs counted once, peak = fp32 MFMA, the bound of the fp32-chain variant A0_NO_X9=1)"
                           if pr["kernel"] == "encoder_fused" else f"a0_igemm_kernel<{pr['kernel']}>",
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
                 "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor) or 512 (learner) observations",
