@@ -70,6 +70,16 @@ class DeviceSynthVecEnv:
         info = {"life_loss": self.life_loss, "final_mask": fm, "final_ret": fr}
         return self._obs[nxt], self.reward, self.terminal, self.truncated, info
 
+    def step_commit(self, action, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, replay, start_slot, ctrl=None):
+        """``step`` + the actor's n-step bookkeeping + the replay row commit in one launch (a0_env_synth_step_commit); ``obs0`` is the first
+        observation of the emitted transition, ``replay`` anything with frames / size / act / rew / done (ReplayDataset, StageRing)."""
+        self.g += 1
+        nxt = 1 - self._cur
+        self.ops.env_step_commit(self.seed, self.rank, self.E, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps, gamma,
+                                 action, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done, ctrl)
+        self._cur = nxt
+        return self._obs[nxt]
+
     def close(self):
         pass
 

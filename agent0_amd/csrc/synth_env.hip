@@ -83,3 +83,88 @@ extern "C" int a0_env_synth_step(unsigned long long seed, unsigned int rank, int
                        truncated, life_loss, final_mask, final_ret, 0, ctrl);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step");
 }
+
+
+// ------------------------------------------------------------------------------------------------ env step + n-step + replay commit
+// One launch for the three actor-side stages that follow action selection when the synthetic env drives the rollout:
+// a0_env_synth_step (new frame, reward, terminal / life-loss flags, episode statistics), a0_actor_nstep (done flag, n-step return and
+// emitted action; reference agent.py:57-73) and a0_replay_insert (st || st_next row + metadata into the ring; agent.py:78-81,
+// replay.py:45-53).  Same arithmetic, same draws, same bytes as the three separate kernels — checked byte for byte against the
+// oracle actor in tests/test_gpu_trainer.py — but the 28 KB observation is read once instead of twice and two launches disappear
+// from every actor step.  obs0 = the observation the emitted transition starts from (obs_in itself for n = 1, the ring entry of
+// n - 1 steps ago otherwise).  Grid (7, E) like a0_env_step_kernel.
+__global__ __launch_bounds__(256) void a0_env_step_commit_kernel(unsigned long long seed, uint32_t rank, int E, uint32_t g, const uint8_t* __restrict__ obs_in,
+                                                                  uint8_t* __restrict__ obs_out, float* __restrict__ ep_ret, float* __restrict__ final_mask,
+                                                                  float* __restrict__ final_ret, int n, long long steps, double gamma,
+                                                                  const int* __restrict__ action, int* __restrict__ ring_act, float* __restrict__ ring_rew,
+                                                                  float* __restrict__ ring_done, const uint8_t* __restrict__ obs0, uint8_t* __restrict__ frames,
+                                                                  long long cap, long long start, int* __restrict__ r_act, float* __restrict__ r_rew,
+                                                                  float* __restrict__ r_done, const long long* __restrict__ ctrl) {
+    if (ctrl) { g += (uint32_t)ctrl[A0_CTRL_ENV_STEP]; steps += ctrl[A0_CTRL_ACTOR_STEPS]; start += ctrl[A0_CTRL_REPLAY_SLOT]; }
+    const uint32_t e = blockIdx.y;
+    const long long slot = (start + e) % cap;
+    const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)seed, (uint32_t)(seed >> 32) ^ rank);
+    const bool term = (x.y % 500u) == 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t rw = x.x % 1000u;
+        const float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+        const bool life = (!term) && ((x.z % 200u) == 0u);
+        const float ret = ep_ret[e] + r;
+        final_mask[e] = term ? 1.f : 0.f;
+        final_ret[e] = term ? ret : 0.f;
+        ep_ret[e] = term ? 0.f : ret;
+        // n-step bookkeeping (a0_nstep_kernel; truncated is always 0 for this env)
+        const bool done = term || life;
+        const int cur = (int)(steps % n);
+        const int a_now = action[e];
+        ring_act[(long long)cur * E + e] = a_now;
+        ring_rew[(long long)cur * E + e] = r;
+        ring_done[(long long)cur * E + e] = done ? 1.f : 0.f;
+        const long long have = steps + 1;
+        const int count = have < n ? (int)have : n;
+        double R = 0.0;
+        bool D = false;
+        for (int k = 0; k < count; ++k) {
+            const int idx = (int)(((steps - k) % n + n) % n);
+            const float dk = (k == 0) ? (done ? 1.f : 0.f) : ring_done[(long long)idx * E + e];
+            const float rk = (k == 0) ? r : ring_rew[(long long)idx * E + e];
+            D = D || (dk != 0.f);
+            R = R * gamma * (double)(1 - (dk != 0.f ? 1 : 0)) + (double)rk;
+        }
+        const int oldest = (int)(((steps - (count - 1)) % n + n) % n);
+        r_act[slot] = (count == 1) ? a_now : ring_act[(long long)oldest * E + e];
+        r_rew[slot] = (float)R;
+        r_done[slot] = D ? 1.f : 0.f;
+    }
+    const uint32_t base = (uint32_t)seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
+    const uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    const int q = A0_ENV_PIX / 4;
+    const uint32_t* in4 = (const uint32_t*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
+    const uint32_t* o04 = (const uint32_t*)(obs0 + (size_t)e * 4 * A0_ENV_PIX);
+    uint32_t* out4 = (uint32_t*)(obs_out + (size_t)e * 4 * A0_ENV_PIX);
+    uint32_t* row4 = (uint32_t*)(frames + slot * (8LL * A0_ENV_PIX));          // [st (4 frames) | st_next (4 frames)]
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) {
+        const uint32_t p = 4u * (uint32_t)j;
+        const uint32_t nw = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
+                            ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
+        const uint32_t i0 = in4[j], i1 = in4[q + j], i2 = in4[2 * q + j], i3 = in4[3 * q + j];
+        uint32_t n0, n1, n2, n3;
+        if (term) { n0 = nw; n1 = nw; n2 = nw; n3 = nw; } else { n0 = i1; n1 = i2; n2 = i3; n3 = nw; }
+        out4[j] = n0; out4[q + j] = n1; out4[2 * q + j] = n2; out4[3 * q + j] = n3;
+        if (obs0 == obs_in) { row4[j] = i0; row4[q + j] = i1; row4[2 * q + j] = i2; row4[3 * q + j] = i3; }
+        else { row4[j] = o04[j]; row4[q + j] = o04[q + j]; row4[2 * q + j] = o04[2 * q + j]; row4[3 * q + j] = o04[3 * q + j]; }
+        row4[4 * q + j] = n0; row4[5 * q + j] = n1; row4[6 * q + j] = n2; row4[7 * q + j] = n3;
+    }
+}
+
+extern "C" int a0_env_synth_step_commit(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                        float* final_mask, float* final_ret, int n, long long steps, double gamma, const int* action, int* ring_act,
+                                        float* ring_rew, float* ring_done, const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act,
+                                        float* r_rew, float* r_done, const long long* ctrl, void* stream) {
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !action || !ring_act || !ring_rew || !ring_done || !obs0 || !frames ||
+        !r_act || !r_rew || !r_done || E < 1 || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        return a0_fail(A0_EINVAL, "a0_env_synth_step_commit: bad argument");
+    hipLaunchKernelGGL(a0_env_step_commit_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n,
+                       steps, gamma, action, ring_act, ring_rew, ring_done, obs0, frames, cap, start_slot % cap, r_act, r_rew, r_done, ctrl);
+    return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step_commit");
+}

@@ -76,6 +76,7 @@ class Actor:
         self.out_act, self.out_rew, self.out_done = ops.zeros(E, dtype=torch.int32), ops.zeros(E), ops.zeros(E)
         self.atoms = self.model.head.atoms.reshape(-1).contiguous() if self.L.algo == "c51" else None
         self._stage = None
+        self.fused_commit = hasattr(self.envs, "step_commit") and (self.obs_bytes == 4 * 84 * 84)
 
     # ------------------------------------------------------------------ agent.py:25-39
     def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None, t: int = 0):
@@ -126,16 +127,24 @@ class Actor:
             if self.n > 1:
                 slot = self.steps % R
                 self.ring_obs[slot * E * self.obs_bytes:(slot + 1) * E * self.obs_bytes].copy_(cur_obs)
-            obs_next, reward, terminal, truncated, info = self.envs.step(self.action, final_mask=self.stat_mask[t * E:(t + 1) * E],
-                                                                         final_ret=self.stat_ret[t * E:(t + 1) * E], ctrl=ctrl)
-            ops.actor_nstep(E, self.n, self.steps, float(cfg.learner.discount), self.action, reward, terminal, truncated, info.get("life_loss"),
-                            self.ring_act, self.ring_rew, self.ring_done, self.out_act, self.out_rew, self.out_done, ctrl)
             if self.n > 1:
                 count = min(self.steps + 1, self.n)
                 oldest = (self.steps - (count - 1)) % R
                 obs0 = self.ring_obs[oldest * E * self.obs_bytes:(oldest + 1) * E * self.obs_bytes]
             else:
                 obs0 = cur_obs
+            if bound and not test and self.fused_commit:
+                # env step, n-step bookkeeping and the replay row in one launch (synthetic env)
+                rp = self.replay
+                obs_next = self.envs.step_commit(self.action, self.stat_mask[t * E:(t + 1) * E], self.stat_ret[t * E:(t + 1) * E], self.n, self.steps,
+                                                 float(cfg.learner.discount), self.ring_act, self.ring_rew, self.ring_done, obs0, rp, (start + t * E) % rp.size, ctrl)
+                self.steps += 1
+                self.obs = obs_next
+                continue
+            obs_next, reward, terminal, truncated, info = self.envs.step(self.action, final_mask=self.stat_mask[t * E:(t + 1) * E],
+                                                                         final_ret=self.stat_ret[t * E:(t + 1) * E], ctrl=ctrl)
+            ops.actor_nstep(E, self.n, self.steps, float(cfg.learner.discount), self.action, reward, terminal, truncated, info.get("life_loss"),
+                            self.ring_act, self.ring_rew, self.ring_done, self.out_act, self.out_rew, self.out_done, ctrl)
             self.steps += 1
             if test:
                 frames_out.append(obs_next.view(E, self.L.C, self.L.H, self.L.W)[:4, -1:].cpu().numpy())

@@ -405,6 +405,18 @@ class HipOps:
                                          _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"),
                                          _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_env_synth_step")
 
+    def env_step_commit(self, seed, rank, E, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, action, ring_act, ring_rew, ring_done, obs0,
+                        frames, cap, start_slot, r_act, r_rew, r_done, ctrl=None):
+        nb = E * 4 * 84 * 84
+        check(self.lib.a0_env_synth_step_commit(seed, rank, E, g, _req(obs_in, torch.uint8, nb, "obs_in"), _req(obs_out, torch.uint8, nb, "obs_out"),
+                                                _req(ep_ret, torch.float32, E, "ep_ret"), _req(final_mask, torch.float32, E, "final_mask"),
+                                                _req(final_ret, torch.float32, E, "final_ret"), n, steps, float(gamma), _req(action, torch.int32, E, "action"),
+                                                _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"),
+                                                _req(ring_done, torch.float32, n * E, "ring_done"), _req(obs0, torch.uint8, nb, "obs0"),
+                                                _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
+                                                _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
+                                                _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_env_synth_step_commit")
+
     # ------------------------------------------------------------------ measurement
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
                   "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}

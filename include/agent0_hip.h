@@ -226,6 +226,13 @@ int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_
 int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
                       float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
                       float* final_ret, const long long* ctrl, void* stream);
+/* a0_env_synth_step + a0_actor_nstep (agent.py:57-73) + a0_replay_insert (agent.py:78-81, replay.py:45-53) in one launch for rollouts
+ * driven by the synthetic env: obs0 = first observation of the emitted transition (obs_in for n = 1).  ctrl adds its ENV_STEP,
+ * ACTOR_STEPS and REPLAY_SLOT words to g, steps and start_slot. */
+int a0_env_synth_step_commit(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                             float* final_mask, float* final_ret, int n, long long steps, double gamma, const int* action, int* ring_act,
+                             float* ring_rew, float* ring_done, const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act,
+                             float* r_rew, float* r_done, const long long* ctrl, void* stream);
 
 #ifdef __cplusplus
 }
