@@ -1,0 +1,339 @@
+// The implicit GEMM of igemm.h on the bf16 matrix pipe with BOTH fp32 operands split exactly into three bf16 terms.
+//
+// Same contract as a0_igemm_kernel (operand policies of operands.h, epilogues, split-K slabs, the row-sum by-product of the
+// weight gradients) and the same fp32 result up to the association order of the additions: any fp32 value is EXACTLY
+// hi + mid + lo with hi = trunc16(x), mid = trunc16(x - hi), lo = x - hi - mid (8 + 8 + 8 significand bits, each term exact in
+// bf16), a product of two bf16 values is exact in fp32, and all nine cross products are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Per 32 k and 32x32 block that is 18 MFMAs of 32 matrix-pipe cycles instead of 16 fp32 MFMAs of 64.
+//
+// The split happens ONCE per element, when a tile moves from registers to LDS; LDS holds three bf16 term planes per operand:
+//   A0_KC operands (k contiguous in memory):  plane[x][32 k], rows of 64 B at a pitch of 80 B; a fragment (8 consecutive k of one
+//          row) is one aligned ds_read_b128, conflict-free (5 is odd, so any 16 rows of a b128 lane group hit 16 different 4-bank units).
+//   A0_XC operands (x contiguous in memory):  plane[32 k][x] exactly as fetched, pitch = 16 or 48 dwords mod 64; the k-major
+//          fragment is produced by the LDS itself: two ds_read_b64_tr_b16 (4 k x 16 x blocks, transposed per 16-lane group).
+// Either way one float4 of fetched data becomes three 8-byte LDS writes.
+#pragma once
+#include "igemm.h"
+
+#if defined(__HIPCC__)
+
+typedef __bf16 a0_bf16x8g __attribute__((ext_vector_type(8)));
+typedef short a0_s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t a0_u32x2g __attribute__((ext_vector_type(2)));
+typedef uint32_t a0_u32x4g __attribute__((ext_vector_type(4)));
+
+// One piece = one float4 of an operand tile per thread.  Its way from registers to the three term planes is cut into six
+// micro-steps (zero-fill / finish, four element splits, pack + store) so that the kernel can place each of them behind an MFMA.
+struct a0_x9_piece {
+    a0_f4 v;
+    uint32_t h[4], m[4], l[4];
+    A0_D void split(int e) {
+        const float x = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+        h[e] = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(h[e] & 0xffff0000u);            // exact: at most 16 significant bits left
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);           // exact: at most 8 significant bits left
+        l[e] = __float_as_uint(r2);
+    }
+    // v_perm_b32: the upper halves of two dwords side by side (the truncation itself); element e of the float4 in bf16 slot e
+    A0_D void pack(a0_u32x2g& hi, a0_u32x2g& mid, a0_u32x2g& lo) const {
+        hi.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);  hi.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
+        mid.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); mid.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+        lo.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);  lo.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+    }
+};
+
+template <int MODE, int BX> struct a0_x9_image;
+template <int BX> struct a0_x9_image<A0_KC, BX> {
+    static constexpr int PITCH = 80;                       // bytes per x row (32 bf16 + 16 B pad)
+    static constexpr int PLANE = BX * PITCH;
+};
+template <int BX> struct a0_x9_image<A0_XC, BX> {
+    static constexpr int PDW = ((BX / 2) % 32 == 16) ? (BX / 2) : (BX / 2 + 16);   // dwords per k row: 16 mod 32, so 4 rows x 16 dwords tile the 64 banks
+    static constexpr int PITCH = 4 * PDW;
+    static constexpr int PLANE = 32 * PITCH;
+};
+
+// global -> registers (the policies' branch-free loads, as in igemm.h) and registers -> term planes, both in PIECES of one float4 per
+// thread: the kernel threads a tile's pieces between its MFMAs, so the ~22 VALU instructions of a split run in the shadow of the
+// matrix pipe instead of in front of it.
+template <class OP, int BX, int NTH, int MODE = OP::MODE> struct a0_x9_stager;
+
+template <class OP, int BX, int NTH> struct a0_x9_stager<OP, BX, NTH, A0_KC> {
+    static constexpr int RPP = NTH / 8;      // rows per pass: eight threads cover the 32 k of one row
+    static constexpr int R = BX / RPP;
+    static_assert(BX % RPP == 0, "tile rows per pass");
+    typedef a0_x9_image<A0_KC, BX> IM;
+    typename OP::Row rows[R];
+    typename OP::KInfo ki;        // gather-table entry of the tile being fetched (looked up when the previous tile's last piece was fetched)
+    struct Slot { typename OP::Raw raw[R]; unsigned okmask; };
+    A0_D void init(const typename OP::Params& P, int x0, int X, int kb, int ke, int tid) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + (tid >> 3) + RPP * j, X);
+        ki = OP::kinfo(P, kb + 4 * (tid & 7), ke);
+    }
+    // pieces of one tile are fetched in the order j = 0 .. R-1; the last one moves the k state on to the next tile
+    A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
+        bool ok;
+        s.raw[j] = OP::load(P, rows[j], ki, ok);
+        s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
+        if (j == R - 1) ki = OP::kinfo(P, k0 + 32 + 4 * (tid & 7), ke);
+    }
+    template <bool RS> A0_D a0_f4 value(const Slot& s, int j, a0_f4&) const {
+        static_assert(!RS, "row sums are taken from x-contiguous A operands");
+        return OP::finish(s.raw[j], (s.okmask >> j) & 1u);
+    }
+    A0_D void store(const a0_x9_piece& pc, int j, char* lds, int tid) const {
+        const int r = (tid >> 3) + RPP * j;
+        a0_u32x2g hi, mid, lo;
+        pc.pack(hi, mid, lo);
+        char* p = lds + r * IM::PITCH + 8 * (tid & 7);
+        *(a0_u32x2g*)(p) = hi;
+        *(a0_u32x2g*)(p + IM::PLANE) = mid;
+        *(a0_u32x2g*)(p + 2 * IM::PLANE) = lo;
+    }
+    // byte offset of this lane's fragment of block 0, k-step 0 (wave rows start at x = woff)
+    A0_D static int frag_base(int lane, int woff) { return (woff + (lane & 31)) * IM::PITCH + (lane >> 5) * 16; }
+    A0_D static a0_u32x4g frag(const char* plane, int base, int blk, int s) {
+        return *(const a0_u32x4g*)(plane + base + blk * 32 * IM::PITCH + s * 32);
+    }
+};
+
+template <class OP, int BX, int NTH> struct a0_x9_stager<OP, BX, NTH, A0_XC> {
+    static constexpr int R = 8 * BX / NTH;
+    static constexpr int Q = BX / 4;   // 16-byte groups per k row
+    static_assert((8 * BX) % NTH == 0 && NTH % Q == 0, "tile columns per pass");
+    typedef a0_x9_image<A0_XC, BX> IM;
+    typename OP::XInfo xi[R];
+    struct Slot { typename OP::Raw raw[R]; unsigned okmask; };
+    A0_D void init(const typename OP::Params& P, int x0, int X, int, int, int tid) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) xi[j] = OP::xinfo(P, x0 + 4 * ((tid + NTH * j) % Q), X);
+    }
+    A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
+        bool ok;
+        s.raw[j] = OP::load(P, k0 + (tid + NTH * j) / Q, ke, xi[j], ok);
+        s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
+    }
+    template <bool RS> A0_D a0_f4 value(const Slot& s, int j, a0_f4& rowsum) const {
+        const a0_f4 v = OP::finish(s.raw[j], (s.okmask >> j) & 1u);
+        if constexpr (RS) { rowsum.x += v.x; rowsum.y += v.y; rowsum.z += v.z; rowsum.w += v.w; }
+        return v;
+    }
+    A0_D void store(const a0_x9_piece& pc, int j, char* lds, int tid) const {
+        const int f = tid + NTH * j;
+        a0_u32x2g hi, mid, lo;
+        pc.pack(hi, mid, lo);
+        char* p = lds + (f / Q) * IM::PITCH + 8 * (f % Q);
+        *(a0_u32x2g*)(p) = hi;
+        *(a0_u32x2g*)(p + IM::PLANE) = mid;
+        *(a0_u32x2g*)(p + 2 * IM::PLANE) = lo;
+    }
+    // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row k0+q, columns 4p..4p+3 of the group's 4 x 16 block and
+    // receives column (lane & 15), rows k0..k0+3.  Groups 0/1 take x 0-15 / 16-31 at k 0-7, groups 2/3 the same at k 8-15.
+    A0_D static int frag_base(int lane, int woff) {
+        return ((lane >> 5) * 8 + ((lane & 15) >> 2)) * IM::PITCH + 2 * (woff + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+    }
+    A0_D static a0_u32x4g frag(const char* plane, int base, int blk, int s) {
+        typedef __attribute__((address_space(3))) a0_s16x4 lds_s16x4;
+        const char* p = plane + base + blk * 64 + s * 16 * IM::PITCH;
+        const a0_s16x4 k03 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+        const a0_s16x4 k47 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * IM::PITCH));
+        const a0_u32x2g a = __builtin_bit_cast(a0_u32x2g, k03), b = __builtin_bit_cast(a0_u32x2g, k47);
+        a0_u32x4g r; r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y;
+        return r;
+    }
+};
+
+template <class OA, class OB, int WM, int WN, int MT, int NT> struct a0_x9_geom {
+    static constexpr int BX = WM * MT * 32, BY = WN * NT * 32;
+    static constexpr int ABYTES = 3 * a0_x9_image<OA::MODE, BX>::PLANE;
+    static constexpr int BBYTES = 3 * a0_x9_image<OB::MODE, BY>::PLANE;
+    static constexpr int LDS_BYTES = 2 * (ABYTES + BBYTES);                 // double-buffered
+};
+
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::Params pa, typename OB::Params pb,
+                                                           typename EP::Params pe, int X, int Y, int K, int kchunk, int gx, int gy) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
+    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT> G;
+    constexpr int BK = 32, BX = G::BX, BY = G::BY, NTH = WM * WN * 64;
+    typedef a0_x9_stager<OA, BX, NTH> SA;
+    typedef a0_x9_stager<OB, BY, NTH> SB;
+    constexpr int APL = a0_x9_image<OA::MODE, BX>::PLANE, BPL = a0_x9_image<OB::MODE, BY>::PLANE;
+    constexpr int RA = SA::R, RB = SB::R, NP = RA + RB;      // commit / fetch pieces per tile
+    constexpr int NG = 18;                                   // product groups per tile: 2 k-steps x 9 term pairs, MT*NT MFMAs each
+    static_assert(!EP::ROWSUM_A || OA::MODE == A0_XC, "row sums need an x-contiguous A operand");
+    extern __shared__ __attribute__((aligned(16))) char a0_x9_lds[];
+    char* const As = a0_x9_lds;                       // [2 buffers][3 planes]
+    char* const Bs = a0_x9_lds + 2 * G::ABYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order.  The grid is one-dimensional; hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each
+    // with its own L2.  Ids are regrouped so that every XCD walks a CONTIGUOUS range of logical tiles, and within the range the
+    // smaller grid dimension runs fastest: the workgroups an XCD runs side by side then share one tile of the operand that would
+    // otherwise be re-read from HBM once per tile of the other dimension (fc1 over 32 768 quantile rows: 411 MB of activations x 8).
+    int bx, by, bz;
+    {
+        const int n = gridDim.x, id = blockIdx.x, per = n >> 3;
+        const int L = (id < (per << 3)) ? (id & 7) * per + (id >> 3) : id;
+        if (gy <= gx) { by = L % gy; const int t = L / gy; bx = t % gx; bz = t / gx; }
+        else          { bx = L % gx; const int t = L / gx; by = t % gy; bz = t / gy; }
+    }
+    const int x0 = bx * BX, y0 = by * BY;
+    const int kb = bz * kchunk;
+    const int ke = (K < kb + kchunk) ? K : (kb + kchunk);
+
+    SA sa; SB sb;
+    sa.init(pa, x0, X, kb, ke, tid);
+    sb.init(pb, y0, Y, kb, ke, tid);
+
+    a0_acc16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // EP::ROWSUM_A (weight gradients): the sums of A's rows over this split's k range are the bias gradient; they are taken from
+    // the fetched registers on their way to LDS by the blockIdx.y == 0 column of workgroups (an extra add per element elsewhere
+    // would be wasted, so the flag picks the instantiation).
+    a0_f4 rowsum = a0_zero4();
+
+    // piece p of a tile: p < RA -> A slot row-group p, else B slot row-group p - RA
+    auto fetch_piece = [&](typename SA::Slot& s_a, typename SB::Slot& s_b, int p, int k0) {
+        if (p < RA) sa.fetch_piece(pa, s_a, p, k0, ke, tid);
+        else sb.fetch_piece(pb, s_b, p - RA, k0, ke, tid);
+    };
+    // micro-step u of a tile's staging work: piece u / 6 (A row-groups first, then B), step u % 6 = finish | split e0..e3 | pack + store + refetch
+    a0_x9_piece pc;
+    auto micro = [&](int u, const typename SA::Slot& s_a_c, const typename SB::Slot& s_b_c, typename SA::Slot& s_a, typename SB::Slot& s_b,
+                     char* a_dst, char* b_dst, int k_fetch) {
+        const int p = u / 6, st = u % 6;
+        if (st == 0) {
+            if (p < RA) pc.v = sa.template value<EP::ROWSUM_A>(s_a_c, p, rowsum);
+            else pc.v = sb.template value<false>(s_b_c, p - RA, rowsum);
+        } else if (st <= 4) {
+            pc.split(st - 1);
+        } else {
+            if (p < RA) sa.store(pc, p, a_dst, tid);
+            else sb.store(pc, p - RA, b_dst, tid);
+            fetch_piece(s_a, s_b, p, k_fetch);
+        }
+    };
+
+    const int abase = SA::frag_base(lane, wm * (MT * 32));
+    const int bbase = SB::frag_base(lane, wn * (NT * 32));
+
+    // One tile: multiply LDS buffer `buf` (tile t) while tile t+1 (slots s_a / s_b) is split and written into the other buffer and
+    // tile t+3 is requested into the registers each piece frees.  The 6*NP micro-steps are dealt out evenly behind the tile's
+    // 18*MT*NT MFMAs and pinned there with sched_barriers: an MFMA holds the vector issue port for 8 of its 32 cycles, so the five
+    // or six VALU instructions of a micro-step issue in its shadow (left to itself the scheduler clusters the MFMAs and the splits
+    // and the two run one after the other).
+    auto mma_tile = [&](int buf, typename SA::Slot& s_a, typename SB::Slot& s_b, int k_fetch) {
+        const char* ap = As + buf * G::ABYTES;
+        const char* bp = Bs + buf * G::BBYTES;
+        char* a_dst = As + (buf ^ 1) * G::ABYTES;
+        char* b_dst = Bs + (buf ^ 1) * G::BBYTES;
+        a0_u32x4g a[2][MT][3], b[2][NT][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[s][i][t] = SA::frag(ap + t * APL, abase, i, s);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[s][j][t] = SB::frag(bp + t * BPL, bbase, j, s);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NM = NG * MT * NT, NU = 6 * NP;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {
+            // MFMA n: product group g = n / (MT*NT) -> k-step g / 9 and term pair g % 9 in the order of increasing magnitude (lo*lo first, hi*hi last)
+            const int g = n / (MT * NT), i = (n / NT) % MT, j = n % NT;
+            const int s = g / 9, q = g % 9;
+            constexpr int TA[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
+            constexpr int TB[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0};
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0_bf16x8g, a[s][i][TA[q]]),
+                                                                 __builtin_bit_cast(a0_bf16x8g, b[s][j][TB[q]]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int u = n * NU / NM; u < (n + 1) * NU / NM; ++u) micro(u, s_a, s_b, s_a, s_b, a_dst, b_dst, k_fetch);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Prologue: tiles 0 and 1 into the two register slots, tile 0 into LDS buffer 0, tile 2 into the freed slot.  Fetches past the
+    // end of the k range are harmless by construction (safe address, zero fill), so the steady state needs no conditionals.
+    typename SA::Slot sa0, sa1;
+    typename SB::Slot sb0, sb1;
+    sa0.okmask = sa1.okmask = 0u; sb0.okmask = sb1.okmask = 0u;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fetch_piece(sa0, sb0, p, kb);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fetch_piece(sa1, sb1, p, kb + BK);
+#pragma unroll
+    for (int u = 0; u < 6 * NP; ++u) micro(u, sa0, sb0, sa0, sb0, As, Bs, kb + 2 * BK);
+    __syncthreads();
+    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
+        mma_tile(0, sa1, sb1, k0 + 3 * BK);
+        __syncthreads();
+        if (k0 + BK >= ke) break;
+        mma_tile(1, sa0, sb0, k0 + 4 * BK);
+        __syncthreads();
+    }
+    if constexpr (EP::ROWSUM_A) {
+        if (by == 0) {                       // every thread's columns are x0 + 4*(tid % Q) .. +3 in all of its slots; the LDS is free (the loop ends with a barrier)
+            constexpr int Q = BX / 4;
+            a0_f4* red = (a0_f4*)a0_x9_lds;
+            red[tid] = rowsum;
+            __syncthreads();
+            if (tid < BX && x0 + tid < X) {
+                const float* rf = (const float*)a0_x9_lds;
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < NTH / Q; ++g) t += rf[4 * (g * Q + (tid >> 2)) + (tid & 3)];
+                EP::store_rowsum(pe, x0 + tid, t, bz);
+            }
+        }
+    }
+
+    // C/D layout of v_mfma_f32_32x32x16_bf16 == that of 32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int z = bz;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int y = y0 + wn * (NT * 32) + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + wm * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (x < X && y < Y) EP::store(pe, x, y, acc[i][j][r], z);
+            }
+        }
+}
+
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+static inline hipError_t a0_igemm_x9_launch(hipStream_t st, const typename OA::Params& pa, const typename OB::Params& pb,
+                                            const typename EP::Params& pe, int X, int Y, int K, int splits) {
+    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT> G;
+    auto kern = a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT>;
+    static bool configured = false;                       // per instantiation: more than 64 KB of dynamic LDS needs the attribute
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    if (splits < 1) splits = 1;
+    const int ktiles = (K + 31) / 32;
+    const int kchunk = ((ktiles + splits - 1) / splits) * 32;
+    const int gx = (X + G::BX - 1) / G::BX, gy = (Y + G::BY - 1) / G::BY;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx * gy * splits)), dim3(WM * WN * 64), G::LDS_BYTES, st, pa, pb, pe, X, Y, K, kchunk, gx, gy);
+    return hipGetLastError();
+}
+
+// operands whose source is fp32 (everything but the u8 frames, which the fused conv1 kernels cover)
+template <class OP> struct a0_x9_ok { static constexpr bool value = sizeof(typename OP::Raw) == sizeof(a0_f4); };
+
+#endif  // __HIPCC__

@@ -1,7 +1,7 @@
 // Nature-CNN encoder + dense layers on gfx950: the HIP backend of net_impl.h plus the exported C entry points.
 // Replaces the ATen -> cuDNN/cuBLAS dispatches behind reference agent0/deepq/model.py:93-101 (ConvEncoder),
 // model.py:112-114 / 144-146 / 203-216 (dense layers of the heads) and their autograd backward (agent.py:153-155).
-#include "igemm.h"
+#include "igemm_x9.h"
 #include "a0_internal.h"
 #include "net_impl.h"
 
@@ -101,6 +101,14 @@ extern "C" int a0_probe_end(double* host_out3) {
     A0_CATCH
 }
 
+static int g_gemm_x9 = (getenv("A0_GEMM") && std::string(getenv("A0_GEMM")) == "fp32") ? 0 : 1;
+static const long long g_x9_big_min = getenv("A0_X9_BIG_MIN") ? atoll(getenv("A0_X9_BIG_MIN")) : 256;     // tuning aid
+extern "C" int a0_gemm_mode(int mode) {
+    const int prev = g_gemm_x9;
+    if (mode >= 0) g_gemm_x9 = mode ? 1 : 0;
+    return prev;
+}
+
 struct a0_hip_backend {
     hipStream_t st;
     int tag = 0;
@@ -108,7 +116,17 @@ struct a0_hip_backend {
     void igemm(const typename OA::Params& pa, const typename OB::Params& pb, const typename EP::Params& pe, int X, int Y, int K, int splits) {
         const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
         if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
-        A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+        // fp32 operands: the split-operand kernel on the bf16 matrix pipe (igemm_x9.h); A0_GEMM=fp32 keeps the fmaf-chain kernel
+        const bool x9 = g_gemm_x9 != 0;
+        if constexpr (a0_x9_ok<OA>::value && a0_x9_ok<OB>::value) {
+            // large problems: 128 x 128 tiles on eight waves (two per SIMD: the splits of one wave issue in the shadow of the other's MFMAs)
+            const long long big = (long long)((X + 127) / 128) * ((Y + 127) / 128) * (splits < 1 ? 1 : splits);
+            if (x9 && Y >= 128 && big >= g_x9_big_min) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
+            else if (x9) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+            else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+        } else {
+            A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+        }
         if (probe) {
             A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
             g_probe.used += 2;

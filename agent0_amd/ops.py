@@ -430,6 +430,10 @@ class HipOps:
         check(self.lib.a0_probe_end(C.addressof(out)), "a0_probe_end")
         return {"kernel": self._probe_name, "launches": int(out[0]), "ms": float(out[1]), "flop": float(out[2])}
 
+    def gemm_mode(self, mode: int = -1) -> int:
+        """1 = split-operand bf16 MFMA GEMMs (default), 0 = fp32 MFMA fmaf chain; returns the previous mode (mode < 0: query only)."""
+        return int(self.lib.a0_gemm_mode(int(mode)))
+
     def device_info(self):
         cu = C.c_int()
         mem = C.c_longlong()

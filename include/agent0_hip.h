@@ -107,6 +107,12 @@ int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, in
 int a0_probe_begin(int tag, int max_launches);
 int a0_probe_end(double* host_out3);
 
+/* Matrix pipe used by every fp32-operand GEMM above (dense layers, conv2/conv3 weight gradients, unfused conv layers):
+ * 1 (default) = bf16 MFMA with both operands split exactly into three bf16 terms, nine products, fp32 accumulation (igemm_x9.h);
+ * 0 = fp32 MFMA fmaf chain (igemm.h).  Same results up to the association order of the fp32 additions.  Returns the previous mode;
+ * mode < 0 only queries.  Process-wide, not a per-stream setting: change it between launches, never during graph capture. */
+int a0_gemm_mode(int mode);
+
 /* ---------------------------------------------------------------- heads and losses */
 /* dueling combine (model.py:127-130,168-172,228-231): raw [R][ld] = [A*T advantages | T values | pad] -> q [R][A][T] */
 int a0_dueling_fwd(const float* raw, int ld, float* q, int R, int A, int T, int dueling, void* stream);

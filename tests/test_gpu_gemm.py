@@ -1,0 +1,114 @@
+"""GPU (MI355X): the dense GEMM entry points (a0_dense_fwd / _dgrad / _wgrad: model.py:112-114,144-146 and their autograd backward)
+on both matrix pipes — the split-operand bf16 kernel (igemm_x9.h, default) and the fp32 fmaf-chain kernel (igemm.h) — against an
+fp64 evaluation, at ragged shapes (rows / columns / reduction lengths that are not multiples of any tile; the ABI asks for N, K and ldx in multiples of 4).
+
+Tolerance: both kernels accumulate exact products in fp32, so either one differs from fp64 by the fp32 accumulation error only:
+a few 1e-7 of sum_k |a||b|.  The assert is 2e-6 of that scale, and the two kernels must agree with each other to the same bound."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from agent0_amd.ops import HipOps
+    ops = HipOps()
+    prev = ops.gemm_mode()
+    yield ops
+    ops.gemm_mode(prev)
+
+
+def D(hip, x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
+
+
+def _scale_close(got, want64, scale64, what, tol=2e-6):
+    err = np.abs(got.astype(np.float64) - want64) / np.maximum(scale64, 1e-30)
+    assert float(err.max()) < tol, f"{what}: {float(err.max()):.3e} of the accumulated magnitude"
+
+
+SHAPES = [(1, 4, 512), (7, 36, 100), (256, 512, 3136), (300, 40, 64), (512, 32, 512), (513, 132, 96), (64, 512, 36), (2048, 64, 3136)]
+
+
+@pytest.mark.parametrize("R,N,K", SHAPES)
+def test_dense_fwd_both_pipes(hip, R, N, K):
+    g = recipe.gen(R * 31 + N * 7 + K)
+    X = g.standard_normal((R, K)).astype(np.float32)
+    W = (g.standard_normal((N, K)) * 0.05).astype(np.float32)
+    b = g.standard_normal(N).astype(np.float32)
+    want = X.astype(np.float64) @ W.astype(np.float64).T + b
+    scale = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)
+    outs = []
+    for mode in (1, 0):
+        hip.gemm_mode(mode)
+        Y = hip.empty(R * N)
+        need = hip.dense_fwd_scratch(R, N, K)
+        scratch = hip.empty(max(need, 1))
+        for relu in (0, 1):
+            hip.dense_fwd(D(hip, X), K, D(hip, W), D(hip, b), Y, R, N, K, relu, scratch)
+            got = Y.cpu().numpy().reshape(R, N)
+            _scale_close(got, np.maximum(want, 0) if relu else want, scale, f"dense_fwd mode={mode} relu={relu} {R}x{N}x{K}")
+        outs.append(got)
+    _scale_close(outs[0], outs[1].astype(np.float64), scale, "split-operand vs fp32-chain kernel")
+
+
+@pytest.mark.parametrize("R,N,K", SHAPES)
+def test_dense_dgrad_both_pipes(hip, R, N, K):
+    g = recipe.gen(R * 13 + N * 5 + K + 1)
+    dY = g.standard_normal((R, N)).astype(np.float32)
+    W = (g.standard_normal((N, K)) * 0.05).astype(np.float32)
+    act = g.standard_normal((R, K)).astype(np.float32)
+    want = dY.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(dY).astype(np.float64) @ np.abs(W).astype(np.float64)
+    for mode in (1, 0):
+        hip.gemm_mode(mode)
+        dX = hip.empty(R * K)
+        hip.dense_dgrad(D(hip, dY), D(hip, W), D(hip, act), dX, R, N, K)
+        _scale_close(dX.cpu().numpy().reshape(R, K), want * (act > 0), scale, f"dense_dgrad masked mode={mode}")
+        hip.dense_dgrad(D(hip, dY), D(hip, W), None, dX, R, N, K)
+        _scale_close(dX.cpu().numpy().reshape(R, K), want, scale, f"dense_dgrad mode={mode}")
+
+
+@pytest.mark.parametrize("R,N,K", SHAPES)
+def test_dense_wgrad_both_pipes(hip, R, N, K):
+    """grad block = [dW (N x K) | db (N)]; db is the by-product row sum of the staged dY^T tiles."""
+    g = recipe.gen(R * 3 + N * 11 + K + 2)
+    dY = g.standard_normal((R, N)).astype(np.float32)
+    X = g.standard_normal((R, K)).astype(np.float32)
+    want_w = dY.astype(np.float64).T @ X.astype(np.float64)
+    scale_w = np.abs(dY).astype(np.float64).T @ np.abs(X).astype(np.float64)
+    want_b = dY.astype(np.float64).sum(0)
+    scale_b = np.abs(dY).astype(np.float64).sum(0)
+    for mode in (1, 0):
+        hip.gemm_mode(mode)
+        grad = hip.empty(N * K + N)
+        slabs = hip.empty(max(hip.dense_wgrad_scratch(R, N, K), 1))
+        hip.dense_wgrad(D(hip, dY), D(hip, X), K, grad, R, N, K, slabs)
+        got = grad.cpu().numpy()
+        _scale_close(got[: N * K].reshape(N, K), want_w, scale_w, f"dense_wgrad dW mode={mode}")
+        _scale_close(got[N * K:], want_b, scale_b, f"dense_wgrad db mode={mode}")
+
+
+def test_split_is_exact_for_extreme_operands(hip):
+    """Operands spanning 30 binades, exact powers of two, negative zero and denormal-adjacent values: the three bf16 terms
+    reproduce every fp32 operand exactly, so a one-term-per-row product (K = 1 live element) returns the exact fp32 product."""
+    R, N, K = 64, 64, 32
+    g = recipe.gen(99)
+    x = (g.standard_normal(R) * np.exp2(g.integers(-15, 15, R))).astype(np.float32)
+    w = (g.standard_normal(N) * np.exp2(g.integers(-15, 15, N))).astype(np.float32)
+    x[:4] = [1.0, -0.0, 2.0 ** -20, 16777215.0]
+    w[:4] = [1.0, 3.0, -(2.0 ** 10), 1.0 + 2.0 ** -23]
+    X = np.zeros((R, K), np.float32); X[:, 5] = x
+    W = np.zeros((N, K), np.float32); W[:, 5] = w
+    hip.gemm_mode(1)
+    Y = hip.empty(R * N)
+    scratch = hip.empty(max(hip.dense_fwd_scratch(R, N, K), 1))
+    hip.dense_fwd(D(hip, X), K, D(hip, W), hip.zeros(N), Y, R, N, K, 0, scratch)
+    got = Y.cpu().numpy().reshape(R, N)
+    want = (x.astype(np.float64)[:, None] * w.astype(np.float64)[None, :])
+    # nine exact partial products summed in fp32: the result is the fp32 product up to the roundings of 8 small additions
+    assert np.all(np.abs(got - want) <= 4 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64))
