@@ -20,6 +20,7 @@ import torch
 from agent0_amd.common.atari_wrappers import make_atari
 from agent0_amd.common.utils import DeviceRng
 from .config import AlgoEnum, ExpConfig
+from .dist import graph_capture_kwargs
 from .engine import DeviceLearner, Workspace
 from .model import DeepQNet, layout_from_cfg
 from .replay import ReplayDataset, StageRing, TransitionBlock
@@ -183,7 +184,7 @@ class Actor:
             base = self._snapshot()
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **graph_capture_kwargs()):
                 self._rollout(epsilon, T, start, True, False, None, None, ctrl=self.ctrl, eps_ptr=self.eps_dev)
             after = self._snapshot()
             assert after["cur"] == base["cur"]
@@ -300,8 +301,9 @@ class BaseLearner:
 
     def _update(self, frames, slot, row_bytes, act, rew, done, weights, rand):
         """engine.update, replayed from hipGraphs when the caller keeps handing in the same device buffers (the Trainer's hot loop
-        does: the replay's persistent batch tensors).  Two graphs — forward+backward (~35 kernels) and optimizer step — so that the
-        data-parallel gradient all-reduce (RCCL, not captured) sits between two graph launches instead of forcing ~45 eager ones."""
+        does: the replay's persistent batch tensors).  Without data parallelism the whole update is ONE graph.  With a gradient hook
+        it is three — forward + dense backward | encoder backward | optimizer step — around the two RCCL calls (not captured): the
+        dense bucket's all-reduce is issued after the first graph and runs on RCCL's stream while the second graph computes."""
         eng = self.engine
         if not self.use_graph:
             return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
@@ -312,21 +314,27 @@ class BaseLearner:
             if len(self._graphs) >= 4 or self._graph_warm.get(key, 0) < 2:       # two eager runs first: every lazy allocation has happened
                 self._graph_warm[key] = self._graph_warm.get(key, 0) + 1
                 return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
-            g_fb, g_apply = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if hooked else None)
+            mode = graph_capture_kwargs()
+            g_f, g_e, g_apply = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if hooked else None), (torch.cuda.CUDAGraph() if hooked else None)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g_fb):
-                out = eng.forward_backward(frames, slot, row_bytes, act, rew, done, weights, rand)
+            with torch.cuda.graph(g_f, **mode):
+                out = eng.forward_dense(frames, slot, row_bytes, act, rew, done, weights, rand)
                 if not hooked:
+                    eng.backward_encoder()
                     eng.apply()                                   # no exchange step: the whole update is one graph
             if hooked:
-                with torch.cuda.graph(g_apply):
+                with torch.cuda.graph(g_e, **mode):
+                    eng.backward_encoder()
+                with torch.cuda.graph(g_apply, **mode):
                     eng.apply()
-            g = self._graphs[key] = (g_fb, g_apply, out)          # capturing records the launches without running them
+            g = self._graphs[key] = (g_f, g_e, g_apply, out)      # capturing records the launches without running them
         g[0].replay()
         if g[1] is not None:
-            eng.grad_hook(eng.grads, eng.state)
+            eng.exchange_begin()
             g[1].replay()
-        return g[2]
+            eng.exchange_end()
+            g[2].replay()
+        return g[3]
 
     # ------------------------------------------------------------------ reference signature (agent.py:124-169)
     def train(self, data):

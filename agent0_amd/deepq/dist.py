@@ -18,11 +18,17 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def dp_forced() -> bool:
+    """A0_DP_FORCE=1: run the data-parallel code path (process group, gradient buckets, graphs split around the exchange) even with
+    one rank, so that a one-GPU box can exercise RCCL + hipGraph capture + the overlap streams (tests/test_gpu_trainer.py)."""
+    return os.environ.get("A0_DP_FORCE") == "1"
+
+
 def init_process_group(backend: str | None = None):
     import torch.distributed as dist
 
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or dp_forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -34,17 +40,46 @@ def init_process_group(backend: str | None = None):
     return rank, local_rank, world
 
 
+def graph_capture_kwargs() -> dict:
+    """Arguments for ``torch.cuda.graph`` while a process group is alive: RCCL's watchdog thread polls events concurrently, so only the
+    capturing thread's own calls may count as part of (or as errors of) the capture."""
+    import torch.distributed as dist
+
+    return dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
+
+
 class GradAllReduce:
-    """``DeviceLearner.grad_hook``: SUM the flat gradient buffer and MAX the NaN flag across ranks."""
+    """``DeviceLearner.grad_hook``: SUM the flat gradient buffer and MAX the NaN flag across ranks, in two buckets.
+
+    The flat layout puts the convolution blocks first ([0, conv_end), 0.3 MB) and the dense blocks after them ([conv_end, n), 6.4 MB
+    for dqn ... 14 MB for noisy c51).  The backward pass finishes the dense blocks FIRST, so their all-reduce — 95 % of the bytes —
+    is issued asynchronously (RCCL runs it on its own stream over xGMI) and overlaps the encoder backward, which is ~40 % of an
+    update's kernel time; the small convolution bucket and the flag follow, then the optimizer waits for both."""
 
     def __init__(self, n_grad: int, group=None):
         import torch.distributed as dist
 
         self.dist, self.n, self.group = dist, n_grad, group
         self.world = dist.get_world_size(group)
+        self.active = self.world > 1 or dp_forced()
+        self._dense = None
+
+    def start_dense(self, grads: torch.Tensor, conv_end: int):
+        if self.active:
+            self._dense = self.dist.all_reduce(grads[conv_end: self.n], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, grads: torch.Tensor, state: torch.Tensor, conv_end: int):
+        if not self.active:
+            return
+        self.dist.all_reduce(grads[:conv_end], op=self.dist.ReduceOp.SUM, group=self.group)
+        self.dist.all_reduce(state[0:1], op=self.dist.ReduceOp.MAX, group=self.group)
+        if self._dense is not None:
+            self._dense.wait()          # the current stream waits for the dense bucket (no host block on RCCL)
+            self._dense = None
 
     def __call__(self, grads: torch.Tensor, state: torch.Tensor):
-        if self.world == 1:
+        """One-shot form (no overlap): the whole buffer, then the flag."""
+        if not self.active:
             return
         self.dist.all_reduce(grads[: self.n], op=self.dist.ReduceOp.SUM, group=self.group)
         self.dist.all_reduce(state[0:1], op=self.dist.ReduceOp.MAX, group=self.group)

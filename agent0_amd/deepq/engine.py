@@ -283,8 +283,10 @@ class DeviceLearner:
         key = name + ".mu" if (L.noisy and name in ("fc1", "head")) else name
         return self.grads[L.blocks[key].all]
 
-    def _backward_trunk(self, ws: Workspace, frames, slot, stride, B, have_draw: bool = False):
-        """dq (w.r.t. the combined head output) -> every parameter gradient of the online net."""
+    def _backward_dense(self, ws: Workspace, B, have_draw: bool = False):
+        """dq (w.r.t. the combined head output) -> the gradients of every dense block (head, fc1, cosine embedding, NoisyNet sigmas)
+        and d3, the gradient w.r.t. the encoder output.  After this call the flat gradient range [L.conv_end, L.n_adam) is final:
+        the data-parallel exchange of that range (95 % of the parameters) can run while the encoder backward is still computing."""
         L, ops, on = self.L, self.ops, self.online
         R, T = ws.R, (1 if L.quantile else L.T)
         if not have_draw:
@@ -302,6 +304,17 @@ class DeviceLearner:
             ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
             ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
             ops.dense_wgrad(ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines, self.slabs)
+        if L.noisy:
+            for prefix, block, r0, r1, in_f in L.noise_modules:
+                mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
+                nz = on.noise[prefix]
+                ops.noisy_grad_sigma(self.grads[mu.all], self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"])
+
+    def backward_encoder(self):
+        """d3 -> the three convolution blocks' gradients (flat range [0, L.conv_end)); the second half of the backward pass, on the
+        batch of the last forward_dense call."""
+        L, ops, on = self.L, self.ops, self.online
+        ws, frames, slot, stride, B = self._bw
         g1, g2, g3 = self.grads[L.blocks["conv1"].all], self.grads[L.blocks["conv2"].all], self.grads[L.blocks["conv3"].all]
         if on.fused and on.fused_dgrad:
             # both data gradients per observation in one kernel (LDS-resident d2), then the three weight-gradient GEMMs
@@ -309,20 +322,41 @@ class DeviceLearner:
             ops.encoder_wgrad(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
         else:
             ops.encoder_bwd(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
-        if L.noisy:
-            for prefix, block, r0, r1, in_f in L.noise_modules:
-                mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
-                nz = on.noise[prefix]
-                ops.noisy_grad_sigma(self.grads[mu.all], self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"])
 
     # ------------------------------------------------------------------ the update
     def update(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
         """One BaseLearner.train step (agent.py:124-169) on a batch that stays on the device: forward + backward, the data-parallel
         gradient exchange when a ``grad_hook`` is installed, optimizer step."""
-        out = self.forward_backward(frames, slot, sample_stride, act, rew, done, wgt, rand)
-        if self.grad_hook is not None:
-            self.grad_hook(self.grads, self.state)
+        out = self.forward_dense(frames, slot, sample_stride, act, rew, done, wgt, rand)
+        self.exchange_begin()
+        self.backward_encoder()
+        self.exchange_end()
         self.apply()
+        return out
+
+    def exchange_begin(self):
+        """Data parallelism, first bucket: the dense blocks' gradients are final once forward_dense returns; a hook with a
+        ``start_dense`` method (dist.GradAllReduce) reduces them asynchronously while backward_encoder runs."""
+        h = self.grad_hook
+        if h is not None and hasattr(h, "start_dense"):
+            h.start_dense(self.grads, self.L.conv_end)
+
+    def exchange_end(self):
+        """Second bucket (convolution blocks + the NaN flag) and the join with the first; a plain callable hook gets one call with
+        the whole buffer instead."""
+        h = self.grad_hook
+        if h is None:
+            return
+        if hasattr(h, "start_dense"):
+            h.finish(self.grads, self.state, self.L.conv_end)
+        else:
+            h(self.grads, self.state)
+
+    def forward_backward(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
+        """Losses and every parameter gradient (into ``self.grads``); no parameter is modified (FQF's fraction net aside, which the
+        reference also steps separately, agent.py:140-147)."""
+        out = self.forward_dense(frames, slot, sample_stride, act, rew, done, wgt, rand)
+        self.backward_encoder()
         return out
 
     def apply(self):
@@ -332,9 +366,10 @@ class DeviceLearner:
         on.refresh_wt()
         self.sync_target(force=False)
 
-    def forward_backward(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
-        """Losses and every parameter gradient (into ``self.grads``); no parameter is modified (FQF's fraction net aside, which the
-        reference also steps separately, agent.py:140-147).
+    def forward_dense(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
+        """Forward passes, losses and the dense half of the backward pass (every gradient but the convolution blocks', which
+        backward_encoder adds); no parameter is modified (FQF's fraction net aside, which the reference also steps separately,
+        agent.py:140-147).
 
         frames: u8 replay rows (st || st_next); slot: optional int32 row indices; act int32, rew/done/wgt fp32 [B].
         rand (IQN only): [taus_K [B*K], taus_N' [B*N'], taus_N [B*N]] in the reference's draw order.
@@ -440,5 +475,6 @@ class DeviceLearner:
             frac = self.frac_loss
         else:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
-        self._backward_trunk(wo, frames, slot, sample_stride, B, have_draw)
+        self._backward_dense(wo, B, have_draw)
+        self._bw = (wo, frames, slot, sample_stride, B)
         return (self.loss, frac) if frac is not None else self.loss

@@ -85,6 +85,7 @@ class NetLayout:
         add("conv1", 32, self.C * 64, 32)
         add("conv2", 64, 512, 64)
         add("conv3", 64, 576, 64)
+        self.conv_end = off                     # [0, conv_end): convolution blocks; [conv_end, n_adam): dense blocks (the two gradient buckets of dist.GradAllReduce)
         if noisy:
             add("fc1.mu", 512, self.feat, 512)
             add("fc1.sigma", 512, self.feat, 512)

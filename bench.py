@@ -91,9 +91,10 @@ def main():
     args = parse()
     import torch
 
-    from agent0_amd.deepq.dist import GradAllReduce, env_world, init_process_group
+    from agent0_amd.deepq.dist import GradAllReduce, dp_forced, env_world, init_process_group
 
     rank, local_rank, world = init_process_group()
+    dp = world > 1 or dp_forced()            # A0_DP_FORCE=1: the data-parallel path with a one-rank RCCL group (rehearsal on a one-GPU box)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
@@ -112,7 +113,7 @@ def main():
     cfg.seed = cfg.seed + 1000003 * rank
     tr = Trainer(cfg, use_lp=(args.entry == "launch"), rank=rank)
     eng = tr.learner.engine
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         eng.grad_hook = GradAllReduce(eng.L.n_adam)
         eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)
@@ -135,7 +136,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -147,7 +148,7 @@ def main():
         last = tr.run_iteration()
     barrier()
     dt = time.time() - t0
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -185,7 +186,7 @@ def main():
         replay_gbps = rp.B * rp.row_bytes * n_rep / (e0.elapsed_time(e1) * 1e-3) / 1e9
     # ---- the same metric at the reference's update:data ratio for 256 envs (learner_steps = 320 instead of 20)
     ratio320 = None
-    if world == 1 and not args.no_ratio320:
+    if not dp and not args.no_ratio320:
         tr.learner.use_graph = True
         tr.actors[1].use_graph = True
         if args.entry == "launch":
@@ -204,7 +205,7 @@ def main():
                     "updates_per_sec": round(320 / d1, 1)}
     # ---- the other entry point's schedule on the same workload (second trainer, own full replay), so that one bench line carries both
     other = None
-    if world == 1 and not args.no_other_entry:
+    if not dp and not args.no_other_entry:
         import copy
         cfg2 = copy.deepcopy(cfg)
         cfg2.trainer.training_start_steps = 1 << 62
@@ -223,10 +224,10 @@ def main():
         other = {"entry": "agent0.deepq." + ("main" if args.entry == "launch" else "launch"), "value": round(per_iter / d2, 1), "unit": "env-frames/sec",
                  "ms_per_step": round(1e3 * d2, 3), "steps": args.steps}
         del tr2
-    if world > 1:
+    if dp:
         barrier()
     if rank != 0:
-        if world > 1:
+        if dp:
             import torch.distributed as dist
             dist.destroy_process_group()
         return
@@ -240,7 +241,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg.env_id} {cfg.learner.algo.name}, {cfg.actor.num_envs} vectorized envs x {cfg.actor.sample_steps} steps + "
                                f"{cfg.learner.learner_steps} updates of batch {cfg.learner.batch_size} per iteration, {cfg.replay.size}-transition HBM replay "
-                               f"(full), obs 4x84x84 u8, per-rank shards, RCCL grad all-reduce" + ("" if world > 1 else " (inactive at 1 GPU)"),
+                               f"(full), obs 4x84x84 u8, per-rank shards, RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)"),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
                    "replay_size": cfg.replay.size, "parallelism": f"dp{world}", "entry": f"agent0.deepq.{args.entry}"},
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
@@ -272,7 +273,7 @@ def main():
     out["roofline"] = roof
     out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args, cfg)     # rank 0 at N=1 only
     print(json.dumps(out))
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -1,5 +1,7 @@
 """GPU (MI355X): the product's Python classes end to end — Actor rollout parity against the oracle actor on the same
 synthetic env and the same random draws, replay contents, Trainer iterations for every algorithm family."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -292,3 +294,28 @@ def test_graphed_update_with_a_gradient_hook_matches_eager():
         torch.cuda.synchronize()
         res.append((tr.learner.engine.online.flat.clone(), len(calls), tr.learner.update_steps))
     assert res[0][1] == res[1][1] == res[0][2] and torch.equal(res[0][0], res[1][0])
+
+
+def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path):
+    """Rehearsal of the multi-GPU bench on a one-GPU box (A0_DP_FORCE=1): a one-rank RCCL process group is alive, the update is three
+    hipGraphs around two eager RCCL calls (the dense gradient bucket's all-reduce asynchronous, overlapping the encoder backward), the
+    parameter broadcast / barriers / max-over-ranks timing all run.  A one-rank all-reduce is the identity and Adam's eps is
+    1e-2/(1*B) either way, so the losses must equal those of the plain single-graph run bit for bit."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "3", "--replay-size", "40960", "--no-cpu-baseline",
+           "--no-ratio320", "--no-other-entry"]
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, A0_DP_FORCE=force, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+                   A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    plain, dp = outs
+    assert "rehearsal" in dp["config"]["workload"] and "inactive" in plain["config"]["workload"]
+    assert dp["value"] > 0 and plain["value"] > 0
+    assert dp["last_loss"] == plain["last_loss"], (dp["last_loss"], plain["last_loss"])
