@@ -143,9 +143,10 @@ class Trainer:
                 q_loss, f_loss = self.learner.train_batch(rp.frames, b.slot, rp.row_bytes, b.act, b.rew, b.done, b.weights)
                 if cfg.replay.policy == ReplayEnum.prioritize:
                     rp.update_priority(b.idx, q_loss, state=self.learner.engine.state)
-                self._loss_means[i] = q_loss.mean()
+                B = cfg.learner.batch_size
+                self.ops.mean_rows(q_loss, 1, B, self._loss_means[i:i + 1])      # one launch; read back once per update block
                 if f_loss is not None:
-                    self._floss_means[i] = f_loss.mean()
+                    self.ops.mean_rows(f_loss, 1, B, self._floss_means[i:i + 1])
                     has_frac = True
                 n_upd += 1
         if n_upd:

@@ -73,7 +73,7 @@ def test_dense_dgrad_both_pipes(hip, R, N, K):
         _scale_close(dX.cpu().numpy().reshape(R, K), want, scale, f"dense_dgrad mode={mode}")
 
 
-@pytest.mark.parametrize("R,N,K", SHAPES)
+@pytest.mark.parametrize("R,N,K", SHAPES + [(8192, 512, 640)])     # the last one is deep enough for the split kernel's 128 x 128 tiles
 def test_dense_wgrad_both_pipes(hip, R, N, K):
     """grad block = [dW (N x K) | db (N)]; db is the by-product row sum of the staged dY^T tiles."""
     g = recipe.gen(R * 3 + N * 11 + K + 2)
