@@ -738,10 +738,99 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kerne
     }
 }
 
+// ---- the same two data gradients on the bf16 pipe with both operands split exactly into three bf16 terms (see a0_conv_stage_x9):
+// d3 is split when it is loaded, d2 by conv3's epilogue; both live in LDS as three zero-padded 11 x 11 term-plane images (116 KB:
+// one workgroup per CU, eight waves), the flipped / phase-split weights come pre-split from a0_conv_wt_kernel (segments 8, 9).
+// Nine v_mfma_f32_16x16x32_bf16 per 32 k replace eight v_mfma_f32_16x16x4_f32 of twice the pipe time each.
+constexpr int A0_DPIX = 11 * 11;                      // padded image: 11 x 11 pixels, A0_P2X bf16 per pixel (64 channels + 16: conflict-free 16-byte reads)
+constexpr int A0_DTERM = A0_DPIX * A0_P2X;            // elements per term plane
+struct AFD3X {   // 3x3 taps over the d3pad planes; MFMA step = half (32 channels) of tap st >> 1; output 9 wide
+    static constexpr int term = A0_DTERM;
+    const uint16_t* planes;
+    A0_D int row(int m) const { const int oh = m / 9, ow = m - oh * 9; return (oh * 11 + ow) * A0_P2X; }
+    A0_D int step_off(int st) const { const int tap = st >> 1; return ((tap / 3) * 11 + tap % 3) * A0_P2X + 32 * (st & 1); }
+};
+struct AFD2X {   // 2x2 taps over the d2pad planes; output 10 wide
+    static constexpr int term = A0_DTERM;
+    const uint16_t* planes;
+    A0_D int row(int m) const { const int oh = m / 10, ow = m - oh * 10; return (oh * 11 + ow) * A0_P2X; }
+    A0_D int step_off(int st) const { const int cell = st >> 1; return ((cell >> 1) * 11 + (cell & 1)) * A0_P2X + 32 * (st & 1); }
+};
+struct EpiBwd3X {               // d2 = act2 > 0 ? acc : 0 -> global [81][64] and, split into three bf16 terms, the interior of the d2pad planes
+    static constexpr bool PER_ELEM = true;
+    static constexpr bool ROW4 = false;
+    A0_D void emit4(int, int, const a0_acc4&, float) const {}
+    const float* mask; float* dst; uint16_t* planes;
+    A0_D float pre_col(int) const { return 0.f; }
+    A0_D float pre_elem(int m, int n) const { return mask[(unsigned)(m * 64 + n)]; }
+    A0_D void emit(int m, int n, float acc, float pre) const {
+        const float v = pre > 0.f ? acc : 0.f;
+        dst[(unsigned)(m * 64 + n)] = v;
+        const int oh = m / 9, ow = m - oh * 9;
+        const uint32_t h = __float_as_uint(v) >> 16;
+        const float r1 = v - __uint_as_float(h << 16);
+        const uint32_t mi = __float_as_uint(r1) >> 16;
+        const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mi << 16)) >> 16;
+        uint16_t* d = planes + ((oh + 1) * 11 + ow + 1) * A0_P2X + n;
+        d[0] = (uint16_t)h; d[A0_DTERM] = (uint16_t)mi; d[2 * A0_DTERM] = (uint16_t)lo;
+    }
+};
+constexpr int A0_RXD3 = 6, A0_RXD2 = 4;               // 32-k steps of split weights in flight (18 and 8 steps per stage)
+
+__global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_kernel(a0_dgrad_args P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* plA = (uint16_t*)smem;                  // d3, padded by 2: three term planes
+    uint16_t* plB = plA + 3 * A0_DTERM;               // d2, padded by 1 (last row / column unused)
+    for (int i = threadIdx.x; i < 3 * A0_DTERM; i += A0_FUSED_THREADS) ((uint32_t*)smem)[i] = 0u;     // both images; borders stay zero for the whole launch
+    a0_wring9<64, 4, A0_RXD3> ring3;
+    a0_wring9<32, 2, A0_RXD2> ringp[2];
+    ring3.init(P.wd3, 576);
+    ring3.prologue();
+    typedef EpiBwd3X E3;
+    typedef EpiBwd<10, 2> E2;
+    a0_pre<64, 4, 3, E3> pre3;
+    a0_pre<32, 2, 2, E2> prep[2];
+    auto epi3 = [&](int b) { return E3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, plB}; };
+    auto epi2 = [&](int b, int ph, int pw) { return E2{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, nullptr, 0, 0, 20, ph, pw, 32}; };
+    if ((int)blockIdx.x < P.B) pre3.load(epi3(blockIdx.x), 81);
+    __syncthreads();
+    for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+        const a0_f4* src = (const a0_f4*)(P.d3 + (long long)b * 49 * 64);
+        for (int i = threadIdx.x; i < 49 * 16; i += A0_FUSED_THREADS) {
+            const a0_f4 v = src[i];
+            const int pos = i >> 4, c4 = (i & 15) * 4, h = pos / 7, w = pos - h * 7;
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hh[e] = __float_as_uint(x[e]);
+                const float r1 = x[e] - __uint_as_float(hh[e] & 0xffff0000u);
+                mm[e] = __float_as_uint(r1);
+                ll[e] = __float_as_uint(r1 - __uint_as_float(mm[e] & 0xffff0000u));
+            }
+            uint16_t* d = plA + ((h + 2) * 11 + w + 2) * A0_P2X + c4;
+            *(uint2*)(d) = uint2{__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u)};
+            *(uint2*)(d + A0_DTERM) = uint2{__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u)};
+            *(uint2*)(d + 2 * A0_DTERM) = uint2{__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u)};
+        }
+        __syncthreads();
+        const AFD3X f3{plA};
+        const AFD2X f2{plB};
+        const int bn = b + gridDim.x < P.B ? b + gridDim.x : b;       // next observation of this workgroup (its masks are prefetched in the last slot)
+        // each `between` slot requests the NEXT stage's weights and ReLU masks before this stage's epilogue runs
+        a0_conv_stage_x9<64, 4, 3, A0_RXD3>(f3, 81, ring3, epi3(b), pre3, [&] { ringp[0].init(P.wd2, 256); ringp[0].prologue(); prep[0].load(epi2(b, 0, 0), 100); });
+        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[0], epi2(b, 0, 0), prep[0], [&] { ringp[1].init(P.wd2 + 1 * 12288, 256); ringp[1].prologue(); prep[1].load(epi2(b, 0, 1), 100); });
+        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[1], epi2(b, 0, 1), prep[1], [&] { ringp[0].init(P.wd2 + 2 * 12288, 256); ringp[0].prologue(); prep[0].load(epi2(b, 1, 0), 100); });
+        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[0], epi2(b, 1, 0), prep[0], [&] { ringp[1].init(P.wd2 + 3 * 12288, 256); ringp[1].prologue(); prep[1].load(epi2(b, 1, 1), 100); });
+        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[1], epi2(b, 1, 1), prep[1], [&] { ring3.prologue(); pre3.load(epi3(bn), 81); });
+    }
+}
+
 // ---- weight copies for the fused kernels, from the packed [N][K] blocks (layouts: a0_wring1 / a0_wring):
 //   seg 1  conv1: fl(w/255) split exactly into three bf16 terms, 16-byte fragments ((t*32 + n)*4 + q)*3 + s   (12 C KB)
 //   seg 2,3 conv2, conv3 fragment-major fp32;  seg 4,5 the flipped / phase-split matrices of the data gradients (wd3 [576][64], wd2 4 x [256][32])
 //   seg 6,7 conv2, conv3 as three exact bf16 terms (a0_wring9 layout) for the split-operand forward path
+//   seg 8,9 the data-gradient matrices of seg 4,5 as three exact bf16 terms (a0_wring9 layout, N = 64 / 4 x N = 32)
 A0_HD uint32_t a0_bf16_trunc(float f) { return __float_as_uint(f) >> 16; }
 A0_HD float a0_bf16_up(uint32_t h) { return __uint_as_float(h << 16); }
 __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
@@ -769,7 +858,28 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
     {   // seg 6 / 7: exact three-term bf16 split of conv2 / conv3, same fragment layout as seg 1 with 64 output channels
         const int j6 = i - (n2 + n3 + n4 + n5);
         if (j6 >= 0) {
-            if (j6 >= n6 + n7) return;
+            if (j6 >= n6 + n7) {       // seg 8 / 9: the data-gradient matrices (seg 4 / 5) as three exact bf16 terms, a0_wring9 layout
+                const int j8 = j6 - (n6 + n7), n8 = 96 * 576, n9p = 48 * 256;
+                if (j8 >= n8 + 4 * n9p) return;
+                const bool d2 = j8 >= n8;
+                const int phase = d2 ? (j8 - n8) / n9p : 0;
+                const int jj = d2 ? (j8 - n8) - phase * n9p : j8, N = d2 ? 32 : 64;
+                const int pair = jj & 3, f = jj >> 2, s = f % 3, q = (f / 3) & 3, n = (f / 12) % N, t = f / (12 * N);
+                uint32_t out = 0;
+                for (int h = 0; h < 2; ++h) {
+                    const int k = 32 * t + 8 * q + 2 * pair + h, cell = k >> 6, co = k & 63;
+                    float w;
+                    if (!d2) { const int kh = 2 - cell / 3, kw = 2 - cell % 3; w = w3[co * 576 + (kh * 3 + kw) * 64 + n]; }
+                    else { const int kh = (phase >> 1) + 2 * (1 - (cell >> 1)), kw = (phase & 1) + 2 * (1 - (cell & 1)); w = w2[co * 512 + (kh * 4 + kw) * 32 + n]; }
+                    const uint32_t hi = a0_bf16_trunc(w);
+                    const float r1 = w - a0_bf16_up(hi);
+                    const uint32_t mid = a0_bf16_trunc(r1);
+                    const uint32_t lo = a0_bf16_trunc(r1 - a0_bf16_up(mid));
+                    out |= (s == 0 ? hi : s == 1 ? mid : lo) << (16 * h);
+                }
+                *(uint32_t*)dst = out;
+                return;
+            }
             const bool c3 = j6 >= n6;
             const int jj = c3 ? j6 - n6 : j6, K = c3 ? 576 : 512;
             const float* wsrc = c3 ? w3 : w2;
@@ -810,7 +920,9 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
     *dst = v;
 }
 
-extern "C" long long a0_net_conv_wt_floats(int C) { return 48LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256 + 96LL * 512 + 96LL * 576; }
+extern "C" long long a0_net_conv_wt_floats(int C) {
+    return 48LL * C * 64 + 64LL * 512 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256 + 96LL * 512 + 96LL * 576 + 96LL * 576 + 4LL * 48 * 256;
+}
 
 extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream) {
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh: bad argument");
@@ -900,14 +1012,22 @@ extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, 
     P.wd2 = P.wd3 + 64LL * 576;
     P.rpa = 11 * A0_P2; while ((P.rpa - 2 * 9) & 31) ++P.rpa;      // conflict-free A reads: RP = 2 * (output width) (mod 32)
     P.rpb = 11 * A0_P2; while ((P.rpb - 2 * 10) & 31) ++P.rpb;
-    const size_t lds = (size_t)11 * (P.rpa + P.rpb) * 4;
-    static bool configured = false;
-    if (!configured) {
-        A0_HIP_THROW(hipFuncSetAttribute((const void*)a0_encoder_dgrad_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+    static const bool no_x9 = getenv("A0_NO_X9") != nullptr;       // fp32-chain variant (as for the forward kernel)
+    const bool x9 = !no_x9;
+    if (x9) {      // split weights behind the forward path's (segments 8, 9)
+        P.wd3 = P.wd2 + 4LL * 32 * 256 + 96LL * 512 + 96LL * 576;
+        P.wd2 = P.wd3 + 96LL * 576;
+    }
+    const size_t lds = x9 ? (size_t)2 * 3 * A0_DTERM * 2 : (size_t)11 * (P.rpa + P.rpb) * 4;
+    static bool configured[2] = {false, false};
+    const void* fn = x9 ? (const void*)a0_encoder_dgrad_fused_x9_kernel : (const void*)a0_encoder_dgrad_fused_kernel;
+    if (!configured[x9]) {
+        A0_HIP_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[x9] = true;
     }
     const bool probed = a0_probe_start(A0_TAG_ENCODER_DGRAD_FUSED, (hipStream_t)stream);
-    hipLaunchKernelGGL(a0_encoder_dgrad_fused_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    if (x9) hipLaunchKernelGGL(a0_encoder_dgrad_fused_x9_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(a0_encoder_dgrad_fused_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     if (probed) a0_probe_stop((hipStream_t)stream, 2.0 * (81.0 * 64 * 576 + 400.0 * 32 * 256) * B);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
