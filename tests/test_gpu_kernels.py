@@ -237,3 +237,60 @@ def test_fused_sample_gather_equals_separate_kernels(prioritize, sumtree):
         b.ops.replay_gather(b.frames, b.row_bytes, bb.slot, 64, ref, b.size)
         assert torch.equal(ba.slot, bb.slot) and torch.equal(ba.idx, bb.idx) and torch.equal(rows, ref)
         assert torch.equal(ba.act, bb.act) and torch.equal(ba.rew, bb.rew) and torch.equal(ba.done, bb.done) and torch.equal(ba.weights, bb.weights)
+
+
+def test_replay_ring_full_size_round_trip(hip):
+    """BASELINE configs[1] size — 1 M rows of 56 448 B = 56.4 GB, byte offsets far beyond 2^32 — checked through a size-independent
+    property: every row carries the serial number of its transition in its first and last 8 bytes of st and of st_next; after the ring
+    has wrapped, logical index i must return transition (written - size + i), through a0_replay_lookup + a0_replay_gather and through
+    the fused a0_replay_sample_gather (uniform permutation), with act / rew / done following the same slot."""
+    cap, ob, n = 1_000_000, 4 * 84 * 84, 8192
+    frames = torch.empty(cap * 2 * ob, dtype=torch.uint8, device=hip.device)
+    r_act, r_rew, r_done = hip.zeros(cap, dtype=torch.int32), hip.zeros(cap), hip.zeros(cap)
+    obs = torch.zeros(n, ob, dtype=torch.uint8, device=hip.device)
+    nxt = torch.zeros(n, ob, dtype=torch.uint8, device=hip.device)
+    shifts = torch.arange(8, device=hip.device, dtype=torch.int64) * 8
+
+    def tag(t):          # int64 [k] -> uint8 [k][8], little endian
+        return ((t[:, None] >> shifts[None, :]) & 255).to(torch.uint8)
+
+    written = 0
+    total = cap + 5 * n + 123           # wraps, and ends off a block boundary
+    while written < total:
+        k = min(n, total - written)
+        t = torch.arange(written, written + k, device=hip.device, dtype=torch.int64)
+        obs[:k, :8] = tag(t); obs[:k, -8:] = tag(t ^ 0x5555)
+        nxt[:k, :8] = tag(t + (1 << 40)); nxt[:k, -8:] = tag(t ^ 0x3333)
+        c = written % cap
+        k1 = min(k, cap - c)            # a0_replay_insert takes a contiguous slot range: split at the wrap like ReplayDataset.extend
+        for o, kk in ((0, k1), (k1, k - k1)):
+            if kk:
+                hip.replay_insert(frames, cap, ob, (written + o) % cap, kk, obs[o:o + kk].reshape(-1), nxt[o:o + kk].reshape(-1),
+                                  (t[o:o + kk] % 18).to(torch.int32), (t[o:o + kk] % 3 - 1).float(), (t[o:o + kk] % 2).float(), r_act, r_rew, r_done)
+        written += k
+    top, head = cap, written % cap
+    B = 4096
+    g = recipe.gen(77)
+    idx_np = np.concatenate(([0, 1, cap - 1, cap - head - 1, cap - head, cap - head + 1], g.integers(0, cap, B - 6))).astype(np.int64)
+    idx = D(hip, idx_np)
+    want_t = idx + (written - cap)
+
+    def check_rows(rows, act, rew, done, t):
+        rows = rows.view(t.numel(), 2 * ob)
+        def untag(b):
+            return (b.to(torch.int64) << shifts[None, :]).sum(1)
+        assert torch.equal(untag(rows[:, :8]), t) and torch.equal(untag(rows[:, ob - 8:ob]), t ^ 0x5555)
+        assert torch.equal(untag(rows[:, ob:ob + 8]), t + (1 << 40)) and torch.equal(untag(rows[:, 2 * ob - 8:]), t ^ 0x3333)
+        assert torch.equal(act.long(), t % 18) and torch.equal(rew, (t % 3 - 1).float()) and torch.equal(done, (t % 2).float())
+
+    slot, act, rew, done, io = hip.zeros(B, dtype=torch.int32), hip.zeros(B, dtype=torch.int32), hip.zeros(B), hip.zeros(B), hip.zeros(B, dtype=torch.int64)
+    hip.replay_lookup(idx, B, top, head, cap, slot, r_act, r_rew, r_done, None, act, rew, done, None, io)
+    assert torch.equal(slot.long(), (head + idx) % cap) and torch.equal(io, idx)
+    out = torch.empty(B * 2 * ob, dtype=torch.uint8, device=hip.device)
+    hip.replay_gather(frames, 2 * ob, slot, B, out, cap)
+    check_rows(out, act, rew, done, want_t)
+    # fused sampler: one epoch position of the Feistel permutation of range(top); indices must be a set of distinct valid positions
+    hip.replay_sample_gather(0, 3 * B, top, 0xC0FFEE, None, 1, None, top, head, cap, frames, 2 * ob, r_act, r_rew, r_done, None, B, out, io, slot, act, rew, done, None)
+    assert int(io.min()) >= 0 and int(io.max()) < top and io.unique().numel() == B
+    assert torch.equal(slot.long(), (head + io) % cap)
+    check_rows(out, act, rew, done, io + (written - cap))
