@@ -42,6 +42,29 @@ __global__ void a0_reduce_bias_act_kernel(const float* __restrict__ slabs, long 
     }
 }
 
+// Up to four slab reductions in one launch: workgroup g serves 32 outputs of the segment its index falls into.
+struct a0_reduce_multi_args { a0_reduce_seg seg[4]; int first_block[5]; };
+__global__ __launch_bounds__(256) void a0_reduce_segments_kernel(a0_reduce_multi_args A) {
+    __shared__ float red[8][33];
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) si += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
+    const a0_reduce_seg S = A.seg[si];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long i = (long long)((int)blockIdx.x - A.first_block[si]) * 32 + c;
+    float s = 0.f;
+    if (i < S.count)
+        for (int z = g; z < S.nslab; z += 8) s += S.slabs[(long long)z * S.slab_stride + i];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < S.count) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][c];
+        S.out[i] = t;
+    }
+}
+
 static inline int a0_grid_for(long long count, int block = 256, int cap = 2048) {
     long long g = (count + block - 1) / block;
     if (g > cap) g = cap;
@@ -154,6 +177,20 @@ struct a0_hip_backend {
     }
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
         hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);
+        A0_HIP_THROW(hipGetLastError());
+    }
+    void reduce_segments(const a0_reduce_seg* segs, int nseg) {
+        if (nseg < 1 || nseg > 4) throw std::runtime_error("reduce_segments: 1..4 segments");
+        a0_reduce_multi_args A;
+        int blocks = 0;
+        for (int k = 0; k < 4; ++k) {
+            A.first_block[k] = blocks;
+            if (k < nseg) { A.seg[k] = segs[k]; blocks += (int)((segs[k].count + 31) / 32); }
+            else A.seg[k] = a0_reduce_seg{nullptr, 0, 0, nullptr, 0};
+        }
+        A.first_block[4] = blocks;
+        for (int k = nseg; k < 4; ++k) A.first_block[k] = 0x7fffffff;        // unused segments are never selected
+        hipLaunchKernelGGL(a0_reduce_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A);
         A0_HIP_THROW(hipGetLastError());
     }
     void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu) {

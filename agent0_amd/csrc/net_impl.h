@@ -7,6 +7,7 @@
 //   template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
 //   void igemm(const OA::Params&, const OB::Params&, const EP::Params&, int X, int Y, int K, int splits);
 //   void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count);
+//   void reduce_segments(const a0_reduce_seg* segs, int nseg);     several reduce_slabs in ONE launch
 //   void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu);
 #pragma once
 #include <cstdlib>
@@ -17,6 +18,9 @@
 // layer tags: set on the backend before each GEMM so a profiler probe can single out one kernel (bench.py roofline)
 enum { A0_TAG_NONE = 0, A0_TAG_CONV1_FWD = 1, A0_TAG_CONV2_FWD = 2, A0_TAG_CONV3_FWD = 3, A0_TAG_DENSE_FWD = 4, A0_TAG_DENSE_DGRAD = 5,
        A0_TAG_DENSE_WGRAD = 6, A0_TAG_CONV3_WGRAD = 7, A0_TAG_CONV3_DGRAD = 8, A0_TAG_CONV2_WGRAD = 9, A0_TAG_CONV2_DGRAD = 10, A0_TAG_CONV1_WGRAD = 11 };
+
+// one slab reduction: out[i] = sum_z slabs[z * slab_stride + i], i < count
+struct a0_reduce_seg { const float* slabs; long long slab_stride; int nslab; float* out; long long count; };
 
 // weight-gradient epilogue: slab z of the layer's [W | b] block.  ROWSUM_A: the GEMM's A operand is dY^T, so the sums of its rows
 // over the k range of the split ARE the bias gradient; the kernel produces them as a by-product (from the LDS tiles it stages
@@ -90,18 +94,29 @@ static inline long long a0_dense_wgrad_scratch_impl(int R, int N, int K) {
     return s > 1 ? (long long)s * ((long long)N * K + N) : 0;
 }
 
-static inline long long a0_encoder_bwd_scratch_impl(const a0_net_core& n, int B) {
-    long long need = 0;
+// Slab regions of the three convolution weight gradients inside the caller's scratch buffer.  They are disjoint, so that the three
+// GEMMs can leave their partial sums behind and ONE reduction launch finishes all of them (a0_encoder_bwd_impl).  conv1 is sized for
+// the per-observation kernel (one slab per workgroup, at most 256) or the GEMM's splits, whichever is larger.
+struct a0_enc_slab_plan { long long off[3], total; int splits[3]; };     // index 0 = conv1, 1 = conv2, 2 = conv3
+
+static inline a0_enc_slab_plan a0_encoder_slab_plan(const a0_net_core& n, int B) {
+    a0_enc_slab_plan p;
     const int M[3] = {B * n.H1 * n.W1, B * n.H2 * n.W2, B * n.H3 * n.W3};
     const int N[3] = {32, 64, 64};
     const int K[3] = {n.K1, n.K2, n.K3};
-    for (int l = 0; l < 3; ++l) {
-        int s = a0_wgrad_splits(1, (K[l] + 127) / 128, M[l]);
-        long long v = (long long)s * ((long long)N[l] * K[l] + N[l]);
-        if (s > 1 && v > need) need = v;
+    long long off = 0;
+    for (int l = 2; l >= 0; --l) {
+        p.splits[l] = a0_wgrad_splits(1, (K[l] + 127) / 128, M[l]);
+        int slabs = p.splits[l] > 1 ? p.splits[l] : 0;
+        if (l == 0) { const int fused = B < 256 ? B : 256; if (fused > slabs) slabs = fused; }
+        p.off[l] = off;
+        off += (long long)slabs * ((long long)N[l] * K[l] + N[l]);
     }
-    return need;
+    p.total = off;
+    return p;
 }
+
+static inline long long a0_encoder_bwd_scratch_impl(const a0_net_core& n, int B) { return a0_encoder_slab_plan(n, B).total; }
 
 // ------------------------------------------------------------------------------------------------ encoder forward
 template <class BK>
@@ -207,15 +222,19 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
                                 float* g1, float* g2, float* g3, float* slabs, bool with_dgrad = true) {
     // with_dgrad == false: d2 / d1 already hold the data gradients (a0_net_encoder_dgrad_fused); only the weight gradients run
     const int M3 = B * n.H3 * n.W3, M2 = B * n.H2 * n.W2, M1 = B * n.H1 * n.W1;
+    const a0_enc_slab_plan plan = a0_encoder_slab_plan(n, B);
+    a0_reduce_seg segs[3];
+    int nseg = 0;
     {   // conv3 weight gradient: dW3[64][K3] = sum_m d3[m][:]^T im2col(act2)[m][:]
-        const int splits = a0_wgrad_splits(1, (n.K3 + 127) / 128, M3);
+        const int splits = plan.splits[2];
         const long long wc = 64LL * n.K3;
+        float* sl = slabs + plan.off[2];
         a0_mat_src a{d3, 64};
         a0_act_src b = a0_act(act2, n.H2, n.W2, 64, n.H3, n.W3, 1, 0, n.ktab3);
-        EpiWgradSlab::Params e{splits > 1 ? slabs : g3, splits > 1 ? wc + 64 : 0, n.K3, wc};
+        EpiWgradSlab::Params e{splits > 1 ? sl : g3, splits > 1 ? wc + 64 : 0, n.K3, wc};
         bk.tag = A0_TAG_CONV3_WGRAD;
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
-        a0_finish_wgrad(bk, 64, wc, g3, slabs, splits);
+        if (splits > 1) segs[nseg++] = a0_reduce_seg{sl, wc + 64, splits, g3, wc + 64};
     }
     if (with_dgrad) {   // conv3 data gradient -> d2 (masked by act2 > 0): gather form, 3x3 taps over d3 with pad 2
         a0_act_src a = a0_act(d3, n.H3, n.W3, 64, n.H2, n.W2, 1, 2, n.ktab_d3);
@@ -225,14 +244,15 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 2>(a, b, e, M2, 64, 9 * 64, 1);
     }
     {   // conv2 weight gradient
-        const int splits = a0_wgrad_splits(1, (n.K2 + 127) / 128, M2);
+        const int splits = plan.splits[1];
         const long long wc = 64LL * n.K2;
+        float* sl = slabs + plan.off[1];
         a0_mat_src a{d2, 64};
         a0_act_src b = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
-        EpiWgradSlab::Params e{splits > 1 ? slabs : g2, splits > 1 ? wc + 64 : 0, n.K2, wc};
+        EpiWgradSlab::Params e{splits > 1 ? sl : g2, splits > 1 ? wc + 64 : 0, n.K2, wc};
         bk.tag = A0_TAG_CONV2_WGRAD;
         bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K2, M2, splits);
-        a0_finish_wgrad(bk, 64, wc, g2, slabs, splits);
+        if (splits > 1) segs[nseg++] = a0_reduce_seg{sl, wc + 64, splits, g2, wc + 64};
     }
     // conv2 data gradient -> d1 (masked by act1 > 0): four stride phases, 2x2 taps over d2 with pad 1
     for (int ph = 0; ph < 2 && with_dgrad; ++ph)
@@ -247,18 +267,20 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         }
     {   // conv1 weight gradient (the input is data: no data gradient)
         const long long wc = 32LL * n.K1;
+        float* sl = slabs + plan.off[0];
         bk.tag = A0_TAG_CONV1_WGRAD;
-        const int fused_slabs = bk.conv1_wgrad_fused(n, f, B, d1, slabs);       // 84x84x4: per-observation kernel on the bf16 pipe
+        const int fused_slabs = bk.conv1_wgrad_fused(n, f, B, d1, sl);       // 84x84x4: per-observation kernel on the bf16 pipe
         if (fused_slabs > 0) {
-            bk.reduce_slabs(slabs, wc + 32, fused_slabs, g1, wc + 32);
-            return;
+            segs[nseg++] = a0_reduce_seg{sl, wc + 32, fused_slabs, g1, wc + 32};
+        } else {
+            const int splits = plan.splits[0];
+            a0_mat_src a{d1, 32};
+            a0_frames_src b = a0_frames(n, f);
+            EpiWgradSlab::Params e{splits > 1 ? sl : g1, splits > 1 ? wc + 32 : 0, n.K1, wc};
+            bk.template igemm<OpMatXC, OpFramesXC, EpiWgradSlab, 1, 4, 1, 1>(a, b, e, 32, n.K1, M1, splits);
+            if (splits > 1) segs[nseg++] = a0_reduce_seg{sl, wc + 32, splits, g1, wc + 32};
         }
-        const int splits = a0_wgrad_splits(1, (n.K1 + 127) / 128, M1);
-        a0_mat_src a{d1, 32};
-        a0_frames_src b = a0_frames(n, f);
-        EpiWgradSlab::Params e{splits > 1 ? slabs : g1, splits > 1 ? wc + 32 : 0, n.K1, wc};
-        bk.tag = A0_TAG_CONV1_WGRAD;
-        bk.template igemm<OpMatXC, OpFramesXC, EpiWgradSlab, 1, 4, 1, 1>(a, b, e, 32, n.K1, M1, splits);
-        a0_finish_wgrad(bk, 32, wc, g1, slabs, splits);
     }
+    // the three layers' slab reductions (weights and the bias row sums behind them) in one launch
+    if (nseg > 0) bk.reduce_segments(segs, nseg);
 }

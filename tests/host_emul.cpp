@@ -78,6 +78,9 @@ struct host_backend {
             out[i] = s;
         }
     }
+    void reduce_segments(const a0_reduce_seg* segs, int nseg) {
+        for (int k = 0; k < nseg; ++k) reduce_slabs(segs[k].slabs, segs[k].slab_stride, segs[k].nslab, segs[k].out, segs[k].count);
+    }
     void reduce_bias_act(const float* slabs, long long slab_stride, int nslab, const float* bias, float* out, int rows, int N, int relu) {
         for (long long i = 0; i < (long long)rows * N; ++i) {
             float s = 0.f;
