@@ -15,7 +15,7 @@ for name in ("fetch", "write"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            key = "enc" if "a0_encoder_fused_kernel" in k else "dgrad" if "a0_encoder_dgrad_fused" in k else "insert" if "replay_insert" in k else None
+            key = "enc" if "a0_encoder_fused_kernel" in k else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else None
             if key: acc[(key, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for (key, gs), d in sorted(acc.items()):
             for c, v in d.items():
