@@ -833,7 +833,10 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
 //   seg 8,9 the data-gradient matrices of seg 4,5 as three exact bf16 terms (a0_wring9 layout, N = 64 / 4 x N = 32)
 A0_HD uint32_t a0_bf16_trunc(float f) { return __float_as_uint(f) >> 16; }
 A0_HD float a0_bf16_up(uint32_t h) { return __uint_as_float(h << 16); }
-__global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1) {
+// wt2 / state: optional second destination (the target network's copies), written only when state[4] ("sync now", optim.hip) is set.
+__global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1,
+                                  float* __restrict__ wt2, const int* __restrict__ state) {
+    const bool mirror = wt2 != nullptr && state[4] != 0;
     const int n1 = 48 * K1, n2 = 64 * 512, n3 = 64 * 576, n4 = 64 * 576, n5 = 4 * 32 * 256;      // n1: 32 channels x K1 x 3 terms x 2 bytes, in floats
     const int n6 = 96 * 512, n7 = 96 * 576;                                                       // conv2 / conv3 as three bf16 terms: 64 x K x 3 x 2 bytes
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -851,7 +854,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
             const uint32_t lo = a0_bf16_trunc(r2);
             out |= (s == 0 ? hi : s == 1 ? mid : lo) << (16 * h);
         }
-        *(uint32_t*)dst = out;
+        { *(uint32_t*)dst = out; if (mirror) *(uint32_t*)(wt2 + (dst - wt)) = out; }
         return;
     }
     i -= n1;
@@ -877,7 +880,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
                     const uint32_t lo = a0_bf16_trunc(r1 - a0_bf16_up(mid));
                     out |= (s == 0 ? hi : s == 1 ? mid : lo) << (16 * h);
                 }
-                *(uint32_t*)dst = out;
+                { *(uint32_t*)dst = out; if (mirror) *(uint32_t*)(wt2 + (dst - wt)) = out; }
                 return;
             }
             const bool c3 = j6 >= n6;
@@ -893,7 +896,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
                 const uint32_t lo = a0_bf16_trunc(r1 - a0_bf16_up(mid));
                 out |= (s == 0 ? hi : s == 1 ? mid : lo) << (16 * h);
             }
-            *(uint32_t*)dst = out;
+            { *(uint32_t*)dst = out; if (mirror) *(uint32_t*)(wt2 + (dst - wt)) = out; }
             return;
         }
     }
@@ -918,6 +921,7 @@ __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __r
         v = w2[co * 512 + (kh * 4 + kw) * 32 + n];
     }
     *dst = v;
+    if (mirror) wt2[dst - wt] = v;
 }
 
 extern "C" long long a0_net_conv_wt_floats(int C) {
@@ -927,8 +931,18 @@ extern "C" long long a0_net_conv_wt_floats(int C) {
 extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream) {
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh: bad argument");
     const long long n = a0_net_conv_wt_floats(C);
-    hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->w1, w->w2, w->w3, wt, C * 64);
+    hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->w1, w->w2, w->w3, wt, C * 64, (float*)nullptr,
+                       (const int*)nullptr);
     return a0_fail_hip((int)hipGetLastError(), "a0_net_conv_wt_refresh");
+}
+
+// The online network's copies after an optimizer step, mirrored into the target network's when that step triggered a target sync
+// (state from a0_adam_step_sync): one launch per update instead of a refresh per network.
+extern "C" int a0_net_conv_wt_refresh_sync(const a0_encoder_weights* w, int C, float* wt, float* wt_target, const int* state, void* stream) {
+    if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || !wt_target || !state || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh_sync: bad argument");
+    const long long n = a0_net_conv_wt_floats(C);
+    hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->w1, w->w2, w->w3, wt, C * 64, wt_target, state);
+    return a0_fail_hip((int)hipGetLastError(), "a0_net_conv_wt_refresh_sync");
 }
 
 static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_bytes) {

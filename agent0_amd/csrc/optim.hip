@@ -57,6 +57,48 @@ extern "C" int a0_adam_step(float* params, const float* grads, float* exp_avg, f
     return a0_fail_hip((int)hipGetLastError(), "a0_adam_step");
 }
 
+// Adam with the target copy folded in: when the prep kernel decided "sync now" (update_steps % target_update_freq == 0, agent.py:160-161)
+// every element's NEW value is also written to the target buffer, over [0, n_total) — n_total > n covers blocks Adam does not own (FQF's
+// fraction net).  A skipped (NaN) step leaves the parameters alone but still syncs, like the reference.  == a0_adam_step + a0_target_sync.
+__global__ void a0_adam_sync_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                    long long n, const int* __restrict__ state, const float* __restrict__ scal,
+                                    float w1, float b2, float w2, float eps, float* __restrict__ target, long long n_total) {
+    const bool skip = state[3] != 0, sync = state[4] != 0;
+    if (skip && !sync) return;
+    const float step_size = scal[0], bc2_sqrt = scal[1];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long end = sync ? n_total : n;
+    for (; i < end; i += stride) {
+        float pi = p[i];
+        if (i < n && !skip) {
+            const float gi = g[i];
+            float mi = m[i], vi = v[i];
+            mi = mi + (gi - mi) * w1;
+            vi = vi * b2 + (w2 * gi) * gi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pi = pi - step_size * (mi / denom);
+            p[i] = pi;
+            m[i] = mi;
+            v[i] = vi;
+        }
+        if (sync) target[i] = pi;
+    }
+}
+
+extern "C" int a0_adam_step_sync(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars,
+                                 double lr, double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !state || !scalars || !target || n < 1 || n_total < n)
+        return a0_fail(A0_EINVAL, "a0_adam_step_sync: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq);
+    long long blocks = (n_total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_adam_sync_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total);
+    return a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync");
+}
+
 // RMSprop(lr, alpha, eps), no momentum, not centered (torch.optim.RMSprop defaults otherwise) — runs unconditionally,
 // like the reference's fqf_optimizer.step() which sits before the NaN guard (agent.py:139-148).
 __global__ void a0_rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long long n,

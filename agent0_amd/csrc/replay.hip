@@ -393,6 +393,44 @@ __global__ __launch_bounds__(256) void a0_sample_gather_kernel(int mode, unsigne
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) d[j] = s[j];
 }
 
+// Uniform sampling without the row copy (the learner reads ring rows through the slot index): permutation element start + b of the
+// epoch -> logical index -> ring slot + metadata, one thread per sample.  == a0_perm_batch + a0_replay_lookup in one launch.
+__global__ void a0_sample_slots_kernel(unsigned long long start, unsigned long long n_perm, uint32_t seed, long long top, long long head, long long cap,
+                                       const int* __restrict__ r_act, const float* __restrict__ r_rew, const float* __restrict__ r_done,
+                                       const float* __restrict__ priority, int B, long long* __restrict__ idx_out, int* __restrict__ slot_out,
+                                       int* __restrict__ act, float* __restrict__ rew, float* __restrict__ done, float* __restrict__ prio) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t h = 1;
+    while ((1ull << (2 * h)) < n_perm) ++h;
+    const uint32_t mask = (uint32_t)((1ull << h) - 1);
+    unsigned long long x = start + (unsigned long long)b;
+    do {
+        uint32_t l = (uint32_t)(x >> h) & mask, r = (uint32_t)x & mask;
+        for (uint32_t round = 0; round < 4; ++round) {
+            const uint32_t f = a0_mix32(r ^ (seed + 0x9E3779B9u * (round + 1))) & mask;
+            const uint32_t nl = r, nr = l ^ f;
+            l = nl; r = nr;
+        }
+        x = ((unsigned long long)l << h) | r;
+    } while (x >= n_perm);
+    const long long li = (long long)(x % (unsigned long long)top);
+    const long long s = (head + li) % cap;
+    idx_out[b] = li; slot_out[b] = (int)s; act[b] = r_act[s]; rew[b] = r_rew[s]; done[b] = r_done[s];
+    if (prio) prio[b] = priority ? priority[li] : 1.f;
+}
+
+extern "C" int a0_replay_sample_slots(unsigned long long start, unsigned long long n_perm, unsigned int seed, long long top, long long head, long long cap,
+                                      const int* r_act, const float* r_rew, const float* r_done, const float* priority, int B, long long* idx_out, int* slot_out,
+                                      int* act, float* rew, float* done, float* prio, void* stream) {
+    if (!r_act || !r_rew || !r_done || !idx_out || !slot_out || !act || !rew || !done || B < 1 || top < 1 || cap < top || cap > 2147483647LL || n_perm < 1 ||
+        start + (unsigned long long)B > n_perm)
+        return a0_fail(A0_EINVAL, "a0_replay_sample_slots: bad argument");
+    hipLaunchKernelGGL(a0_sample_slots_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, start, n_perm, seed, top, head, cap, r_act, r_rew, r_done, priority,
+                       B, idx_out, slot_out, act, rew, done, prio);
+    return a0_fail_hip((int)hipGetLastError(), "a0_replay_sample_slots");
+}
+
 extern "C" int a0_replay_sample_gather(int mode, unsigned long long start, unsigned long long n_perm, unsigned int seed, const float* tree, long long cap2,
                                        const float* xi, long long top, long long head, long long cap, const uint8_t* frames, int row_bytes, const int* r_act,
                                        const float* r_rew, const float* r_done, const float* priority, int B, uint8_t* out, long long* idx_out, int* slot_out,

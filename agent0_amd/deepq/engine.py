@@ -361,7 +361,14 @@ class DeviceLearner:
 
     def apply(self):
         """Adam on the flat buffer (NaN-skip and step counter on the device), refresh of the fused kernels' weight copies, target sync."""
-        L, ops, on = self.L, self.ops, self.online
+        L, ops, on, tg = self.L, self.ops, self.online, self.target
+        if hasattr(ops, "adam_step_sync"):
+            # three launches: Adam's scalars; Adam with the target copy folded in; the online conv copies, mirrored to the target's on a sync
+            ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
+                               self.target_update_freq, tg.flat, L.n_params_padded)
+            if on.fused:
+                ops.conv_wt_refresh_sync(on.encoder_weights(), L.C, on.wt, tg.wt, self.state)
+            return
         ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
         on.refresh_wt()
         self.sync_target(force=False)

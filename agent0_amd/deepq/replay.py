@@ -193,8 +193,9 @@ class ReplayDataset:
             self.ops.priority_update(self.priority, ids, pr, B, float(rc.eps), float(rc.alpha), self._pstate, state)
 
     # ------------------------------------------------------------------ sampling
-    def _next_uniform(self, B: int):
-        """DataLoader(shuffle=True) + DataPrefetcher semantics (trainer.py:63-72, utils.py:31-56)."""
+    def _next_uniform(self, B: int, draw: bool = True):
+        """DataLoader(shuffle=True) + DataPrefetcher semantics (trainer.py:63-72, utils.py:31-56).  Returns (start, n_perm, seed) of the
+        batch; ``draw`` also materialises the permutation elements in ``_idx``."""
         ep = self._epoch
         if ep is None or ep["pos"] + 1 >= ep["nb"]:
             top = self.top
@@ -204,7 +205,9 @@ class ReplayDataset:
             self._epoch = ep
         start = ep["pos"] * B
         ep["pos"] += 1
-        self.ops.perm_batch(start, B, ep["top"], ep["seed"], self._idx)
+        if draw:
+            self.ops.perm_batch(start, B, ep["top"], ep["seed"], self._idx)
+        return start, ep["top"], ep["seed"]
 
     def sample_gathered(self, out_rows: torch.Tensor) -> Batch:
         """``sample()`` plus a dense copy of the sampled rows into ``out_rows`` [B * row_bytes] in ONE launch — the device counterpart of a
@@ -244,9 +247,13 @@ class ReplayDataset:
             self.ops.is_weights(self._prio, B, self.tree[1:2], self.top, float(self.beta), self._w)
             idx = self._idx
         else:
-            self._next_uniform(B)
-            self.ops.replay_lookup(self._idx, B, self.top, self.head, self.size, self._slot, self.act, self.rew, self.done,
-                                   self.priority if self.prioritize else None, self._act, self._rew, self._done, self._prio, self._idx_out)
+            start, n_perm, seed = self._next_uniform(B, draw=not hasattr(self.ops, "replay_sample_slots"))
+            if hasattr(self.ops, "replay_sample_slots"):       # permutation element -> slot + metadata in one launch
+                self.ops.replay_sample_slots(start, n_perm, seed, self.top, self.head, self.size, self.act, self.rew, self.done,
+                                             self.priority if self.prioritize else None, B, self._idx_out, self._slot, self._act, self._rew, self._done, self._prio)
+            else:
+                self.ops.replay_lookup(self._idx, B, self.top, self.head, self.size, self._slot, self.act, self.rew, self.done,
+                                       self.priority if self.prioritize else None, self._act, self._rew, self._done, self._prio, self._idx_out)
             if self.prioritize:
                 self.ops.sum_f32(self.priority, self.size, self._scratch, self._psum)
                 self.ops.is_weights(self._prio, B, self._psum, self.top, float(self.beta), self._w)

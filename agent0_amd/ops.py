@@ -109,6 +109,12 @@ class HipOps:
         ew = self._enc_w(w)
         check(self.lib.a0_net_conv_wt_refresh(C.addressof(ew), C_, _req(wt, torch.float32, self.conv_wt_floats(C_), "wt"), _stream()), "a0_net_conv_wt_refresh")
 
+    def conv_wt_refresh_sync(self, w, C_, wt, wt_target, state):
+        ew = self._enc_w(w)
+        n = self.conv_wt_floats(C_)
+        check(self.lib.a0_net_conv_wt_refresh_sync(C.addressof(ew), C_, _req(wt, torch.float32, n, "wt"), _req(wt_target, torch.float32, n, "wt_target"),
+                                                   _req(state, torch.int32, 8, "state"), _stream()), "a0_net_conv_wt_refresh_sync")
+
     def encoder_fwd_fused(self, net, wt, w, frames, slot, sample_stride, chan_off, B, act1, act2, act3):
         fa = self._frames(net, frames, slot, sample_stride, chan_off, B)
         ew = self._enc_w(w)
@@ -251,6 +257,11 @@ class HipOps:
                                     _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
                                     lr, b1, b2, eps, target_freq, _stream()), "a0_adam_step")
 
+    def adam_step_sync(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total):
+        check(self.lib.a0_adam_step_sync(_req(params, torch.float32, n_total, "params"), _req(grads, torch.float32, n, "grads"), _req(m, torch.float32, n, "m"),
+                                         _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
+                                         lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total, _stream()), "a0_adam_step_sync")
+
     def rmsprop_step(self, params, grads, sq, n, lr, alpha, eps, max_grad_norm, clip_scratch):
         check(self.lib.a0_rmsprop_step(_req(params, torch.float32, n, "params"), _req(grads, torch.float32, n, "grads"), _req(sq, torch.float32, n, "sq"), n,
                                        lr, alpha, eps, max_grad_norm, _req(clip_scratch, torch.float32, 1, "clip_scratch", optional=True), _stream()), "a0_rmsprop_step")
@@ -287,6 +298,13 @@ class HipOps:
     def replay_gather(self, frames, row_bytes, slot, B, out, rows_available):
         check(self.lib.a0_replay_gather(_req(frames, torch.uint8, rows_available * row_bytes, "frames"), row_bytes, _req(slot, torch.int32, B, "slot"), B,
                                         _req(out, torch.uint8, B * row_bytes, "out"), _stream()), "a0_replay_gather")
+
+    def replay_sample_slots(self, start, n_perm, seed, top, head, cap, r_act, r_rew, r_done, priority, B, idx_out, slot_out, act, rew, done, prio):
+        check(self.lib.a0_replay_sample_slots(start, n_perm, seed & 0xFFFFFFFF, top, head, cap, _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"),
+                                              _req(r_done, torch.float32, cap, "r_done"), _req(priority, torch.float32, top, "priority", optional=True), B,
+                                              _req(idx_out, torch.int64, B, "idx_out"), _req(slot_out, torch.int32, B, "slot_out"), _req(act, torch.int32, B, "act"),
+                                              _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"), _req(prio, torch.float32, B, "prio", optional=True),
+                                              _stream()), "a0_replay_sample_slots")
 
     def replay_sample_gather(self, mode, start, n_perm, seed, tree, cap2, xi, top, head, cap, frames, row_bytes, r_act, r_rew, r_done, priority, B, out,
                              idx_out, slot_out, act, rew, done, prio):

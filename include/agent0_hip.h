@@ -71,6 +71,9 @@ int a0_net_encoder_fwd(const a0_net* net, const a0_encoder_weights* w, const a0_
 int a0_net_encoder_fused_supported(int C, int H, int W);
 long long a0_net_conv_wt_floats(int C);
 int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* stream);
+/* the online network's copies after an optimizer step, mirrored into the target network's copies when that step triggered a target sync
+ * (state[4] of a0_adam_step_sync): one launch per update instead of one refresh per network */
+int a0_net_conv_wt_refresh_sync(const a0_encoder_weights* w, int C, float* wt, float* wt_target, const int* state, void* stream);
 int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
                              float* act1, float* act2, float* act3, void* stream);
 
@@ -162,6 +165,11 @@ int a0_fqf_fraction_loss(const float* q, const float* qh, const float* taus, con
 /* state: int[8] device block: [0] nan flag (set by losses) [1] update_steps [2] skipped [3] skip_now [4] sync_now */
 int a0_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state,
                  float* scalars2, double lr, double beta1, double beta2, double eps, int target_update_freq, void* stream);
+/* a0_adam_step with the target copy of agent.py:160-161 folded into the same pass: when update_steps % target_update_freq == 0 after this
+ * update, target[0, n_total) receives the new parameters (n_total >= n also covers blocks Adam does not own).  == a0_adam_step +
+ * a0_target_sync(force = 0), two launches instead of three. */
+int a0_adam_step_sync(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars2, double lr,
+                      double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, void* stream);
 int a0_rmsprop_step(float* params, const float* grads, float* square_avg, long long n, double lr, double alpha, double eps,
                     double max_grad_norm, float* clip_scratch, void* stream);
 int a0_target_sync(float* target, const float* online, long long n, const int* state, int force, void* stream);
@@ -185,6 +193,10 @@ int a0_replay_sample_gather(int mode, unsigned long long start, unsigned long lo
                             const float* xi, long long top, long long head, long long cap, const uint8_t* frames, int row_bytes, const int* r_act,
                             const float* r_rew, const float* r_done, const float* priority, int B, uint8_t* out, long long* idx_out, int* slot_out,
                             int* act, float* rew, float* done, float* prio, void* stream);
+/* uniform sampling without the row copy (the learner's conv1 reads ring rows through slot_out): == a0_perm_batch + a0_replay_lookup */
+int a0_replay_sample_slots(unsigned long long start, unsigned long long n_perm, unsigned int seed, long long top, long long head, long long cap,
+                           const int* r_act, const float* r_rew, const float* r_done, const float* priority, int B, long long* idx_out, int* slot_out,
+                           int* act, float* rew, float* done, float* prio, void* stream);
 int a0_fill_f32(float* p, long long n, float v, void* stream);
 int a0_priority_update(float* priority, const long long* ids, const float* loss, int B, float eps, float alpha,
                        float* pstate, const int* state, void* stream);

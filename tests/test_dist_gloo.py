@@ -46,7 +46,16 @@ def _worker(rank, world, port, nan_rank, out):
     dist.destroy_process_group()
 
 
-def _run(world, nan_rank, port):
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:        # a fixed port can still sit in TIME_WAIT from the previous run of this suite
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run(world, nan_rank, port=None):
+    port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, nan_rank, out), nprocs=world, join=True)

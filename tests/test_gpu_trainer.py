@@ -308,9 +308,13 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "3", "--replay-size", "40960", "--no-cpu-baseline",
            "--no-ratio320", "--no-other-entry"]
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     outs = []
     for force in ("0", "1"):
-        env = dict(os.environ, A0_DP_FORCE=force, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+        env = dict(os.environ, A0_DP_FORCE=force, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
