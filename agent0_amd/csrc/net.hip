@@ -142,16 +142,17 @@ struct a0_hip_backend {
         // fp32 operands: the split-operand kernel on the bf16 matrix pipe (igemm_x9.h); A0_GEMM=fp32 keeps the fmaf-chain kernel
         const bool x9 = g_gemm_x9 != 0;
         if constexpr (a0_x9_ok<OA>::value && a0_x9_ok<OB>::value) {
-            // large, deep problems: 128 x 128 tiles on eight waves (two per SIMD: the splits of one wave issue in the shadow of the other's MFMAs)
+            // large problems: 128 x 128 tiles on eight waves (two per SIMD: the splits of one wave issue in the shadow of the other's MFMAs)
             const int sp = splits < 1 ? 1 : splits;
             const long long big = (long long)((X + 127) / 128) * ((Y + 127) / 128) * sp;
             // weight gradients (x-contiguous A): the short, heavily split reductions of a 512-row batch are staging-bound, and there
             // the fp32 kernel's plain 16-byte LDS commits win (conv2/conv3 36 vs 44 us, fc1 17.7 vs 19.4 us); the split kernel takes
-            // them only at the large-tile sizes (fc1 over 32 768 quantile rows: 1.12 vs 1.34 ms)
+            // them only when each split is at least 512 deep (the quantile networks' B*N-row reductions: fc1 1.12 vs 1.34 ms)
             constexpr bool wgrad_family = OA::MODE == A0_XC;
-            const bool large = X >= 128 && Y >= 128 && big >= g_x9_big_min && K / sp >= 512;
+            const bool deep = K / sp >= 512;
+            const bool large = X >= 128 && Y >= 128 && big >= g_x9_big_min && (deep || !wgrad_family);
             if (x9 && large) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
-            else if (x9 && !wgrad_family) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+            else if (x9 && (!wgrad_family || deep)) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
             else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
         } else {
             A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
