@@ -36,4 +36,14 @@ struct a0_geom {
     int stride, pad;
     int HWout;
     long long sample_stride;  // elements (bytes for u8) between consecutive samples of the input
+    unsigned hw_magic, w_magic;   // ceil(2^32 / HWout), ceil(2^32 / Wout): row index -> (sample, oh, ow) without integer division (a0_udiv)
 };
+
+// floor(m / d) for any 32-bit m, given magic = ceil(2^32 / d), d >= 2: the multiply-high overestimates by at most one.
+A0_HD unsigned a0_udiv_magic(unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; }
+A0_HD int a0_udiv(int m, int d, unsigned magic) {
+    if (d <= 1) return m;
+    unsigned q = (unsigned)(((unsigned long long)(unsigned)m * magic) >> 32);
+    if (q * (unsigned)d > (unsigned)m) --q;
+    return (int)q;
+}

@@ -1000,7 +1000,9 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
         configured[which] = lds;
     }
     const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
-    if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 0;       // tuning aid: persistent workgroups (each loops over b += gridDim.x)
+    const int gridx = (grid_cap > 0 && B > grid_cap) ? grid_cap : B;
+    if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     else if (which == 1) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     else hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 4, 2, 0, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     if (probed) {   // algorithmic FLOP of the three convolutions: 2 * (M1*32*K1 + M2*64*512 + M3*64*576) per observation
@@ -1040,7 +1042,11 @@ extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, 
         configured[x9] = true;
     }
     const bool probed = a0_probe_start(A0_TAG_ENCODER_DGRAD_FUSED, (hipStream_t)stream);
-    if (x9) hipLaunchKernelGGL(a0_encoder_dgrad_fused_x9_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    // at most one workgroup per CU, each looping over its observations (b += gridDim.x): the next observation's masks and the first
+    // stage's weights are prefetched in the last stage's `between` slot instead of at workgroup start (-5 us per 512 observations)
+    static const int grid_cap = getenv("A0_DGRAD_GRID") ? atoi(getenv("A0_DGRAD_GRID")) : 256;
+    const int gridx = (grid_cap > 0 && B > grid_cap) ? grid_cap : B;
+    if (x9) hipLaunchKernelGGL(a0_encoder_dgrad_fused_x9_kernel, dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(a0_encoder_dgrad_fused_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     if (probed) a0_probe_stop((hipStream_t)stream, 2.0 * (81.0 * 64 * 576 + 400.0 * 32 * 256) * B);
     A0_HIP_THROW(hipGetLastError());

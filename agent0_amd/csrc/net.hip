@@ -132,6 +132,10 @@ extern "C" int a0_gemm_mode(int mode) {
     return prev;
 }
 
+// im2col-gathered B operands (conv weight gradients): their address arithmetic already fills the issue slots the splits would need
+template <class OP> struct a0_is_gather { static constexpr bool value = false; };
+template <> struct a0_is_gather<OpActXC> { static constexpr bool value = true; };
+
 struct a0_hip_backend {
     hipStream_t st;
     int tag = 0;
@@ -152,7 +156,7 @@ struct a0_hip_backend {
             const bool deep = K / sp >= 512;
             const bool large = X >= 128 && Y >= 128 && big >= g_x9_big_min && (deep || !wgrad_family);
             if (x9 && large) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
-            else if (x9 && (!wgrad_family || deep)) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+            else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
             else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
         } else {
             A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));

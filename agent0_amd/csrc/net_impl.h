@@ -39,6 +39,7 @@ static inline a0_frames_src a0_frames(const a0_net_core& n, const a0_frames_arg&
     s.frames = f.frames; s.slot = f.slot;
     s.g.Hin = n.H; s.g.Win = n.W; s.g.C = n.C;
     s.g.Hout = n.H1; s.g.Wout = n.W1; s.g.stride = 4; s.g.pad = 0; s.g.HWout = n.H1 * n.W1;
+    s.g.hw_magic = a0_udiv_magic((unsigned)s.g.HWout); s.g.w_magic = a0_udiv_magic((unsigned)s.g.Wout);
     s.g.sample_stride = f.sample_stride;
     s.chan_off = f.chan_off;
     s.ktab = n.ktab1;
@@ -51,6 +52,7 @@ static inline a0_act_src a0_act(const float* x, int Hin, int Win, int C, int Hou
     s.x = x; s.ktab = ktab;
     s.g.Hin = Hin; s.g.Win = Win; s.g.C = C; s.g.Hout = Hout; s.g.Wout = Wout; s.g.stride = stride; s.g.pad = pad;
     s.g.HWout = Hout * Wout; s.g.sample_stride = (long long)Hin * Win * C;
+    s.g.hw_magic = a0_udiv_magic((unsigned)s.g.HWout); s.g.w_magic = a0_udiv_magic((unsigned)s.g.Wout);
     return s;
 }
 
@@ -82,6 +84,22 @@ static inline int a0_wgrad_splits(int gx, int gy, int R) {
     return splits;
 }
 
+// conv2 / conv3 weight gradients: 64 x 64 output tiles and a split count that gives two workgroups per CU, i.e. 400-650 reduction rows
+// and 25 MB of slabs instead of 200-330 rows and 40 MB with 64 x 128 tiles (106 vs 110 us for the three layers + reduction at B = 512,
+// tools/ubench_convwgrad.py).  A0_CONV_WGRAD_T64 = target workgroup count (tuning aid; 0 = the 64 x 128 tiles of a0_wgrad_splits).
+static inline int a0_conv_wgrad_t64() {
+    static const int target = getenv("A0_CONV_WGRAD_T64") ? atoi(getenv("A0_CONV_WGRAD_T64")) : 512;
+    return target;
+}
+static inline int a0_conv_wgrad_splits(int K, int M) {
+    const int t = a0_conv_wgrad_t64();
+    if (t <= 0) return a0_wgrad_splits(1, (K + 127) / 128, M);
+    int s = t / ((K + 63) / 64);
+    const int maxs = (M + 255) / 256;
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : s;
+}
+
 static inline int a0_chunk_rows(int R, int splits) { return (((R + 31) / 32 + splits - 1) / splits) * 32; }
 
 static inline long long a0_dense_fwd_scratch_impl(int R, int N, int K) {
@@ -106,7 +124,7 @@ static inline a0_enc_slab_plan a0_encoder_slab_plan(const a0_net_core& n, int B)
     const int K[3] = {n.K1, n.K2, n.K3};
     long long off = 0;
     for (int l = 2; l >= 0; --l) {
-        p.splits[l] = a0_wgrad_splits(1, (K[l] + 127) / 128, M[l]);
+        p.splits[l] = l == 0 ? a0_wgrad_splits(1, (K[l] + 127) / 128, M[l]) : a0_conv_wgrad_splits(K[l], M[l]);
         int slabs = p.splits[l] > 1 ? p.splits[l] : 0;
         if (l == 0) { const int fused = B < 256 ? B : 256; if (fused > slabs) slabs = fused; }
         p.off[l] = off;
@@ -233,7 +251,8 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_act_src b = a0_act(act2, n.H2, n.W2, 64, n.H3, n.W3, 1, 0, n.ktab3);
         EpiWgradSlab::Params e{splits > 1 ? sl : g3, splits > 1 ? wc + 64 : 0, n.K3, wc};
         bk.tag = A0_TAG_CONV3_WGRAD;
-        bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
+        if (a0_conv_wgrad_t64() > 0) bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 1>(a, b, e, 64, n.K3, M3, splits);
+        else bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K3, M3, splits);
         if (splits > 1) segs[nseg++] = a0_reduce_seg{sl, wc + 64, splits, g3, wc + 64};
     }
     if (with_dgrad) {   // conv3 data gradient -> d2 (masked by act2 > 0): gather form, 3x3 taps over d3 with pad 2
@@ -251,7 +270,8 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         a0_act_src b = a0_act(act1, n.H1, n.W1, 32, n.H2, n.W2, 2, 0, n.ktab2);
         EpiWgradSlab::Params e{splits > 1 ? sl : g2, splits > 1 ? wc + 64 : 0, n.K2, wc};
         bk.tag = A0_TAG_CONV2_WGRAD;
-        bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K2, M2, splits);
+        if (a0_conv_wgrad_t64() > 0) bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 1>(a, b, e, 64, n.K2, M2, splits);
+        else bk.template igemm<OpMatXC, OpActXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, 64, n.K2, M2, splits);
         if (splits > 1) segs[nseg++] = a0_reduce_seg{sl, wc + 64, splits, g2, wc + 64};
     }
     // conv2 data gradient -> d1 (masked by act1 > 0): four stride phases, 2x2 taps over d2 with pad 1

@@ -65,9 +65,9 @@ A0_HD a0_f4 a0_u8x4_to_f4(uint32_t w, bool valid) {
 }
 
 A0_HD const uint8_t* a0_frames_row(const a0_frames_src& P, int m) {
-    int b = m / P.g.HWout;
+    int b = a0_udiv(m, P.g.HWout, P.g.hw_magic);
     int rem = m - b * P.g.HWout;
-    int oh = rem / P.g.Wout;
+    int oh = a0_udiv(rem, P.g.Wout, P.g.w_magic);
     int ow = rem - oh * P.g.Wout;
     long long s = P.slot ? (long long)P.slot[b] : (long long)b;
     return P.frames + s * P.g.sample_stride + P.chan_off + (long long)(oh * P.g.stride) * P.g.Win + ow * P.g.stride;
@@ -119,9 +119,9 @@ struct a0_act_row { long long base; int h0, w0; bool ok; };
 A0_HD a0_act_row a0_act_rowdesc(const a0_act_src& P, int m, bool ok) {
     a0_act_row r;
     if (!ok) m = 0;
-    int b = m / P.g.HWout;
+    int b = a0_udiv(m, P.g.HWout, P.g.hw_magic);         // the weight-gradient GEMMs evaluate this per fetched k row: no integer division
     int rem = m - b * P.g.HWout;
-    int oh = rem / P.g.Wout;
+    int oh = a0_udiv(rem, P.g.Wout, P.g.w_magic);
     int ow = rem - oh * P.g.Wout;
     r.h0 = oh * P.g.stride - P.g.pad;
     r.w0 = ow * P.g.stride - P.g.pad;

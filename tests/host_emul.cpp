@@ -140,3 +140,12 @@ void emul_dense_wgrad(const float* dY, const float* X, int ldx, float* grad, int
 }
 
 }  // extern "C"
+
+// a0_udiv (a0_defs.h): number of m in [lo, hi) with step `step` where the multiply-high quotient differs from m / d
+extern "C" long long emul_udiv_mismatches(unsigned d, unsigned lo, unsigned hi, unsigned step) {
+    const unsigned magic = a0_udiv_magic(d);
+    long long bad = 0;
+    for (unsigned long long m = lo; m < hi; m += step)
+        if (a0_udiv((int)(unsigned)m, (int)d, magic) != (int)((unsigned)m / d)) ++bad;
+    return bad;
+}

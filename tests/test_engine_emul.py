@@ -239,3 +239,17 @@ def check_nan_skip(ops):
 
 def test_nan_loss_skips_the_step(ops):
     check_nan_skip(ops)
+
+
+def test_gather_row_division_by_multiply_high_is_exact():
+    """a0_udiv replaces the two integer divisions of the im2col row descriptor (row -> sample, oh, ow) by a multiply-high with
+    magic = ceil(2^32 / d) and one correction: exact for every 31-bit row index, for the divisors the network geometries produce."""
+    import ctypes as C
+    import cpu_ops
+    lib = C.CDLL(cpu_ops.build_emul())
+    lib.emul_udiv_mismatches.restype = C.c_longlong
+    lib.emul_udiv_mismatches.argtypes = [C.c_uint] * 4
+    for d in (1, 2, 3, 7, 9, 10, 20, 49, 81, 100, 400, 1024, 6561, 65535):
+        assert lib.emul_udiv_mismatches(d, 0, 3_000_000, 1) == 0, d                       # every row index of a 512- to 7 000-sample batch
+        assert lib.emul_udiv_mismatches(d, 0, 2**31 - 1, 104_729) == 0, d                  # strided up to the largest int
+        assert lib.emul_udiv_mismatches(d, 2**31 - 1 - 2_000_000, 2**31 - 1, 1) == 0, d   # and the top of the range
