@@ -261,6 +261,147 @@ extern "C" int a0_dqn_head_loss(const float* h_on, const float* h_tg, const floa
     return a0_fail_hip((int)hipGetLastError(), "a0_dqn_head_loss");
 }
 
+// Variant that also finishes fc1: the three fc1 GEMMs (online on s, target on s', online on s' for double-Q) leave their split-K slabs
+// behind (a0_dense_fwd_partial) and this kernel sums them in slab order, adds the bias and applies the ReLU exactly like
+// a0_reduce_bias_act_kernel would (bit-identical), writing only the online activations h(s) that the backward pass needs.  Two or three
+// reduction launches per update disappear.
+__global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float* __restrict__ s_on, const float* __restrict__ s_tg, const float* __restrict__ s_sel,
+                                                                     long long slab_stride, int nslab, const float* __restrict__ b1_on,
+                                                                     const float* __restrict__ b1_tg, float* __restrict__ h_on_out,
+                                                                     const float* __restrict__ W_on, const float* __restrict__ b_on, const float* __restrict__ W_tg,
+                                                                     const float* __restrict__ b_tg, int A, int dueling, int ld, const int* __restrict__ act,
+                                                                     const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ wgt,
+                                                                     float gamma_n, int B, float* __restrict__ loss, float* __restrict__ q_on_out,
+                                                                     float* __restrict__ q_tg_out, float* __restrict__ draw, int* __restrict__ nan_flag) {
+    extern __shared__ float wsm[];                 // [online rows | target rows], NQ x 512 each
+    __shared__ float raw[4][3][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NQ = A + (dueling ? 1 : 0);
+    for (int i = threadIdx.x; i < NQ * 128; i += 256) { ((a0_f4*)wsm)[i] = ((const a0_f4*)W_on)[i]; ((a0_f4*)wsm)[NQ * 128 + i] = ((const a0_f4*)W_tg)[i]; }
+    const int b = blockIdx.x * 4 + wave;
+    const int br = b < B ? b : B - 1;
+    float ho[8], ht[8], hs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ho[i] = 0.f; ht[i] = 0.f; hs[i] = 0.f; }
+    const long long ro = (long long)br * 512 + lane;
+    // four slabs per trip: every column of the trip is requested before any is added, so 64 (96) loads overlap instead of queueing;
+    // the additions stay in slab order
+    auto sum4 = [&](const float* __restrict__ sp, float (&h)[8]) {
+        int z = 0;
+        for (; z + 4 <= nslab; z += 4) {
+            float t[4][8];
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[zz][i] = sp[(long long)(z + zz) * slab_stride + ro + 64 * i];
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h[i] += t[zz][i];
+        }
+        for (; z < nslab; ++z) {
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = sp[(long long)z * slab_stride + ro + 64 * i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] += t[i];
+        }
+    };
+    sum4(s_on, ho);
+    sum4(s_tg, ht);
+    if (s_sel) sum4(s_sel, hs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float bo = b1_on[lane + 64 * i], bt = b1_tg[lane + 64 * i];
+        float v = ho[i] + bo; ho[i] = v < 0.f ? 0.f : v;
+        v = ht[i] + bt; ht[i] = v < 0.f ? 0.f : v;
+        v = hs[i] + bo; hs[i] = v < 0.f ? 0.f : v;
+    }
+    __syncthreads();
+    if (b >= B) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h_on_out[(long long)b * 512 + lane + 64 * i] = ho[i];
+    for (int a = 0; a < NQ; ++a) {
+        const float* wo = wsm + a * 512;
+        const float* wt = wsm + (NQ + a) * 512;
+        float so = 0.f, st = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float w1 = wo[lane + 64 * i];
+            so = fmaf(ho[i], w1, so);
+            ss = fmaf(hs[i], w1, ss);
+            st = fmaf(ht[i], wt[lane + 64 * i], st);
+        }
+        so = a0_wave_sum(so); st = a0_wave_sum(st); ss = a0_wave_sum(ss);
+        if (lane == 0) { raw[wave][0][a] = so + b_on[a]; raw[wave][1][a] = st + b_tg[a]; raw[wave][2][a] = ss + b_on[a]; }
+    }
+    if (lane != 0) return;
+    const int nsel = s_sel ? 2 : 1;
+    float mean[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+    if (dueling)
+        for (int s3 = 0; s3 < 3; ++s3) {
+            float t = 0.f;
+            for (int a = 0; a < A; ++a) t += raw[wave][s3][a];
+            mean[s3] = t / (float)A;
+            v[s3] = raw[wave][s3][A];
+        }
+    auto q = [&](int s3, int a) { return dueling ? v[s3] + (raw[wave][s3][a] - mean[s3]) : raw[wave][s3][a]; };
+    float best = 0.f;
+    int a_star = 0;
+    for (int a = 0; a < A; ++a) {
+        const float x = q(nsel, a);
+        if (a == 0 || x > best) { best = x; a_star = a; }       // first maximum wins, like torch.argmax on CPU
+        q_on_out[(long long)b * A + a] = q(0, a);
+        if (q_tg_out) q_tg_out[(long long)b * A + a] = q(1, a);
+    }
+    const float qn = q(1, a_star);
+    const float y = rew[b] + (gamma_n * (1.f - done[b])) * qn;
+    const int ab = act[b];
+    const float d = q(0, ab) - y;
+    const float ad = fabsf(d);
+    const float l = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+    loss[b] = l;
+    if (l != l) atomicOr(nan_flag, 1);
+    const float g = wgt[b] * fminf(fmaxf(d, -1.f), 1.f);
+    float* o = draw + (long long)b * ld;
+    for (int c = 0; c < ld; ++c) {
+        float out = 0.f;
+        if (c < A) {
+            out = (c == ab) ? g : 0.f;
+            if (dueling) {
+                float s = 0.f;
+                for (int a = 0; a < A; ++a) s += (a == ab) ? g : 0.f;
+                out -= s / (float)A;
+            }
+        } else if (dueling && c == A) {
+            float s = 0.f;
+            for (int a = 0; a < A; ++a) s += (a == ab) ? g : 0.f;
+            out = s;
+        }
+        o[c] = out;
+    }
+}
+
+extern "C" int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const float* slabs_sel, long long slab_stride, int nslab, const float* b1_on,
+                                      const float* b1_tg, float* h_on_out, const float* W_on, const float* b_on, const float* W_tg, const float* b_tg, int A,
+                                      int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt, float gamma_n, int B, float* loss,
+                                      float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream) {
+    const int NQ = A + (dueling ? 1 : 0);
+    if (!slabs_on || !slabs_tg || !b1_on || !b1_tg || !h_on_out || !W_on || !b_on || !W_tg || !b_tg || !act || !rew || !done || !wgt || !loss || !q_on_out || !draw ||
+        !nan_flag || B < 1 || A < 1 || NQ > 24 || ld < NQ || nslab < 1 || slab_stride < (long long)B * 512)
+        return a0_fail(A0_EINVAL, "a0_dqn_head_loss_slabs: bad argument (A + dueling <= 24)");
+    const size_t lds = (size_t)2 * NQ * 512 * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_dqn_head_loss_slabs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_dqn_head_loss_slabs: LDS");
+        configured = lds;
+    }
+    hipLaunchKernelGGL(a0_dqn_head_loss_slabs_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, slabs_on, slabs_tg, slabs_sel, slab_stride, nslab, b1_on, b1_tg,
+                       h_on_out, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag);
+    return a0_fail_hip((int)hipGetLastError(), "a0_dqn_head_loss_slabs");
+}
+
 // ------------------------------------------------------------------------------------------------ Munchausen DQN
 // MDQNLearner.train_step (reference agent.py:194-215, log_softmax_stable 116-119), per sample:
 //   lp(x)  = z - tau * logsumexp(z / tau),  z = x - max(x)

@@ -268,6 +268,28 @@ extern "C" int a0_dense_fwd(const float* X, int ldx, const float* W, const float
     A0_CATCH
 }
 
+// The split-K GEMM of a0_dense_fwd WITHOUT its reduction: slab z = X W^T over the z-th k range, [R][N] each at stride R*N; the caller's
+// next kernel sums the slabs (a0_dqn_head_loss_slabs, a0_actor_qhead).  Returns the slab count.
+extern "C" int a0_dense_fwd_partial_slabs(int R, int N, int K) {
+    const int s = a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int R, int N, int K, float* slabs, void* stream) {
+    A0_TRY
+    if (!X || !W || !slabs || R < 1 || (N & 3) || (K & 3) || (ldx & 3)) return a0_fail(A0_EINVAL, "a0_dense_fwd_partial: bad shape (N, K, ldx must be multiples of 4)");
+    a0_hip_backend bk{(hipStream_t)stream};
+    const int splits = a0_dense_fwd_partial_slabs(R, N, K);
+    a0_mat_src a{X, ldx};
+    a0_mat_src bw{W, K};
+    EpiSlab::Params ep{slabs, (long long)R * N, N};
+    bk.tag = A0_TAG_DENSE_FWD;
+    if (N <= 32) bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 1>(a, bw, ep, R, N, K, splits);
+    else bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, ep, R, N, K, splits);
+    return A0_OK;
+    A0_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ fused actor tail (dqn / mdqn)
 // Everything between the conv features and the chosen action of Actor.act (reference agent.py:25-39 with model.py:108-131 behind
 // it), for scalar-valued heads: fc1 runs as the usual split-K implicit GEMM, but its slabs are consumed directly by ONE kernel that

@@ -403,16 +403,32 @@ class DeviceLearner:
             ops.loss_mdqn(wo.q, wt.q, wm.q, L.A, act, rew, done, wgt, self.gamma_n, self.mdqn_tau, self.mdqn_lo, B, self.loss, wo.dq, self.state)
         elif algo == "dqn" and getattr(ops, "fused_dqn_head", False) and L.A + (1 if L.dueling else 0) <= 24:
             # heads, loss and head gradient in one kernel (a0_dqn_head_loss); only fc1 runs as a GEMM
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
-            tg.fc1(wt, B)
-            if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
-                on.fc1(wsel, B)
-            on.encode(wo, frames, slot, sample_stride, 0, B)
-            on.fc1(wo, B)
             (Wo, bo), (Wt, bt) = on.wb("head"), tg.wb("head")
-            ops.dqn_head_loss(wo.h, wt.h, wsel.h if self.double_q else None, Wo, bo, Wt, bt, L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B,
-                              self.loss, wo.q, wt.q, wo.draw, self.state)
+            if getattr(ops, "fused_dqn_head_slabs", False):
+                # ... and that kernel also finishes fc1 from the GEMMs' split-K slabs (no reduction launches)
+                ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
+                if getattr(self, "_fc1_slabs", None) is None or self._fc1_slabs[0].numel() < ns * B * 512:
+                    self._fc1_slabs = [ops.empty(ns * B * 512) for _ in range(3 if self.double_q else 2)]
+                (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
+                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, self._fc1_slabs[1])
+                if self.double_q:
+                    on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
+                    ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
+                on.encode(wo, frames, slot, sample_stride, 0, B)
+                ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
+                ops.dqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
+                                        L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state)
+            else:
+                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+                tg.fc1(wt, B)
+                if self.double_q:
+                    on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
+                    on.fc1(wsel, B)
+                on.encode(wo, frames, slot, sample_stride, 0, B)
+                on.fc1(wo, B)
+                ops.dqn_head_loss(wo.h, wt.h, wsel.h if self.double_q else None, Wo, bo, Wt, bt, L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B,
+                                  self.loss, wo.q, wt.q, wo.draw, self.state)
             have_draw = True
         elif algo in ("dqn", "c51", "qr"):
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)

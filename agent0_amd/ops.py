@@ -328,6 +328,30 @@ class HipOps:
                                         _req(q_on, torch.float32, B * A, "q_on"), _req(q_tg, torch.float32, B * A, "q_tg", optional=True),
                                         _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"), _stream()), "a0_dqn_head_loss")
 
+    fused_dqn_head_slabs = True
+
+    def dense_fwd_partial_slabs(self, R, N, K) -> int:
+        return int(self.lib.a0_dense_fwd_partial_slabs(R, N, K))
+
+    def dense_fwd_partial(self, X, ldx, W, R, N, K, slabs):
+        ns = self.dense_fwd_partial_slabs(R, N, K)
+        check(self.lib.a0_dense_fwd_partial(_req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx, _req(W, torch.float32, N * K, "W"), R, N, K,
+                                            _req(slabs, torch.float32, ns * R * N, "slabs"), _stream()), "a0_dense_fwd_partial")
+        return ns
+
+    def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
+                            draw, state):
+        nq = A + (1 if dueling else 0)
+        n = nslab * B * 512
+        check(self.lib.a0_dqn_head_loss_slabs(_req(s_on, torch.float32, n, "slabs_on"), _req(s_tg, torch.float32, n, "slabs_tg"),
+                                              _req(s_sel, torch.float32, n, "slabs_sel", optional=True), B * 512, nslab, _req(b1_on, torch.float32, 512, "b1_on"),
+                                              _req(b1_tg, torch.float32, 512, "b1_tg"), _req(h_on, torch.float32, B * 512, "h_on"),
+                                              _req(W_on, torch.float32, nq * 512, "W_on"), _req(b_on, torch.float32, nq, "b_on"), _req(W_tg, torch.float32, nq * 512, "W_tg"),
+                                              _req(b_tg, torch.float32, nq, "b_tg"), A, int(dueling), ld, _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"),
+                                              _req(done, torch.float32, B, "done"), _req(wgt, torch.float32, B, "wgt"), float(gamma_n), B, _req(loss, torch.float32, B, "loss"),
+                                              _req(q_on, torch.float32, B * A, "q_on"), _req(q_tg, torch.float32, B * A, "q_tg", optional=True),
+                                              _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"), _stream()), "a0_dqn_head_loss_slabs")
+
     def actor_qhead_scratch(self, E, K) -> int:
         return int(self.lib.a0_actor_qhead_scratch(E, K))
 

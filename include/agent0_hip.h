@@ -104,6 +104,11 @@ int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float
 long long a0_dense_wgrad_scratch(int R, int N, int K);
 int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
 
+/* a0_dense_fwd without its slab reduction: slab z of [R][N] at stride R*N holds X W^T over the z-th k range; the consumer kernel sums the
+ * a0_dense_fwd_partial_slabs(R, N, K) slabs in order, adds the bias and applies the activation (a0_dqn_head_loss_slabs) */
+int a0_dense_fwd_partial_slabs(int R, int N, int K);
+int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int R, int N, int K, float* slabs, void* stream);
+
 /* measurement hook for bench.py: HIP events around every launch of the GEMM tagged `tag` (1 conv1 fwd, 2 conv2 fwd, 3 conv3 fwd,
  * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad, 12 fused encoder), recorded on the
  * launch stream.  a0_probe_end writes host_out3 = {launches, total ms, total algorithmic FLOP (2*M*N*K)}. */
@@ -136,6 +141,12 @@ int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, cons
 int a0_dqn_head_loss(const float* h_on, const float* h_tg, const float* h_sel, const float* W_on, const float* b_on, const float* W_tg,
                      const float* b_tg, int A, int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt,
                      float gamma_n, int B, float* loss, float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream);
+/* a0_dqn_head_loss that also finishes the three fc1 layers from their split-K slabs (a0_dense_fwd_partial): slab sum in order + bias + ReLU,
+ * bit-identical to a0_dense_fwd; writes the online activations h(s) [B][512] for the backward pass.  slabs_sel = NULL without double-Q. */
+int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const float* slabs_sel, long long slab_stride, int nslab, const float* b1_on,
+                           const float* b1_tg, float* h_on_out, const float* W_on, const float* b_on, const float* W_tg, const float* b_tg, int A,
+                           int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt, float gamma_n, int B, float* loss,
+                           float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream);
 
 /* MDQNLearner.train_step (agent.py:194-215): q_next = target(next_obs), q_cur_tgt = target(obs), both [B][A] */
 int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,
