@@ -436,6 +436,27 @@ extern "C" int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* g
     A0_CATCH
 }
 
+// Up to four dense weight gradients whose slab reductions share ONE launch (head + fc1 [+ cosine embedding]): layer i uses
+// slabs + slab_off[i] (a0_dense_wgrad_scratch(R[i], N[i], K[i]) floats each).  Same results as four a0_dense_wgrad calls.
+extern "C" int a0_dense_wgrad_multi(int n, const float* const* dY, const float* const* X, const int* ldx, float* const* grad, const int* R, const int* N, const int* K,
+                                    float* slabs, const long long* slab_off, void* stream) {
+    A0_TRY
+    if (n < 1 || n > 4 || !dY || !X || !ldx || !grad || !R || !N || !K || !slab_off) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: 1..4 layers");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_reduce_seg segs[4];
+    int nseg = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dY[i] || !X[i] || !grad[i] || R[i] < 1 || (N[i] & 3) || (K[i] & 3) || (ldx[i] & 3)) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: bad shape");
+        if (a0_dense_wgrad_scratch_impl(R[i], N[i], K[i]) > 0 && !slabs) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: needs slab scratch");
+        a0_reduce_seg seg;
+        a0_dense_wgrad_impl(bk, dY[i], X[i], ldx[i], grad[i], R[i], N[i], K[i], slabs ? slabs + slab_off[i] : nullptr, &seg);
+        if (seg.nslab > 0) segs[nseg++] = seg;
+    }
+    if (nseg > 0) bk.reduce_segments(segs, nseg);
+    return A0_OK;
+    A0_CATCH
+}
+
 extern "C" int a0_net_encoder_wgrad(const a0_net* n, const a0_encoder_weights* w, const a0_frames_arg* f, int B, const float* act1, const float* act2,
                                     const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, void* stream) {
     A0_TRY

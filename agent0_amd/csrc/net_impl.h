@@ -212,12 +212,15 @@ static void a0_finish_wgrad(BK& bk, int N, long long wcount, float* grad, float*
     if (splits > 1) bk.reduce_slabs(slabs, wcount + N, splits, grad, wcount + N);
 }
 
+// defer != nullptr: leave the partial sums in `slabs` and describe the pending reduction in *defer (nslab = 0: nothing pending, the
+// GEMM wrote the gradient itself); the caller finishes several layers with one bk.reduce_segments launch.
 template <class BK>
-static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx, float* grad, int R, int N, int K, float* slabs) {
+static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx, float* grad, int R, int N, int K, float* slabs, a0_reduce_seg* defer = nullptr) {
     const long long wcount = (long long)N * K;
     a0_mat_src a{dY, N};
     a0_mat_src b{X, ldx};
     bk.tag = A0_TAG_DENSE_WGRAD;
+    if (defer) *defer = a0_reduce_seg{nullptr, 0, 0, nullptr, 0};
     static const int var = getenv("A0_WGRAD_VARIANT") ? atoi(getenv("A0_WGRAD_VARIANT")) : 0;      // tuning aid
     const long long blocks64 = (long long)((N + 63) / 64) * ((K + 63) / 64);
     if (var == 1 && blocks64 >= 256) {
@@ -229,7 +232,8 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
     const int splits = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
     EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K, wcount};
     bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
-    a0_finish_wgrad(bk, N, wcount, grad, slabs, splits);
+    if (defer && splits > 1) *defer = a0_reduce_seg{slabs, wcount + N, splits, grad, wcount + N};
+    else a0_finish_wgrad(bk, N, wcount, grad, slabs, splits);
 }
 
 // ------------------------------------------------------------------------------------------------ encoder backward

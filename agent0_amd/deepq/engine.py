@@ -269,6 +269,9 @@ class DeviceLearner:
                      ops.dense_wgrad_scratch(self.ws_o.R, L.Npad, 512), ops.dense_wgrad_scratch(self.ws_o.R, 512, L.feat),
                      ops.dense_wgrad_scratch(self.ws_o.R, L.feat, L.num_cosines) if L.quantile else 0,
                      ops.dense_wgrad_scratch(B, L.Fpad, L.feat) if L.algo == "fqf" else 0, 4)
+        if hasattr(ops, "dense_wgrad_multi_scratch"):     # head + fc1 (+ cosine embedding) reduce in disjoint regions of one launch
+            shapes = [(self.ws_o.R, L.Npad, 512), (self.ws_o.R, 512, L.feat)] + ([(self.ws_o.R, L.feat, L.num_cosines)] if L.quantile else [])
+            n_slab = max(n_slab, ops.dense_wgrad_multi_scratch(shapes))
         self.slabs = ops.empty(n_slab)
         self.obs_bytes = L.C * L.H * L.W
         self.grad_hook = None       # data parallelism: callable(grads, state) run between backward and the optimizer (dist.GradAllReduce)
@@ -293,17 +296,28 @@ class DeviceLearner:
             ops.dueling_bwd(ws.dq, ws.draw, L.Npad, R, L.A, T, L.dueling)
         Wh, _ = on.wb("head")
         Wf, _ = on.wb("fc1")
-        ops.dense_wgrad(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512, self.slabs)
+        multi = hasattr(ops, "dense_wgrad_multi")       # the data gradients first, then every dense weight gradient with ONE slab reduction
+        wg = [(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512)]
+        if not multi:
+            ops.dense_wgrad(*wg[0], self.slabs)
         ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
         if not L.quantile:
-            ops.dense_wgrad(ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat, self.slabs)
+            wg.append((ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat))
+            if not multi:
+                ops.dense_wgrad(*wg[1], self.slabs)
             ops.dense_dgrad(ws.dh, Wf, ws.act3, ws.d3, R, 512, L.feat)
         else:
             n = ws.n_tau
-            ops.dense_wgrad(ws.dh, ws.x, L.feat, self._grad("fc1"), R, 512, L.feat, self.slabs)
+            wg.append((ws.dh, ws.x, L.feat, self._grad("fc1"), R, 512, L.feat))
+            if not multi:
+                ops.dense_wgrad(*wg[1], self.slabs)
             ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
             ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
-            ops.dense_wgrad(ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines, self.slabs)
+            wg.append((ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines))
+            if not multi:
+                ops.dense_wgrad(*wg[2], self.slabs)
+        if multi:
+            ops.dense_wgrad_multi(wg, self.slabs)
         if L.noisy:
             for prefix, block, r0, r1, in_f in L.noise_modules:
                 mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]

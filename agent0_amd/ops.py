@@ -463,6 +463,24 @@ class HipOps:
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
                   "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}
 
+    def dense_wgrad_multi(self, layers, slabs):
+        """layers: [(dY, X, ldx, grad, R, N, K)] (at most four); their slab reductions run as one launch."""
+        n = len(layers)
+        offs, total = [], 0
+        for (_, _, _, _, R, N, K) in layers:
+            offs.append(total)
+            total += (self.dense_wgrad_scratch(R, N, K) + 3) // 4 * 4
+        PP = C.c_void_p * n
+        II = C.c_int * n
+        dY = PP(*[_req(l[0], torch.float32, l[4] * l[5], "dY") for l in layers])
+        X = PP(*[_req(l[1], torch.float32, (l[4] - 1) * l[2] + l[6], "X") for l in layers])
+        G = PP(*[_req(l[3], torch.float32, l[5] * l[6] + l[5], "grad") for l in layers])
+        check(self.lib.a0_dense_wgrad_multi(n, dY, X, II(*[l[2] for l in layers]), G, II(*[l[4] for l in layers]), II(*[l[5] for l in layers]), II(*[l[6] for l in layers]),
+                                            _req(slabs, torch.float32, total, "slabs", optional=(total == 0)), (C.c_longlong * n)(*offs), _stream()), "a0_dense_wgrad_multi")
+
+    def dense_wgrad_multi_scratch(self, shapes) -> int:
+        return sum((self.dense_wgrad_scratch(R, N, K) + 3) // 4 * 4 for (R, N, K) in shapes)
+
     def probe_begin(self, name: str, max_launches: int = 8192):
         self._probe_name = name
         check(self.lib.a0_probe_begin(self.PROBE_TAGS[name], max_launches), "a0_probe_begin")

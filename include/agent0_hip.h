@@ -103,6 +103,10 @@ int a0_dense_fwd(const float* X, int ldx, const float* W, const float* b, float*
 int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K, void* stream);
 long long a0_dense_wgrad_scratch(int R, int N, int K);
 int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
+/* n <= 4 dense weight gradients (the head's and fc1's, + the cosine embedding's) whose slab reductions share one launch; layer i reduces in
+ * slabs + slab_off[i] (a0_dense_wgrad_scratch floats each, disjoint).  The pointer / shape arrays are host arrays. */
+int a0_dense_wgrad_multi(int n, const float* const* dY, const float* const* X, const int* ldx, float* const* grad_w_b, const int* R, const int* N, const int* K,
+                         float* slabs, const long long* slab_off, void* stream);
 
 /* a0_dense_fwd without its slab reduction: slab z of [R][N] at stride R*N holds X W^T over the z-th k range; the consumer kernel sums the
  * a0_dense_fwd_partial_slabs(R, N, K) slabs in order, adds the bias and applies the activation (a0_dqn_head_loss_slabs) */
