@@ -12,9 +12,12 @@
 //   [3] skip_now      decision for the update in flight (1 = NaN seen, leave the parameters alone)
 //   [4] sync_now      1 if update_steps % target_update_freq == 0 after this update
 // scalars (floats): [0] step_size = lr / (1 - b1^t), [1] bc2_sqrt = sqrt(1 - b2^t)
-__global__ void a0_adam_prep_kernel(int* __restrict__ state, float* __restrict__ scal, double lr, double b1, double b2, int target_freq) {
+// extra_flag (optional): a float that is nonzero when ANY data-parallel rank saw a NaN — the sum over ranks of a0_nan_flag_export's
+// output, which travels at the tail of the dense gradient bucket instead of in an all-reduce of its own.
+__global__ void a0_adam_prep_kernel(int* __restrict__ state, float* __restrict__ scal, double lr, double b1, double b2, int target_freq,
+                                    const float* __restrict__ extra_flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int skip = state[0] != 0;
+    const int skip = (state[0] != 0) || (extra_flag && extra_flag[0] != 0.f);
     int steps = state[1];
     if (!skip) steps += 1; else state[2] += 1;
     const int t = steps > 0 ? steps : 1;
@@ -49,7 +52,7 @@ extern "C" int a0_adam_step(float* params, const float* grads, float* exp_avg, f
                             double lr, double beta1, double beta2, double eps, int target_update_freq, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !state || !scalars || n < 1) return a0_fail(A0_EINVAL, "a0_adam_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq);
+    hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq, (const float*)nullptr);
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(a0_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
@@ -87,16 +90,27 @@ __global__ void a0_adam_sync_kernel(float* __restrict__ p, const float* __restri
 }
 
 extern "C" int a0_adam_step_sync(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars,
-                                 double lr, double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, void* stream) {
+                                 double lr, double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total,
+                                 const float* extra_nan_flag, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !state || !scalars || !target || n < 1 || n_total < n)
         return a0_fail(A0_EINVAL, "a0_adam_step_sync: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq);
+    hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq, extra_nan_flag);
     long long blocks = (n_total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(a0_adam_sync_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total);
     return a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync");
+}
+
+// out[0] = 1.0f if this rank's NaN flag (state[0], set by the loss kernels) is up, else 0.0f — a float so that it can ride along in
+// the SUM all-reduce of a gradient bucket (dist.GradAllReduce)
+__global__ void a0_nan_flag_export_kernel(const int* __restrict__ state, float* __restrict__ out) { out[0] = state[0] != 0 ? 1.f : 0.f; }
+
+extern "C" int a0_nan_flag_export(const int* state, float* out, void* stream) {
+    if (!state || !out) return a0_fail(A0_EINVAL, "a0_nan_flag_export: bad argument");
+    hipLaunchKernelGGL(a0_nan_flag_export_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, out);
+    return a0_fail_hip((int)hipGetLastError(), "a0_nan_flag_export");
 }
 
 // RMSprop(lr, alpha, eps), no momentum, not centered (torch.optim.RMSprop defaults otherwise) — runs unconditionally,

@@ -54,7 +54,8 @@ class GradAllReduce:
     The flat layout puts the convolution blocks first ([0, conv_end), 0.3 MB) and the dense blocks after them ([conv_end, n), 6.4 MB
     for dqn ... 14 MB for noisy c51).  The backward pass finishes the dense blocks FIRST, so their all-reduce — 95 % of the bytes —
     is issued asynchronously (RCCL runs it on its own stream over xGMI) and overlaps the encoder backward, which is ~40 % of an
-    update's kernel time; the small convolution bucket and the flag follow, then the optimizer waits for both."""
+    update's kernel time; the NaN flag rides at its tail as a float (any rank's NaN makes the sum nonzero); the small convolution
+    bucket follows, then the optimizer waits for both: two collectives per update."""
 
     def __init__(self, n_grad: int, group=None):
         import torch.distributed as dist
@@ -64,15 +65,19 @@ class GradAllReduce:
         self.active = self.world > 1 or dp_forced()
         self._dense = None
 
-    def start_dense(self, grads: torch.Tensor, conv_end: int):
+    def start_dense(self, grads: torch.Tensor, conv_end: int, end: int | None = None):
+        """Asynchronous SUM of grads[conv_end:end]; ``end`` may reach past the parameters to the tail slot that carries the NaN flag as
+        a float (DeviceLearner), so that the flag needs no collective of its own."""
         if self.active:
-            self._dense = self.dist.all_reduce(grads[conv_end: self.n], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._dense = self.dist.all_reduce(grads[conv_end: (self.n if end is None else end)], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self, grads: torch.Tensor, state: torch.Tensor, conv_end: int):
+    def finish(self, grads: torch.Tensor, state: torch.Tensor | None, conv_end: int):
+        """The convolution bucket, the NaN flag when it did not travel with the dense bucket (``state`` given), and the join."""
         if not self.active:
             return
         self.dist.all_reduce(grads[:conv_end], op=self.dist.ReduceOp.SUM, group=self.group)
-        self.dist.all_reduce(state[0:1], op=self.dist.ReduceOp.MAX, group=self.group)
+        if state is not None:
+            self.dist.all_reduce(state[0:1], op=self.dist.ReduceOp.MAX, group=self.group)
         if self._dense is not None:
             self._dense.wait()          # the current stream waits for the dense bucket (no host block on RCCL)
             self._dense = None

@@ -223,7 +223,7 @@ class DeviceLearner:
         self.net = ops.net(L.C, L.H, L.W)
         self.online = DeviceNet(ops, L, self.net)
         self.target = DeviceNet(ops, L, self.net)
-        self.grads = ops.zeros(L.n_params_padded)
+        self.grads = ops.zeros(L.n_params_padded + 4)     # tail slot [n_params_padded]: the NaN flag as a float, reduced with the dense bucket
         self.adam_m = ops.zeros(L.n_params_padded)
         self.adam_v = ops.zeros(L.n_params_padded)
         self.state = ops.zeros(8, dtype=torch.int32)
@@ -274,6 +274,7 @@ class DeviceLearner:
             n_slab = max(n_slab, ops.dense_wgrad_multi_scratch(shapes))
         self.slabs = ops.empty(n_slab)
         self.obs_bytes = L.C * L.H * L.W
+        self._flag_in_tail = hasattr(ops, "nan_flag_export") and hasattr(ops, "adam_step_sync")
         self.grad_hook = None       # data parallelism: callable(grads, state) run between backward and the optimizer (dist.GradAllReduce)
 
     # ------------------------------------------------------------------ helpers
@@ -348,12 +349,15 @@ class DeviceLearner:
         self.apply()
         return out
 
+    def _bucketed_hook(self) -> bool:
+        return self.grad_hook is not None and hasattr(self.grad_hook, "start_dense")
+
     def exchange_begin(self):
         """Data parallelism, first bucket: the dense blocks' gradients are final once forward_dense returns; a hook with a
         ``start_dense`` method (dist.GradAllReduce) reduces them asynchronously while backward_encoder runs."""
         h = self.grad_hook
         if h is not None and hasattr(h, "start_dense"):
-            h.start_dense(self.grads, self.L.conv_end)
+            h.start_dense(self.grads, self.L.conv_end, self.L.n_params_padded + (1 if self._flag_in_tail else 0))
 
     def exchange_end(self):
         """Second bucket (convolution blocks + the NaN flag) and the join with the first; a plain callable hook gets one call with
@@ -362,7 +366,7 @@ class DeviceLearner:
         if h is None:
             return
         if hasattr(h, "start_dense"):
-            h.finish(self.grads, self.state, self.L.conv_end)
+            h.finish(self.grads, None if self._flag_in_tail else self.state, self.L.conv_end)
         else:
             h(self.grads, self.state)
 
@@ -378,8 +382,9 @@ class DeviceLearner:
         L, ops, on, tg = self.L, self.ops, self.online, self.target
         if hasattr(ops, "adam_step_sync"):
             # three launches: Adam's scalars; Adam with the target copy folded in; the online conv copies, mirrored to the target's on a sync
+            tail = self.grads[L.n_params_padded: L.n_params_padded + 1] if (self._flag_in_tail and self._bucketed_hook()) else None
             ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
-                               self.target_update_freq, tg.flat, L.n_params_padded)
+                               self.target_update_freq, tg.flat, L.n_params_padded, tail)
             if on.fused:
                 ops.conv_wt_refresh_sync(on.encoder_weights(), L.C, on.wt, tg.wt, self.state)
             return
@@ -514,4 +519,6 @@ class DeviceLearner:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
         self._backward_dense(wo, B, have_draw)
         self._bw = (wo, frames, slot, sample_stride, B)
+        if self._flag_in_tail and self._bucketed_hook():      # the NaN flag rides at the tail of the dense gradient bucket
+            ops.nan_flag_export(self.state, self.grads[L.n_params_padded: L.n_params_padded + 1])
         return (self.loss, frac) if frac is not None else self.loss

@@ -257,10 +257,14 @@ class HipOps:
                                     _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
                                     lr, b1, b2, eps, target_freq, _stream()), "a0_adam_step")
 
-    def adam_step_sync(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total):
+    def adam_step_sync(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag=None):
         check(self.lib.a0_adam_step_sync(_req(params, torch.float32, n_total, "params"), _req(grads, torch.float32, n, "grads"), _req(m, torch.float32, n, "m"),
                                          _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
-                                         lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total, _stream()), "a0_adam_step_sync")
+                                         lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total,
+                                         _req(extra_nan_flag, torch.float32, 1, "extra_nan_flag", optional=True), _stream()), "a0_adam_step_sync")
+
+    def nan_flag_export(self, state, out):
+        check(self.lib.a0_nan_flag_export(_req(state, torch.int32, 8, "state"), _req(out, torch.float32, 1, "out"), _stream()), "a0_nan_flag_export")
 
     def rmsprop_step(self, params, grads, sq, n, lr, alpha, eps, max_grad_norm, clip_scratch):
         check(self.lib.a0_rmsprop_step(_req(params, torch.float32, n, "params"), _req(grads, torch.float32, n, "grads"), _req(sq, torch.float32, n, "sq"), n,

@@ -184,7 +184,11 @@ int a0_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
  * update, target[0, n_total) receives the new parameters (n_total >= n also covers blocks Adam does not own).  == a0_adam_step +
  * a0_target_sync(force = 0), two launches instead of three. */
 int a0_adam_step_sync(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars2, double lr,
-                      double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, void* stream);
+                      double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, const float* extra_nan_flag,
+                      void* stream);
+/* data parallelism: this rank's NaN flag as a float (1.0 / 0.0) that rides at the tail of a SUM-reduced gradient bucket; the reduced value
+ * comes back through extra_nan_flag (nonzero = some rank saw a NaN: every rank skips the step), NULL on one GPU */
+int a0_nan_flag_export(const int* state, float* out, void* stream);
 int a0_rmsprop_step(float* params, const float* grads, float* square_avg, long long n, double lr, double alpha, double eps,
                     double max_grad_norm, float* clip_scratch, void* stream);
 int a0_target_sync(float* target, const float* online, long long n, const int* state, int force, void* stream);
