@@ -241,11 +241,15 @@ extern "C" int a0_perm_batch(unsigned long long start, int count, unsigned long 
 // Contract: oracle/sumtree.c.  tree[1] root, leaf i at tree[cap2 + i]; ancestors recomputed as left + right.
 __global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict__ tree, long long cap2, const long long* __restrict__ idx,
                                                                const float* __restrict__ val, int n) {
-    // single workgroup: leaves first (a later duplicate wins), then one level per barrier, bottom-up
+    // single workgroup: leaves first (a later duplicate wins), then one level per barrier, bottom-up.  The indices are staged in LDS
+    // once: the duplicate scan and the twenty levels re-read them from there instead of from global memory.
+    __shared__ long long sidx[1024];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sidx[i] = idx[i];
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const long long id = idx[i];
+        const long long id = sidx[i];
         bool last = true;
-        for (int c = i + 1; c < n; ++c) if (idx[c] == id) { last = false; break; }
+        for (int c = i + 1; c < n; ++c) if (sidx[c] == id) { last = false; break; }
         if (last) tree[cap2 + id] = val[i];
     }
     __threadfence_block();
@@ -253,12 +257,45 @@ __global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict_
     for (long long span = cap2 >> 1; span >= 1; span >>= 1) {   // span = number of nodes on the level being recomputed
         const int shift = __builtin_ctzll(cap2 / span);          // leaf -> ancestor on this level
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const long long p = (cap2 + idx[i]) >> shift;
+            const long long p = (cap2 + sidx[i]) >> shift;
             tree[p] = tree[2 * p] + tree[2 * p + 1];             // identical value from every writer of p
         }
         __threadfence_block();
         __syncthreads();
     }
+}
+
+// Leaves (start + i) % size, i < n, all set to val[0] — what ReplayDataset.extend does for a rollout's new transitions (replay.py:45-53:
+// new entries get max_p^alpha) — then every affected ancestor recomputed level by level.  The leaves are one ring range (two node ranges
+// per level when it wraps), so a level is a contiguous loop instead of n scattered updates: one launch for a 20 480-transition rollout
+// where the batch kernel needed twenty.  Same tree as a0_sumtree_set with those (idx, val) pairs (oracle/sumtree.c).
+__global__ __launch_bounds__(1024) void a0_sumtree_set_range_kernel(float* __restrict__ tree, long long cap2, long long start, long long n, long long size,
+                                                                     const float* __restrict__ val) {
+    const float v = val[0];
+    const long long n1 = (start + n <= size) ? n : size - start;       // [start, start + n1) and, when the ring wraps, [0, n - n1)
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) tree[cap2 + (i < n1 ? start + i : i - n1)] = v;
+    __threadfence_block();
+    __syncthreads();
+    for (long long span = cap2 >> 1; span >= 1; span >>= 1) {
+        const int shift = __builtin_ctzll(cap2 / span);
+        const long long a0 = (cap2 + start) >> shift, a1 = (cap2 + start + n1 - 1) >> shift;
+        const long long ca = a1 - a0 + 1;
+        long long cb = 0, b0 = 0;
+        if (n1 < n) { b0 = cap2 >> shift; cb = ((cap2 + (n - n1) - 1) >> shift) - b0 + 1; }
+        for (long long i = threadIdx.x; i < ca + cb; i += blockDim.x) {
+            const long long p = i < ca ? a0 + i : b0 + (i - ca);
+            tree[p] = tree[2 * p] + tree[2 * p + 1];             // a node covered by both ranges gets the same value twice
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+extern "C" int a0_sumtree_set_range(float* tree, long long cap2, long long start, long long n, long long size, const float* val, void* stream) {
+    if (!tree || !val || n < 1 || size < 1 || n > size || start < 0 || start >= size || cap2 < size || (cap2 & (cap2 - 1)))
+        return a0_fail(A0_EINVAL, "a0_sumtree_set_range: bad argument");
+    hipLaunchKernelGGL(a0_sumtree_set_range_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree, cap2, start, n, size, val);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set_range");
 }
 
 extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, void* stream) {

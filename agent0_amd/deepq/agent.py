@@ -289,8 +289,8 @@ class BaseLearner:
     def train_batch(self, frames: torch.Tensor, slot: Optional[torch.Tensor], row_bytes: int, act, rew, done, weights):
         cfg = self.cfg
         if cfg.learner.noisy_net:
-            self.model.reset_noise()
-            self.model_target.reset_noise()
+            self.model.reset_noise(compose=False)            # DeviceLearner.forward_dense composes both nets' effective weights
+            self.model_target.reset_noise(compose=False)
         rand = None
         if self._taus is not None:
             for t in self._taus:

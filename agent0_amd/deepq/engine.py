@@ -63,9 +63,17 @@ class DeviceNet:
         self.flat = ops.zeros(L.n_params_padded)
         self.eff = ops.zeros(max(L.n_eff, 4)) if L.noisy else None
         # noise vectors in KERNEL order (noise_in of first_dense permuted to (h,w,c))
+        # All of them live in ONE buffer, in the order reset_noise draws them and each padded to a multiple of four floats — the stride of
+        # the Philox offsets (DeviceRng._advance) — so a single normal fill over the buffer produces exactly the draws of nine fills.
         self.noise: Dict[str, Dict[str, torch.Tensor]] = {}
-        for prefix, block, r0, r1, in_f in L.noise_modules:
-            self.noise[prefix] = {"noise_in": ops.zeros(in_f), "noise_out_weight": ops.zeros(r1 - r0), "noise_out_bias": ops.zeros(r1 - r0)}
+        sizes = [(prefix, leaf, n) for prefix, block, r0, r1, in_f in L.noise_modules
+                 for leaf, n in (("noise_in", in_f), ("noise_out_weight", r1 - r0), ("noise_out_bias", r1 - r0))]
+        self.noise_buf = ops.zeros(max(sum((n + 3) // 4 * 4 for _, _, n in sizes), 4))
+        off = 0
+        for prefix, leaf, n in sizes:
+            self.noise.setdefault(prefix, {})[leaf] = self.noise_buf[off:off + n]
+            off += (n + 3) // 4 * 4
+        self.noise_len = off
         self._scratch: Optional[torch.Tensor] = None
         # fused per-observation encoder (encoder_fused.hip): needs k-major copies of the conv weights, refreshed when they change
         self.fused = bool(ops.fused_supported(L.C, L.H, L.W))
@@ -84,9 +92,8 @@ class DeviceNet:
             self.wt.copy_(other.wt)
         if self.eff is not None:
             self.eff.copy_(other.eff)
-        for prefix, nz in self.noise.items():
-            for k, v in nz.items():
-                v.copy_(other.noise[prefix][k])
+        if self.noise:
+            self.noise_buf.copy_(other.noise_buf)
 
     # ------------------------------------------------------------------ weights
     def block(self, name: str) -> Block:
@@ -107,11 +114,16 @@ class DeviceNet:
     def compose_noise(self):
         """NoisyLinear.reset_noise's weight_epsilon/bias_epsilon + forward composition (model.py:54-62,78-83)."""
         L = self.L
+        mods = []
         for prefix, block, r0, r1, in_f in L.noise_modules:
             mu, sg, ef = L.blocks[block + ".mu"], L.blocks[block + ".sigma"], L.eff[block]
             nz = self.noise[prefix]
-            self.ops.noisy_compose(self.flat[mu.all], self.flat[sg.all], self.eff[ef.all], mu.N, mu.K, r0, r1,
-                                   nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"])
+            mods.append((self.flat[mu.all], self.flat[sg.all], self.eff[ef.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
+        if hasattr(self.ops, "noisy_multi") and mods:
+            self.ops.noisy_multi(False, mods)              # the two or three modules in one launch
+        else:
+            for m in mods:
+                self.ops.noisy_compose(*m)
 
     def set_noise(self, prefix: str, noise_in, noise_out_weight, noise_out_bias):
         """Install the three noise vectors of one NoisyLinear (reference order/layout; model.py:73-76)."""
@@ -320,10 +332,16 @@ class DeviceLearner:
         if multi:
             ops.dense_wgrad_multi(wg, self.slabs)
         if L.noisy:
+            mods = []
             for prefix, block, r0, r1, in_f in L.noise_modules:
                 mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
                 nz = on.noise[prefix]
-                ops.noisy_grad_sigma(self.grads[mu.all], self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"])
+                mods.append((self.grads[mu.all], None, self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
+            if hasattr(ops, "noisy_multi"):
+                ops.noisy_multi(True, mods)
+            else:
+                for m in mods:
+                    ops.noisy_grad_sigma(m[0], m[2], *m[3:])
 
     def backward_encoder(self):
         """d3 -> the three convolution blocks' gradients (flat range [0, L.conv_end)); the second half of the backward pass, on the

@@ -159,8 +159,10 @@ class DeepQNet(nn.Module):
         return chain(v for k, v in self.named_parameters() if "fraction" not in k)
 
     # ------------------------------------------------------------------ noise
-    def reset_noise(self, rng=None):
-        """NoisyLinear.reset_noise for every noisy layer (model.py:73-83,335-338): N(0, 0.1^2) draws on the device."""
+    def reset_noise(self, rng=None, compose: bool = True):
+        """NoisyLinear.reset_noise for every noisy layer (model.py:73-83,335-338): N(0, 0.1^2) draws on the device.  The noise vectors are
+        adjacent in one buffer in draw order (DeviceNet), so ONE fill produces the same Philox draws as a fill per vector.
+        ``compose=False``: the caller composes the effective weights itself before the next forward (the learner's update does)."""
         if not self.L.noisy:
             return
         if rng is None:
@@ -168,11 +170,9 @@ class DeepQNet(nn.Module):
                 from agent0_amd.common.utils import DeviceRng
                 self._rng = DeviceRng(self.ops, self.cfg.seed + 7919)
             rng = self._rng
-        for prefix, *_ in self.L.noise_modules:
-            nz = self._dev.noise[prefix]
-            for leaf in ("noise_in", "noise_out_weight", "noise_out_bias"):
-                rng.normal(rng.STREAM_NOISE, 0.1, nz[leaf], nz[leaf].numel())
-        self._dev.compose_noise()
+        rng.normal(rng.STREAM_NOISE, 0.1, self._dev.noise_buf, self._dev.noise_len)
+        if compose:
+            self._dev.compose_noise()
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B: int, n_tau: int) -> Workspace:

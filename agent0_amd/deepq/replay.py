@@ -162,11 +162,16 @@ class ReplayDataset:
         if self.prioritize:
             if self.use_sumtree:
                 start = (self.written - n) % self.size
-                idx = (torch.arange(n, device=self.ops.device, dtype=torch.int64) + start) % self.size
-                val = (self._pstate[0].double() ** self.cfg.replay.alpha).float().expand(n).contiguous()
-                for o in range(0, n, 1024):           # the set kernel handles up to one workgroup's worth per call
-                    k = min(1024, n - o)
-                    self.ops.sumtree_set(self.tree, self.cap2, idx[o:o + k].contiguous(), val[o:o + k].contiguous(), k)
+                val = (self._pstate[0:1].double() ** self.cfg.replay.alpha).float()
+                if hasattr(self.ops, "sumtree_set_range"):      # one launch: the new leaves are a ring range
+                    k = min(n, self.size)
+                    self.ops.sumtree_set_range(self.tree, self.cap2, (self.written - k) % self.size, k, self.size, val)
+                else:
+                    idx = (torch.arange(n, device=self.ops.device, dtype=torch.int64) + start) % self.size
+                    val = val.expand(n).contiguous()
+                    for o in range(0, n, 1024):           # the set kernel handles up to one workgroup's worth per call
+                        k = min(1024, n - o)
+                        self.ops.sumtree_set(self.tree, self.cap2, idx[o:o + k].contiguous(), val[o:o + k].contiguous(), k)
             else:
                 self.ops.priority_tail(self.priority, self.size, min(n, self.size), self._pstate, float(self.cfg.replay.alpha))
             self.beta = self.beta_schedule(n)

@@ -285,6 +285,17 @@ class HipOps:
                                            _req(noise_out_b, torch.float32, r1 - r0, "noise_out_b"), _stream()), "a0_noisy_grad_sigma")
 
     # ------------------------------------------------------------------ replay
+    def noisy_multi(self, grad: bool, mods):
+        """mods: [(mu, sigma, out, N, K, r0, r1, noise_in, noise_out_w, noise_out_b)] (at most three NoisyLinear modules), one launch."""
+        n = len(mods)
+        PP, II = C.c_void_p * n, C.c_int * n
+        blk = lambda t, m, nm: _req(t, torch.float32, m[3] * m[4] + m[3], nm)
+        check(self.lib.a0_noisy_multi(int(grad), n, PP(*[blk(m[0], m, "mu") for m in mods]), PP(*[None if grad else blk(m[1], m, "sigma") for m in mods]),
+                                      PP(*[blk(m[2], m, "out") for m in mods]), II(*[m[3] for m in mods]), II(*[m[4] for m in mods]), II(*[m[5] for m in mods]),
+                                      II(*[m[6] for m in mods]), PP(*[_req(m[7], torch.float32, m[4], "noise_in") for m in mods]),
+                                      PP(*[_req(m[8], torch.float32, m[6] - m[5], "noise_out_w") for m in mods]),
+                                      PP(*[_req(m[9], torch.float32, m[6] - m[5], "noise_out_b") for m in mods]), _stream()), "a0_noisy_multi")
+
     def replay_insert(self, frames, cap, obs_bytes, start_slot, n, obs, obs_next, act, rew, done, r_act, r_rew, r_done, ctrl=None):
         check(self.lib.a0_replay_insert(_req(frames, torch.uint8, cap * 2 * obs_bytes, "frames"), cap, obs_bytes, start_slot, n,
                                         _req(obs, torch.uint8, n * obs_bytes, "obs"), _req(obs_next, torch.uint8, n * obs_bytes, "obs_next"),
@@ -391,6 +402,10 @@ class HipOps:
 
     def sumtree_set(self, tree, cap2, idx, val, n):
         check(self.lib.a0_sumtree_set(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(val, torch.float32, n, "val"), n, _stream()), "a0_sumtree_set")
+
+    def sumtree_set_range(self, tree, cap2, start, n, size, val):
+        check(self.lib.a0_sumtree_set_range(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, start, n, size, _req(val, torch.float32, 1, "val"), _stream()),
+              "a0_sumtree_set_range")
 
     def sumtree_rebuild(self, tree, cap2):
         check(self.lib.a0_sumtree_rebuild(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _stream()), "a0_sumtree_rebuild")

@@ -197,6 +197,10 @@ int a0_noisy_compose(const float* mu, const float* sigma, float* eff, int N, int
                      const float* noise_out_w, const float* noise_out_b, void* stream);
 int a0_noisy_grad_sigma(const float* gmu, float* gsigma, int N, int K, int r0, int r1, const float* noise_in,
                         const float* noise_out_w, const float* noise_out_b, void* stream);
+/* up to three NoisyLinear modules (first_dense, q_head, value_head) in one launch; host arrays of per-module arguments.
+ * grad = 0: a0_noisy_compose per module; grad = 1: a0_noisy_grad_sigma per module (mu = gmu, eff = gsigma, sigma unused) */
+int a0_noisy_multi(int grad, int nmod, const float* const* mu, const float* const* sigma, float* const* eff, const int* N, const int* K, const int* r0,
+                   const int* r1, const float* const* noise_in, const float* const* noise_out_w, const float* const* noise_out_b, void* stream);
 
 /* ---------------------------------------------------------------- replay (agent0/deepq/replay.py:14-59, trainer.py:63-72,91-96) */
 int a0_replay_insert(uint8_t* frames, long long cap, int obs_bytes, long long start_slot, int n, const uint8_t* obs,
@@ -225,6 +229,9 @@ int a0_is_weights(const float* prio, int B, const float* psum, long long top, fl
 int a0_perm_batch(unsigned long long start, int count, unsigned long long n, unsigned int seed, long long* out, void* stream);
 /* sum-tree (new component, contract in oracle/sumtree.c): tree float[2*cap2] */
 int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, void* stream);
+/* leaves (start + i) % size, i < n, all set to val[0] (device scalar) and their ancestors recomputed: the rollout's new transitions enter at
+ * max_p^alpha (replay.py:45-53) in one launch; same tree as a0_sumtree_set on those pairs */
+int a0_sumtree_set_range(float* tree, long long cap2, long long start, long long n, long long size, const float* val, void* stream);
 int a0_sumtree_rebuild(float* tree, long long cap2, void* stream);
 int a0_sumtree_sample(const float* tree, long long cap2, const float* xi, int B, long long* out_idx, float* out_p, void* stream);
 int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, void* stream);

@@ -294,3 +294,19 @@ def test_replay_ring_full_size_round_trip(hip):
     assert int(io.min()) >= 0 and int(io.max()) < top and io.unique().numel() == B
     assert torch.equal(slot.long(), (head + io) % cap)
     check_rows(out, act, rew, done, io + (written - cap))
+
+
+@pytest.mark.parametrize("size,start,n", [(1000, 0, 1000), (1000, 990, 37), (24, 20, 24), (100000, 99000, 20480), (100000, 5, 1), (1 << 20, (1 << 20) - 3, 20480)])
+def test_sumtree_set_range_equals_batch_set(hip, size, start, n):
+    """a0_sumtree_set_range (one launch per rollout) against the oracle's set on the same (idx, val) pairs, including ring wrap-around."""
+    g = recipe.gen(size + start + n)
+    t = core.SumTree(size)
+    leaves = g.uniform(0.0, 2.0, size).astype(np.float32)
+    t.tree[t.cap2:t.cap2 + size] = leaves
+    t.rebuild()
+    tree = D(hip, t.tree.copy())
+    v = np.float32(g.uniform(0.5, 3.0))
+    idx = (start + np.arange(n)) % size
+    t.set(idx, np.full(n, v, np.float32))
+    hip.sumtree_set_range(tree, t.cap2, start, n, size, D(hip, np.array([v], np.float32)))
+    assert np.array_equal(tree.cpu().numpy(), t.tree)
