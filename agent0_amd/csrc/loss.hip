@@ -125,6 +125,116 @@ extern "C" int a0_select_action(const float* x, long long sb, long long sa, long
     return a0_fail_hip((int)hipGetLastError(), "a0_select_action");
 }
 
+// ------------------------------------------------------------------------------------------------ actor tail for distributional heads
+// Everything between the head GEMM and the chosen action of Actor.act (reference agent.py:25-39 with model.py:163-177 / 190-192
+// behind it) for c51 and qr: the head GEMM leaves its split-K slabs (a0_dense_fwd_partial) and this kernel sums them in slab order and
+// adds the bias (== a0_reduce_bias_act_kernel), applies the dueling combine per atom (== a0_dueling_fwd_kernel), takes the expectation
+// (c51: softmax over atoms x support; qr: mean over quantiles) and the first maximum (== a0_select_action_kernel) and makes the
+// epsilon-greedy draw from the actor's Philox streams (== a0_egreedy_rng_kernel).  Same arithmetic, statement for statement, as the four
+// kernels it replaces; one wave per environment, the row's head outputs live in LDS.
+#include "philox.h"
+__global__ __launch_bounds__(256) void a0_actor_dist_tail_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab, const float* __restrict__ bias,
+                                                                 int ld, int A, int T, int dueling, int mode, const float* __restrict__ atoms, int E,
+                                                                 unsigned long long seed, uint32_t stream_a, uint32_t stream_u, unsigned long long off_a,
+                                                                 unsigned long long off_u, float eps, const long long* __restrict__ ctrl,
+                                                                 const float* __restrict__ eps_ptr, int* __restrict__ action, float* __restrict__ qmax) {
+    extern __shared__ float xs_all[];                    // [4 waves][A*T + T]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    const int er = e < E ? e : E - 1;
+    const int NC = A * T + (dueling ? T : 0);
+    float* xs = xs_all + (size_t)wave * (A * T + T);
+    // head output = slab sum in slab order + bias
+    const float* sp = slabs + (long long)er * ld;
+    for (int c0 = lane; c0 < NC; c0 += 256) {          // four columns x eight slabs requested before any is added; additions in slab order
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nslab; z += 8) {
+            float t[8][4];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + 64 * j;
+                    t[zz][j] = (z + zz < nslab && c < NC) ? sp[(long long)(z + zz) * slab_stride + c] : 0.f;
+                }
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+                if (z + zz < nslab) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += t[zz][j];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + 64 * j;
+            if (c < NC) xs[c] = acc[j] + bias[c];
+        }
+    }
+    __syncthreads();
+    if (dueling) {
+        for (int t = lane; t < T; t += 64) {
+            float s = 0.f;
+            for (int a = 0; a < A; ++a) s += xs[a * T + t];
+            const float mean = s / (float)A;
+            const float v = xs[A * T + t];
+            for (int a = 0; a < A; ++a) xs[a * T + t] = v + (xs[a * T + t] - mean);
+        }
+    }
+    __syncthreads();
+    float best = 0.f;
+    int besta = 0;
+    for (int a = 0; a < A; ++a) {
+        const float* p = xs + a * T;
+        float v;
+        if (mode == 1) {
+            float s = 0.f;
+            for (int t = lane; t < T; t += 64) s += p[t];
+            v = a0_wave_sum(s) / (float)T;
+        } else {
+            float mx = -INFINITY;
+            for (int t = lane; t < T; t += 64) mx = fmaxf(mx, p[t]);
+            mx = a0_wave_max(mx);
+            float se = 0.f, sz = 0.f;
+            for (int t = lane; t < T; t += 64) {
+                float ex = expf(p[t] - mx);
+                se += ex;
+                sz += ex * atoms[t];
+            }
+            se = a0_wave_sum(se);
+            sz = a0_wave_sum(sz);
+            v = sz / se;
+        }
+        if (a == 0 || v > best) { best = v; besta = a; }   // first maximum wins, like torch.argmax on CPU
+    }
+    if (lane != 0 || e >= E) return;
+    if (ctrl) { off_a += (unsigned long long)ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)ctrl[A0_CTRL_RNG_UNIFORM]; }
+    if (eps_ptr) eps = eps_ptr[0];
+    const int ra = (int)(a0_philox_word(seed, stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
+    const float u = (float)(a0_philox_word(seed, stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
+    action[e] = (u > eps) ? besta : ra;
+    qmax[e] = best;
+}
+
+// mode 1: mean over the T quantiles (qr); mode 2: C51 expectation with `atoms` [T]
+extern "C" int a0_actor_dist_tail(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                  const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                  unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax, void* stream) {
+    if (!slabs || !bias || !action || !qmax || E < 1 || A < 1 || T < 1 || nslab < 1 || ld < A * T + (dueling ? T : 0) || slab_stride < (long long)E * ld ||
+        (mode != 1 && mode != 2) || (mode == 2 && !atoms))
+        return a0_fail(A0_EINVAL, "a0_actor_dist_tail: bad argument");
+    const size_t lds = (size_t)4 * (A * T + T) * sizeof(float);
+    if (lds > 160 * 1024) return a0_fail(A0_EINVAL, "a0_actor_dist_tail: head too wide for LDS");
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_actor_dist_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_actor_dist_tail: LDS");
+        configured = lds;
+    }
+    hipLaunchKernelGGL(a0_actor_dist_tail_kernel, dim3((E + 3) / 4), dim3(256), lds, (hipStream_t)stream, slabs, slab_stride, nslab, bias, ld, A, T, dueling, mode, atoms, E,
+                       seed, stream_a, stream_u, off_a, off_u, eps, ctrl, eps_ptr, action, qmax);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail");
+}
+
 // ------------------------------------------------------------------------------------------------ DQN
 // loss[b] = smooth_l1(q[b][a_b] - y_b), y_b = r + gamma_n*(1-d)*q_next[b][a*_b];  dq = w * clamp(q - y, -1, 1) at a_b.
 __global__ void a0_dqn_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next, int A, const int* __restrict__ act,

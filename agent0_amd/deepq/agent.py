@@ -59,7 +59,10 @@ class Actor:
         self.qs = ops.zeros(T)
         # scalar heads take the fused tail (fc1 slabs -> q -> dueling -> argmax -> epsilon-greedy in one kernel, a0_actor_qhead)
         self.fused_tail = self.L.algo in ("dqn", "mdqn") and self.L.feat % 4 == 0 and self.L.A + (1 if self.L.dueling else 0) <= 24
-        self.qmax_all = ops.zeros(T * E) if self.fused_tail else None
+        # distributional heads (c51, qr): head GEMM slabs -> one tail kernel (bias, dueling, expectation, argmax, epsilon-greedy)
+        self.dist_tail = (not self.fused_tail) and self.L.algo in ("c51", "qr") and hasattr(ops, "actor_dist_tail") and 4 * (self.L.A * self.L.T + self.L.T) * 4 <= 160 * 1024
+        self._head_slabs = ops.empty(ops.dense_fwd_partial_slabs(E, self.L.Npad, 512) * E * self.L.Npad) if self.dist_tail else None
+        self.qmax_all = ops.zeros(T * E) if (self.fused_tail or self.dist_tail) else None
         self._qh_scratch = ops.empty(ops.actor_qhead_scratch(E, self.L.feat)) if self.fused_tail else None
         self.stat_mask, self.stat_ret = ops.zeros(T * E), ops.zeros(T * E)
         self.ring_act, self.ring_rew, self.ring_done = ops.zeros(self.n * E, dtype=torch.int32), ops.zeros(self.n * E), ops.zeros(self.n * E)
@@ -90,6 +93,15 @@ class Actor:
                             rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action,
                             self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
             return
+        if self.dist_tail:
+            rng = self.rng
+            dev._dense(self.ws.act3, L.feat, "fc1", self.ws.h, E, True)
+            Wh, bh = dev.wb("head")
+            ns = ops.dense_fwd_partial(self.ws.h, 512, Wh, E, L.Npad, 512, self._head_slabs)
+            ops.actor_dist_tail(self._head_slabs, ns, bh, L.Npad, L.A, L.T, L.dueling, 2 if L.algo == "c51" else 1, self.atoms, E, rng.seed, rng.STREAM_EGREEDY_A,
+                                rng.STREAM_EGREEDY_U, rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action,
+                                self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+            return
         if L.algo == "fqf":
             dev.fqf_taus(self.ws, E)
             dev.head(self.ws, E, self.ws.tau_hat, L.F)
@@ -108,7 +120,7 @@ class Actor:
     def act(self, epsilon):
         one = self.ops.zeros(1)
         self._act_device(epsilon, one)
-        if self.fused_tail:
+        if self.fused_tail or self.dist_tail:
             self.ops.mean_rows(self.qmax_all, 1, self.E, one)
         return self.action.cpu().numpy().astype(np.int64), float(one[0])
 
@@ -158,7 +170,7 @@ class Actor:
                 stage["obs"][sl].copy_(obs0.view(E, -1)); stage["obs_next"][sl].copy_(obs_next.view(E, -1))
                 stage["act"][sl].copy_(self.out_act); stage["rew"][sl].copy_(self.out_rew); stage["done"][sl].copy_(self.out_done)
             self.obs = obs_next
-        if self.fused_tail:
+        if self.fused_tail or self.dist_tail:
             ops.mean_rows(self.qmax_all, T, E, self.qs)          # per-step mean max-Q (agent.py:38,88), all steps at once
 
     def _graph_eligible(self, T, bound, test, state_dict) -> bool:

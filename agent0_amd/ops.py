@@ -367,6 +367,12 @@ class HipOps:
                                               _req(q_on, torch.float32, B * A, "q_on"), _req(q_tg, torch.float32, B * A, "q_tg", optional=True),
                                               _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"), _stream()), "a0_dqn_head_loss_slabs")
 
+    def actor_dist_tail(self, slabs, nslab, bias, ld, A, T, dueling, mode, atoms, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl=None, eps_ptr=None):
+        check(self.lib.a0_actor_dist_tail(_req(slabs, torch.float32, nslab * E * ld, "slabs"), E * ld, nslab, _req(bias, torch.float32, ld, "bias"), ld, A, T, int(dueling),
+                                          mode, _req(atoms, torch.float32, T, "atoms", optional=(mode != 2)), E, seed, stream_a, stream_u, off_a, off_u, float(eps),
+                                          _req(ctrl, torch.int64, 8, "ctrl", optional=True), _req(eps_ptr, torch.float32, 1, "eps_ptr", optional=True),
+                                          _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax"), _stream()), "a0_actor_dist_tail")
+
     def actor_qhead_scratch(self, E, K) -> int:
         return int(self.lib.a0_actor_qhead_scratch(E, K))
 

@@ -135,6 +135,12 @@ int a0_dueling_bwd(const float* dq, float* draw, int ld, int R, int A, int T, in
  * 3 FQF sum (tau[t+1]-tau[t]) x (aux = taus [B][T+1]).  Outputs optional. */
 int a0_select_action(const float* x, long long sb, long long sa, long long st, int B, int A, int T, int mode,
                      const float* aux, int* a_star, float* qsel, float* qmax, void* stream);
+/* Actor.act's tail for distributional heads (c51: mode 2 with atoms [T]; qr: mode 1) in one launch: head slabs (a0_dense_fwd_partial) ->
+ * slab sum + bias -> dueling combine -> expectation -> first-max argmax -> epsilon-greedy draw from the actor's Philox streams.  Same
+ * arithmetic as a0_dense_fwd's reduction + a0_dueling_fwd + a0_select_action + a0_actor_egreedy_rng. */
+int a0_actor_dist_tail(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                       const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                       unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax, void* stream);
 
 /* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
 int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
