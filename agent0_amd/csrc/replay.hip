@@ -239,6 +239,22 @@ extern "C" int a0_perm_batch(unsigned long long start, int count, unsigned long 
 
 // ------------------------------------------------------------------------------------------------ sum-tree
 // Contract: oracle/sumtree.c.  tree[1] root, leaf i at tree[cap2 + i]; ancestors recomputed as left + right.
+// Top of the tree in LDS.  Every level costs one global round trip (store, fence, barrier, load) when it is recomputed in place; the
+// levels with at most A0_ST_TOP nodes are instead recomputed WHOLE from a copy of level A0_ST_TOP staged in LDS (all of its parents, not
+// only the touched ones — by the tree's invariant the untouched ones come out unchanged, bit for bit) and written back once: eleven of a
+// 1 M-leaf tree's twenty levels become LDS work.  Call with level `s0` = min(cap2, A0_ST_TOP) up to date in global memory and a barrier
+// behind its last writes.
+constexpr int A0_ST_TOP = 2048;
+A0_D void a0_sumtree_top(float* __restrict__ tree, long long s0, float* __restrict__ lds) {
+    for (long long p = threadIdx.x; p < s0; p += blockDim.x) lds[s0 + p] = tree[s0 + p];
+    __syncthreads();
+    for (long long span = s0 >> 1; span >= 1; span >>= 1) {
+        for (long long p = span + threadIdx.x; p < 2 * span; p += blockDim.x) lds[p] = lds[2 * p] + lds[2 * p + 1];
+        __syncthreads();
+    }
+    for (long long p = 1 + threadIdx.x; p < s0; p += blockDim.x) tree[p] = lds[p];
+}
+
 __global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict__ tree, long long cap2, const long long* __restrict__ idx,
                                                                const float* __restrict__ val, int n) {
     // single workgroup: leaves first (a later duplicate wins), then one level per barrier, bottom-up.  The indices are staged in LDS
@@ -254,7 +270,9 @@ __global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict_
     }
     __threadfence_block();
     __syncthreads();
-    for (long long span = cap2 >> 1; span >= 1; span >>= 1) {   // span = number of nodes on the level being recomputed
+    __shared__ float top[2 * A0_ST_TOP];
+    const long long s0 = cap2 < A0_ST_TOP ? cap2 : A0_ST_TOP;
+    for (long long span = cap2 >> 1; span >= s0; span >>= 1) {  // span = number of nodes on the level being recomputed
         const int shift = __builtin_ctzll(cap2 / span);          // leaf -> ancestor on this level
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const long long p = (cap2 + sidx[i]) >> shift;
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict_
         __threadfence_block();
         __syncthreads();
     }
+    a0_sumtree_top(tree, s0, top);
 }
 
 // Leaves (start + i) % size, i < n, all set to val[0] — what ReplayDataset.extend does for a rollout's new transitions (replay.py:45-53:
@@ -276,7 +295,9 @@ __global__ __launch_bounds__(1024) void a0_sumtree_set_range_kernel(float* __res
     for (long long i = threadIdx.x; i < n; i += blockDim.x) tree[cap2 + (i < n1 ? start + i : i - n1)] = v;
     __threadfence_block();
     __syncthreads();
-    for (long long span = cap2 >> 1; span >= 1; span >>= 1) {
+    __shared__ float top[2 * A0_ST_TOP];
+    const long long s0 = cap2 < A0_ST_TOP ? cap2 : A0_ST_TOP;
+    for (long long span = cap2 >> 1; span >= s0; span >>= 1) {
         const int shift = __builtin_ctzll(cap2 / span);
         const long long a0 = (cap2 + start) >> shift, a1 = (cap2 + start + n1 - 1) >> shift;
         const long long ca = a1 - a0 + 1;
@@ -289,6 +310,7 @@ __global__ __launch_bounds__(1024) void a0_sumtree_set_range_kernel(float* __res
         __threadfence_block();
         __syncthreads();
     }
+    a0_sumtree_top(tree, s0, top);
 }
 
 extern "C" int a0_sumtree_set_range(float* tree, long long cap2, long long start, long long n, long long size, const float* val, void* stream) {
