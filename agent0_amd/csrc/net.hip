@@ -268,6 +268,24 @@ extern "C" int a0_dense_fwd(const float* X, int ldx, const float* W, const float
     A0_CATCH
 }
 
+// Y[r][:] = act(X[r] W^T + b) * M[r / group][:] — the quantile networks' embedding times the state features in the GEMM's epilogue
+// (reference model.py:244-247: relu(cosine_emb(cos(pi i tau))) * features), for passes that are not differentiated: the embedding never
+// goes to HBM and the Hadamard pass disappears.  Only for shapes whose forward GEMM is not split (a0_dense_fwd_scratch == 0).
+extern "C" int a0_dense_fwd_mul(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* Y, int R, int N, int K, int relu, void* stream) {
+    A0_TRY
+    if (!X || !W || !b || !M || !Y || R < 1 || group < 1 || (N & 3) || (K & 3) || (ldx & 3)) return a0_fail(A0_EINVAL, "a0_dense_fwd_mul: bad shape (N, K, ldx must be multiples of 4)");
+    if (a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K) != 1) return a0_fail(A0_EINVAL, "a0_dense_fwd_mul: this shape runs as a split GEMM; use a0_dense_fwd + a0_hadamard_fwd");
+    a0_hip_backend bk{(hipStream_t)stream};
+    a0_mat_src a{X, ldx};
+    a0_mat_src bw{W, K};
+    EpiBiasActMul::Params e{Y, b, N, relu, M, group, a0_udiv_magic((unsigned)group)};
+    bk.tag = A0_TAG_DENSE_FWD;
+    if (N <= 32) bk.template igemm<OpMatKC, OpMatKC, EpiBiasActMul, 4, 1, 1, 1>(a, bw, e, R, N, K, 1);
+    else bk.template igemm<OpMatKC, OpMatKC, EpiBiasActMul, 4, 1, 1, 2>(a, bw, e, R, N, K, 1);
+    return A0_OK;
+    A0_CATCH
+}
+
 // The split-K GEMM of a0_dense_fwd WITHOUT its reduction: slab z = X W^T over the z-th k range, [R][N] each at stride R*N; the caller's
 // next kernel sums the slabs (a0_dqn_head_loss_slabs, a0_actor_qhead).  Returns the slab count.
 extern "C" int a0_dense_fwd_partial_slabs(int R, int N, int K) {

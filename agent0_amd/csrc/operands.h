@@ -225,6 +225,17 @@ struct EpiBiasAct {            // y = act(v + bias[y]);  relu keeps NaN like tor
     }
 };
 
+struct EpiBiasActMul {         // y = act(v + bias[y]) * mul[(x / group)][y]: the IQN / FQF embedding relu(cos W + b) times the state features (model.py:244-247)
+    static constexpr bool ROWSUM_A = false;
+    struct Params { float* out; const float* bias; int ld; int relu; const float* mul; int group; unsigned group_magic; };
+    A0_HD static void store(const Params& P, int x, int y, float v, int) {
+        v += P.bias[y];
+        if (P.relu) v = (v < 0.f) ? 0.f : v;
+        const int g = a0_udiv(x, P.group, P.group_magic);
+        P.out[(long long)x * P.ld + y] = v * P.mul[(long long)g * P.ld + y];
+    }
+};
+
 struct EpiSlab {               // raw partial sums, one slab per z (split-K forward, weight gradients)
     static constexpr bool ROWSUM_A = false;
     struct Params { float* out; long long slab_stride; int ld; };

@@ -25,7 +25,7 @@ class Workspace:
     """Activations of one forward pass over ``B`` observations (``n_tau`` quantile samples each for IQN/FQF)."""
 
     def __init__(self, ops, L: NetLayout, B: int, n_tau: int = 1, grads: bool = False):
-        self.B, self.n_tau = B, n_tau
+        self.B, self.n_tau, self.grads = B, n_tau, grads
         R = B * n_tau if L.quantile else B
         self.R = R
         self.act1 = ops.empty(B * L.H1 * L.W1 * 32)
@@ -193,8 +193,13 @@ class DeviceNet:
             return ws.q
         R = B * n_tau
         ops.cos_features(taus, ws.cosx, R, L.num_cosines)
-        self._dense(ws.cosx, L.num_cosines, "cos", ws.emb, R, True)
-        ops.hadamard_fwd(ws.emb, feat, ws.x, B, n_tau, L.feat)
+        if ws.emb is None or (not ws.grads and hasattr(ops, "dense_fwd_mul") and ops.dense_fwd_scratch(R, L.feat, L.num_cosines) == 0):
+            # a pass that is not differentiated: embedding x features in the GEMM's epilogue, the embedding never reaches HBM
+            Wc, bc = self.wb("cos")
+            ops.dense_fwd_mul(ws.cosx, L.num_cosines, Wc, bc, feat, n_tau, ws.x, R, L.feat, L.num_cosines, True)
+        else:
+            self._dense(ws.cosx, L.num_cosines, "cos", ws.emb, R, True)
+            ops.hadamard_fwd(ws.emb, feat, ws.x, B, n_tau, L.feat)
         self._dense(ws.x, L.feat, "fc1", ws.h, R, True)
         self._dense(ws.h, 512, "head", ws.raw, R, False)
         ops.dueling_fwd(ws.raw, L.Npad, ws.q, R, L.A, 1, L.dueling)

@@ -173,6 +173,11 @@ class HipOps:
                                     _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu),
                                     _req(scratch, torch.float32, need, "scratch", optional=(need == 0)), _stream()), "a0_dense_fwd")
 
+    def dense_fwd_mul(self, X, ldx, W, b, M, group, Y, R, N, K, relu):
+        check(self.lib.a0_dense_fwd_mul(_req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx, _req(W, torch.float32, N * K, "W"), _req(b, torch.float32, N, "b"),
+                                        _req(M, torch.float32, ((R - 1) // group + 1) * N, "M"), group, _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu), _stream()),
+              "a0_dense_fwd_mul")
+
     def dense_dgrad(self, dY, W, mask, dX, R, N, K):
         check(self.lib.a0_dense_dgrad(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"),
                                       _req(mask, torch.float32, R * K, "mask", optional=True), _req(dX, torch.float32, R * K, "dX"), R, N, K, _stream()), "a0_dense_dgrad")

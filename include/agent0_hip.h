@@ -108,6 +108,10 @@ int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, in
 int a0_dense_wgrad_multi(int n, const float* const* dY, const float* const* X, const int* ldx, float* const* grad_w_b, const int* R, const int* N, const int* K,
                          float* slabs, const long long* slab_off, void* stream);
 
+/* Y[r] = act(X[r] W^T + b) * M[r / group]: the IQN / FQF embedding relu(cosine_emb(...)) times the state features (model.py:244-247) in the
+ * GEMM's epilogue, for passes that are not differentiated; only when a0_dense_fwd_scratch(R, N, K) == 0 (unsplit GEMM) */
+int a0_dense_fwd_mul(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* Y, int R, int N, int K, int relu, void* stream);
+
 /* a0_dense_fwd without its slab reduction: slab z of [R][N] at stride R*N holds X W^T over the z-th k range; the consumer kernel sums the
  * a0_dense_fwd_partial_slabs(R, N, K) slabs in order, adds the bias and applies the activation (a0_dqn_head_loss_slabs) */
 int a0_dense_fwd_partial_slabs(int R, int N, int K);
