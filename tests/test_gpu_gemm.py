@@ -112,3 +112,46 @@ def test_split_is_exact_for_extreme_operands(hip):
     want = (x.astype(np.float64)[:, None] * w.astype(np.float64)[None, :])
     # nine exact partial products summed in fp32: the result is the fp32 product up to the roundings of 8 small additions
     assert np.all(np.abs(got - want) <= 4 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64))
+
+
+def test_dense_fwd_mul_equals_dense_fwd_then_hadamard(hip):
+    """a0_dense_fwd_mul (embedding x state features in the GEMM's epilogue, model.py:244-247) against a0_dense_fwd + a0_hadamard_fwd:
+    bit-identical, and against fp64."""
+    B, n, N, K = 40, 32, 3136, 64             # 1280 rows: an unsplit GEMM
+    R = B * n
+    assert hip.dense_fwd_scratch(R, N, K) == 0
+    g = recipe.gen(11)
+    X = g.standard_normal((R, K)).astype(np.float32)
+    W = (g.standard_normal((N, K)) * 0.1).astype(np.float32)
+    b = g.standard_normal(N).astype(np.float32)
+    M = g.standard_normal((B, N)).astype(np.float32)
+    Xd, Wd, bd, Md = D(hip, X), D(hip, W), D(hip, b), D(hip, M)
+    fused, emb, ref = hip.empty(R * N), hip.empty(R * N), hip.empty(R * N)
+    hip.dense_fwd_mul(Xd, K, Wd, bd, Md, n, fused, R, N, K, 1)
+    hip.dense_fwd(Xd, K, Wd, bd, emb, R, N, K, 1, None)
+    hip.hadamard_fwd(emb, Md, ref, B, n, N)
+    assert torch.equal(fused, ref)
+    want = np.maximum(X.astype(np.float64) @ W.astype(np.float64).T + b, 0) * np.repeat(M.astype(np.float64), n, axis=0)
+    scale = (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)) * np.abs(np.repeat(M.astype(np.float64), n, axis=0)) + 1e-30
+    assert float((np.abs(fused.cpu().numpy().reshape(R, N) - want) / scale).max()) < 2e-6
+
+
+def test_dense_wgrad_multi_equals_single_calls(hip):
+    """a0_dense_wgrad_multi (head + fc1 + cosine-embedding weight gradients, one slab reduction) against one a0_dense_wgrad per layer:
+    bit-identical gradient blocks."""
+    g = recipe.gen(12)
+    R = 512
+    shapes = [(R, 32, 512), (R, 512, 3136), (R, 3136, 64)]
+    layers, singles = [], []
+    for (r, N, K) in shapes:
+        dY = D(hip, g.standard_normal((r, N)).astype(np.float32))
+        X = D(hip, g.standard_normal((r, K)).astype(np.float32))
+        G1, G2 = hip.empty(N * K + N), hip.empty(N * K + N)
+        layers.append((dY, X, K, G1, r, N, K))
+        singles.append((dY, X, K, G2, r, N, K))
+    slabs = hip.empty(max(hip.dense_wgrad_multi_scratch(shapes), 4))
+    hip.dense_wgrad_multi(layers, slabs)
+    for (dY, X, ldx, G2, r, N, K) in singles:
+        hip.dense_wgrad(dY, X, ldx, G2, r, N, K, hip.empty(max(hip.dense_wgrad_scratch(r, N, K), 4)))
+    for a, b in zip(layers, singles):
+        assert torch.equal(a[3], b[3])

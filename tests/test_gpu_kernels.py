@@ -310,3 +310,30 @@ def test_sumtree_set_range_equals_batch_set(hip, size, start, n):
     t.set(idx, np.full(n, v, np.float32))
     hip.sumtree_set_range(tree, t.cap2, start, n, size, D(hip, np.array([v], np.float32)))
     assert np.array_equal(tree.cpu().numpy(), t.tree)
+
+
+def test_noisy_multi_equals_per_module_kernels(hip):
+    """a0_noisy_multi (all NoisyLinear modules of a network in one launch) against a0_noisy_compose / a0_noisy_grad_sigma per module:
+    bit-identical effective weights and sigma gradients (reference model.py:54-62,78-83)."""
+    g = recipe.gen(21)
+    mods_spec = [(512, 3136, 0, 512), (256, 512, 0, 204), (256, 512, 204, 255)]      # fc1; q_head and value_head rows of one packed block
+    def blk(N, K):
+        return D(hip, g.standard_normal(N * K + N).astype(np.float32))
+    blocks = {}
+    mods_c, mods_g, per = [], [], []
+    for (N, K, r0, r1) in mods_spec:
+        key = (N, K)
+        if key not in blocks:
+            blocks[key] = (blk(N, K), blk(N, K), hip.zeros(N * K + N), hip.zeros(N * K + N), hip.zeros(N * K + N), hip.zeros(N * K + N))
+        mu, sg, eff_a, eff_b, gs_a, gs_b = blocks[key]
+        nin = D(hip, g.standard_normal(K).astype(np.float32)); now = D(hip, g.standard_normal(r1 - r0).astype(np.float32)); nob = D(hip, g.standard_normal(r1 - r0).astype(np.float32))
+        mods_c.append((mu, sg, eff_a, N, K, r0, r1, nin, now, nob))
+        mods_g.append((mu, None, gs_a, N, K, r0, r1, nin, now, nob))
+        per.append((mu, sg, eff_b, gs_b, N, K, r0, r1, nin, now, nob))
+    hip.noisy_multi(False, mods_c)
+    hip.noisy_multi(True, mods_g)
+    for (mu, sg, eff_b, gs_b, N, K, r0, r1, nin, now, nob) in per:
+        hip.noisy_compose(mu, sg, eff_b, N, K, r0, r1, nin, now, nob)
+        hip.noisy_grad_sigma(mu, gs_b, N, K, r0, r1, nin, now, nob)
+    for (mu, sg, eff_a, eff_b, gs_a, gs_b) in blocks.values():
+        assert torch.equal(eff_a, eff_b) and torch.equal(gs_a, gs_b)
