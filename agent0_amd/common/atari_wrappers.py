@@ -51,6 +51,20 @@ class DeviceSynthVecEnv:
     def obs(self) -> torch.Tensor:
         return self._obs[self._cur]
 
+    def set_history(self, k: int):
+        """Keep the last ``k`` observations addressable (k >= 2 buffers, cycled): an n-step actor reads the observation of n-1 steps ago
+        straight from here (``history``) instead of copying every observation into a ring of its own."""
+        k = max(int(k), 2)
+        if k != len(self._obs):
+            n = self._obs[0].numel()
+            cur = self._obs[self._cur]
+            self._obs = [cur] + [self.ops.zeros(n, dtype=torch.uint8) for _ in range(k - 1)]
+            self._cur = 0
+
+    def history(self, j: int) -> torch.Tensor:
+        """The observation of ``j`` steps ago (0 = current); valid for j < number of buffers - 1 while the next step is being written."""
+        return self._obs[(self._cur - j) % len(self._obs)]
+
     def reset(self, **kwargs):
         self.g = 0
         self._cur = 0
@@ -61,7 +75,7 @@ class DeviceSynthVecEnv:
         """``final_mask`` / ``final_ret``: optional caller buffers for the finished-episode record of this step (the gymnasium
         ``info["final_info"]`` / ``info["_final_info"]`` pair, agent.py:85-88)."""
         self.g += 1
-        nxt = 1 - self._cur
+        nxt = (self._cur + 1) % len(self._obs)
         fm = self.final_mask if final_mask is None else final_mask
         fr = self.final_ret if final_ret is None else final_ret
         self.ops.env_step(self.seed, self.rank, self.E, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, self.reward,
@@ -74,7 +88,7 @@ class DeviceSynthVecEnv:
         """``step`` + the actor's n-step bookkeeping + the replay row commit in one launch (a0_env_synth_step_commit); ``obs0`` is the first
         observation of the emitted transition, ``replay`` anything with frames / size / act / rew / done (ReplayDataset, StageRing)."""
         self.g += 1
-        nxt = 1 - self._cur
+        nxt = (self._cur + 1) % len(self._obs)
         self.ops.env_step_commit(self.seed, self.rank, self.E, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps, gamma,
                                  action, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done, ctrl)
         self._cur = nxt

@@ -70,7 +70,11 @@ class Actor:
         # slot pattern of a rollout repeats (required for hipGraph replay)
         T_ = int(cfg.actor.sample_steps)
         self.ring_len = next((r for r in range(self.n, 2 * self.n + 1) if T_ % r == 0), self.n)
-        self.ring_obs = ops.zeros(self.ring_len * E * self.obs_bytes, dtype=torch.uint8) if self.n > 1 else None
+        # a device env that keeps its own observation history needs no copy at all: n + 1 (or the next divisor of the rollout length) buffers
+        self.env_history = self.n > 1 and hasattr(self.envs, "set_history")
+        if self.env_history:
+            self.envs.set_history(next((r for r in range(self.n + 1, 2 * self.n + 3) if T_ % r == 0), self.n + 1))
+        self.ring_obs = ops.zeros(self.ring_len * E * self.obs_bytes, dtype=torch.uint8) if (self.n > 1 and not self.env_history) else None
         self.use_graph = True
         self._graph, self._graph_warm = None, 0
         self.ctrl = ops.zeros(8, dtype=torch.int64)
@@ -137,10 +141,11 @@ class Actor:
                 self.model.reset_noise(rng=self.rng)
             self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t)
             cur_obs = self.obs
-            if self.n > 1:
+            if self.n > 1 and self.env_history:
+                obs0 = self.envs.history(min(self.steps + 1, self.n) - 1)         # first observation of the emitted n-step transition
+            elif self.n > 1:
                 slot = self.steps % R
                 self.ring_obs[slot * E * self.obs_bytes:(slot + 1) * E * self.obs_bytes].copy_(cur_obs)
-            if self.n > 1:
                 count = min(self.steps + 1, self.n)
                 oldest = (self.steps - (count - 1)) % R
                 obs0 = self.ring_obs[oldest * E * self.obs_bytes:(oldest + 1) * E * self.obs_bytes]
@@ -175,8 +180,8 @@ class Actor:
 
     def _graph_eligible(self, T, bound, test, state_dict) -> bool:
         cfg = self.cfg
-        return (self.use_graph and bound and not test and state_dict is None and T % 2 == 0 and hasattr(self.envs, "_cur")
-                and (not cfg.learner.noisy_net or T % cfg.learner.reset_noise_freq == 0) and (self.n == 1 or T % self.ring_len == 0))
+        return (self.use_graph and bound and not test and state_dict is None and hasattr(self.envs, "_cur") and T % len(self.envs._obs) == 0
+                and (not cfg.learner.noisy_net or T % cfg.learner.reset_noise_freq == 0) and (self.n == 1 or self.env_history or T % self.ring_len == 0))
 
     def _snapshot(self):
         rng = self.rng
