@@ -7,6 +7,7 @@
 // (agent.py:78-81): slot -> [8][H][W] u8 = st || st_next; 56 448 B per transition at 84x84, so 1 M transitions
 // = 56.4 GB of the 288 GB HBM.  Integer / index results are bit-exact against oracle/sumtree.c.
 #include "a0_internal.h"
+#include "philox.h"
 
 #pragma clang fp contract(off)
 
@@ -390,6 +391,57 @@ extern "C" int a0_sumtree_sample(const float* tree, long long cap2, const float*
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_sample");
 }
 
+
+// ------------------------------------------------------------------------------------------------ prioritized batch in one launch
+// The stratified uniforms (element b of the sampler's Philox stream: the value a0_rng_uniform would write), the sum-tree descent, the
+// slot / metadata lookup and the importance weights w = (top * p / total)^-beta / (max w + 1e-8) (trainer.py:91-94) for one batch:
+// == a0_rng_uniform + a0_sumtree_sample + a0_replay_lookup + a0_is_weights, statement for statement.  Single workgroup, B <= 1024.
+__global__ __launch_bounds__(1024) void a0_sumtree_batch_kernel(unsigned long long seed, uint32_t stream, unsigned long long offset, const float* __restrict__ tree,
+                                                                 long long cap2, int B, long long top, long long cap, float beta, const int* __restrict__ r_act,
+                                                                 const float* __restrict__ r_rew, const float* __restrict__ r_done, long long* __restrict__ idx_out,
+                                                                 int* __restrict__ slot_out, int* __restrict__ act, float* __restrict__ rew, float* __restrict__ done,
+                                                                 float* __restrict__ prio, float* __restrict__ w) {
+    __shared__ float red[1024];
+    const float total = tree[1];
+    const float seg = total / (float)B;
+    float mx = 0.f;
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const float xi = (float)(a0_philox_word(seed, stream, offset + (unsigned long long)k) >> 8) * 0x1.0p-24f;
+        float u = ((float)k + xi) * seg;
+        long long n = 1;
+        while (n < cap2) {
+            const float left = tree[2 * n];
+            const float right = tree[2 * n + 1];
+            if (u < left || !(right > 0.0f)) { n = 2 * n; } else { u -= left; n = 2 * n + 1; }
+        }
+        const long long li = (n - cap2) % cap;          // sum-tree leaves are addressed by ring slot (head = 0): logical index == slot
+        const long long sl = li;
+        const float p = tree[n];
+        idx_out[k] = li; slot_out[k] = (int)sl; act[k] = r_act[sl]; rew[k] = r_rew[sl]; done[k] = r_done[sl];
+        prio[k] = p;
+        const float probs = p / total;
+        const float v = powf((float)top * probs, -beta);
+        w[k] = v;
+        mx = fmaxf(mx, v);
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    const float denom = red[0] + 1e-8f;
+    for (int k = threadIdx.x; k < B; k += blockDim.x) w[k] = w[k] / denom;
+}
+
+extern "C" int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, const float* tree, long long cap2, int B, long long top,
+                                       long long cap, float beta, const int* r_act, const float* r_rew, const float* r_done, long long* idx_out, int* slot_out,
+                                       int* act, float* rew, float* done, float* prio, float* w, void* stream_h) {
+    if (!tree || !r_act || !r_rew || !r_done || !idx_out || !slot_out || !act || !rew || !done || !prio || !w || B < 1 || B > 1024 || top < 1 || cap < top ||
+        cap2 < cap || (cap2 & (cap2 - 1)) || cap > 2147483647LL)
+        return a0_fail(A0_EINVAL, "a0_sumtree_sample_batch: bad argument");
+    int threads = 64; while (threads < B && threads < 1024) threads <<= 1;
+    hipLaunchKernelGGL(a0_sumtree_batch_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream_h, seed, stream, offset, tree, cap2, B, top, cap, beta, r_act, r_rew, r_done,
+                       idx_out, slot_out, act, rew, done, prio, w);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_sample_batch");
+}
 
 // ------------------------------------------------------------------------------------------------ fused sample + gather
 // One launch draws the batch indices AND copies the rows: workgroup column b computes its own index (mode 0: Feistel permutation

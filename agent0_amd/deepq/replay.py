@@ -243,7 +243,13 @@ class ReplayDataset:
     def sample(self, B: Optional[int] = None) -> Batch:
         B = B or self.B
         assert B == self.B
-        if self.use_sumtree:
+        if self.use_sumtree and hasattr(self.ops, "sumtree_sample_batch") and B <= 1024:
+            # stratified draws, descent, slot + metadata and importance weights in one launch
+            rng = self.rng
+            self.ops.sumtree_sample_batch(rng.seed, rng.STREAM_SUMTREE, rng.reserve(rng.STREAM_SUMTREE, B), self.tree, self.cap2, B, self.top, self.size, float(self.beta),
+                                          self.act, self.rew, self.done, self._idx, self._slot, self._act, self._rew, self._done, self._prio, self._w)
+            idx = self._idx
+        elif self.use_sumtree:
             self.rng.uniform(self.rng.STREAM_SUMTREE, self._xi, B)
             self.ops.sumtree_sample(self.tree, self.cap2, self._xi, B, self._idx, self._prio)
             # sum-tree leaves are addressed by ring slot: logical index == slot, no deque shift (head = 0)

@@ -414,6 +414,13 @@ class HipOps:
     def sumtree_set(self, tree, cap2, idx, val, n):
         check(self.lib.a0_sumtree_set(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(val, torch.float32, n, "val"), n, _stream()), "a0_sumtree_set")
 
+    def sumtree_sample_batch(self, seed, stream, offset, tree, cap2, B, top, cap, beta, r_act, r_rew, r_done, idx_out, slot_out, act, rew, done, prio, w):
+        check(self.lib.a0_sumtree_sample_batch(seed, stream, offset, _req(tree, torch.float32, 2 * cap2, "tree"), cap2, B, top, cap, float(beta),
+                                               _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
+                                               _req(idx_out, torch.int64, B, "idx_out"), _req(slot_out, torch.int32, B, "slot_out"), _req(act, torch.int32, B, "act"),
+                                               _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"), _req(prio, torch.float32, B, "prio"),
+                                               _req(w, torch.float32, B, "w"), _stream()), "a0_sumtree_sample_batch")
+
     def sumtree_set_range(self, tree, cap2, start, n, size, val):
         check(self.lib.a0_sumtree_set_range(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, start, n, size, _req(val, torch.float32, 1, "val"), _stream()),
               "a0_sumtree_set_range")

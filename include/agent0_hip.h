@@ -244,6 +244,11 @@ int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const floa
 int a0_sumtree_set_range(float* tree, long long cap2, long long start, long long n, long long size, const float* val, void* stream);
 int a0_sumtree_rebuild(float* tree, long long cap2, void* stream);
 int a0_sumtree_sample(const float* tree, long long cap2, const float* xi, int B, long long* out_idx, float* out_p, void* stream);
+/* one prioritized batch in one launch: stratified uniforms from the sampler's Philox stream, sum-tree descent, slot + metadata lookup and
+ * importance weights (trainer.py:91-94); == a0_rng_uniform + a0_sumtree_sample + a0_replay_lookup + a0_is_weights.  B <= 1024. */
+int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, const float* tree, long long cap2, int B, long long top,
+                            long long cap, float beta, const int* r_act, const float* r_rew, const float* r_done, long long* idx_out, int* slot_out,
+                            int* act, float* rew, float* done, float* prio, float* w, void* stream_h);
 int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, void* stream);
 
 /* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */

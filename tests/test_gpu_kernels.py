@@ -337,3 +337,28 @@ def test_noisy_multi_equals_per_module_kernels(hip):
         hip.noisy_grad_sigma(mu, gs_b, N, K, r0, r1, nin, now, nob)
     for (mu, sg, eff_a, eff_b, gs_a, gs_b) in blocks.values():
         assert torch.equal(eff_a, eff_b) and torch.equal(gs_a, gs_b)
+
+
+def test_sumtree_sample_batch_equals_separate_kernels(hip):
+    """a0_sumtree_sample_batch (draws + descent + lookup + importance weights, one launch) against a0_rng_uniform + a0_sumtree_sample +
+    a0_replay_lookup + a0_is_weights: identical indices, slots, metadata, priorities and weights."""
+    size, B = 100000, 512
+    g = recipe.gen(31)
+    t = core.SumTree(size)
+    t.tree[t.cap2:t.cap2 + size] = g.uniform(0.0, 2.0, size).astype(np.float32)
+    t.tree[t.cap2 + 100:t.cap2 + 5000] = 0.0          # a dead stretch the descent must never enter
+    t.rebuild()
+    tree = D(hip, t.tree)
+    r_act = D(hip, g.integers(0, 18, size).astype(np.int32)); r_rew = D(hip, g.standard_normal(size).astype(np.float32)); r_done = D(hip, (g.random(size) < 0.1).astype(np.float32))
+    seed, stream, off, top, beta = 0x1234_0000_002A, 5, 4096, 77777, 0.45
+    xi, idx0, p0 = hip.zeros(B), hip.zeros(B, dtype=torch.int64), hip.zeros(B)
+    hip.rng_uniform(seed, stream, off, xi, B)
+    hip.sumtree_sample(tree, t.cap2, xi, B, idx0, p0)
+    slot0, act0, rew0, done0, io0, w0 = hip.zeros(B, dtype=torch.int32), hip.zeros(B, dtype=torch.int32), hip.zeros(B), hip.zeros(B), hip.zeros(B, dtype=torch.int64), hip.zeros(B)
+    hip.replay_lookup(idx0, B, size, 0, size, slot0, r_act, r_rew, r_done, None, act0, rew0, done0, None, io0)
+    hip.is_weights(p0, B, tree[1:2], top, beta, w0)
+    idx1, slot1, act1, rew1, done1, p1, w1 = hip.zeros(B, dtype=torch.int64), hip.zeros(B, dtype=torch.int32), hip.zeros(B, dtype=torch.int32), hip.zeros(B), hip.zeros(B), hip.zeros(B), hip.zeros(B)
+    hip.sumtree_sample_batch(seed, stream, off, tree, t.cap2, B, top, size, beta, r_act, r_rew, r_done, idx1, slot1, act1, rew1, done1, p1, w1)
+    for a, b in ((idx0, idx1), (slot0, slot1), (act0, act1), (rew0, rew1), (done0, done1), (p0, p1), (w0, w1)):
+        assert torch.equal(a, b)
+    assert float(w1.max()) <= 1.0 and float(p1.min()) > 0.0
