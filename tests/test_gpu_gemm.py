@@ -31,7 +31,8 @@ def _scale_close(got, want64, scale64, what, tol=2e-6):
     assert float(err.max()) < tol, f"{what}: {float(err.max()):.3e} of the accumulated magnitude"
 
 
-SHAPES = [(1, 4, 512), (7, 36, 100), (256, 512, 3136), (300, 40, 64), (512, 32, 512), (513, 132, 96), (64, 512, 36), (2048, 64, 3136)]
+SHAPES = [(1, 4, 512), (7, 36, 100), (256, 512, 3136), (300, 40, 64), (512, 32, 512), (513, 132, 96), (64, 512, 36), (2048, 64, 3136),
+          (16384, 512, 96), (16500, 64, 256)]      # the last two reach the large-tile kernels (forward: 512 tiles of 128 x 128; data gradient: 258)
 
 
 @pytest.mark.parametrize("R,N,K", SHAPES)
