@@ -170,21 +170,30 @@ class Trainer:
         if self.use_lp:
             torch.cuda.synchronize()                # the test actor shares the learner's weights: no update may be in flight
         rs = []
+        video = []
         self.logger.info("Testing ... ")
         self.actors[0].reset()
         guard = 0
         while len(rs) < cfg.trainer.test_episodes and guard < 200:
-            _, returns, _ = self.actors[0].sample(cfg.actor.test_eps, test=True)
+            images, returns, _ = self.actors[0].sample(cfg.actor.test_eps, test=True)
             rs.extend(returns)
+            if len(video) < 3600:                   # trainer.py:131-132: the newest frame of the first four envs, per step
+                video.extend(images)
             guard += 1
         self.RTs.extend(rs)
+        # trainer.py:134-135: (n, t, c, h, w) uint8 with the grey channel repeated three times
+        self.last_test_video = np.repeat(np.stack(video, axis=1), 3, axis=2) if video else None
         if rs:
             if self.writer is not None:
                 self.writer.add_scalar("return_test", np.mean(rs), self.frame_count)
                 self.writer.add_scalar("return_test_max", np.max(self.RTs), self.frame_count)
+                if self.last_test_video is not None and hasattr(self.writer, "add_video"):
+                    self.writer.add_video("test_video", self.last_test_video, self.frame_count, fps=60)
             if self._wandb is not None:
                 self._wandb.log({"return_test": np.mean(rs), "frame": self.frame_count})
                 self._wandb.log({"return_test_max": np.max(self.RTs), "frame": self.frame_count})
+                if self.last_test_video is not None:
+                    self._wandb.log({"test_video": self._wandb.Video(self.last_test_video, fps=60, format="mp4"), "frame": self.frame_count})
             self.logger.info(f"TEST ---> Frames: {self.frame_count} | Return Avg: {np.mean(rs):.2f} Max: {np.max(rs)}")
         return rs
 

@@ -199,6 +199,10 @@ def test_checkpoint_roundtrip_and_modes(tmp_path):
     tr3 = Trainer(cfg)
     tr3.run()
     assert tr3.learner.update_steps == 0 and torch.equal(tr3.learner.engine.online.flat, e1.online.flat)
+    # the evaluation's video (trainer.py:131-135): newest frame of the first four envs per step, grey channel repeated three times
+    v = tr3.last_test_video
+    assert v is not None and v.dtype == np.uint8 and v.shape[0] == 4 and v.shape[2:] == (3, 84, 84) and v.shape[1] >= cfg.actor.sample_steps
+    assert np.array_equal(v[:, :, 0], v[:, :, 1]) and np.array_equal(v[:, :, 0], v[:, :, 2])
 
 
 def test_host_env_adapter_matches_device_env():
