@@ -9,6 +9,8 @@
 #include "a0_internal.h"
 #include "philox.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------------------ insert / gather
@@ -501,7 +503,13 @@ __global__ __launch_bounds__(256) void a0_sample_gather_kernel(int mode, unsigne
     const int q = row_bytes >> 4;
     const uint4* s = (const uint4*)(frames + s_slot * row_bytes);
     uint4* d = (uint4*)(out + (long long)b * row_bytes);
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) d[j] = s[j];
+    const int step = gridDim.x * blockDim.x;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; j + 3 * step < q; j += 4 * step) {          // four 16-byte loads in flight per lane before the first store
+        const uint4 v0 = s[j], v1 = s[j + step], v2 = s[j + 2 * step], v3 = s[j + 3 * step];
+        d[j] = v0; d[j + step] = v1; d[j + 2 * step] = v2; d[j + 3 * step] = v3;
+    }
+    for (; j < q; j += step) d[j] = s[j];
 }
 
 // Uniform sampling without the row copy (the learner reads ring rows through the slot index): permutation element start + b of the
@@ -551,7 +559,11 @@ extern "C" int a0_replay_sample_gather(int mode, unsigned long long start, unsig
     if (mode == 0 && (n_perm < 1 || start + (unsigned long long)B > n_perm)) return a0_fail(A0_EINVAL, "a0_replay_sample_gather: permutation window out of range");
     if (mode == 1 && (!tree || !xi || cap2 < 1 || (cap2 & (cap2 - 1)))) return a0_fail(A0_EINVAL, "a0_replay_sample_gather: sum-tree arguments");
     if (mode != 0 && mode != 1) return a0_fail(A0_EINVAL, "a0_replay_sample_gather: mode");
-    int gx = ((row_bytes >> 4) + 255) / 256; if (gx > 4) gx = 4;
+    // three workgroups per row: 768 lanes x four 16-byte loads cover 3072 of a row's 3528 vectors in one unrolled trip (12.8 us per
+    // 512-row batch = 2.25 TB/s sampled, 4.5 TB/s of HBM traffic; 14.4 us with four workgroups and one load in flight; non-temporal
+    // loads / stores measured slower: tools/ubench_gather.py).  A0_GATHER_GX: tuning aid.
+    static const int gx_cap = getenv("A0_GATHER_GX") ? atoi(getenv("A0_GATHER_GX")) : 3;
+    int gx = ((row_bytes >> 4) + 255) / 256; if (gx > gx_cap) gx = gx_cap;
     hipLaunchKernelGGL(a0_sample_gather_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, mode, start, n_perm, seed, tree, cap2, xi, top, head, cap, frames,
                        row_bytes, r_act, r_rew, r_done, priority, B, out, idx_out, slot_out, act, rew, done, prio);
     return a0_fail_hip((int)hipGetLastError(), "a0_replay_sample_gather");
