@@ -92,7 +92,7 @@ extern "C" int a0_env_synth_step(unsigned long long seed, unsigned int rank, int
 // replay.py:45-53).  Same arithmetic, same draws, same bytes as the three separate kernels — checked byte for byte against the
 // oracle actor in tests/test_gpu_trainer.py — but the 28 KB observation is read once instead of twice and two launches disappear
 // from every actor step.  obs0 = the observation the emitted transition starts from (obs_in itself for n = 1, the ring entry of
-// n - 1 steps ago otherwise).  Grid (7, E) like a0_env_step_kernel.
+// n - 1 steps ago otherwise).  Grid (2, E): 16 bytes per lane.
 __global__ __launch_bounds__(256) void a0_env_step_commit_kernel(unsigned long long seed, uint32_t rank, int E, uint32_t g, const uint8_t* __restrict__ obs_in,
                                                                   uint8_t* __restrict__ obs_out, float* __restrict__ ep_ret, float* __restrict__ final_mask,
                                                                   float* __restrict__ final_ret, int n, long long steps, double gamma,
@@ -138,22 +138,28 @@ __global__ __launch_bounds__(256) void a0_env_step_commit_kernel(unsigned long l
     }
     const uint32_t base = (uint32_t)seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
     const uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
-    const int q = A0_ENV_PIX / 4;
-    const uint32_t* in4 = (const uint32_t*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
-    const uint32_t* o04 = (const uint32_t*)(obs0 + (size_t)e * 4 * A0_ENV_PIX);
-    uint32_t* out4 = (uint32_t*)(obs_out + (size_t)e * 4 * A0_ENV_PIX);
-    uint32_t* row4 = (uint32_t*)(frames + slot * (8LL * A0_ENV_PIX));          // [st (4 frames) | st_next (4 frames)]
+    // 16 bytes per lane: 441 lanes cover a frame (two workgroups per env); every load and store is a full-width vector access
+    const int q = A0_ENV_PIX / 16;
+    const uint4* in16 = (const uint4*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
+    const uint4* o016 = (const uint4*)(obs0 + (size_t)e * 4 * A0_ENV_PIX);
+    uint4* out16 = (uint4*)(obs_out + (size_t)e * 4 * A0_ENV_PIX);
+    uint4* row16 = (uint4*)(frames + slot * (8LL * A0_ENV_PIX));          // [st (4 frames) | st_next (4 frames)]
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) {
-        const uint32_t p = 4u * (uint32_t)j;
-        const uint32_t nw = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
-                            ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
-        const uint32_t i0 = in4[j], i1 = in4[q + j], i2 = in4[2 * q + j], i3 = in4[3 * q + j];
-        uint32_t n0, n1, n2, n3;
+        const uint4 i0 = in16[j], i1 = in16[q + j], i2 = in16[2 * q + j], i3 = in16[3 * q + j];
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = 16u * (uint32_t)j + 4u * (uint32_t)k;
+            w[k] = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
+                   ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
+        }
+        const uint4 nw = uint4{w[0], w[1], w[2], w[3]};
+        uint4 n0, n1, n2, n3;
         if (term) { n0 = nw; n1 = nw; n2 = nw; n3 = nw; } else { n0 = i1; n1 = i2; n2 = i3; n3 = nw; }
-        out4[j] = n0; out4[q + j] = n1; out4[2 * q + j] = n2; out4[3 * q + j] = n3;
-        if (obs0 == obs_in) { row4[j] = i0; row4[q + j] = i1; row4[2 * q + j] = i2; row4[3 * q + j] = i3; }
-        else { row4[j] = o04[j]; row4[q + j] = o04[q + j]; row4[2 * q + j] = o04[2 * q + j]; row4[3 * q + j] = o04[3 * q + j]; }
-        row4[4 * q + j] = n0; row4[5 * q + j] = n1; row4[6 * q + j] = n2; row4[7 * q + j] = n3;
+        out16[j] = n0; out16[q + j] = n1; out16[2 * q + j] = n2; out16[3 * q + j] = n3;
+        if (obs0 == obs_in) { row16[j] = i0; row16[q + j] = i1; row16[2 * q + j] = i2; row16[3 * q + j] = i3; }
+        else { row16[j] = o016[j]; row16[q + j] = o016[q + j]; row16[2 * q + j] = o016[2 * q + j]; row16[3 * q + j] = o016[3 * q + j]; }
+        row16[4 * q + j] = n0; row16[5 * q + j] = n1; row16[6 * q + j] = n2; row16[7 * q + j] = n3;
     }
 }
 
@@ -164,7 +170,8 @@ extern "C" int a0_env_synth_step_commit(unsigned long long seed, unsigned int ra
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !action || !ring_act || !ring_rew || !ring_done || !obs0 || !frames ||
         !r_act || !r_rew || !r_done || E < 1 || n < 1 || steps < 0 || cap < E || start_slot < 0)
         return a0_fail(A0_EINVAL, "a0_env_synth_step_commit: bad argument");
-    hipLaunchKernelGGL(a0_env_step_commit_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n,
+    if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_env_synth_step_commit: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(a0_env_step_commit_kernel, dim3(2, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n,
                        steps, gamma, action, ring_act, ring_rew, ring_done, obs0, frames, cap, start_slot % cap, r_act, r_rew, r_done, ctrl);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step_commit");
 }
