@@ -42,25 +42,47 @@ __global__ void a0_reduce_bias_act_kernel(const float* __restrict__ slabs, long 
     }
 }
 
-// Up to four slab reductions in one launch: workgroup g serves 32 outputs of the segment its index falls into.
-struct a0_reduce_multi_args { a0_reduce_seg seg[4]; int first_block[5]; };
+// Up to four slab reductions in one launch: workgroup g serves 128 outputs of the segment its index falls into — 32 lanes x 16 bytes wide,
+// eight row groups striding over the slabs and combined in a fixed order through LDS (deterministic); a segment whose base, stride or
+// count is not a multiple of four floats takes the scalar path (32 outputs per workgroup).
+struct a0_reduce_multi_args { a0_reduce_seg seg[4]; int first_block[5]; int vec[4]; };
 __global__ __launch_bounds__(256) void a0_reduce_segments_kernel(a0_reduce_multi_args A) {
-    __shared__ float red[8][33];
+    __shared__ a0_f4 red4[8][33];
     int si = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k) si += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
     const a0_reduce_seg S = A.seg[si];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const long long i = (long long)((int)blockIdx.x - A.first_block[si]) * 32 + c;
+    const long long blk = (long long)((int)blockIdx.x - A.first_block[si]);
+    if (A.vec[si]) {
+        const long long i4 = blk * 32 + c;                    // float4 index
+        const long long n4 = S.count >> 2, st4 = S.slab_stride >> 2;
+        a0_f4 s = a0_zero4();
+        if (i4 < n4) {
+            const a0_f4* p = (const a0_f4*)S.slabs + i4;
+            for (int z = g; z < S.nslab; z += 8) { const a0_f4 v = p[(long long)z * st4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        }
+        red4[g][c] = s;
+        __syncthreads();
+        if (g == 0 && i4 < n4) {
+            a0_f4 t = a0_zero4();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const a0_f4 v = red4[j][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            ((a0_f4*)S.out)[i4] = t;
+        }
+        return;
+    }
+    float* red = (float*)red4;                                 // [8][33] floats
+    const long long i = blk * 32 + c;
     float s = 0.f;
     if (i < S.count)
         for (int z = g; z < S.nslab; z += 8) s += S.slabs[(long long)z * S.slab_stride + i];
-    red[g][c] = s;
+    red[g * 33 + c] = s;
     __syncthreads();
     if (g == 0 && i < S.count) {
         float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t += red[j][c];
+        for (int j = 0; j < 8; ++j) t += red[j * 33 + c];
         S.out[i] = t;
     }
 }
@@ -190,8 +212,14 @@ struct a0_hip_backend {
         int blocks = 0;
         for (int k = 0; k < 4; ++k) {
             A.first_block[k] = blocks;
-            if (k < nseg) { A.seg[k] = segs[k]; blocks += (int)((segs[k].count + 31) / 32); }
-            else A.seg[k] = a0_reduce_seg{nullptr, 0, 0, nullptr, 0};
+            A.vec[k] = 0;
+            if (k < nseg) {
+                A.seg[k] = segs[k];
+                A.vec[k] = ((segs[k].count | segs[k].slab_stride) % 4 == 0) && ((((uintptr_t)segs[k].slabs) | ((uintptr_t)segs[k].out)) % 16 == 0);
+                blocks += A.vec[k] ? (int)((segs[k].count / 4 + 31) / 32) : (int)((segs[k].count + 31) / 32);
+            } else {
+                A.seg[k] = a0_reduce_seg{nullptr, 0, 0, nullptr, 0};
+            }
         }
         A.first_block[4] = blocks;
         for (int k = nseg; k < 4; ++k) A.first_block[k] = 0x7fffffff;        // unused segments are never selected
