@@ -65,13 +65,37 @@ extern "C" int a0_adam_step(float* params, const float* grads, float* exp_avg, f
 // fraction net).  A skipped (NaN) step leaves the parameters alone but still syncs, like the reference.  == a0_adam_step + a0_target_sync.
 __global__ void a0_adam_sync_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                     long long n, const int* __restrict__ state, const float* __restrict__ scal,
-                                    float w1, float b2, float w2, float eps, float* __restrict__ target, long long n_total) {
+                                    float w1, float b2, float w2, float eps, float* __restrict__ target, long long n_total, int vec4) {
     const bool skip = state[3] != 0, sync = state[4] != 0;
     if (skip && !sync) return;
     const float step_size = scal[0], bc2_sqrt = scal[1];
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long end = sync ? n_total : n;
+    if (vec4) {                     // n, n_total multiples of four and every buffer 16-byte aligned: 16 bytes per lane, same arithmetic per element
+        const long long n4 = n >> 2, end4 = end >> 2;
+        for (; i < end4; i += stride) {
+            a0_f4 pv = ((a0_f4*)p)[i];
+            if (i < n4 && !skip) {
+                const a0_f4 gv = ((const a0_f4*)g)[i];
+                a0_f4 mv = ((a0_f4*)m)[i], vv = ((a0_f4*)v)[i];
+                float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gi = gp[e];
+                    float mi = mp[e], vi = vp[e];
+                    mi = mi + (gi - mi) * w1;
+                    vi = vi * b2 + (w2 * gi) * gi;
+                    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+                    pp[e] = pp[e] - step_size * (mi / denom);
+                    mp[e] = mi; vp[e] = vi;
+                }
+                ((a0_f4*)p)[i] = pv; ((a0_f4*)m)[i] = mv; ((a0_f4*)v)[i] = vv;
+            }
+            if (sync) ((a0_f4*)target)[i] = pv;
+        }
+        return;
+    }
     for (; i < end; i += stride) {
         float pi = p[i];
         if (i < n && !skip) {
@@ -96,10 +120,12 @@ extern "C" int a0_adam_step_sync(float* params, const float* grads, float* exp_a
         return a0_fail(A0_EINVAL, "a0_adam_step_sync: bad argument");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(a0_adam_prep_kernel, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, target_update_freq, extra_nan_flag);
-    long long blocks = (n_total + 255) / 256;
+    const int vec4 = ((n | n_total) % 4 == 0) &&
+                     ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq) | ((uintptr_t)target)) % 16 == 0);
+    long long blocks = ((vec4 ? n_total / 4 : n_total) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(a0_adam_sync_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4);
     return a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync");
 }
 
