@@ -403,6 +403,9 @@ class DeviceLearner:
     def apply(self):
         """Adam on the flat buffer (NaN-skip and step counter on the device), refresh of the fused kernels' weight copies, target sync."""
         L, ops, on, tg = self.L, self.ops, self.online, self.target
+        if L.algo == "fqf":           # unconditional, like the reference's fqf_optimizer.step() in front of the NaN guard (agent.py:139-148)
+            blk = L.blocks["frac"]
+            ops.rmsprop_step(on.flat[blk.all], self.grads[blk.all], self.rms_sq, blk.size, self.lr / 2e4, 0.95, 1e-5, self.max_grad_norm, self.clip)
         if hasattr(ops, "adam_step_sync"):
             # three launches: Adam's scalars; Adam with the target copy folded in; the online conv copies, mirrored to the target's on a sync
             tail = self.grads[L.n_params_padded: L.n_params_padded + 1] if (self._flag_in_tail and self._bucketed_hook()) else None
@@ -535,8 +538,8 @@ class DeviceLearner:
             ops.fqf_fraction_loss(wf.q, wo.q, wo.tau_all, act, wgt, B, F, L.A, L.Fpad, self.frac_loss, self.dfrac_logits, wo.frac_logits)
             gfr = self.grads[L.blocks["frac"].all]
             ops.dense_wgrad(self.dfrac_logits, wo.act3, L.feat, gfr, B, L.Fpad, L.feat, self.slabs)
-            blk = L.blocks["frac"]
-            ops.rmsprop_step(on.flat[blk.all], gfr, self.rms_sq, blk.size, self.lr / 2e4, 0.95, 1e-5, self.max_grad_norm, self.clip)
+            # the fraction net's RMSprop step (agent.py:140-147) runs in apply(): nothing in this update reads the fraction net again, and
+            # under data parallelism its gradient has then been reduced with the dense bucket like every other block
             frac = self.frac_loss
         else:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
