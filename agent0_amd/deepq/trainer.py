@@ -85,6 +85,14 @@ class Trainer:
             except ImportError:
                 pass
         self.logger = logging.getLogger("agent0")
+        # the reference gets level INFO and a console handler from Hydra's job-logging defaults; without Hydra they are set here, so that
+        # msg.log and the console carry the per-iteration lines (trainer.py:158-169)
+        if self.logger.getEffectiveLevel() > logging.INFO:
+            self.logger.setLevel(logging.INFO)
+        if not logging.getLogger().handlers and not any(isinstance(h, logging.StreamHandler) and not isinstance(h, logging.FileHandler) for h in self.logger.handlers):
+            console = logging.StreamHandler()
+            console.setFormatter(logging.Formatter("[%(asctime)s][%(name)s][%(levelname)s] - %(message)s"))
+            self.logger.addHandler(console)
         try:
             os.makedirs(cfg.logdir, exist_ok=True)
             self.logger.addHandler(logging.FileHandler(os.path.join(cfg.logdir, "msg.log")))

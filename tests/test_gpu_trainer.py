@@ -88,6 +88,10 @@ def test_trainer_iterations(algo, extra):
         res = tr.run_iteration()
     assert res["frames"] == 7 * 80 and len(tr.replay) == 400 and tr.replay.written == 560
     assert res["loss"] is not None and np.isfinite(res["loss"]) and res["fps"] > 0 and np.isfinite(res["qmax"])
+    tr.logging(res)                        # trainer.py:158-169: the per-iteration line reaches msg.log (level INFO without Hydra's logging config)
+    for h in tr.logger.handlers:
+        h.flush()
+    assert "frames:" in open(os.path.join(cfg.logdir, "msg.log")).read()
     if algo == "fqf":
         assert np.isfinite(res["fraction_loss"])
     eng = tr.learner.engine
