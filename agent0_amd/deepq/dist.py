@@ -62,7 +62,7 @@ class GradAllReduce:
 
         self.dist, self.n, self.group = dist, n_grad, group
         self.world = dist.get_world_size(group)
-        self.active = self.world > 1 or dp_forced()
+        self.active = (self.world > 1 or dp_forced()) and os.environ.get("A0_DP_DRYRUN") != "1"      # DRYRUN: graph split without collectives (diagnostics)
         self._dense = None
 
     def start_dense(self, grads: torch.Tensor, conv_end: int, end: int | None = None):
