@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--entry", choices=("main", "launch"), default="main",
                     help="main: agent0.deepq.main schedule (rollout, then update block, strictly alternating); launch: agent0.deepq.launch schedule "
                          "(next rollout with a weight snapshot on a second stream while the update block runs)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1 without a gradient exchange: every rank trains its own network on its own game (rank r plays the r-th of the 8 README games; "
+                         "BASELINE configs[4] read as 'one game per GPU') — the ranks share only the barriers and the max-over-ranks clock")
     ap.add_argument("overrides", nargs="*", help="extra key=value config overrides")
     return ap.parse_args()
 
@@ -105,6 +108,8 @@ def main():
     from agent0_amd.deepq.trainer import Trainer
     from agent0_amd.common.atari_wrappers import ACTION_DIMS
 
+    if args.replicas and world > 1:          # q-head shapes differ between games (4 / 6 / 9 / 18 actions): nothing to reduce across them
+        args.env = ("Asterix", "BeamRider", "Breakout", "Enduro", "MsPacman", "Qbert", "Seaquest", "SpaceInvaders")[rank % 8]
     cfg = parse_overrides([f"env_id={args.env}", f"learner.algo={args.algo}", f"actor.num_envs={args.num_envs}", f"replay.size={args.replay_size}",
                            f"learner.batch_size={args.batch}", f"learner.learner_steps={args.learner_steps}", f"actor.sample_steps={args.sample_steps}",
                            "wandb=false", "tb=false", f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}", *args.overrides])
@@ -113,7 +118,7 @@ def main():
     cfg.seed = cfg.seed + 1000003 * rank
     tr = Trainer(cfg, use_lp=(args.entry == "launch"), rank=rank)
     eng = tr.learner.engine
-    if dp:
+    if dp and not args.replicas:
         import torch.distributed as dist
         eng.grad_hook = GradAllReduce(eng.L.n_adam)
         eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)
@@ -241,9 +246,10 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg.env_id} {cfg.learner.algo.name}, {cfg.actor.num_envs} vectorized envs x {cfg.actor.sample_steps} steps + "
                                f"{cfg.learner.learner_steps} updates of batch {cfg.learner.batch_size} per iteration, {cfg.replay.size}-transition HBM replay "
-                               f"(full), obs 4x84x84 u8, per-rank shards, RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)"),
+                               f"(full), obs 4x84x84 u8, per-rank shards, " + ("independent replicas: one game per rank, no gradient exchange" if args.replicas else
+                               "RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)")),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
-                   "replay_size": cfg.replay.size, "parallelism": f"dp{world}", "entry": f"agent0.deepq.{args.entry}"},
+                   "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}"},
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),
         "at_reference_update_ratio": ratio320, "other_entry": other,
