@@ -259,7 +259,8 @@ A0_D void a0_sumtree_top(float* __restrict__ tree, long long s0, float* __restri
 }
 
 __global__ __launch_bounds__(1024) void a0_sumtree_set_kernel(float* __restrict__ tree, long long cap2, const long long* __restrict__ idx,
-                                                               const float* __restrict__ val, int n) {
+                                                               const float* __restrict__ val, int n, const int* __restrict__ state) {
+    if (state && state[3]) return;      // the update was skipped on a NaN loss (agent.py:152-158): nothing to write, like a0_priority_update
     // single workgroup: leaves first (a later duplicate wins), then one level per barrier, bottom-up.  The indices are staged in LDS
     // once: the duplicate scan and the twenty levels re-read them from there instead of from global memory.
     __shared__ long long sidx[1024];
@@ -323,16 +324,18 @@ extern "C" int a0_sumtree_set_range(float* tree, long long cap2, long long start
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set_range");
 }
 
-extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, void* stream) {
+extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, void* stream) {
     if (!tree || !idx || !val || n < 1 || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_set: cap2 must be a power of two");
+    if (n > 1024) return a0_fail(A0_EINVAL, "a0_sumtree_set: at most 1024 leaves per call (the indices are staged in one workgroup's LDS); split the batch in order");
     int threads = 64; while (threads < n && threads < 1024) threads <<= 1;
-    hipLaunchKernelGGL(a0_sumtree_set_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, tree, cap2, idx, val, n);
+    hipLaunchKernelGGL(a0_sumtree_set_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, tree, cap2, idx, val, n, state);
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set");
 }
 
 // transform-and-set used by the learner: val = (loss + eps)^alpha; also tracks max_p like a0_priority_update
 __global__ __launch_bounds__(1024) void a0_sumtree_prio_kernel(const float* __restrict__ loss, int n, float eps, float alpha, float* __restrict__ val,
-                                                                float* __restrict__ pstate) {
+                                                                float* __restrict__ pstate, const int* __restrict__ state) {
+    if (state && state[3]) return;      // NaN-skipped update: max_p and the staged values stay as they were
     __shared__ float red[1024];
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < n; i += blockDim.x) { const float l = loss[i]; val[i] = a0_prio_pow(l + eps, alpha); mx = fmaxf(mx, l); }
@@ -342,10 +345,10 @@ __global__ __launch_bounds__(1024) void a0_sumtree_prio_kernel(const float* __re
     if (threadIdx.x == 0) pstate[0] = fmaxf(pstate[0], red[0]);
 }
 
-extern "C" int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, void* stream) {
+extern "C" int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, const int* state, void* stream) {
     if (!loss || !val || !pstate || n < 1) return a0_fail(A0_EINVAL, "a0_priority_from_loss: bad argument");
     int threads = 64; while (threads < n && threads < 1024) threads <<= 1;
-    hipLaunchKernelGGL(a0_sumtree_prio_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, loss, n, eps, alpha, val, pstate);
+    hipLaunchKernelGGL(a0_sumtree_prio_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, loss, n, eps, alpha, val, pstate, state);
     return a0_fail_hip((int)hipGetLastError(), "a0_priority_from_loss");
 }
 

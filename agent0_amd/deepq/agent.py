@@ -60,7 +60,7 @@ class Actor:
         # scalar heads take the fused tail (fc1 slabs -> q -> dueling -> argmax -> epsilon-greedy in one kernel, a0_actor_qhead)
         self.fused_tail = self.L.algo in ("dqn", "mdqn") and self.L.feat % 4 == 0 and self.L.A + (1 if self.L.dueling else 0) <= 24
         # distributional heads (c51, qr): head GEMM slabs -> one tail kernel (bias, dueling, expectation, argmax, epsilon-greedy)
-        self.dist_tail = (not self.fused_tail) and self.L.algo in ("c51", "qr") and hasattr(ops, "actor_dist_tail") and 4 * (self.L.A * self.L.T + self.L.T) * 4 <= 160 * 1024
+        self.dist_tail = (not self.fused_tail) and self.L.algo in ("c51", "qr") and 4 * (self.L.A * self.L.T + self.L.T) * 4 <= 160 * 1024
         self._head_slabs = ops.empty(ops.dense_fwd_partial_slabs(E, self.L.Npad, 512) * E * self.L.Npad) if self.dist_tail else None
         self.qmax_all = ops.zeros(T * E) if (self.fused_tail or self.dist_tail) else None
         self._qh_scratch = ops.empty(ops.actor_qhead_scratch(E, self.L.feat)) if self.fused_tail else None
@@ -203,6 +203,7 @@ class Actor:
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, **graph_capture_kwargs()):
                 self._rollout(epsilon, T, start, True, False, None, None, ctrl=self.ctrl, eps_ptr=self.eps_dev)
+            rng.ctrl = None                              # the captured kernels hold the pointer; eager rollouts must not add stale deltas
             after = self._snapshot()
             assert after["cur"] == base["cur"]
             self._graph = (graph, base, {k: after["rng"].get(k, 0) - base["rng"].get(k, 0) for k in after["rng"]})

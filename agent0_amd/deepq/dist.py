@@ -18,6 +18,15 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def free_port() -> int:
+    """A TCP port that is free right now on the loopback interface (for a job's rendezvous)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def dp_forced() -> bool:
     """A0_DP_FORCE=1: run the data-parallel code path (process group, gradient buckets, graphs split around the exchange) even with
     one rank, so that a one-GPU box can exercise RCCL + hipGraph capture + the overlap streams (tests/test_gpu_trainer.py)."""
@@ -56,6 +65,8 @@ class GradAllReduce:
     is issued asynchronously (RCCL runs it on its own stream over xGMI) and overlaps the encoder backward, which is ~40 % of an
     update's kernel time; the NaN flag rides at its tail as a float (any rank's NaN makes the sum nonzero); the small convolution
     bucket follows, then the optimizer waits for both: two collectives per update."""
+
+    bucketed = True       # DeviceLearner calls start_dense / finish around the encoder backward (a plain callable gets one call instead)
 
     def __init__(self, n_grad: int, group=None):
         import torch.distributed as dist

@@ -119,11 +119,8 @@ class DeviceNet:
             mu, sg, ef = L.blocks[block + ".mu"], L.blocks[block + ".sigma"], L.eff[block]
             nz = self.noise[prefix]
             mods.append((self.flat[mu.all], self.flat[sg.all], self.eff[ef.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
-        if hasattr(self.ops, "noisy_multi") and mods:
+        if mods:
             self.ops.noisy_multi(False, mods)              # the two or three modules in one launch
-        else:
-            for m in mods:
-                self.ops.noisy_compose(*m)
 
     def set_noise(self, prefix: str, noise_in, noise_out_weight, noise_out_bias):
         """Install the three noise vectors of one NoisyLinear (reference order/layout; model.py:73-76)."""
@@ -193,7 +190,7 @@ class DeviceNet:
             return ws.q
         R = B * n_tau
         ops.cos_features(taus, ws.cosx, R, L.num_cosines)
-        if ws.emb is None or (not ws.grads and hasattr(ops, "dense_fwd_mul") and ops.dense_fwd_scratch(R, L.feat, L.num_cosines) == 0):
+        if not ws.grads and ops.dense_fwd_scratch(R, L.feat, L.num_cosines) == 0:
             # a pass that is not differentiated: embedding x features in the GEMM's epilogue, the embedding never reaches HBM
             Wc, bc = self.wb("cos")
             ops.dense_fwd_mul(ws.cosx, L.num_cosines, Wc, bc, feat, n_tau, ws.x, R, L.feat, L.num_cosines, True)
@@ -286,12 +283,11 @@ class DeviceLearner:
                      ops.dense_wgrad_scratch(self.ws_o.R, L.Npad, 512), ops.dense_wgrad_scratch(self.ws_o.R, 512, L.feat),
                      ops.dense_wgrad_scratch(self.ws_o.R, L.feat, L.num_cosines) if L.quantile else 0,
                      ops.dense_wgrad_scratch(B, L.Fpad, L.feat) if L.algo == "fqf" else 0, 4)
-        if hasattr(ops, "dense_wgrad_multi_scratch"):     # head + fc1 (+ cosine embedding) reduce in disjoint regions of one launch
-            shapes = [(self.ws_o.R, L.Npad, 512), (self.ws_o.R, 512, L.feat)] + ([(self.ws_o.R, L.feat, L.num_cosines)] if L.quantile else [])
-            n_slab = max(n_slab, ops.dense_wgrad_multi_scratch(shapes))
+        # head + fc1 (+ cosine embedding) reduce in disjoint regions of one launch
+        shapes = [(self.ws_o.R, L.Npad, 512), (self.ws_o.R, 512, L.feat)] + ([(self.ws_o.R, L.feat, L.num_cosines)] if L.quantile else [])
+        n_slab = max(n_slab, ops.dense_wgrad_multi_scratch(shapes))
         self.slabs = ops.empty(n_slab)
         self.obs_bytes = L.C * L.H * L.W
-        self._flag_in_tail = hasattr(ops, "nan_flag_export") and hasattr(ops, "adam_step_sync")
         self.grad_hook = None       # data parallelism: callable(grads, state) run between backward and the optimizer (dist.GradAllReduce)
 
     # ------------------------------------------------------------------ helpers
@@ -314,39 +310,26 @@ class DeviceLearner:
             ops.dueling_bwd(ws.dq, ws.draw, L.Npad, R, L.A, T, L.dueling)
         Wh, _ = on.wb("head")
         Wf, _ = on.wb("fc1")
-        multi = hasattr(ops, "dense_wgrad_multi")       # the data gradients first, then every dense weight gradient with ONE slab reduction
+        # the data gradients first, then every dense weight gradient with ONE slab reduction
         wg = [(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512)]
-        if not multi:
-            ops.dense_wgrad(*wg[0], self.slabs)
         ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
         if not L.quantile:
             wg.append((ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat))
-            if not multi:
-                ops.dense_wgrad(*wg[1], self.slabs)
             ops.dense_dgrad(ws.dh, Wf, ws.act3, ws.d3, R, 512, L.feat)
         else:
             n = ws.n_tau
             wg.append((ws.dh, ws.x, L.feat, self._grad("fc1"), R, 512, L.feat))
-            if not multi:
-                ops.dense_wgrad(*wg[1], self.slabs)
             ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
             ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
             wg.append((ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines))
-            if not multi:
-                ops.dense_wgrad(*wg[2], self.slabs)
-        if multi:
-            ops.dense_wgrad_multi(wg, self.slabs)
+        ops.dense_wgrad_multi(wg, self.slabs)
         if L.noisy:
             mods = []
             for prefix, block, r0, r1, in_f in L.noise_modules:
                 mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
                 nz = on.noise[prefix]
                 mods.append((self.grads[mu.all], None, self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
-            if hasattr(ops, "noisy_multi"):
-                ops.noisy_multi(True, mods)
-            else:
-                for m in mods:
-                    ops.noisy_grad_sigma(m[0], m[2], *m[3:])
+            ops.noisy_multi(True, mods)
 
     def backward_encoder(self):
         """d3 -> the three convolution blocks' gradients (flat range [0, L.conv_end)); the second half of the backward pass, on the
@@ -373,14 +356,14 @@ class DeviceLearner:
         return out
 
     def _bucketed_hook(self) -> bool:
-        return self.grad_hook is not None and hasattr(self.grad_hook, "start_dense")
+        return self.grad_hook is not None and getattr(self.grad_hook, "bucketed", False)
 
     def exchange_begin(self):
         """Data parallelism, first bucket: the dense blocks' gradients are final once forward_dense returns; a hook with a
         ``start_dense`` method (dist.GradAllReduce) reduces them asynchronously while backward_encoder runs."""
         h = self.grad_hook
-        if h is not None and hasattr(h, "start_dense"):
-            h.start_dense(self.grads, self.L.conv_end, self.L.n_params_padded + (1 if self._flag_in_tail else 0))
+        if self._bucketed_hook():
+            h.start_dense(self.grads, self.L.conv_end, self.L.n_params_padded + 1)
 
     def exchange_end(self):
         """Second bucket (convolution blocks + the NaN flag) and the join with the first; a plain callable hook gets one call with
@@ -388,8 +371,8 @@ class DeviceLearner:
         h = self.grad_hook
         if h is None:
             return
-        if hasattr(h, "start_dense"):
-            h.finish(self.grads, None if self._flag_in_tail else self.state, self.L.conv_end)
+        if self._bucketed_hook():
+            h.finish(self.grads, None, self.L.conv_end)
         else:
             h(self.grads, self.state)
 
@@ -406,17 +389,12 @@ class DeviceLearner:
         if L.algo == "fqf":           # unconditional, like the reference's fqf_optimizer.step() in front of the NaN guard (agent.py:139-148)
             blk = L.blocks["frac"]
             ops.rmsprop_step(on.flat[blk.all], self.grads[blk.all], self.rms_sq, blk.size, self.lr / 2e4, 0.95, 1e-5, self.max_grad_norm, self.clip)
-        if hasattr(ops, "adam_step_sync"):
-            # three launches: Adam's scalars; Adam with the target copy folded in; the online conv copies, mirrored to the target's on a sync
-            tail = self.grads[L.n_params_padded: L.n_params_padded + 1] if (self._flag_in_tail and self._bucketed_hook()) else None
-            ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
-                               self.target_update_freq, tg.flat, L.n_params_padded, tail)
-            if on.fused:
-                ops.conv_wt_refresh_sync(on.encoder_weights(), L.C, on.wt, tg.wt, self.state)
-            return
-        ops.adam_step(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps, self.target_update_freq)
-        on.refresh_wt()
-        self.sync_target(force=False)
+        # three launches: Adam's scalars; Adam with the target copy folded in; the online conv copies, mirrored to the target's on a sync
+        tail = self.grads[L.n_params_padded: L.n_params_padded + 1] if self._bucketed_hook() else None
+        ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
+                           self.target_update_freq, tg.flat, L.n_params_padded, tail)
+        if on.fused:
+            ops.conv_wt_refresh_sync(on.encoder_weights(), L.C, on.wt, tg.wt, self.state)
 
     def forward_dense(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
         """Forward passes, losses and the dense half of the backward pass (every gradient but the convolution blocks', which
@@ -446,34 +424,23 @@ class DeviceLearner:
             on.encode(wo, frames, slot, sample_stride, 0, B)
             on.head(wo, B)
             ops.loss_mdqn(wo.q, wt.q, wm.q, L.A, act, rew, done, wgt, self.gamma_n, self.mdqn_tau, self.mdqn_lo, B, self.loss, wo.dq, self.state)
-        elif algo == "dqn" and getattr(ops, "fused_dqn_head", False) and L.A + (1 if L.dueling else 0) <= 24:
-            # heads, loss and head gradient in one kernel (a0_dqn_head_loss); only fc1 runs as a GEMM
+        elif algo == "dqn" and L.A + (1 if L.dueling else 0) <= 24:
+            # heads, loss and head gradient in one kernel that also finishes fc1 from the GEMMs' split-K slabs (a0_dqn_head_loss_slabs):
+            # only fc1 runs as a GEMM, and there are no reduction launches
             (Wo, bo), (Wt, bt) = on.wb("head"), tg.wb("head")
-            if getattr(ops, "fused_dqn_head_slabs", False):
-                # ... and that kernel also finishes fc1 from the GEMMs' split-K slabs (no reduction launches)
-                ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
-                if getattr(self, "_fc1_slabs", None) is None or self._fc1_slabs[0].numel() < ns * B * 512:
-                    self._fc1_slabs = [ops.empty(ns * B * 512) for _ in range(3 if self.double_q else 2)]
-                (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
-                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
-                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, self._fc1_slabs[1])
-                if self.double_q:
-                    on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
-                    ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
-                on.encode(wo, frames, slot, sample_stride, 0, B)
-                ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
-                ops.dqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
-                                        L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state)
-            else:
-                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
-                tg.fc1(wt, B)
-                if self.double_q:
-                    on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
-                    on.fc1(wsel, B)
-                on.encode(wo, frames, slot, sample_stride, 0, B)
-                on.fc1(wo, B)
-                ops.dqn_head_loss(wo.h, wt.h, wsel.h if self.double_q else None, Wo, bo, Wt, bt, L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B,
-                                  self.loss, wo.q, wt.q, wo.draw, self.state)
+            ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
+            if getattr(self, "_fc1_slabs", None) is None or self._fc1_slabs[0].numel() < ns * B * 512:
+                self._fc1_slabs = [ops.empty(ns * B * 512) for _ in range(3 if self.double_q else 2)]
+            (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+            ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, self._fc1_slabs[1])
+            if self.double_q:
+                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
+                ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
+            ops.dqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
+                                    L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state)
             have_draw = True
         elif algo in ("dqn", "c51", "qr"):
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
@@ -545,6 +512,6 @@ class DeviceLearner:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
         self._backward_dense(wo, B, have_draw)
         self._bw = (wo, frames, slot, sample_stride, B)
-        if self._flag_in_tail and self._bucketed_hook():      # the NaN flag rides at the tail of the dense gradient bucket
+        if self._bucketed_hook():      # the NaN flag rides at the tail of the dense gradient bucket
             ops.nan_flag_export(self.state, self.grads[L.n_params_padded: L.n_params_padded + 1])
         return (self.loss, frac) if frac is not None else self.loss

@@ -26,7 +26,7 @@ class TrainerNode:
         from .trainer import Trainer
 
         cfg.seed = cfg.seed + 1000003 * rank          # per-rank env / replay / exploration streams
-        self.trainer = Trainer(cfg, use_lp=True, rank=rank)          # asynchronous actor on its own stream, weight snapshots
+        self.trainer = Trainer(cfg, use_lp=True, rank=rank, primary=(rank == 0))      # asynchronous actor on its own stream, weight snapshots
         eng = self.trainer.learner.engine
         if world > 1:
             eng.grad_hook = GradAllReduce(eng.L.n_adam)
@@ -50,13 +50,26 @@ def main(argv=None):
         n_gpu = torch.cuda.device_count()             # does not initialise the GPU
         world = max(1, min(parse_overrides(argv).num_actors, n_gpu))
         if world > 1:
+            from .dist import free_port
+            from .main import _fresh_subdir
+
+            # one rendezvous port per job (two jobs on one box must not collide) and ONE run directory for all ranks
+            env = dict(os.environ, A0_RUN_SUBDIR=_fresh_subdir(parse_overrides(argv)))
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                   "--master-port", os.environ.get("MASTER_PORT", "29511"), "-m", "agent0_amd.deepq.launch", *argv]
-            raise SystemExit(subprocess.call(cmd))
-    from .main import build_config
+                   "--master-port", os.environ.get("MASTER_PORT") or str(free_port()), "-m", "agent0_amd.deepq.launch", *argv]
+            raise SystemExit(subprocess.call(cmd, env=env))
+    from .main import _fresh_subdir, build_config
+    from .config import parse_overrides
 
     rank, local_rank, world = init_process_group()
-    cfg = build_config(argv)
+    subdir = os.environ.get("A0_RUN_SUBDIR")
+    if subdir is None and world > 1:          # started under torch.distributed.run directly: rank 0 names the run directory
+        import torch.distributed as dist
+
+        box = [_fresh_subdir(parse_overrides(argv)) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        subdir = box[0]
+    cfg = build_config(argv, subdir)
     TrainerNode(cfg, rank, world).run()
 
 

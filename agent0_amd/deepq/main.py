@@ -25,9 +25,18 @@ def _git_sha() -> str:
         return "nogit000"      # the reference requires a git checkout (quirk Q18); we do not
 
 
-def build_config(argv) -> ExpConfig:
+def run_subdir(cfg: ExpConfig) -> str:
+    """main.py:18-24,30.  ``A0_RUN_SUBDIR`` (set by launch.py's parent process) makes every rank of one job use the same directory."""
+    return os.environ.get("A0_RUN_SUBDIR") or _fresh_subdir(cfg)
+
+
+def _fresh_subdir(cfg: ExpConfig) -> str:
+    return f"{cfg.name}-{cfg.env_id}-{cfg.learner.algo.name}-{cfg.seed}-{_git_sha()}-{strftime('%Y%m%d-%H%M%S', localtime())}-{_uuid.uuid4().hex[:4]}"
+
+
+def build_config(argv, subdir: str | None = None) -> ExpConfig:
     cfg = parse_overrides(argv)
-    subdir = f"{cfg.name}-{cfg.env_id}-{cfg.learner.algo.name}-{cfg.seed}-{_git_sha()}-{strftime('%Y%m%d-%H%M%S', localtime())}-{_uuid.uuid4().hex[:4]}"
+    subdir = subdir or run_subdir(cfg)
     dummy_env = make_atari(cfg.env_id, num_envs=1)
     dummy_env.close()
     cfg.logdir = os.path.join(cfg.logdir, subdir)

@@ -161,17 +161,9 @@ class ReplayDataset:
         self.top = min(self.top + n, self.size)
         if self.prioritize:
             if self.use_sumtree:
-                start = (self.written - n) % self.size
                 val = (self._pstate[0:1].double() ** self.cfg.replay.alpha).float()
-                if hasattr(self.ops, "sumtree_set_range"):      # one launch: the new leaves are a ring range
-                    k = min(n, self.size)
-                    self.ops.sumtree_set_range(self.tree, self.cap2, (self.written - k) % self.size, k, self.size, val)
-                else:
-                    idx = (torch.arange(n, device=self.ops.device, dtype=torch.int64) + start) % self.size
-                    val = val.expand(n).contiguous()
-                    for o in range(0, n, 1024):           # the set kernel handles up to one workgroup's worth per call
-                        k = min(1024, n - o)
-                        self.ops.sumtree_set(self.tree, self.cap2, idx[o:o + k].contiguous(), val[o:o + k].contiguous(), k)
+                k = min(n, self.size)                     # one launch: the new leaves are a ring range
+                self.ops.sumtree_set_range(self.tree, self.cap2, (self.written - k) % self.size, k, self.size, val)
             else:
                 self.ops.priority_tail(self.priority, self.size, min(n, self.size), self._pstate, float(self.cfg.replay.alpha))
             self.beta = self.beta_schedule(n)
@@ -186,14 +178,20 @@ class ReplayDataset:
 
     # ------------------------------------------------------------------ priorities
     def update_priority(self, ids: torch.Tensor, priorities: torch.Tensor, state: Optional[torch.Tensor] = None):
-        """replay.py:55-59: priority[ids] = (loss + eps)^alpha; max_p = max(max_p, max loss)."""
+        """replay.py:55-59: priority[ids] = (loss + eps)^alpha; max_p = max(max_p, max loss).  ``state``: the learner's status words — when
+        the update these losses come from was skipped on a NaN (agent.py:152-158 returns None and trainer.py:103 then skips the call), the
+        device-side guard leaves priorities, sum-tree and max_p untouched on both paths."""
         rc = self.cfg.replay
         B = ids.numel()
         ids = ids.to(self.ops.device, torch.int64).contiguous()
         pr = priorities.to(self.ops.device, torch.float32).contiguous()
         if self.use_sumtree:
-            self.ops.priority_from_loss(pr, B, float(rc.eps), float(rc.alpha), self._val, self._pstate)
-            self.ops.sumtree_set(self.tree, self.cap2, ids, self._val, B)
+            if self._val.numel() < B:
+                self._val = self.ops.zeros(B)
+            self.ops.priority_from_loss(pr, B, float(rc.eps), float(rc.alpha), self._val, self._pstate, state)
+            for o in range(0, B, 1024):       # one workgroup's worth of leaves per call, in batch order: a later duplicate still wins
+                k = min(1024, B - o)
+                self.ops.sumtree_set(self.tree, self.cap2, ids[o:o + k], self._val[o:o + k], k, state)
         else:
             self.ops.priority_update(self.priority, ids, pr, B, float(rc.eps), float(rc.alpha), self._pstate, state)
 
@@ -243,7 +241,7 @@ class ReplayDataset:
     def sample(self, B: Optional[int] = None) -> Batch:
         B = B or self.B
         assert B == self.B
-        if self.use_sumtree and hasattr(self.ops, "sumtree_sample_batch") and B <= 1024:
+        if self.use_sumtree and B <= 1024:
             # stratified draws, descent, slot + metadata and importance weights in one launch
             rng = self.rng
             self.ops.sumtree_sample_batch(rng.seed, rng.STREAM_SUMTREE, rng.reserve(rng.STREAM_SUMTREE, B), self.tree, self.cap2, B, self.top, self.size, float(self.beta),
@@ -258,13 +256,10 @@ class ReplayDataset:
             self.ops.is_weights(self._prio, B, self.tree[1:2], self.top, float(self.beta), self._w)
             idx = self._idx
         else:
-            start, n_perm, seed = self._next_uniform(B, draw=not hasattr(self.ops, "replay_sample_slots"))
-            if hasattr(self.ops, "replay_sample_slots"):       # permutation element -> slot + metadata in one launch
-                self.ops.replay_sample_slots(start, n_perm, seed, self.top, self.head, self.size, self.act, self.rew, self.done,
-                                             self.priority if self.prioritize else None, B, self._idx_out, self._slot, self._act, self._rew, self._done, self._prio)
-            else:
-                self.ops.replay_lookup(self._idx, B, self.top, self.head, self.size, self._slot, self.act, self.rew, self.done,
-                                       self.priority if self.prioritize else None, self._act, self._rew, self._done, self._prio, self._idx_out)
+            start, n_perm, seed = self._next_uniform(B, draw=False)
+            # permutation element -> slot + metadata in one launch
+            self.ops.replay_sample_slots(start, n_perm, seed, self.top, self.head, self.size, self.act, self.rew, self.done,
+                                         self.priority if self.prioritize else None, B, self._idx_out, self._slot, self._act, self._rew, self._done, self._prio)
             if self.prioritize:
                 self.ops.sum_f32(self.priority, self.size, self._scratch, self._psum)
                 self.ops.is_weights(self._prio, B, self._psum, self.top, float(self.beta), self._w)

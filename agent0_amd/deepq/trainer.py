@@ -33,8 +33,10 @@ def epsilon_schedule(cfg: ExpConfig):
 
 
 class Trainer:
-    def __init__(self, cfg: ExpConfig, use_lp: bool = False, ops=None, rank: int = 0):
-        self.cfg, self.use_lp, self.rank = cfg, use_lp, rank
+    def __init__(self, cfg: ExpConfig, use_lp: bool = False, ops=None, rank: int = 0, primary: bool = True):
+        """``primary=False`` (data-parallel replicas other than rank 0, launch.py here): no run directory, msg.log, tensorboard / wandb, final
+        checkpoint or final test — the replicas are identical, so rank 0 reports for all of them."""
+        self.cfg, self.use_lp, self.rank, self.primary = cfg, use_lp, rank, primary
         set_random_seed(cfg.seed)
         if cfg.device.value != "cuda":
             raise RuntimeError("agent0_amd runs on MI355X only: set device=cuda (no CPU fallback)")
@@ -71,14 +73,14 @@ class Trainer:
         self.epsilon_fn = epsilon_schedule(cfg)
         self.writer = None
         self._wandb = None
-        if cfg.wandb:
+        if cfg.wandb and primary:
             try:
                 import wandb
                 wandb.init(project=cfg.name, config=to_dict(cfg))
                 self._wandb = wandb
             except ImportError:
                 pass
-        if cfg.tb:
+        if cfg.tb and primary:
             try:
                 from torch.utils.tensorboard import SummaryWriter
                 self.writer = SummaryWriter(cfg.logdir)
@@ -93,11 +95,12 @@ class Trainer:
             console = logging.StreamHandler()
             console.setFormatter(logging.Formatter("[%(asctime)s][%(name)s][%(levelname)s] - %(message)s"))
             self.logger.addHandler(console)
-        try:
-            os.makedirs(cfg.logdir, exist_ok=True)
-            self.logger.addHandler(logging.FileHandler(os.path.join(cfg.logdir, "msg.log")))
-        except OSError:
-            pass
+        if primary:
+            try:
+                os.makedirs(cfg.logdir, exist_ok=True)
+                self.logger.addHandler(logging.FileHandler(os.path.join(cfg.logdir, "msg.log")))
+            except OSError:
+                pass
         self.num_transitions = cfg.actor.sample_steps * cfg.actor.num_envs
         self.Ls, self.Rs, self.RTs, self.Qs, self.FLs = [], [], [], [], []
         self.frame_count = 0
@@ -120,7 +123,7 @@ class Trainer:
         return path
 
     def load_checkpoint(self, path: str, weights_only: bool = False):
-        blob = torch.load(path, map_location="cpu", weights_only=False)
+        blob = torch.load(path, map_location="cpu", weights_only=True)      # tensors, dicts, tuples, strings, ints only
         if blob.get("algo") not in (None, self.cfg.learner.algo.name) or int(blob.get("action_dim", self.cfg.action_dim)) != int(self.cfg.action_dim):
             raise ValueError(f"checkpoint {path} was written for {blob.get('algo')} / {blob.get('action_dim')} actions")
         self.learner.model.load_state_dict(blob["model"])
@@ -206,6 +209,8 @@ class Trainer:
         return rs
 
     def logging(self, result):
+        if not self.primary:
+            return
         msg = ""
         for k, v in result.items():
             if v is None:
@@ -276,12 +281,13 @@ class Trainer:
         if self.use_lp and self._pending is not None:
             self.actors[1].sample_finish(self._pending)      # drain the rollout still in flight
             self._pending = None
-        if save:
+        if save and self.primary:
             try:
                 self.save_checkpoint(os.path.join(self.cfg.logdir, "final.pth"))
             except OSError:
                 pass
-        self.test()
+        if self.primary:
+            self.test()
         for actor in self.actors:
             if actor is not None:
                 actor.close()

@@ -411,8 +411,9 @@ class HipOps:
     def perm_batch(self, start, count, n, seed, out):
         check(self.lib.a0_perm_batch(start, count, n, seed & 0xFFFFFFFF, _req(out, torch.int64, count, "out"), _stream()), "a0_perm_batch")
 
-    def sumtree_set(self, tree, cap2, idx, val, n):
-        check(self.lib.a0_sumtree_set(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(val, torch.float32, n, "val"), n, _stream()), "a0_sumtree_set")
+    def sumtree_set(self, tree, cap2, idx, val, n, state=None):
+        check(self.lib.a0_sumtree_set(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(val, torch.float32, n, "val"), n,
+                                      _req(state, torch.int32, 8, "state", optional=True), _stream()), "a0_sumtree_set")
 
     def sumtree_sample_batch(self, seed, stream, offset, tree, cap2, B, top, cap, beta, r_act, r_rew, r_done, idx_out, slot_out, act, rew, done, prio, w):
         check(self.lib.a0_sumtree_sample_batch(seed, stream, offset, _req(tree, torch.float32, 2 * cap2, "tree"), cap2, B, top, cap, float(beta),
@@ -432,8 +433,9 @@ class HipOps:
         check(self.lib.a0_sumtree_sample(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(xi, torch.float32, B, "xi"), B,
                                          _req(out_idx, torch.int64, B, "out_idx"), _req(out_p, torch.float32, B, "out_p"), _stream()), "a0_sumtree_sample")
 
-    def priority_from_loss(self, loss, n, eps, alpha, val, pstate):
-        check(self.lib.a0_priority_from_loss(_req(loss, torch.float32, n, "loss"), n, eps, alpha, _req(val, torch.float32, n, "val"), _req(pstate, torch.float32, 1, "pstate"), _stream()), "a0_priority_from_loss")
+    def priority_from_loss(self, loss, n, eps, alpha, val, pstate, state=None):
+        check(self.lib.a0_priority_from_loss(_req(loss, torch.float32, n, "loss"), n, eps, alpha, _req(val, torch.float32, n, "val"), _req(pstate, torch.float32, 1, "pstate"),
+                                             _req(state, torch.int32, 8, "state", optional=True), _stream()), "a0_priority_from_loss")
 
     # ------------------------------------------------------------------ actor / rng / env
     def actor_egreedy(self, greedy, rand_action, u, eps, E, action, qmax, qs_out):

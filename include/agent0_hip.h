@@ -238,7 +238,9 @@ int a0_sum_f32(const float* x, long long n, float* scratch256, float* out, void*
 int a0_is_weights(const float* prio, int B, const float* psum, long long top, float beta, float* w, void* stream);
 int a0_perm_batch(unsigned long long start, int count, unsigned long long n, unsigned int seed, long long* out, void* stream);
 /* sum-tree (new component, contract in oracle/sumtree.c): tree float[2*cap2] */
-int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, void* stream);
+/* n <= 1024 leaves per call (larger batches: consecutive calls in batch order, so that a later duplicate still wins).  state (optional,
+ * the learner's status words): the call is a no-op when state[3] != 0, i.e. when the update was skipped on a NaN loss (agent.py:152-158) */
+int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, void* stream);
 /* leaves (start + i) % size, i < n, all set to val[0] (device scalar) and their ancestors recomputed: the rollout's new transitions enter at
  * max_p^alpha (replay.py:45-53) in one launch; same tree as a0_sumtree_set on those pairs */
 int a0_sumtree_set_range(float* tree, long long cap2, long long start, long long n, long long size, const float* val, void* stream);
@@ -249,7 +251,8 @@ int a0_sumtree_sample(const float* tree, long long cap2, const float* xi, int B,
 int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, const float* tree, long long cap2, int B, long long top,
                             long long cap, float beta, const int* r_act, const float* r_rew, const float* r_done, long long* idx_out, int* slot_out,
                             int* act, float* rew, float* done, float* prio, float* w, void* stream_h);
-int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, void* stream);
+/* val = (loss + eps)^alpha, pstate[0] = max(pstate[0], max loss) (replay.py:55-59); no-op when state && state[3] (NaN-skipped update) */
+int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, const int* state, void* stream);
 
 /* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */
 int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action,

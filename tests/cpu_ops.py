@@ -324,3 +324,66 @@ class CpuOps:
         gsigma[rows] = gmu[rows] * torch.outer(self._f(noise_out_w[: r1 - r0]), self._f(noise_in[:K])).reshape(-1)
         bs = slice(N * K + r0, N * K + r1)
         gsigma[bs] = gmu[bs] * self._f(noise_out_b[: r1 - r0])
+
+    # ------------------------------------------------------------------ the product's fused entry points, composed from the pieces above
+    # (the HIP library has one kernel for each; agent0_amd.deepq.engine calls only these, so the emulation provides the same arithmetic
+    # as compositions — test scaffolding lives here, not in the product's control flow)
+    def noisy_multi(self, grad: bool, mods):
+        for m in mods:
+            if grad:
+                self.noisy_grad_sigma(m[0], m[2], *m[3:])
+            else:
+                self.noisy_compose(*m)
+
+    def dense_fwd_mul(self, X, ldx, W, b, M, group, Y, R, N, K, relu):
+        tmp = torch.empty(R * N)
+        self.dense_fwd(X, ldx, W, b, tmp, R, N, K, relu, self.empty(max(self.dense_fwd_scratch(R, N, K), 1)))
+        Y[: R * N] = (tmp.view(R // group, group, N) * M[: (R // group) * N].view(R // group, 1, N)).reshape(-1)
+
+    def dense_wgrad_multi_scratch(self, shapes) -> int:
+        return max([self.dense_wgrad_scratch(R, N, K) for (R, N, K) in shapes] + [0])
+
+    def dense_wgrad_multi(self, layers, slabs):
+        for (dY, X, ldx, grad, R, N, K) in layers:
+            self.dense_wgrad(dY, X, ldx, grad, R, N, K, slabs)
+
+    def nan_flag_export(self, state, out):
+        out[0] = 1.0 if int(state[0]) != 0 else 0.0
+
+    def adam_step_sync(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag=None):
+        if extra_nan_flag is not None and float(extra_nan_flag[0]) != 0.0:
+            state[0] = 1
+        self.adam_step(params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq)
+        self.target_sync(target, params, n_total, state, False)
+
+    def dense_fwd_partial_slabs(self, R, N, K) -> int:
+        return 1
+
+    def dense_fwd_partial(self, X, ldx, W, R, N, K, slabs):
+        self.dense_fwd(X, ldx, W, torch.zeros(N), slabs, R, N, K, False, self.empty(max(self.dense_fwd_scratch(R, N, K), 1)))
+        return 1
+
+    def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
+                            draw, state):
+        def fc1(slabs, bias):
+            return torch.relu(slabs[: nslab * B * 512].view(nslab, B, 512).sum(0) + bias[:512]).reshape(-1).contiguous()
+
+        def head(h, W, b, q):
+            raw = torch.empty(B * ld)
+            self.dense_fwd(h, 512, W, b, raw, B, ld, 512, False, self.empty(max(self.dense_fwd_scratch(B, ld, 512), 1)))
+            self.dueling_fwd(raw, ld, q, B, A, 1, dueling)
+
+        h_on[: B * 512] = fc1(s_on, b1_on)
+        q_t = q_tg if q_tg is not None else torch.empty(B * A)
+        head(h_on, W_on, b_on, q_on)
+        head(fc1(s_tg, b1_tg), W_tg, b_tg, q_t)
+        a_star = torch.zeros(B, dtype=torch.int32)
+        if s_sel is not None:
+            q_s = torch.empty(B * A)
+            head(fc1(s_sel, b1_on), W_on, b_on, q_s)
+            self.select_action(q_s, A, 1, 1, B, A, 1, 0, None, a_star, None, None)
+        else:
+            self.select_action(q_t, A, 1, 1, B, A, 1, 0, None, a_star, None, None)
+        dq = torch.zeros(B * A)
+        self.loss_dqn(q_on, q_t, A, act, a_star, rew, done, wgt, gamma_n, B, loss, dq, state)
+        self.dueling_bwd(dq, draw, ld, B, A, 1, dueling)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any HIP call, so it is testable here
     assert lib.a0_dense_fwd(None, 4, None, None, None, 1, 4, 4, 0, None, None) == -1
     assert "a0_dense_fwd" in _abi.last_error()
-    assert lib.a0_sumtree_set(None, 3, None, None, 1, None) == -1 and "power of two" in _abi.last_error()
+    assert lib.a0_sumtree_set(None, 3, None, None, 1, None, None) == -1 and "power of two" in _abi.last_error()
 
 
 def test_gfx950_code_object_only():

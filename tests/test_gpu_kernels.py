@@ -362,3 +362,59 @@ def test_sumtree_sample_batch_equals_separate_kernels(hip):
     for a, b in ((idx0, idx1), (slot0, slot1), (act0, act1), (rew0, rew1), (done0, done1), (p0, p1), (w0, w1)):
         assert torch.equal(a, b)
     assert float(w1.max()) <= 1.0 and float(p1.min()) > 0.0
+
+
+def _filled_replay(hip, size, B, extra=()):
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.replay import ReplayDataset, TransitionBlock
+    cfg = parse_overrides([f"replay.size={size}", f"learner.batch_size={B}", "replay.policy=prioritize", "wandb=false", "tb=false", *extra])
+    cfg.obs_shape = (4, 36, 36)              # small rows: the priority logic does not depend on the frame size
+    rp = ReplayDataset(cfg, ops=hip)
+    rp.extend(TransitionBlock(size, start=0))
+    return rp
+
+
+def test_nan_skipped_update_leaves_the_sumtree_alone(hip):
+    """A NaN loss makes the learner skip the step (agent.py:152-158) and the reference's trainer then never calls update_priority
+    (trainer.py:103 sees q_loss None).  On the device the skip decision is state[3]; with it set, neither the leaves, nor the root, nor
+    max_p may change — a NaN priority would poison total, the stratified segments and every later importance weight."""
+    rp = _filled_replay(hip, 3000, 64)
+    tree0, p0 = rp.tree.clone(), rp._pstate.clone()
+    ids = D(hip, recipe.gen(3).integers(0, 3000, 64).astype(np.int64))
+    loss = D(hip, np.full(64, np.nan, np.float32))
+    state = hip.zeros(8, dtype=torch.int32)
+    state[3] = 1
+    rp.update_priority(ids, loss, state=state)
+    assert torch.equal(rp.tree, tree0) and torch.equal(rp._pstate, p0) and torch.isfinite(rp.tree[1])
+    # the same call with the flag down does write (and would have poisoned the tree with these losses)
+    state[3] = 0
+    good = D(hip, recipe.gen(4).uniform(0, 2, 64).astype(np.float32))
+    rp.update_priority(ids, good, state=state)
+    assert not torch.equal(rp.tree, tree0) and torch.isfinite(rp.tree).all()
+    b = rp.sample()
+    assert torch.isfinite(b.weights).all() and float(b.weights.max()) <= 1.0
+
+
+def test_priority_update_of_a_batch_larger_than_one_workgroup(hip):
+    """B = 2048 > the 1024 leaves a0_sumtree_set stages in LDS: ReplayDataset.update_priority splits the batch in order (a later duplicate
+    still wins across the split); the C entry point itself refuses n > 1024.  Tree bytes against the oracle's set on the same pairs."""
+    from agent0_amd._abi import A0Error
+    B, size = 2048, 5000
+    rp = _filled_replay(hip, size, B)
+    t = core.SumTree(size)
+    t.tree[:] = rp.tree.cpu().numpy()
+    g = recipe.gen(9)
+    ids = g.integers(0, size, B)
+    ids[1500] = ids[3]                      # a duplicate that straddles the split: the later one (second chunk) must win
+    loss = g.uniform(0, 3, B).astype(np.float32)
+    rp.update_priority(D(hip, ids.astype(np.int64)), D(hip, loss))
+    val = np.sqrt(loss + np.float32(0.01))            # fp32 add, IEEE sqrt — what a0_prio_pow computes for alpha = 0.5
+    t.set(ids, val)
+    got = rp.tree.cpu().numpy()
+    assert np.array_equal(got[t.cap2:], t.tree[t.cap2:]), "leaves (IEEE sqrt on both sides)"
+    assert np.array_equal(got, t.tree), "every ancestor"
+    assert got[t.cap2 + ids[3]] == val[1500]
+    with pytest.raises(A0Error, match="1024"):
+        hip.sumtree_set(rp.tree, rp.cap2, D(hip, ids.astype(np.int64)), D(hip, val), B)
+    b = rp.sample()                          # B > 1024 takes the unfused sampling path
+    assert int(b.idx.min()) >= 0 and int(b.idx.max()) < size and torch.isfinite(b.weights).all()
