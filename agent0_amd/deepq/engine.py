@@ -402,7 +402,10 @@ class DeviceLearner:
         agent.py:140-147).
 
         frames: u8 replay rows (st || st_next); slot: optional int32 row indices; act int32, rew/done/wgt fp32 [B].
-        rand (IQN only): [taus_K [B*K], taus_N' [B*N'], taus_N [B*N]] in the reference's draw order.
+        rand (IQN): [taus_K [B*K], taus_N' [B*N'], taus_N [B*N]] in the reference's draw order.
+        rand (FQF, parity tests only): [taus [B*(F+1)], tau_hats [B*F]] of the online net on the observations, then the same pair for the
+        action-selection pass on the next observations — fractions evaluated elsewhere (the oracle's), written over the fraction net's own
+        so that both sides evaluate q(tau) at bit-identical fractions; the fraction net still runs (its logits feed the fraction loss).
         Returns the per-sample loss tensor (device) — and for FQF also the fraction loss.
         """
         L, ops, B = self.L, self.ops, self.B
@@ -481,17 +484,21 @@ class DeviceLearner:
             ops.loss_quantile_huber(wo.q, N * L.A, L.A, 1, self.y, t_on, N, act, wgt, B, N, Nd, self.loss, wo.dq, self.state)
         elif algo == "fqf":
             F = L.F
+            def taus(net, ws, k):
+                net.fqf_taus(ws, B)
+                if rand is not None:
+                    ws.tau_all[: B * (F + 1)].copy_(rand[2 * k].reshape(-1)); ws.tau_hat[: B * F].copy_(rand[2 * k + 1].reshape(-1))
             on.encode(wo, frames, slot, sample_stride, 0, B)
-            on.fqf_taus(wo, B)
+            taus(on, wo, 0)
             on.head(wo, B, wo.tau_hat, F)
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             if self.double_q:
                 on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
-                on.fqf_taus(wsel, B)
+                taus(on, wsel, 1)
                 on.head(wsel, B, wsel.tau_hat, F)
                 on.select(wsel, B, F, self.a_star)
             else:
-                tg.fqf_taus(wt, B)
+                taus(tg, wt, 1)
                 tg.head(wt, B, wt.tau_hat, F)
                 tg.select(wt, B, F, self.a_star)
             tg.head(wt, B, wo.tau_hat, F)           # quirk Q16: target evaluated at the ONLINE tau-hats

@@ -114,6 +114,11 @@ def head_iqn(p: Params, spec, feat: torch.Tensor, taus: torch.Tensor) -> torch.T
     return q.view(B, n, spec.action_dim)
 
 
+# When a list, every fqf_prop_taus call appends its (taus, taus_hat): the parity tests hand these to the device path so that both sides
+# evaluate q(tau) at bit-identical fractions (cos(pi*64*tau) amplifies ulp-level differences of two softmax/cumsum evaluations ~200x).
+TAU_LOG: Optional[list] = None
+
+
 def fqf_prop_taus(p: Params, spec, feat_detached: torch.Tensor):
     """(taus [B,F+1,1], taus_hat [B,F,1], entropies [B,1])  model.py:268-278."""
     logp = F.linear(feat_detached, p["head.fraction_net.weight"], p["head.fraction_net.bias"]).log_softmax(dim=-1)
@@ -121,6 +126,8 @@ def fqf_prop_taus(p: Params, spec, feat_detached: torch.Tensor):
     taus = torch.cat((torch.zeros(feat_detached.shape[0], 1, dtype=probs.dtype), torch.cumsum(probs, dim=-1)), dim=-1)
     taus_hat = (taus[:, :-1] + taus[:, 1:]).detach() / 2.0
     ent = -(probs * logp).sum(dim=-1, keepdim=True)
+    if TAU_LOG is not None:
+        TAU_LOG.append((taus.detach().clone(), taus_hat.detach().clone()))
     return taus.unsqueeze(-1), taus_hat.unsqueeze(-1), ent
 
 

@@ -58,46 +58,200 @@ def _batch(hip, spec, B, seed_f, seed_t):
     return D(frames.reshape(-1)), D(a.astype(np.int32)), D(r), D(d.astype(np.float32)), D(w)
 
 
-G3_GPU = ["dqn_b8_dq0_n1", "dqn_b8_dq1_n3", "dqn_duel_b8_dq1_n1", "c51_b8_dq0_n1", "c51_b8_dq1_n3", "qr_b8_dq0_n1", "qr_duel_b8_dq1_n3",
-          "dqn_b512_dq0_n1", "c51_b512_dq1_n3"]
+def _golden_noise_g3(dev, L, g):
+    """Install the NoisyNet draws the reference made for this fixture (keys noise::<online|target>::<module>.<vector>)."""
+    for tag, net in (("online", dev.online), ("target", dev.target)):
+        for prefix, *_ in L.noise_modules:
+            net.set_noise(prefix, *[g[f"noise::{tag}::{prefix}.{leaf}"] for leaf in ("noise_in", "noise_out_weight", "noise_out_bias")])
+
+
+def _oracle_fqf_taus(spec, po, pt, hp, frames, a, r, d):
+    """The fractions the oracle (== the reference: same torch ops) proposes for this batch: (online net on obs, selection pass on next obs).
+    Both sides then evaluate q(tau) at bit-identical fractions — cos(pi*64*tau) amplifies ulp-level differences of two softmax/cumsum
+    evaluations ~200x; the fraction net itself is compared in test_forward[fqf]."""
+    from oracle import losses, nets
+    ft = nets.normalize(torch.from_numpy(frames))
+    obs, nxt = torch.split(ft, spec.obs_shape[0], 1)
+    nets.TAU_LOG = []
+    try:
+        with torch.no_grad():
+            losses.train_step(po, pt, spec, hp, obs, torch.from_numpy(a), torch.from_numpy(r), torch.from_numpy(d).float(), nxt, None)
+        log = nets.TAU_LOG
+    finally:
+        nets.TAU_LOG = None
+    assert len(log) == 2
+    return [x for pair in log for x in pair]
+
+
+def _case(case):
+    name, b, dq, n = case.rsplit("_", 3)
+    return name, int(b[1:]), bool(int(dq[2:])), int(n[1:])
+
+
+G3_GPU = ["dqn_b8_dq0_n1", "dqn_b8_dq1_n3", "dqn_duel_b8_dq1_n1", "mdqn_b8_dq0_n1", "c51_b8_dq0_n1", "c51_b8_dq1_n3", "c51_duel_noisy_b8_dq1_n3",
+          "qr_b8_dq0_n1", "qr_duel_b8_dq1_n3", "iqn_b8_dq0_n1", "iqn_duel_b8_dq1_n3", "fqf_b8_dq0_n1", "fqf_b8_dq1_n3", "dqn_tiny_b32_dq1_n1",
+          "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1", "c51_b512_dq1_n3"]
+
+
+def test_every_committed_g3_g6_fixture_reaches_the_gpu():
+    import glob, os
+    from util import GOLDEN
+    have3 = sorted(os.path.basename(f)[3:-4] for f in glob.glob(os.path.join(GOLDEN, "g3_*.npz")))
+    have6 = sorted(os.path.basename(f)[3:-4] for f in glob.glob(os.path.join(GOLDEN, "g6_*.npz")))
+    assert have3 == sorted(G3_GPU) and have6 == sorted(G6_GPU)
 
 
 @pytest.mark.parametrize("case", G3_GPU)
 def test_golden_losses(hip, case):
-    """Per-sample TD losses of the reference learners (fixture group G3) reproduced by the HIP path."""
-    name, b, dq, n = case.rsplit("_", 3)
-    B, dq, n = int(b[1:]), bool(int(dq[2:])), int(n[1:])
+    """Per-sample TD losses of the reference learners (fixture group G3, all 17 cases: six algorithms, dueling, NoisyNet, double-Q, n-step,
+    B up to 512) reproduced by the HIP path, with the reference's own random draws (IQN taus, NoisyNet noise) injected."""
+    from oracle import learner as olearner
+    from oracle.losses import Hyper
+    name, B, dq, n = _case(case)
     spec = SPECS[name]
     g = golden(f"g3_{case}")
     L, dev = _device_learner(hip, spec, B, dq, n)
+    if spec.noisy:
+        _golden_noise_g3(dev, L, g)
+    frames_np = recipe.make_frames(B, 31, spec.obs_shape)
+    a_np, r_np, d_np, _ = recipe.make_transitions(B, spec.action_dim, 32)
     frames, a, r, d, w = _batch(hip, spec, B, 31, 32)
     w = torch.ones_like(w)
-    loss = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x).reshape(-1).copy()).to(hip.device)
+    rand = None
+    if spec.algo == "iqn":
+        rand = [D(g[f"rand_{i}"]) for i in range(3)]
+    elif spec.algo == "fqf":
+        po, pt = olearner.to_params(recipe.make_state_dict(spec, 11)), olearner.to_params(recipe.make_state_dict(spec, 12))
+        rand = [D(x.numpy()) for x in _oracle_fqf_taus(spec, po, pt, Hyper(double_q=dq, n_step=n), frames_np, a_np, r_np, d_np)]
+    out = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w, rand=rand)
+    loss, frac = out if isinstance(out, tuple) else (out, None)
     assert_close(loss[:B], g["loss"], 5e-5, 5e-6, "per-sample loss vs reference")
+    if frac is not None:
+        assert_close(frac[:B], g["fraction_loss"], 5e-5, 2e-5, "fraction loss vs reference")
+    assert int(dev.state[2]) == 0
 
 
-def test_golden_train_step_b512(hip):
-    """One full reference train() at B=512 (fixture G6): loss and post-Adam parameter fingerprints."""
-    spec = SPECS["dqn"]
-    g = golden("g6_dqn_b512_dq0_n1")
-    B = 512
-    L, dev = _device_learner(hip, spec, B, False, 1, target_update_freq=2)
-    frames, a, r, d, w = _batch(hip, spec, B, 61, 62)
-    loss = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w)
-    assert_close(loss[:B], g["s0::q_loss"], 5e-5, 5e-6, "q_loss")
-    grads = L.unpack(dev.grads)
-    params = dev.online.state_dict()
-    for k in g.files:
-        parts = k.split("::")
-        if parts[0] != "s0" or len(parts) < 3:
-            continue
-        if parts[1] == "grad":
-            want, got = g[k], recipe.checksum(grads[parts[2]].cpu().numpy())
-            assert abs(got[1] - want[1]) <= 3e-4 * max(want[1], 1e-6), (k, got[1], want[1])
-        elif parts[1] == "param":
-            want, got = g[k], recipe.checksum(params[parts[2]].cpu().numpy())
-            assert abs(got[1] - want[1]) <= 1e-5 * max(want[1], 1e-6), (k, got[1], want[1])
-            assert np.all(np.abs(got[2:] - want[2:]) <= 5e-5 + 1e-4 * np.abs(want[2:])), (k, got[2:], want[2:])
+G6_GPU = ["dqn_b16_dq0_n1", "dqn_duel_b16_dq1_n3", "c51_duel_noisy_b16_dq1_n3", "c51_b16_dq0_n1", "qr_b16_dq0_n1", "iqn_b16_dq0_n1", "fqf_b16_dq0_n1",
+          "mdqn_b16_dq0_n1", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1"]
+
+
+@pytest.mark.parametrize("case", G6_GPU)
+def test_golden_train_steps(hip, case):
+    """Full reference ``learner.train()`` calls (fixture group G6, all 11 cases; two consecutive steps with a target sync for B <= 32):
+    per-sample losses, gradient and post-optimizer parameter fingerprints (sum-of-squares norm + first eight values) of every tensor of
+    the online net, the target net's fingerprints, the update counter — Adam eps = 1e-2/B, FQF's RMSprop on the fraction net included."""
+    from oracle import learner as olearner, nets
+    from oracle.losses import Hyper
+    name, B, dq, n = _case(case)
+    spec = SPECS[name]
+    g = golden(f"g6_{case}")
+    L, dev = _device_learner(hip, spec, B, dq, n, target_update_freq=2)
+    ora = None
+    if spec.algo == "fqf":      # the oracle steps alongside only to supply the fractions (see _oracle_fqf_taus)
+        ora = olearner.OracleLearner(spec, recipe.make_state_dict(spec, 11), recipe.make_state_dict(spec, 12), Hyper(double_q=dq, n_step=n), batch_size=B, target_update_freq=2)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x).reshape(-1).copy()).to(hip.device)
+    steps = 2 if B <= 32 else 1
+    for s in range(steps):
+        frames_np = recipe.make_frames(B, 61 + s, spec.obs_shape)
+        a_np, r_np, d_np, w_np = recipe.make_transitions(B, spec.action_dim, 62 + s)
+        frames, a, r, d, w = _batch(hip, spec, B, 61 + s, 62 + s)
+        rand = None
+        if spec.algo == "iqn":
+            rand = [D(g[f"s{s}::rand_{i}"]) for i in range(3)]
+        elif spec.algo == "fqf":
+            nets.TAU_LOG = []
+            ora.train(frames_np.reshape(B, -1), a_np, r_np, d_np.astype(np.float32), w_np, np.arange(B))
+            rand = [D(x.numpy()) for pair in nets.TAU_LOG for x in pair]
+            nets.TAU_LOG = None
+        if spec.noisy:
+            nd = len(L.noise_modules) * 3
+            draws = [g[f"s{s}::normal_{i}"] for i in range(2 * nd)]
+            E.install_noise(dev.online, draws[:nd])
+            E.install_noise(dev.target, draws[nd:])
+        out = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w, rand=rand)
+        loss, frac = out if isinstance(out, tuple) else (out, None)
+        assert_close(loss[:B], g[f"s{s}::q_loss"], 5e-5, 5e-6, f"s{s} q_loss")
+        if frac is not None:
+            assert_close(frac[:B], g[f"s{s}::fraction_loss"], 5e-5, 2e-5, f"s{s} fraction_loss")
+        assert int(dev.state[1]) == int(g[f"s{s}::update_steps"])
+        grads = L.unpack(dev.grads)
+        params, target = dev.online.state_dict(), dev.target.state_dict()
+        for k in g.files:
+            parts = k.split("::")
+            if parts[0] != f"s{s}" or len(parts) < 3:
+                continue
+            want = g[k]
+            if parts[1] == "grad":
+                got = recipe.checksum(grads[parts[2]].cpu().numpy())
+                scale = max(want[1], 1e-6)
+                assert abs(got[1] - want[1]) <= 3e-4 * scale, (k, got[1], want[1])
+                assert np.all(np.abs(got[2:] - want[2:]) <= 3e-4 * scale / np.sqrt(max(grads[parts[2]].numel(), 1)) + 2e-4 * np.abs(want[2:]) + 1e-7), (k, got, want)
+            elif parts[1] in ("param", "target"):
+                got = recipe.checksum((params if parts[1] == "param" else target)[parts[2]].cpu().numpy())
+                assert abs(got[1] - want[1]) <= 1e-5 * max(want[1], 1e-6), (k, got[1], want[1])
+                assert np.all(np.abs(got[2:] - want[2:]) <= 5e-5 + 1e-4 * np.abs(want[2:])), (k, got[2:], want[2:])
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_golden_c51_projection_edge_cases(hip, n):
+    """Fixture group G4: the reference's categorical projection (agent.py:236-264) on the known-answer rows — integer b (lo == up, both
+    fix-ups), b = 0 and b = 50, rewards that clamp to either end, terminals — through a0_loss_c51.  (i) The kernel alone, fed the
+    reference's selected target distribution as log-probabilities: projected distribution m against the reference's ``target_prob``.
+    (ii) The whole learner on the fixture's frames: m and the per-sample loss."""
+    g = golden(f"g4_c51_projection_n{n}")
+    spec = SPECS["c51"]
+    A, T = spec.action_dim, spec.num_atoms
+    rew, done, act_np = g["rewards"], g["terminals"], g["actions"]
+    B = len(rew)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
+    atoms = torch.linspace(-10.0, 10.0, T).to(hip.device)
+    gamma_n = float(0.99 ** n)
+    # (i) kernel alone: a_star = 1 everywhere, its row holds log p (softmax(log p) == p to an ulp), the other rows are arbitrary
+    tgt = torch.full((B, A, T), -3.0)
+    tgt[:, 1, :] = torch.from_numpy(g["prob_next_sel"]).log()
+    a_star = torch.ones(B, dtype=torch.int32)
+    loss, dq, m, state = hip.empty(B), hip.zeros(B * A * T), hip.empty(B * T), hip.zeros(8, dtype=torch.int32)
+    hip.loss_c51(hip.zeros(B * A * T), D(tgt.reshape(-1).numpy()), A, T, D(act_np.astype(np.int32)), D(a_star.numpy()), D(rew), D(done), D(np.ones(B, np.float32)), atoms,
+                 gamma_n, -10.0, 10.0, B, loss, dq, m, state)
+    assert_close(m.view(B, T), g["target_prob"], 2e-6, 2e-7, "projected distribution vs the reference's target_prob")
+    assert_close(m.view(B, T).sum(-1), np.ones(B), 1e-5, 0, "mass conserved")
+    # every edge row puts its mass exactly where the reference does (same support, zero elsewhere)
+    assert np.array_equal(m.view(B, T).cpu().numpy() > 0, g["target_prob"] > 0)
+    # (ii) whole learner
+    L, dev = _device_learner(hip, spec, B, False, n)
+    frames = D(recipe.make_frames(B, 41).reshape(-1))
+    out = dev.update(frames, None, 2 * 4 * 84 * 84, D(act_np.astype(np.int32)), D(rew), D(done), D(np.ones(B, np.float32)))
+    assert_close(out[:B], g["loss"], 5e-5, 5e-6, "c51 loss on the edge-case rows")
+    assert_close(dev.m_proj.view(B, T), g["target_prob"], 5e-5, 1e-6, "projected distribution, end to end")
+
+
+@pytest.mark.parametrize("tag", ["4x200x200", "8x64x64", "8x32x32", "3x8x5"])
+def test_golden_quantile_huber(hip, tag):
+    """Fixture group G5: the reference's huber_qr_loss (agent.py:110-114) and its gradient on random (q, T, tau) including exact ties
+    (T == q: indicator 0, zero Huber slope) and |q - T| == 1 (the quadratic/linear seam), shared QR midpoints (4x200x200) and per-sample
+    taus — through a0_loss_quantile_huber: loss [B] and d(sum_b w_b loss_b)/dq."""
+    g = golden("g5_huber_qr")
+    q, t, tau, w = g[f"q_{tag}"], g[f"t_{tag}"], g[f"tau_{tag}"], g[f"w_{tag}"]
+    B, N = q.shape
+    Nd = t.shape[1]
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x).reshape(-1)).to(hip.device)
+    loss, dq, state = hip.empty(B), hip.zeros(B * N), hip.zeros(8, dtype=torch.int32)
+    hip.loss_quantile_huber(D(q), N, 1, N, D(t), D(tau), (N if tau.shape[0] == B and tau.shape[0] > 1 else 0), hip.zeros(B, dtype=torch.int32), D(w), B, N, Nd, loss, dq, state)
+    assert_close(loss, g[f"loss_{tag}"], 1e-5, 1e-6, "loss")
+    assert_close(dq.view(B, N), g[f"dq_{tag}"], 1e-5, 1e-7, "dloss/dq")
+    assert int(state[0]) == 0
+
+
+@pytest.mark.parametrize("algo,dq,n", [("iqn", True, 3), ("fqf", False, 1)])
+def test_update_full_size_quantile_networks(hip, algo, dq, n):
+    """BASELINE configs[3] / configs[4] at their real geometry — 84x84 observations, A = 9 (Asterix), B = 512, IQN N = N' = 64 and K = 32,
+    FQF F = 32 — one whole update against the oracle: per-sample losses, every gradient tensor (cosine-embedding weight gradient,
+    Hadamard backward and the fc1 GEMMs over B*64 = 32 768 rows included), parameters and target after Adam / RMSprop.  Same tolerances
+    as the small cases (R6): losses rtol 5e-5, gradients 3e-5 of the tensor's max, parameters 2e-5 absolute."""
+    from oracle.losses import Hyper
+    spec = recipe.NetSpec(algo, 9)
+    E.check_update(hip, algo, 512, dq, n, spec=spec, hp=Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), steps=1, target_freq=1)
 
 
 def test_gather_fused_equals_dense_batch(hip):
