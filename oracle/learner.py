@@ -75,6 +75,33 @@ def to_params(sd_np: "OrderedDict[str, np.ndarray]") -> "OrderedDict[str, torch.
     return p
 
 
+def exact_gradients(spec, hp: Hyper, po, pt, frames_u8: np.ndarray, actions, rewards, terminals, weights, rand=None, taus=None):
+    """The gradients of one ``train`` call evaluated in float64 on the SAME fp32 inputs (parameters, fl(x/255) observations, draws) —
+    the arbiter for long reductions: at B = 512 a conv1 weight gradient sums 204 800 products per element, and two correct fp32
+    evaluations (torch's blocked sums, the MFMA's k-ordered chain) differ from each other by more than they each differ from this.
+    ``taus`` (FQF): the (taus, taus_hat) pairs the fp32 run used, in call order.  -> {key: float64 tensor}, per-sample loss (float64)."""
+    assert not spec.noisy
+    keys = nets.trainable_keys(po)
+    p64 = OrderedDict((k, v.detach().double().requires_grad_(k in keys)) for k, v in po.items())
+    t64 = OrderedDict((k, v.detach().double()) for k, v in pt.items())
+    C = spec.obs_shape[0]
+    fr = torch.from_numpy(np.ascontiguousarray(frames_u8)).float().reshape(-1, 2 * C, *spec.obs_shape[1:]).div(255.0).double()
+    obs, next_obs = torch.split(fr, C, 1)
+    a, r, d, w = torch.as_tensor(actions).long(), torch.as_tensor(rewards).double(), torch.as_tensor(terminals).double(), torch.as_tensor(weights).double()
+    rnd = None if rand is None else [torch.as_tensor(x).double() for x in rand]
+    nets.TAU_OVERRIDE = None if taus is None else [(t.double(), th.double()) for t, th in taus]
+    try:
+        q_loss, f_loss = losses.train_step(p64, t64, spec, hp, obs, a, r, d, next_obs, rnd)
+    finally:
+        nets.TAU_OVERRIDE = None
+    q_keys = [k for k in keys if "fraction" not in k]
+    out = dict(zip(q_keys, torch.autograd.grad((q_loss * w).sum(), [p64[k] for k in q_keys], allow_unused=True, retain_graph=f_loss is not None)))
+    if f_loss is not None:
+        f_keys = [k for k in keys if "fraction" in k]
+        out.update(zip(f_keys, torch.autograd.grad((f_loss * w).sum(), [p64[k] for k in f_keys])))
+    return out, q_loss.detach()
+
+
 class OracleLearner:
     def __init__(self, spec, online_sd, target_sd, hp: Hyper, batch_size: int, lr: float = 5e-4,
                  target_update_freq: int = 500, max_grad_norm: float = -1.0):

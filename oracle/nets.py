@@ -117,6 +117,9 @@ def head_iqn(p: Params, spec, feat: torch.Tensor, taus: torch.Tensor) -> torch.T
 # When a list, every fqf_prop_taus call appends its (taus, taus_hat): the parity tests hand these to the device path so that both sides
 # evaluate q(tau) at bit-identical fractions (cos(pi*64*tau) amplifies ulp-level differences of two softmax/cumsum evaluations ~200x).
 TAU_LOG: Optional[list] = None
+# When a list of (taus, taus_hat) pairs, fqf_prop_taus takes its VALUES from there, call by call (the autograd path to the fraction net is
+# kept): lets the fp64 evaluation of a step (learner.exact_gradients) run at the same fractions as the fp32 one it arbitrates.
+TAU_OVERRIDE: Optional[list] = None
 
 
 def fqf_prop_taus(p: Params, spec, feat_detached: torch.Tensor):
@@ -125,6 +128,10 @@ def fqf_prop_taus(p: Params, spec, feat_detached: torch.Tensor):
     probs = logp.exp()
     taus = torch.cat((torch.zeros(feat_detached.shape[0], 1, dtype=probs.dtype), torch.cumsum(probs, dim=-1)), dim=-1)
     taus_hat = (taus[:, :-1] + taus[:, 1:]).detach() / 2.0
+    if TAU_OVERRIDE is not None:
+        t_in, th_in = TAU_OVERRIDE.pop(0)
+        taus = taus + (t_in.to(taus.dtype) - taus).detach()
+        taus_hat = th_in.to(taus.dtype)
     ent = -(probs * logp).sum(dim=-1, keepdim=True)
     if TAU_LOG is not None:
         TAU_LOG.append((taus.detach().clone(), taus_hat.detach().clone()))
