@@ -25,6 +25,26 @@ import torch.nn.functional as F
 Params = Dict[str, torch.Tensor]
 
 
+# ReLU decisions of the differentiated pass, injected (parity tests at full size).  A ReLU's VALUE is continuous in its input but its
+# gradient is not: where a pre-activation sits within fp32 rounding of zero, two correct evaluations (torch's blocked sums, the MFMA's
+# k-ordered chain) can disagree on the 0/1 decision, and each such disagreement moves a weight gradient by one whole term of its sum.  When
+# RELU_MASKS = {"conv1" | "conv2" | "conv3" | "fc1" | "cos": 0/1 tensor in this module's layout} is set, every ReLU evaluated with autograd
+# enabled keeps its forward value but back-propagates through the given mask, and RELU_STATS[name] records (number of decisions that differ
+# from this module's own, number of decisions, largest |pre-activation| among the differing ones relative to the layer's largest).
+RELU_MASKS: Optional[dict] = None
+RELU_STATS: dict = {}
+
+
+def _relu(x: torch.Tensor, name: str) -> torch.Tensor:
+    if RELU_MASKS is None or not torch.is_grad_enabled() or name not in RELU_MASKS:
+        return F.relu(x)
+    m = RELU_MASKS[name].reshape(x.shape).to(x.dtype)
+    differ = (x > 0) != (m > 0)
+    worst = float(x.detach().abs()[differ].max()) / (float(x.detach().abs().max()) + 1e-30) if bool(differ.any()) else 0.0
+    RELU_STATS[name] = (int(differ.sum()), differ.numel(), worst)
+    return F.relu(x).detach() + m * (x - x.detach())
+
+
 def noise_f(x: torch.Tensor) -> torch.Tensor:
     """f(x) = sign(x) * sqrt(|x|)   (model.py:85-87)"""
     return x.sign() * x.abs().sqrt()
@@ -55,9 +75,9 @@ def dense(p: Params, prefix: str, x: torch.Tensor, noisy: bool) -> torch.Tensor:
 
 def encoder(p: Params, x: torch.Tensor, return_all: bool = False):
     """x: [B,C,H,W] fp32 in [0,1] -> [B, 64*h*w] flattened in (C,H,W) order."""
-    a1 = F.relu(F.conv2d(x, p["encoder.convs.0.weight"], p["encoder.convs.0.bias"], stride=4))
-    a2 = F.relu(F.conv2d(a1, p["encoder.convs.2.weight"], p["encoder.convs.2.bias"], stride=2))
-    a3 = F.relu(F.conv2d(a2, p["encoder.convs.4.weight"], p["encoder.convs.4.bias"], stride=1))
+    a1 = _relu(F.conv2d(x, p["encoder.convs.0.weight"], p["encoder.convs.0.bias"], stride=4), "conv1")
+    a2 = _relu(F.conv2d(a1, p["encoder.convs.2.weight"], p["encoder.convs.2.bias"], stride=2), "conv2")
+    a3 = _relu(F.conv2d(a2, p["encoder.convs.4.weight"], p["encoder.convs.4.bias"], stride=1), "conv3")
     feat = a3.flatten(1)
     if return_all:
         return feat, (a1, a2, a3)
@@ -71,7 +91,7 @@ def normalize(frames_u8: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- heads
 def head_dqn(p: Params, spec, feat: torch.Tensor) -> torch.Tensor:
-    h = F.relu(dense(p, "head.first_dense", feat, spec.noisy))
+    h = _relu(dense(p, "head.first_dense", feat, spec.noisy), "fc1")
     q = dense(p, "head.q_head", h, spec.noisy)
     if spec.dueling:
         v = dense(p, "head.value_head", h, spec.noisy)
@@ -81,7 +101,7 @@ def head_dqn(p: Params, spec, feat: torch.Tensor) -> torch.Tensor:
 
 def head_dist(p: Params, spec, feat: torch.Tensor) -> torch.Tensor:
     """C51 / QR: [B, A, atoms]; dueling value is [B,1,atoms], mean over the ACTION dim."""
-    h = F.relu(dense(p, "head.first_dense", feat, spec.noisy))
+    h = _relu(dense(p, "head.first_dense", feat, spec.noisy), "fc1")
     q = dense(p, "head.q_head", h, spec.noisy).view(feat.shape[0], spec.action_dim, spec.num_atoms)
     if spec.dueling:
         v = dense(p, "head.value_head", h, spec.noisy).view(feat.shape[0], 1, spec.num_atoms)
@@ -98,7 +118,7 @@ def cos_features(p: Params, spec, feat: torch.Tensor, taus: torch.Tensor) -> tor
     B, n, _ = taus.shape
     ipi = math.pi * torch.arange(1, spec.num_cosines + 1, dtype=feat.dtype).view(1, 1, -1)
     cosine = (ipi * taus).cos().reshape(B * n, spec.num_cosines)
-    emb = F.relu(F.linear(cosine, p["head.cosine_emb.0.weight"], p["head.cosine_emb.0.bias"])).view(B, n, -1)
+    emb = _relu(F.linear(cosine, p["head.cosine_emb.0.weight"], p["head.cosine_emb.0.bias"]), "cos").view(B, n, -1)
     return (emb * feat.unsqueeze(1)).reshape(B * n, -1)
 
 
@@ -106,7 +126,7 @@ def head_iqn(p: Params, spec, feat: torch.Tensor, taus: torch.Tensor) -> torch.T
     """[B,n,A] quantile values at the given taus [B,n,1]."""
     B, n, _ = taus.shape
     x = cos_features(p, spec, feat, taus)
-    h = F.relu(dense(p, "head.first_dense", x, spec.noisy))
+    h = _relu(dense(p, "head.first_dense", x, spec.noisy), "fc1")
     q = dense(p, "head.q_head", h, spec.noisy)
     if spec.dueling:
         v = dense(p, "head.value_head", h, spec.noisy)

@@ -233,6 +233,87 @@ def test_update_matches_oracle(ops, name, B, dq, n):
     check_update(ops, name, B, dq, n)
 
 
+def device_relu_masks(dev: DeviceLearner, L: NetLayout, B: int):
+    """The 0/1 ReLU decisions of the device's differentiated (online, current-observation) pass, in the oracle's layouts."""
+    ws, R = dev.ws_o, dev.ws_o.R
+    nchw = lambda t, h, w, c: (t[: B * h * w * c].view(B, h, w, c).permute(0, 3, 1, 2) > 0).float().cpu()
+    m = {"conv1": nchw(ws.act1, L.H1, L.W1, 32), "conv2": nchw(ws.act2, L.H2, L.W2, 64), "conv3": nchw(ws.act3, L.H3, L.W3, 64),
+         "fc1": (ws.h[: R * 512].view(R, 512) > 0).float().cpu()}
+    if L.quantile:      # embedding columns are (h, w, c) on the device, (c, h, w) in the reference
+        m["cos"] = (ws.emb[: R * L.feat].view(R, L.H3, L.W3, 64).permute(0, 3, 1, 2).reshape(R, L.feat) > 0).float().cpu()
+    return m
+
+
+def check_update_full_size(ops, spec, hp, B, seed=61, lr=5e-4):
+    """One whole update at a batch size where reductions are long (B = 512: 204 800 products per conv1 weight, 32 768 rows per fc1 weight
+    of the quantile networks), HIP against the oracle.  Two effects that the small cases do not show are separated out instead of being
+    absorbed into a loose tolerance:
+
+      * ReLU decisions.  With ~10^7 ReLUs in the differentiated pass a handful of pre-activations sit within fp32 rounding of zero, where
+        two correct evaluations disagree on the 0/1 decision; each disagreement moves a weight gradient by one whole term.  The test (a)
+        asserts that the device's decisions differ from the oracle's only at pre-activations below 1e-5 of the layer's largest, and at
+        most for 1e-4 of them, and (b) has the oracle back-propagate through the device's decisions (oracle.nets.RELU_MASKS; forward
+        values untouched).  Then losses agree to rtol 5e-5 and EVERY gradient tensor to 3e-5 of its largest element — the small cases'
+        tolerances.
+      * Adam's first step is lr * g / (|g| + eps) with eps = 1e-2 / B = 2e-5: where |g| is below the gradient tolerance the step's sign is
+        undetermined.  Parameters are compared with the tolerance that the measured gradient difference dg implies through that formula,
+        2e-5 + lr * min(2, dg * eps / (max(|g| - dg, 0) + eps)^2): 2e-5 absolute for all but the few elements with |g| ~ dg (the test
+        asserts that fewer than 2 % of a tensor's elements get more than 1e-4).
+    """
+    L = NetLayout.from_spec(spec)
+    sd_o, sd_t = recipe.make_state_dict(spec, 11), recipe.make_state_dict(spec, 12)
+    dev = DeviceLearner(ops, L, B, n_step=hp.n_step, double_q=hp.double_q, target_update_freq=1, K=hp.K, N=hp.N, N_dash=hp.N_dash, lr=lr)
+    dev.online.load_state_dict(sd_o)
+    dev.target.load_state_dict(sd_t)
+    frames = recipe.make_frames(B, seed, spec.obs_shape)
+    a, r, d, w = recipe.make_transitions(B, spec.action_dim, seed + 1)
+    rand_np = None
+    if spec.algo == "iqn":
+        g = recipe.gen(seed + 9)
+        rand_np = [g.random((B, n, 1), dtype=np.float32) for n in (hp.K, hp.N_dash, hp.N)]
+    args = (frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B))
+    taus = None
+    if spec.algo == "fqf":      # the fractions both sides use (see run_both)
+        nets.TAU_LOG = []
+        olearner.OracleLearner(spec, sd_o, sd_t, hp, batch_size=B, target_update_freq=1).train(*args)
+        taus, nets.TAU_LOG = nets.TAU_LOG, None
+        rand_np = [x.numpy() for pair in taus for x in pair]
+    D = lambda t: t.to(ops.device)
+    out = dev.update(D(torch.from_numpy(frames).reshape(-1)), None, 2 * int(np.prod(spec.obs_shape)), D(torch.from_numpy(a.astype(np.int32))), D(torch.from_numpy(r)),
+                     D(torch.from_numpy(d.astype(np.float32))), D(torch.from_numpy(w)),
+                     rand=None if rand_np is None else [D(torch.from_numpy(np.ascontiguousarray(x).reshape(-1).copy())) for x in rand_np])
+    loss_d, frac_d = (out if isinstance(out, tuple) else (out, None))
+    ora = olearner.OracleLearner(spec, sd_o, sd_t, hp, batch_size=B, lr=lr, target_update_freq=1)
+    nets.RELU_MASKS, nets.RELU_STATS = device_relu_masks(dev, L, B), {}
+    try:
+        res = ora.train(*args, rand=rand_np if spec.algo == "iqn" else None)
+    finally:
+        nets.RELU_MASKS = None
+    stats = dict(nets.RELU_STATS)
+    assert set(stats) == set(["conv1", "conv2", "conv3", "fc1"] + (["cos"] if L.quantile else []))
+    for name, (n_bad, n, worst) in stats.items():
+        assert worst <= 1e-5 and n_bad <= 1e-4 * n, f"ReLU decisions of {name}: {n_bad}/{n} differ, largest |pre-activation| {worst:.2e} of the layer's largest"
+    assert_close(loss_d[:B], res["q_loss"], 5e-5, 5e-6, "q_loss")
+    if frac_d is not None:
+        assert_close(frac_d[:B], res["fraction_loss"], 5e-5, 2e-5, "fraction_loss")
+    g_dev = L.unpack(dev.grads)
+    got, tgt = dev.online.state_dict(), dev.target.state_dict()
+    eps = 1e-2 / B
+    for k, g in ora.last_grads.items():
+        if g is None:
+            continue
+        scale = float(g.abs().max()) + 1e-12
+        assert_close(g_dev[k] / scale, g / scale, 0, 3e-5, f"grad {k}")
+        dg = float((g_dev[k].cpu() - g).abs().max())
+        tol = 2e-5 + (0.0 if "fraction" in k else lr) * torch.clamp(dg * eps / ((g.abs() - dg).clamp(min=0) + eps) ** 2, max=2.0)
+        for src, ref, tag in ((got, ora.po, "param"), (tgt, ora.pt, "target param")):
+            err = (src[k].cpu() - ref[k].detach()).abs()
+            assert bool((err <= tol).all()), f"{tag} {k}: {int((err > tol).sum())}/{err.numel()} outside the Adam-sensitivity tolerance, worst {float((err - tol).max()):.3e}"
+        assert float((tol > 1e-4).float().mean()) <= 2e-2, f"{k}: a tolerance above 1e-4 (a fifth of one Adam step) applies to more than 2 % of the elements"
+    assert int(dev.state[1]) == ora.update_steps == 1
+    return stats
+
+
 def check_nan_skip(ops):
     spec = CASES["dqn"]
     L = NetLayout.from_spec(spec)
@@ -269,3 +350,12 @@ def test_gather_row_division_by_multiply_high_is_exact():
         assert lib.emul_udiv_mismatches(d, 0, 3_000_000, 1) == 0, d                       # every row index of a 512- to 7 000-sample batch
         assert lib.emul_udiv_mismatches(d, 0, 2**31 - 1, 104_729) == 0, d                  # strided up to the largest int
         assert lib.emul_udiv_mismatches(d, 2**31 - 1 - 2_000_000, 2**31 - 1, 1) == 0, d   # and the top of the range
+
+
+@pytest.mark.parametrize("name", ["dqn_duel", "iqn", "fqf"])
+def test_full_size_check_machinery_on_the_small_geometry(ops, name):
+    """check_update_full_size (ReLU decisions injected into the oracle's backward pass, Adam-sensitivity tolerance) runs on the GPU at
+    B = 512 and 84x84; here the same function on the emulation backend at the tiny geometry, so that the machinery itself is tested on CPU."""
+    spec = CASES[name]
+    stats = check_update_full_size(ops, spec, Hyper(double_q=(name != "fqf"), n_step=3, K=6, N=8, N_dash=5), 16)
+    assert all(n > 0 for _, n, _ in stats.values())

@@ -169,11 +169,6 @@ def test_golden_train_steps(hip, case):
             draws = [g[f"s{s}::normal_{i}"] for i in range(2 * nd)]
             E.install_noise(dev.online, draws[:nd])
             E.install_noise(dev.target, draws[nd:])
-        g64 = None
-        if B >= 256:      # long reductions: a float64 evaluation of the same step arbitrates between the two fp32 summation orders
-            assert s == 0 and rand is None and not spec.noisy
-            g64, _ = olearner.exact_gradients(spec, Hyper(double_q=dq, n_step=n), olearner.to_params(recipe.make_state_dict(spec, 11)),
-                                              olearner.to_params(recipe.make_state_dict(spec, 12)), frames_np.reshape(B, -1), a_np, r_np, d_np.astype(np.float32), w_np)
         out = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w, rand=rand)
         loss, frac = out if isinstance(out, tuple) else (out, None)
         assert_close(loss[:B], g[f"s{s}::q_loss"], 5e-5, 5e-6, f"s{s} q_loss")
@@ -191,11 +186,13 @@ def test_golden_train_steps(hip, case):
                 got = recipe.checksum(grads[parts[2]].cpu().numpy())
                 scale = max(want[1], 1e-6)
                 assert abs(got[1] - want[1]) <= 3e-4 * scale, (k, got[1], want[1])
-                near = np.all(np.abs(got[2:] - want[2:]) <= 3e-4 * scale / np.sqrt(max(grads[parts[2]].numel(), 1)) + 2e-4 * np.abs(want[2:]) + 1e-7)
-                if not near and g64 is not None:      # ... or at least as close to the float64 values as twice the reference's own fp32 error
-                    exact = g64[parts[2]].reshape(-1)[:8].numpy()
-                    near = np.abs(got[2:] - exact).max() <= 2.0 * np.abs(want[2:] - exact).max()
-                assert near, (k, got, want)
+                # At B = 512 a handful of the batch's ~10^7 ReLU decisions fall on pre-activations within fp32 rounding of zero and come out
+                # differently than in torch; each moves a convolution weight gradient by one whole term of its sum (measured: up to 1.2e-3
+                # of the tensor's max, profiles/r02_grad_accuracy.txt).  The fixture cannot be re-evaluated with the device's decisions, so
+                # its convolution fingerprints get that width here; test_update_full_size[dqn] makes the same comparison against the
+                # oracle WITH the decisions injected, at 3e-5.
+                flip = 2e-3 * float(grads[parts[2]].abs().max()) if (B >= 256 and "convs" in k) else 0.0
+                assert np.all(np.abs(got[2:] - want[2:]) <= 3e-4 * scale / np.sqrt(max(grads[parts[2]].numel(), 1)) + 2e-4 * np.abs(want[2:]) + 1e-7 + flip), (k, got, want)
             elif parts[1] in ("param", "target"):
                 got = recipe.checksum((params if parts[1] == "param" else target)[parts[2]].cpu().numpy())
                 assert abs(got[1] - want[1]) <= 1e-5 * max(want[1], 1e-6), (k, got[1], want[1])
@@ -252,17 +249,17 @@ def test_golden_quantile_huber(hip, tag):
     assert int(state[0]) == 0
 
 
-@pytest.mark.parametrize("algo,dq,n", [("iqn", True, 3), ("fqf", False, 1)])
-def test_update_full_size_quantile_networks(hip, algo, dq, n):
-    """BASELINE configs[3] / configs[4] at their real geometry — 84x84 observations, A = 9 (Asterix), B = 512, IQN N = N' = 64 and K = 32,
-    FQF F = 32 — one whole update against the oracle: per-sample losses, every gradient tensor (cosine-embedding weight gradient,
-    Hadamard backward and the fc1 GEMMs over B*64 = 32 768 rows included), parameters and target after Adam / RMSprop.  Tolerances of the
-    small cases (R6): losses rtol 5e-5, parameters 2e-5 absolute, gradients 3e-5 of the tensor's max — except where a reduction is so long
-    (conv1: 204 800 products per weight) that two correct fp32 summation orders differ by more: there the HIP gradient must be at least as
-    close to a float64 evaluation of the same step as twice the oracle's fp32 error (check_update, ``arbiter``)."""
+@pytest.mark.parametrize("algo,A,dq,n", [("dqn", 4, False, 1), ("c51", 4, True, 3), ("iqn", 9, True, 3), ("fqf", 9, False, 1)])
+def test_update_full_size(hip, algo, A, dq, n):
+    """BASELINE configs[1..4] at their real geometry — 84x84 observations, B = 512; Breakout's A = 4 for dqn / c51, Asterix's A = 9 with
+    IQN N = N' = 64, K = 32 and FQF F = 32 — one whole update against the oracle: per-sample losses, every gradient tensor (the
+    cosine-embedding weight gradient, Hadamard backward and the fc1 GEMMs over B*64 = 32 768 rows included), parameters and target after
+    Adam / RMSprop, at the small cases' tolerances (losses rtol 5e-5, gradients 3e-5 of the tensor's max, parameters 2e-5 absolute), with
+    the two effects of scale — ReLU decisions at rounding-level pre-activations, Adam's sign-like first step at eps = 2e-5 — separated
+    out and bounded (tests/test_engine_emul.py::check_update_full_size)."""
     from oracle.losses import Hyper
-    spec = recipe.NetSpec(algo, 9)
-    E.check_update(hip, algo, 512, dq, n, spec=spec, hp=Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), steps=1, target_freq=1, arbiter=True)
+    stats = E.check_update_full_size(hip, recipe.NetSpec(algo, A, **({"num_atoms": 51} if algo == "c51" else {})), Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), 512)
+    print({k: (v[0], v[1], f"{v[2]:.1e}") for k, v in stats.items()})
 
 
 def test_gather_fused_equals_dense_batch(hip):
