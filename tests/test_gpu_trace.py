@@ -1,0 +1,226 @@
+"""GPU (MI355X): the COMPOSED loop — Actor.sample -> replay.extend -> sample -> importance weights -> train -> update_priority — of the
+product's Trainer walked in lock-step with oracle.trainer.OracleTrainer (reference trainer.py:74-119,171-184; launch.py:30-63).
+
+Every link is compared right where it happens, from identical state: the test wraps the Trainer's own replay.extend / replay.sample /
+learner.train_batch / replay.update_priority (the calls Trainer.step makes, in its order), lets the original run, performs the oracle's
+corresponding step and compares —
+  after extend:            the whole ring (st||st_next bytes, actions, n-step rewards, dones) incl. the wrap, top, beta, max_p and the
+                           priority vector / every node of the sum-tree, the rollout's episode returns and per-step mean max-Q     [exact; Q 5e-5]
+  after sample:            sampled indices, ring slots, the rows those slots hold, metadata, priorities                          [exact]
+                           importance weights                                                                                     [2e-6]
+  after train_batch:       per-sample losses [rtol 5e-5]; every gradient tensor [3e-5 of its max]; the parameters after Adam against the
+                           oracle's Adam formula applied to the device's gradients from the common pre-step state [2e-6 abs]; the Adam
+                           moments; the target (bitwise copy on a sync step, untouched otherwise); the update counter
+  after update_priority:   priorities / tree and max_p                                                                            [1 ulp]
+— and then copies the oracle's floating-point state (parameters, Adam moments, priorities) over the device's, so that ulp-level drift
+cannot move a later comparison: an index that differs, a β off by one extend, a priority written to the wrong leaf or a rollout acting
+with the wrong weights shows up at the link where it happens.  Ring size 200 with 80 transitions per rollout: the ring wraps in the
+third rollout and again in the fifth; training starts in the second iteration; the target syncs every 4 updates.
+"""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle.trainer import OracleTrainer
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+E_, T_, B_, SIZE, LSTEPS, START, TFREQ = 8, 10, 32, 200, 3, 100, 4
+
+
+def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS):
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    over = [f"learner.algo={algo}", f"actor.num_envs={E_}", f"actor.sample_steps={T_}", f"learner.batch_size={B_}", f"replay.size={SIZE}",
+            f"learner.learner_steps={ls}", f"trainer.training_start_steps={START}", f"learner.target_update_freq={TFREQ}", f"learner.n_step_q={n_step}",
+            f"learner.double_q={str(double_q).lower()}", f"replay.policy={policy}", f"replay.sumtree={str(sumtree).lower()}", "trainer.exploration_steps=100",
+            "trainer.total_steps=4000", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"]
+    cfg = parse_overrides(over)
+    tr = Trainer(cfg, use_lp=launch)
+    spec = recipe.SPECS[algo]
+    sd = recipe.make_state_dict(spec, 11)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    tr.learner.model.load_state_dict(tsd)
+    tr.learner.engine.sync_target(force=True)
+    if launch:
+        tr.actors[1].model.load_state_dict(tsd)
+    ora = OracleTrainer(spec, sd, num_envs=E_, sample_steps=T_, batch_size=B_, replay_size=SIZE, learner_steps=ls, training_start_steps=START, policy=policy,
+                        sumtree=sumtree, n_step=n_step, double_q=double_q, seed=cfg.seed, target_update_freq=TFREQ, total_steps=4000, exploration_steps=100,
+                        launch=launch)
+    return tr, ora, spec
+
+
+class LockStep:
+    def __init__(self, tr, ora, spec):
+        self.tr, self.ora, self.spec = tr, ora, spec
+        self.rp, self.eng, self.L = tr.replay, tr.learner.engine, tr.learner.engine.L
+        self.rec = None
+        self.n_ext = self.n_upd = 0
+        self.rollout_stats = None
+        rp, ln = self.rp, tr.learner
+        self._extend, self._sample, self._train, self._update = rp.extend, rp.sample, ln.train_batch, rp.update_priority
+        rp.extend, rp.sample, ln.train_batch, rp.update_priority = self.extend, self.sample, self.train, self.update
+
+    # ---- state helpers
+    def _cmp_priorities(self, tol_ulp, what):
+        rp, orp = self.rp, self.ora.replay
+        if self.ora.sumtree:
+            got, want = rp.tree.cpu().numpy(), orp.tree.tree
+            assert got.shape == want.shape
+            if tol_ulp == 0:
+                assert np.array_equal(got, want), f"{what}: sum-tree nodes"
+            else:
+                assert_close(got, want, 6e-5, 0, f"{what}: sum-tree nodes")     # the device's priorities come from the device's losses (rtol 5e-5)
+                assert np.array_equal(got == 0, want == 0)
+            assert float(rp._pstate[0]) == float(orp.max_p) or abs(float(rp._pstate[0]) - float(orp.max_p)) <= 6e-5 * float(orp.max_p), f"{what}: max_p"
+        elif self.ora.prioritize:
+            if tol_ulp == 0:
+                assert np.array_equal(rp.priority.cpu().numpy(), orp.priority), f"{what}: priority vector"
+            else:
+                assert_close(rp.priority, orp.priority, 6e-5, 0, f"{what}: priority vector")
+                assert np.array_equal(rp.priority.cpu().numpy() == 1.0, orp.priority == 1.0)
+            assert abs(rp.max_p - orp.max_p) <= 6e-5 * orp.max_p, f"{what}: max_p"
+
+    def _resync_priorities(self):
+        rp, orp = self.rp, self.ora.replay
+        if self.ora.sumtree:
+            rp.tree.copy_(torch.from_numpy(orp.tree.tree))
+            rp._pstate[0] = float(orp.max_p)
+        elif self.ora.prioritize:
+            rp.priority.copy_(torch.from_numpy(orp.priority))
+            rp._pstate[0] = float(np.float32(orp.max_p))
+            orp.max_p = float(np.float32(orp.max_p))        # the device keeps max_p in fp32; both sides continue from that value
+
+    def _resync_learner(self):
+        eng, L, ol = self.eng, self.L, self.ora.learner
+        L.pack({k: v.detach() for k, v in ol.po.items()}, eng.online.flat)
+        L.pack({k: v.detach() for k, v in ol.pt.items()}, eng.target.flat)
+        eng.online.refresh_wt(); eng.target.refresh_wt()
+        L.pack(ol.adam.m, eng.adam_m)
+        L.pack(ol.adam.v, eng.adam_v)
+
+    # ---- the wrapped calls, in the order Trainer.step makes them
+    def extend(self, transitions):
+        rp, ora = self.rp, self.ora
+        self._extend(transitions)
+        data, rs, qs = ora.next_transitions()
+        self.rollout_stats = (rs, qs)
+        ora.begin_step(data, rs, qs)
+        self.n_ext += 1
+        assert rp.top == len(ora.replay) and self.tr.frame_count + self.tr.num_transitions == ora.frame_count
+        frames = rp.frames.view(rp.size, -1).cpu().numpy()
+        act, rew, done = rp.act.cpu().numpy(), rp.rew.cpu().numpy(), rp.done.cpu().numpy()
+        n_live = 0
+        for s, t in enumerate(ora.replay.slots):
+            if t is None:
+                continue
+            n_live += 1
+            assert np.array_equal(frames[s], t[0].reshape(-1)), f"extend {self.n_ext}: ring slot {s}: st||st_next bytes"
+            assert act[s] == int(t[1]) and rew[s] == np.float32(t[2]) and bool(done[s]) == bool(t[3]), f"extend {self.n_ext}: ring slot {s}: (a, R, D)"
+        assert n_live == rp.top
+        if not self.ora.sumtree:
+            assert rp.head == ora.replay.head, "deque index 0 sits at the same ring slot"
+        if ora.prioritize:
+            assert rp.beta == ora.replay.beta, f"extend {self.n_ext}: beta"
+            self._cmp_priorities(0, f"extend {self.n_ext}")
+
+    def sample(self, *a, **k):
+        b = self._sample(*a, **k)
+        rec = self.rec = self.ora.sample_batch()
+        tag = f"update {self.n_upd}"
+        assert np.array_equal(b.idx.cpu().numpy(), rec.idx), f"{tag}: sampled indices"
+        assert np.array_equal(b.slot.cpu().numpy(), rec.slot), f"{tag}: ring slots"
+        rows = self.rp.frames.view(self.rp.size, -1)[b.slot.long()].cpu().numpy()
+        assert np.array_equal(rows, rec.frames.reshape(len(rec.idx), -1)), f"{tag}: the rows the learner will read"
+        assert np.array_equal(b.act.cpu().numpy(), rec.act) and np.array_equal(b.rew.cpu().numpy(), rec.rew) and np.array_equal(b.done.cpu().numpy(), rec.done)
+        if self.ora.prioritize:
+            assert np.array_equal(b.prio.cpu().numpy(), rec.prio), f"{tag}: priorities of the batch"
+            assert_close(b.weights, rec.weights, 2e-6, 1e-7, f"{tag}: importance weights")
+            b.weights.copy_(torch.from_numpy(rec.weights))
+        else:
+            assert np.array_equal(b.weights.cpu().numpy(), rec.weights)
+        return b
+
+    def train(self, *a, **k):
+        from oracle import learner as olearner
+        q, f = self._train(*a, **k)
+        ol = self.ora.learner
+        clone = lambda d: {key: val.detach().clone() for key, val in d.items()}
+        pre_p, pre_t, pre_m, pre_v, pre_steps = clone({key: ol.po[key] for key in ol.q_keys}), clone(ol.pt), clone(ol.adam.m), clone(ol.adam.v), ol.adam.t
+        rec = self.ora.train_batch(self.rec)
+        tag = f"update {self.n_upd}"
+        assert_close(q[: len(rec.idx)], rec.q_loss, 5e-5, 5e-6, f"{tag}: per-sample loss")
+        got, tgt = self.eng.online.state_dict(), self.eng.target.state_dict()
+        # gradients: 3e-5 of each tensor's largest element
+        g_dev = {key: val.cpu() for key, val in self.L.unpack(self.eng.grads).items()}
+        for key in ol.q_keys:
+            sc = float(ol.last_grads[key].abs().max()) + 1e-12
+            assert_close(g_dev[key] / sc, ol.last_grads[key] / sc, 0, 3e-5, f"{tag}: grad {key}")
+        # the optimizer's arithmetic, on the DEVICE's gradients from the common pre-step state (parameters and moments were made identical
+        # after the previous update): the oracle's Adam formula must land on the device's parameters.  (Comparing against the oracle's own
+        # post-step parameters would fold in Adam's amplification of the 3e-5 gradient differences where |g| is near eps = 1e-2/B.)
+        ad = olearner.Adam(ol.adam.lr, ol.adam.eps)
+        ad.t, ad.m, ad.v = pre_steps, pre_m, pre_v
+        ad.step(pre_p, {key: g_dev[key] for key in ol.q_keys})
+        synced = ol.update_steps % TFREQ == 0
+        for key in ol.q_keys:
+            assert_close(got[key], pre_p[key], 0, 2e-6, f"{tag}: param {key} after Adam")
+            if synced:
+                assert torch.equal(tgt[key], got[key]), f"{tag}: target sync {key}"
+            else:
+                assert torch.equal(tgt[key].cpu(), pre_t[key]), f"{tag}: target {key} untouched"
+        m, v = self.L.unpack(self.eng.adam_m), self.L.unpack(self.eng.adam_v)
+        for key in ol.q_keys:
+            sc = float(ol.adam.m[key].abs().max()) + 1e-12
+            assert_close(m[key] / sc, ol.adam.m[key] / sc, 0, 3e-5, f"{tag}: Adam m {key}")
+            sv = float(ol.adam.v[key].abs().max()) + 1e-20
+            assert_close(v[key] / sv, ol.adam.v[key] / sv, 0, 6e-5, f"{tag}: Adam v {key}")
+        assert int(self.eng.state[1]) == ol.update_steps
+        self._resync_learner()
+        self.n_upd += 1
+        return q, f
+
+    def update(self, ids, pr, state=None):
+        self._update(ids, pr, state=state)
+        self.ora.update_priority(self.rec)
+        self._cmp_priorities(1, f"update {self.n_upd - 1} priorities")
+        self._resync_priorities()
+
+
+CASES = [("dqn", "uniform", False, 1, False, False), ("dqn", "prioritize", True, 3, True, False), ("c51", "prioritize", False, 3, False, False),
+         ("c51", "prioritize", True, 3, True, False), ("dqn", "uniform", False, 3, False, True), ("c51", "prioritize", True, 1, True, True)]
+
+
+@pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,launch", CASES)
+def test_trainer_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_step, double_q, launch):
+    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch)
+    ls = LockStep(tr, ora, spec)
+    for it in range(7):
+        res = tr.run_iteration()
+        want = ora.end_step()
+        rs, qs = ls.rollout_stats
+        # the rollout this step consumed: episode returns in the reference's order, mean max-Q per step
+        assert tr.Rs == [float(x) for x in ora.Rs], f"iteration {it}: episode returns"
+        assert_close(tr.Qs, ora.Qs, 5e-5, 5e-6, f"iteration {it}: mean max-Q per step")
+        assert res["frames"] == want["frames"] == (it + 1) * E_ * T_
+        for key in ("loss", "return_train", "return_train_max", "qmax"):
+            if want[key] is None:
+                assert res[key] is None, key
+            else:
+                assert abs(res[key] - want[key]) <= 5e-5 * abs(want[key]) + 5e-6, (it, key, res[key], want[key])
+    assert ls.n_ext == 7 and ls.n_upd == 6 * LSTEPS and tr.learner.update_steps == 18 and tr.replay.written == 560
+
+
+def test_launch_schedule_rollout_uses_the_weights_of_its_issue_time():
+    """launch.py:47-62: the rollout consumed by step k+1 was issued BEFORE update block k ran.  Shown by contradiction: an oracle that
+    rolls out with the weights AFTER the block (the main schedule's behaviour) must disagree with the device's launch-mode rollout."""
+    tr, ora, spec = _build("dqn", "uniform", False, 1, False, True)
+    ora.launch = False                                   # deliberately the wrong schedule on the oracle's side
+    ora.actor.p = ora.learner.po
+    ls = LockStep(tr, ora, spec)
+    with pytest.raises(AssertionError):
+        for it in range(7):
+            tr.run_iteration()
+            assert_close(tr.Qs, ora.Qs, 5e-5, 5e-6, "mean max-Q per step")
