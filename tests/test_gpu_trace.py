@@ -22,6 +22,8 @@ import pytest
 import torch
 
 import recipe
+import test_engine_emul as E
+from oracle import nets
 from oracle.trainer import OracleTrainer
 from util import assert_close
 
@@ -57,7 +59,7 @@ class LockStep:
         self.tr, self.ora, self.spec = tr, ora, spec
         self.rp, self.eng, self.L = tr.replay, tr.learner.engine, tr.learner.engine.L
         self.rec = None
-        self.n_ext = self.n_upd = 0
+        self.n_ext = self.n_upd = self.relu_flips = 0
         self.rollout_stats = None
         rp, ln = self.rp, tr.learner
         self._extend, self._sample, self._train, self._update = rp.extend, rp.sample, ln.train_batch, rp.update_priority
@@ -149,8 +151,17 @@ class LockStep:
         ol = self.ora.learner
         clone = lambda d: {key: val.detach().clone() for key, val in d.items()}
         pre_p, pre_t, pre_m, pre_v, pre_steps = clone({key: ol.po[key] for key in ol.q_keys}), clone(ol.pt), clone(ol.adam.m), clone(ol.adam.v), ol.adam.t
-        rec = self.ora.train_batch(self.rec)
+        # ReLU decisions: the oracle keeps its forward values but back-propagates through the device's 0/1 decisions, after checking that the
+        # two differ only at pre-activations within rounding of zero (see tests/test_engine_emul.py::check_update_full_size)
         tag = f"update {self.n_upd}"
+        nets.RELU_MASKS, nets.RELU_STATS = E.device_relu_masks(self.eng, self.L, len(self.rec.idx)), {}
+        try:
+            rec = self.ora.train_batch(self.rec)
+        finally:
+            nets.RELU_MASKS = None
+        for name, (n_bad, n, worst) in nets.RELU_STATS.items():
+            assert worst <= 1e-5 and n_bad <= 1e-4 * n, f"{tag}: ReLU decisions of {name}: {n_bad}/{n} differ, largest |pre-activation| {worst:.2e} of the layer's largest"
+            self.relu_flips += n_bad
         assert_close(q[: len(rec.idx)], rec.q_loss, 5e-5, 5e-6, f"{tag}: per-sample loss")
         got, tgt = self.eng.online.state_dict(), self.eng.target.state_dict()
         # gradients: 3e-5 of each tensor's largest element
