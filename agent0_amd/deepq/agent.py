@@ -319,13 +319,15 @@ class BaseLearner:
 
     def _update(self, frames, slot, row_bytes, act, rew, done, weights, rand):
         """engine.update, replayed from hipGraphs when the caller keeps handing in the same device buffers (the Trainer's hot loop
-        does: the replay's persistent batch tensors).  Without data parallelism the whole update is ONE graph.  With a gradient hook
-        it is three — forward + dense backward | encoder backward | optimizer step — around the two RCCL calls (not captured): the
-        dense bucket's all-reduce is issued after the first graph and runs on RCCL's stream while the second graph computes."""
+        does: the replay's persistent batch tensors).  The whole update is ONE graph — under data parallelism too: the gradient exchange
+        (dist.RcclGradAllReduce -> a0_dp_allreduce) is a stream-ordered launch like any other and is captured with it, the dense bucket's
+        all-reduce as a parallel branch beside the encoder backward.  Only a hook that must run on the host (a plain callable, or the
+        torch.distributed fallback) splits the update into three graphs — forward + dense backward | encoder backward | optimizer step —
+        around its eager calls."""
         eng = self.engine
         if not self.use_graph:
             return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
-        hooked = eng.grad_hook is not None
+        hooked = eng.grad_hook is not None and not getattr(eng.grad_hook, "in_graph", False)
         key = (frames.data_ptr(), None if slot is None else slot.data_ptr(), row_bytes, act.data_ptr(), rew.data_ptr(), done.data_ptr(), weights.data_ptr(), hooked)
         g = self._graphs.get(key)
         if g is None:
@@ -335,11 +337,23 @@ class BaseLearner:
             mode = graph_capture_kwargs()
             g_f, g_e, g_apply = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if hooked else None), (torch.cuda.CUDAGraph() if hooked else None)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g_f, **mode):
-                out = eng.forward_dense(frames, slot, row_bytes, act, rew, done, weights, rand)
-                if not hooked:
-                    eng.backward_encoder()
-                    eng.apply()                                   # no exchange step: the whole update is one graph
+            try:
+                with torch.cuda.graph(g_f, **mode):
+                    out = eng.forward_dense(frames, slot, row_bytes, act, rew, done, weights, rand)
+                    if not hooked:                                # the whole update is one graph, in-graph exchange included
+                        eng.exchange_begin()
+                        eng.backward_encoder()
+                        eng.exchange_end()
+                        eng.apply()
+            except Exception as e:      # noqa: BLE001
+                if eng.grad_hook is None or hooked:
+                    raise
+                # an RCCL build that cannot be captured: keep the same exchange, issued eagerly between three graphs from now on
+                import sys
+                print(f"agent0_amd: capturing the gradient exchange into the update's hipGraph failed ({e}); splitting the update around it", file=sys.stderr)
+                eng.grad_hook.in_graph = False
+                torch.cuda.synchronize()
+                return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
             if hooked:
                 with torch.cuda.graph(g_e, **mode):
                     eng.backward_encoder()

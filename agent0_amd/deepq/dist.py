@@ -99,3 +99,63 @@ class GradAllReduce:
             return
         self.dist.all_reduce(grads[: self.n], op=self.dist.ReduceOp.SUM, group=self.group)
         self.dist.all_reduce(state[0:1], op=self.dist.ReduceOp.MAX, group=self.group)
+
+
+class RcclGradAllReduce:
+    """``DeviceLearner.grad_hook`` over the C-ABI's own exchange (``a0_dp_allreduce``: RCCL on a HIP stream).  Same two buckets as
+    GradAllReduce, but every call is an ordinary stream-ordered launch, so the whole update — forward, dense backward, the dense bucket's
+    all-reduce on a side stream WHILE the encoder backward runs on the main one, the convolution bucket's all-reduce, Adam — is captured
+    into ONE hipGraph: the side stream forks from and joins the capturing stream through events, which the graph records as parallel
+    branches.  One communicator, used on the side stream only, so the two collectives are totally ordered on every rank.  The
+    communicator's 128-byte rendezvous blob travels through torch.distributed (broadcast from rank 0)."""
+
+    bucketed = True
+    in_graph = True       # BaseLearner._update: no eager call between graphs is needed
+
+    def __init__(self, ops, n_grad: int, group=None):
+        import torch.distributed as dist
+
+        self.ops, self.n = ops, n_grad
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.world = world
+        blob = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            blob = torch.frombuffer(bytearray(ops.dp_unique_id()), dtype=torch.uint8).clone()
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        blob = blob.to(dev)
+        dist.broadcast(blob, src=0, group=group)
+        self.comm = ops.dp_init(bytes(blob.cpu().numpy().tobytes()), rank, world)
+        self.side = torch.cuda.Stream()
+        self.active = os.environ.get("A0_DP_DRYRUN") != "1"
+
+    def start_dense(self, grads: torch.Tensor, conv_end: int, end: int | None = None):
+        end = self.n if end is None else end
+        if self.active:
+            self.side.wait_stream(torch.cuda.current_stream())      # the dense blocks' gradients (and the NaN flag behind them) are final
+            self.ops.dp_allreduce(self.comm, grads[conv_end:end], end - conv_end, stream=self.side)
+
+    def finish(self, grads: torch.Tensor, state, conv_end: int):
+        if not self.active:
+            return
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)                                   # the convolution blocks' gradients are final
+        self.ops.dp_allreduce(self.comm, grads[:conv_end], conv_end, stream=self.side)
+        cur.wait_stream(self.side)                                   # Adam sees both buckets reduced
+
+    def close(self):
+        if self.comm:
+            self.ops.dp_destroy(self.comm)
+            self.comm = 0
+
+
+def make_grad_hook(ops, n_grad: int, group=None):
+    """The gradient exchange for this process group: the in-graph RCCL path on GPUs (A0_DP_BACKEND=torch forces the torch.distributed
+    calls, which is also what a CPU/gloo group gets); if RCCL cannot be initialised through the C-ABI the torch path is used and said so."""
+    import sys
+
+    if torch.cuda.is_available() and os.environ.get("A0_DP_BACKEND", "rccl") != "torch":
+        try:
+            return RcclGradAllReduce(ops, n_grad, group)
+        except Exception as e:      # noqa: BLE001 — any failure here must not take the job down: the torch path computes the same sums
+            print(f"agent0_amd.dist: a0_dp_* unavailable ({e}); falling back to torch.distributed all_reduce", file=sys.stderr)
+    return GradAllReduce(n_grad, group)

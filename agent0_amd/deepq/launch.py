@@ -16,7 +16,7 @@ import os
 import subprocess
 import sys
 
-from .dist import GradAllReduce, env_world, init_process_group
+from .dist import env_world, init_process_group, make_grad_hook
 
 
 class TrainerNode:
@@ -29,7 +29,7 @@ class TrainerNode:
         self.trainer = Trainer(cfg, use_lp=True, rank=rank, primary=(rank == 0))      # asynchronous actor on its own stream, weight snapshots
         eng = self.trainer.learner.engine
         if world > 1:
-            eng.grad_hook = GradAllReduce(eng.L.n_adam)
+            eng.grad_hook = make_grad_hook(self.trainer.ops, eng.L.n_adam)
             eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)       # SUM-reduced gradients == one step on the global batch
             # identical initial replicas: broadcast rank 0's parameters
             import torch.distributed as dist

@@ -498,6 +498,27 @@ class HipOps:
                                                 _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
                                                 _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_env_synth_step_commit")
 
+    # ------------------------------------------------------------------ data-parallel gradient exchange (RCCL, include/agent0_hip.h a0_dp_*)
+    def dp_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        check(self.lib.a0_dp_unique_id(buf), "a0_dp_unique_id")
+        return buf.raw
+
+    def dp_init(self, unique_id: bytes, rank: int, world: int) -> int:
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL rendezvous blob is 128 bytes")
+        comm = int(self.lib.a0_dp_init(C.create_string_buffer(unique_id, 128), rank, world))
+        if comm == 0:
+            check(-1, "a0_dp_init")
+        return comm
+
+    def dp_allreduce(self, comm: int, buf, n: int, stream=None):
+        """In-place fp32 SUM over the communicator's ranks, enqueued on ``stream`` (a torch.cuda.Stream; default: the current one)."""
+        check(self.lib.a0_dp_allreduce(comm, _req(buf, torch.float32, n, "buf"), n, _stream() if stream is None else stream.cuda_stream), "a0_dp_allreduce")
+
+    def dp_destroy(self, comm: int):
+        check(self.lib.a0_dp_destroy(comm), "a0_dp_destroy")
+
     # ------------------------------------------------------------------ measurement
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
                   "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}

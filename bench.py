@@ -44,8 +44,37 @@ def parse():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1 without a gradient exchange: every rank trains its own network on its own game (rank r plays the r-th of the 8 README games; "
                          "BASELINE configs[4] read as 'one game per GPU') — the ranks share only the barriers and the max-over-ranks clock")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks as a child torch.distributed.run even for --gpus 1 (what --gpus N > 1 does when no launcher environment is present)")
     ap.add_argument("overrides", nargs="*", help="extra key=value config overrides")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start ``torch.distributed.run`` as a CHILD process (before anything in this process
+    touches the GPU; never an exec), one rank per GPU, relay rank 0's JSON line and the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 1
 
 
 def cpu_baseline(args, cfg):
@@ -92,17 +121,18 @@ def cpu_baseline(args, cfg):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        sys.exit(self_launch(args))
     import torch
 
-    from agent0_amd.deepq.dist import GradAllReduce, dp_forced, env_world, init_process_group
+    from agent0_amd.deepq.dist import dp_forced, init_process_group, make_grad_hook
 
     rank, local_rank, world = init_process_group()
     dp = world > 1 or dp_forced()            # A0_DP_FORCE=1: the data-parallel path with a one-rank RCCL group (rehearsal on a one-GPU box)
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     from agent0_amd.deepq.config import parse_overrides
     from agent0_amd.deepq.trainer import Trainer
@@ -120,7 +150,7 @@ def main():
     eng = tr.learner.engine
     if dp and not args.replicas:
         import torch.distributed as dist
-        eng.grad_hook = GradAllReduce(eng.L.n_adam)
+        eng.grad_hook = make_grad_hook(tr.ops, eng.L.n_adam)
         eng.adam_eps = 1e-2 / (world * cfg.learner.batch_size)
         dist.broadcast(eng.online.flat, src=0)
         eng.online.refresh_wt()
@@ -231,6 +261,11 @@ def main():
         del tr2
     if dp:
         barrier()
+    exchange = None
+    if eng.grad_hook is not None:
+        exchange = type(eng.grad_hook).__name__ + (" (captured in the update's hipGraph)" if getattr(eng.grad_hook, "in_graph", False) else " (eager, between three graphs)")
+        if hasattr(eng.grad_hook, "close"):
+            eng.grad_hook.close()
     if rank != 0:
         if dp:
             import torch.distributed as dist
@@ -249,7 +284,7 @@ def main():
                                f"(full), obs 4x84x84 u8, per-rank shards, " + ("independent replicas: one game per rank, no gradient exchange" if args.replicas else
                                "RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)")),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
-                   "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}"},
+                   "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}", "gradient_exchange": exchange},
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),
         "at_reference_update_ratio": ratio320, "other_entry": other,

@@ -296,6 +296,17 @@ int a0_env_synth_step_commit(unsigned long long seed, unsigned int rank, int E, 
                              float* ring_rew, float* ring_done, const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act,
                              float* r_rew, float* r_done, const long long* ctrl, void* stream);
 
+/* ---------------------------------------------------------------- data-parallel gradient exchange (no reference counterpart)
+ * One process per GPU; every rank holds a full replica and SUM-reduces its flat fp32 gradient buffer once per update over RCCL/xGMI.  The
+ * reference reduces its loss by SUM (agent.py:154), so a SUM all-reduce with Adam eps = 1e-2/(world*B) is one reference step on the global
+ * batch.  a0_dp_allreduce is enqueued on the caller's stream (in place, asynchronous, capturable into the update's hipGraph).  Rendezvous:
+ * rank 0 fills a 128-byte HOST blob with a0_dp_unique_id and hands it to the other ranks by its own means; every rank then calls a0_dp_init
+ * (collective; binds to the calling thread's current device) and gets an opaque communicator handle, 0 on error. */
+int a0_dp_unique_id(void* host_id128);
+long long a0_dp_init(const void* host_id128, int rank, int world);
+int a0_dp_allreduce(long long comm, float* buf, long long n, void* stream);
+int a0_dp_destroy(long long comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -346,3 +346,14 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
     assert "rehearsal" in dp["config"]["workload"] and "inactive" in plain["config"]["workload"]
     assert dp["value"] > 0 and plain["value"] > 0
     assert dp["last_loss"] == plain["last_loss"], (dp["last_loss"], plain["last_loss"])
+    # the exchange goes through the C-ABI (a0_dp_allreduce over RCCL) and is part of the update's single hipGraph
+    assert dp["config"]["gradient_exchange"].startswith("RcclGradAllReduce") and "captured" in dp["config"]["gradient_exchange"], dp["config"]["gradient_exchange"]
+    # ``python bench.py --gpus N`` with no launcher environment: bench.py starts torch.distributed.run itself, as a child (here N = 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(A0_DP_FORCE="1", A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd + ["--gpus", "1", "--self-launch"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    launched = json.loads(lines[0])
+    assert launched["n_gpus"] == 1 and launched["last_loss"] == plain["last_loss"] and "rehearsal" in launched["config"]["workload"]
