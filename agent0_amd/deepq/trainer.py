@@ -24,6 +24,14 @@ from agent0_amd.common.atari_wrappers import make_atari
 from agent0_amd.common.utils import set_random_seed
 
 
+def _git_sha() -> str:
+    from .main import _git_sha as sha
+    return sha()
+
+
+PROGRESS_COLUMNS = ("frames", "fraction_loss", "loss", "return_train", "return_train_max", "qmax", "fps")      # trainer.py:111-118 + fps (180-181)
+
+
 def epsilon_schedule(cfg: ExpConfig):
     def fn(step):
         if step > cfg.trainer.exploration_steps:
@@ -115,7 +123,10 @@ class Trainer:
         blob = {"model": {k: v.cpu() for k, v in self.learner.model.state_dict().items()},
                 "model_target": {k: v.cpu() for k, v in self.learner.model_target.state_dict().items()},
                 "adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(), "state": eng.state.cpu(), "frame_count": self.frame_count,
-                "algo": self.cfg.learner.algo.name, "obs_shape": tuple(self.cfg.obs_shape), "action_dim": int(self.cfg.action_dim)}
+                "algo": self.cfg.learner.algo.name, "obs_shape": tuple(self.cfg.obs_shape), "action_dim": int(self.cfg.action_dim),
+                # what agent0/summary.py:39-58 reads from a run: the test returns ("ITRs"), the frame count, and — there from params.json —
+                # game / algo / commit; all in the checkpoint here (agent0_amd/summary.py)
+                "ITRs": [float(x) for x in self.RTs], "game": str(self.cfg.env_id), "name": str(self.cfg.name), "sha": _git_sha()}
         if hasattr(eng, "rms_sq"):
             blob["rms_sq"] = eng.rms_sq.cpu()
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -211,6 +222,7 @@ class Trainer:
     def logging(self, result):
         if not self.primary:
             return
+        self._progress_row(result)
         msg = ""
         for k, v in result.items():
             if v is None:
@@ -222,6 +234,22 @@ class Trainer:
             if k in ["frames", "loss", "qmax", "fps"] or "return" in k:
                 msg += f"{k}: {v:.2f} | "
         self.logger.info(msg)
+
+    def _progress_row(self, result):
+        """One CSV row per logged iteration under the run directory (``progress.csv``, columns = the result keys of trainer.py:111-118 plus
+        fps): the machine-readable twin of msg.log, aggregated across runs by agent0_amd/summary.py."""
+        import csv
+
+        try:
+            path = os.path.join(self.cfg.logdir, "progress.csv")
+            new = not os.path.exists(path)
+            with open(path, "a", newline="") as f:
+                w = csv.writer(f)
+                if new:
+                    w.writerow(PROGRESS_COLUMNS)
+                w.writerow(["" if result.get(k) is None else result[k] for k in PROGRESS_COLUMNS])
+        except OSError:
+            pass
 
     def _issue_rollout(self):
         """``actor.futures.sample(eps, state_dict)`` (launch.py:34-36,58-62): snapshot the weights, start the rollout, do not wait."""
@@ -281,13 +309,13 @@ class Trainer:
         if self.use_lp and self._pending is not None:
             self.actors[1].sample_finish(self._pending)      # drain the rollout still in flight
             self._pending = None
-        if save and self.primary:
+        if self.primary:
+            self.test()
+        if save and self.primary:            # after the final test, so that its returns ("ITRs") are part of the run's record
             try:
                 self.save_checkpoint(os.path.join(self.cfg.logdir, "final.pth"))
             except OSError:
                 pass
-        if self.primary:
-            self.test()
         for actor in self.actors:
             if actor is not None:
                 actor.close()
