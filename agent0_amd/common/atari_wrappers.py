@@ -4,8 +4,12 @@ The reference builds a gymnasium AsyncVectorEnv of ALE emulators on the host; ne
 this image, and the hot path this build accelerates starts at the (E,4,84,84) uint8 observation batch.  ``make_atari``
 therefore returns a DEVICE-RESIDENT synthetic vector env (agent0_amd/csrc/synth_env.hip, defined in
 oracle/synth_env.c) that honours the tuple/info contract Actor.sample consumes (agent.py:55-62,85-88).  It is not
-Atari — it exists so that throughput is measured on inputs of the right shape; a host ALE front-end
-feeding the same device buffers is the next-row item N1.
+Atari — it exists so that throughput is measured on inputs of the right shape.
+
+Host environments go through ``env_pool.HostEnvPool``: worker processes step slices of the vector env into a
+double-buffered page-locked uint8 ring, observations are uploaded on a copy stream, actions reach the workers by DMA.  With gymnasium +
+ale-py installed ``make_atari`` builds the real Atari pipeline that way (``AtariSlice``: per-env AtariPreprocessing + FrameStack from
+gymnasium, the life-loss / FIRE handling below, episode statistics and reward clipping in ``env_pool.VectorizedSingles``).
 """
 from __future__ import annotations
 
@@ -98,125 +102,105 @@ class DeviceSynthVecEnv:
         pass
 
 
-class HostVecEnvAdapter:
-    """Runs any host vector env with the gymnasium step/reset contract the reference consumes (agent0/deepq/agent.py:42,55-62,85-88:
-    ``reset() -> (obs, info)``, ``step(a) -> (obs, reward, terminated, truncated, info)`` with ``info["life_loss"]``,
-    ``info["final_info"]`` / ``info["_final_info"]``) behind the device interface of DeviceSynthVecEnv: actions come down with one
-    D2H copy, the (E,4,84,84) uint8 observation batch goes up through a pinned buffer (7 KB per env per step).  This is the N1
-    front-end of SURVEY.md §8(f): with gymnasium + ale-py installed, ``make_atari`` wraps the real Atari env in it."""
+class _Delegate:
+    """Minimal single-env wrapper base (no gymnasium dependency): everything not overridden goes to the wrapped env."""
 
-    def __init__(self, env, num_envs: int, ops=None, action_dim=None):
-        if ops is None:
-            from agent0_amd.ops import HipOps
-            ops = HipOps()
-        self.env, self.E, self.ops = env, num_envs, ops
-        obs_shape = tuple(env.observation_space.shape[1:]) if hasattr(env, "observation_space") else (4, 84, 84)
-        self.observation_space = _Space(shape=(num_envs,) + obs_shape)
-        n = action_dim if action_dim is not None else int(env.action_space[0].n)
-        self.action_dim = n
-        self.action_space = _Space(n=n)
-        numel = num_envs * int(torch.tensor(obs_shape).prod())
-        self._obs = [ops.zeros(numel, dtype=torch.uint8), ops.zeros(numel, dtype=torch.uint8)]
-        self._pin = torch.zeros(numel, dtype=torch.uint8).pin_memory()
-        self._cur_i = 0
-        self.reward, self.terminal, self.truncated = ops.zeros(num_envs), ops.zeros(num_envs), ops.zeros(num_envs)
-        self.life_loss, self.final_mask, self.final_ret = ops.zeros(num_envs), ops.zeros(num_envs), ops.zeros(num_envs)
-        self._scal = torch.zeros(6, num_envs).pin_memory()
-        self.g = 0
+    def __init__(self, env):
+        self.env = env
 
-    def _upload(self, obs_np, dst):
-        import numpy as np
-        self._pin.copy_(torch.from_numpy(np.ascontiguousarray(obs_np, dtype=np.uint8).reshape(-1)))
-        dst.copy_(self._pin, non_blocking=True)
+    def __getattr__(self, name):
+        return getattr(self.env, name)
 
-    def reset(self, **kwargs):
-        obs, info = self.env.reset(**kwargs)
-        self._cur_i = 0
-        self._upload(obs, self._obs[0])
-        self.g = 0
-        return self._obs[0], info
+    def reset(self, **kw):
+        return self.env.reset(**kw)
 
-    def step(self, action: torch.Tensor, final_mask=None, final_ret=None, ctrl=None):
-        import numpy as np
-        obs, reward, terminated, truncated, info = self.env.step(action.cpu().numpy().astype(np.int64))
-        self.g += 1
-        nxt = 1 - self._cur_i
-        torch.cuda.current_stream().synchronize()          # the pinned staging buffers are reused every step
-        self._upload(obs, self._obs[nxt])
-        E = self.E
-        sc = self._scal
-        sc.zero_()
-        sc[0] = torch.from_numpy(np.asarray(reward, dtype=np.float32))
-        sc[1] = torch.from_numpy(np.asarray(terminated, dtype=np.float32))
-        sc[2] = torch.from_numpy(np.asarray(truncated, dtype=np.float32))
-        has_life = "life_loss" in info
-        if has_life:
-            sc[3] = torch.from_numpy(np.asarray(info["life_loss"], dtype=np.float32))
-        if "final_info" in info:
-            mask = np.asarray(info["_final_info"], dtype=bool)
-            sc[4] = torch.from_numpy(mask.astype(np.float32))
-            for i in np.nonzero(mask)[0]:
-                sc[5, i] = float(info["final_info"][i]["episode"]["r"][0])
-        fm = self.final_mask if final_mask is None else final_mask
-        fr = self.final_ret if final_ret is None else final_ret
-        for k, dst in enumerate((self.reward, self.terminal, self.truncated, self.life_loss, fm, fr)):
-            dst.copy_(sc[k], non_blocking=True)
-        self._cur_i = nxt
-        out_info = {"final_mask": fm, "final_ret": fr}
-        if has_life:
-            out_info["life_loss"] = self.life_loss
-        return self._obs[nxt], self.reward, self.terminal, self.truncated, out_info
-
-    def close(self):
-        self.env.close()
+    def step(self, action):
+        return self.env.step(action)
 
 
-def _make_gymnasium_atari(env_id: str, num_envs: int, episode_life: bool):
-    """The reference's wrapper stack (atari_wrappers.py:11-69) on a real gymnasium/ALE install."""
-    import gymnasium as gym
-    import numpy as np
-    from gymnasium.wrappers import AtariPreprocessing, FrameStack, RecordEpisodeStatistics
-    import ale_py  # noqa: F401
-
-    class ClipRewardEnv(gym.RewardWrapper):
-        def reward(self, reward):
-            return np.sign(reward)
-
-    class FireResetEnv(gym.Wrapper):
-        def reset(self, **kwargs):
-            self.env.reset(**kwargs)
-            for a in range(3):
-                obs, _, terminated, _, info = self.env.step(a)
-                if terminated:
-                    obs, info = self.env.reset(**kwargs)
-            return obs, info
-
-    class EpisodicLifeEnv(gym.Wrapper):
-        def step(self, action):
-            old = self.env.unwrapped.ale.lives()
-            obs, reward, done, trunc, info = super().step(action)
-            new = self.env.unwrapped.ale.lives()
-            life_loss = old > new > 0
-            info["life_loss"] = life_loss
-            if life_loss and self.env.unwrapped.get_action_meanings()[1] == "FIRE":
-                for a in range(3):
-                    obs, _, _, _, step_info = self.env.step(a)
-                info.update(step_info)
-            return obs, reward, done, trunc, info
-
-    wrappers = [lambda x: AtariPreprocessing(x, terminal_on_life_loss=False), lambda x: FrameStack(x, 4),
-                (lambda x: EpisodicLifeEnv(x)) if episode_life else (lambda x: x), FireResetEnv, RecordEpisodeStatistics, ClipRewardEnv]
-    return gym.make_vec(f"{env_id}NoFrameskip-v4", num_envs, wrappers=wrappers)
+PRESS_AFTER_RESET = (0, 1, 2)      # NOOP, FIRE, and the action after it: what the reference presses to get a game going (atari_wrappers.py:24-27,47-48)
 
 
-def make_atari(env_id: str, num_envs: int, episode_life: bool = True, seed: int = 42, rank: int = 0, ops=None, synthetic=None):
-    """``synthetic=None``: use the real Atari env when gymnasium + ale-py are importable, else the device-resident synthetic env."""
+def _press_start(env, fallback_reset):
+    """Press the start sequence; a game that ends during it is reset again.  -> (obs, info) of the last press."""
+    obs = info = None
+    for a in PRESS_AFTER_RESET:
+        obs, _, over, _, info = env.step(a)
+        if over:
+            obs, info = fallback_reset()
+    return obs, info
+
+
+class FireOnReset(_Delegate):
+    """Some Atari games idle until FIRE is pressed: a reset is followed by the start sequence (semantics of atari_wrappers.py:20-32)."""
+
+    def reset(self, **kw):
+        self.env.reset(**kw)
+        return _press_start(self.env, lambda: self.env.reset(**kw))
+
+
+class LifeLossInfo(_Delegate):
+    """Reports a lost life as ``info["life_loss"]`` — the flag Actor.sample ORs into ``done`` (agent.py:57-60) — without ending the
+    episode, and restarts games that wait for FIRE after a lost life (semantics of atari_wrappers.py:35-51).  ``lives`` is read through
+    the ALE handle of the unwrapped env."""
+
+    def _lives(self) -> int:
+        return int(self.env.unwrapped.ale.lives())
+
+    def step(self, action):
+        before = self._lives()
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        after = self._lives()
+        lost = before > after > 0
+        info = dict(info, life_loss=lost)
+        if lost and self.env.unwrapped.get_action_meanings()[1] == "FIRE":
+            obs, extra = _press_start(self.env, lambda: (obs, {}))
+            info.update(extra or {})
+            info["life_loss"] = lost
+        return obs, reward, terminated, truncated, info
+
+
+class AtariSlice:
+    """``make_slice`` for the env pool (picklable): k real Atari envs behind the vector contract.  Per env: gymnasium's AtariPreprocessing
+    (grey 84x84, frame-skip 4, max-pool) and FrameStack(4) — library code, as in atari_wrappers.py:61-63 — then LifeLossInfo (when
+    ``episode_life``) and FireOnReset; autoreset, episode statistics and sign-clipping are done by ``VectorizedSingles``."""
+
+    def __init__(self, env_id: str, episode_life: bool = True, seed: int = 42):
+        self.env_id, self.episode_life, self.seed = env_id, episode_life, seed
+
+    def single(self, index: int):
+        import gymnasium as gym
+        from gymnasium.wrappers import AtariPreprocessing, FrameStack
+        import ale_py  # noqa: F401  (registers the ALE namespace)
+
+        env = FrameStack(AtariPreprocessing(gym.make(f"{self.env_id}NoFrameskip-v4"), terminal_on_life_loss=False), 4)
+        env = LifeLossInfo(env) if self.episode_life else env
+        return FireOnReset(env)
+
+    def __call__(self, e0: int, k: int):
+        from .env_pool import VectorizedSingles
+
+        return VectorizedSingles([self.single(e0 + i) for i in range(k)], clip_reward=True)
+
+
+def real_atari_available() -> bool:
+    try:
+        import gymnasium, ale_py  # noqa: F401,E401
+    except ImportError:
+        return False
+    return True
+
+
+def make_atari(env_id: str, num_envs: int, episode_life: bool = True, seed: int = 42, rank: int = 0, ops=None, synthetic=None, num_workers=None):
+    """``synthetic=None``: the real Atari env (through the host env pool) when gymnasium + ale-py are importable, else the device-resident
+    synthetic env.  ``num_workers``: env worker processes (default: one per 16 envs, at most 16; 0 = step in this process)."""
     if synthetic is None:
-        try:
-            import gymnasium, ale_py  # noqa: F401,E401
-            synthetic = False
-        except ImportError:
-            synthetic = True
+        synthetic = not real_atari_available()
     if synthetic:
         return DeviceSynthVecEnv(env_id, num_envs, seed=seed, rank=rank, ops=ops)
-    return HostVecEnvAdapter(_make_gymnasium_atari(env_id, num_envs, episode_life), num_envs, ops=ops)
+    from .env_pool import HostEnvPool
+
+    if num_workers is None:
+        num_workers = 0 if num_envs < 4 else min(16, max(1, num_envs // 16))
+    return HostEnvPool(AtariSlice(env_id, episode_life, seed + 1000003 * rank), num_envs, obs_shape=(4, 84, 84), action_dim=ACTION_DIMS.get(env_id, 18),
+                       num_workers=num_workers, ops=ops)

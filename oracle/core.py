@@ -158,14 +158,15 @@ class SynthVecEnv:
 
     H = W = 84
 
-    def __init__(self, num_envs: int, seed: int = 42, rank: int = 0, action_dim: int = 4):
-        self.E, self.seed, self.rank, self.action_dim = num_envs, seed, rank, action_dim
+    def __init__(self, num_envs: int, seed: int = 42, rank: int = 0, action_dim: int = 4, env_offset: int = 0):
+        """``env_offset``: this object is envs [env_offset, env_offset + num_envs) of a larger vector env (a slice owned by one worker)."""
+        self.E, self.seed, self.rank, self.action_dim, self.e0 = num_envs, seed, rank, action_dim, env_offset
         self.g = np.zeros(num_envs, dtype=np.uint32)
         self.ep_ret = np.zeros(num_envs, dtype=np.float32)
         self.obs = np.zeros((num_envs, 4, 84, 84), dtype=np.uint8)
 
     def reset(self):
-        lib().a0o_env_reset(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.E), _p(self.g), _p(self.ep_ret), _p(self.obs))
+        lib().a0o_env_reset_at(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.e0), C.c_int64(self.E), _p(self.g), _p(self.ep_ret), _p(self.obs))
         return self.obs.copy(), {}
 
     def step(self, action):
@@ -177,7 +178,7 @@ class SynthVecEnv:
         life = np.empty(self.E, dtype=np.uint8)
         fmask = np.empty(self.E, dtype=np.uint8)
         fret = np.empty(self.E, dtype=np.float32)
-        lib().a0o_env_step(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.E), _p(a), _p(self.g), _p(self.ep_ret),
+        lib().a0o_env_step_at(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.e0), C.c_int64(self.E), _p(a), _p(self.g), _p(self.ep_ret),
                            _p(self.obs), _p(out), _p(rew), _p(term), _p(trunc), _p(life), _p(fmask), _p(fret))
         self.obs = out
         info = {"life_loss": life.astype(bool)}

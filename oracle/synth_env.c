@@ -40,24 +40,29 @@ void a0o_env_frame(uint32_t seed, uint32_t e, uint32_t g, uint8_t* out /* [84*84
         }
 }
 
-void a0o_env_reset(uint64_t seed, uint32_t rank, int64_t E, uint32_t* g, float* ep_ret, uint8_t* obs /* [E,4,84,84] */) {
+/* envs e0 .. e0+E-1 of the vector env (a worker process of a host env pool owns such a slice); arrays are indexed from 0 */
+void a0o_env_reset_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, uint32_t* g, float* ep_ret, uint8_t* obs /* [E,4,84,84] */) {
     (void)rank;
     for (int64_t e = 0; e < E; ++e) {
         g[e] = 0; ep_ret[e] = 0.0f;
         uint8_t* o = obs + (size_t)e * 4 * A0O_PIX;
-        a0o_env_frame((uint32_t)seed, (uint32_t)e, 0, o);
+        a0o_env_frame((uint32_t)seed, (uint32_t)(e0 + e), 0, o);
         for (int c = 1; c < 4; ++c) memcpy(o + c * A0O_PIX, o, A0O_PIX);
     }
 }
 
-void a0o_env_step(uint64_t seed, uint32_t rank, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,
-                  const uint8_t* obs_in, uint8_t* obs_out, float* reward, uint8_t* terminal, uint8_t* truncated,
-                  uint8_t* life_loss, uint8_t* final_mask, float* final_ret) {
+void a0o_env_reset(uint64_t seed, uint32_t rank, int64_t E, uint32_t* g, float* ep_ret, uint8_t* obs) {
+    a0o_env_reset_at(seed, rank, 0, E, g, ep_ret, obs);
+}
+
+void a0o_env_step_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,
+                     const uint8_t* obs_in, uint8_t* obs_out, float* reward, uint8_t* terminal, uint8_t* truncated,
+                     uint8_t* life_loss, uint8_t* final_mask, float* final_ret) {
     (void)action;
     for (int64_t e = 0; e < E; ++e) {
         uint32_t gg = g[e] + 1u;
         g[e] = gg;
-        uint32_t ctr[4] = {(uint32_t)e, gg, 0u, 0x454E56u};
+        uint32_t ctr[4] = {(uint32_t)(e0 + e), gg, 0u, 0x454E56u};
         uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ rank};
         uint32_t x[4];
         a0o_philox4x32_10(ctr, key, x);
@@ -72,7 +77,7 @@ void a0o_env_step(uint64_t seed, uint32_t rank, int64_t E, const int32_t* action
         const uint8_t* in = obs_in + (size_t)e * 4 * A0O_PIX;
         uint8_t* out = obs_out + (size_t)e * 4 * A0O_PIX;
         uint8_t fr[A0O_PIX];
-        a0o_env_frame((uint32_t)seed, (uint32_t)e, gg, fr);
+        a0o_env_frame((uint32_t)seed, (uint32_t)(e0 + e), gg, fr);
         if (term) {
             for (int c = 0; c < 4; ++c) memcpy(out + c * A0O_PIX, fr, A0O_PIX);
         } else {
@@ -80,4 +85,10 @@ void a0o_env_step(uint64_t seed, uint32_t rank, int64_t E, const int32_t* action
             memcpy(out + 3 * A0O_PIX, fr, A0O_PIX);
         }
     }
+}
+
+void a0o_env_step(uint64_t seed, uint32_t rank, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,
+                  const uint8_t* obs_in, uint8_t* obs_out, float* reward, uint8_t* terminal, uint8_t* truncated,
+                  uint8_t* life_loss, uint8_t* final_mask, float* final_ret) {
+    a0o_env_step_at(seed, rank, 0, E, action, g, ep_ret, obs_in, obs_out, reward, terminal, truncated, life_loss, final_mask, final_ret);
 }

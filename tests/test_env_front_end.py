@@ -1,0 +1,93 @@
+"""CPU: the host-environment front-end's own logic — the single-env wrappers (life-loss flag, FIRE start sequence;
+semantics of the reference's atari_wrappers.py:20-51) and the vectorisation layer (autoreset, final_info, episode statistics over unclipped
+rewards, sign clipping; atari_wrappers.py:61-68 + gymnasium 0.28 vector semantics) — against a scripted fake ALE.  The pool itself (shared
+page-locked ring, DMA) needs a GPU: tests/test_gpu_trainer.py::test_host_env_pool_matches_device_env."""
+import numpy as np
+
+from agent0_amd.common.atari_wrappers import FireOnReset, LifeLossInfo
+from agent0_amd.common.env_pool import VectorizedSingles
+
+
+class FakeAle:
+    """A tiny deterministic 'Atari': obs = step counter; a life is lost every ``life_every`` steps, the game ends when lives reach 0;
+    rewards are 0 / +7 / -3 by step; the game does not start (no reward, counter frozen) until FIRE (action 1) has been pressed."""
+
+    def __init__(self, lives=3, life_every=4, needs_fire=True):
+        self.lives0, self.life_every, self.needs_fire = lives, life_every, needs_fire
+        self.unwrapped = self
+        self.ale = self
+        self.log = []
+
+    def lives(self):
+        return self._lives
+
+    def get_action_meanings(self):
+        return ["NOOP", "FIRE" if self.needs_fire else "UP", "RIGHT", "LEFT"]
+
+    def reset(self, **kw):
+        self._lives, self.t, self.started = self.lives0, 0, not self.needs_fire
+        self.log.append("reset")
+        return np.full((2, 2), 0, np.uint8), {}
+
+    def step(self, a):
+        self.log.append(int(a))
+        if a == 1:
+            self.started = True
+        if not self.started:
+            return np.full((2, 2), self.t, np.uint8), 0.0, False, False, {}
+        self.t += 1
+        r = 7.0 if self.t % 3 == 0 else (-3.0 if self.t % 5 == 0 else 0.0)
+        if self.t % self.life_every == 0:
+            self._lives -= 1
+            self.started = not self.needs_fire       # the game waits for FIRE again after a lost life
+        return np.full((2, 2), self.t, np.uint8), r, self._lives == 0, False, {"t": self.t}
+
+
+def test_fire_on_reset_presses_the_start_sequence():
+    env = FakeAle()
+    obs, info = FireOnReset(env).reset()
+    assert env.log == ["reset", 0, 1, 2] and env.started and int(obs[0, 0]) == 2      # NOOP (frozen), FIRE (t=1), action 2 (t=2)
+
+
+def test_life_loss_is_reported_not_terminal_and_fire_restarts():
+    env = FakeAle(lives=3, life_every=4)
+    w = LifeLossInfo(env)
+    w.reset()
+    env.step(1)                                     # start the game: t = 1
+    flags, terms = [], []
+    for _ in range(9):
+        obs, r, term, trunc, info = w.step(3)
+        flags.append(bool(info["life_loss"])); terms.append(bool(term))
+        if term:
+            break
+    # t = 2, 3, 4 (life 3 -> 2: reported, FIRE sequence pressed -> game runs again), ...; the LAST life ends the episode and is NOT a life_loss
+    assert flags[2] is True and terms[2] is False
+    assert env.log.count(1) >= 2, "FIRE pressed again after the lost life"
+    assert terms[-1] is True and flags[-1] is False, "lives hitting 0 is terminal, not a life loss (old > new > 0, atari_wrappers.py:42)"
+    # a game without FIRE is left alone
+    env2 = FakeAle(lives=2, life_every=2, needs_fire=False)
+    w2 = LifeLossInfo(env2)
+    w2.reset()
+    n0 = len(env2.log)
+    w2.step(3); _, _, _, _, info = w2.step(3)
+    assert info["life_loss"] is True and len(env2.log) == n0 + 2
+
+
+def test_vectorised_singles_autoreset_statistics_and_clipping():
+    envs = [FakeAle(lives=1, life_every=6, needs_fire=False), FakeAle(lives=1, life_every=4, needs_fire=False)]
+    v = VectorizedSingles(envs)
+    obs, _ = v.reset()
+    assert obs.shape == (2, 2, 2)
+    raw = [0.0, 0.0]
+    for step in range(1, 7):
+        obs, rew, term, trunc, info = v.step(np.array([3, 3]))
+        for i, e in enumerate(envs):
+            pass
+        assert set(np.unique(rew)) <= {-1.0, 0.0, 1.0}, "sign-clipped rewards out (ClipRewardEnv is the outermost wrapper)"
+        if step == 4:          # env 1 (life_every 4, one life) ends: final_info carries the UNCLIPPED return 7 (t=3), obs is the reset one
+            assert term.tolist() == [False, True] and info["_final_info"].tolist() == [False, True]
+            assert float(info["final_info"][1]["episode"]["r"][0]) == 7.0 and info["final_info"][0] is None
+            assert int(obs[1, 0, 0]) == 0 and int(obs[0, 0, 0]) == 4, "autoreset: the first observation of the next episode is returned"
+        if step == 6:          # env 0 ends at t = 6: rewards 7 (t=3) - 3 (t=5) + 7 (t=6) = 11
+            assert term.tolist() == [True, False] and float(info["final_info"][0]["episode"]["r"][0]) == 11.0
+    assert "life_loss" in info and info["life_loss"].dtype == bool

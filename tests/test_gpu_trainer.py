@@ -224,35 +224,39 @@ def test_checkpoint_roundtrip_and_modes(tmp_path):
     assert np.array_equal(v[:, :, 0], v[:, :, 1]) and np.array_equal(v[:, :, 0], v[:, :, 2])
 
 
-def test_host_env_adapter_matches_device_env():
-    """N1: a HOST vector env behind HostVecEnvAdapter feeds the same device pipeline.  Using the oracle's CPU twin of the synthetic
-    env as the host env, the replay contents must equal those produced with the device-resident env, byte for byte."""
-    from agent0_amd.common.atari_wrappers import HostVecEnvAdapter
+@pytest.mark.parametrize("workers", [0, 3])
+def test_host_env_pool_matches_device_env(workers):
+    """N1: HOST environments behind env_pool.HostEnvPool feed the same device pipeline — worker processes (3 workers over 8 envs: slices
+    of 3 / 2 / 3) or in-process stepping (0) write into the page-locked double-buffered ring, observations arrive over the copy stream,
+    actions reach the workers by DMA.  With the oracle's CPU twin of the synthetic env inside the workers, the replay contents, episode
+    returns and per-step max-Q must equal those produced with the device-resident env, byte for byte, for n-step 3 over 5 rollouts."""
+    import host_slices
+    from agent0_amd.common.env_pool import HostEnvPool
     from agent0_amd.deepq.agent import Actor
     from agent0_amd.deepq.model import DeepQNet
     from agent0_amd.deepq.replay import ReplayDataset
-    E = 4
+    E = 8
     outs = []
     for host in (False, True):
-        cfg = make_cfg("dqn", E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 128, "learner.batch_size": 8})
+        cfg = make_cfg("dqn", E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 300, "learner.batch_size": 8})
         model = DeepQNet(cfg)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec("dqn", 4), 11).items()})
         replay = ReplayDataset(cfg, ops=model.ops)
-        envs = None
-        if host:
-            henv = core.SynthVecEnv(E, seed=cfg.seed, rank=0)
-            henv.observation_space = type("S", (), {"shape": (E, 4, 84, 84)})()
-            envs = HostVecEnvAdapter(henv, E, ops=model.ops, action_dim=4)
+        envs = HostEnvPool(host_slices.synth_slice(cfg.seed, 0), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops) if host else None
         actor = Actor(cfg, model, replay=replay, rank=0, envs=envs)
-        rs_all = []
-        for _ in range(3):
+        rs_all, qs_all = [], []
+        for _ in range(5):
             data, rs, qs = actor.sample(0.3)
             replay.extend(data)
             rs_all += rs
-        outs.append((replay.frames[: 72 * replay.row_bytes].clone(), replay.act[:72].clone(), replay.rew[:72].clone(), replay.done[:72].clone(), rs_all))
+            qs_all += qs
+        n = 5 * 6 * E
+        outs.append((replay.frames[: n * replay.row_bytes].clone(), replay.act[:n].clone(), replay.rew[:n].clone(), replay.done[:n].clone(), rs_all, qs_all))
+        actor.close()
     for a, b in zip(outs[0][:4], outs[1][:4]):
         assert torch.equal(a, b)
-    assert outs[0][4] == outs[1][4]
+    assert outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5]
+    assert float(outs[0][3].sum()) > 0, "the run contains done flags (life losses), so the flag path is exercised"
 
 
 @pytest.mark.parametrize("algo,extra", [("dqn", []), ("c51", ["learner.noisy_net=true", "learner.n_step_q=3", "replay.policy=prioritize"])])
