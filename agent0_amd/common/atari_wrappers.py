@@ -102,85 +102,7 @@ class DeviceSynthVecEnv:
         pass
 
 
-class _Delegate:
-    """Minimal single-env wrapper base (no gymnasium dependency): everything not overridden goes to the wrapped env."""
-
-    def __init__(self, env):
-        self.env = env
-
-    def __getattr__(self, name):
-        return getattr(self.env, name)
-
-    def reset(self, **kw):
-        return self.env.reset(**kw)
-
-    def step(self, action):
-        return self.env.step(action)
-
-
-PRESS_AFTER_RESET = (0, 1, 2)      # NOOP, FIRE, and the action after it: what the reference presses to get a game going (atari_wrappers.py:24-27,47-48)
-
-
-def _press_start(env, fallback_reset):
-    """Press the start sequence; a game that ends during it is reset again.  -> (obs, info) of the last press."""
-    obs = info = None
-    for a in PRESS_AFTER_RESET:
-        obs, _, over, _, info = env.step(a)
-        if over:
-            obs, info = fallback_reset()
-    return obs, info
-
-
-class FireOnReset(_Delegate):
-    """Some Atari games idle until FIRE is pressed: a reset is followed by the start sequence (semantics of atari_wrappers.py:20-32)."""
-
-    def reset(self, **kw):
-        self.env.reset(**kw)
-        return _press_start(self.env, lambda: self.env.reset(**kw))
-
-
-class LifeLossInfo(_Delegate):
-    """Reports a lost life as ``info["life_loss"]`` — the flag Actor.sample ORs into ``done`` (agent.py:57-60) — without ending the
-    episode, and restarts games that wait for FIRE after a lost life (semantics of atari_wrappers.py:35-51).  ``lives`` is read through
-    the ALE handle of the unwrapped env."""
-
-    def _lives(self) -> int:
-        return int(self.env.unwrapped.ale.lives())
-
-    def step(self, action):
-        before = self._lives()
-        obs, reward, terminated, truncated, info = self.env.step(action)
-        after = self._lives()
-        lost = before > after > 0
-        info = dict(info, life_loss=lost)
-        if lost and self.env.unwrapped.get_action_meanings()[1] == "FIRE":
-            obs, extra = _press_start(self.env, lambda: (obs, {}))
-            info.update(extra or {})
-            info["life_loss"] = lost
-        return obs, reward, terminated, truncated, info
-
-
-class AtariSlice:
-    """``make_slice`` for the env pool (picklable): k real Atari envs behind the vector contract.  Per env: gymnasium's AtariPreprocessing
-    (grey 84x84, frame-skip 4, max-pool) and FrameStack(4) — library code, as in atari_wrappers.py:61-63 — then LifeLossInfo (when
-    ``episode_life``) and FireOnReset; autoreset, episode statistics and sign-clipping are done by ``VectorizedSingles``."""
-
-    def __init__(self, env_id: str, episode_life: bool = True, seed: int = 42):
-        self.env_id, self.episode_life, self.seed = env_id, episode_life, seed
-
-    def single(self, index: int):
-        import gymnasium as gym
-        from gymnasium.wrappers import AtariPreprocessing, FrameStack
-        import ale_py  # noqa: F401  (registers the ALE namespace)
-
-        env = FrameStack(AtariPreprocessing(gym.make(f"{self.env_id}NoFrameskip-v4"), terminal_on_life_loss=False), 4)
-        env = LifeLossInfo(env) if self.episode_life else env
-        return FireOnReset(env)
-
-    def __call__(self, e0: int, k: int):
-        from .env_pool import VectorizedSingles
-
-        return VectorizedSingles([self.single(e0 + i) for i in range(k)], clip_reward=True)
+from .host_envs import AtariSlice, FireOnReset, LifeLossInfo, PRESS_AFTER_RESET  # noqa: E402,F401  (numpy-only module: env workers import it without torch)
 
 
 def real_atari_available() -> bool:

@@ -25,14 +25,14 @@ the autoreset, episode statistics and reward clipping the reference gets from gy
 from __future__ import annotations
 
 import time
+from multiprocessing import shared_memory
 from typing import Callable, Optional
 
 import numpy as np
 import torch
 
-CMD_NONE, CMD_STEP, CMD_RESET, CMD_CLOSE = 0, 1, 2, 3
-# control block (int64): [0] command sequence number, [1] command, [2 + w] sequence number worker w has completed
-CTL_SEQ, CTL_CMD, CTL_DONE0 = 0, 1, 2
+from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_CMD, CTL_DONE0, CTL_SEQ, HostSynthSlice, VectorizedSingles, block_layout, block_views, record,  # noqa: F401
+                        worker_main)
 
 
 class _Space:
@@ -41,142 +41,6 @@ class _Space:
 
     def __getitem__(self, i):
         return self
-
-
-class VectorizedSingles:
-    """k single environments behind the gymnasium vector contract: autoreset (the observation returned at the end of an episode is the
-    first one of the next; the finished episode's return goes to ``info["final_info"][i]["episode"]["r"]``), episode statistics over the
-    UNCLIPPED rewards and sign-clipped rewards out — the order of the reference's wrapper list (atari_wrappers.py:61-68: statistics inside,
-    clipping outside) — plus the OR of the per-env ``life_loss`` flags the reference's EpisodicLifeEnv reports (atari_wrappers.py:35-51)."""
-
-    def __init__(self, envs, clip_reward: bool = True):
-        self.envs, self.clip = list(envs), clip_reward
-        self.returns = np.zeros(len(self.envs), dtype=np.float64)
-
-    def reset(self, **kw):
-        obs = [e.reset(**kw)[0] for e in self.envs]
-        self.returns[:] = 0
-        return np.stack(obs), {}
-
-    def step(self, actions):
-        k = len(self.envs)
-        obs, rew, term, trunc, life = [None] * k, np.zeros(k, np.float64), np.zeros(k, bool), np.zeros(k, bool), np.zeros(k, bool)
-        final = [None] * k
-        for i, (env, a) in enumerate(zip(self.envs, actions)):
-            o, r, te, tr, info = env.step(int(a))
-            self.returns[i] += r
-            rew[i], term[i], trunc[i], life[i] = r, te, tr, bool(info.get("life_loss", False))
-            if te or tr:
-                final[i] = {"episode": {"r": np.array([self.returns[i]], dtype=np.float32)}}
-                self.returns[i] = 0
-                o, _ = env.reset()
-            obs[i] = o
-        info = {"life_loss": life}
-        if any(f is not None for f in final):
-            info["final_info"] = np.array(final, dtype=object)
-            info["_final_info"] = np.array([f is not None for f in final])
-        return np.stack(obs), (np.sign(rew) if self.clip else rew), term, trunc, info
-
-    def close(self):
-        for e in self.envs:
-            if hasattr(e, "close"):
-                e.close()
-
-
-class HostSynthSlice:
-    """``make_slice`` of a HOST synthetic env with the shapes and rates of the device one (84x84 frame stack, rewards P = 0.05 / 0.05 / 0.9,
-    terminal 1/500, life loss 1/200; frames drawn from a small pre-generated bank): stands in for ALE when measuring the front-end's
-    PCIe-inclusive throughput (tools/bench_host_env.py).  Not byte-compatible with the device env — parity tests use the oracle's twin."""
-
-    def __init__(self, seed: int = 42, bank: int = 32):
-        self.seed, self.bank = seed, bank
-
-    def __call__(self, e0: int, k: int):
-        return _HostSynthEnv(e0, k, self.seed, self.bank)
-
-
-class _HostSynthEnv:
-    def __init__(self, e0, k, seed, bank):
-        self.k = k
-        self.rng = np.random.default_rng([seed, e0])
-        self.frames = self.rng.integers(0, 256, (bank, 84, 84), dtype=np.uint8) * (self.rng.random((bank, 84, 84)) < 0.25)
-        self.obs = np.zeros((k, 4, 84, 84), dtype=np.uint8)
-        self.ret = np.zeros(k, dtype=np.float32)
-
-    def reset(self, **kw):
-        self.obs[:] = self.frames[self.rng.integers(0, len(self.frames), self.k)][:, None]
-        self.ret[:] = 0
-        return self.obs.copy(), {}
-
-    def step(self, action):
-        k, rng = self.k, self.rng
-        new = self.frames[rng.integers(0, len(self.frames), k)]
-        u = rng.random(k)
-        rew = np.where(u < 0.05, -1.0, np.where(u < 0.10, 1.0, 0.0))
-        term = rng.random(k) < 1 / 500
-        life = (~term) & (rng.random(k) < 1 / 200)
-        self.ret += rew
-        self.obs[:, :3] = self.obs[:, 1:]
-        self.obs[:, 3] = new
-        self.obs[term] = new[term][:, None]
-        info = {"life_loss": life}
-        if term.any():
-            fi = np.empty(k, dtype=object)
-            for i in np.nonzero(term)[0]:
-                fi[i] = {"episode": {"r": np.array([self.ret[i]], dtype=np.float32)}}
-            info["final_info"], info["_final_info"] = fi, term.copy()
-            self.ret[term] = 0
-        return self.obs.copy(), rew, term, np.zeros(k, bool), info
-
-    def close(self):
-        pass
-
-
-def _record(buf, half, lo, k, obs, reward, terminated, truncated, info):
-    """One slice's step result into the shared buffers (views into shared memory)."""
-    buf["obs"][half, lo:lo + k] = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
-    sc = buf["scal"][half]
-    sc[0, lo:lo + k] = np.asarray(reward, dtype=np.float32)
-    sc[1, lo:lo + k] = np.asarray(terminated, dtype=np.float32)
-    sc[2, lo:lo + k] = np.asarray(truncated, dtype=np.float32)
-    sc[3, lo:lo + k] = np.asarray(info["life_loss"], dtype=np.float32) if "life_loss" in info else 0.0
-    sc[4, lo:lo + k] = 0.0
-    sc[5, lo:lo + k] = 0.0
-    if "final_info" in info:
-        mask = np.asarray(info["_final_info"], dtype=bool)
-        sc[4, lo:lo + k] = mask.astype(np.float32)
-        for i in np.nonzero(mask)[0]:
-            sc[5, lo + i] = float(info["final_info"][i]["episode"]["r"][0])
-
-
-def _views(obs_t, scal_t, act_t, ctl_t):
-    return {"obs": obs_t.numpy(), "scal": scal_t.numpy(), "act": act_t.numpy(), "ctl": ctl_t.numpy()}
-
-
-def _worker_main(w, make_slice, lo, k, obs_t, scal_t, act_t, ctl_t, spin_us):
-    torch.set_num_threads(1)
-    buf = _views(obs_t, scal_t, act_t, ctl_t)
-    ctl = buf["ctl"]
-    env = make_slice(lo, k)
-    seen = 0
-    try:
-        while True:
-            while int(ctl[CTL_SEQ]) == seen:                 # the sequence number arrives by DMA (steps) or from the parent (reset / close)
-                time.sleep(spin_us * 1e-6)
-            seen = int(ctl[CTL_SEQ])
-            cmd = int(ctl[CTL_CMD])
-            if cmd == CMD_CLOSE:
-                break
-            half = seen & 1
-            if cmd == CMD_RESET:
-                obs, _ = env.reset()
-                buf["obs"][half, lo:lo + k] = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
-            else:
-                _record(buf, half, lo, k, *env.step(buf["act"][lo:lo + k].copy()))
-            ctl[CTL_DONE0 + w] = seen
-    finally:
-        env.close()
-        ctl[CTL_DONE0 + w] = -1
 
 
 class HostEnvPool:
@@ -195,19 +59,23 @@ class HostEnvPool:
         self.action_space = _Space(n=self.action_dim)
         self.has_life_loss = has_life_loss
         E = self.E
-        # ---- shared, page-locked host block: observations and scalars double-buffered by step parity, actions, control words
-        self._obs_h = torch.zeros(2, E, self.obs_bytes, dtype=torch.uint8).share_memory_()
-        self._scal_h = torch.zeros(2, 6, E, dtype=torch.float32).share_memory_()
-        self._act_h = torch.zeros(E, dtype=torch.int32).share_memory_()
-        self._ctl_h = torch.zeros(CTL_DONE0 + max(self.W, 1), dtype=torch.int64).share_memory_()
-        self._pinned = []
-        rt = torch.cuda.cudart()
-        for t in (self._obs_h, self._scal_h, self._act_h, self._ctl_h):
-            err = rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
-            if int(err) != 0:
-                raise RuntimeError(f"hipHostRegister failed ({err}): the env pool needs page-locked shared memory for its DMA ring")
-            self._pinned.append(t)
-        self._np = _views(self._obs_h, self._scal_h, self._act_h, self._ctl_h)
+        # ---- ONE shared, page-locked host block (multiprocessing.shared_memory: the workers map it by name and need no torch):
+        # observations and scalars double-buffered by step parity, actions, control words
+        o_obs, o_scal, o_act, o_ctl, total = block_layout(E, self.obs_bytes, self.W)
+        self._shm = shared_memory.SharedMemory(create=True, size=total)
+        self._np = block_views(self._shm.buf, E, self.obs_bytes, self.W)
+        for v in self._np.values():
+            v[...] = 0
+        whole = torch.frombuffer(self._shm.buf, dtype=torch.uint8)
+        self._whole = whole
+        self._obs_h = whole[o_obs:o_obs + 2 * E * self.obs_bytes].view(2, E, self.obs_bytes)
+        self._scal_h = whole[o_scal:o_scal + 2 * 6 * E * 4].view(torch.float32).view(2, 6, E)
+        self._act_h = whole[o_act:o_act + 4 * E].view(torch.int32)
+        self._ctl_h = whole[o_ctl:o_ctl + 8 * (CTL_DONE0 + max(self.W, 1))].view(torch.int64)
+        err = torch.cuda.cudart().cudaHostRegister(whole.data_ptr(), total, 0)
+        if int(err) != 0:
+            raise RuntimeError(f"hipHostRegister failed ({err}): the env pool needs page-locked shared memory for its DMA ring")
+        self._registered = True
         # ---- device side
         self._obs = [ops.zeros(E * self.obs_bytes, dtype=torch.uint8), ops.zeros(E * self.obs_bytes, dtype=torch.uint8)]
         self._scal_d = [ops.zeros(6, E), ops.zeros(6, E)]
@@ -228,7 +96,7 @@ class HostEnvPool:
             import multiprocessing as mp
             ctx = mp.get_context(start_method)
             for w, (lo, k) in enumerate(self._slices):
-                p = ctx.Process(target=_worker_main, args=(w, make_slice, lo, k, self._obs_h, self._scal_h, self._act_h, self._ctl_h, spin_us), daemon=True)
+                p = ctx.Process(target=worker_main, args=(w, make_slice, lo, k, self._shm.name, E, self.obs_bytes, self.W, spin_us), daemon=True)
                 p.start()
                 self._procs.append(p)
 
@@ -291,7 +159,7 @@ class HostEnvPool:
             ev = torch.cuda.Event()
             ev.record(cur)
             ev.synchronize()                     # in-process stepping has to wait for the action here (worker mode: the workers poll instead)
-            _record(self._np, half, 0, self.E, *self._local.step(self._np["act"].copy()))
+            record(self._np, half, 0, self.E, *self._local.step(self._np["act"].copy()))
         else:
             self._wait_workers()                 # CPU work only: the env steps themselves
         self._upload(half, scalars=True)
@@ -315,10 +183,18 @@ class HostEnvPool:
                 if p.is_alive():
                     p.terminate()
             self._procs = []
-        rt = torch.cuda.cudart()
-        for t in self._pinned:
-            rt.cudaHostUnregister(t.data_ptr())
-        self._pinned = []
+        if getattr(self, "_registered", False):
+            torch.cuda.current_stream().synchronize()
+            self.copy_stream.synchronize()
+            torch.cuda.cudart().cudaHostUnregister(self._whole.data_ptr())
+            self._registered = False
+            self._np = None
+            del self._obs_h, self._scal_h, self._act_h, self._ctl_h, self._whole
+            try:
+                self._shm.close()
+                self._shm.unlink()
+            except (BufferError, FileNotFoundError):
+                pass
 
     def __del__(self):
         try:

@@ -1,0 +1,255 @@
+"""Host-side environment code of the N1 front-end — everything an env WORKER PROCESS imports: numpy only, no torch, so
+that a worker never opens the GPU.  The device / DMA side is env_pool.HostEnvPool.
+
+  VectorizedSingles   k single envs behind the gymnasium vector contract (autoreset, final_info, episode statistics, reward clipping)
+  FireOnReset, LifeLossInfo, AtariSlice   the real Atari pipeline (gymnasium + ale-py when installed); semantics of the reference's
+                      agent0/common/atari_wrappers.py:20-51,59-69
+  HostSynthSlice      a host synthetic env of the right shapes for PCIe-inclusive throughput measurements
+  worker_main         the worker loop: poll the command sequence number in the shared block, step / reset the slice, write the results
+"""
+from __future__ import annotations
+
+import time
+from multiprocessing import shared_memory
+
+import numpy as np
+
+CMD_NONE, CMD_STEP, CMD_RESET, CMD_CLOSE = 0, 1, 2, 3
+# control block (int64): [0] command sequence number, [1] command, [2 + w] sequence number worker w has completed
+CTL_SEQ, CTL_CMD, CTL_DONE0 = 0, 1, 2
+
+
+def block_layout(E: int, obs_bytes: int, workers: int):
+    """Byte offsets of the shared block: observations [2][E][obs_bytes] u8 | scalars [2][6][E] f32 | actions [E] i32 | control i64."""
+    a16 = lambda n: (n + 63) // 64 * 64
+    off_obs = 0
+    off_scal = a16(off_obs + 2 * E * obs_bytes)
+    off_act = a16(off_scal + 2 * 6 * E * 4)
+    off_ctl = a16(off_act + E * 4)
+    total = a16(off_ctl + 8 * (CTL_DONE0 + max(workers, 1)))
+    return off_obs, off_scal, off_act, off_ctl, total
+
+
+def block_views(buf, E: int, obs_bytes: int, workers: int):
+    o_obs, o_scal, o_act, o_ctl, _ = block_layout(E, obs_bytes, workers)
+    return {"obs": np.ndarray((2, E, obs_bytes), dtype=np.uint8, buffer=buf, offset=o_obs),
+            "scal": np.ndarray((2, 6, E), dtype=np.float32, buffer=buf, offset=o_scal),
+            "act": np.ndarray((E,), dtype=np.int32, buffer=buf, offset=o_act),
+            "ctl": np.ndarray((CTL_DONE0 + max(workers, 1),), dtype=np.int64, buffer=buf, offset=o_ctl)}
+
+
+class VectorizedSingles:
+    """k single environments behind the gymnasium vector contract: autoreset (the observation returned at the end of an episode is the
+    first one of the next; the finished episode's return goes to ``info["final_info"][i]["episode"]["r"]``), episode statistics over the
+    UNCLIPPED rewards and sign-clipped rewards out — the order of the reference's wrapper list (atari_wrappers.py:61-68: statistics inside,
+    clipping outside) — plus the OR of the per-env ``life_loss`` flags the reference's EpisodicLifeEnv reports (atari_wrappers.py:35-51)."""
+
+    def __init__(self, envs, clip_reward: bool = True):
+        self.envs, self.clip = list(envs), clip_reward
+        self.returns = np.zeros(len(self.envs), dtype=np.float64)
+
+    def reset(self, **kw):
+        obs = [e.reset(**kw)[0] for e in self.envs]
+        self.returns[:] = 0
+        return np.stack(obs), {}
+
+    def step(self, actions):
+        k = len(self.envs)
+        obs, rew, term, trunc, life = [None] * k, np.zeros(k, np.float64), np.zeros(k, bool), np.zeros(k, bool), np.zeros(k, bool)
+        final = [None] * k
+        for i, (env, a) in enumerate(zip(self.envs, actions)):
+            o, r, te, tr, info = env.step(int(a))
+            self.returns[i] += r
+            rew[i], term[i], trunc[i], life[i] = r, te, tr, bool(info.get("life_loss", False))
+            if te or tr:
+                final[i] = {"episode": {"r": np.array([self.returns[i]], dtype=np.float32)}}
+                self.returns[i] = 0
+                o, _ = env.reset()
+            obs[i] = o
+        info = {"life_loss": life}
+        if any(f is not None for f in final):
+            info["final_info"] = np.array(final, dtype=object)
+            info["_final_info"] = np.array([f is not None for f in final])
+        return np.stack(obs), (np.sign(rew) if self.clip else rew), term, trunc, info
+
+    def close(self):
+        for e in self.envs:
+            if hasattr(e, "close"):
+                e.close()
+
+
+class HostSynthSlice:
+    """``make_slice`` of a HOST synthetic env with the shapes and rates of the device one (84x84 frame stack, rewards P = 0.05 / 0.05 / 0.9,
+    terminal 1/500, life loss 1/200; frames drawn from a small pre-generated bank): stands in for ALE when measuring the front-end's
+    PCIe-inclusive throughput (tools/bench_host_env.py).  Not byte-compatible with the device env — parity tests use the oracle's twin."""
+
+    def __init__(self, seed: int = 42, bank: int = 32):
+        self.seed, self.bank = seed, bank
+
+    def __call__(self, e0: int, k: int):
+        return _HostSynthEnv(e0, k, self.seed, self.bank)
+
+
+class _HostSynthEnv:
+    def __init__(self, e0, k, seed, bank):
+        self.k = k
+        self.rng = np.random.default_rng([seed, e0])
+        self.frames = self.rng.integers(0, 256, (bank, 84, 84), dtype=np.uint8) * (self.rng.random((bank, 84, 84)) < 0.25)
+        self.obs = np.zeros((k, 4, 84, 84), dtype=np.uint8)
+        self.ret = np.zeros(k, dtype=np.float32)
+
+    def reset(self, **kw):
+        self.obs[:] = self.frames[self.rng.integers(0, len(self.frames), self.k)][:, None]
+        self.ret[:] = 0
+        return self.obs.copy(), {}
+
+    def step(self, action):
+        k, rng = self.k, self.rng
+        new = self.frames[rng.integers(0, len(self.frames), k)]
+        u = rng.random(k)
+        rew = np.where(u < 0.05, -1.0, np.where(u < 0.10, 1.0, 0.0))
+        term = rng.random(k) < 1 / 500
+        life = (~term) & (rng.random(k) < 1 / 200)
+        self.ret += rew
+        self.obs[:, :3] = self.obs[:, 1:]
+        self.obs[:, 3] = new
+        self.obs[term] = new[term][:, None]
+        info = {"life_loss": life}
+        if term.any():
+            fi = np.empty(k, dtype=object)
+            for i in np.nonzero(term)[0]:
+                fi[i] = {"episode": {"r": np.array([self.ret[i]], dtype=np.float32)}}
+            info["final_info"], info["_final_info"] = fi, term.copy()
+            self.ret[term] = 0
+        return self.obs.copy(), rew, term, np.zeros(k, bool), info
+
+    def close(self):
+        pass
+
+
+def record(buf, half, lo, k, obs, reward, terminated, truncated, info):
+    """One slice's step result into the shared buffers (views into shared memory)."""
+    buf["obs"][half, lo:lo + k] = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
+    sc = buf["scal"][half]
+    sc[0, lo:lo + k] = np.asarray(reward, dtype=np.float32)
+    sc[1, lo:lo + k] = np.asarray(terminated, dtype=np.float32)
+    sc[2, lo:lo + k] = np.asarray(truncated, dtype=np.float32)
+    sc[3, lo:lo + k] = np.asarray(info["life_loss"], dtype=np.float32) if "life_loss" in info else 0.0
+    sc[4, lo:lo + k] = 0.0
+    sc[5, lo:lo + k] = 0.0
+    if "final_info" in info:
+        mask = np.asarray(info["_final_info"], dtype=bool)
+        sc[4, lo:lo + k] = mask.astype(np.float32)
+        for i in np.nonzero(mask)[0]:
+            sc[5, lo + i] = float(info["final_info"][i]["episode"]["r"][0])
+
+
+
+def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us):
+    shm = shared_memory.SharedMemory(name=shm_name)
+    buf = block_views(shm.buf, E, obs_bytes, workers)
+    ctl = buf["ctl"]
+    env = make_slice(lo, k)
+    seen = 0
+    try:
+        while True:
+            while int(ctl[CTL_SEQ]) == seen:                 # the sequence number arrives by DMA (steps) or from the parent (reset / close)
+                time.sleep(spin_us * 1e-6)
+            seen = int(ctl[CTL_SEQ])
+            cmd = int(ctl[CTL_CMD])
+            if cmd == CMD_CLOSE:
+                break
+            half = seen & 1
+            if cmd == CMD_RESET:
+                obs, _ = env.reset()
+                buf["obs"][half, lo:lo + k] = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
+            else:
+                record(buf, half, lo, k, *env.step(buf["act"][lo:lo + k].copy()))
+            ctl[CTL_DONE0 + w] = seen
+    finally:
+        env.close()
+        ctl[CTL_DONE0 + w] = -1
+        del buf, ctl
+        shm.close()
+
+
+# ------------------------------------------------------------------------------------------------ the real Atari pipeline
+class _Delegate:
+    """Minimal single-env wrapper base (no gymnasium dependency): everything not overridden goes to the wrapped env."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def reset(self, **kw):
+        return self.env.reset(**kw)
+
+    def step(self, action):
+        return self.env.step(action)
+
+
+PRESS_AFTER_RESET = (0, 1, 2)      # NOOP, FIRE, and the action after it: what the reference presses to get a game going (atari_wrappers.py:24-27,47-48)
+
+
+def _press_start(env, fallback_reset):
+    """Press the start sequence; a game that ends during it is reset again.  -> (obs, info) of the last press."""
+    obs = info = None
+    for a in PRESS_AFTER_RESET:
+        obs, _, over, _, info = env.step(a)
+        if over:
+            obs, info = fallback_reset()
+    return obs, info
+
+
+class FireOnReset(_Delegate):
+    """Some Atari games idle until FIRE is pressed: a reset is followed by the start sequence (semantics of atari_wrappers.py:20-32)."""
+
+    def reset(self, **kw):
+        self.env.reset(**kw)
+        return _press_start(self.env, lambda: self.env.reset(**kw))
+
+
+class LifeLossInfo(_Delegate):
+    """Reports a lost life as ``info["life_loss"]`` — the flag Actor.sample ORs into ``done`` (agent.py:57-60) — without ending the
+    episode, and restarts games that wait for FIRE after a lost life (semantics of atari_wrappers.py:35-51).  ``lives`` is read through
+    the ALE handle of the unwrapped env."""
+
+    def _lives(self) -> int:
+        return int(self.env.unwrapped.ale.lives())
+
+    def step(self, action):
+        before = self._lives()
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        after = self._lives()
+        lost = before > after > 0
+        info = dict(info, life_loss=lost)
+        if lost and self.env.unwrapped.get_action_meanings()[1] == "FIRE":
+            obs, extra = _press_start(self.env, lambda: (obs, {}))
+            info.update(extra or {})
+            info["life_loss"] = lost
+        return obs, reward, terminated, truncated, info
+
+
+class AtariSlice:
+    """``make_slice`` for the env pool (picklable): k real Atari envs behind the vector contract.  Per env: gymnasium's AtariPreprocessing
+    (grey 84x84, frame-skip 4, max-pool) and FrameStack(4) — library code, as in atari_wrappers.py:61-63 — then LifeLossInfo (when
+    ``episode_life``) and FireOnReset; autoreset, episode statistics and sign-clipping are done by ``VectorizedSingles``."""
+
+    def __init__(self, env_id: str, episode_life: bool = True, seed: int = 42):
+        self.env_id, self.episode_life, self.seed = env_id, episode_life, seed
+
+    def single(self, index: int):
+        import gymnasium as gym
+        from gymnasium.wrappers import AtariPreprocessing, FrameStack
+        import ale_py  # noqa: F401  (registers the ALE namespace)
+
+        env = FrameStack(AtariPreprocessing(gym.make(f"{self.env_id}NoFrameskip-v4"), terminal_on_life_loss=False), 4)
+        env = LifeLossInfo(env) if self.episode_life else env
+        return FireOnReset(env)
+
+    def __call__(self, e0: int, k: int):
+        return VectorizedSingles([self.single(e0 + i) for i in range(k)], clip_reward=True)
+
+

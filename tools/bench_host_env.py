@@ -16,35 +16,40 @@ from agent0_amd.deepq import agent as agents
 from agent0_amd.deepq.config import parse_overrides
 from agent0_amd.deepq.trainer import Trainer
 
-workers = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-cfg = parse_overrides(["env_id=Breakout", "actor.num_envs=256", "replay.size=100000", "learner.batch_size=512", "wandb=false", "tb=false",
-                       f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}"])
-cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
-tr = Trainer(cfg)
-pool = HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops)
-tr.actors[1] = agents.Actor(cfg, tr.learner.model, replay=tr.replay, ops=tr.ops, rank=0, envs=pool)
-start = cfg.trainer.training_start_steps
-cfg.trainer.training_start_steps = 1 << 62
-tr.run_iteration()
-torch.cuda.synchronize()
-t0 = time.time()
-for _ in range(iters):
+def main():
+    workers = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    cfg = parse_overrides(["env_id=Breakout", "actor.num_envs=256", "replay.size=100000", "learner.batch_size=512", "wandb=false", "tb=false",
+                           f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}"])
+    cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
+    tr = Trainer(cfg)
+    pool = HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops)
+    tr.actors[1] = agents.Actor(cfg, tr.learner.model, replay=tr.replay, ops=tr.ops, rank=0, envs=pool)
+    start = cfg.trainer.training_start_steps
+    cfg.trainer.training_start_steps = 1 << 62
     tr.run_iteration()
-torch.cuda.synchronize()
-t_act = (time.time() - t0) / iters
-cfg.trainer.training_start_steps = 1000
-for _ in range(3):
-    tr.run_iteration()
-torch.cuda.synchronize()
-t0 = time.time()
-for _ in range(iters):
-    tr.run_iteration()
-torch.cuda.synchronize()
-t_full = (time.time() - t0) / iters
-n = cfg.actor.sample_steps * cfg.actor.num_envs
-print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "host_cores": os.cpu_count(),
-                  "actor_only_env_frames_per_sec": round(n / t_act, 1), "actor_only_ms_per_rollout": round(1e3 * t_act, 2),
-                  "iteration_env_frames_per_sec": round(n / t_full, 1), "iteration_ms": round(1e3 * t_full, 2),
-                  "pcie_bytes_per_step": pool.pcie_bytes_per_step, "pcie_GBps_at_actor_rate": round(pool.pcie_bytes_per_step * cfg.actor.sample_steps / t_act / 1e9, 2)}))
-pool.close()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        tr.run_iteration()
+    torch.cuda.synchronize()
+    t_act = (time.time() - t0) / iters
+    cfg.trainer.training_start_steps = 1000
+    for _ in range(3):
+        tr.run_iteration()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        tr.run_iteration()
+    torch.cuda.synchronize()
+    t_full = (time.time() - t0) / iters
+    n = cfg.actor.sample_steps * cfg.actor.num_envs
+    print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "host_cores": os.cpu_count(),
+                      "actor_only_env_frames_per_sec": round(n / t_act, 1), "actor_only_ms_per_rollout": round(1e3 * t_act, 2),
+                      "iteration_env_frames_per_sec": round(n / t_full, 1), "iteration_ms": round(1e3 * t_full, 2),
+                      "pcie_bytes_per_step": pool.pcie_bytes_per_step, "pcie_GBps_at_actor_rate": round(pool.pcie_bytes_per_step * cfg.actor.sample_steps / t_act / 1e9, 2)}))
+    pool.close()
+
+
+if __name__ == "__main__":      # worker processes are spawned: they re-import this file and must not run the benchmark themselves
+    main()
