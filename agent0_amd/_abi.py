@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(ROOT, "include", "agent0_hip.h")
-LIB_PATH = os.path.join(_PKG, "lib", "libagent0_hip.so")
+LIB_PATH = os.environ.get("A0_LIB") or os.path.join(_PKG, "lib", "libagent0_hip.so")      # A0_LIB: tuning aid (a differently built copy of the same library)
 
 _SCALARS = {
     "int": C.c_int,

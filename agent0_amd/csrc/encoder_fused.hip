@@ -408,22 +408,23 @@ struct a0_wring9 {          // uint4 index ((t*N + n)*4 + q)*3 + s: the eight k 
 template <int TERM>
 struct AF2X {   // conv2 4x4/2 over act1 planes [pixel = h*W1 + w][P]; MFMA step = tap (kh, kw), all 32 channels
     static constexpr int term = TERM;       // elements per term plane: compile-time, so the three term reads of a fragment differ only in the DS immediate
-    const uint16_t* planes; int W1, W2, P;
-    A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return ((2 * oh) * W1 + 2 * ow) * P; }
-    A0_D int step_off(int st) const { return ((st >> 2) * W1 + (st & 3)) * P; }
+    const uint16_t* planes; int RP, W2, P;          // RP: elements per image row (W1 * P + pad)
+    A0_D int row(int m) const { const int oh = m / W2, ow = m - oh * W2; return (2 * oh) * RP + 2 * ow * P; }
+    A0_D int step_off(int st) const { return (st >> 2) * RP + (st & 3) * P; }
 };
 template <int TERM>
 struct AF3X {   // conv3 3x3/1 over act2 planes [pixel][P]; MFMA step = half (32 channels) of tap st >> 1
     static constexpr int term = TERM;
-    const uint16_t* planes; int W2, W3, P;
-    A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return (oh * W2 + ow) * P; }
-    A0_D int step_off(int st) const { const int tap = st >> 1; return ((tap / 3) * W2 + tap % 3) * P + 32 * (st & 1); }
+    const uint16_t* planes; int RP, W3, P;          // RP: elements per image row (W2 * P + pad)
+    A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return oh * RP + ow * P; }
+    A0_D int step_off(int st) const { const int tap = st >> 1; return (tap / 3) * RP + (tap % 3) * P + 32 * (st & 1); }
 };
-template <int OWC>
-struct EpiFwdX {            // y = relu(acc + bias[n]) -> three bf16 planes in LDS [term][m][P] (+ fp32 to global [m][N])
+template <int OWC, int P, int RP, int term>
+struct EpiFwdX {            // y = relu(acc + bias[n]) -> three bf16 planes in LDS [term][oh][ow][P], image rows RP apart (+ fp32 to global [m][N])
     static constexpr bool PER_ELEM = false;
     static constexpr bool ROW4 = false;
-    const float* bias; uint16_t* planes; int term, P; float* glb; int N;
+    static_assert(OWC > 0, "output width known at compile time");
+    const float* bias; uint16_t* planes; float* glb; int N;
     A0_D float pre_col(int n) const { return bias[n]; }
     A0_D float pre_elem(int, int) const { return 0.f; }
     A0_D void emit4(int, int, const a0_acc4&, float) const {}
@@ -435,7 +436,8 @@ struct EpiFwdX {            // y = relu(acc + bias[n]) -> three bf16 planes in L
         const float r1 = v - __uint_as_float(h << 16);
         const uint32_t mi = __float_as_uint(r1) >> 16;
         const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mi << 16)) >> 16;
-        uint16_t* d = planes + m * P + n;
+        const int oh = m / OWC;
+        uint16_t* d = planes + oh * RP + (m - oh * OWC) * P + n;
         d[0] = (uint16_t)h; d[term] = (uint16_t)mi; d[2 * term] = (uint16_t)lo;
     }
 };
@@ -511,8 +513,24 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
     }
     __syncthreads();
 }
-constexpr int A0_P1X = 40, A0_P2X = 80;       // pixel pitches (bf16 elements) of the act1 / act2 term planes: channels + 8
-constexpr int A0_RX2 = 4, A0_RX3 = 6;         // 32-k steps of split weights in flight
+constexpr int A0_P1X = 40, A0_P2X = 80;       // pixel pitches (bf16 elements) of the act1 / act2 term planes: channels + 8 / + 16
+// Image-row pitches of the term planes (84x84 geometry).  A fragment read is a ds_read_b128 whose 16-lane groups are {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} (+32); along one image row the pixel pitches above put a group's 16 reads on 16 different 16-byte slots of the
+// 256-byte bank row, but a 16-row block spans two or three image rows, and with rows packed back to back the reads behind a row wrap
+// fell onto slots already taken: 8.0 (conv2) and 7.0 (conv3) LDS cycles per wave-read instead of 4.  The pads below are the smallest that
+// bring the average over all blocks and taps down to 4.7 / 5.0 cycles (tools/lds_bank_model.py enumerates the layouts).
+constexpr int A0_RP1X = 20 * A0_P1X + 8;      // act1 planes: 20 pixels per row + 16 bytes
+constexpr int A0_RP2X = 9 * A0_P2X + 96;      // act2 planes: 9 pixels per row + 192 bytes
+#ifndef A0_RX2_D
+#define A0_RX2_D 4
+#endif
+#ifndef A0_RX3_D
+#define A0_RX3_D 6
+#endif
+constexpr int A0_RX2 = A0_RX2_D, A0_RX3 = A0_RX3_D;         // 32-k steps of split weights in flight (tuning aids: -DA0_RX2_D / -DA0_RX3_D)
+#ifndef A0_WNX
+#define A0_WNX 4                              // waves along N in the split-operand conv2 / conv3 stages
+#endif
 
 // Register-ring depths (16-k chunks in flight per wave): >= 2 us of MFMA work ahead of every weight load.
 constexpr int A0_R1 = 4, A0_R2 = 4, A0_R3 = 6;     // conv1: 32-k steps (three 16-byte terms each); conv2 / conv3: 16-k chunks
@@ -530,19 +548,29 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
     uint16_t* a1p = (uint16_t*)(smem + 2 * obs_bytes);
     uint16_t* a2p = (uint16_t*)smem;
-    const int term1 = M1 * A0_P1X, term2 = M2 * A0_P2X;
+    constexpr int term1 = 20 * A0_RP1X, term2 = 9 * A0_RP2X;
+    typedef EpiFwdX<20, A0_P1X, A0_RP1X, term1> E1X;
+    typedef EpiFwdX<9, A0_P2X, A0_RP2X, term2> E2X;
+    // conv2 / conv3 wave tiling: WNX waves along N (each owns 64 / 16 / WNX column blocks), 8 / WNX groups along M.  An A fragment read
+    // from LDS feeds 9 * NBW MFMAs, and the waves along N re-read the same fragments: with four waves along N (NBW = 1) the two stages
+    // moved 72 / 48 KB of LDS per 32-k step against 864 / 576 matrix-pipe cycles — LDS-bound at 128 B/clk.  Two waves along N halve that.
+    // Four M groups over conv2's six 16-row blocks: groups 0, 1 own two blocks, groups 2, 3 one (the MBW - 1 instantiation); a SIMD hosts
+    // one wave of each kind (wave w and w + 4), so the matrix pipes stay evenly loaded.  conv3: four blocks, one per group.
+    constexpr int WNX = A0_WNX, WMGX = A0_FUSED_WAVES / WNX;
+    constexpr int MBW2X = (6 + WMGX - 1) / WMGX, MBW3X = (4 + WMGX - 1) / WMGX;
+    static_assert(MBW2X <= MBW2 * 2 && MBW3X <= MBW3 * 2, "84x84 geometry");
     a0_wring1<A0_R1> ring1;
-    a0_wring9<64, 4, A0_RX2> ring2;
-    a0_wring9<64, 4, A0_RX3> ring3;
+    a0_wring9<64, WNX, A0_RX2> ring2;
+    a0_wring9<64, WNX, A0_RX3> ring3;
     ring1.init(P.wt1, P.C);
     ring2.init(P.wx2, 512);
     ring3.init(P.wx3, 576);
     ring1.prologue();
-    a0_pre<32, 2, MBW1, EpiFwdX<0>> pre1;
-    a0_pre<64, 4, MBW2, EpiFwdX<0>> pre2;
-    a0_pre<64, 4, MBW3, EpiFwd<0>> pre3;
-    pre1.load(EpiFwdX<0>{P.b1, nullptr, 0, 0, nullptr, 32}, M1);
-    pre2.load(EpiFwdX<0>{P.b2, nullptr, 0, 0, nullptr, 64}, M2);
+    a0_pre<32, 2, MBW1, E1X> pre1;
+    a0_pre<64, WNX, MBW2X, E2X> pre2;
+    a0_pre<64, WNX, MBW3X, EpiFwd<0>> pre3;
+    pre1.load(E1X{P.b1, nullptr, nullptr, 32}, M1);
+    pre2.load(E2X{P.b2, nullptr, nullptr, 64}, M2);
     pre3.load(EpiFwd<0>{P.b3, nullptr, 0, 0, 1, nullptr, 64}, M3);
     // the pad channels (32..39 / 64..71) of the term planes are never read; nothing to initialise
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
@@ -575,18 +603,26 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
             }
         }
         __syncthreads();
-        const EpiFwdX<0> e1{P.b1, a1p, term1, A0_P1X, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
+        const E1X e1{P.b1, a1p, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
         const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
         if (MBW1 > 1 && wmg1 + (MBW1 - 1) * 4 >= ((M1 + 15) >> 4))
             a0_conv1_stage<(MBW1 > 1 ? MBW1 - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
             a0_conv1_stage<MBW1, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
-        const AF2X<400 * A0_P1X> f2{a1p, P.W1, P.W2, A0_P1X};
-        const EpiFwdX<0> e2{P.b2, a2p, term2, A0_P2X, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
-        a0_conv_stage_x9<64, 4, MBW2, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
-        const AF3X<81 * A0_P2X> f3{a2p, P.W2, P.W3, A0_P2X};
+        const AF2X<20 * A0_RP1X> f2{a1p, A0_RP1X, P.W2, A0_P1X};
+        const E2X e2{P.b2, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
+        const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
+        constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
+        if (uneven2 && wmgx + (MBW2X - 1) * WMGX >= 6)
+            a0_conv_stage_x9<64, WNX, (MBW2X > 1 ? MBW2X - 1 : 1), A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+        else
+            a0_conv_stage_x9<64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+        const AF3X<9 * A0_RP2X> f3{a2p, A0_RP2X, P.W3, A0_P2X};
         const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
-        a0_conv_stage_x9<64, 4, MBW3, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
+        if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
+            a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
+        else
+            a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
     }
 }
 
@@ -742,19 +778,21 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kerne
 // d3 is split when it is loaded, d2 by conv3's epilogue; both live in LDS as three zero-padded 11 x 11 term-plane images (116 KB:
 // one workgroup per CU, eight waves), the flipped / phase-split weights come pre-split from a0_conv_wt_kernel (segments 8, 9).
 // Nine v_mfma_f32_16x16x32_bf16 per 32 k replace eight v_mfma_f32_16x16x4_f32 of twice the pipe time each.
-constexpr int A0_DPIX = 11 * 11;                      // padded image: 11 x 11 pixels, A0_P2X bf16 per pixel (64 channels + 16: conflict-free 16-byte reads)
-constexpr int A0_DTERM = A0_DPIX * A0_P2X;            // elements per term plane
+// padded images: 11 x 11 pixels, A0_P2X bf16 per pixel (64 channels + 16); image rows padded like the forward planes, per image (3x3 taps,
+// 9-wide output: +192 bytes -> 4.7 LDS cycles per fragment read instead of 8.0; 2x2 taps, 10-wide output: +96 bytes -> 4.6 instead of 7.4)
+constexpr int A0_RPDA = 11 * A0_P2X + 96, A0_RPDB = 11 * A0_P2X + 48;
+constexpr int A0_DTERMA = 11 * A0_RPDA, A0_DTERMB = 11 * A0_RPDB;      // elements per term plane
 struct AFD3X {   // 3x3 taps over the d3pad planes; MFMA step = half (32 channels) of tap st >> 1; output 9 wide
-    static constexpr int term = A0_DTERM;
+    static constexpr int term = A0_DTERMA;
     const uint16_t* planes;
-    A0_D int row(int m) const { const int oh = m / 9, ow = m - oh * 9; return (oh * 11 + ow) * A0_P2X; }
-    A0_D int step_off(int st) const { const int tap = st >> 1; return ((tap / 3) * 11 + tap % 3) * A0_P2X + 32 * (st & 1); }
+    A0_D int row(int m) const { const int oh = m / 9, ow = m - oh * 9; return oh * A0_RPDA + ow * A0_P2X; }
+    A0_D int step_off(int st) const { const int tap = st >> 1; return (tap / 3) * A0_RPDA + (tap % 3) * A0_P2X + 32 * (st & 1); }
 };
 struct AFD2X {   // 2x2 taps over the d2pad planes; output 10 wide
-    static constexpr int term = A0_DTERM;
+    static constexpr int term = A0_DTERMB;
     const uint16_t* planes;
-    A0_D int row(int m) const { const int oh = m / 10, ow = m - oh * 10; return (oh * 11 + ow) * A0_P2X; }
-    A0_D int step_off(int st) const { const int cell = st >> 1; return ((cell >> 1) * 11 + (cell & 1)) * A0_P2X + 32 * (st & 1); }
+    A0_D int row(int m) const { const int oh = m / 10, ow = m - oh * 10; return oh * A0_RPDB + ow * A0_P2X; }
+    A0_D int step_off(int st) const { const int cell = st >> 1; return (cell >> 1) * A0_RPDB + (cell & 1) * A0_P2X + 32 * (st & 1); }
 };
 struct EpiBwd3X {               // d2 = act2 > 0 ? acc : 0 -> global [81][64] and, split into three bf16 terms, the interior of the d2pad planes
     static constexpr bool PER_ELEM = true;
@@ -771,8 +809,8 @@ struct EpiBwd3X {               // d2 = act2 > 0 ? acc : 0 -> global [81][64] an
         const float r1 = v - __uint_as_float(h << 16);
         const uint32_t mi = __float_as_uint(r1) >> 16;
         const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mi << 16)) >> 16;
-        uint16_t* d = planes + ((oh + 1) * 11 + ow + 1) * A0_P2X + n;
-        d[0] = (uint16_t)h; d[A0_DTERM] = (uint16_t)mi; d[2 * A0_DTERM] = (uint16_t)lo;
+        uint16_t* d = planes + (oh + 1) * A0_RPDB + (ow + 1) * A0_P2X + n;
+        d[0] = (uint16_t)h; d[A0_DTERMB] = (uint16_t)mi; d[2 * A0_DTERMB] = (uint16_t)lo;
     }
 };
 constexpr int A0_RXD3 = 6, A0_RXD2 = 4;               // 32-k steps of split weights in flight (18 and 8 steps per stage)
@@ -780,8 +818,8 @@ constexpr int A0_RXD3 = 6, A0_RXD2 = 4;               // 32-k steps of split wei
 __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_kernel(a0_dgrad_args P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* plA = (uint16_t*)smem;                  // d3, padded by 2: three term planes
-    uint16_t* plB = plA + 3 * A0_DTERM;               // d2, padded by 1 (last row / column unused)
-    for (int i = threadIdx.x; i < 3 * A0_DTERM; i += A0_FUSED_THREADS) ((uint32_t*)smem)[i] = 0u;     // both images; borders stay zero for the whole launch
+    uint16_t* plB = plA + 3 * A0_DTERMA;              // d2, padded by 1 (last row / column unused)
+    for (int i = threadIdx.x; i < 3 * (A0_DTERMA + A0_DTERMB) / 2; i += A0_FUSED_THREADS) ((uint32_t*)smem)[i] = 0u;     // both images; borders stay zero for the whole launch
     a0_wring9<64, 4, A0_RXD3> ring3;
     a0_wring9<32, 2, A0_RXD2> ringp[2];
     ring3.init(P.wd3, 576);
@@ -808,10 +846,10 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
                 mm[e] = __float_as_uint(r1);
                 ll[e] = __float_as_uint(r1 - __uint_as_float(mm[e] & 0xffff0000u));
             }
-            uint16_t* d = plA + ((h + 2) * 11 + w + 2) * A0_P2X + c4;
+            uint16_t* d = plA + (h + 2) * A0_RPDA + (w + 2) * A0_P2X + c4;
             *(uint2*)(d) = uint2{__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u)};
-            *(uint2*)(d + A0_DTERM) = uint2{__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u)};
-            *(uint2*)(d + 2 * A0_DTERM) = uint2{__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u)};
+            *(uint2*)(d + A0_DTERMA) = uint2{__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u)};
+            *(uint2*)(d + 2 * A0_DTERMA) = uint2{__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u)};
         }
         __syncthreads();
         const AFD3X f3{plA};
@@ -991,7 +1029,8 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     static const bool no_x9 = getenv("A0_NO_X9") != nullptr;
     const bool x9 = standard && H == 84 && C == 4 && !no_x9;
     const int which = x9 ? 2 : (standard ? 1 : 0);
-    if (x9) lds = (size_t)2 * C * H * W + (size_t)3 * P.H1 * P.W1 * A0_P1X * 2;       // image + act1 term planes (act2 planes reuse the image)
+    if (x9) lds = (size_t)2 * C * H * W + (size_t)3 * P.H1 * A0_RP1X * 2;            // image + act1 term planes (act2 planes reuse the image)
+    static_assert(3 * 9 * A0_RP2X * 2 <= 2 * 4 * 84 * 84, "the act2 term planes fit into the dead image");
     static size_t configured[3] = {0, 0, 0};
     const void* fn = which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
                    : which == 1 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, false> : (const void*)a0_encoder_fused_kernel<7, 4, 2, 0, false>;
@@ -1034,7 +1073,7 @@ extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, 
         P.wd3 = P.wd2 + 4LL * 32 * 256 + 96LL * 512 + 96LL * 576;
         P.wd2 = P.wd3 + 96LL * 576;
     }
-    const size_t lds = x9 ? (size_t)2 * 3 * A0_DTERM * 2 : (size_t)11 * (P.rpa + P.rpb) * 4;
+    const size_t lds = x9 ? (size_t)3 * (A0_DTERMA + A0_DTERMB) * 2 : (size_t)11 * (P.rpa + P.rpb) * 4;
     static bool configured[2] = {false, false};
     const void* fn = x9 ? (const void*)a0_encoder_dgrad_fused_x9_kernel : (const void*)a0_encoder_dgrad_fused_kernel;
     if (!configured[x9]) {

@@ -29,3 +29,12 @@ for B in (256, 512, 4096):
     t_u = timeit(lambda: hip.encoder_fwd(net.net, net.encoder_weights(), frames, None, 28224, 0, B, ws.act1, ws.act2, ws.act3))
     gf = B * 15.47e6 / 1e9
     print(f"B={B} stages={os.environ.get('A0_FUSED_STAGES','7')}: fused {t_f:.1f} us ({gf/t_f*1e-3*1e3:.1f} TF/s), fused+store {t_fk:.1f} us, unfused {t_u:.1f} us")
+
+# fused data gradients (conv3 + conv2), B = 512
+B = 512
+ws = Workspace(hip, L, B, grads=True)
+frames = torch.randint(0, 256, (B * 28224,), dtype=torch.uint8, device="cuda")
+net.encode(ws, frames, None, 28224, 0, B, keep=True)
+ws.d3.normal_()
+t_d = timeit(lambda: hip.encoder_dgrad_fused(net.net, net.wt, ws.d3, ws.act1, ws.act2, B, ws.d2, ws.d1))
+print(f"B={B}: fused dgrad {t_d:.1f} us ({B * 12.5e6 / t_d * 1e-6:.1f} TF/s)")
