@@ -519,8 +519,11 @@ constexpr int A0_P1X = 40, A0_P2X = 80;       // pixel pitches (bf16 elements) o
 // 256-byte bank row, but a 16-row block spans two or three image rows, and with rows packed back to back the reads behind a row wrap
 // fell onto slots already taken: 8.0 (conv2) and 7.0 (conv3) LDS cycles per wave-read instead of 4.  The pads below are the smallest that
 // bring the average over all blocks and taps down to 4.7 / 5.0 cycles (tools/lds_bank_model.py enumerates the layouts).
-constexpr int A0_RP1X = 20 * A0_P1X + 8;      // act1 planes: 20 pixels per row + 16 bytes
-constexpr int A0_RP2X = 9 * A0_P2X + 96;      // act2 planes: 9 pixels per row + 192 bytes
+#ifndef A0_PADS
+#define A0_PADS 1                             // tuning aid: 0 = image rows packed back to back (the round-1 layout)
+#endif
+constexpr int A0_RP1X = 20 * A0_P1X + (A0_PADS ? 8 : 0);      // act1 planes: 20 pixels per row + 16 bytes
+constexpr int A0_RP2X = 9 * A0_P2X + (A0_PADS ? 96 : 0);      // act2 planes: 9 pixels per row + 192 bytes
 #ifndef A0_RX2_D
 #define A0_RX2_D 4
 #endif
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_kerne
 // Nine v_mfma_f32_16x16x32_bf16 per 32 k replace eight v_mfma_f32_16x16x4_f32 of twice the pipe time each.
 // padded images: 11 x 11 pixels, A0_P2X bf16 per pixel (64 channels + 16); image rows padded like the forward planes, per image (3x3 taps,
 // 9-wide output: +192 bytes -> 4.7 LDS cycles per fragment read instead of 8.0; 2x2 taps, 10-wide output: +96 bytes -> 4.6 instead of 7.4)
-constexpr int A0_RPDA = 11 * A0_P2X + 96, A0_RPDB = 11 * A0_P2X + 48;
+constexpr int A0_RPDA = 11 * A0_P2X + (A0_PADS ? 96 : 0), A0_RPDB = 11 * A0_P2X + (A0_PADS ? 48 : 0);
 constexpr int A0_DTERMA = 11 * A0_RPDA, A0_DTERMB = 11 * A0_RPDB;      // elements per term plane
 struct AFD3X {   // 3x3 taps over the d3pad planes; MFMA step = half (32 channels) of tap st >> 1; output 9 wide
     static constexpr int term = A0_DTERMA;
