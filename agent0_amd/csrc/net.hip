@@ -158,58 +158,9 @@ extern "C" int a0_gemm_mode(int mode) {
 template <class OP> struct a0_is_gather { static constexpr bool value = false; };
 template <> struct a0_is_gather<OpActXC> { static constexpr bool value = true; };
 
-// Side streams for independent launches inside ONE entry point (the three convolution weight gradients; the dense layers' weight
-// gradients): the short, split reductions of a 512-row batch are latency-bound, not throughput-bound, so running them side by side hides
-// one kernel's tail and staging latency behind the others.  From the caller's point of view the call is still ordered on its `stream`:
-// the side streams wait for an event recorded on it (fork) and it waits for theirs (join); inside a hipGraph capture the fork / join
-// become parallel branches of the graph.  One set per process: the library is driven by one host thread per GPU.
-struct a0_branch_pool {
-    static constexpr int N = 3;
-    hipStream_t side[N] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, done[N] = {nullptr, nullptr, nullptr};
-    bool ready = false;
-    void init() {
-        if (ready) return;
-        for (int i = 0; i < N; ++i) {
-            A0_HIP_THROW(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
-            A0_HIP_THROW(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-        }
-        A0_HIP_THROW(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        ready = true;
-    }
-};
-static a0_branch_pool g_branches;
-static const bool g_no_branch = getenv("A0_NO_BRANCH") != nullptr;      // tuning aid: everything on the caller's stream
-
 struct a0_hip_backend {
     hipStream_t st;
     int tag = 0;
-    hipStream_t home = nullptr;      // the caller's stream while branches are open
-    unsigned used = 0;
-    // branch(0) = the caller's stream, branch(i > 0) = side stream i - 1; join() makes the caller's stream wait for every side stream used
-    void branch(int i) {
-        if (g_no_branch || (g_probe.tag != 0 && g_probe.tag == tag)) return;      // probed launches are timed one at a time
-        if (!home) {
-            g_branches.init();
-            home = st;
-            A0_HIP_THROW(hipEventRecord(g_branches.fork, home));
-        }
-        if (i <= 0 || i > a0_branch_pool::N) { st = home; return; }
-        st = g_branches.side[i - 1];
-        if (!(used & (1u << (i - 1)))) {
-            A0_HIP_THROW(hipStreamWaitEvent(st, g_branches.fork, 0));
-            used |= 1u << (i - 1);
-        }
-    }
-    void join() {
-        if (!home) return;
-        for (int i = 0; i < a0_branch_pool::N; ++i)
-            if (used & (1u << i)) {
-                A0_HIP_THROW(hipEventRecord(g_branches.done[i], g_branches.side[i]));
-                A0_HIP_THROW(hipStreamWaitEvent(home, g_branches.done[i], 0));
-            }
-        st = home; home = nullptr; used = 0;
-    }
     template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
     void igemm(const typename OA::Params& pa, const typename OB::Params& pb, const typename EP::Params& pe, int X, int Y, int K, int splits) {
         const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
@@ -544,11 +495,9 @@ extern "C" int a0_dense_wgrad_multi(int n, const float* const* dY, const float* 
         if (!dY[i] || !X[i] || !grad[i] || R[i] < 1 || (N[i] & 3) || (K[i] & 3) || (ldx[i] & 3)) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: bad shape");
         if (a0_dense_wgrad_scratch_impl(R[i], N[i], K[i]) > 0 && !slabs) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: needs slab scratch");
         a0_reduce_seg seg;
-        bk.branch(i);           // the layers are independent: side by side, one reduction behind the join
         a0_dense_wgrad_impl(bk, dY[i], X[i], ldx[i], grad[i], R[i], N[i], K[i], slabs ? slabs + slab_off[i] : nullptr, &seg);
         if (seg.nslab > 0) segs[nseg++] = seg;
     }
-    bk.join();
     if (nseg > 0) bk.reduce_segments(segs, nseg);
     return A0_OK;
     A0_CATCH

@@ -247,9 +247,6 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
     const a0_enc_slab_plan plan = a0_encoder_slab_plan(n, B);
     a0_reduce_seg segs[3];
     int nseg = 0;
-    // with the data gradients already there the three weight gradients are independent of each other: the backend may run them side by
-    // side (bk.branch), their slab regions are disjoint, and the one reduction follows the join
-    if (!with_dgrad) bk.branch(0);
     {   // conv3 weight gradient: dW3[64][K3] = sum_m d3[m][:]^T im2col(act2)[m][:]
         const int splits = plan.splits[2];
         const long long wc = 64LL * n.K3;
@@ -269,7 +266,6 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         bk.tag = A0_TAG_CONV3_DGRAD;
         bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 2>(a, b, e, M2, 64, 9 * 64, 1);
     }
-    if (!with_dgrad) bk.branch(1);
     {   // conv2 weight gradient
         const int splits = plan.splits[1];
         const long long wc = 64LL * n.K2;
@@ -293,7 +289,6 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
             bk.tag = A0_TAG_CONV2_DGRAD;
             bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 1>(a, b, e, B * Hv * Wv, 32, 4 * 64, 1);
         }
-    if (!with_dgrad) bk.branch(2);
     {   // conv1 weight gradient (the input is data: no data gradient)
         const long long wc = 32LL * n.K1;
         float* sl = slabs + plan.off[0];
@@ -311,6 +306,5 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         }
     }
     // the three layers' slab reductions (weights and the bias row sums behind them) in one launch
-    if (!with_dgrad) bk.join();
     if (nseg > 0) bk.reduce_segments(segs, nseg);
 }
