@@ -292,16 +292,28 @@ def main():
     }
     roof = None
     traffic = None
+    traffic_file = None
     try:      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["per_launch"]
+        traffic_file = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # newest round
+        pm = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["per_launch"]
         n_act, n_lrn = cfg.actor.sample_steps, 2 * cfg.learner.learner_steps
         traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["512"]["hbm_bytes"]) / (n_act + n_lrn))
     except Exception:
         pass
     if pr is not None and pr["launches"] and pr["ms"] > 0:
         achieved = pr["flop"] / (pr["ms"] * 1e-3) / 1e12
+        # the same launches priced as what the kernel actually issues: every layer runs on v_mfma_f32_16x16x32_bf16 with operands split exactly
+        # into bf16 terms — 3 products per conv1 MAC (bytes x three weight terms), 9 per conv2 / conv3 MAC — against the dense bf16 MFMA peak
+        issued_ratio = 1.0
+        if pr["kernel"] == "encoder_fused":
+            f1, f2, f3 = 2.0 * 400 * 32 * 256, 2.0 * 81 * 64 * 512, 2.0 * 49 * 64 * 576
+            issued_ratio = (3 * f1 + 9 * (f2 + f3)) / (f1 + f2 + f3)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json; "
+                "issued_bf16": {"achieved": round(achieved * issued_ratio, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved * issued_ratio / 2500.0, 4),
+                                "note": "bf16 MFMA FLOPs the kernel issues (3 products per conv1 MAC, 9 per conv2 / conv3 MAC: 99.96 MFLOP per observation) against the dense "
+                                        "bf16 MFMA peak; `frac` above counts every MAC once against the fp32 MFMA peak"},
+                "traffic_note": f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                f"at --replay-size 100000 --steps 2 (tools/refresh_profiles.sh), read from profiles/{traffic_file}; "
                                 "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB (512 obs); the learner's online pass also stores act1/act2 for the backward pass",
                 "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation; u8 input, activations in LDS, weights streamed through registers; "
                           "all layers on v_mfma_f32_16x16x32_bf16 with operands split exactly into bf16 terms (bytes x 3 weight terms; 3 activation x 3 weight terms), fp32 accumulation; "
