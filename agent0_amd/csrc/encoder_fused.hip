@@ -25,6 +25,15 @@
 
 #include <cstdlib>
 
+// Cross products a_i * b_j of the three-term splits that are formed: those with i + j <= A0_X9_MAXORD.  4 = all nine (every partial product
+// of the fp32 fmaf chain, exactly) — the default.  2 = six: a1*b2, a2*b1 and a2*b2 are left out — each is below 2^-24 of a*b (|a1| <= 2^-8 |a|, |b2| <= 2^-16 |b|),
+// i.e. below the rounding the fp32 chain itself applies to every partial SUM, which for a K-term dot product is ~sqrt(K) times larger.
+// Measured (tools/build_variant.sh x6 -DA0_X9_MAXORD=2; profiles/r02_encoder_experiments.md): a third fewer conv2 / conv3 MFMAs shorten the
+// forward kernel by 7-9 % and the data-gradient kernel by 9 % with every parity test unchanged — the stages are not matrix-pipe-bound —
+// and the build keeps all nine: exact products are worth more here than 3.6 % of an iteration.
+#ifndef A0_X9_MAXORD
+#define A0_X9_MAXORD 4
+#endif
 typedef float a0_acc4 __attribute__((ext_vector_type(4)));
 
 struct a0_fused_args {
@@ -486,6 +495,7 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
                     for (int i = 0; i < MBW; ++i)
 #pragma unroll
                         for (int jn = 0; jn < NBW; ++jn) {
+                            if (ta + tw > A0_X9_MAXORD) continue;      // see A0_X9_MAXORD
                             const a0_u32x4 av = {a[u & 1][i][ta].x, a[u & 1][i][ta].y, a[u & 1][i][ta].z, a[u & 1][i][ta].w};
                             const a0_u32x4 bv = {ring.v[u][jn][tw].x, ring.v[u][jn][tw].y, ring.v[u][jn][tw].z, ring.v[u][jn][tw].w};
                             acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i][jn], 0, 0, 0);
