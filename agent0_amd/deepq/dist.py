@@ -127,6 +127,43 @@ class RcclGradAllReduce:
         self.comm = ops.dp_init(bytes(blob.cpu().numpy().tobytes()), rank, world)
         self.side = torch.cuda.Stream()
         self.active = os.environ.get("A0_DP_DRYRUN") != "1"
+        if self.active:
+            self._self_test(rank, world, group)
+
+    def _self_test(self, rank: int, world: int, group):
+        """Before the learner builds its update graph around this exchange: one eager all-reduce (checks the communicator and lets RCCL do its
+        lazy allocations outside any capture), then the same call captured on the side stream into a small hipGraph and replayed.  If the
+        capture does not work with this RCCL build the hook stays usable — it then runs eagerly between three graphs (in_graph = False) —
+        and every rank takes the same decision (MIN over ranks)."""
+        import sys
+        import torch.distributed as dist
+
+        x = torch.full((1024,), float(rank + 1), device="cuda")
+        want = world * (world + 1) / 2.0
+        self.ops.dp_allreduce(self.comm, x, x.numel())
+        torch.cuda.synchronize()
+        if abs(float(x[0]) - want) > 1e-3 or abs(float(x[-1]) - want) > 1e-3:
+            raise RuntimeError(f"a0_dp_allreduce self-test: got {float(x[0])}, expected {want}")
+        ok = 1.0
+        try:
+            x.fill_(float(rank + 1))
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, **graph_capture_kwargs()):
+                self.side.wait_stream(torch.cuda.current_stream())
+                self.ops.dp_allreduce(self.comm, x, x.numel(), stream=self.side)
+                torch.cuda.current_stream().wait_stream(self.side)
+            g.replay()
+            torch.cuda.synchronize()
+            if abs(float(x[0]) - want) > 1e-3:
+                ok = 0.0
+        except Exception as e:      # noqa: BLE001
+            print(f"agent0_amd.dist: a0_dp_allreduce cannot be captured into a hipGraph here ({e}); it will run eagerly between graphs", file=sys.stderr)
+            ok = 0.0
+            torch.cuda.synchronize()
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.in_graph = bool(float(flag[0]) > 0.5)
 
     def start_dense(self, grads: torch.Tensor, conv_end: int, end: int | None = None):
         end = self.n if end is None else end
