@@ -1,5 +1,5 @@
 """Builds the tracked evidence under profiles/ from the scratch output of tools/refresh_profiles.sh + tools/bench_configs.sh
-(gpurun_out/r01/): bench lines, rocprofv3 kernel statistics, per-grid durations of the fused kernels, PMC traffic, the other
+(gpurun_out/<round>/): bench lines, rocprofv3 kernel statistics, per-grid durations of the fused kernels, PMC traffic, the other
 BASELINE configurations, and the summary table.   usage: python tools/make_profiles.py [round_tag]"""
 import csv, json, os, shutil, sys
 
@@ -72,13 +72,22 @@ for f, name in names.items():
             other[name] = {"error": str(e)}
 json.dump(other, open(os.path.join(DST, f"{tag}_other_configs.json"), "w"), indent=1)
 
+# ---- data-parallel rehearsal (one-rank RCCL group, A0_DP_FORCE=1) and the host-environment front-end, when their runs are there
+for src, dst in (("bench_dpforce.json", f"{tag}_bench_dqn_dp_rehearsal.json"), ("host_env.json", f"{tag}_host_env_front_end.json")):
+    path = os.path.join(SRC, src)
+    if os.path.exists(path):
+        try:
+            json.dump(last_json(path), open(os.path.join(DST, dst), "w"), indent=1)
+        except Exception as e:      # noqa: BLE001
+            print("skipped", src, e)
+
 # ---- summary table
 rows = list(csv.DictReader(open(os.path.join(SRC, "kernel_stats.csv"))))
 tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
 tot_calls = sum(int(r["Calls"]) for r in rows)
-lines = [f"# rocprofv3 --kernel-trace --stats  --  python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry   (round 1, MI355X gfx950, 1 GPU)", "",
+lines = [f"# rocprofv3 --kernel-trace --stats  --  python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry   ({tag}, MI355X gfx950, 1 GPU)", "",
          "Commands (on the GPU box, `tools/refresh_profiles.sh`; this file is generated from their output by `tools/make_profiles.py`): `cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && "
-         "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01/prof -- python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry`;",
+         "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/<round>/prof -- python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry`;",
          "HBM traffic from two further runs, `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...` and `rocprofv3 --pmc WRITE_SIZE --kernel-trace ...` (counters never combined with other trace domains).",
          "The run covers the untimed replay fill (49 actor-only iterations), 2 warm-up, 8 timed iterations of BASELINE configs[1] and the 8 probe iterations (hipGraph replay off).",
          f"Files: `{tag}_bench_dqn_kernel_stats.csv` (full table), `{tag}_bench_dqn.json` (bench line of the un-profiled default run), `{tag}_bench_dqn_launch_entry.json` (`--entry launch`), "
