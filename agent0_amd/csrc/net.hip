@@ -316,8 +316,39 @@ extern "C" int a0_dense_fwd_mul(const float* X, int ldx, const float* W, const f
 
 // The split-K GEMM of a0_dense_fwd WITHOUT its reduction: slab z = X W^T over the z-th k range, [R][N] each at stride R*N; the caller's
 // next kernel sums the slabs (a0_dqn_head_loss_slabs, a0_actor_qhead).  Returns the slab count.
+// Tile of the split-K fc1 GEMM whose slabs a consumer kernel finishes (actor tail, DQN head + loss).  A0_FC1_VARIANT (tuning aid):
+// 0 = 128 x 64, waves 4 x 1, 1 = 128 x 64, waves 2 x 2, 2 = 64 x 64, 3 = 64 x 128, 4 = 128 x 32; unset: 64 x 64 up to 256 rows (the actor's
+// batch: 8 slabs instead of 16 for the tail kernel to sum, GEMM + tail 19.9 vs 22.3 us at 256 rows), 128 x 64 above (28.0 us at 512 rows,
+// where the variants are within 1 us of each other) — tools/ubench_actor_tail.py, profiles/r02_encoder_experiments.md.
+static inline int a0_fc1_variant(int R) {
+    static const int v = getenv("A0_FC1_VARIANT") ? atoi(getenv("A0_FC1_VARIANT")) : -1;
+    return v >= 0 ? v : (R <= 256 ? 2 : 0);
+}
+static inline int a0_fc1_splits(int R, int N, int K) {
+    const int v = a0_fc1_variant(R);
+    const int bx = (v == 2 || v == 3) ? 64 : 128, by = (v == 3) ? 128 : (v == 4 ? 32 : 64);
+    static const int wg = getenv("A0_FC1_WGS") ? atoi(getenv("A0_FC1_WGS")) : 256;      // target workgroup count
+    const int blocks = ((R + bx - 1) / bx) * ((N + by - 1) / by);
+    if (v == 0 && wg == 256) return a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
+    int splits = blocks < wg ? wg / blocks : 1;
+    const int maxs = (K / 32) / 2;
+    if (splits > maxs) splits = maxs;
+    if (splits > 64) splits = 64;
+    return splits < 1 ? 1 : splits;
+}
+template <class BK>
+static void a0_fc1_partial_launch(BK& bk, const a0_mat_src& a, const a0_mat_src& bw, const EpiSlab::Params& ep, int R, int N, int K, int splits) {
+    switch (a0_fc1_variant(R)) {
+        case 1: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 2, 2, 2, 1>(a, bw, ep, R, N, K, splits); break;
+        case 4: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 1>(a, bw, ep, R, N, K, splits); break;
+        case 2: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 2, 2, 1, 1>(a, bw, ep, R, N, K, splits); break;
+        case 3: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 2, 2, 1, 2>(a, bw, ep, R, N, K, splits); break;
+        default: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, ep, R, N, K, splits);
+    }
+}
+
 extern "C" int a0_dense_fwd_partial_slabs(int R, int N, int K) {
-    const int s = a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
+    const int s = N <= 32 ? a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K) : a0_fc1_splits(R, N, K);
     return s < 1 ? 1 : s;
 }
 
@@ -331,7 +362,7 @@ extern "C" int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int
     EpiSlab::Params ep{slabs, (long long)R * N, N};
     bk.tag = A0_TAG_DENSE_FWD;
     if (N <= 32) bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 1>(a, bw, ep, R, N, K, splits);
-    else bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, ep, R, N, K, splits);
+    else a0_fc1_partial_launch(bk, a, bw, ep, R, N, K, splits);
     return A0_OK;
     A0_CATCH
 }
@@ -419,7 +450,7 @@ __global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __rest
 }
 
 extern "C" long long a0_actor_qhead_scratch(int E, int K) {
-    const int splits = a0_fwd_splits((E + 127) / 128, (512 + 63) / 64, K);
+    const int splits = a0_fc1_splits(E, 512, K);
     return (long long)splits * E * 512;
 }
 
@@ -430,12 +461,12 @@ extern "C" int a0_actor_qhead(const float* feat, int E, int K, const float* W1, 
     if (!feat || !W1 || !b1 || !W2 || !b2 || !scratch || !action || !qmax || E < 1 || K < 4 || (K & 3) || A < 1 || A + (dueling ? 1 : 0) > 24)
         return a0_fail(A0_EINVAL, "a0_actor_qhead: bad argument (A + dueling <= 24: the head rows are staged in 48 KB of LDS)");
     a0_hip_backend bk{(hipStream_t)stream};
-    const int splits = a0_fwd_splits((E + 127) / 128, (512 + 63) / 64, K);
+    const int splits = a0_fc1_splits(E, 512, K);
     a0_mat_src a{feat, K};
     a0_mat_src bw{W1, K};
     EpiSlab::Params ep{scratch, (long long)E * 512, 512};
     bk.tag = A0_TAG_DENSE_FWD;
-    bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, ep, E, 512, K, splits);
+    a0_fc1_partial_launch(bk, a, bw, ep, E, 512, K, splits);
     hipLaunchKernelGGL(a0_actor_qhead_kernel, dim3((E + 3) / 4), dim3(256), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, scratch, (long long)E * 512, splits, b1, W2, b2, A, dueling, E,
                        seed, stream_a, stream_u, off_a, off_u, eps, ctrl, eps_ptr, action, qmax);
     A0_HIP_THROW(hipGetLastError());
