@@ -136,6 +136,11 @@ class Actor:
         """The body of Actor.sample's loop (agent.py:48-88), every step enqueued on the stream without touching the host."""
         cfg, ops, E = self.cfg, self.ops, self.E
         R = self.ring_len
+        if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq != 0:
+            # NoisyLinear.forward composes mu + sigma * epsilon on every call (model.py:54-62), i.e. with the parameters as they are NOW; the
+            # composed copies the device keeps were last written before the learner's latest Adam step (or come from a weight snapshot).
+            # A rollout that does not start on a noise reset recomposes them once (with the default sample_steps = 80 it always does).
+            self.model._dev.compose_noise()
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
                 self.model.reset_noise(rng=self.rng)

@@ -126,12 +126,19 @@ class OracleTrainer:
     def __init__(self, spec, state_dict, *, num_envs: int, sample_steps: int, batch_size: int, replay_size: int, learner_steps: int,
                  training_start_steps: int, policy: str = "uniform", sumtree: bool = True, n_step: int = 1, double_q: bool = False, seed: int = 42,
                  rank: int = 0, discount: float = 0.99, lr: float = 5e-4, target_update_freq: int = 500, alpha: float = 0.5, prio_eps: float = 0.01,
-                 beta0: float = 0.4, total_steps: int = int(1e7), exploration_steps: int = int(1e6), min_eps: float = 0.01, launch: bool = False):
+                 beta0: float = 0.4, total_steps: int = int(1e7), exploration_steps: int = int(1e6), min_eps: float = 0.01, launch: bool = False,
+                 reset_noise_freq: int = 4, actor_noise=None, learner_noise=None):
+        """NoisyNet (spec.noisy): the N(0, 0.1^2) draws are supplied by the caller, like every other random number — ``actor_noise()`` returns the
+        draws of the actor's next ``reset_noise`` (agent.py:49-50: every reset_noise_freq steps), ``learner_noise()`` the (online, target) draws
+        of the next ``train`` (agent.py:125-127); each a list [noise_in, noise_out_weight, noise_out_bias] per NoisyLinear in module order."""
         self.spec, self.E, self.T, self.B = spec, num_envs, sample_steps, batch_size
         self.learner_steps, self.start = learner_steps, training_start_steps
         self.prioritize, self.sumtree = policy == "prioritize", (policy == "prioritize" and sumtree)
         self.exploration_steps, self.min_eps = exploration_steps, min_eps
         self.launch = launch
+        self.actor_noise, self.learner_noise = actor_noise, learner_noise
+        if spec.noisy and (actor_noise is None or learner_noise is None):
+            raise ValueError("a NoisyNet spec needs actor_noise and learner_noise draw sources")
         hp = Hyper(discount=discount, n_step=n_step, double_q=double_q)
         self.learner = OracleLearner(spec, state_dict, state_dict, hp, batch_size=batch_size, lr=lr, target_update_freq=target_update_freq)   # target = deepcopy(model), agent.py:100
         self.actor_rng = Stream(seed, rank)
@@ -144,7 +151,17 @@ class OracleTrainer:
 
         env = core.SynthVecEnv(num_envs, seed=seed, rank=rank, action_dim=A)
         # main schedule: the actor shares the learner's model (trainer.py:41-44); launch schedule: it owns a copy, refreshed per rollout
-        self.actor = OracleActor(env, self.learner.po if not launch else self._snapshot(), spec, n_step=n_step, discount=discount, sample_steps=sample_steps, draw=draw)
+        def noisy_reset(p):      # NoisyLinear.reset_noise on the actor's model (agent.py:49-50, model.py:73-83)
+            from . import nets
+            it = iter(self.actor_noise())
+            with torch.no_grad():
+                for prefix in nets.dense_prefixes(spec):
+                    for leaf in ("noise_in", "noise_out_weight", "noise_out_bias"):
+                        p[f"{prefix}.{leaf}"] = torch.from_numpy(np.array(next(it), dtype=np.float32))
+                    nets.compose_noise(p, prefix)
+
+        self.actor = OracleActor(env, self.learner.po if not launch else self._snapshot(), spec, n_step=n_step, discount=discount, sample_steps=sample_steps, draw=draw,
+                                 noisy_reset=noisy_reset if spec.noisy else None, reset_noise_freq=reset_noise_freq)
         if self.sumtree:
             self.replay = SumTreeReplay(replay_size, beta0, alpha, prio_eps, total_steps)
         else:
@@ -213,7 +230,10 @@ class OracleTrainer:
 
     # ------------------------------------------------------------------ trainer.py:97-110
     def train_batch(self, rec: BatchRecord) -> BatchRecord:
-        res = self.learner.train(rec.frames.reshape(self.B, -1), rec.act, rec.rew, rec.done, rec.weights, rec.idx)
+        no = nt = None
+        if self.spec.noisy:
+            no, nt = self.learner_noise()
+        res = self.learner.train(rec.frames.reshape(self.B, -1), rec.act, rec.rew, rec.done, rec.weights, rec.idx, noise_online=no, noise_target=nt)
         rec.q_loss, rec.fraction_loss = res["q_loss"], res["fraction_loss"]
         if rec.q_loss is not None:
             self.Ls.append(float(rec.q_loss.mean()))

@@ -32,25 +32,52 @@ pytestmark = pytest.mark.gpu
 E_, T_, B_, SIZE, LSTEPS, START, TFREQ = 8, 10, 32, 200, 3, 100, 4
 
 
-def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS):
+def device_noise(net):
+    """The NoisyNet draws a DeviceNet currently holds, as the oracle takes them: [noise_in, noise_out_weight, noise_out_bias] per module, noise_in
+    back in the reference's (c, h, w) column order."""
+    out = []
+    for prefix, *_ in net.L.noise_modules:
+        nz = net.noise[prefix]
+        out += [net.L.noise_in_from_kernel(prefix, nz["noise_in"]).clone().cpu().numpy(), nz["noise_out_weight"].clone().cpu().numpy(), nz["noise_out_bias"].clone().cpu().numpy()]
+    return out
+
+
+def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS, spec_name=None):
     from agent0_amd.deepq.config import parse_overrides
     from agent0_amd.deepq.trainer import Trainer
     over = [f"learner.algo={algo}", f"actor.num_envs={E_}", f"actor.sample_steps={T_}", f"learner.batch_size={B_}", f"replay.size={SIZE}",
             f"learner.learner_steps={ls}", f"trainer.training_start_steps={START}", f"learner.target_update_freq={TFREQ}", f"learner.n_step_q={n_step}",
             f"learner.double_q={str(double_q).lower()}", f"replay.policy={policy}", f"replay.sumtree={str(sumtree).lower()}", "trainer.exploration_steps=100",
             "trainer.total_steps=4000", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"]
+    spec = recipe.SPECS[spec_name or algo]
+    over += [f"learner.dueling_head={str(bool(spec.dueling)).lower()}", f"learner.noisy_net={str(bool(spec.noisy)).lower()}"]
     cfg = parse_overrides(over)
     tr = Trainer(cfg, use_lp=launch)
-    spec = recipe.SPECS[algo]
     sd = recipe.make_state_dict(spec, 11)
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
     tr.learner.model.load_state_dict(tsd)
     tr.learner.engine.sync_target(force=True)
     if launch:
         tr.actors[1].model.load_state_dict(tsd)
+    actor_q, learner_box = [], []
+    if spec.noisy:
+        # every random number is injected: the DEVICE's NoisyNet draws (Philox normals; the oracle's Box-Muller agrees with them only to 1e-4) are
+        # snapshotted where they are made — at each of the actor's resets, in rollout order — and read back after each update for the learner
+        tr.actors[1].use_graph = False
+        amodel = tr.actors[1].model
+        orig = amodel.reset_noise
+
+        def reset_noise(rng=None, compose=True):
+            orig(rng=rng, compose=compose)
+            if compose:                                  # the actor's call (agent.py:49-50); the learner's passes compose=False
+                actor_q.append(device_noise(amodel._dev))
+
+        amodel.reset_noise = reset_noise
     ora = OracleTrainer(spec, sd, num_envs=E_, sample_steps=T_, batch_size=B_, replay_size=SIZE, learner_steps=ls, training_start_steps=START, policy=policy,
                         sumtree=sumtree, n_step=n_step, double_q=double_q, seed=cfg.seed, target_update_freq=TFREQ, total_steps=4000, exploration_steps=100,
-                        launch=launch)
+                        launch=launch, reset_noise_freq=cfg.learner.reset_noise_freq, actor_noise=(lambda: actor_q.pop(0)) if spec.noisy else None,
+                        learner_noise=(lambda: learner_box.pop(0)) if spec.noisy else None)
+    ora._learner_box = learner_box
     return tr, ora, spec
 
 
@@ -154,6 +181,8 @@ class LockStep:
         # ReLU decisions: the oracle keeps its forward values but back-propagates through the device's 0/1 decisions, after checking that the
         # two differ only at pre-activations within rounding of zero (see tests/test_engine_emul.py::check_update_full_size)
         tag = f"update {self.n_upd}"
+        if self.spec.noisy:
+            self.ora._learner_box.append((device_noise(self.eng.online), device_noise(self.eng.target)))
         nets.RELU_MASKS, nets.RELU_STATS = E.device_relu_masks(self.eng, self.L, len(self.rec.idx)), {}
         try:
             rec = self.ora.train_batch(self.rec)
@@ -200,13 +229,15 @@ class LockStep:
         self._resync_priorities()
 
 
-CASES = [("dqn", "uniform", False, 1, False, False), ("dqn", "prioritize", True, 3, True, False), ("c51", "prioritize", False, 3, False, False),
-         ("c51", "prioritize", True, 3, True, False), ("dqn", "uniform", False, 3, False, True), ("c51", "prioritize", True, 1, True, True)]
+# the last two rows are BASELINE configs[2] (rainbow-lite: c51, prioritized sum-tree replay, double-Q, dueling, NoisyNet, n = 3) on both schedules
+CASES = [("dqn", "uniform", False, 1, False, False, None), ("dqn", "prioritize", True, 3, True, False, None), ("c51", "prioritize", False, 3, False, False, None),
+         ("c51", "prioritize", True, 3, True, False, None), ("dqn", "uniform", False, 3, False, True, None), ("c51", "prioritize", True, 1, True, True, None),
+         ("c51", "prioritize", True, 3, True, False, "c51_duel_noisy"), ("c51", "prioritize", True, 3, True, True, "c51_duel_noisy")]
 
 
-@pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,launch", CASES)
-def test_trainer_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_step, double_q, launch):
-    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch)
+@pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,launch,spec_name", CASES)
+def test_trainer_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_step, double_q, launch, spec_name):
+    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch, spec_name=spec_name)
     ls = LockStep(tr, ora, spec)
     for it in range(7):
         res = tr.run_iteration()
