@@ -41,6 +41,7 @@ from .schedules import LinearSchedule, epsilon
 # stream ids and seed offsets of the build's random-stream contract
 STREAM_EGREEDY_U, STREAM_EGREEDY_A, STREAM_TAUS, STREAM_NOISE, STREAM_SUMTREE, STREAM_PERM = 1, 2, 3, 4, 5, 6
 SAMPLER_SEED_OFFSET = 104729
+LEARNER_SEED_OFFSET = 15485863
 
 
 def seed64(seed: int, rank: int = 0) -> int:
@@ -143,6 +144,8 @@ class OracleTrainer:
         self.learner = OracleLearner(spec, state_dict, state_dict, hp, batch_size=batch_size, lr=lr, target_update_freq=target_update_freq)   # target = deepcopy(model), agent.py:100
         self.actor_rng = Stream(seed, rank)
         self.sampler_rng = Stream(seed + SAMPLER_SEED_OFFSET)
+        self.learner_rng = Stream(seed + LEARNER_SEED_OFFSET)
+        self.hp = hp
         A = spec.action_dim
 
         def draw(E_):   # agent.py:29-36: randint(0, A, E) first, then rand(E) — each from its own stream
@@ -160,8 +163,11 @@ class OracleTrainer:
                         p[f"{prefix}.{leaf}"] = torch.from_numpy(np.array(next(it), dtype=np.float32))
                     nets.compose_noise(p, prefix)
 
+        def actor_taus(E_):      # IQN: K fresh taus per env for every act (model.py:238, agent.py:25-28), from the actor's tau stream
+            return torch.from_numpy(self.actor_rng.uniform(STREAM_TAUS, E_ * hp.K).reshape(E_, hp.K, 1))
+
         self.actor = OracleActor(env, self.learner.po if not launch else self._snapshot(), spec, n_step=n_step, discount=discount, sample_steps=sample_steps, draw=draw,
-                                 noisy_reset=noisy_reset if spec.noisy else None, reset_noise_freq=reset_noise_freq)
+                                 noisy_reset=noisy_reset if spec.noisy else None, reset_noise_freq=reset_noise_freq, taus_fn=actor_taus if spec.algo == "iqn" else None)
         if self.sumtree:
             self.replay = SumTreeReplay(replay_size, beta0, alpha, prio_eps, total_steps)
         else:
@@ -233,7 +239,10 @@ class OracleTrainer:
         no = nt = None
         if self.spec.noisy:
             no, nt = self.learner_noise()
-        res = self.learner.train(rec.frames.reshape(self.B, -1), rec.act, rec.rew, rec.done, rec.weights, rec.idx, noise_online=no, noise_target=nt)
+        rand = None
+        if self.spec.algo == "iqn":      # agent.py:297-327 draws action-selection taus (K), target taus (N') and online taus (N), in this order
+            rand = [self.learner_rng.uniform(STREAM_TAUS, self.B * n).reshape(self.B, n, 1) for n in (self.hp.K, self.hp.N_dash, self.hp.N)]
+        res = self.learner.train(rec.frames.reshape(self.B, -1), rec.act, rec.rew, rec.done, rec.weights, rec.idx, rand=rand, noise_online=no, noise_target=nt)
         rec.q_loss, rec.fraction_loss = res["q_loss"], res["fraction_loss"]
         if rec.q_loss is not None:
             self.Ls.append(float(rec.q_loss.mean()))

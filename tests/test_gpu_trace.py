@@ -50,6 +50,8 @@ def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS, spec_name
             f"learner.double_q={str(double_q).lower()}", f"replay.policy={policy}", f"replay.sumtree={str(sumtree).lower()}", "trainer.exploration_steps=100",
             "trainer.total_steps=4000", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"]
     spec = recipe.SPECS[spec_name or algo]
+    if spec.action_dim == 9:
+        over.append("env_id=Asterix")                    # nine actions (BASELINE configs[3])
     over += [f"learner.dueling_head={str(bool(spec.dueling)).lower()}", f"learner.noisy_net={str(bool(spec.noisy)).lower()}"]
     cfg = parse_overrides(over)
     tr = Trainer(cfg, use_lp=launch)
@@ -229,10 +231,11 @@ class LockStep:
         self._resync_priorities()
 
 
-# the last two rows are BASELINE configs[2] (rainbow-lite: c51, prioritized sum-tree replay, double-Q, dueling, NoisyNet, n = 3) on both schedules
+# rows 7, 8 are BASELINE configs[2] (rainbow-lite: c51, prioritized sum-tree replay, double-Q, dueling, NoisyNet, n = 3) on both schedules
 CASES = [("dqn", "uniform", False, 1, False, False, None), ("dqn", "prioritize", True, 3, True, False, None), ("c51", "prioritize", False, 3, False, False, None),
          ("c51", "prioritize", True, 3, True, False, None), ("dqn", "uniform", False, 3, False, True, None), ("c51", "prioritize", True, 1, True, True, None),
-         ("c51", "prioritize", True, 3, True, False, "c51_duel_noisy"), ("c51", "prioritize", True, 3, True, True, "c51_duel_noisy")]
+         ("c51", "prioritize", True, 3, True, False, "c51_duel_noisy"), ("c51", "prioritize", True, 3, True, True, "c51_duel_noisy"),
+         ("iqn", "uniform", False, 1, True, False, "iqn")]       # BASELINE configs[3]: Asterix iqr — actor and learner taus from their Philox streams
 
 
 @pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,launch,spec_name", CASES)
