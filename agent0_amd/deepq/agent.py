@@ -309,13 +309,14 @@ class BaseLearner:
         return int(self.engine.state[1])
 
     # ------------------------------------------------------------------ hot path: batch addressed by ring slots
-    def train_batch(self, frames: torch.Tensor, slot: Optional[torch.Tensor], row_bytes: int, act, rew, done, weights):
+    def train_batch(self, frames: torch.Tensor, slot: Optional[torch.Tensor], row_bytes: int, act, rew, done, weights, rand=None):
+        """``rand`` (parity tests): the update's random / proposed fractions handed in instead of drawn here — see DeviceLearner.forward_dense;
+        the tensors must be persistent device buffers (the update is replayed from a hipGraph that holds their addresses)."""
         cfg = self.cfg
         if cfg.learner.noisy_net:
             self.model.reset_noise(compose=False)            # DeviceLearner.forward_dense composes both nets' effective weights
             self.model_target.reset_noise(compose=False)
-        rand = None
-        if self._taus is not None:
+        if rand is None and self._taus is not None:
             for t in self._taus:
                 self.rng.uniform(self.rng.STREAM_TAUS, t, t.numel())
             rand = self._taus
