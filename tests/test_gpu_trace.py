@@ -130,8 +130,9 @@ class LockStep:
         L.pack({k: v.detach() for k, v in ol.po.items()}, eng.online.flat)
         L.pack({k: v.detach() for k, v in ol.pt.items()}, eng.target.flat)
         eng.online.refresh_wt(); eng.target.refresh_wt()
-        L.pack(ol.adam.m, eng.adam_m)
-        L.pack(ol.adam.v, eng.adam_v)
+        zeros = {k: torch.zeros_like(ol.po[k]) for k in ol.f_keys}      # the fraction net has no Adam moments (its own RMSprop, agent.py:333-338)
+        L.pack({**ol.adam.m, **zeros}, eng.adam_m)
+        L.pack({**ol.adam.v, **zeros}, eng.adam_v)
 
     # ---- the wrapped calls, in the order Trainer.step makes them
     def extend(self, transitions):
