@@ -221,10 +221,13 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
     a0_mat_src b{X, ldx};
     bk.tag = A0_TAG_DENSE_WGRAD;
     if (defer) *defer = a0_reduce_seg{nullptr, 0, 0, nullptr, 0};
-    static const int var = getenv("A0_WGRAD_VARIANT") ? atoi(getenv("A0_WGRAD_VARIANT")) : 0;      // tuning aid
+    static const int var = getenv("A0_WGRAD_VARIANT") ? atoi(getenv("A0_WGRAD_VARIANT")) : -1;      // tuning aid: 0 = always split, 1 = never for >= 256 tiles
     const long long blocks64 = (long long)((N + 63) / 64) * ((K + 63) / 64);
-    if (var == 1 && blocks64 >= 256) {
-        // experiment (A0_WGRAD_VARIANT=1): 64x64 output tiles without a reduction split — measured slower than 64x128 tiles + 3 slabs for fc1
+    if (blocks64 >= 256 && (var == 1 || (var < 0 && R <= 1024))) {
+        // 64x64 output tiles without a reduction split when the output alone has >= 256 tiles and the batch is short (fc1 of a 512-row batch:
+        // 392 tiles).  As a lone kernel this is slower than 64x128 tiles + 3 slabs, but no slabs means 19 MB less to write and to reduce: the
+        // whole B = 512 update measures 419 vs 432 us (tools/ubench_update.py, profiles/r02_encoder_experiments.md).  The quantile networks'
+        // 32 768-row reductions keep the split kernel.
         EpiWgradSlab::Params e{grad, 0, K, wcount};
         bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>(a, b, e, N, K, R, 1);
         return;
