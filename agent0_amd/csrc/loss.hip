@@ -382,9 +382,11 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
                                                                      const float* __restrict__ b_tg, int A, int dueling, int ld, const int* __restrict__ act,
                                                                      const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ wgt,
                                                                      float gamma_n, int B, float* __restrict__ loss, float* __restrict__ q_on_out,
-                                                                     float* __restrict__ q_tg_out, float* __restrict__ draw, int* __restrict__ nan_flag) {
+                                                                     float* __restrict__ q_tg_out, float* __restrict__ draw, int* __restrict__ nan_flag,
+                                                                     float* __restrict__ dh_out) {
     extern __shared__ float wsm[];                 // [online rows | target rows], NQ x 512 each
     __shared__ float raw[4][3][32];
+    __shared__ float dsh[4][32];                   // this row's head gradient (draw), for the fused head data gradient
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NQ = A + (dueling ? 1 : 0);
     for (int i = threadIdx.x; i < NQ * 128; i += 256) { ((a0_f4*)wsm)[i] = ((const a0_f4*)W_on)[i]; ((a0_f4*)wsm)[NQ * 128 + i] = ((const a0_f4*)W_tg)[i]; }
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
         so = a0_wave_sum(so); st = a0_wave_sum(st); ss = a0_wave_sum(ss);
         if (lane == 0) { raw[wave][0][a] = so + b_on[a]; raw[wave][1][a] = st + b_tg[a]; raw[wave][2][a] = ss + b_on[a]; }
     }
-    if (lane != 0) return;
+    if (lane == 0) {
     const int nsel = s_sel ? 2 : 1;
     float mean[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
     if (dueling)
@@ -489,13 +491,27 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
             out = s;
         }
         o[c] = out;
+        if (c < 32) dsh[wave][c] = out;
+    }
+    }
+    // head data gradient, fused: dh[k] = (h[k] > 0) * sum_c draw[c] * W_on[c][k] over the head's rows (what a0_dense_dgrad computes from
+    // draw, W_on and the ReLU mask h) — the row's draw values come from lane 0 through LDS, the weights are already staged, h is in registers
+    if (dh_out) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): lane 0's LDS stores of dsh have landed (one wave: lock step, LDS in order)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float acc = 0.f;
+            for (int c = 0; c < NQ; ++c) acc = fmaf(dsh[wave][c], wsm[c * 512 + lane + 64 * i], acc);
+            dh_out[(long long)b * 512 + lane + 64 * i] = ho[i] > 0.f ? acc : 0.f;
+        }
     }
 }
 
 extern "C" int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const float* slabs_sel, long long slab_stride, int nslab, const float* b1_on,
                                       const float* b1_tg, float* h_on_out, const float* W_on, const float* b_on, const float* W_tg, const float* b_tg, int A,
                                       int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt, float gamma_n, int B, float* loss,
-                                      float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream) {
+                                      float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, float* dh_out, void* stream) {
     const int NQ = A + (dueling ? 1 : 0);
     if (!slabs_on || !slabs_tg || !b1_on || !b1_tg || !h_on_out || !W_on || !b_on || !W_tg || !b_tg || !act || !rew || !done || !wgt || !loss || !q_on_out || !draw ||
         !nan_flag || B < 1 || A < 1 || NQ > 24 || ld < NQ || nslab < 1 || slab_stride < (long long)B * 512)
@@ -508,7 +524,7 @@ extern "C" int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_
         configured = lds;
     }
     hipLaunchKernelGGL(a0_dqn_head_loss_slabs_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, slabs_on, slabs_tg, slabs_sel, slab_stride, nslab, b1_on, b1_tg,
-                       h_on_out, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag);
+                       h_on_out, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag, dh_out);
     return a0_fail_hip((int)hipGetLastError(), "a0_dqn_head_loss_slabs");
 }
 

@@ -300,7 +300,7 @@ class DeviceLearner:
         key = name + ".mu" if (L.noisy and name in ("fc1", "head")) else name
         return self.grads[L.blocks[key].all]
 
-    def _backward_dense(self, ws: Workspace, B, have_draw: bool = False):
+    def _backward_dense(self, ws: Workspace, B, have_draw: bool = False, have_dh: bool = False):
         """dq (w.r.t. the combined head output) -> the gradients of every dense block (head, fc1, cosine embedding, NoisyNet sigmas)
         and d3, the gradient w.r.t. the encoder output.  After this call the flat gradient range [L.conv_end, L.n_adam) is final:
         the data-parallel exchange of that range (95 % of the parameters) can run while the encoder backward is still computing."""
@@ -312,7 +312,8 @@ class DeviceLearner:
         Wf, _ = on.wb("fc1")
         # the data gradients first, then every dense weight gradient with ONE slab reduction
         wg = [(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512)]
-        ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
+        if not have_dh:
+            ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
         if not L.quantile:
             wg.append((ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat))
             ops.dense_dgrad(ws.dh, Wf, ws.act3, ws.d3, R, 512, L.feat)
@@ -417,7 +418,7 @@ class DeviceLearner:
         algo = L.algo
         wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
         frac = None
-        have_draw = False
+        have_draw = have_dh = False
         if algo == "mdqn":
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             tg.head(wt, B)
@@ -443,7 +444,8 @@ class DeviceLearner:
             on.encode(wo, frames, slot, sample_stride, 0, B)
             ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
             ops.dqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
-                                    L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state)
+                                    L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state, wo.dh)
+            have_dh = True           # ... and the head's backward-data pass: dh is written by the same kernel
             have_draw = True
         elif algo in ("dqn", "c51", "qr"):
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
@@ -517,7 +519,7 @@ class DeviceLearner:
             frac = self.frac_loss
         else:
             raise NotImplementedError(f"algo {algo} has no device learner yet")
-        self._backward_dense(wo, B, have_draw)
+        self._backward_dense(wo, B, have_draw, have_dh)
         self._bw = (wo, frames, slot, sample_stride, B)
         if self._bucketed_hook():      # the NaN flag rides at the tail of the dense gradient bucket
             ops.nan_flag_export(self.state, self.grads[L.n_params_padded: L.n_params_padded + 1])

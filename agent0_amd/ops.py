@@ -360,7 +360,7 @@ class HipOps:
         return ns
 
     def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
-                            draw, state):
+                            draw, state, dh=None):
         nq = A + (1 if dueling else 0)
         n = nslab * B * 512
         check(self.lib.a0_dqn_head_loss_slabs(_req(s_on, torch.float32, n, "slabs_on"), _req(s_tg, torch.float32, n, "slabs_tg"),
@@ -370,7 +370,8 @@ class HipOps:
                                               _req(b_tg, torch.float32, nq, "b_tg"), A, int(dueling), ld, _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"),
                                               _req(done, torch.float32, B, "done"), _req(wgt, torch.float32, B, "wgt"), float(gamma_n), B, _req(loss, torch.float32, B, "loss"),
                                               _req(q_on, torch.float32, B * A, "q_on"), _req(q_tg, torch.float32, B * A, "q_tg", optional=True),
-                                              _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"), _stream()), "a0_dqn_head_loss_slabs")
+                                              _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"),
+                                              _req(dh, torch.float32, B * 512, "dh", optional=True), _stream()), "a0_dqn_head_loss_slabs")
 
     def actor_dist_tail(self, slabs, nslab, bias, ld, A, T, dueling, mode, atoms, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl=None, eps_ptr=None):
         check(self.lib.a0_actor_dist_tail(_req(slabs, torch.float32, nslab * E * ld, "slabs"), E * ld, nslab, _req(bias, torch.float32, ld, "bias"), ld, A, T, int(dueling),

@@ -156,11 +156,13 @@ int a0_dqn_head_loss(const float* h_on, const float* h_tg, const float* h_sel, c
                      const float* b_tg, int A, int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt,
                      float gamma_n, int B, float* loss, float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream);
 /* a0_dqn_head_loss that also finishes the three fc1 layers from their split-K slabs (a0_dense_fwd_partial): slab sum in order + bias + ReLU,
- * bit-identical to a0_dense_fwd; writes the online activations h(s) [B][512] for the backward pass.  slabs_sel = NULL without double-Q. */
+ * bit-identical to a0_dense_fwd; writes the online activations h(s) [B][512] for the backward pass.  slabs_sel = NULL without double-Q.
+ * dh_out (optional, [B][512]): the gradient w.r.t. h(s), i.e. draw times the online head's rows masked by h > 0 — what a0_dense_dgrad would
+ * compute from draw (the head's backward-data pass, agent.py:153-155), produced here where all of its operands already are. */
 int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const float* slabs_sel, long long slab_stride, int nslab, const float* b1_on,
                            const float* b1_tg, float* h_on_out, const float* W_on, const float* b_on, const float* W_tg, const float* b_tg, int A,
                            int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt, float gamma_n, int B, float* loss,
-                           float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, void* stream);
+                           float* q_on_out, float* q_tg_out, float* draw, int* nan_flag, float* dh_out, void* stream);
 
 /* MDQNLearner.train_step (agent.py:194-215): q_next = target(next_obs), q_cur_tgt = target(obs), both [B][A] */
 int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,

@@ -364,7 +364,7 @@ class CpuOps:
         return 1
 
     def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
-                            draw, state):
+                            draw, state, dh=None):
         def fc1(slabs, bias):
             return torch.relu(slabs[: nslab * B * 512].view(nslab, B, 512).sum(0) + bias[:512]).reshape(-1).contiguous()
 
@@ -387,3 +387,5 @@ class CpuOps:
         dq = torch.zeros(B * A)
         self.loss_dqn(q_on, q_t, A, act, a_star, rew, done, wgt, gamma_n, B, loss, dq, state)
         self.dueling_bwd(dq, draw, ld, B, A, 1, dueling)
+        if dh is not None:
+            self.dense_dgrad(draw, W_on, h_on, dh, B, ld, 512)
