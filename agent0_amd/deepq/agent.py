@@ -263,6 +263,16 @@ class Actor:
         done_ev.record()
         return (T, bound, test, st, start, frames_out, done_ev)
 
+    def block_of(self, pending) -> TransitionBlock:
+        """The TransitionBlock of a rollout that has been issued (``sample_async``) but not necessarily finished: what ``replay.extend`` needs is
+        known on the host from the start (row count, ring position); the rows themselves are ordered before any later kernel on the stream."""
+        T, bound, test, st, start, frames_out, done_ev = pending
+        if test:
+            raise ValueError("a test rollout produces frames, not transitions")
+        if bound:
+            return TransitionBlock(T * self.E, start=start, source=self.replay if isinstance(self.replay, StageRing) else None)
+        return TransitionBlock(T * self.E, staged=st)
+
     def sample_finish(self, pending):
         T, bound, test, st, start, frames_out, done_ev = pending
         E = self.E
@@ -273,11 +283,7 @@ class Actor:
         rs = self.stat_ret[:T * E].cpu().numpy()[mask].tolist()
         if test:
             return frames_out, rs, qs
-        if bound:
-            data = TransitionBlock(T * E, start=start, source=self.replay if isinstance(self.replay, StageRing) else None)
-        else:
-            data = TransitionBlock(T * E, staged=st)
-        return data, rs, qs
+        return self.block_of(pending), rs, qs
 
     def close(self):
         self.envs.close()

@@ -148,9 +148,15 @@ class Trainer:
 
     # ------------------------------------------------------------------ trainer.py:74-119
     def step(self, transitions, returns, qmax):
-        cfg = self.cfg
         self.Qs.extend(qmax)
         self.Rs.extend(returns)
+        self._step_device(transitions)
+        return self._result()
+
+    def _step_device(self, transitions):
+        """trainer.py:76-110 without the host-side statistics: commit the rollout, run the update block.  Everything here is enqueued on the
+        stream; nothing waits for the device except the one read of the block's loss means at the end."""
+        cfg = self.cfg
         self.replay.extend(transitions)
         self.frame_count += self.num_transitions
         n_upd = 0
@@ -175,6 +181,9 @@ class Trainer:
             self.Ls.extend(self._loss_means[:n_upd].cpu().tolist())        # the one device->host read of the update block
             if has_frac:
                 self.FLs.extend(self._floss_means[:n_upd].cpu().tolist())
+
+    def _result(self):
+        """The result dict of trainer.py:111-118."""
         return dict(
             frames=self.frame_count,
             fraction_loss=np.mean(self.FLs[-20:]) if len(self.FLs) > 0 else None,
@@ -285,8 +294,16 @@ class Trainer:
             return self.run_iteration_lp()
         tic = time.time()
         epsilon = self.epsilon_fn(self.frame_count)
-        transitions, returns, qmax = self.actors[1].sample(epsilon)
-        result = self.step(transitions, returns, qmax)
+        # Same work in the same stream order as ``step(*actor.sample(eps))`` — the update block's kernels are ordered behind the rollout's — but
+        # the host does not stop between them: the rollout's statistics (episode returns, per-step max-Q: one small read-back) are collected
+        # after the update block has been enqueued instead of before, so the GPU never waits for Python at the rollout / update boundary.
+        actor = self.actors[1]
+        pending = actor.sample_async(epsilon)
+        self._step_device(actor.block_of(pending))
+        _, returns, qmax = actor.sample_finish(pending)
+        self.Qs.extend(qmax)
+        self.Rs.extend(returns)
+        result = self._result()
         torch.cuda.synchronize()
         result.update(fps=self.num_transitions / (time.time() - tic))
         return result
