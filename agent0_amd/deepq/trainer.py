@@ -326,13 +326,15 @@ class Trainer:
         if self.use_lp and self._pending is not None:
             self.actors[1].sample_finish(self._pending)      # drain the rollout still in flight
             self._pending = None
-        if self.primary:
-            self.test()
-        if save and self.primary:            # after the final test, so that its returns ("ITRs") are part of the run's record
-            try:
-                self.save_checkpoint(os.path.join(self.cfg.logdir, "final.pth"))
-            except OSError:
-                pass
+        try:
+            if self.primary:
+                self.test()
+        finally:
+            if save and self.primary:        # after the final test, so that its returns ("ITRs") are part of the run's record — and even if it failed
+                try:
+                    self.save_checkpoint(os.path.join(self.cfg.logdir, "final.pth"))
+                except OSError:
+                    pass
         for actor in self.actors:
             if actor is not None:
                 actor.close()
