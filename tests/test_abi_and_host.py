@@ -129,3 +129,46 @@ def test_u8_division_shortcut_is_exact():
     e = np.float32(x.astype(np.float64) - q0.astype(np.float64) * 255.0)          # fma(-q0, 255, x): exact in fp64, then one rounding
     q = (q0.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
     assert np.array_equal(q, x / np.float32(255.0))
+
+
+def test_bench_starts_its_own_launcher_as_a_child(monkeypatch, capsys):
+    """``python bench.py --gpus N`` with no launcher environment (the way the driver may call it): bench.py must start
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`` as a CHILD
+    process — never an exec, and before anything in this process imports the GPU stack — relay rank 0's JSON line on stdout and return the
+    child's exit code."""
+    import io
+    import json
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, stdout=None, text=None, env=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('some library banner\n{"metric": "env-frames/sec", "value": 1.0, "n_gpus": 4}\n')
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--self-launch"])
+    monkeypatch.setattr(os, "execv", lambda *a, **k: (_ for _ in ()).throw(AssertionError("bench.py must never exec")))
+    gpu_stack = [m for m in ("agent0_amd.ops", "agent0_amd.deepq.trainer") if m in sys.modules]
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"], "the child gets the same flags, minus --self-launch"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip())["n_gpus"] == 4 and "banner" in out.err, "exactly the JSON line on stdout, everything else on stderr"
+    assert [m for m in ("agent0_amd.ops", "agent0_amd.deepq.trainer") if m in sys.modules] == gpu_stack, "the parent did not load the GPU stack"
