@@ -91,3 +91,53 @@ def test_vectorised_singles_autoreset_statistics_and_clipping():
         if step == 6:          # env 0 ends at t = 6: rewards 7 (t=3) - 3 (t=5) + 7 (t=6) = 11
             assert term.tolist() == [True, False] and float(info["final_info"][0]["episode"]["r"][0]) == 11.0
     assert "life_loss" in info and info["life_loss"].dtype == bool
+
+
+def test_atari_slice_builds_the_reference_pipeline_from_gymnasium(monkeypatch):
+    """``AtariSlice`` (what ``make_atari`` hands to the env pool when gymnasium + ale-py are installed): per env
+    ``gym.make("<Game>NoFrameskip-v4")`` -> AtariPreprocessing(terminal_on_life_loss=False) -> FrameStack(4) (the library wrappers of
+    atari_wrappers.py:61-63) -> LifeLossInfo (only with episode_life) -> FireOnReset, vectorised with statistics and clipping.  gymnasium and
+    ale-py are not in this image, so stand-in modules record how they are called."""
+    import sys
+    import types
+
+    from agent0_amd.common.host_envs import AtariSlice
+
+    calls = []
+
+    class Pre:
+        def __init__(self, env, terminal_on_life_loss=None):
+            calls.append(("AtariPreprocessing", terminal_on_life_loss))
+            self.env, self.unwrapped = env, env
+
+        def __getattr__(self, n):
+            return getattr(self.env, n)
+
+    class Stack(Pre):
+        def __init__(self, env, k):
+            calls.append(("FrameStack", k))
+            self.env, self.unwrapped = env, env.unwrapped
+
+    gym = types.ModuleType("gymnasium")
+    gym.make = lambda name: (calls.append(("make", name)), FakeAle(lives=2, life_every=3))[1]
+    wr = types.ModuleType("gymnasium.wrappers")
+    wr.AtariPreprocessing, wr.FrameStack = Pre, Stack
+    gym.wrappers = wr
+    for name, mod in (("gymnasium", gym), ("gymnasium.wrappers", wr), ("ale_py", types.ModuleType("ale_py"))):
+        monkeypatch.setitem(sys.modules, name, mod)
+    from agent0_amd.common.atari_wrappers import real_atari_available
+    assert real_atari_available()
+    vec = AtariSlice("Breakout", episode_life=True)(4, 2)              # envs 4 and 5 of the vector env
+    assert [c for c in calls if c[0] == "make"] == [("make", "BreakoutNoFrameskip-v4")] * 2
+    assert ("AtariPreprocessing", False) in calls and ("FrameStack", 4) in calls
+    assert type(vec).__name__ == "VectorizedSingles" and len(vec.envs) == 2
+    assert type(vec.envs[0]).__name__ == "FireOnReset" and type(vec.envs[0].env).__name__ == "LifeLossInfo"
+    obs, _ = vec.reset()
+    assert obs.shape[0] == 2
+    seen_life = False
+    for _ in range(8):
+        obs, rew, term, trunc, info = vec.step(np.array([3, 3]))
+        seen_life |= bool(info["life_loss"].any())
+    assert seen_life and set(np.unique(rew)) <= {-1.0, 0.0, 1.0}
+    no_life = AtariSlice("Breakout", episode_life=False)(0, 1)
+    assert type(no_life.envs[0].env).__name__ == "Stack", "without episode_life the life-loss wrapper is left out (atari_wrappers.py:64)"
