@@ -9,6 +9,7 @@ that a worker never opens the GPU.  The device / DMA side is env_pool.HostEnvPoo
 """
 from __future__ import annotations
 
+import os
 import time
 from multiprocessing import shared_memory
 
@@ -151,10 +152,14 @@ def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us):
     ctl = buf["ctl"]
     env = make_slice(lo, k)
     seen = 0
+    parent, spins = os.getppid(), 0
     try:
         while True:
             while int(ctl[CTL_SEQ]) == seen:                 # the sequence number arrives by DMA (steps) or from the parent (reset / close)
                 time.sleep(spin_us * 1e-6)
+                spins += 1
+                if (spins & 0x3FFF) == 0 and os.getppid() != parent:
+                    return                                   # the parent is gone (killed): do not poll a dead ring forever
             seen = int(ctl[CTL_SEQ])
             cmd = int(ctl[CTL_CMD])
             if cmd == CMD_CLOSE:
