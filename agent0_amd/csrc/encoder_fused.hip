@@ -49,7 +49,11 @@ struct a0_fused_args {
 };
 
 // Eight waves per workgroup = two per SIMD: while one wave waits for its LDS operands the other keeps the matrix pipe busy.
-constexpr int A0_FUSED_WAVES = 8;
+#ifndef A0_FUSED_WAVES_D
+#define A0_FUSED_WAVES_D 8
+#endif
+constexpr int A0_FUSED_WAVES = A0_FUSED_WAVES_D;
+constexpr int A0_WMG1 = A0_FUSED_WAVES / 2;       // conv1: two waves along N, the rest along M
 constexpr int A0_FUSED_THREADS = 64 * A0_FUSED_WAVES;
 // LDS layout of the activations: [row][pixel][channel] with pixel pitch P and row pitch RP.  An A-fragment read (ds_read_b32) is served
 // in two groups of 32 lanes = 16 consecutive output positions m x 2 adjacent k; it is conflict-free when position m lands on bank
@@ -320,7 +324,7 @@ A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0
     int rows[MBW];
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
-        int m = (wmg + i * 4) * 16 + r16;
+        int m = (wmg + i * A0_WMG1) * 16 + r16;
         m = m < M ? m : 0;
         const int oh = m / W1, ow = m - oh * W1;
         rows[i] = (4 * oh + q) * W + 4 * ow;
@@ -363,7 +367,7 @@ A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0
     between();
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
-        const int mb = wmg + i * 4;
+        const int mb = wmg + i * A0_WMG1;
         if (mb < MB) {
             const int n = wn * 16 + r16;
             if (EPI::ROW4 && mb * 16 + 16 <= M) {
@@ -548,8 +552,11 @@ constexpr int A0_RX2 = A0_RX2_D, A0_RX3 = A0_RX3_D;         // 32-k steps of spl
 // Register-ring depths (16-k chunks in flight per wave): >= 2 us of MFMA work ahead of every weight load.
 constexpr int A0_R1 = 4, A0_R2 = 4, A0_R3 = 6;     // conv1: 32-k steps (three 16-byte terms each); conv2 / conv3: 16-k chunks
 
+#ifndef A0_FUSED_MINWAVES
+#define A0_FUSED_MINWAVES 1
+#endif
 template <int MBW1, int MBW2, int MBW3, int WC, bool X9>
-__global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_fused_args P);
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P);
 
 // Split-operand variant (84 x 84 geometry): all three layers on the bf16 pipe.  LDS: bf16 image [0, 56 448), act1 term planes behind it;
 // the act2 term planes reuse the image's bytes (the image is dead once conv1 has finished).
@@ -559,9 +566,14 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     uint16_t* img = (uint16_t*)smem;
     const int obs_bytes = P.C * P.H * P.W;
     const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
+#ifdef A0_EXP_ALIAS        // TIMING-ONLY experiment (results are garbage): all LDS regions overlap so that two workgroups fit a CU
+    uint16_t* a1p = (uint16_t*)smem;
+    constexpr int term1 = 10 * A0_RP1X, term2 = 9 * A0_RP2X;
+#else
     uint16_t* a1p = (uint16_t*)(smem + 2 * obs_bytes);
-    uint16_t* a2p = (uint16_t*)smem;
     constexpr int term1 = 20 * A0_RP1X, term2 = 9 * A0_RP2X;
+#endif
+    uint16_t* a2p = (uint16_t*)smem;
     typedef EpiFwdX<20, A0_P1X, A0_RP1X, term1> E1X;
     typedef EpiFwdX<9, A0_P2X, A0_RP2X, term2> E2X;
     // conv2 / conv3 wave tiling: WNX waves along N (each owns 64 / 16 / WNX column blocks), 8 / WNX groups along M.  An A fragment read
@@ -579,7 +591,9 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     ring2.init(P.wx2, 512);
     ring3.init(P.wx3, 576);
     ring1.prologue();
-    a0_pre<32, 2, MBW1, E1X> pre1;
+    constexpr int MBW1X = (25 + A0_WMG1 - 1) / A0_WMG1;
+    static_assert(A0_FUSED_WAVES != 8 || MBW1X == MBW1, "84x84 geometry");
+    a0_pre<32, 2, MBW1X, E1X> pre1;
     a0_pre<64, WNX, MBW2X, E2X> pre2;
     a0_pre<64, WNX, MBW3X, EpiFwd<0>> pre3;
     pre1.load(E1X{P.b1, nullptr, nullptr, 32}, M1);
@@ -618,11 +632,11 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
         __syncthreads();
         const E1X e1{P.b1, a1p, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
         const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
-        if (MBW1 > 1 && wmg1 + (MBW1 - 1) * 4 >= ((M1 + 15) >> 4))
-            a0_conv1_stage<(MBW1 > 1 ? MBW1 - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
+        if (MBW1X > 1 && wmg1 + (MBW1X - 1) * A0_WMG1 >= ((M1 + 15) >> 4))
+            a0_conv1_stage<(MBW1X > 1 ? MBW1X - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
-            a0_conv1_stage<MBW1, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
-        const AF2X<20 * A0_RP1X> f2{a1p, A0_RP1X, P.W2, A0_P1X};
+            a0_conv1_stage<MBW1X, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
+        const AF2X<term1> f2{a1p, A0_RP1X, P.W2, A0_P1X};
         const E2X e2{P.b2, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
         const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
         constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
@@ -630,7 +644,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
             a0_conv_stage_x9<64, WNX, (MBW2X > 1 ? MBW2X - 1 : 1), A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
         else
             a0_conv_stage_x9<64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
-        const AF3X<9 * A0_RP2X> f3{a2p, A0_RP2X, P.W3, A0_P2X};
+        const AF3X<term2> f3{a2p, A0_RP2X, P.W3, A0_P2X};
         const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
         if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
             a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
@@ -640,7 +654,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
 }
 
 template <int MBW1, int MBW2, int MBW3, int WC, bool X9>
-__global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_fused_kernel(a0_fused_args P) {
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P) {
     if constexpr (X9) {
         a0_encoder_fused_x9_body<MBW1, MBW2, MBW3>(P);
         return;
@@ -1043,6 +1057,9 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     const bool x9 = standard && H == 84 && C == 4 && !no_x9;
     const int which = x9 ? 2 : (standard ? 1 : 0);
     if (x9) lds = (size_t)2 * C * H * W + (size_t)3 * P.H1 * A0_RP1X * 2;            // image + act1 term planes (act2 planes reuse the image)
+#ifdef A0_EXP_ALIAS
+    if (x9) lds = (size_t)(2 * 10 + 20) * A0_RP1X * 2;
+#endif
     static_assert(3 * 9 * A0_RP2X * 2 <= 2 * 4 * 84 * 84, "the act2 term planes fit into the dead image");
     static size_t configured[3] = {0, 0, 0};
     const void* fn = which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
