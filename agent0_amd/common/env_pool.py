@@ -12,7 +12,12 @@ What it replaces: the reference's ``make_atari`` returns a gymnasium AsyncVector
     same shared block in stream order, and the workers poll the sequence number — the Python thread never calls ``.cpu()`` or
     ``stream.synchronize()`` on the step path; it only waits for its own workers (CPU work) before enqueueing the next upload;
   * uploads run on a dedicated copy stream; the compute stream waits for them through an event, so the n-step / replay-insert kernels
-    of step t and anything else already enqueued overlap the DMA of step t+1's observations.
+    of step t and anything else already enqueued overlap the DMA of step t+1's observations;
+  * the frame stack lives on the DEVICE (``newest_frame=True``, the default for stacked observations): a worker marks every env whose
+    stack merely advanced — its older frames are byte-for-byte the previous observation's newer ones — and for those only the newest
+    frame crosses PCIe (7 KB instead of 28 KB per env and step); ``a0_env_frame_stack`` rebuilds the stack from the previous observation
+    the device already holds.  Envs whose stack changed in any other way (episode boundary, the extra presses after a lost life) are
+    uploaded whole, so the device observation is bit-identical to the host one for any wrapper order.
 
 Interface: the one ``Actor`` consumes (DeviceSynthVecEnv): ``reset() -> (obs, info)``, ``step(action, final_mask, final_ret, ctrl) ->
 (obs, reward, terminal, truncated, info)`` with device tensors; ``info["life_loss"]``, ``info["final_mask"]``, ``info["final_ret"]`` carry
@@ -31,8 +36,8 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
-from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_CMD, CTL_DONE0, CTL_SEQ, HostSynthSlice, VectorizedSingles, block_layout, block_views, record,  # noqa: F401
-                        worker_main)
+from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_CMD, CTL_DONE0, CTL_SEQ, N_SCAL, HostSynthSlice, VectorizedSingles, block_layout,  # noqa: F401
+                        block_views, record, worker_main)
 
 
 class _Space:
@@ -45,7 +50,8 @@ class _Space:
 
 class HostEnvPool:
     def __init__(self, make_slice: Callable[[int, int], object], num_envs: int, obs_shape=(4, 84, 84), action_dim: int = 4, num_workers: int = 4, ops=None,
-                 start_method: str = "spawn", spin_us: float = 20.0, has_life_loss: bool = True):
+                 start_method: str = "spawn", spin_us: float = 20.0, has_life_loss: bool = True, newest_frame: Optional[bool] = None,
+                 busy_us: float = 500.0):
         """``make_slice(e0, k)`` -> vector env over envs [e0, e0 + k) (must be picklable for worker processes).  ``num_workers = 0`` steps
         the whole vector env in this process (same buffers and copy stream; the action then has to be waited for here)."""
         if ops is None:
@@ -59,17 +65,27 @@ class HostEnvPool:
         self.action_space = _Space(n=self.action_dim)
         self.has_life_loss = has_life_loss
         E = self.E
+        # device frame stack: possible when the leading axis stacks frames of a multiple of 16 bytes
+        self.nstack = self.obs_shape[0] if len(self.obs_shape) > 1 else 1
+        fb = self.obs_bytes // self.nstack
+        can_stack = self.nstack > 1 and fb % 16 == 0
+        if newest_frame and not can_stack:
+            raise ValueError(f"newest_frame needs stacked observations with frames of a multiple of 16 bytes, got shape {self.obs_shape}")
+        self.newest_frame = can_stack if newest_frame is None else bool(newest_frame)
+        self.frame_bytes = fb if self.newest_frame else 0
+        self.full_uploads = 0                 # envs whose whole stack crossed PCIe on the step path (device frame-stack mode)
         # ---- ONE shared, page-locked host block (multiprocessing.shared_memory: the workers map it by name and need no torch):
         # observations and scalars double-buffered by step parity, actions, control words
-        o_obs, o_scal, o_act, o_ctl, total = block_layout(E, self.obs_bytes, self.W)
+        o_obs, o_scal, o_act, o_ctl, o_new, total = block_layout(E, self.obs_bytes, self.W, self.frame_bytes)
         self._shm = shared_memory.SharedMemory(create=True, size=total)
-        self._np = block_views(self._shm.buf, E, self.obs_bytes, self.W)
+        self._np = block_views(self._shm.buf, E, self.obs_bytes, self.W, self.frame_bytes)
         for v in self._np.values():
             v[...] = 0
         whole = torch.frombuffer(self._shm.buf, dtype=torch.uint8)
         self._whole = whole
         self._obs_h = whole[o_obs:o_obs + 2 * E * self.obs_bytes].view(2, E, self.obs_bytes)
-        self._scal_h = whole[o_scal:o_scal + 2 * 6 * E * 4].view(torch.float32).view(2, 6, E)
+        self._scal_h = whole[o_scal:o_scal + 2 * N_SCAL * E * 4].view(torch.float32).view(2, N_SCAL, E)
+        self._new_h = whole[o_new:o_new + 2 * E * self.frame_bytes].view(2, E * self.frame_bytes)
         self._act_h = whole[o_act:o_act + 4 * E].view(torch.int32)
         self._ctl_h = whole[o_ctl:o_ctl + 8 * (CTL_DONE0 + max(self.W, 1))].view(torch.int64)
         err = torch.cuda.cudart().cudaHostRegister(whole.data_ptr(), total, 0)
@@ -78,14 +94,15 @@ class HostEnvPool:
         self._registered = True
         # ---- device side
         self._obs = [ops.zeros(E * self.obs_bytes, dtype=torch.uint8), ops.zeros(E * self.obs_bytes, dtype=torch.uint8)]
-        self._scal_d = [ops.zeros(6, E), ops.zeros(6, E)]
+        self._scal_d = [ops.zeros(N_SCAL, E), ops.zeros(N_SCAL, E)]
+        self._new_d = ops.zeros(max(E * self.frame_bytes, 16), dtype=torch.uint8)
         self._seq_d = torch.zeros(2, dtype=torch.int64, device=ops.device)          # [seq, CMD_STEP]: DMA-copied over ctl[0:2] behind the actions
         self._seq_d[1] = CMD_STEP
         self.copy_stream = torch.cuda.Stream()
         self._uploaded = torch.cuda.Event()
         self.seq = 0
         self.g = 0
-        self.pcie_bytes_per_step = E * (self.obs_bytes + 6 * 4 + 4) + 16
+        self.pcie_bytes_per_step = E * ((self.frame_bytes or self.obs_bytes) + N_SCAL * 4 + 4) + 16      # + obs_bytes per whole-stack upload (full_uploads)
         # ---- workers
         self._procs, self._local = [], None
         bounds = [round(i * E / max(self.W, 1)) for i in range(max(self.W, 1) + 1)]
@@ -96,7 +113,8 @@ class HostEnvPool:
             import multiprocessing as mp
             ctx = mp.get_context(start_method)
             for w, (lo, k) in enumerate(self._slices):
-                p = ctx.Process(target=worker_main, args=(w, make_slice, lo, k, self._shm.name, E, self.obs_bytes, self.W, spin_us), daemon=True)
+                p = ctx.Process(target=worker_main, args=(w, make_slice, lo, k, self._shm.name, E, self.obs_bytes, self.W, spin_us, self.frame_bytes, busy_us),
+                                daemon=True)
                 p.start()
                 self._procs.append(p)
 
@@ -108,24 +126,44 @@ class HostEnvPool:
         self._np["ctl"][CTL_SEQ] = self.seq
 
     def _wait_workers(self, timeout_s: float = 120.0):
-        ctl, t0 = self._np["ctl"], time.time()
+        ctl, t0 = self._np["ctl"], time.perf_counter()
         while True:
             done = ctl[CTL_DONE0:CTL_DONE0 + self.W]
             if (done == self.seq).all():
                 return
             if (done < 0).any():
                 raise RuntimeError("an env worker process died")
-            if time.time() - t0 > timeout_s:
+            waited = time.perf_counter() - t0
+            if waited > timeout_s:
                 raise TimeoutError(f"env workers did not finish step {self.seq} within {timeout_s} s (completed: {done.tolist()})")
-            time.sleep(5e-6)
+            if waited > 2e-3:                    # a step of a real emulator takes longer than this: stop burning the core (a sleep costs ~60 us of timer slack)
+                time.sleep(2e-5)
 
     def _upload(self, half: int, scalars: bool):
-        """Page-locked half -> device buffers on the copy stream; the compute stream picks the result up through an event."""
+        """Page-locked half -> device buffers on the copy stream; the compute stream picks the result up through an event.  ``scalars`` is
+        False for a reset (whole stacks, nothing else)."""
         self.copy_stream.wait_stream(torch.cuda.current_stream())      # kernels still reading this half of the DEVICE ring (n-step / replay insert of two steps ago)
         with torch.cuda.stream(self.copy_stream):
-            self._obs[half].copy_(self._obs_h[half].view(-1), non_blocking=True)
-            if scalars:
+            if scalars and self.newest_frame:
+                self._new_d.copy_(self._new_h[half], non_blocking=True)
                 self._scal_d[half].copy_(self._scal_h[half], non_blocking=True)
+                # whole stacks for the envs that did not merely advance (host memory: the workers have finished); adjacent envs in one copy
+                whole = np.flatnonzero(self._np["scal"][half, 6] == 0.0)
+                self.full_uploads += len(whole)
+                dst, src, ob = self._obs[half], self._obs_h[half].view(-1), self.obs_bytes
+                i = 0
+                while i < len(whole):
+                    j = i
+                    while j + 1 < len(whole) and whole[j + 1] == whole[j] + 1:
+                        j += 1
+                    a, b = int(whole[i]) * ob, (int(whole[j]) + 1) * ob
+                    dst[a:b].copy_(src[a:b], non_blocking=True)
+                    i = j + 1
+                self.ops.env_frame_stack(self._obs[half ^ 1], self._new_d, self._scal_d[half][6], self._obs[half], self.E, self.nstack, self.frame_bytes)
+            else:
+                self._obs[half].copy_(self._obs_h[half].view(-1), non_blocking=True)
+                if scalars:
+                    self._scal_d[half].copy_(self._scal_h[half], non_blocking=True)
             self._uploaded.record(self.copy_stream)
         torch.cuda.current_stream().wait_event(self._uploaded)
 
@@ -189,7 +227,7 @@ class HostEnvPool:
             torch.cuda.cudart().cudaHostUnregister(self._whole.data_ptr())
             self._registered = False
             self._np = None
-            del self._obs_h, self._scal_h, self._act_h, self._ctl_h, self._whole
+            del self._obs_h, self._scal_h, self._act_h, self._ctl_h, self._new_h, self._whole
             try:
                 self._shm.close()
                 self._shm.unlink()

@@ -20,23 +20,29 @@ CMD_NONE, CMD_STEP, CMD_RESET, CMD_CLOSE = 0, 1, 2, 3
 CTL_SEQ, CTL_CMD, CTL_DONE0 = 0, 1, 2
 
 
-def block_layout(E: int, obs_bytes: int, workers: int):
-    """Byte offsets of the shared block: observations [2][E][obs_bytes] u8 | scalars [2][6][E] f32 | actions [E] i32 | control i64."""
+N_SCAL = 7      # scalar rows per env and step: reward, terminated, truncated, life_loss, final mask, final return, advance (see record)
+
+
+def block_layout(E: int, obs_bytes: int, workers: int, frame_bytes: int = 0):
+    """Byte offsets of the shared block: observations [2][E][obs_bytes] u8 | scalars [2][N_SCAL][E] f32 | actions [E] i32 | control i64 |
+    newest frames [2][E][frame_bytes] u8 (device frame-stack mode; frame_bytes = 0: absent)."""
     a16 = lambda n: (n + 63) // 64 * 64
     off_obs = 0
     off_scal = a16(off_obs + 2 * E * obs_bytes)
-    off_act = a16(off_scal + 2 * 6 * E * 4)
+    off_act = a16(off_scal + 2 * N_SCAL * E * 4)
     off_ctl = a16(off_act + E * 4)
-    total = a16(off_ctl + 8 * (CTL_DONE0 + max(workers, 1)))
-    return off_obs, off_scal, off_act, off_ctl, total
+    off_new = a16(off_ctl + 8 * (CTL_DONE0 + max(workers, 1)))
+    total = a16(off_new + 2 * E * frame_bytes)
+    return off_obs, off_scal, off_act, off_ctl, off_new, total
 
 
-def block_views(buf, E: int, obs_bytes: int, workers: int):
-    o_obs, o_scal, o_act, o_ctl, _ = block_layout(E, obs_bytes, workers)
+def block_views(buf, E: int, obs_bytes: int, workers: int, frame_bytes: int = 0):
+    o_obs, o_scal, o_act, o_ctl, o_new, _ = block_layout(E, obs_bytes, workers, frame_bytes)
     return {"obs": np.ndarray((2, E, obs_bytes), dtype=np.uint8, buffer=buf, offset=o_obs),
-            "scal": np.ndarray((2, 6, E), dtype=np.float32, buffer=buf, offset=o_scal),
+            "scal": np.ndarray((2, N_SCAL, E), dtype=np.float32, buffer=buf, offset=o_scal),
             "act": np.ndarray((E,), dtype=np.int32, buffer=buf, offset=o_act),
-            "ctl": np.ndarray((CTL_DONE0 + max(workers, 1),), dtype=np.int64, buffer=buf, offset=o_ctl)}
+            "ctl": np.ndarray((CTL_DONE0 + max(workers, 1),), dtype=np.int64, buffer=buf, offset=o_ctl),
+            "new": np.ndarray((2, E, frame_bytes), dtype=np.uint8, buffer=buf, offset=o_new)}
 
 
 class VectorizedSingles:
@@ -129,9 +135,24 @@ class _HostSynthEnv:
 
 
 def record(buf, half, lo, k, obs, reward, terminated, truncated, info):
-    """One slice's step result into the shared buffers (views into shared memory)."""
-    buf["obs"][half, lo:lo + k] = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
+    """One slice's step result into the shared buffers (views into shared memory).
+
+    Device frame-stack mode (``buf["new"]`` has a frame size): besides the whole stack, the newest frame of every env goes into its own
+    compact array, and row 6 of the scalars says whether the stack merely ADVANCED — its older frames are byte-for-byte the previous
+    observation's newer ones (the other half of the ring: what this slice wrote one command ago).  Then the device can rebuild the stack
+    from what it already holds plus the newest frame, and only that frame has to cross PCIe; otherwise (episode boundaries, the extra
+    presses after a lost life, anything a wrapper did to the stack) the whole stack is uploaded.  The test is on the bytes, so it is exact
+    for any wrapper order."""
+    obs = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
+    buf["obs"][half, lo:lo + k] = obs
     sc = buf["scal"][half]
+    fb = buf["new"].shape[2]
+    if fb:
+        prev = buf["obs"][half ^ 1, lo:lo + k]
+        buf["new"][half, lo:lo + k] = obs[:, -fb:]
+        sc[6, lo:lo + k] = (obs[:, :-fb] == prev[:, fb:]).all(axis=1).astype(np.float32)
+    else:
+        sc[6, lo:lo + k] = 0.0
     sc[0, lo:lo + k] = np.asarray(reward, dtype=np.float32)
     sc[1, lo:lo + k] = np.asarray(terminated, dtype=np.float32)
     sc[2, lo:lo + k] = np.asarray(truncated, dtype=np.float32)
@@ -145,17 +166,21 @@ def record(buf, half, lo, k, obs, reward, terminated, truncated, info):
             sc[5, lo + i] = float(info["final_info"][i]["episode"]["r"][0])
 
 
-
-def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us):
+def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us, frame_bytes=0, busy_us=500.0):
     shm = shared_memory.SharedMemory(name=shm_name)
-    buf = block_views(shm.buf, E, obs_bytes, workers)
+    buf = block_views(shm.buf, E, obs_bytes, workers, frame_bytes)
     ctl = buf["ctl"]
     env = make_slice(lo, k)
     seen = 0
-    parent, spins = os.getppid(), 0
+    parent, spins, busy_until = os.getppid(), 0, 0.0
     try:
         while True:
-            while int(ctl[CTL_SEQ]) == seen:                 # the sequence number arrives by DMA (steps) or from the parent (reset / close)
+            # the sequence number arrives by DMA (steps) or from the parent (reset / close).  Inside a rollout the next command follows
+            # within a few hundred microseconds (one actor step on the GPU + the upload): poll without sleeping for busy_us after each
+            # command — a sleep costs ~60 us of timer slack per step, a sixth of the step — and fall back to sleeping between rollouts.
+            while int(ctl[CTL_SEQ]) == seen:
+                if time.perf_counter() < busy_until:
+                    continue
                 time.sleep(spin_us * 1e-6)
                 spins += 1
                 if (spins & 0x3FFF) == 0 and os.getppid() != parent:
@@ -171,6 +196,7 @@ def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us):
             else:
                 record(buf, half, lo, k, *env.step(buf["act"][lo:lo + k].copy()))
             ctl[CTL_DONE0 + w] = seen
+            busy_until = time.perf_counter() + busy_us * 1e-6
     finally:
         env.close()
         ctl[CTL_DONE0 + w] = -1

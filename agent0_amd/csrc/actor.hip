@@ -104,3 +104,29 @@ extern "C" int a0_actor_nstep(int E, int n, long long steps, double gamma, const
                        life_loss, ring_act, ring_rew, ring_done, out_act, out_rew, out_done, ctrl);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_nstep");
 }
+
+// Device frame stack of the host-environment front-end.  The reference stacks frames on the host (gymnasium
+// FrameStack, atari_wrappers.py:63) and copies the whole (E, 4, 84, 84) batch to the device every step (agent.py:27); here only the
+// newest frame of an env crosses PCIe when its stack merely advanced, and the stack is rebuilt from the previous observation the
+// device already holds:  out[e] = prev[e][1:] ‖ newest[e]  where advance[e] != 0.  Rows with advance[e] == 0 were uploaded whole.
+__global__ __launch_bounds__(256) void a0_frame_stack_kernel(const uint4* __restrict__ prev, const uint4* __restrict__ newest, const float* __restrict__ advance,
+                                                              uint4* __restrict__ out, int nstack, int fv) {
+    const int e = blockIdx.y;
+    if (advance[e] == 0.f) return;
+    const int keep = (nstack - 1) * fv, total = nstack * fv;
+    const uint4* p = prev + (long long)e * total + fv;
+    const uint4* n = newest + (long long)e * fv;
+    uint4* o = out + (long long)e * total;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) o[i] = i < keep ? p[i] : n[i - keep];
+}
+
+extern "C" int a0_env_frame_stack(const uint8_t* prev, const uint8_t* newest, const float* advance, uint8_t* out, int E, int nstack, long long frame_bytes,
+                                  void* stream) {
+    if (!prev || !newest || !advance || !out || prev == out || E < 1 || nstack < 2 || frame_bytes < 16 || (frame_bytes % 16) ||
+        ((((uintptr_t)prev) | ((uintptr_t)newest) | ((uintptr_t)out)) % 16))
+        return a0_fail(A0_EINVAL, "a0_env_frame_stack: bad argument (frames of a multiple of 16 bytes, 16-byte aligned, out != prev)");
+    const int fv = (int)(frame_bytes / 16);
+    int gx = (nstack * fv + 255) / 256; if (gx > 4) gx = 4;
+    hipLaunchKernelGGL(a0_frame_stack_kernel, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, (const uint4*)prev, (const uint4*)newest, advance, (uint4*)out, nstack, fv);
+    return a0_fail_hip((int)hipGetLastError(), "a0_env_frame_stack");
+}

@@ -458,6 +458,11 @@ class HipOps:
                                       _req(out_act, torch.int32, E, "out_act"), _req(out_rew, torch.float32, E, "out_rew"), _req(out_done, torch.float32, E, "out_done"),
                                       _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_actor_nstep")
 
+    def env_frame_stack(self, prev, newest, advance, out, E, nstack, frame_bytes):
+        check(self.lib.a0_env_frame_stack(_req(prev, torch.uint8, E * nstack * frame_bytes, "prev"), _req(newest, torch.uint8, E * frame_bytes, "newest"),
+                                          _req(advance, torch.float32, E, "advance"), _req(out, torch.uint8, E * nstack * frame_bytes, "out"), E, nstack,
+                                          frame_bytes, _stream()), "a0_env_frame_stack")
+
     def rng_uniform(self, seed, stream_id, offset, out, n):
         check(self.lib.a0_rng_uniform(seed, stream_id, offset, _req(out, torch.float32, n, "out"), n, _stream()), "a0_rng_uniform")
 

@@ -277,6 +277,13 @@ int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* actio
                    const float* truncated, const float* life_loss, int* ring_act, float* ring_rew, float* ring_done,
                    int* out_act, float* out_rew, float* out_done, const long long* ctrl, void* stream);
 
+/* Device frame stack for host environments.  Replaces gymnasium FrameStack's host-side stacking plus the
+ * per-step upload of the whole (E, nstack, H, W) batch (atari_wrappers.py:63, agent.py:27): out[e] = prev[e][1:] || newest[e] for envs
+ * with advance[e] != 0 (their stack moved on by exactly one frame); rows with advance[e] == 0 are left untouched (uploaded whole).
+ * prev / out: [E][nstack][frame_bytes] u8, newest: [E][frame_bytes]; frame_bytes a multiple of 16, pointers 16-byte aligned. */
+int a0_env_frame_stack(const uint8_t* prev, const uint8_t* newest, const float* advance, uint8_t* out, int E, int nstack, long long frame_bytes,
+                       void* stream);
+
 /* ---------------------------------------------------------------- device RNG + synthetic env (no reference counterpart) */
 int a0_rng_u32(unsigned long long seed, unsigned int stream_id, unsigned long long offset, unsigned int* out, long long n, void* stream);
 int a0_rng_uniform(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float* out, long long n, void* stream);

@@ -11,3 +11,51 @@ def _synth(seed, rank, e0, k):
 def synth_slice(seed=42, rank=0):
     """envs [e0, e0 + k) of the oracle's CPU twin of the synthetic vector env."""
     return functools.partial(_synth, seed, rank)
+
+
+class ScriptedStack:
+    """A vector env over envs [e0, e0 + k) whose (4, 84, 84) frame stacks change in every way a wrapper stack can produce: most steps
+    append one frame, some append two (the stack jumps), some replace the whole stack (episode boundary).  Frames are a pure function
+    of (seed, env, step), so any process can rebuild the expected observations."""
+
+    def __init__(self, seed, e0, k):
+        import numpy as np
+        self.np, self.seed, self.e0, self.k, self.t = np, seed, e0, k, 0
+        self.obs = np.zeros((k, 4, 84, 84), dtype=np.uint8)
+
+    def frame(self, e, t, j=0):
+        return self.np.random.default_rng([self.seed, e, t, j]).integers(0, 256, (84, 84), dtype=self.np.uint8)
+
+    @staticmethod
+    def mode(e, t):
+        return (t + 3 * e) % 7        # 0: whole new stack, 3: two new frames, else one
+
+    def reset(self, **kw):
+        self.t = 0
+        for i in range(self.k):
+            self.obs[i] = self.frame(self.e0 + i, 0)[None]
+        return self.obs.copy(), {}
+
+    def step(self, action):
+        np = self.np
+        self.t += 1
+        for i in range(self.k):
+            e = self.e0 + i
+            m = self.mode(e, self.t)
+            if m == 0:
+                self.obs[i] = np.stack([self.frame(e, self.t, j) for j in range(4)])
+            elif m == 3:
+                self.obs[i, :2] = self.obs[i, 2:].copy()
+                self.obs[i, 2], self.obs[i, 3] = self.frame(e, self.t, 0), self.frame(e, self.t, 1)
+            else:
+                self.obs[i, :3] = self.obs[i, 1:].copy()
+                self.obs[i, 3] = self.frame(e, self.t)
+        z = np.zeros(self.k)
+        return self.obs.copy(), z, z.astype(bool), z.astype(bool), {"life_loss": z.astype(bool)}
+
+    def close(self):
+        pass
+
+
+def scripted_slice(seed=5):
+    return functools.partial(ScriptedStack, seed)

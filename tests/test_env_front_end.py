@@ -141,3 +141,29 @@ def test_atari_slice_builds_the_reference_pipeline_from_gymnasium(monkeypatch):
     assert seen_life and set(np.unique(rew)) <= {-1.0, 0.0, 1.0}
     no_life = AtariSlice("Breakout", episode_life=False)(0, 1)
     assert type(no_life.envs[0].env).__name__ == "Stack", "without episode_life the life-loss wrapper is left out (atari_wrappers.py:64)"
+
+
+def test_record_marks_envs_whose_stack_merely_advanced():
+    """Device frame-stack mode of the shared block: the newest frame of every env is written to its own array and scalar row 6 is 1 exactly
+    for envs whose older frames equal the previous observation's newer ones (byte test — independent of the wrapper order)."""
+    import host_slices
+    from agent0_amd.common.host_envs import N_SCAL, block_layout, block_views, record
+    E, ob, fb = 5, 4 * 84 * 84, 84 * 84
+    total = block_layout(E, ob, 1, fb)[-1]
+    buf = block_views(bytearray(total), E, ob, 1, fb)
+    assert buf["scal"].shape == (2, N_SCAL, E) and buf["new"].shape == (2, E, fb)
+    env = host_slices.ScriptedStack(5, 0, E)
+    obs, _ = env.reset()
+    buf["obs"][0] = obs.reshape(E, -1)                  # what a worker writes on CMD_RESET (sequence number 0 -> half 0)
+    for t in range(1, 9):
+        half = t & 1
+        out = env.step(None)
+        record(buf, half, 0, E, *out)
+        assert np.array_equal(buf["obs"][half].reshape(E, 4, 84, 84), out[0])
+        assert np.array_equal(buf["new"][half].reshape(E, 84, 84), out[0][:, 3])
+        want = [0.0 if host_slices.ScriptedStack.mode(e, t) in (0, 3) else 1.0 for e in range(E)]
+        assert buf["scal"][half, 6].tolist() == want
+    # without the newest-frame array the flag is never set (whole stacks are uploaded)
+    plain = block_views(bytearray(block_layout(E, ob, 1)[-1]), E, ob, 1)
+    record(plain, 1, 0, E, *env.step(None))
+    assert plain["new"].shape[2] == 0 and not plain["scal"][1, 6].any()

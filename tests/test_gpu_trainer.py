@@ -224,8 +224,36 @@ def test_checkpoint_roundtrip_and_modes(tmp_path):
     assert np.array_equal(v[:, :, 0], v[:, :, 1]) and np.array_equal(v[:, :, 0], v[:, :, 2])
 
 
-@pytest.mark.parametrize("workers", [0, 3])
-def test_host_env_pool_matches_device_env(workers):
+@pytest.mark.parametrize("workers", [0, 2])
+def test_host_env_pool_device_frame_stack_is_exact(workers):
+    """N1, device frame stack: only the newest frame of an env crosses PCIe when its stack advanced by one frame; stacks that changed in any
+    other way (two new frames, a whole new stack) are uploaded whole.  The device observation must equal the host one byte for byte at
+    every step, and the number of whole-stack uploads must be exactly the number of such events of the scripted env."""
+    import host_slices
+    from agent0_amd.common.env_pool import HostEnvPool
+    from agent0_amd.ops import HipOps
+    E, T = 6, 20
+    pool = HostEnvPool(host_slices.scripted_slice(5), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=HipOps(), newest_frame=True)
+    ref = host_slices.ScriptedStack(5, 0, E)
+    try:
+        obs, _ = pool.reset()
+        want, _ = ref.reset()
+        assert np.array_equal(obs.cpu().numpy().reshape(E, 4, 84, 84), want)
+        act = torch.zeros(E, dtype=torch.int32, device="cuda")
+        events = 0
+        for t in range(1, T + 1):
+            obs = pool.step(act)[0]
+            want = ref.step(None)[0]
+            assert np.array_equal(obs.cpu().numpy().reshape(E, 4, 84, 84), want), f"step {t}"
+            events += sum(host_slices.ScriptedStack.mode(e, t) in (0, 3) for e in range(E))
+        assert 0 < events < T * E and pool.full_uploads == events
+        assert pool.pcie_bytes_per_step < E * 28224 // 3
+    finally:
+        pool.close()
+
+
+@pytest.mark.parametrize("workers,newest", [(0, True), (3, True), (3, False)])
+def test_host_env_pool_matches_device_env(workers, newest):
     """N1: HOST environments behind env_pool.HostEnvPool feed the same device pipeline — worker processes (3 workers over 8 envs: slices
     of 3 / 2 / 3) or in-process stepping (0) write into the page-locked double-buffered ring, observations arrive over the copy stream,
     actions reach the workers by DMA.  With the oracle's CPU twin of the synthetic env inside the workers, the replay contents, episode
@@ -242,7 +270,8 @@ def test_host_env_pool_matches_device_env(workers):
         model = DeepQNet(cfg)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec("dqn", 4), 11).items()})
         replay = ReplayDataset(cfg, ops=model.ops)
-        envs = HostEnvPool(host_slices.synth_slice(cfg.seed, 0), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops) if host else None
+        envs = HostEnvPool(host_slices.synth_slice(cfg.seed, 0), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops,
+                           newest_frame=newest) if host else None
         actor = Actor(cfg, model, replay=replay, rank=0, envs=envs)
         rs_all, qs_all = [], []
         for _ in range(5):

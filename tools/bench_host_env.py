@@ -1,7 +1,7 @@
 """PCIe-inclusive throughput of the host-environment front-end (env_pool.HostEnvPool) on BASELINE configs[1]'s shapes: 256 envs x 80 steps
 per rollout, Breakout dqn, observations stepped on the host by worker processes, uploaded through the page-locked ring.  Prints one JSON
 line: actor-only env-frames/s, the full iteration (rollout + 20 updates of batch 512) and the bytes that cross PCIe per step.
-usage: python tools/bench_host_env.py [workers] [iterations]"""
+usage: python tools/bench_host_env.py [workers] [iterations] [device_frame_stack 1|0]"""
 import json
 import os
 import sys
@@ -19,21 +19,24 @@ from agent0_amd.deepq.trainer import Trainer
 def main():
     workers = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    newest = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
     cfg = parse_overrides(["env_id=Breakout", "actor.num_envs=256", "replay.size=100000", "learner.batch_size=512", "wandb=false", "tb=false",
                            f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}"])
     cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
     tr = Trainer(cfg)
-    pool = HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops)
+    pool = HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops, newest_frame=newest)
     tr.actors[1] = agents.Actor(cfg, tr.learner.model, replay=tr.replay, ops=tr.ops, rank=0, envs=pool)
     start = cfg.trainer.training_start_steps
     cfg.trainer.training_start_steps = 1 << 62
     tr.run_iteration()
     torch.cuda.synchronize()
-    t0 = time.time()
+    t0, whole0 = time.time(), pool.full_uploads
     for _ in range(iters):
         tr.run_iteration()
     torch.cuda.synchronize()
     t_act = (time.time() - t0) / iters
+    whole = (pool.full_uploads - whole0) / (iters * cfg.actor.sample_steps)
+    per_step = pool.pcie_bytes_per_step + whole * pool.obs_bytes
     cfg.trainer.training_start_steps = 1000
     for _ in range(3):
         tr.run_iteration()
@@ -45,9 +48,10 @@ def main():
     t_full = (time.time() - t0) / iters
     n = cfg.actor.sample_steps * cfg.actor.num_envs
     print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "host_cores": os.cpu_count(),
+                      "device_frame_stack": pool.newest_frame, "whole_stack_uploads_per_step": round(whole, 3),
                       "actor_only_env_frames_per_sec": round(n / t_act, 1), "actor_only_ms_per_rollout": round(1e3 * t_act, 2),
                       "iteration_env_frames_per_sec": round(n / t_full, 1), "iteration_ms": round(1e3 * t_full, 2),
-                      "pcie_bytes_per_step": pool.pcie_bytes_per_step, "pcie_GBps_at_actor_rate": round(pool.pcie_bytes_per_step * cfg.actor.sample_steps / t_act / 1e9, 2)}))
+                      "pcie_bytes_per_step": round(per_step), "pcie_GBps_at_actor_rate": round(per_step * cfg.actor.sample_steps / t_act / 1e9, 2)}))
     pool.close()
 
 
