@@ -120,6 +120,7 @@ A0_D float a0_f4_get(const a0_f4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y
 template <int OWC>
 struct EpiFwd {                 // y = relu(acc + bias[n]) -> LDS image [oh][ow][n] (pitch / row pitch) and / or global [m][n]
     static constexpr bool PER_ELEM = false;
+    static constexpr bool TR = false;
     const float* bias; float* lds; int pitch, rp, ow; float* glb; int N;
     A0_D float pre_col(int n) const { return bias[n]; }
     A0_D float pre_elem(int, int) const { return 0.f; }
@@ -151,6 +152,7 @@ struct EpiFwd {                 // y = relu(acc + bias[n]) -> LDS image [oh][ow]
 template <int OW, int S>
 struct EpiBwd {                 // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, ow*S + pw) of a Wfull-wide NHWC image; optional padded LDS image
     static constexpr bool PER_ELEM = true;
+    static constexpr bool TR = false;
     static constexpr bool ROW4 = false;
     A0_D void emit4(int, int, const a0_acc4&, float) const {}
     const float* mask; float* dst; float* lds; int pitch, rp, Wfull, ph, pw, N;
@@ -166,25 +168,43 @@ struct EpiBwd {                 // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, 
 
 // What a layer's epilogue needs from global memory, in the wave's tile layout.  Loaded well ahead of the layer (kernel start, or the
 // previous layer's `between` slot) so that its latency is never waited for on its own.
+// Epilogues with TR = true receive TRANSPOSED accumulators (the split-operand stages issue their MFMAs with the operands swapped, weights
+// as A and activations as B): a lane then holds four consecutive output CHANNELS n0 .. n0+3 (n0 = 4 * (lane >> 4) within the 16-column
+// block) of ONE output position m = lane & 15, instead of four positions of one channel — so one bf16 term of its four values is a
+// single 8-byte LDS write (was four 2-byte writes), its fp32 values one 16-byte global store, and a ReLU mask one 16-byte load.
 template <int N, int WN, int MBW, class EPI>
 struct a0_pre {
     static constexpr int NBW = N / 16 / WN, WMG = A0_FUSED_WAVES / WN;
-    float pc[NBW], pe[EPI::PER_ELEM ? MBW : 1][NBW][4];
+    float pc[NBW][EPI::TR ? 4 : 1], pe[EPI::PER_ELEM ? MBW : 1][NBW][4];
     A0_D void load(const EPI& epi, int M) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int wn = wave % WN, wmg = wave / WN, q = lane >> 4, r16 = lane & 15;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
-            const int n = (wn * NBW + j) * 16 + r16;
-            pc[j] = epi.pre_col(n);
-            if (EPI::PER_ELEM) {
+            if constexpr (EPI::TR) {
+                const int n0 = (wn * NBW + j) * 16 + 4 * q;
 #pragma unroll
-                for (int i = 0; i < MBW; ++i)
+                for (int r = 0; r < 4; ++r) pc[j][r] = epi.pre_col(n0 + r);
+                if constexpr (EPI::PER_ELEM) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = (wmg + i * WMG) * 16 + 4 * q + r;
-                        pe[EPI::PER_ELEM ? i : 0][j][r] = epi.pre_elem(m < M ? m : M - 1, n);
+                    for (int i = 0; i < MBW; ++i) {
+                        const int m = (wmg + i * WMG) * 16 + r16;
+                        const a0_f4 v = epi.pre_elem4(m < M ? m : M - 1, n0);
+                        pe[i][j][0] = v.x; pe[i][j][1] = v.y; pe[i][j][2] = v.z; pe[i][j][3] = v.w;
                     }
+                }
+            } else {
+                const int n = (wn * NBW + j) * 16 + r16;
+                pc[j][0] = epi.pre_col(n);
+                if constexpr (EPI::PER_ELEM) {
+#pragma unroll
+                    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = (wmg + i * WMG) * 16 + 4 * q + r;
+                            pe[i][j][r] = epi.pre_elem(m < M ? m : M - 1, n);
+                        }
+                }
             }
         }
     }
@@ -269,7 +289,7 @@ A0_D void a0_conv_stage(const AF& af, int M, int K, a0_wring<N, WN, R>& ring, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mb * 16 + 4 * q + r;
-                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j][r] : pre.pc[j]);
+                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j][r] : pre.pc[j][0]);
                 }
             }
         }
@@ -357,7 +377,8 @@ A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0
                 for (int i = 0; i < MBW; ++i) {
                     const a0_u32x4 av = {a[u & 1][i][0].x, a[u & 1][i][0].y, a[u & 1][i][1].x, a[u & 1][i][1].y};
                     const a0_u32x4 bv = {ring.v[u][s].x, ring.v[u][s].y, ring.v[u][s].z, ring.v[u][s].w};
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i], 0, 0, 0);
+                    if constexpr (EPI::TR) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[i], 0, 0, 0);
+                    else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
             ring.fill(u);
@@ -369,14 +390,19 @@ A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0
     for (int i = 0; i < MBW; ++i) {
         const int mb = wmg + i * A0_WMG1;
         if (mb < MB) {
-            const int n = wn * 16 + r16;
-            if (EPI::ROW4 && mb * 16 + 16 <= M) {
-                epi.emit4(mb * 16 + 4 * q, n, acc[i], pre.pc[0]);
+            if constexpr (EPI::TR) {
+                const int m = mb * 16 + r16;
+                if (m < M) epi.emit_n4(m, wn * 16 + 4 * q, acc[i], pre.pc[0]);
             } else {
+                const int n = wn * 16 + r16;
+                if (EPI::ROW4 && mb * 16 + 16 <= M) {
+                    epi.emit4(mb * 16 + 4 * q, n, acc[i], pre.pc[0][0]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mb * 16 + 4 * q + r;
-                    if (m < M) epi.emit(m, n, acc[i][r], pre.pc[0]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb * 16 + 4 * q + r;
+                        if (m < M) epi.emit(m, n, acc[i][r], pre.pc[0][0]);
+                    }
                 }
             }
         }
@@ -432,26 +458,53 @@ struct AF3X {   // conv3 3x3/1 over act2 planes [pixel][P]; MFMA step = half (32
     A0_D int row(int m) const { const int oh = m / W3, ow = m - oh * W3; return oh * RP + ow * P; }
     A0_D int step_off(int st) const { const int tap = st >> 1; return (tap / 3) * RP + (tap % 3) * P + 32 * (st & 1); }
 };
+// exact three-term bf16 split of four fp32 values, packed: hi / mid / lo as four bf16 (8 bytes) each
+A0_D void a0_split4(const float (&v)[4], uint2& hi, uint2& mid, uint2& lo) {
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h[r] = __float_as_uint(v[r]);
+        const float r1 = v[r] - __uint_as_float(h[r] & 0xffff0000u);          // exact: at most 16 significant bits left
+        m[r] = __float_as_uint(r1);
+        l[r] = __float_as_uint(r1 - __uint_as_float(m[r] & 0xffff0000u));      // exact: at most 8 significant bits left
+    }
+    hi = uint2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};      // v_perm_b32: the upper halves side by side (the truncation itself)
+    mid = uint2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    lo = uint2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
 template <int OWC, int P, int RP, int term>
-struct EpiFwdX {            // y = relu(acc + bias[n]) -> three bf16 planes in LDS [term][oh][ow][P], image rows RP apart (+ fp32 to global [m][N])
+struct EpiFwdX {            // y = relu(acc + bias[n]) -> three bf16 planes in LDS [term][oh][ow][P], image rows RP apart (+ fp32 to global [m][N]); transposed accumulators
     static constexpr bool PER_ELEM = false;
     static constexpr bool ROW4 = false;
-    static_assert(OWC > 0, "output width known at compile time");
-    const float* bias; uint16_t* planes; float* glb; int N;
-    A0_D float pre_col(int n) const { return bias[n]; }
-    A0_D float pre_elem(int, int) const { return 0.f; }
-    A0_D void emit4(int, int, const a0_acc4&, float) const {}
-    A0_D void emit(int m, int n, float acc, float pre) const {
-        float v = acc + pre;
-        v = (v < 0.f) ? 0.f : v;
-        if (glb) glb[(unsigned)(m * N + n)] = v;
-        const uint32_t h = __float_as_uint(v) >> 16;
-        const float r1 = v - __uint_as_float(h << 16);
-        const uint32_t mi = __float_as_uint(r1) >> 16;
-        const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mi << 16)) >> 16;
+    static constexpr bool TR = true;
+    static_assert(OWC > 0 && (P % 4) == 0 && (RP % 4) == 0 && (term % 4) == 0, "output width known at compile time; 8-byte aligned plane writes");
+    const float* bias; uint16_t* planes; float* glb; int N;          // bias: the workgroup's LDS copy (one 16-byte read per block; kept in registers across the launch the biases cost 12 VGPRs the kernel does not have)
+    A0_D float pre_col(int) const { return 0.f; }
+    A0_D void emit_n4(int m, int n0, const a0_acc4& acc, const float*) const {       // channels n0 .. n0+3 of output position m
+        const a0_f4 bv = *(const a0_f4*)(bias + n0);
+        float v[4] = {acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] < 0.f) ? 0.f : v[r];
+        if (glb) *(a0_f4*)(glb + (unsigned)(m * N + n0)) = a0_f4{v[0], v[1], v[2], v[3]};
+        uint2 hi, mid, lo;
+        a0_split4(v, hi, mid, lo);
         const int oh = m / OWC;
-        uint16_t* d = planes + oh * RP + (m - oh * OWC) * P + n;
-        d[0] = (uint16_t)h; d[term] = (uint16_t)mi; d[2 * term] = (uint16_t)lo;
+        uint16_t* d = planes + oh * RP + (m - oh * OWC) * P + n0;
+        *(uint2*)d = hi; *(uint2*)(d + term) = mid; *(uint2*)(d + 2 * term) = lo;
+    }
+};
+struct EpiFwdT {            // y = relu(acc + bias[n]) -> fp32 global [m][N] (conv3 of the split-operand path); transposed accumulators
+    static constexpr bool PER_ELEM = false;
+    static constexpr bool ROW4 = false;
+    static constexpr bool TR = true;
+    const float* bias; float* glb; int N;          // bias: LDS copy, as in EpiFwdX
+    A0_D float pre_col(int) const { return 0.f; }
+    A0_D void emit_n4(int m, int n0, const a0_acc4& acc, const float*) const {
+        const a0_f4 bv = *(const a0_f4*)(bias + n0);
+        float v[4] = {acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] < 0.f) ? 0.f : v[r];
+        *(a0_f4*)(glb + (unsigned)(m * N + n0)) = a0_f4{v[0], v[1], v[2], v[3]};
     }
 };
 
@@ -502,7 +555,8 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
                             if (ta + tw > A0_X9_MAXORD) continue;      // see A0_X9_MAXORD
                             const a0_u32x4 av = {a[u & 1][i][ta].x, a[u & 1][i][ta].y, a[u & 1][i][ta].z, a[u & 1][i][ta].w};
                             const a0_u32x4 bv = {ring.v[u][jn][tw].x, ring.v[u][jn][tw].y, ring.v[u][jn][tw].z, ring.v[u][jn][tw].w};
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i][jn], 0, 0, 0);
+                            if constexpr (EPI::TR) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[i][jn], 0, 0, 0);
+                            else acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i][jn], 0, 0, 0);
                         }
             __builtin_amdgcn_sched_barrier(0);
             ring.fill(u);
@@ -514,13 +568,21 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
     for (int i = 0; i < MBW; ++i) {
         const int mb = wmg + i * WMG;
         if (mb < MB) {
+            if constexpr (EPI::TR) {
+                const int m = mb * 16 + r16;
+                if (m < M) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) {
-                const int n = (wn * NBW + j) * 16 + r16;
+                    for (int j = 0; j < NBW; ++j) epi.emit_n4(m, (wn * NBW + j) * 16 + 4 * q, acc[i][j], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j] : pre.pc[j]);
+                }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mb * 16 + 4 * q + r;
-                    if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j][r] : pre.pc[j]);
+                for (int j = 0; j < NBW; ++j) {
+                    const int n = (wn * NBW + j) * 16 + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb * 16 + 4 * q + r;
+                        if (m < M) epi.emit(m, n, acc[i][j][r], EPI::PER_ELEM ? pre.pe[EPI::PER_ELEM ? i : 0][j][r] : pre.pc[j][0]);
+                    }
                 }
             }
         }
@@ -560,6 +622,12 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encode
 
 // Split-operand variant (84 x 84 geometry): all three layers on the bf16 pipe.  LDS: bf16 image [0, 56 448), act1 term planes behind it;
 // the act2 term planes reuse the image's bytes (the image is dead once conv1 has finished).
+#ifdef A0_EXP_ALIAS
+constexpr int A0_X9_BIAS_OFF = (2 * 10 + 20) * A0_RP1X * 2;
+#else
+constexpr int A0_X9_BIAS_OFF = 2 * 4 * 84 * 84 + 3 * 20 * A0_RP1X * 2;      // bf16 image + act1 term planes
+#endif
+constexpr int A0_X9_LDS_BYTES = A0_X9_BIAS_OFF + 160 * 4;
 template <int MBW1, int MBW2, int MBW3>
 A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -593,12 +661,11 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     ring1.prologue();
     constexpr int MBW1X = (25 + A0_WMG1 - 1) / A0_WMG1;
     static_assert(A0_FUSED_WAVES != 8 || MBW1X == MBW1, "84x84 geometry");
-    a0_pre<32, 2, MBW1X, E1X> pre1;
+    a0_pre<32, 2, MBW1X, E1X> pre1;           // (empty: these epilogues take nothing from global memory)
     a0_pre<64, WNX, MBW2X, E2X> pre2;
-    a0_pre<64, WNX, MBW3X, EpiFwd<0>> pre3;
-    pre1.load(E1X{P.b1, nullptr, nullptr, 32}, M1);
-    pre2.load(E2X{P.b2, nullptr, nullptr, 64}, M2);
-    pre3.load(EpiFwd<0>{P.b3, nullptr, 0, 0, 1, nullptr, 64}, M3);
+    a0_pre<64, WNX, MBW3X, EpiFwdT> pre3;
+    float* bias_lds = (float*)(smem + A0_X9_BIAS_OFF);      // b1 | b2 | b3 behind the activation planes; visible after the first barrier below
+    if (threadIdx.x < 160) bias_lds[threadIdx.x] = threadIdx.x < 32 ? P.b1[threadIdx.x] : threadIdx.x < 96 ? P.b2[threadIdx.x - 32] : P.b3[threadIdx.x - 96];
     // the pad channels (32..39 / 64..71) of the term planes are never read; nothing to initialise
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
         const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
@@ -630,14 +697,14 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
             }
         }
         __syncthreads();
-        const E1X e1{P.b1, a1p, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
+        const E1X e1{bias_lds, a1p, P.act1 ? P.act1 + (long long)b * M1 * 32 : nullptr, 32};
         const int wmg1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / 2;
         if (MBW1X > 1 && wmg1 + (MBW1X - 1) * A0_WMG1 >= ((M1 + 15) >> 4))
             a0_conv1_stage<(MBW1X > 1 ? MBW1X - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
             a0_conv1_stage<MBW1X, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         const AF2X<term1> f2{a1p, A0_RP1X, P.W2, A0_P1X};
-        const E2X e2{P.b2, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
+        const E2X e2{bias_lds + 32, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
         const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
         constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
         if (uneven2 && wmgx + (MBW2X - 1) * WMGX >= 6)
@@ -645,7 +712,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
         else
             a0_conv_stage_x9<64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
         const AF3X<term2> f3{a2p, A0_RP2X, P.W3, A0_P2X};
-        const EpiFwd<0> e3{P.b3, nullptr, 0, 0, 1, P.act3 + (long long)b * M3 * 64, 64};
+        const EpiFwdT e3{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
         if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
             a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
         else
@@ -821,23 +888,37 @@ struct AFD2X {   // 2x2 taps over the d2pad planes; output 10 wide
     A0_D int row(int m) const { const int oh = m / 10, ow = m - oh * 10; return oh * A0_RPDB + ow * A0_P2X; }
     A0_D int step_off(int st) const { const int cell = st >> 1; return (cell >> 1) * A0_RPDB + (cell & 1) * A0_P2X + 32 * (st & 1); }
 };
-struct EpiBwd3X {               // d2 = act2 > 0 ? acc : 0 -> global [81][64] and, split into three bf16 terms, the interior of the d2pad planes
+struct EpiBwd3X {               // d2 = act2 > 0 ? acc : 0 -> global [81][64] and, split into three bf16 terms, the interior of the d2pad planes; transposed accumulators
     static constexpr bool PER_ELEM = true;
     static constexpr bool ROW4 = false;
-    A0_D void emit4(int, int, const a0_acc4&, float) const {}
+    static constexpr bool TR = true;
     const float* mask; float* dst; uint16_t* planes;
     A0_D float pre_col(int) const { return 0.f; }
-    A0_D float pre_elem(int m, int n) const { return mask[(unsigned)(m * 64 + n)]; }
-    A0_D void emit(int m, int n, float acc, float pre) const {
-        const float v = pre > 0.f ? acc : 0.f;
-        dst[(unsigned)(m * 64 + n)] = v;
+    A0_D a0_f4 pre_elem4(int m, int n0) const { return *(const a0_f4*)(mask + (unsigned)(m * 64 + n0)); }
+    A0_D void emit_n4(int m, int n0, const a0_acc4& acc, const float* pre) const {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = pre[r] > 0.f ? acc[r] : 0.f;
+        *(a0_f4*)(dst + (unsigned)(m * 64 + n0)) = a0_f4{v[0], v[1], v[2], v[3]};
+        uint2 hi, mid, lo;
+        a0_split4(v, hi, mid, lo);
         const int oh = m / 9, ow = m - oh * 9;
-        const uint32_t h = __float_as_uint(v) >> 16;
-        const float r1 = v - __uint_as_float(h << 16);
-        const uint32_t mi = __float_as_uint(r1) >> 16;
-        const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mi << 16)) >> 16;
-        uint16_t* d = planes + (oh + 1) * A0_RPDB + (ow + 1) * A0_P2X + n;
-        d[0] = (uint16_t)h; d[A0_DTERMB] = (uint16_t)mi; d[2 * A0_DTERMB] = (uint16_t)lo;
+        uint16_t* d = planes + (oh + 1) * A0_RPDB + (ow + 1) * A0_P2X + n0;
+        *(uint2*)d = hi; *(uint2*)(d + A0_DTERMB) = mid; *(uint2*)(d + 2 * A0_DTERMB) = lo;
+    }
+};
+static_assert((A0_RPDB % 4) == 0 && (A0_DTERMB % 4) == 0 && (A0_P2X % 4) == 0, "8-byte aligned plane writes");
+template <int OW, int S>
+struct EpiBwdT {                // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, ow*S + pw) of a Wfull-wide NHWC image in global memory; transposed accumulators
+    static constexpr bool PER_ELEM = true;
+    static constexpr bool ROW4 = false;
+    static constexpr bool TR = true;
+    const float* mask; float* dst; int Wfull, ph, pw, N;
+    A0_D unsigned gi(int m, int n) const { const int oh = m / OW, ow = m - oh * OW; return (unsigned)(((oh * S + ph) * Wfull + ow * S + pw) * N + n); }
+    A0_D float pre_col(int) const { return 0.f; }
+    A0_D a0_f4 pre_elem4(int m, int n0) const { return *(const a0_f4*)(mask + gi(m, n0)); }
+    A0_D void emit_n4(int m, int n0, const a0_acc4& acc, const float* pre) const {
+        *(a0_f4*)(dst + gi(m, n0)) = a0_f4{pre[0] > 0.f ? acc[0] : 0.f, pre[1] > 0.f ? acc[1] : 0.f, pre[2] > 0.f ? acc[2] : 0.f, pre[3] > 0.f ? acc[3] : 0.f};
     }
 };
 constexpr int A0_RXD3 = 6, A0_RXD2 = 4;               // 32-k steps of split weights in flight (18 and 8 steps per stage)
@@ -852,11 +933,11 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
     ring3.init(P.wd3, 576);
     ring3.prologue();
     typedef EpiBwd3X E3;
-    typedef EpiBwd<10, 2> E2;
+    typedef EpiBwdT<10, 2> E2;
     a0_pre<64, 4, 3, E3> pre3;
     a0_pre<32, 2, 2, E2> prep[2];
     auto epi3 = [&](int b) { return E3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, plB}; };
-    auto epi2 = [&](int b, int ph, int pw) { return E2{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, nullptr, 0, 0, 20, ph, pw, 32}; };
+    auto epi2 = [&](int b, int ph, int pw) { return E2{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, 20, ph, pw, 32}; };
     if ((int)blockIdx.x < P.B) pre3.load(epi3(blockIdx.x), 81);
     __syncthreads();
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
@@ -1056,10 +1137,7 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     static const bool no_x9 = getenv("A0_NO_X9") != nullptr;
     const bool x9 = standard && H == 84 && C == 4 && !no_x9;
     const int which = x9 ? 2 : (standard ? 1 : 0);
-    if (x9) lds = (size_t)2 * C * H * W + (size_t)3 * P.H1 * A0_RP1X * 2;            // image + act1 term planes (act2 planes reuse the image)
-#ifdef A0_EXP_ALIAS
-    if (x9) lds = (size_t)(2 * 10 + 20) * A0_RP1X * 2;
-#endif
+    if (x9) lds = A0_X9_LDS_BYTES;            // image + act1 term planes (act2 planes reuse the image) + the biases
     static_assert(3 * 9 * A0_RP2X * 2 <= 2 * 4 * 84 * 84, "the act2 term planes fit into the dead image");
     static size_t configured[3] = {0, 0, 0};
     const void* fn = which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
