@@ -1147,7 +1147,9 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
         configured[which] = lds;
     }
     const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
-    static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 0;       // tuning aid: persistent workgroups (each loops over b += gridDim.x)
+    // at most one workgroup per CU (152 KB of LDS each), looping over its observations (b += gridDim.x): ring / bias set-up is paid once and the
+    // next observation's conv1 weights are requested behind conv3 (-4 % per 512 observations, tools/ubench_encoder_fwd.py).  A0_ENC_GRID: tuning aid (0 = one workgroup per observation)
+    static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 256;
     const int gridx = (grid_cap > 0 && B > grid_cap) ? grid_cap : B;
     if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     else if (which == 1) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
