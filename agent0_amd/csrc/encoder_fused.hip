@@ -617,7 +617,7 @@ constexpr int A0_R1 = 4, A0_R2 = 4, A0_R3 = 6;     // conv1: 32-k steps (three 1
 #ifndef A0_FUSED_MINWAVES
 #define A0_FUSED_MINWAVES 1
 #endif
-template <int MBW1, int MBW2, int MBW3, int WC, bool X9>
+template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP = false>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P);
 
 // Split-operand variant (84 x 84 geometry): all three layers on the bf16 pipe.  LDS: bf16 image [0, 56 448), act1 term planes behind it;
@@ -628,7 +628,9 @@ constexpr int A0_X9_BIAS_OFF = (2 * 10 + 20) * A0_RP1X * 2;
 constexpr int A0_X9_BIAS_OFF = 2 * 4 * 84 * 84 + 3 * 20 * A0_RP1X * 2;      // bf16 image + act1 term planes
 #endif
 constexpr int A0_X9_LDS_BYTES = A0_X9_BIAS_OFF + 160 * 4;
-template <int MBW1, int MBW2, int MBW3>
+// LOOP: the workgroup walks over several observations (b += gridDim.x; launches of more observations than CUs) and requests the next
+// observation's conv1 weights behind conv3; without it (the actor's launches: one observation per workgroup) that request is not made.
+template <int MBW1, int MBW2, int MBW3, bool LOOP>
 A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* img = (uint16_t*)smem;
@@ -714,16 +716,17 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
         const AF3X<term2> f3{a2p, A0_RP2X, P.W3, A0_P2X};
         const EpiFwdT e3{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
         if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
-            a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
+            a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
         else
-            a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { ring1.prologue(); });
+            a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
+        if constexpr (!LOOP) break;
     }
 }
 
-template <int MBW1, int MBW2, int MBW3, int WC, bool X9>
+template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P) {
     if constexpr (X9) {
-        a0_encoder_fused_x9_body<MBW1, MBW2, MBW3>(P);
+        a0_encoder_fused_x9_body<MBW1, MBW2, MBW3, LOOP>(P);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1133,25 +1136,28 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     // 16-row blocks per wave: conv1 ceil(MB1/4), conv2 ceil(MB2/2), conv3 ceil(MB3/2); exact for 84x84, generous otherwise
     const int mb1 = (P.H1 * P.W1 + 15) / 16, mb2 = (P.H2 * P.W2 + 15) / 16, mb3 = (P.H3 * P.W3 + 15) / 16;
     const bool standard = ((mb1 + 3) / 4 == 7) && ((mb2 + 1) / 2 == 3) && ((mb3 + 1) / 2 == 2) && W == 84;
-    // three instantiations: split-operand (all layers on the bf16 pipe; 84x84, C = 4), fp32 conv2/conv3 for 84-wide inputs, generic
+    // instantiations: split-operand (all layers on the bf16 pipe; 84x84, C = 4; one observation per workgroup, or looping), fp32 conv2/conv3 for 84-wide inputs, generic
     static const bool no_x9 = getenv("A0_NO_X9") != nullptr;
     const bool x9 = standard && H == 84 && C == 4 && !no_x9;
-    const int which = x9 ? 2 : (standard ? 1 : 0);
+    int which = x9 ? 2 : (standard ? 1 : 0);
     if (x9) lds = A0_X9_LDS_BYTES;            // image + act1 term planes (act2 planes reuse the image) + the biases
     static_assert(3 * 9 * A0_RP2X * 2 <= 2 * 4 * 84 * 84, "the act2 term planes fit into the dead image");
-    static size_t configured[3] = {0, 0, 0};
-    const void* fn = which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
+    static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 256;
+    const int gridx = (which == 2 && grid_cap > 0 && B > grid_cap) ? grid_cap : B;
+    if (which == 2 && gridx < B) which = 3;                  // the looping instantiation of the split-operand kernel
+    static size_t configured[4] = {0, 0, 0, 0};
+    const void* fn = which == 3 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true, true> : which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
                    : which == 1 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, false> : (const void*)a0_encoder_fused_kernel<7, 4, 2, 0, false>;
     if (lds > configured[which]) {
         A0_HIP_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured[which] = lds;
     }
     const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
-    // at most one workgroup per CU (152 KB of LDS each), looping over its observations (b += gridDim.x): ring / bias set-up is paid once and the
-    // next observation's conv1 weights are requested behind conv3 (-4 % per 512 observations, tools/ubench_encoder_fwd.py).  A0_ENC_GRID: tuning aid (0 = one workgroup per observation)
-    static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 256;
-    const int gridx = (grid_cap > 0 && B > grid_cap) ? grid_cap : B;
-    if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    // split-operand kernel: at most one workgroup per CU (152 KB of LDS each), looping over its observations (b += gridDim.x) when there are more
+    // observations than that: ring set-up is paid once and the next observation's conv1 weights are requested behind conv3 (-4 % per 512
+    // observations, tools/ubench_encoder_fwd.py).  A0_ENC_GRID: tuning aid (0 = one workgroup per observation)
+    if (which == 3) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true, true>), dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
+    else if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     else if (which == 1) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     else hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 4, 2, 0, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     if (probed) {   // algorithmic FLOP of the three convolutions: 2 * (M1*32*K1 + M2*64*512 + M3*64*576) per observation

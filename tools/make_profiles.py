@@ -33,7 +33,8 @@ for k in list(pm):
         g = k.split(":")[1]
         cal_r, cal_w = kb(f"envcommit:{g}", "FETCH_SIZE"), kb(f"envcommit:{g}", "WRITE_SIZE")
 traffic = {
-    "kernels": "a0_encoder_fused_kernel<7,3,2,84,true> (enc), a0_encoder_dgrad_fused_x9_kernel (dgrad); a0_env_step_commit_kernel as the calibration kernel",
+    "kernels": "a0_encoder_fused_kernel<7,3,2,84,true[,true]> (enc: one observation per workgroup for the actor's 256, looping for the learner's 512), a0_encoder_dgrad_fused_x9_kernel (dgrad); "
+               "a0_env_step_commit_kernel as the calibration kernel",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
               "--no-ratio320 --no-other-entry --replay-size 100000 (tools/refresh_profiles.sh)",
     "corrections": "counter unit KB; FETCH_SIZE x2 on gfx950 (64 B counted per 128-B request on wide coalesced reads), WRITE_SIZE x1.  Calibration on "
@@ -41,7 +42,7 @@ traffic = {
                    + (f"FETCH_SIZE x2 = {2 * cal_r / 1e6:.2f} MB, WRITE_SIZE = {cal_w / 1e6:.2f} MB" if cal_r and cal_w else "not captured in this run"),
     "per_launch": {},
 }
-for n_obs, grid in ((256, 256 * 512), (512, 512 * 512)):
+for n_obs, grid in ((256, 256 * 512), (512, "loop")):       # "loop": the looping instantiation, which the bench uses for its 512-observation launches only
     r, w = kb(f"enc:{grid}", "FETCH_SIZE"), kb(f"enc:{grid}", "WRITE_SIZE")
     if r is None or w is None:
         continue
@@ -50,7 +51,7 @@ for n_obs, grid in ((256, 256 * 512), (512, 512 * 512)):
         "algorithmic_bytes_min": n_obs * (OBS + 49 * 64 * 4) + 470016,
         "note": "actor launches: observations in (7.2 MB), conv features out (3.2 MB, exact), bf16-term weights (0.47 MB, fetched once per XCD L2)" if n_obs == 256 else
                 "learner launches, average of the online pass (also stores act1/act2 for the backward pass: +36.8 MB) and the target pass (features only)"}
-r, w = kb(f"dgrad:{512 * 512}", "FETCH_SIZE"), kb(f"dgrad:{512 * 512}", "WRITE_SIZE")
+r, w = kb(f"dgrad:{256 * 512}", "FETCH_SIZE"), kb(f"dgrad:{256 * 512}", "WRITE_SIZE")        # 256 looping workgroups for 512 observations
 if r is not None and w is not None:
     traffic["dgrad_per_launch_512"] = {"hbm_read_bytes": 2 * r, "hbm_write_bytes": w,
                                        "algorithmic_bytes": {"read": 512 * (49 * 64 + 81 * 64 + 400 * 32) * 4, "write": 512 * (81 * 64 + 400 * 32) * 4}}
@@ -101,9 +102,10 @@ enc = {k.split("grid=")[1]: v for k, v in by_grid.items() if "a0_encoder_fused_k
 dg = [v for k, v in by_grid.items() if "dgrad" in k]
 FLOP = 15.47e6
 roof = bench.get("roofline") or {}
-lines += ["## Dominant kernel: `a0_encoder_fused_kernel<7,3,2,84,true>` (conv1 + conv2 + conv3 of the Nature CNN, one workgroup per observation)", ""]
-if "131072" in enc and "262144" in enc:
-    a, l = enc["131072"], enc["262144"]
+lines += ["## Dominant kernel: `a0_encoder_fused_kernel<7,3,2,84,true[,true]>` (conv1 + conv2 + conv3 of the Nature CNN per observation; one workgroup per observation for the actor's "
+          "256-observation launches, 256 looping workgroups for the learner's 512)", ""]
+if "131072" in enc and "loop" in enc:
+    a, l = enc["131072"], enc["loop"]
     mix = (80 * a["avg_us"] + 40 * l["avg_us"]) / 120
     lines += [f"* kernel trace, by launch size: 256 observations (actor) {a['avg_us']:.2f} us average over {a['launches']} launches = {256 * FLOP / a['avg_us'] / 1e6:.1f} TFLOP/s; "
               f"512 observations (learner) {l['avg_us']:.2f} us over {l['launches']} launches = {512 * FLOP / l['avg_us'] / 1e6:.1f} TFLOP/s (15.47 MFLOP per observation, counted once).",

@@ -10,6 +10,8 @@ A0_PROBE=none rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d g
 R=$R python3 - <<'PY'
 import csv, glob, collections, json, os
 R = os.environ.get("R", "r02")
+def looping(name):      # a0_encoder_fused_kernel<7, 3, 2, 84, true, true>: the last template argument
+    return name.split(">")[0].replace(" ", "").endswith("true,true")
 out = {}
 for name in ("fetch", "write"):
     for f in glob.glob(f"gpurun_out/{R}/pmc_{name}/*/*counter_collection.csv"):
@@ -17,7 +19,9 @@ for name in ("fetch", "write"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             key = "enc" if "a0_encoder_fused_kernel" in k else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else None
-            if key: acc[(key, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            gs = r["Grid_Size"]
+            if key == "enc" and looping(k): gs = "loop"          # the looping instantiation (launches of more observations than CUs: the learner's 512)
+            if key: acc[(key, gs)][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for (key, gs), d in sorted(acc.items()):
             for c, v in d.items():
                 out[f"{key}:{gs}:{c}"] = {"mean": sum(v) / len(v), "n": len(v)}
@@ -28,7 +32,7 @@ for f in glob.glob(f"gpurun_out/{R}/prof/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "a0_encoder_fused_kernel" in k or "a0_encoder_dgrad_fused" in k:
-            per[(k.split("(")[0][:48], r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            per[(k.split("(")[0][:48], "loop" if ("a0_encoder_fused_kernel" in k and looping(k)) else r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tr = {f"{k}|grid={g}": {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)} for (k, g), v in per.items()}
 json.dump(tr, open(f"gpurun_out/{R}/fused_by_grid.json", "w"), indent=1)
 print(json.dumps(tr, indent=1))
