@@ -172,3 +172,17 @@ def test_bench_starts_its_own_launcher_as_a_child(monkeypatch, capsys):
     out = capsys.readouterr()
     assert json.loads(out.out.strip())["n_gpus"] == 4 and "banner" in out.err, "exactly the JSON line on stdout, everything else on stderr"
     assert [m for m in ("agent0_amd.ops", "agent0_amd.deepq.trainer") if m in sys.modules] == gpu_stack, "the parent did not load the GPU stack"
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """build.sh records the compiler's per-kernel resource remarks (agent0_amd/lib/kernel_resources.txt).  A kernel that spills registers
+    to scratch still computes the right thing — only slower, with HBM traffic nobody asked for (round 2: ten spilled VGPRs of the fused
+    encoder showed up as 8.45 MB written per launch instead of 3.21 MB) — so nothing else would notice."""
+    import os
+    from agent0_amd import _abi
+    path = os.path.join(os.path.dirname(_abi.LIB_PATH), "kernel_resources.txt")
+    assert os.path.exists(path), "agent0_amd/csrc/build.sh writes the report next to the library"
+    rows = [dict(kv.split("=") for kv in line.split()[2:]) | {"name": line.split()[1]} for line in open(path) if line.strip()]
+    assert len(rows) > 100 and any("a0_encoder_fused_kernel" in r["name"] for r in rows)
+    bad = [r for r in rows if int(r["scratch"]) or int(r["vgpr_spill"]) or int(r["sgpr_spill"])]
+    assert not bad, f"kernels with scratch / spills: {[(r['name'], r['scratch'], r['vgpr_spill'], r['sgpr_spill']) for r in bad]}"
