@@ -542,6 +542,9 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int nxt = tb + u + 1;
+#if defined(A0_EXP_HALF_A)      // TIMING-ONLY experiment (garbage results): every other step re-uses the previous step's A fragments (half the LDS reads)
+            if (u & 1) { for (int i = 0; i < MBW; ++i) for (int t = 0; t < 3; ++t) a[(u + 1) & 1][i][t] = a[u & 1][i][t]; } else
+#endif
             fetch((u + 1) & 1, af.step_off(nxt < NST ? nxt : NST - 1));          // past the end: re-read the last step (never consumed)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -559,6 +562,9 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
                             else acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i][jn], 0, 0, 0);
                         }
             __builtin_amdgcn_sched_barrier(0);
+#if defined(A0_EXP_HALF_B)      // TIMING-ONLY experiment (garbage results): every other ring slot is never refilled (half the weight loads)
+            if (!(u & 1))
+#endif
             ring.fill(u);
             __builtin_amdgcn_sched_barrier(0);
         }
