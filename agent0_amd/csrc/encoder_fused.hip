@@ -24,6 +24,7 @@
 #include "operands.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // Cross products a_i * b_j of the three-term splits that are formed: those with i + j <= A0_X9_MAXORD.  4 = all nine (every partial product
 // of the fp32 fmaf chain, exactly) — the default.  2 = six: a1*b2, a2*b1 and a2*b2 are left out — each is below 2^-24 of a*b (|a1| <= 2^-8 |a|, |b2| <= 2^-16 |b|),
@@ -417,17 +418,18 @@ A0_D void a0_conv1_stage(const uint16_t* img, int HW, int Wrt, int W1, int M, a0
 // The sum is accumulated in fp32 like the fmaf chain; against fp64 it is as close (tools/check_bf16x9.hip: 4.8e-7 vs 3.3e-7 of the
 // scale at K = 512).  Activations live in LDS as three bf16 planes [term][pixel][channels + 8]; a lane's A fragment is the 8
 // consecutive channels 8q .. 8q+7 of one pixel: one aligned 16-byte read per term.
-template <int N, int WN, int R>
+template <int N, int WN, int R, int WK = 1>
 struct a0_wring9 {          // uint4 index ((t*N + n)*4 + q)*3 + s: the eight k = 32t + 8q .. +7 of output channel n, term s
     static constexpr int NBW = N / 16 / WN;
     uint4 v[R][NBW][3];
     const uint4* base;
     const uint4* p;
     int nst, left;
+    // WK > 1 (a0_conv_stage_x9k): the waves wave / WN = 0 .. WK-1 share the k steps round-robin; this ring walks steps wk, wk + WK, ...
     A0_D void init(const float* wp, int K) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        base = (const uint4*)wp + (((wave % WN) * (NBW * 16) + (lane & 15)) * 4 + (lane >> 4)) * 3;
-        nst = K >> 5;
+        base = (const uint4*)wp + (((wave % WN) * (NBW * 16) + (lane & 15)) * 4 + (lane >> 4)) * 3 + (WK > 1 ? (wave / WN) * (N * 12) : 0);
+        nst = (K >> 5) / WK;
     }
     A0_D void fill(int slot) {
 #pragma unroll
@@ -435,7 +437,7 @@ struct a0_wring9 {          // uint4 index ((t*N + n)*4 + q)*3 + s: the eight k 
 #pragma unroll
             for (int s = 0; s < 3; ++s) v[slot][j][s] = p[j * 192 + s];
         const bool more = left > 1;
-        p += more ? N * 12 : 0;
+        p += more ? N * 12 * WK : 0;
         left -= more ? 1 : 0;
     }
     A0_D void prologue() {
@@ -595,6 +597,107 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
     }
     __syncthreads();
 }
+// N-stationary form of a0_conv_stage_x9 for the forward stages (N = 64: four waves along N, the two groups of four along K).  In the form
+// above the two groups of waves along M both stream the complete weight set (1 MB per observation and CU through the vector L1), and the
+// kernel is more sensitive to that stream than to anything else (profiles/r02_encoder_experiments.md: half the weight loads = -8 %, half the
+// LDS fragment reads = -2 %).  Here wave (wn, wk) owns column block wn, ALL 16-row blocks and the k steps wk, wk + 2, ...: every weight
+// fragment is loaded by exactly one wave.  A k step is processed in two halves of MBT / 2 row blocks (the A fragments of the next half are in
+// flight while this one's MFMAs issue: same register ring as above).  At the end the two waves of a column block exchange partial sums
+// through LDS — wave wk finishes row-block half wk, so each sends the other's half — which costs one barrier and 2 x 4 KB x MBT of LDS traffic.
+// `xch`: 8 * MBT / 2 KB of LDS nobody reads any more when the first wave leaves its k loop.  Association of the k sum: (even steps) + (odd steps).
+template <int N, int WN, int MBT, int R, int LR, class AFX, class EPI, class Between>
+A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_WAVES / WN>& ring, const EPI& epi, float* xch0, float* xch1, Between&& between) {
+    constexpr int WK = A0_FUSED_WAVES / WN, HB = MBT / 2;
+    static_assert(WK == 2 && N == 16 * WN && (MBT % 2) == 0 && EPI::TR && !EPI::PER_ELEM && LR >= 1 && LR <= 16, "tile shape");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wk = wave / WN;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int MB = (M + 15) >> 4, NSTW = ring.nst;       // NSTW is a multiple of R for every supported shape
+    int rows[MBT];
+#pragma unroll
+    for (int i = 0; i < MBT; ++i) {
+        const int m = i * 16 + r16;
+        rows[i] = af.row(m < M ? m : 0) + 8 * q;
+    }
+    a0_acc4 acc[MBT];
+#pragma unroll
+    for (int i = 0; i < MBT; ++i) acc[i] = a0_acc4{0.f, 0.f, 0.f, 0.f};
+    uint4 a[2][HB][3];
+    auto fetch = [&](int slot, int h, int off) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[slot][i][t] = *(const uint4*)(af.planes + rows[h * HB + i] + off + t * AFX::term);
+    };
+    fetch(0, 0, af.step_off(wk));
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see a0_conv_stage
+#pragma unroll 1
+    for (int tb = 0; tb < NSTW; tb += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int st = wk + WK * (tb + u);
+            const int off = af.step_off(st), offn = af.step_off(tb + u + 1 < NSTW ? st + WK : st);      // past the end: re-read the last step (never consumed)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0) fetch(1, 1, off);
+                else fetch(0, 0, offn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+                    for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) {
+                            if (ta + tw > A0_X9_MAXORD) continue;      // see A0_X9_MAXORD
+                            const a0_u32x4 av = {a[h][i][ta].x, a[h][i][ta].y, a[h][i][ta].z, a[h][i][ta].w};
+                            const a0_u32x4 bv = {ring.v[u][0][tw].x, ring.v[u][0][tw].y, ring.v[u][0][tw].z, ring.v[u][0][tw].w};
+                            acc[h * HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[h * HB + i], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ring.fill(u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    between();
+    // xch0: WN * HB KB for the partial sums of row-block half 0 (written by the wk = 1 waves), xch1: the same for half 1 (written by
+    // wk = 0).  Only the first LR rows of the last row block exist (M = 16 * (MBT - 1) + LR): with transposed accumulators a lane holds
+    // row lane & 15, so that block travels as 4 * LR lanes instead of 64 (conv2, LR = 1: 64 bytes per wave instead of 1 KB — which is
+    // what lets both regions fit beside the stage's live data, no barrier before the exchange).
+    a0_acc4* x0 = (a0_acc4*)xch0;
+    a0_acc4* x1 = (a0_acc4*)xch1;
+    constexpr int P1 = (HB - 1) * 64 + 4 * LR;      // float4 slots per wave in region 1
+    const int last = q * LR + r16;                  // slot of this lane's values of the last block (lanes with r16 < LR)
+    // H = row-block half this wave finishes: compile-time in both lambdas, so the accumulators stay in registers
+    auto send = [&](auto mine) {
+        constexpr int H = decltype(mine)::value;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            if (H == 1) x0[(wn * HB + i) * 64 + lane] = acc[i];
+            else if (i < HB - 1) x1[wn * P1 + i * 64 + lane] = acc[HB + i];
+            else if (r16 < LR) x1[wn * P1 + (HB - 1) * 64 + last] = acc[HB + i];
+        }
+    };
+    auto recv = [&](auto mine) {
+        constexpr int H = decltype(mine)::value;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int mb = H * HB + i;
+            const int m = mb * 16 + r16;
+            if (H == 0) acc[mb] += x0[(wn * HB + i) * 64 + lane];
+            else if (i < HB - 1) acc[mb] += x1[wn * P1 + i * 64 + lane];
+            else if (r16 < LR) acc[mb] += x1[wn * P1 + (HB - 1) * 64 + last];
+            if (mb < MB && m < M) epi.emit_n4(m, wn * 16 + 4 * q, acc[mb], nullptr);
+        }
+    };
+    if (wk == 0) send(std::integral_constant<int, 0>{});
+    else send(std::integral_constant<int, 1>{});
+    __syncthreads();
+    if (wk == 0) recv(std::integral_constant<int, 0>{});
+    else recv(std::integral_constant<int, 1>{});
+    __syncthreads();
+}
 constexpr int A0_P1X = 40, A0_P2X = 80;       // pixel pitches (bf16 elements) of the act1 / act2 term planes: channels + 8 / + 16
 // Image-row pitches of the term planes (84x84 geometry).  A fragment read is a ds_read_b128 whose 16-lane groups are {0-3, 12-15, 20-27},
 // {4-11, 16-19, 28-31} (+32); along one image row the pixel pitches above put a group's 16 reads on 16 different 16-byte slots of the
@@ -613,6 +716,9 @@ constexpr int A0_RP2X = 9 * A0_P2X + (A0_PADS ? 96 : 0);      // act2 planes: 9 
 #define A0_RX3_D 6
 #endif
 constexpr int A0_RX2 = A0_RX2_D, A0_RX3 = A0_RX3_D;         // 32-k steps of split weights in flight (tuning aids: -DA0_RX2_D / -DA0_RX3_D)
+#ifndef A0_KSPLIT
+#define A0_KSPLIT 1                           // 1: N-stationary conv2 / conv3 stages of the forward kernel (a0_conv_stage_x9k); 0: M x N wave tiling (a0_conv_stage_x9)
+#endif
 #ifndef A0_WNX
 #define A0_WNX 4                              // waves along N in the split-operand conv2 / conv3 stages
 #endif
@@ -633,7 +739,18 @@ constexpr int A0_X9_BIAS_OFF = (2 * 10 + 20) * A0_RP1X * 2;
 #else
 constexpr int A0_X9_BIAS_OFF = 2 * 4 * 84 * 84 + 3 * 20 * A0_RP1X * 2;      // bf16 image + act1 term planes
 #endif
-constexpr int A0_X9_LDS_BYTES = A0_X9_BIAS_OFF + 160 * 4;
+#ifndef A0_RK2_D
+#define A0_RK2_D 2
+#endif
+#ifndef A0_RK3_D
+#define A0_RK3_D 3
+#endif
+constexpr int A0_RK2 = A0_RK2_D, A0_RK3 = A0_RK3_D;      // weight-ring depths of the N-stationary stages, in own k steps (8 resp. 9 per wave)
+constexpr int A0_X9_XCH0 = 3 * 9 * A0_RP2X * 2;             // conv2 exchange region 0: behind the act2 planes, inside the (dead) image
+constexpr int A0_X9_XCH1 = A0_X9_BIAS_OFF + 160 * 4;        // region 1: behind the biases (4 waves x (2 KB + 64 B))
+static_assert(A0_X9_XCH0 + 4 * 3 * 1024 <= 2 * 4 * 84 * 84, "conv2 exchange region 0 fits into the image");
+constexpr int A0_X9_LDS_BYTES = A0_X9_XCH1 + (A0_KSPLIT ? 4 * (2 * 64 + 4) * 16 : 0);
+static_assert(A0_X9_LDS_BYTES <= 160 * 1024, "LDS");
 // LOOP: the workgroup walks over several observations (b += gridDim.x; launches of more observations than CUs) and requests the next
 // observation's conv1 weights behind conv3; without it (the actor's launches: one observation per workgroup) that request is not made.
 template <int MBW1, int MBW2, int MBW3, bool LOOP>
@@ -661,8 +778,14 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     constexpr int MBW2X = (6 + WMGX - 1) / WMGX, MBW3X = (4 + WMGX - 1) / WMGX;
     static_assert(MBW2X <= MBW2 * 2 && MBW3X <= MBW3 * 2, "84x84 geometry");
     a0_wring1<A0_R1> ring1;
+#if A0_KSPLIT
+    static_assert(WNX == 4 && A0_FUSED_WAVES == 8, "N-stationary stages: four waves along N, two along K");
+    a0_wring9<64, 4, A0_RK2, 2> ring2;      // 8 own steps of conv2's 16
+    a0_wring9<64, 4, A0_RK3, 2> ring3;      // 9 own steps of conv3's 18
+#else
     a0_wring9<64, WNX, A0_RX2> ring2;
     a0_wring9<64, WNX, A0_RX3> ring3;
+#endif
     ring1.init(P.wt1, P.C);
     ring2.init(P.wx2, 512);
     ring3.init(P.wx3, 576);
@@ -713,6 +836,14 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
             a0_conv1_stage<MBW1X, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         const AF2X<term1> f2{a1p, A0_RP1X, P.W2, A0_P1X};
         const E2X e2{bias_lds + 32, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
+#if A0_KSPLIT
+        // exchange buffers, all dead while their stage's k loops run: conv2's partial sums go behind the act2 planes-to-be (the top 12 KB of the
+        // image region) and into the tail of the LDS allocation, conv3's where act1 was
+        const AF3X<term2> f3k{a2p, A0_RP2X, P.W3, A0_P2X};
+        const EpiFwdT e3k{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
+        a0_conv_stage_x9k<64, 4, 6, A0_RK2, 1>(f2, M2, ring2, e2, (float*)(smem + A0_X9_XCH0), (float*)(smem + A0_X9_XCH1), [&] { ring3.prologue(); });
+        a0_conv_stage_x9k<64, 4, 4, A0_RK3, 16>(f3k, M3, ring3, e3k, (float*)a1p, (float*)a1p + 4 * 2 * 256, [&] { if (LOOP) ring1.prologue(); });
+#else
         const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
         constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
         if (uneven2 && wmgx + (MBW2X - 1) * WMGX >= 6)
@@ -725,6 +856,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
             a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
         else
             a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
+#endif
         if constexpr (!LOOP) break;
     }
 }
