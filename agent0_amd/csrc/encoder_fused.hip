@@ -640,7 +640,11 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
             const int off = af.step_off(st), offn = af.step_off(tb + u + 1 < NSTW ? st + WK : st);      // past the end: re-read the last step (never consumed)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+#if defined(A0_EXP_HALF_A)      // TIMING-ONLY experiment (garbage results): the second half of a step re-uses the first half's A fragments
+                if (h == 0) { for (int i = 0; i < HB; ++i) for (int t = 0; t < 3; ++t) a[1][i][t] = a[0][i][t]; }
+#else
                 if (h == 0) fetch(1, 1, off);
+#endif
                 else fetch(0, 0, offn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -656,6 +660,9 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
                         }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if defined(A0_EXP_HALF_B)      // TIMING-ONLY experiment (garbage results): every other ring slot is never refilled
+            if (!((tb + u) & 1))
+#endif
             ring.fill(u);
             __builtin_amdgcn_sched_barrier(0);
         }
