@@ -424,20 +424,23 @@ struct a0_wring9 {          // uint4 index ((t*N + n)*4 + q)*3 + s: the eight k 
     uint4 v[R][NBW][3];
     const uint4* base;
     const uint4* p;
-    int nst, left;
+    int nst, left, stride;
     // WK > 1 (a0_conv_stage_x9k): the waves wave / WN = 0 .. WK-1 share the k steps round-robin; this ring walks steps wk, wk + WK, ...
     A0_D void init(const float* wp, int K) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         base = (const uint4*)wp + (((wave % WN) * (NBW * 16) + (lane & 15)) * 4 + (lane >> 4)) * 3 + (WK > 1 ? (wave / WN) * (N * 12) : 0);
         nst = (K >> 5) / WK;
+        stride = N * 12 * WK;
     }
+    // explicit form: `first` = this lane's fragment of the wave's first own step, `step` = uint4 between two of its own steps
+    A0_D void init_at(const uint4* first, int own_steps, int step) { base = first; nst = own_steps; stride = step; }
     A0_D void fill(int slot) {
 #pragma unroll
         for (int j = 0; j < NBW; ++j)
 #pragma unroll
             for (int s = 0; s < 3; ++s) v[slot][j][s] = p[j * 192 + s];
         const bool more = left > 1;
-        p += more ? N * 12 * WK : 0;
+        p += more ? stride : 0;
         left -= more ? 1 : 0;
     }
     A0_D void prologue() {
@@ -607,8 +610,8 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
 // `xch`: 8 * MBT / 2 KB of LDS nobody reads any more when the first wave leaves its k loop.  Association of the k sum: (even steps) + (odd steps).
 template <int N, int WN, int MBT, int R, int LR, class AFX, class EPI, class Between>
 A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_WAVES / WN>& ring, const EPI& epi, float* xch0, float* xch1, Between&& between) {
-    constexpr int WK = A0_FUSED_WAVES / WN, HB = MBT / 2;
-    static_assert(WK == 2 && N == 16 * WN && (MBT % 2) == 0 && EPI::TR && !EPI::PER_ELEM && LR >= 1 && LR <= 16, "tile shape");
+    constexpr int WK = A0_FUSED_WAVES / WN, HB0 = (MBT + 1) / 2, HB1 = MBT / 2;       // row blocks of the two halves of a k step: [0, HB0) and [HB0, MBT)
+    static_assert(WK == 2 && N == 16 * WN && HB1 >= 1 && EPI::TR && LR >= 1 && LR <= 16, "tile shape");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wk = wave / WN;
@@ -623,12 +626,14 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
     a0_acc4 acc[MBT];
 #pragma unroll
     for (int i = 0; i < MBT; ++i) acc[i] = a0_acc4{0.f, 0.f, 0.f, 0.f};
-    uint4 a[2][HB][3];
+    uint4 a[2][HB0][3];
     auto fetch = [&](int slot, int h, int off) {
 #pragma unroll
-        for (int i = 0; i < HB; ++i)
+        for (int i = 0; i < HB0; ++i)
+            if (h * HB0 + i < MBT) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[slot][i][t] = *(const uint4*)(af.planes + rows[h * HB + i] + off + t * AFX::term);
+                for (int t = 0; t < 3; ++t) a[slot][i][t] = *(const uint4*)(af.planes + rows[h * HB0 + i] + off + t * AFX::term);
+            }
     };
     fetch(0, 0, af.step_off(wk));
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see a0_conv_stage
@@ -641,7 +646,7 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #if defined(A0_EXP_HALF_A)      // TIMING-ONLY experiment (garbage results): the second half of a step re-uses the first half's A fragments
-                if (h == 0) { for (int i = 0; i < HB; ++i) for (int t = 0; t < 3; ++t) a[1][i][t] = a[0][i][t]; }
+                if (h == 0) { for (int i = 0; i < HB0; ++i) for (int t = 0; t < 3; ++t) a[1][i][t] = a[0][i][t]; }
 #else
                 if (h == 0) fetch(1, 1, off);
 #endif
@@ -652,11 +657,11 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
 #pragma unroll
                     for (int tw = 0; tw < 3; ++tw)
 #pragma unroll
-                        for (int i = 0; i < HB; ++i) {
-                            if (ta + tw > A0_X9_MAXORD) continue;      // see A0_X9_MAXORD
+                        for (int i = 0; i < HB0; ++i) {
+                            if (ta + tw > A0_X9_MAXORD || h * HB0 + i >= MBT) continue;      // see A0_X9_MAXORD
                             const a0_u32x4 av = {a[h][i][ta].x, a[h][i][ta].y, a[h][i][ta].z, a[h][i][ta].w};
                             const a0_u32x4 bv = {ring.v[u][0][tw].x, ring.v[u][0][tw].y, ring.v[u][0][tw].z, ring.v[u][0][tw].w};
-                            acc[h * HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[h * HB + i], 0, 0, 0);
+                            acc[h * HB0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[h * HB0 + i], 0, 0, 0);
                         }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -668,34 +673,51 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
         }
     }
     between();
-    // xch0: WN * HB KB for the partial sums of row-block half 0 (written by the wk = 1 waves), xch1: the same for half 1 (written by
+    // xch0: WN * HB0 KB for the partial sums of row-block half 0 (written by the wk = 1 waves), xch1: the same for half 1 (written by
     // wk = 0).  Only the first LR rows of the last row block exist (M = 16 * (MBT - 1) + LR): with transposed accumulators a lane holds
     // row lane & 15, so that block travels as 4 * LR lanes instead of 64 (conv2, LR = 1: 64 bytes per wave instead of 1 KB — which is
     // what lets both regions fit beside the stage's live data, no barrier before the exchange).
     a0_acc4* x0 = (a0_acc4*)xch0;
     a0_acc4* x1 = (a0_acc4*)xch1;
-    constexpr int P1 = (HB - 1) * 64 + 4 * LR;      // float4 slots per wave in region 1
+    constexpr int P1 = (HB1 - 1) * 64 + 4 * LR;     // float4 slots per wave in region 1
     const int last = q * LR + r16;                  // slot of this lane's values of the last block (lanes with r16 < LR)
-    // H = row-block half this wave finishes: compile-time in both lambdas, so the accumulators stay in registers
+    const int n0 = wn * 16 + 4 * q;
+    // H = row-block half this wave finishes: compile-time in the lambdas, so the accumulators stay in registers.  Per-element epilogue
+    // inputs (ReLU masks) of that half are requested before the exchange and used after it.
+    float pe[EPI::PER_ELEM ? HB0 : 1][4];
     auto send = [&](auto mine) {
         constexpr int H = decltype(mine)::value;
+        if constexpr (EPI::PER_ELEM) {
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            if (H == 1) x0[(wn * HB + i) * 64 + lane] = acc[i];
-            else if (i < HB - 1) x1[wn * P1 + i * 64 + lane] = acc[HB + i];
-            else if (r16 < LR) x1[wn * P1 + (HB - 1) * 64 + last] = acc[HB + i];
+            for (int i = 0; i < (H == 0 ? HB0 : HB1); ++i) {
+                const int m = (H * HB0 + i) * 16 + r16;
+                const a0_f4 v = epi.pre_elem4(m < M ? m : M - 1, n0);
+                pe[i][0] = v.x; pe[i][1] = v.y; pe[i][2] = v.z; pe[i][3] = v.w;
+            }
+        }
+        if constexpr (H == 1) {
+#pragma unroll
+            for (int i = 0; i < HB0; ++i) x0[(wn * HB0 + i) * 64 + lane] = acc[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < HB1; ++i) {
+                if (i < HB1 - 1) x1[wn * P1 + i * 64 + lane] = acc[HB0 + i];
+                else if (r16 < LR) x1[wn * P1 + (HB1 - 1) * 64 + last] = acc[HB0 + i];
+            }
         }
     };
     auto recv = [&](auto mine) {
         constexpr int H = decltype(mine)::value;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int mb = H * HB + i;
+        for (int i = 0; i < (H == 0 ? HB0 : HB1); ++i) {
+            const int mb = H * HB0 + i;
             const int m = mb * 16 + r16;
-            if (H == 0) acc[mb] += x0[(wn * HB + i) * 64 + lane];
-            else if (i < HB - 1) acc[mb] += x1[wn * P1 + i * 64 + lane];
-            else if (r16 < LR) acc[mb] += x1[wn * P1 + (HB - 1) * 64 + last];
-            if (mb < MB && m < M) epi.emit_n4(m, wn * 16 + 4 * q, acc[mb], nullptr);
+            if constexpr (H == 0) acc[mb] += x0[(wn * HB0 + i) * 64 + lane];
+            else {
+                if (i < HB1 - 1) acc[mb] += x1[wn * P1 + i * 64 + lane];
+                else if (r16 < LR) acc[mb] += x1[wn * P1 + (HB1 - 1) * 64 + last];
+            }
+            if (mb < MB && m < M) epi.emit_n4(m, n0, acc[mb], EPI::PER_ELEM ? pe[EPI::PER_ELEM ? i : 0] : nullptr);
         }
     };
     if (wk == 0) send(std::integral_constant<int, 0>{});
@@ -723,6 +745,9 @@ constexpr int A0_RP2X = 9 * A0_P2X + (A0_PADS ? 96 : 0);      // act2 planes: 9 
 #define A0_RX3_D 6
 #endif
 constexpr int A0_RX2 = A0_RX2_D, A0_RX3 = A0_RX3_D;         // 32-k steps of split weights in flight (tuning aids: -DA0_RX2_D / -DA0_RX3_D)
+#ifndef A0_KSPLIT_D
+#define A0_KSPLIT_D 1                         // 1: N-stationary stages in the data-gradient kernel too (two stride phases per stage)
+#endif
 #ifndef A0_KSPLIT
 #define A0_KSPLIT 1                           // 1: N-stationary conv2 / conv3 stages of the forward kernel (a0_conv_stage_x9k); 0: M x N wave tiling (a0_conv_stage_x9)
 #endif
@@ -1069,6 +1094,21 @@ struct EpiBwdT {                // dx = mask > 0 ? acc : 0 at pixel (oh*S + ph, 
         *(a0_f4*)(dst + gi(m, n0)) = a0_f4{pre[0] > 0.f ? acc[0] : 0.f, pre[1] > 0.f ? acc[1] : 0.f, pre[2] > 0.f ? acc[2] : 0.f, pre[3] > 0.f ? acc[3] : 0.f};
     }
 };
+struct EpiBwdPair {             // two stride phases of conv2's data gradient side by side: virtual column n0 -> phase p0 + (n0 >> 5), channel n0 & 31; transposed accumulators
+    static constexpr bool PER_ELEM = true;
+    static constexpr bool ROW4 = false;
+    static constexpr bool TR = true;
+    const float* mask; float* dst; int p0;         // act1 / d1 of this observation, [20][20][32]
+    A0_D unsigned gi(int m, int n0) const {
+        const int p = p0 + (n0 >> 5), oh = m / 10, ow = m - oh * 10;
+        return (unsigned)(((oh * 2 + (p >> 1)) * 20 + ow * 2 + (p & 1)) * 32 + (n0 & 31));
+    }
+    A0_D float pre_col(int) const { return 0.f; }
+    A0_D a0_f4 pre_elem4(int m, int n0) const { return *(const a0_f4*)(mask + gi(m, n0)); }
+    A0_D void emit_n4(int m, int n0, const a0_acc4& acc, const float* pre) const {
+        *(a0_f4*)(dst + gi(m, n0)) = a0_f4{pre[0] > 0.f ? acc[0] : 0.f, pre[1] > 0.f ? acc[1] : 0.f, pre[2] > 0.f ? acc[2] : 0.f, pre[3] > 0.f ? acc[3] : 0.f};
+    }
+};
 constexpr int A0_RXD3 = 6, A0_RXD2 = 4;               // 32-k steps of split weights in flight (18 and 8 steps per stage)
 
 __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_kernel(a0_dgrad_args P) {
@@ -1076,6 +1116,46 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
     uint16_t* plA = (uint16_t*)smem;                  // d3, padded by 2: three term planes
     uint16_t* plB = plA + 3 * A0_DTERMA;              // d2, padded by 1 (last row / column unused)
     for (int i = threadIdx.x; i < 3 * (A0_DTERMA + A0_DTERMB) / 2; i += A0_FUSED_THREADS) ((uint32_t*)smem)[i] = 0u;     // both images; borders stay zero for the whole launch
+#if A0_KSPLIT_D
+    // N-stationary stages (a0_conv_stage_x9k): conv3's data gradient as in the forward kernel; conv2's four stride phases share their A operand
+    // (the d2pad taps), so two phases at a time form ONE stage of 64 virtual columns — column block wn = phase (wn >> 1) of the pair, channel
+    // block wn & 1 — and every weight fragment of the kernel is loaded once per workgroup (was twice / four times), every d2pad fragment
+    // read for two phases at once.  Partial sums are exchanged through the 38 KB the two padded images leave free.
+    float* const xch0 = (float*)(smem + 3 * (A0_DTERMA + A0_DTERMB) * 2);
+    float* const xch1 = xch0 + 4 * 4 * 256;                // region 0: 4 column blocks x up to 4 row blocks x 1 KB
+    {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wn = wave & 3, wk = wave >> 2;
+        a0_wring9<64, 4, 3, 2> ring3;
+        a0_wring9<64, 4, 2, 2> ringq[2];
+        ring3.init(P.wd3, 576);
+        ring3.prologue();
+        // phase matrices: 4 x [256 k][32 n] in the N = 32 ring layout (3072 uint4 each, 384 per k step)
+        const uint4* const wq = (const uint4*)P.wd2 + (((wn & 1) * 16 + (lane & 15)) * 4 + (lane >> 4)) * 3 + (wn >> 1) * 3072 + wk * 384;
+        __syncthreads();
+        for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+            const a0_f4* src = (const a0_f4*)(P.d3 + (long long)b * 49 * 64);
+            for (int i = threadIdx.x; i < 49 * 16; i += A0_FUSED_THREADS) {
+                const a0_f4 v = src[i];
+                const int pos = i >> 4, c4 = (i & 15) * 4, h = pos / 7, w = pos - h * 7;
+                const float x[4] = {v.x, v.y, v.z, v.w};
+                uint2 hi, mid, lo;
+                a0_split4(x, hi, mid, lo);
+                uint16_t* d = plA + (h + 2) * A0_RPDA + (w + 2) * A0_P2X + c4;
+                *(uint2*)(d) = hi; *(uint2*)(d + A0_DTERMA) = mid; *(uint2*)(d + 2 * A0_DTERMA) = lo;
+            }
+            __syncthreads();
+            const AFD3X f3{plA};
+            const AFD2X f2{plB};
+            const EpiBwd3X e3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, plB};
+            const EpiBwdPair e2a{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, 0};
+            const EpiBwdPair e2b{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, 2};
+            a0_conv_stage_x9k<64, 4, 6, 3, 1>(f3, 81, ring3, e3, xch0, xch1, [&] { ringq[0].init_at(wq, 4, 768); ringq[0].prologue(); });
+            a0_conv_stage_x9k<64, 4, 7, 2, 4>(f2, 100, ringq[0], e2a, xch0, xch1, [&] { ringq[1].init_at(wq + 2 * 3072, 4, 768); ringq[1].prologue(); });
+            a0_conv_stage_x9k<64, 4, 7, 2, 4>(f2, 100, ringq[1], e2b, xch0, xch1, [&] { ring3.prologue(); });
+        }
+        return;
+    }
+#endif
     a0_wring9<64, 4, A0_RXD3> ring3;
     a0_wring9<32, 2, A0_RXD2> ringp[2];
     ring3.init(P.wd3, 576);
@@ -1334,7 +1414,7 @@ extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, 
         P.wd3 = P.wd2 + 4LL * 32 * 256 + 96LL * 512 + 96LL * 576;
         P.wd2 = P.wd3 + 96LL * 576;
     }
-    const size_t lds = x9 ? (size_t)3 * (A0_DTERMA + A0_DTERMB) * 2 : (size_t)11 * (P.rpa + P.rpb) * 4;
+    const size_t lds = x9 ? (size_t)3 * (A0_DTERMA + A0_DTERMB) * 2 + (A0_KSPLIT_D ? (4 * 4 + 4 * 3) * 1024 : 0) : (size_t)11 * (P.rpa + P.rpb) * 4;      // + the exchange regions of the N-stationary stages
     static bool configured[2] = {false, false};
     const void* fn = x9 ? (const void*)a0_encoder_dgrad_fused_x9_kernel : (const void*)a0_encoder_dgrad_fused_kernel;
     if (!configured[x9]) {
