@@ -167,6 +167,10 @@ struct a0_hip_backend {
         if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
         // fp32 operands: the split-operand kernel on the bf16 matrix pipe (igemm_x9.h); A0_GEMM=fp32 keeps the fmaf-chain kernel
         const bool x9 = g_gemm_x9 != 0;
+        // the fmaf-chain kernel has four waves: an eight-wave tile shape falls back to the same tile on four (twice the blocks per wave along N)
+        constexpr bool eight = WM * WN == 8;
+        constexpr int FWM = eight ? WM : WM, FWN = eight ? WN / 2 : WN, FMT = MT, FNT = eight ? NT * 2 : NT;
+        static_assert(!eight || (WN % 2) == 0, "eight-wave shapes: even wave count along N");
         if constexpr (a0_x9_ok<OA>::value && a0_x9_ok<OB>::value) {
             // large problems: 128 x 128 tiles on eight waves (two per SIMD: the splits of one wave issue in the shadow of the other's MFMAs)
             const int sp = splits < 1 ? 1 : splits;
@@ -179,9 +183,9 @@ struct a0_hip_backend {
             const bool large = X >= 128 && Y >= 128 && big >= g_x9_big_min && (deep || !wgrad_family);
             if (x9 && large) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
             else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
-            else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+            else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));
         } else {
-            A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
+            A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));
         }
         if (probe) {
             A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
@@ -317,16 +321,17 @@ extern "C" int a0_dense_fwd_mul(const float* X, int ldx, const float* W, const f
 // The split-K GEMM of a0_dense_fwd WITHOUT its reduction: slab z = X W^T over the z-th k range, [R][N] each at stride R*N; the caller's
 // next kernel sums the slabs (a0_dqn_head_loss_slabs, a0_actor_qhead).  Returns the slab count.
 // Tile of the split-K fc1 GEMM whose slabs a consumer kernel finishes (actor tail, DQN head + loss).  A0_FC1_VARIANT (tuning aid):
-// 0 = 128 x 64, waves 4 x 1, 1 = 128 x 64, waves 2 x 2, 2 = 64 x 64, 3 = 64 x 128, 4 = 128 x 32; unset: 64 x 64 up to 256 rows (the actor's
-// batch: 8 slabs instead of 16 for the tail kernel to sum, GEMM + tail 19.9 vs 22.3 us at 256 rows), 128 x 64 above (28.0 us at 512 rows,
-// where the variants are within 1 us of each other) — tools/ubench_actor_tail.py, profiles/r02_encoder_experiments.md.
+// 0 = 128 x 64, waves 4 x 1, 1 = 128 x 64, waves 2 x 2, 2 = 64 x 64, 3 = 64 x 128, 4 = 128 x 32, 5 / 6 = 128 x 64 / 64 x 128 on EIGHT waves (two per
+// SIMD: one wave's staging work in the shadow of the other's MFMAs); unset: 64 x 64 up to 256 rows (the actor's
+// batch: 8 slabs instead of 16 for the tail kernel to sum, GEMM + tail 19.9 vs 22.3 us at 256 rows; the eight-wave tiles need 16 slabs
+// there and lose), 128 x 64 on eight waves above (512 rows: GEMM + tail 26.5 vs 27.8 us on four waves, whole B = 512 update 380 vs 385 us) — tools/ubench_actor_tail.py, profiles/r02_encoder_experiments.md.
 static inline int a0_fc1_variant(int R) {
     static const int v = getenv("A0_FC1_VARIANT") ? atoi(getenv("A0_FC1_VARIANT")) : -1;
-    return v >= 0 ? v : (R <= 256 ? 2 : 0);
+    return v >= 0 ? v : (R <= 256 ? 2 : 5);
 }
 static inline int a0_fc1_splits(int R, int N, int K) {
     const int v = a0_fc1_variant(R);
-    const int bx = (v == 2 || v == 3) ? 64 : 128, by = (v == 3) ? 128 : (v == 4 ? 32 : 64);
+    const int bx = (v == 2 || v == 3 || v == 6) ? 64 : 128, by = (v == 3 || v == 6) ? 128 : (v == 4 ? 32 : 64);
     static const int wg = getenv("A0_FC1_WGS") ? atoi(getenv("A0_FC1_WGS")) : 256;      // target workgroup count
     const int blocks = ((R + bx - 1) / bx) * ((N + by - 1) / by);
     if (v == 0 && wg == 256) return a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);
@@ -343,6 +348,8 @@ static void a0_fc1_partial_launch(BK& bk, const a0_mat_src& a, const a0_mat_src&
         case 4: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 1>(a, bw, ep, R, N, K, splits); break;
         case 2: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 2, 2, 1, 1>(a, bw, ep, R, N, K, splits); break;
         case 3: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 2, 2, 1, 2>(a, bw, ep, R, N, K, splits); break;
+        case 5: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 2, 1, 1>(a, bw, ep, R, N, K, splits); break;      // 128 x 64, eight waves
+        case 6: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 2, 4, 1, 1>(a, bw, ep, R, N, K, splits); break;      // 64 x 128, eight waves
         default: bk.template igemm<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2>(a, bw, ep, R, N, K, splits);
     }
 }
