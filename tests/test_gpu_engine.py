@@ -342,7 +342,7 @@ def test_fused_dgrad_matches_unfused():
     net = DeviceNet(hip, L, hip.net(4, 84, 84))
     net.load_state_dict(recipe.make_state_dict(spec, 5))
     assert net.fused_dgrad
-    for B in (3, 64):
+    for B in (3, 64, 300):      # 300: more observations than workgroups (the looping path), unevenly divided
         g = recipe.gen(B)
         frames = torch.from_numpy(g.integers(0, 256, B * 28224, dtype=np.uint8)).cuda()
         ws = Workspace(hip, L, B, grads=True)
