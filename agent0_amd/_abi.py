@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(ROOT, "include", "agent0_hip.h")
-LIB_PATH = os.environ.get("A0_LIB") or os.path.join(_PKG, "lib", "libagent0_hip.so")      # A0_LIB: tuning aid (a differently built copy of the same library)
+LIB_PATH = os.path.join(_PKG, "lib", "libagent0_hip.so")
 
 _SCALARS = {
     "int": C.c_int,
@@ -70,8 +70,12 @@ _lib = None
 _protos: Dict[str, Tuple[str, List[str]]] = {}
 
 
-def load(path: str = LIB_PATH):
-    """Load the shared library and attach argtypes/restype.  Raises if anything is missing."""
+def load(path: str = LIB_PATH, allow_variant: bool = False):
+    """Load the shared library and attach argtypes/restype.  Raises if anything is missing.
+
+    The product loads exactly one file, ``agent0_amd/lib/libagent0_hip.so``, and only a build that reports itself as "default"
+    (``a0_build_info``).  Tuning builds (tools/build_variant.sh: extra -D flags, possibly timing-only code) are loaded by the
+    diagnostics under ``tools/`` alone, through ``tools/with_lib.py``, which passes ``allow_variant=True`` before anything else loads."""
     global _lib
     if _lib is not None:
         return _lib
@@ -91,6 +95,9 @@ def load(path: str = LIB_PATH):
         _protos[name] = (ret, types)
     if lib.a0_abi_version() != 1:
         raise A0Error("libagent0_hip.so ABI version mismatch")
+    info = (lib.a0_build_info() or b"").decode()
+    if info != "default" and not allow_variant:
+        raise A0Error(f"{path} is a tuning build ({info}); the product only loads the default build of agent0_amd/csrc/build.sh")
     _lib = lib
     return lib
 

@@ -36,8 +36,8 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
-from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_CMD, CTL_DONE0, CTL_SEQ, N_SCAL, HostSynthSlice, VectorizedSingles, block_layout,  # noqa: F401
-                        block_views, record, worker_main)
+from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_ARG, CTL_DONE0, CTL_WORD, N_SCAL, HostSynthSlice, VectorizedSingles, block_layout,  # noqa: F401
+                        block_views, ctl_word, record, worker_main)
 
 
 class _Space:
@@ -96,8 +96,7 @@ class HostEnvPool:
         self._obs = [ops.zeros(E * self.obs_bytes, dtype=torch.uint8), ops.zeros(E * self.obs_bytes, dtype=torch.uint8)]
         self._scal_d = [ops.zeros(N_SCAL, E), ops.zeros(N_SCAL, E)]
         self._new_d = ops.zeros(max(E * self.frame_bytes, 16), dtype=torch.uint8)
-        self._seq_d = torch.zeros(2, dtype=torch.int64, device=ops.device)          # [seq, CMD_STEP]: DMA-copied over ctl[0:2] behind the actions
-        self._seq_d[1] = CMD_STEP
+        self._seq_d = torch.zeros(1, dtype=torch.int64, device=ops.device)          # (CMD_STEP << 56) | seq: ONE word, DMA-copied over ctl[0] behind the actions
         self.copy_stream = torch.cuda.Stream()
         self._uploaded = torch.cuda.Event()
         self.seq = 0
@@ -119,11 +118,12 @@ class HostEnvPool:
                 self._procs.append(p)
 
     # ------------------------------------------------------------------ host-side handshake
-    def _post(self, cmd: int):
-        """reset / close: the parent writes the command itself (no device work involved)."""
+    def _post(self, cmd: int, arg: int = -1):
+        """reset / close: the parent writes the command itself (no device work involved) — the argument first, then the one word that
+        carries command and sequence number together."""
         self.seq += 1
-        self._np["ctl"][CTL_CMD] = cmd
-        self._np["ctl"][CTL_SEQ] = self.seq
+        self._np["ctl"][CTL_ARG] = arg
+        self._np["ctl"][CTL_WORD] = ctl_word(cmd, self.seq)
 
     def _wait_workers(self, timeout_s: float = 120.0):
         ctl, t0 = self._np["ctl"], time.perf_counter()
@@ -171,14 +171,17 @@ class HostEnvPool:
     def reset(self, **kw):
         # nothing may still be reading the ring: a reset is outside the step path
         torch.cuda.current_stream().synchronize()
+        seed = kw.get("seed")
         if self.W == 0:
             self.seq += 1
             obs, _ = self._local.reset(**kw)
             self._np["obs"][self.seq & 1] = np.asarray(obs, dtype=np.uint8).reshape(self.E, -1)
         else:
-            self._post(CMD_RESET)
+            if set(kw) - {"seed"}:
+                raise TypeError(f"HostEnvPool.reset: only `seed` reaches the worker processes, got {sorted(kw)}")
+            self._post(CMD_RESET, -1 if seed is None else int(seed))      # worker w resets its slice [lo, lo + k) with seed + lo
             self._wait_workers()
-        self._seq_d[0] = self.seq
+        self._seq_d[0] = ctl_word(CMD_STEP, self.seq)
         self.g = 0
         half = self.seq & 1
         self._upload(half, scalars=False)
@@ -189,10 +192,11 @@ class HostEnvPool:
         self.g += 1
         half = self.seq & 1
         cur = torch.cuda.current_stream()
-        # actions, then (sequence number, command): two DMA copies in stream order — workers that see the new number see the actions
+        # actions, then the command word (CMD_STEP and the sequence number in ONE 8-byte word): two DMA copies in stream order — workers
+        # that see the new number see the actions, and can never pair it with the previous command
         self._act_h.copy_(action, non_blocking=True)
-        self._seq_d[0:1].add_(1)
-        self._ctl_h[CTL_SEQ:CTL_CMD + 1].copy_(self._seq_d, non_blocking=True)
+        self._seq_d.add_(1)
+        self._ctl_h[CTL_WORD:CTL_WORD + 1].copy_(self._seq_d, non_blocking=True)
         if self.W == 0:
             ev = torch.cuda.Event()
             ev.record(cur)

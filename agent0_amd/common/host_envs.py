@@ -16,8 +16,17 @@ from multiprocessing import shared_memory
 import numpy as np
 
 CMD_NONE, CMD_STEP, CMD_RESET, CMD_CLOSE = 0, 1, 2, 3
-# control block (int64): [0] command sequence number, [1] command, [2 + w] sequence number worker w has completed
-CTL_SEQ, CTL_CMD, CTL_DONE0 = 0, 1, 2
+# control block (int64): [0] command WORD = (command << 56) | sequence number — one 8-byte word, so a worker can never see a new sequence
+# number with the previous command (the word arrives by one aligned DMA / one store); [1] argument of a reset (seed, -1 = none), written
+# by the parent before the word; [2 + w] sequence number worker w has completed
+CTL_WORD, CTL_ARG, CTL_DONE0 = 0, 1, 2
+CTL_SEQ = CTL_WORD
+CMD_SHIFT = 56
+SEQ_MASK = (1 << CMD_SHIFT) - 1
+
+
+def ctl_word(cmd: int, seq: int) -> int:
+    return (int(cmd) << CMD_SHIFT) | (int(seq) & SEQ_MASK)
 
 
 N_SCAL = 7      # scalar rows per env and step: reward, terminated, truncated, life_loss, final mask, final return, advance (see record)
@@ -51,12 +60,20 @@ class VectorizedSingles:
     UNCLIPPED rewards and sign-clipped rewards out — the order of the reference's wrapper list (atari_wrappers.py:61-68: statistics inside,
     clipping outside) — plus the OR of the per-env ``life_loss`` flags the reference's EpisodicLifeEnv reports (atari_wrappers.py:35-51)."""
 
-    def __init__(self, envs, clip_reward: bool = True):
+    def __init__(self, envs, clip_reward: bool = True, seeds=None):
+        """``seeds``: one seed per env, used by the FIRST reset that is not given one (every env gets its own emulator stream and a run is
+        reproducible; later resets continue the streams, like gymnasium's)."""
         self.envs, self.clip = list(envs), clip_reward
         self.returns = np.zeros(len(self.envs), dtype=np.float64)
+        self.seeds = None if seeds is None else [int(s) for s in seeds]
 
-    def reset(self, **kw):
-        obs = [e.reset(**kw)[0] for e in self.envs]
+    def reset(self, seed=None, **kw):
+        """``seed``: None, an int (env i gets seed + i, gymnasium's vector convention) or one per env."""
+        k = len(self.envs)
+        if seed is None and self.seeds is not None:
+            seed, self.seeds = self.seeds, None
+        seeds = [None] * k if seed is None else [int(seed) + i for i in range(k)] if np.isscalar(seed) else [None if s is None else int(s) for s in seed]
+        obs = [e.reset(**kw)[0] if sd is None else e.reset(seed=sd, **kw)[0] for e, sd in zip(self.envs, seeds)]
         self.returns[:] = 0
         return np.stack(obs), {}
 
@@ -178,20 +195,21 @@ def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us, 
             # the sequence number arrives by DMA (steps) or from the parent (reset / close).  Inside a rollout the next command follows
             # within a few hundred microseconds (one actor step on the GPU + the upload): poll without sleeping for busy_us after each
             # command — a sleep costs ~60 us of timer slack per step, a sixth of the step — and fall back to sleeping between rollouts.
-            while int(ctl[CTL_SEQ]) == seen:
+            while (int(ctl[CTL_WORD]) & SEQ_MASK) == seen:
                 if time.perf_counter() < busy_until:
                     continue
                 time.sleep(spin_us * 1e-6)
                 spins += 1
                 if (spins & 0x3FFF) == 0 and os.getppid() != parent:
                     return                                   # the parent is gone (killed): do not poll a dead ring forever
-            seen = int(ctl[CTL_SEQ])
-            cmd = int(ctl[CTL_CMD])
+            word = int(ctl[CTL_WORD])                    # ONE read: command and sequence number belong together
+            seen, cmd = word & SEQ_MASK, word >> CMD_SHIFT
             if cmd == CMD_CLOSE:
                 break
             half = seen & 1
             if cmd == CMD_RESET:
-                obs, _ = env.reset()
+                seed = int(ctl[CTL_ARG])                 # written by the parent before the word
+                obs, _ = env.reset(seed=seed + lo) if seed >= 0 else env.reset()
                 buf["obs"][half, lo:lo + k] = np.asarray(obs, dtype=np.uint8).reshape(k, -1)
             else:
                 record(buf, half, lo, k, *env.step(buf["act"][lo:lo + k].copy()))
@@ -257,9 +275,12 @@ class LifeLossInfo(_Delegate):
         lost = before > after > 0
         info = dict(info, life_loss=lost)
         if lost and self.env.unwrapped.get_action_meanings()[1] == "FIRE":
-            obs, extra = _press_start(self.env, lambda: (obs, {}))
+            # the reference presses the three actions and ignores what they return except the last observation and info — a game that
+            # ends during the presses is NOT reset here, the next step reports it (atari_wrappers.py:52-55)
+            extra = None
+            for a in PRESS_AFTER_RESET:
+                obs, _, _, _, extra = self.env.step(a)
             info.update(extra or {})
-            info["life_loss"] = lost
         return obs, reward, terminated, truncated, info
 
 
@@ -281,6 +302,7 @@ class AtariSlice:
         return FireOnReset(env)
 
     def __call__(self, e0: int, k: int):
-        return VectorizedSingles([self.single(e0 + i) for i in range(k)], clip_reward=True)
+        # env e0 + i of the vector gets emulator seed `seed + e0 + i` on its first reset (make_atari adds 1000003 * rank to `seed`)
+        return VectorizedSingles([self.single(e0 + i) for i in range(k)], clip_reward=True, seeds=[self.seed + e0 + i for i in range(k)])
 
 

@@ -14,7 +14,9 @@ for s in "${SRCS[@]}"; do
     # the compiler's per-kernel resource remarks go to _obj/<source>.res (registers, scratch, spills): see kernel_resources.txt below
     ( rc=0; "${HIPCC}" "${FLAGS[@]}" -Rpass-analysis=kernel-resource-usage -c "${src}" -o "${obj}" 2> "${HERE}/_obj/${s}.err" || rc=$?
       { grep -E "remark: +(Function Name|VGPRs|ScratchSize|VGPRs Spill|SGPRs Spill|LDS Size)" "${HERE}/_obj/${s}.err" || true; } | sed -E 's/^.*remark: +//; s/ \[-Rpass.*$//' > "${HERE}/_obj/${s}.res"
-      if [[ $rc -ne 0 ]]; then { grep -v "kernel-resource-usage" "${HERE}/_obj/${s}.err" || true; } >&2; rm -f "${obj}"; fi
+      # warnings and errors of this unit (everything that is not a resource remark), also when the compile succeeded
+      { grep -A2 -E ": (warning|error|fatal error):" "${HERE}/_obj/${s}.err" || true; } >&2
+      if [[ $rc -ne 0 ]]; then rm -f "${obj}"; fi
       exit $rc ) &
     pids+=($!)
   fi

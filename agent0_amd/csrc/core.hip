@@ -19,6 +19,12 @@ int a0_fail_hip(int hip_error, const char* what) {
 
 extern "C" const char* a0_last_error(void) { return a0_tls_error.c_str(); }
 extern "C" int a0_abi_version(void) { return A0_ABI_VERSION; }
+// "default" for the product build (agent0_amd/csrc/build.sh); tools/build_variant.sh stamps its name and extra -D flags here, and the
+// product loader (agent0_amd/_abi.py) refuses any library that does not say "default".
+#ifndef A0_BUILD_VARIANT
+#define A0_BUILD_VARIANT "default"
+#endif
+extern "C" const char* a0_build_info(void) { return A0_BUILD_VARIANT; }
 
 extern "C" int a0_device_info(int* cu_count, long long* hbm_bytes, char* arch_name64) {
     int dev = 0;

@@ -11,7 +11,19 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
-#include <rccl/rccl.h>
+#include <string>
+
+// The five RCCL entry points this file uses, declared here so that the library builds without the RCCL development headers (the
+// symbols are looked up with dlsym at run time anyway).  Values as in rccl.h of ROCm 7.2: ncclSuccess = 0, ncclFloat32 = 7, ncclSum = 0,
+// ncclUniqueId = 128 opaque bytes, ncclComm_t = opaque pointer.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclFloat32 = 7;
+static const ncclRedOp_t ncclSum = 0;
 
 namespace {
 struct rccl_api {
@@ -28,6 +40,7 @@ rccl_api& api() {
     static rccl_api a;
     static std::once_flag once;
     std::call_once(once, [] {
+        std::string why = "?";
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);       // the copy the process already has, if any
             if (a.lib) break;
@@ -35,8 +48,9 @@ rccl_api& api() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             if (a.lib) break;
             a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!a.lib) { const char* e = dlerror(); why = e ? e : "?"; }     // dlerror() clears the state it returns: read it once
         }
-        if (!a.lib) { a.error = std::string("a0_dp: cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!a.lib) { a.error = "a0_dp: cannot load librccl.so.1: " + why; return; }
         auto sym = [&](const char* n) { void* p = dlsym(a.lib, n); if (!p && a.error.empty()) a.error = std::string("a0_dp: librccl lacks ") + n; return p; };
         a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");

@@ -547,9 +547,6 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int nxt = tb + u + 1;
-#if defined(A0_EXP_HALF_A)      // TIMING-ONLY experiment (garbage results): every other step re-uses the previous step's A fragments (half the LDS reads)
-            if (u & 1) { for (int i = 0; i < MBW; ++i) for (int t = 0; t < 3; ++t) a[(u + 1) & 1][i][t] = a[u & 1][i][t]; } else
-#endif
             fetch((u + 1) & 1, af.step_off(nxt < NST ? nxt : NST - 1));          // past the end: re-read the last step (never consumed)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -567,9 +564,6 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
                             else acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, av), __builtin_bit_cast(a0_bf16x8, bv), acc[i][jn], 0, 0, 0);
                         }
             __builtin_amdgcn_sched_barrier(0);
-#if defined(A0_EXP_HALF_B)      // TIMING-ONLY experiment (garbage results): every other ring slot is never refilled (half the weight loads)
-            if (!(u & 1))
-#endif
             ring.fill(u);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -645,11 +639,7 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
             const int off = af.step_off(st), offn = af.step_off(tb + u + 1 < NSTW ? st + WK : st);      // past the end: re-read the last step (never consumed)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-#if defined(A0_EXP_HALF_A)      // TIMING-ONLY experiment (garbage results): the second half of a step re-uses the first half's A fragments
-                if (h == 0) { for (int i = 0; i < HB0; ++i) for (int t = 0; t < 3; ++t) a[1][i][t] = a[0][i][t]; }
-#else
                 if (h == 0) fetch(1, 1, off);
-#endif
                 else fetch(0, 0, offn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -665,9 +655,6 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
                         }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#if defined(A0_EXP_HALF_B)      // TIMING-ONLY experiment (garbage results): every other ring slot is never refilled
-            if (!((tb + u) & 1))
-#endif
             ring.fill(u);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -744,7 +731,7 @@ constexpr int A0_RP2X = 9 * A0_P2X + (A0_PADS ? 96 : 0);      // act2 planes: 9 
 #ifndef A0_RX3_D
 #define A0_RX3_D 6
 #endif
-constexpr int A0_RX2 = A0_RX2_D, A0_RX3 = A0_RX3_D;         // 32-k steps of split weights in flight (tuning aids: -DA0_RX2_D / -DA0_RX3_D)
+[[maybe_unused]] constexpr int A0_RX2 = A0_RX2_D, A0_RX3 = A0_RX3_D;         // 32-k steps of split weights in flight (tuning aids: -DA0_RX2_D / -DA0_RX3_D)
 #ifndef A0_KSPLIT_D
 #define A0_KSPLIT_D 1                         // 1: N-stationary stages in the data-gradient kernel too (two stride phases per stage)
 #endif
@@ -766,11 +753,7 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encode
 
 // Split-operand variant (84 x 84 geometry): all three layers on the bf16 pipe.  LDS: bf16 image [0, 56 448), act1 term planes behind it;
 // the act2 term planes reuse the image's bytes (the image is dead once conv1 has finished).
-#ifdef A0_EXP_ALIAS
-constexpr int A0_X9_BIAS_OFF = (2 * 10 + 20) * A0_RP1X * 2;
-#else
 constexpr int A0_X9_BIAS_OFF = 2 * 4 * 84 * 84 + 3 * 20 * A0_RP1X * 2;      // bf16 image + act1 term planes
-#endif
 #ifndef A0_RK2_D
 #define A0_RK2_D 2
 #endif
@@ -791,13 +774,8 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     uint16_t* img = (uint16_t*)smem;
     const int obs_bytes = P.C * P.H * P.W;
     const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
-#ifdef A0_EXP_ALIAS        // TIMING-ONLY experiment (results are garbage): all LDS regions overlap so that two workgroups fit a CU
-    uint16_t* a1p = (uint16_t*)smem;
-    constexpr int term1 = 10 * A0_RP1X, term2 = 9 * A0_RP2X;
-#else
     uint16_t* a1p = (uint16_t*)(smem + 2 * obs_bytes);
     constexpr int term1 = 20 * A0_RP1X, term2 = 9 * A0_RP2X;
-#endif
     uint16_t* a2p = (uint16_t*)smem;
     typedef EpiFwdX<20, A0_P1X, A0_RP1X, term1> E1X;
     typedef EpiFwdX<9, A0_P2X, A0_RP2X, term2> E2X;
@@ -825,8 +803,10 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     constexpr int MBW1X = (25 + A0_WMG1 - 1) / A0_WMG1;
     static_assert(A0_FUSED_WAVES != 8 || MBW1X == MBW1, "84x84 geometry");
     a0_pre<32, 2, MBW1X, E1X> pre1;           // (empty: these epilogues take nothing from global memory)
+#if !A0_KSPLIT
     a0_pre<64, WNX, MBW2X, E2X> pre2;
     a0_pre<64, WNX, MBW3X, EpiFwdT> pre3;
+#endif
     float* bias_lds = (float*)(smem + A0_X9_BIAS_OFF);      // b1 | b2 | b3 behind the activation planes; visible after the first barrier below
     if (threadIdx.x < 160) bias_lds[threadIdx.x] = threadIdx.x < 32 ? P.b1[threadIdx.x] : threadIdx.x < 96 ? P.b2[threadIdx.x - 32] : P.b3[threadIdx.x - 96];
     // the pad channels (32..39 / 64..71) of the term planes are never read; nothing to initialise

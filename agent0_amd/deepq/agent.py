@@ -390,8 +390,9 @@ class BaseLearner:
         q_loss, f_loss = self.train_batch(u8, None, u8.numel() // B, actions.to(dev).to(torch.int32).contiguous(), rewards.to(dev).float().contiguous(),
                                           terminals.to(dev).float().contiguous(), weights.to(dev).float().contiguous())
         skipped = bool(self.engine.state[3])
-        return {"q_loss": None if skipped else q_loss[:B].clone(), "fraction_loss": None if f_loss is None else f_loss[:B].clone(),
-                "indices": indices.long()}
+        # CPU copies, like the reference's `.detach().cpu()` (agent.py:163-169); the Trainer's hot loop uses train_batch and stays on the device
+        return {"q_loss": None if skipped else q_loss[:B].cpu(), "fraction_loss": None if f_loss is None else f_loss[:B].cpu(),
+                "indices": indices.long().cpu()}
 
 
 class DQNLearner(BaseLearner):

@@ -101,6 +101,81 @@ class GradAllReduce:
         self.dist.all_reduce(state[0:1], op=self.dist.ReduceOp.MAX, group=self.group)
 
 
+class DpUnavailable(RuntimeError):
+    """The C-ABI exchange cannot be used by this process GROUP (agreed on by every rank): use torch.distributed instead."""
+
+
+class DpInitTimeout(RuntimeError):
+    """A rank did not come back from a collective initialisation call: the job cannot continue (nothing to fall back to safely)."""
+
+
+def _call_with_timeout(fn, seconds: float, what: str):
+    """Run ``fn`` on a helper thread bound to the caller's device; DpInitTimeout if it has not returned after ``seconds`` (the thread is a
+    daemon: the process can then exit non-zero instead of hanging in a collective a peer never entered)."""
+    import threading
+
+    box, dev = {}, torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def run():
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            box["value"] = fn()
+        except BaseException as e:      # noqa: BLE001
+            box["error"] = e
+
+    t = threading.Thread(target=run, daemon=True, name="a0-dp-init")
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise DpInitTimeout(f"{what} did not return within {seconds:.0f} s (a peer rank never entered it?)")
+    if "error" in box:
+        raise box["error"]
+    return box["value"]
+
+
+def _agree(group, ok: bool, what: str, err: str = "", on_fail=None):
+    """MIN all-reduce of a success flag over the torch group: returns on every rank, or raises DpUnavailable on every rank."""
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if float(flag[0]) < 0.5:
+        if on_fail is not None:
+            on_fail()
+        raise DpUnavailable(f"{what} failed on " + (f"this rank: {err}" if not ok else "another rank"))
+
+
+def collective_communicator(ops, group=None) -> int:
+    """An RCCL communicator over the C-ABI for every rank of ``group``, or DpUnavailable on every rank (ranks that did get one destroy it).
+    Stage 1: librccl resolves on every rank (a0_dp_unique_id is local; only rank 0's id is used).  Stage 2: the rendezvous blob (ALWAYS
+    broadcast), then a0_dp_init — ncclCommInitRank is itself collective, and stage 1 has established that every rank will enter it; a
+    rank that does not come back within A0_DP_INIT_TIMEOUT seconds ends the job with DpInitTimeout."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    my_id, err = bytes(128), ""
+    try:
+        my_id = ops.dp_unique_id()
+    except Exception as e:      # noqa: BLE001
+        err = str(e)
+    _agree(group, not err, "loading RCCL through the C-ABI (a0_dp_unique_id)", err)
+    blob = torch.frombuffer(bytearray(my_id), dtype=torch.uint8).clone().to(dev)
+    dist.broadcast(blob, src=0, group=group)
+    comm, err = 0, ""
+    try:
+        comm = _call_with_timeout(lambda: ops.dp_init(bytes(blob.cpu().numpy().tobytes()), rank, world),
+                                  float(os.environ.get("A0_DP_INIT_TIMEOUT", "180")), "a0_dp_init (ncclCommInitRank)")
+    except DpInitTimeout:
+        raise
+    except Exception as e:      # noqa: BLE001
+        err = str(e)
+    _agree(group, not err, "a0_dp_init", err, (lambda: ops.dp_destroy(comm)) if comm else None)
+    return comm
+
+
 class RcclGradAllReduce:
     """``DeviceLearner.grad_hook`` over the C-ABI's own exchange (``a0_dp_allreduce``: RCCL on a HIP stream).  Same two buckets as
     GradAllReduce, but every call is an ordinary stream-ordered launch, so the whole update — forward, dense backward, the dense bucket's
@@ -113,40 +188,49 @@ class RcclGradAllReduce:
     in_graph = True       # BaseLearner._update: no eager call between graphs is needed
 
     def __init__(self, ops, n_grad: int, group=None):
+        """Collective: every rank of ``group`` must construct this at the same point.  Each stage that can fail on ONE rank (loading
+        librccl, ncclCommInitRank, the eager self-test) is followed by a MIN all-reduce of a success flag over the torch group, so either
+        every rank ends up with a communicator or every rank raises ``DpUnavailable`` — and then ``make_grad_hook`` puts all of them on the
+        torch.distributed exchange.  No rank skips a collective another rank is waiting in."""
         import torch.distributed as dist
 
         self.ops, self.n = ops, n_grad
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        self.world = world
-        blob = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            blob = torch.frombuffer(bytearray(ops.dp_unique_id()), dtype=torch.uint8).clone()
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        blob = blob.to(dev)
-        dist.broadcast(blob, src=0, group=group)
-        self.comm = ops.dp_init(bytes(blob.cpu().numpy().tobytes()), rank, world)
+        self.world, self.comm = world, 0
+        self.comm = collective_communicator(ops, group)          # stages 1 and 2
+        agree = lambda ok, what, err="": _agree(group, ok, what, err, self.close)
         self.side = torch.cuda.Stream()
         self.active = os.environ.get("A0_DP_DRYRUN") != "1"
         if self.active:
-            self._self_test(rank, world, group)
+            # stage 3: one eager all-reduce (checks the communicator; RCCL's lazy allocations happen outside any capture)
+            err = ""
+            try:
+                self._eager_self_test(rank, world)
+            except Exception as e:      # noqa: BLE001
+                err = str(e)
+            agree(not err, "the a0_dp_allreduce self-test", err)
+            # stage 4: can the call be captured?  (decides in-graph vs eager; MIN over ranks inside)
+            self._capture_self_test(rank, world, group)
 
-    def _self_test(self, rank: int, world: int, group):
-        """Before the learner builds its update graph around this exchange: one eager all-reduce (checks the communicator and lets RCCL do its
-        lazy allocations outside any capture), then the same call captured on the side stream into a small hipGraph and replayed.  If the
-        capture does not work with this RCCL build the hook stays usable — it then runs eagerly between three graphs (in_graph = False) —
-        and every rank takes the same decision (MIN over ranks)."""
-        import sys
-        import torch.distributed as dist
-
+    def _eager_self_test(self, rank: int, world: int):
         x = torch.full((1024,), float(rank + 1), device="cuda")
         want = world * (world + 1) / 2.0
         self.ops.dp_allreduce(self.comm, x, x.numel())
         torch.cuda.synchronize()
         if abs(float(x[0]) - want) > 1e-3 or abs(float(x[-1]) - want) > 1e-3:
             raise RuntimeError(f"a0_dp_allreduce self-test: got {float(x[0])}, expected {want}")
+
+    def _capture_self_test(self, rank: int, world: int, group):
+        """The same call captured on the side stream into a small hipGraph and replayed.  If the capture does not work with this RCCL
+        build the hook stays usable — it then runs eagerly between three graphs (in_graph = False) — and every rank takes the same
+        decision (MIN over ranks)."""
+        import sys
+        import torch.distributed as dist
+
+        x = torch.full((1024,), float(rank + 1), device="cuda")
+        want = world * (world + 1) / 2.0
         ok = 1.0
         try:
-            x.fill_(float(rank + 1))
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, **graph_capture_kwargs()):
@@ -187,12 +271,15 @@ class RcclGradAllReduce:
 
 def make_grad_hook(ops, n_grad: int, group=None):
     """The gradient exchange for this process group: the in-graph RCCL path on GPUs (A0_DP_BACKEND=torch forces the torch.distributed
-    calls, which is also what a CPU/gloo group gets); if RCCL cannot be initialised through the C-ABI the torch path is used and said so."""
+    calls, which is also what a CPU/gloo group gets — the variable must be the same on every rank); if RCCL cannot be initialised through
+    the C-ABI on ANY rank, ALL ranks use the torch path and say so.  Collective: call it at the same point on every rank."""
     import sys
 
     if torch.cuda.is_available() and os.environ.get("A0_DP_BACKEND", "rccl") != "torch":
         try:
             return RcclGradAllReduce(ops, n_grad, group)
-        except Exception as e:      # noqa: BLE001 — any failure here must not take the job down: the torch path computes the same sums
-            print(f"agent0_amd.dist: a0_dp_* unavailable ({e}); falling back to torch.distributed all_reduce", file=sys.stderr)
+        except DpUnavailable as e:      # raised on EVERY rank or on none (RcclGradAllReduce.__init__): the torch path computes the same sums
+            print(f"agent0_amd.dist: a0_dp_* unavailable ({e}); every rank falls back to torch.distributed all_reduce", file=sys.stderr)
+        # anything else (DpInitTimeout, an error outside the agreed stages) propagates: the job exits non-zero rather than run with ranks
+        # on different exchanges
     return GradAllReduce(n_grad, group)

@@ -566,3 +566,6 @@ class HipOps:
         name = C.create_string_buffer(64)
         check(self.lib.a0_device_info(C.addressof(cu), C.addressof(mem), C.addressof(name)), "a0_device_info")
         return cu.value, mem.value, name.value.decode()
+
+    def build_info(self) -> str:
+        return (self.lib.a0_build_info() or b"").decode()

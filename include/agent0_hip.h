@@ -34,6 +34,8 @@ extern "C" {
 
 const char* a0_last_error(void);
 int a0_abi_version(void);
+/* "default" for the product build; a tuning build (tools/build_variant.sh) reports its name and -D flags, and the product loader refuses it. */
+const char* a0_build_info(void);
 int a0_device_info(int* cu_count, long long* hbm_bytes, char* arch_name64);
 
 /* ---------------------------------------------------------------- network geometry (agent0/deepq/model.py:90-105) */

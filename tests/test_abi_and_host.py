@@ -29,6 +29,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.a0_sumtree_set(None, 3, None, None, 1, None, None) == -1 and "power of two" in _abi.last_error()
 
 
+def test_product_loader_refuses_a_tuning_build(tmp_path):
+    """A library stamped by tools/build_variant.sh (extra -D flags, possibly timing-only code) must never be loaded by the product:
+    the loader takes one fixed path (no environment override) and only a build that reports "default"."""
+    from agent0_amd import _abi
+    assert "A0_LIB" not in open(os.path.join(ROOT, "agent0_amd", "_abi.py")).read()
+    assert _abi.load().a0_build_info() == b"default"
+    assert not os.path.exists(os.path.join(ROOT, "agent0_amd", "lib", "variants"))
+    assert "A0_EXP" not in open(os.path.join(ROOT, "agent0_amd", "csrc", "encoder_fused.hip")).read()
+    # the same library with core.hip re-stamped, in a fresh interpreter (the loader caches its handle)
+    csrc = os.path.join(ROOT, "agent0_amd", "csrc")
+    objs = [os.path.join(csrc, "_obj", f) for f in sorted(os.listdir(os.path.join(csrc, "_obj"))) if f.endswith(".o") and f != "core.o"]
+    core = str(tmp_path / "core.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           '-DA0_BUILD_VARIANT="x6: -DA0_X9_MAXORD=2"', "-c", os.path.join(csrc, "core.hip"), "-o", core])
+    lib = str(tmp_path / "libagent0_hip_x6.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, core] + objs + ["-ldl"])
+    code = ("import sys; sys.path.insert(0, %r)\nfrom agent0_amd import _abi\n"
+            "try:\n    _abi.load(%r)\n    print('LOADED')\nexcept _abi.A0Error as e:\n    print('REFUSED', e)\n"
+            "print(_abi.load(%r, allow_variant=True).a0_build_info().decode())\n" % (ROOT, lib, lib))
+    out = subprocess.check_output([sys.executable, "-c", code]).decode()
+    assert "REFUSED" in out and "tuning build (x6: -DA0_X9_MAXORD=2)" in out and "LOADED" not in out
+    assert out.strip().splitlines()[-1] == "x6: -DA0_X9_MAXORD=2"
+
+
 def test_gfx950_code_object_only():
     from agent0_amd import _abi
     blob = open(_abi.LIB_PATH, "rb").read()

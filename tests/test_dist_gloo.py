@@ -120,3 +120,83 @@ def test_fqf_fraction_net_is_reduced_too():
     for k, v in got.items():
         ref = ora.po[k].detach()
         assert float((v - ref).abs().max()) < 2e-5 + 2e-5 * float(ref.abs().max()), k
+
+
+class _FakeDpOps:
+    """Stand-in for the a0_dp_* entry points (no RCCL on a CPU box): records calls, fails where told to."""
+
+    def __init__(self, fail_id=False, fail_init=False, hang_init=False):
+        self.fail_id, self.fail_init, self.hang_init, self.destroyed, self.inits = fail_id, fail_init, hang_init, [], 0
+
+    def dp_unique_id(self):
+        if self.fail_id:
+            raise RuntimeError("a0_dp: cannot load librccl.so.1: no such file")
+        return bytes(range(128))
+
+    def dp_init(self, blob, rank, world):
+        assert blob == bytes(range(128)), "every rank received rank 0's blob"
+        self.inits += 1
+        if self.hang_init:
+            import time
+            time.sleep(30)
+        if self.fail_init:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        return 1000 + rank
+
+    def dp_destroy(self, comm):
+        self.destroyed.append(comm)
+
+
+def _agreement_worker(rank, world, port, case, out):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from agent0_amd.deepq import dist as adist
+
+    adist.init_process_group(backend="gloo")
+    ops = _FakeDpOps(fail_id=(case == "id" and rank == 1), fail_init=(case == "init" and rank == 0))
+    try:
+        comm = adist.collective_communicator(ops)
+        res = ("comm", comm)
+    except adist.DpUnavailable as e:
+        res = ("unavailable", str(e))
+    # the very next collective pairs up on every rank (ADVICE round 2: a rank that skipped the blob broadcast used to pair a
+    # differently sized broadcast with it)
+    x = torch.full((7,), float(rank + 1))
+    dist.all_reduce(x)
+    out[rank] = res + (float(x[0]), ops.inits, list(ops.destroyed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ok", "id", "init"])
+def test_rccl_hook_choice_is_collective(case):
+    """RCCL failing on ONE rank (library missing on rank 1 / ncclCommInitRank failing on rank 0) must put EVERY rank on the same branch:
+    all get a communicator or all raise DpUnavailable (ranks that did get one destroy it), and the group's collectives stay in step."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_agreement_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    res = dict(out)
+    kinds = {res[r][0] for r in (0, 1)}
+    assert len(kinds) == 1, res
+    assert res[0][2] == 3.0 and res[1][2] == 3.0
+    if case == "ok":
+        assert res[0][1] == 1000 and res[1][1] == 1001 and res[0][4] == [] and res[1][4] == []
+    elif case == "id":
+        assert kinds == {"unavailable"} and "this rank" in res[1][1] and "another rank" in res[0][1]
+        assert res[0][3] == 0 and res[1][3] == 0, "nobody enters ncclCommInitRank when a rank cannot load RCCL"
+    else:
+        assert kinds == {"unavailable"} and res[1][4] == [1001], "the rank whose communicator was created destroys it"
+
+
+def test_dp_init_timeout_raises_instead_of_hanging():
+    from agent0_amd.deepq import dist as adist
+    import time
+
+    t0 = time.time()
+    with pytest.raises(adist.DpInitTimeout, match="did not return within"):
+        adist._call_with_timeout(lambda: time.sleep(20), 0.3, "a0_dp_init (ncclCommInitRank)")
+    assert time.time() - t0 < 5
+    assert adist._call_with_timeout(lambda: 41 + 1, 5, "x") == 42
+    with pytest.raises(ValueError):
+        adist._call_with_timeout(lambda: (_ for _ in ()).throw(ValueError("boom")), 5, "x")

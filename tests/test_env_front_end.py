@@ -167,3 +167,91 @@ def test_record_marks_envs_whose_stack_merely_advanced():
     plain = block_views(bytearray(block_layout(E, ob, 1)[-1]), E, ob, 1)
     record(plain, 1, 0, E, *env.step(None))
     assert plain["new"].shape[2] == 0 and not plain["scal"][1, 6].any()
+
+
+def test_game_over_during_the_post_life_loss_presses_is_left_to_the_next_step():
+    """atari_wrappers.py:52-55: after a lost life the reference presses actions 0, 1, 2, ignores their termination flags and returns the LAST
+    press's observation and info — it does not reset there."""
+    class EndsDuringPresses(FakeAle):
+        def step(self, a):
+            out = super().step(a)
+            if self.t == 5:                           # the game "ends" on a press (t: 4 = lost life, then presses NOOP (frozen), FIRE t=5, 2 t=6)
+                return out[0], out[1], True, False, {"t": self.t, "over": True}
+            return out
+    env = EndsDuringPresses(lives=3, life_every=4)
+    w = LifeLossInfo(env)
+    w.reset(); env.step(1)
+    for _ in range(2):
+        w.step(3)
+    n_resets = env.log.count("reset")
+    obs, r, term, trunc, info = w.step(3)             # t = 4: life lost, three presses follow
+    assert info["life_loss"] is True and env.log[-3:] == [0, 1, 2]
+    assert env.log.count("reset") == n_resets, "no reset inside the wrapper"
+    assert int(obs[0, 0]) == 6 and info["t"] == 6, "observation and info of the LAST press"
+    assert term is False, "termination is the lost-life step's own flag; the presses' flags are ignored"
+
+
+def test_vectorised_singles_seed_every_env_on_the_first_reset():
+    class Rec(FakeAle):
+        def reset(self, **kw):
+            self.seeds = getattr(self, "seeds", []) + [kw.get("seed")]
+            return super().reset()
+    envs = [Rec(needs_fire=False) for _ in range(3)]
+    v = VectorizedSingles(envs, seeds=[1042, 1043, 1044])
+    v.reset(); v.reset()
+    assert [e.seeds for e in envs] == [[1042, None], [1043, None], [1044, None]], "own streams on the first reset, continued afterwards"
+    v.reset(seed=7)
+    assert [e.seeds[-1] for e in envs] == [7, 8, 9], "an int seed spreads as seed + i (gymnasium's vector convention)"
+    from agent0_amd.common.host_envs import AtariSlice
+    import inspect
+    src = inspect.getsource(AtariSlice.__call__)
+    assert "seeds=" in src and "self.seed + e0 + i" in src
+
+
+def test_worker_handshake_is_one_word():
+    """command and sequence number travel in ONE 8-byte word, so a worker cannot pair a new sequence number with the previous
+    command (a step after a reset being executed as a second reset).  worker_main runs on a thread against a plain bytearray block."""
+    import threading
+    import time
+    import host_slices
+    from agent0_amd.common.host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_ARG, CTL_DONE0, CTL_WORD, block_layout, block_views, ctl_word,
+                                             worker_main)
+    from multiprocessing import shared_memory
+    assert ctl_word(CMD_STEP, 5) >> 56 == CMD_STEP and ctl_word(CMD_STEP, 5) & ((1 << 56) - 1) == 5
+    E, ob = 3, 4 * 84 * 84
+    total = block_layout(E, ob, 1)[-1]
+    shm = shared_memory.SharedMemory(create=True, size=total)
+    try:
+        buf = block_views(shm.buf, E, ob, 1)
+        for v in buf.values():
+            v[...] = 0
+        resets = []
+
+        class Slice(host_slices.ScriptedStack):
+            def reset(self, **kw):
+                resets.append(kw)
+                return super().reset()
+        th = threading.Thread(target=worker_main, args=(0, lambda lo, k: Slice(5, lo, k), 0, E, shm.name, E, ob, 1, 20.0), daemon=True)
+        th.start()
+
+        def post(cmd, seq, arg=-1):
+            buf["ctl"][CTL_ARG] = arg
+            buf["ctl"][CTL_WORD] = ctl_word(cmd, seq)
+            t0 = time.time()
+            while int(buf["ctl"][CTL_DONE0]) != seq:
+                assert time.time() - t0 < 20
+                time.sleep(1e-4)
+        post(CMD_RESET, 1, arg=1234)
+        assert resets == [{"seed": 1234}], "the reset's seed reaches the worker (slice offset 0)"
+        twin = host_slices.ScriptedStack(5, 0, E)
+        twin.reset()
+        for seq in (2, 3, 4):
+            post(CMD_STEP, seq)              # the stale CMD_RESET is gone with the old word: these are steps
+            assert np.array_equal(buf["obs"][seq & 1].reshape(E, 4, 84, 84), twin.step(None)[0])
+        assert len(resets) == 1
+        buf["ctl"][CTL_WORD] = ctl_word(CMD_CLOSE, 5)
+        th.join(10)
+        assert not th.is_alive() and int(buf["ctl"][CTL_DONE0]) == -1
+        del buf
+    finally:
+        shm.close(); shm.unlink()

@@ -129,6 +129,7 @@ def test_trainer_iterations(algo, extra):
     a, r, d, w = recipe.make_transitions(B, 4, 4)
     out = tr.learner.train((fr, torch.from_numpy(a).float(), torch.from_numpy(r), torch.from_numpy(d).float(), torch.from_numpy(w), torch.arange(B).float()))
     assert out["q_loss"].shape == (B,) and out["indices"].dtype == torch.int64
+    assert out["q_loss"].device.type == "cpu" and out["indices"].device.type == "cpu", "CPU copies like the reference's .detach().cpu() (agent.py:163-169)"
 
 
 def test_model_api_matches_reference_shapes():

@@ -1,4 +1,4 @@
-"""GPU micro-benchmark (diagnostics): the fused encoder forward alone, at several launch sizes (select a variant library with A0_LIB)."""
+"""GPU micro-benchmark (diagnostics): the fused encoder forward alone, at several launch sizes (against a tuning build: python tools/with_lib.py <lib> tools/ubench_encoder_fwd.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -28,4 +28,4 @@ for B in (128, 256, 512, 1024, 4096):
     t = timeit(lambda: hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), frames, None, 28224, 0, B, None, None, ws.act3))
     tk = timeit(lambda: hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), frames, None, 28224, 0, B, ws.act1, ws.act2, ws.act3))
     out.append(f"B={B}: {t:.1f} us (+store {tk:.1f})")
-print(os.environ.get("A0_LIB", "default").split("/")[-1], " | ".join(out))
+print(hip.build_info(), " | ".join(out))
