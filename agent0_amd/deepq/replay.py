@@ -128,10 +128,47 @@ class ReplayDataset:
         return self.written % self.size
 
     # ------------------------------------------------------------------ insert
+    def _stage_tuples(self, transitions) -> TransitionBlock:
+        """The reference's transition list (agent.py:78-81: ``(compress(concatenate((st, st_next))), at, rt, dt)`` per env and step) -> staged
+        device buffers.  The frame blob may be the raw ``st || st_next`` bytes (bytes / bytearray / memoryview / uint8 array of row_bytes
+        elements) or, when its length differs from row_bytes, an lz4 block as the reference stores it (needs the ``lz4`` module)."""
+        n = len(transitions)
+        rows = np.empty((n, self.row_bytes), dtype=np.uint8)
+        act, rew, done = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float32), np.empty(n, dtype=np.float32)
+        for i, tr in enumerate(transitions):
+            if not isinstance(tr, (tuple, list)) or len(tr) != 4:
+                raise TypeError(f"ReplayDataset.extend: item {i} is not a (frames, action, reward, done) tuple")
+            blob, at, rt, dt = tr
+            if isinstance(blob, np.ndarray):
+                flat = np.ascontiguousarray(blob, dtype=np.uint8).reshape(-1)
+            else:
+                raw = bytes(blob)
+                if len(raw) != self.row_bytes:
+                    try:
+                        from lz4.block import decompress
+                    except ImportError as e:
+                        raise ValueError(f"ReplayDataset.extend: item {i} holds {len(raw)} bytes, a raw row is {self.row_bytes}; compressed rows need the lz4 module") from e
+                    raw = decompress(raw)
+                flat = np.frombuffer(raw, dtype=np.uint8)
+            if flat.size != self.row_bytes:
+                raise ValueError(f"ReplayDataset.extend: item {i} has {flat.size} frame bytes, expected {self.row_bytes} (st || st_next)")
+            rows[i] = flat
+            act[i], rew[i], done[i] = int(at), float(rt), float(bool(dt))      # the reference's float64 n-step sums are rounded to fp32 once
+        dev = self.ops.device
+        t = torch.from_numpy(rows).to(dev)
+        return TransitionBlock(n, staged={"obs": t[:, : self.obs_bytes].contiguous(), "obs_next": t[:, self.obs_bytes:].contiguous(),
+                                          "act": torch.from_numpy(act).to(dev), "rew": torch.from_numpy(rew).to(dev), "done": torch.from_numpy(done).to(dev)})
+
     def extend(self, transitions):
-        """replay.py:45-53.  ``transitions`` is a TransitionBlock produced by the device Actor."""
+        """replay.py:45-53.  ``transitions``: the TransitionBlock the device Actor returns (rows already in HBM; the hot path), or the
+        reference's own list of ``(frames, at, rt, dt)`` tuples — what its Actor.sample / TrainerNode hand over (agent.py:78-81,
+        launch.py:49-62) — which is staged to the device and inserted with a0_replay_insert."""
+        if isinstance(transitions, (list, tuple)):
+            if len(transitions) == 0:
+                return
+            transitions = self._stage_tuples(transitions)
         if not isinstance(transitions, TransitionBlock):
-            raise TypeError("ReplayDataset.extend takes the TransitionBlock returned by Actor.sample (transitions stay on the device)")
+            raise TypeError("ReplayDataset.extend takes the TransitionBlock returned by Actor.sample or the reference's list of (frames, action, reward, done) tuples")
         n = transitions.count
         if transitions.source is not None:
             src, done_rows = transitions.source, 0

@@ -193,6 +193,13 @@ def batch_tuple(frames_u8, actions, rewards, terminals, weights, indices):
 OUT = {}
 
 
+ONLY = [n for n in os.environ.get("A0_GOLDEN_ONLY", "").split(",") if n]      # spec names: (re)generate just their G1 / G3 / G6 fixtures
+
+
+def wanted(name: str) -> bool:
+    return not ONLY or name in ONLY
+
+
 def save(name, **arrays):
     path = os.path.join(HERE, f"{name}.npz")
     meta = dict(torch_version=np.array(torch.__version__), numpy_version=np.array(np.__version__))
@@ -205,6 +212,8 @@ def save(name, **arrays):
 def g1_forward():
     print("G1 forward/qval per algo")
     for name, spec in SPECS.items():
+        if not wanted(name):
+            continue
         B = 8
         cfg = ref_cfg(spec, B)
         inj = Injector(1000 + len(name))
@@ -321,8 +330,11 @@ def g3_losses():
         ("fqf", 8, False, 1), ("fqf", 8, True, 3),
         ("dqn_tiny", 32, True, 1), ("c51_tiny", 32, True, 3),
         ("dqn", 512, False, 1), ("c51", 512, True, 3),
+        ("fqf_duel", 8, True, 3), ("dqn_duel_a18", 8, True, 1), ("fqf_duel_a18", 8, True, 3),
     ]
     for name, B, dq, ns in cases:
+        if not wanted(name):
+            continue
         arrays = run_train_step(name, SPECS[name], B, double_q=dq, n_step=ns, seed=3000 + B + ns)
         save(f"g3_{name}_b{B}_dq{int(dq)}_n{ns}", **arrays)
 
@@ -399,8 +411,11 @@ def g6_train():
     print("G6 full learner.train(): post-step parameter fingerprints")
     cases = [("dqn", 16, False, 1), ("dqn_duel", 16, True, 3), ("c51_duel_noisy", 16, True, 3), ("c51", 16, False, 1),
              ("qr", 16, False, 1), ("iqn", 16, False, 1), ("fqf", 16, False, 1), ("mdqn", 16, False, 1),
-             ("dqn_tiny", 32, True, 1), ("c51_tiny", 32, True, 3), ("dqn", 512, False, 1)]
+             ("dqn_tiny", 32, True, 1), ("c51_tiny", 32, True, 3), ("dqn", 512, False, 1),
+             ("fqf_duel", 16, True, 3), ("dqn_duel_a18", 16, True, 1), ("fqf_duel_a18", 16, True, 3)]
     for name, B, dq, ns in cases:
+        if not wanted(name):
+            continue
         spec = SPECS[name]
         cfg = ref_cfg(spec, B, double_q=dq, n_step=ns)
         cfg.learner.target_update_freq = 2

@@ -211,6 +211,11 @@ SPECS: Dict[str, NetSpec] = {
     "iqn": NetSpec("iqn", 9),
     "iqn_duel": NetSpec("iqn", 4, dueling=True),
     "fqf": NetSpec("fqf", 9),
+    # the reference's own 8-game suite (README.md:62-112, atari8_double_duel_prior): fqf + double-Q + dueling + prioritized; and the largest
+    # action set of that suite (Seaquest: the full 18 ALE actions)
+    "fqf_duel": NetSpec("fqf", 9, dueling=True),
+    "dqn_duel_a18": NetSpec("dqn", 18, dueling=True),
+    "fqf_duel_a18": NetSpec("fqf", 18, dueling=True),
     # tiny geometry: conv stack output 1x1x64 (36x36 input), fast kernel tests
     "dqn_tiny": NetSpec("dqn", 4, obs_shape=(4, 36, 36)),
     "c51_tiny": NetSpec("c51", 6, dueling=True, noisy=True, obs_shape=(4, 36, 36)),

@@ -33,6 +33,13 @@ CASES = {
     "fqf": NetSpec("fqf", 4, obs_shape=TINY),
     "dqn_noisy": NetSpec("dqn", 4, noisy=True, obs_shape=TINY),
     "mdqn": NetSpec("mdqn", 5, obs_shape=TINY),
+    # the reference's suite configuration (README.md:62-112: fqf + double-Q + dueling) and the 18-action games (Seaquest)
+    "fqf_duel": NetSpec("fqf", 9, dueling=True, obs_shape=TINY),
+    "dqn_duel_a18": NetSpec("dqn", 18, dueling=True, obs_shape=TINY),
+    "dqn_a24": NetSpec("dqn", 24, obs_shape=TINY),             # upper end of the head/loss kernel's A + dueling <= 24 range
+    "dqn_duel_a24": NetSpec("dqn", 24, dueling=True, obs_shape=TINY),      # just beyond it: the generic path
+    "fqf_duel_a18": NetSpec("fqf", 18, dueling=True, obs_shape=TINY),
+    "c51_duel_a18": NetSpec("c51", 18, dueling=True, num_atoms=51, obs_shape=TINY),
     "dqn_odd": NetSpec("dqn", 4, obs_shape=(4, 44, 52)),   # non-square, odd conv1 output (10x12 -> 4x5 -> 2x3)
 }
 
@@ -192,7 +199,9 @@ def run_both(ops, name, B, double_q, n_step, steps=2, target_freq=2, resync=True
 
 TRAIN = [("dqn", 8, False, 1), ("dqn_duel", 8, True, 3), ("c51", 8, False, 1), ("c51_duel_noisy", 8, True, 3), ("qr", 6, False, 1),
          ("qr_duel_noisy", 6, True, 1), ("iqn", 6, False, 1), ("iqn_duel", 6, True, 3), ("fqf", 6, False, 1), ("fqf", 6, True, 3),
-         ("dqn_noisy", 8, True, 1), ("dqn_odd", 8, True, 1), ("mdqn", 8, False, 3)]
+         ("dqn_noisy", 8, True, 1), ("dqn_odd", 8, True, 1), ("mdqn", 8, False, 3),
+         ("fqf_duel", 6, True, 3), ("dqn_duel_a18", 8, True, 1), ("dqn_a24", 8, False, 1), ("dqn_duel_a24", 8, True, 3), ("fqf_duel_a18", 6, True, 3),
+         ("c51_duel_a18", 6, True, 3)]
 
 
 def check_update(ops, name, B, dq, n, **kw):
@@ -312,6 +321,73 @@ def check_update_full_size(ops, spec, hp, B, seed=61, lr=5e-4):
         assert float((tol > 1e-4).float().mean()) <= 2e-2, f"{k}: a tolerance above 1e-4 (a fifth of one Adam step) applies to more than 2 % of the elements"
     assert int(dev.state[1]) == ora.update_steps == 1
     return stats
+
+
+def check_update_fqf_own_fractions(ops, spec, hp, B, seed=61, bounds=None):
+    """One FQF update in which the DEVICE proposes its own fractions (a0_fqf_taus -> cosine embedding -> head -> losses -> gradients), against
+    the oracle proposing its own.  The injected-fraction tests above compare q(tau) at bit-identical fractions and therefore cannot see a
+    wiring error between a0_fqf_taus and the rest of the update; this one can.  The two softmax / cumsum evaluations differ by a few ulp
+    (asserted: fractions to 1e-5 absolute) and cos(pi * i * tau), i <= 64, amplifies that ~200x into the quantile values, so the comparison
+    is a bounded-outlier one: the median and the 99th percentile of the per-sample loss error (relative to the batch's mean |loss|), the worst
+    element of every gradient tensor relative to the tensor's max, the share of parameters further than 2e-5 + a fifth of an Adam step from the
+    oracle's.  A mis-wired fraction buffer moves all of these by O(1).  -> the measured metrics."""
+    L = NetLayout.from_spec(spec)
+    sd_o, sd_t = recipe.make_state_dict(spec, 11), recipe.make_state_dict(spec, 12)
+    dev = DeviceLearner(ops, L, B, n_step=hp.n_step, double_q=hp.double_q, target_update_freq=1)
+    dev.online.load_state_dict(sd_o)
+    dev.target.load_state_dict(sd_t)
+    frames = recipe.make_frames(B, seed, spec.obs_shape)
+    a, r, d, w = recipe.make_transitions(B, spec.action_dim, seed + 1)
+    D = lambda t: t.to(ops.device)
+    out = dev.update(D(torch.from_numpy(frames).reshape(-1)), None, 2 * int(np.prod(spec.obs_shape)), D(torch.from_numpy(a.astype(np.int32))), D(torch.from_numpy(r)),
+                     D(torch.from_numpy(d.astype(np.float32))), D(torch.from_numpy(w)), rand=None)
+    loss_d, frac_d = out
+    F = L.F
+    dev_taus = [(dev.ws_o.tau_all[: B * (F + 1)].view(B, F + 1).cpu().clone(), dev.ws_o.tau_hat[: B * F].view(B, F).cpu().clone())]
+    ws_sel = dev.ws_s if hp.double_q else dev.ws_t
+    dev_taus.append((ws_sel.tau_all[: B * (F + 1)].view(B, F + 1).cpu().clone(), ws_sel.tau_hat[: B * F].view(B, F).cpu().clone()))
+    ora = olearner.OracleLearner(spec, sd_o, sd_t, hp, batch_size=B, target_update_freq=1)
+    nets.TAU_LOG = []
+    try:
+        res = ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B))
+        log = nets.TAU_LOG
+    finally:
+        nets.TAU_LOG = None
+    assert len(log) == 2
+    m = {}
+    for k, ((t_d, th_d), (t_o, th_o)) in enumerate(zip(dev_taus, log)):
+        m[f"taus_{k}"] = max(float((t_d - t_o.reshape(B, F + 1)).abs().max()), float((th_d - th_o.reshape(B, F)).abs().max()))
+        assert m[f"taus_{k}"] <= 1e-5, f"fractions of pass {k}: {m[f'taus_{k}']:.2e}"
+        assert float(t_d[:, 0].abs().max()) == 0.0 and float((t_d[:, -1] - 1).abs().max()) <= 1e-5 and bool((t_d[:, 1:] >= t_d[:, :-1]).all())
+    for tag, got, want in (("q_loss", loss_d[:B].cpu(), res["q_loss"]), ("fraction_loss", frac_d[:B].cpu(), res["fraction_loss"])):
+        err = (got - want).abs() / (float(want.abs().mean()) + 1e-12)
+        m[f"{tag}_median"], m[f"{tag}_p99"], m[f"{tag}_max"] = float(err.median()), float(err.kthvalue(max(1, int(0.99 * B))).values), float(err.max())
+    g_dev = L.unpack(dev.grads)
+    worst = ("", 0.0)
+    for k, g in ora.last_grads.items():
+        if g is None:
+            continue
+        e = float((g_dev[k].cpu() - g).abs().max()) / (float(g.abs().max()) + 1e-12)
+        if e > worst[1]:
+            worst = (k, e)
+    m["grad_worst"], m["grad_worst_tensor"] = worst[1], worst[0]
+    got = dev.online.state_dict()
+    far = tot = 0
+    for k in nets.trainable_keys(ora.po):
+        err = (got[k].cpu() - ora.po[k].detach()).abs()
+        lr_k = 0.0 if "fraction" in k else 5e-4
+        far += int((err > 2e-5 + 0.2 * lr_k).sum()); tot += err.numel()
+    m["params_far_share"] = far / tot
+    b = dict(q_loss_median=2e-4, q_loss_p99=5e-3, q_loss_max=5e-2, fraction_loss_median=2e-3, fraction_loss_p99=5e-2, grad_worst=2e-2, params_far_share=2e-2)
+    b.update(bounds or {})
+    for k, v in b.items():
+        assert m[k] <= v, f"{k} = {m[k]:.3e} exceeds {v:.1e} ({m})"
+    return m
+
+
+@pytest.mark.parametrize("name", ["fqf", "fqf_duel", "fqf_duel_a18"])
+def test_fqf_update_with_device_fractions(ops, name):
+    print(check_update_fqf_own_fractions(ops, CASES[name], Hyper(double_q=(name != "fqf"), n_step=3), 16))
 
 
 def check_nan_skip(ops):

@@ -90,7 +90,7 @@ def _case(case):
 
 G3_GPU = ["dqn_b8_dq0_n1", "dqn_b8_dq1_n3", "dqn_duel_b8_dq1_n1", "mdqn_b8_dq0_n1", "c51_b8_dq0_n1", "c51_b8_dq1_n3", "c51_duel_noisy_b8_dq1_n3",
           "qr_b8_dq0_n1", "qr_duel_b8_dq1_n3", "iqn_b8_dq0_n1", "iqn_duel_b8_dq1_n3", "fqf_b8_dq0_n1", "fqf_b8_dq1_n3", "dqn_tiny_b32_dq1_n1",
-          "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1", "c51_b512_dq1_n3"]
+          "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1", "c51_b512_dq1_n3", "fqf_duel_b8_dq1_n3", "dqn_duel_a18_b8_dq1_n1", "fqf_duel_a18_b8_dq1_n3"]
 
 
 def test_every_committed_g3_g6_fixture_reaches_the_gpu():
@@ -133,7 +133,8 @@ def test_golden_losses(hip, case):
 
 
 G6_GPU = ["dqn_b16_dq0_n1", "dqn_duel_b16_dq1_n3", "c51_duel_noisy_b16_dq1_n3", "c51_b16_dq0_n1", "qr_b16_dq0_n1", "iqn_b16_dq0_n1", "fqf_b16_dq0_n1",
-          "mdqn_b16_dq0_n1", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1"]
+          "mdqn_b16_dq0_n1", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1", "fqf_duel_b16_dq1_n3", "dqn_duel_a18_b16_dq1_n1",
+          "fqf_duel_a18_b16_dq1_n3"]
 
 
 @pytest.mark.parametrize("case", G6_GPU)
@@ -249,8 +250,21 @@ def test_golden_quantile_huber(hip, tag):
     assert int(state[0]) == 0
 
 
-@pytest.mark.parametrize("algo,A,dq,n", [("dqn", 4, False, 1), ("c51", 4, True, 3), ("iqn", 9, True, 3), ("fqf", 9, False, 1)])
-def test_update_full_size(hip, algo, A, dq, n):
+def _record(name, payload):
+    """Measured statistics of a GPU test, for profiles/ (gpurun merges gpurun_out/ back): one JSON file per statistic and case."""
+    import json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_stats")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(payload, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("algo,A,dq,n,duel", [("dqn", 4, False, 1, False), ("c51", 4, True, 3, False), ("iqn", 9, True, 3, False), ("fqf", 9, False, 1, False),
+                                              ("dqn", 18, True, 1, True), ("fqf", 18, True, 3, True), ("fqf", 9, True, 3, True)])
+def test_update_full_size(hip, algo, A, dq, n, duel):
     """BASELINE configs[1..4] at their real geometry — 84x84 observations, B = 512; Breakout's A = 4 for dqn / c51, Asterix's A = 9 with
     IQN N = N' = 64, K = 32 and FQF F = 32 — one whole update against the oracle: per-sample losses, every gradient tensor (the
     cosine-embedding weight gradient, Hadamard backward and the fc1 GEMMs over B*64 = 32 768 rows included), parameters and target after
@@ -258,8 +272,30 @@ def test_update_full_size(hip, algo, A, dq, n):
     the two effects of scale — ReLU decisions at rounding-level pre-activations, Adam's sign-like first step at eps = 2e-5 — separated
     out and bounded (tests/test_engine_emul.py::check_update_full_size)."""
     from oracle.losses import Hyper
-    stats = E.check_update_full_size(hip, recipe.NetSpec(algo, A, **({"num_atoms": 51} if algo == "c51" else {})), Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), 512)
+    # the last three: the reference's own suite configuration (README.md:62-112, atari8_double_duel_prior: fqf + double-Q + dueling) at
+    # Asterix's A = 9 and Seaquest's A = 18, and the 18-action dueling dqn head (upper range of the head/loss kernel's A + dueling <= 24 path)
+    stats = E.check_update_full_size(hip, recipe.NetSpec(algo, A, dueling=duel, **({"num_atoms": 51} if algo == "c51" else {})), Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), 512)
     print({k: (v[0], v[1], f"{v[2]:.1e}") for k, v in stats.items()})
+    _record(f"relu_decisions_{algo}_a{A}_duel{int(duel)}_dq{int(dq)}_n{n}_b512",
+            {k: {"differ": int(v[0]), "of": int(v[1]), "largest_preactivation_rel": float(v[2])} for k, v in stats.items()})
+
+
+@pytest.mark.parametrize("name", ["fqf", "fqf_duel", "fqf_duel_a18"])
+def test_fqf_update_with_device_fractions(hip, name):
+    """The un-injected FQF update at the small geometry: the device's own a0_fqf_taus -> cos -> head -> loss -> gradient chain against
+    the oracle's own fractions (tests/test_engine_emul.py::check_update_fqf_own_fractions, bounded-outlier metric)."""
+    from oracle.losses import Hyper
+    m = E.check_update_fqf_own_fractions(hip, E.CASES[name], Hyper(double_q=(name != "fqf"), n_step=3), 16)
+    print(m)
+
+
+@pytest.mark.parametrize("A,duel,dq", [(9, False, False), (18, True, True)])
+def test_fqf_update_with_device_fractions_full_size(hip, A, duel, dq):
+    """... and at BASELINE configs[4]'s geometry (84x84, B = 512, F = 32; Asterix A = 9 plain, Seaquest A = 18 dueling + double-Q)."""
+    from oracle.losses import Hyper
+    m = E.check_update_fqf_own_fractions(hip, recipe.NetSpec("fqf", A, dueling=duel), Hyper(double_q=dq, n_step=3), 512)
+    print(m)
+    _record(f"fqf_device_fractions_a{A}_duel{int(duel)}_b512", m)
 
 
 def test_gather_fused_equals_dense_batch(hip):

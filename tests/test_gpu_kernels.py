@@ -23,8 +23,10 @@ def D(hip, x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
 
 
-@pytest.mark.parametrize("size", [1, 5, 24, 1000, 100000])
+@pytest.mark.parametrize("size", [1, 5, 24, 1000, 100000, 1_000_000])
 def test_sumtree_bit_exact(hip, size):
+    """Every node of the tree after priority updates, the sampled leaves and their priorities, and a bulk rebuild, bit for bit against
+    oracle/sumtree.c — up to BASELINE's full replay size (1 M leaves, 2^21 nodes, 20 levels)."""
     g = recipe.gen(size)
     t = core.SumTree(size)
     tree = hip.zeros(2 * t.cap2)
@@ -37,7 +39,7 @@ def test_sumtree_bit_exact(hip, size):
         t.set(idx, val)
         hip.sumtree_set(tree, t.cap2, D(hip, idx.astype(np.int64)), D(hip, val), n)
         assert np.array_equal(tree.cpu().numpy(), t.tree), "tree bytes after set"
-        B = 64
+        B = 64 if size < 100000 else 512
         xi = g.random(B).astype(np.float32)
         want_i, want_p = t.sample(xi)
         out_i, out_p = hip.zeros(B, dtype=torch.int64), hip.zeros(B)
@@ -418,3 +420,52 @@ def test_priority_update_of_a_batch_larger_than_one_workgroup(hip):
         hip.sumtree_set(rp.tree, rp.cap2, D(hip, ids.astype(np.int64)), D(hip, val), B)
     b = rp.sample()                          # B > 1024 takes the unfused sampling path
     assert int(b.idx.min()) >= 0 and int(b.idx.max()) < size and torch.isfinite(b.weights).all()
+
+
+@pytest.mark.parametrize("size,prioritize", [(64, False), (40, True)])
+def test_replay_extend_accepts_the_reference_transition_list(hip, size, prioritize):
+    """ReplayDataset.extend(list) with the reference's own transition tuples (agent.py:78-81: ``(frames blob, at, rt, dt)`` per env and
+    step; replay.py:45-53) — what its Actor.sample / TrainerNode hand over.  The list is produced by the oracle actor under the G7 script
+    (whose blobs are pinned to the reference's by the g7 fixture's hashes); after the insert the ring must hold exactly those rows, in the
+    reference's deque order, also when the ring wraps (size 40 < 48 transitions)."""
+    import hashlib
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.replay import ReplayDataset
+    from test_oracle_golden import FakeEnv, _script, params_for
+    from util import golden
+    n_step = 3
+    g = golden(f"g7_actor_n{n_step}_life1")
+    spec = recipe.SPECS["dqn"]
+    E, T = 4, 12
+    env = FakeEnv(E, _script(E, T, 70 + n_step, True))
+    it = iter(zip(g["draws_int"], g["draws_u"]))
+    act = oactor.OracleActor(env, params_for(spec, 11), spec, n_step=n_step, sample_steps=6, draw=lambda E_: next(it))
+    cfg = parse_overrides([f"replay.size={size}", "learner.batch_size=8", "wandb=false", "tb=false"] + (["replay.policy=prioritize"] if prioritize else []))
+    cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
+    rp = ReplayDataset(cfg, ops=hip)
+    rp.extend([])
+    assert len(rp) == 0
+    everything = []
+    for call in range(2):
+        data, _, _ = act.sample(float(g["eps"]))
+        # the blob in every form a caller may hold it: (8, 84, 84) array, flat array, bytes, bytearray, memoryview; rewards as numpy float64
+        forms = [lambda f: f, lambda f: f.reshape(-1), lambda f: f.tobytes(), lambda f: bytearray(f.tobytes()), lambda f: memoryview(f.tobytes())]
+        lst = [(forms[i % 5](frames), at, rt, dt) for i, (frames, at, rt, dt) in enumerate(data)]
+        rp.extend(lst)
+        everything += data
+        assert len(rp) == min(len(everything), size) and rp.written == len(everything)
+    n = len(everything)
+    assert n == 48
+    hashes = [np.frombuffer(hashlib.sha256(f.tobytes()).digest()[:8], dtype=np.uint64)[0] for f, *_ in everything]
+    assert np.array_equal(np.array(hashes, dtype=np.uint64), g["blob_hash"]), "the list itself is the reference's (g7 fixture)"
+    first = n - len(rp)                     # the deque dropped the oldest entries
+    for i in range(len(rp)):
+        row, at, rt, dt, pr, idx = rp[i]
+        f, a_w, r_w, d_w = everything[first + i]
+        assert np.array_equal(row, f.reshape(-1)) and at == int(a_w) and rt == float(np.float32(r_w)) and dt == bool(d_w) and idx == i
+    if prioritize:
+        assert float(rp.priority[-1]) == 1.0 and 0.4 < rp.beta < 0.41
+    with pytest.raises(ValueError, match="frame bytes|lz4"):
+        rp.extend([(b"\x00" * 100, 0, 0.0, False)])
+    with pytest.raises(TypeError):
+        rp.extend([(1, 2, 3)])

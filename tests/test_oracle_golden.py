@@ -83,7 +83,9 @@ def test_g2_layers():
 
 G3 = ["dqn_b8_dq0_n1", "dqn_b8_dq1_n3", "dqn_duel_b8_dq1_n1", "mdqn_b8_dq0_n1", "c51_b8_dq0_n1", "c51_b8_dq1_n3",
       "c51_duel_noisy_b8_dq1_n3", "qr_b8_dq0_n1", "qr_duel_b8_dq1_n3", "iqn_b8_dq0_n1", "iqn_duel_b8_dq1_n3",
-      "fqf_b8_dq0_n1", "fqf_b8_dq1_n3", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1", "c51_b512_dq1_n3"]
+      "fqf_b8_dq0_n1", "fqf_b8_dq1_n3", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1", "c51_b512_dq1_n3",
+      # the reference's own suite configuration (README.md:62-112: fqf + double-Q + dueling) and the 18-action games
+      "fqf_duel_b8_dq1_n3", "dqn_duel_a18_b8_dq1_n1", "fqf_duel_a18_b8_dq1_n3"]
 
 
 def parse_case(case):
@@ -150,7 +152,8 @@ def test_g5_quantile_huber(tag):
 
 
 G6 = ["dqn_b16_dq0_n1", "dqn_duel_b16_dq1_n3", "c51_duel_noisy_b16_dq1_n3", "c51_b16_dq0_n1", "qr_b16_dq0_n1",
-      "iqn_b16_dq0_n1", "fqf_b16_dq0_n1", "mdqn_b16_dq0_n1", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1"]
+      "iqn_b16_dq0_n1", "fqf_b16_dq0_n1", "mdqn_b16_dq0_n1", "dqn_tiny_b32_dq1_n1", "c51_tiny_b32_dq1_n3", "dqn_b512_dq0_n1",
+      "fqf_duel_b16_dq1_n3", "dqn_duel_a18_b16_dq1_n1", "fqf_duel_a18_b16_dq1_n3"]
 
 
 def run_oracle_g6(case, g):
