@@ -29,7 +29,14 @@ from util import assert_close
 
 pytestmark = pytest.mark.gpu
 
-E_, T_, B_, SIZE, LSTEPS, START, TFREQ = 8, 10, 32, 200, 3, 100, 4
+import collections
+
+Dims = collections.namedtuple("Dims", "E T B size lsteps start tfreq")
+SMALL = Dims(8, 10, 32, 200, 3, 100, 4)
+# BASELINE configs[0]'s actor / learner sizes (reference config.py:108-120 defaults: 16 envs x 80 steps per rollout, batch 512) on a ring that
+# wraps in the fourth rollout (the 100 k default would make every whole-ring comparison a 5.6 GB copy); two updates per block
+CONFIG0 = Dims(16, 80, 512, 4000, 2, 2000, 3)
+E_, T_, B_, SIZE, LSTEPS, START, TFREQ = SMALL
 
 
 def device_noise(net):
@@ -42,16 +49,21 @@ def device_noise(net):
     return out
 
 
-def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS, spec_name=None):
+def _build(algo, policy, sumtree, n_step, double_q, launch, ls=None, spec_name=None, dims=SMALL):
     from agent0_amd.deepq.config import parse_overrides
     from agent0_amd.deepq.trainer import Trainer
+    E_, T_, B_, SIZE, LSTEPS, START, TFREQ = dims
+    ls = LSTEPS if ls is None else ls
+    total = 20 * E_ * T_ * 5 // 2
     over = [f"learner.algo={algo}", f"actor.num_envs={E_}", f"actor.sample_steps={T_}", f"learner.batch_size={B_}", f"replay.size={SIZE}",
             f"learner.learner_steps={ls}", f"trainer.training_start_steps={START}", f"learner.target_update_freq={TFREQ}", f"learner.n_step_q={n_step}",
             f"learner.double_q={str(double_q).lower()}", f"replay.policy={policy}", f"replay.sumtree={str(sumtree).lower()}", "trainer.exploration_steps=100",
-            "trainer.total_steps=4000", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"]
+            f"trainer.total_steps={total}", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"]
     spec = recipe.SPECS[spec_name or algo]
     if spec.action_dim == 9:
         over.append("env_id=Asterix")                    # nine actions (BASELINE configs[3])
+    elif spec.action_dim == 18:
+        over.append("env_id=Seaquest")                   # the full ALE action set (the largest head of the reference's 8-game suite)
     over += [f"learner.dueling_head={str(bool(spec.dueling)).lower()}", f"learner.noisy_net={str(bool(spec.noisy)).lower()}"]
     cfg = parse_overrides(over)
     tr = Trainer(cfg, use_lp=launch)
@@ -76,7 +88,7 @@ def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS, spec_name
 
         amodel.reset_noise = reset_noise
     ora = OracleTrainer(spec, sd, num_envs=E_, sample_steps=T_, batch_size=B_, replay_size=SIZE, learner_steps=ls, training_start_steps=START, policy=policy,
-                        sumtree=sumtree, n_step=n_step, double_q=double_q, seed=cfg.seed, target_update_freq=TFREQ, total_steps=4000, exploration_steps=100,
+                        sumtree=sumtree, n_step=n_step, double_q=double_q, seed=cfg.seed, target_update_freq=TFREQ, total_steps=total, exploration_steps=100,
                         launch=launch, reset_noise_freq=cfg.learner.reset_noise_freq, actor_noise=(lambda: actor_q.pop(0)) if spec.noisy else None,
                         learner_noise=(lambda: learner_box.pop(0)) if spec.noisy else None)
     ora._learner_box = learner_box
@@ -84,8 +96,12 @@ def _build(algo, policy, sumtree, n_step, double_q, launch, ls=LSTEPS, spec_name
 
 
 class LockStep:
-    def __init__(self, tr, ora, spec):
-        self.tr, self.ora, self.spec = tr, ora, spec
+    def __init__(self, tr, ora, spec, tfreq=SMALL.tfreq, free_running=False):
+        """``free_running``: nothing is copied from the oracle to the device after an update (parameters, Adam moments, priorities and importance
+        weights all keep the device's own values), the per-update comparisons that assume a common pre-step state are replaced by drift
+        records (``self.drift``), and everything discrete — ring bytes, actions, n-step rewards, indices, slots — must STILL be identical."""
+        self.tr, self.ora, self.spec, self.tfreq, self.free = tr, ora, spec, tfreq, free_running
+        self.drift = []
         self.rp, self.eng, self.L = tr.replay, tr.learner.engine, tr.learner.engine.L
         self.rec = None
         self.n_ext = self.n_upd = self.relu_flips = 0
@@ -157,7 +173,7 @@ class LockStep:
             assert rp.head == ora.replay.head, "deque index 0 sits at the same ring slot"
         if ora.prioritize:
             assert rp.beta == ora.replay.beta, f"extend {self.n_ext}: beta"
-            self._cmp_priorities(0, f"extend {self.n_ext}")
+            self._cmp_priorities(1 if self.free else 0, f"extend {self.n_ext}")
 
     def sample(self, *a, **k):
         b = self._sample(*a, **k)
@@ -169,9 +185,15 @@ class LockStep:
         assert np.array_equal(rows, rec.frames.reshape(len(rec.idx), -1)), f"{tag}: the rows the learner will read"
         assert np.array_equal(b.act.cpu().numpy(), rec.act) and np.array_equal(b.rew.cpu().numpy(), rec.rew) and np.array_equal(b.done.cpu().numpy(), rec.done)
         if self.ora.prioritize:
-            assert np.array_equal(b.prio.cpu().numpy(), rec.prio), f"{tag}: priorities of the batch"
-            assert_close(b.weights, rec.weights, 2e-6, 1e-7, f"{tag}: importance weights")
-            b.weights.copy_(torch.from_numpy(rec.weights))
+            if self.free:
+                assert_close(b.prio, rec.prio, 2e-4, 0, f"{tag}: priorities of the batch (free-running)")
+            else:
+                assert np.array_equal(b.prio.cpu().numpy(), rec.prio), f"{tag}: priorities of the batch"
+            if self.free:        # the priorities carry the device's own losses: compared, not overwritten
+                assert_close(b.weights, rec.weights, 2e-4, 1e-6, f"{tag}: importance weights (free-running)")
+            else:
+                assert_close(b.weights, rec.weights, 2e-6, 1e-7, f"{tag}: importance weights")
+                b.weights.copy_(torch.from_numpy(rec.weights))
         else:
             assert np.array_equal(b.weights.cpu().numpy(), rec.weights)
         return b
@@ -216,8 +238,24 @@ class LockStep:
         finally:
             nets.RELU_MASKS = None
         for name, (n_bad, n, worst) in nets.RELU_STATS.items():
-            assert worst <= 1e-5 and n_bad <= 1e-4 * n, f"{tag}: ReLU decisions of {name}: {n_bad}/{n} differ, largest |pre-activation| {worst:.2e} of the layer's largest"
+            assert worst <= (1e-4 if self.free else 1e-5) and n_bad <= 1e-4 * n, f"{tag}: ReLU decisions of {name}: {n_bad}/{n} differ, largest |pre-activation| {worst:.2e} of the layer's largest"
             self.relu_flips += n_bad
+        if self.free:
+            # drift record of this update: per-sample losses, every gradient tensor (of its max), parameters, Adam moments — device state vs
+            # oracle state, each having run all previous updates on its own
+            B = len(rec.idx)
+            got = self.eng.online.state_dict()
+            g_dev = {key: val.cpu() for key, val in self.L.unpack(self.eng.grads).items()}
+            m = self.L.unpack(self.eng.adam_m)
+            d = {"update": self.n_upd,
+                 "loss_rel": float(((q[:B].cpu() - rec.q_loss).abs() / (rec.q_loss.abs() + 1e-3)).max()),
+                 "grad_of_max": max(float((g_dev[key] - ol.last_grads[key]).abs().max() / (ol.last_grads[key].abs().max() + 1e-12)) for key in ol.q_keys),
+                 "param_abs": max(float((got[key].cpu() - ol.po[key].detach()).abs().max()) for key in ol.q_keys),
+                 "adam_m_of_max": max(float((m[key].cpu() - ol.adam.m[key]).abs().max() / (ol.adam.m[key].abs().max() + 1e-12)) for key in ol.q_keys)}
+            self.drift.append(d)
+            assert int(self.eng.state[1]) == ol.update_steps
+            self.n_upd += 1
+            return q, f
         assert_close(q[: len(rec.idx)], rec.q_loss, 5e-5, 5e-6, f"{tag}: per-sample loss")
         if rec.fraction_loss is not None:
             assert_close(f[: len(rec.idx)], rec.fraction_loss, 5e-5, 2e-5, f"{tag}: fraction loss")
@@ -233,7 +271,7 @@ class LockStep:
         ad = olearner.Adam(ol.adam.lr, ol.adam.eps)
         ad.t, ad.m, ad.v = pre_steps, pre_m, pre_v
         ad.step(pre_p, {key: g_dev[key] for key in ol.q_keys})
-        synced = ol.update_steps % TFREQ == 0
+        synced = ol.update_steps % self.tfreq == 0
         for key in ol.q_keys:
             assert_close(got[key], pre_p[key], 0, 2e-6, f"{tag}: param {key} after Adam")
             if synced:
@@ -256,6 +294,8 @@ class LockStep:
     def update(self, ids, pr, state=None):
         self._update(ids, pr, state=state)
         self.ora.update_priority(self.rec)
+        if self.free:
+            return
         self._cmp_priorities(1, f"update {self.n_upd - 1} priorities")
         self._resync_priorities()
 
@@ -265,29 +305,68 @@ CASES = [("dqn", "uniform", False, 1, False, False, None), ("dqn", "prioritize",
          ("c51", "prioritize", True, 3, True, False, None), ("dqn", "uniform", False, 3, False, True, None), ("c51", "prioritize", True, 1, True, True, None),
          ("c51", "prioritize", True, 3, True, False, "c51_duel_noisy"), ("c51", "prioritize", True, 3, True, True, "c51_duel_noisy"),
          ("iqn", "uniform", False, 1, True, False, "iqn"),       # BASELINE configs[3]: Asterix iqr — actor and learner taus from their Philox streams
-         ("fqf", "uniform", False, 1, False, False, "fqf")]      # BASELINE configs[4] on one rank: Asterix fqf, the learner at the oracle's fractions
+         ("fqf", "uniform", False, 1, False, False, "fqf"),      # BASELINE configs[4] on one rank: Asterix fqf, the learner at the oracle's fractions
+         # the reference's own 8-game suite configuration (README.md:62-112, atari8_double_duel_prior): fqf + double-Q + dueling + prioritized — with
+         # the reference's flat priority vector on Asterix (A = 9) and with the sum-tree on Seaquest (A = 18, the full ALE action set)
+         ("fqf", "prioritize", False, 1, True, False, "fqf_duel"), ("fqf", "prioritize", True, 1, True, False, "fqf_duel_a18"),
+         ("dqn", "prioritize", True, 1, True, False, "dqn_duel_a18")]
 
 
 @pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,launch,spec_name", CASES)
 def test_trainer_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_step, double_q, launch, spec_name):
-    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch, spec_name=spec_name)
-    ls = LockStep(tr, ora, spec)
-    for it in range(7):
+    _walk(algo, policy, sumtree, n_step, double_q, launch, spec_name, SMALL, 7)
+
+
+def _walk(algo, policy, sumtree, n_step, double_q, launch, spec_name, dims, iters, free_running=False):
+    E_, T_, B_, SIZE, LSTEPS, START, TFREQ = dims
+    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch, spec_name=spec_name, dims=dims)
+    ls = LockStep(tr, ora, spec, tfreq=TFREQ, free_running=free_running)
+    loose = free_running or spec.algo == "fqf"
+    for it in range(iters):
         res = tr.run_iteration()
         want = ora.end_step()
         rs, qs = ls.rollout_stats
         # the rollout this step consumed: episode returns in the reference's order, mean max-Q per step
         assert tr.Rs == [float(x) for x in ora.Rs], f"iteration {it}: episode returns"
         # fqf's actor evaluates q at its own fraction net's taus: an ulp there is amplified ~200x by cos(pi*64*tau)
-        assert_close(tr.Qs, ora.Qs, *((5e-4, 5e-5) if spec.algo == "fqf" else (5e-5, 5e-6)), f"iteration {it}: mean max-Q per step")
+        assert_close(tr.Qs, ora.Qs, *((5e-4, 5e-5) if loose else (5e-5, 5e-6)), f"iteration {it}: mean max-Q per step")
         assert res["frames"] == want["frames"] == (it + 1) * E_ * T_
         for key in ("loss", "fraction_loss", "return_train", "return_train_max", "qmax"):
             if want[key] is None:
                 assert res[key] is None, key
             else:
-                rt, at = (5e-4, 5e-5) if (spec.algo == "fqf" and key in ("qmax", "fraction_loss")) else (5e-5, 5e-6)
+                rt, at = (5e-4, 5e-5) if (loose and key in ("qmax", "fraction_loss", "loss")) else (5e-5, 5e-6)
                 assert abs(res[key] - want[key]) <= rt * abs(want[key]) + at, (it, key, res[key], want[key])
-    assert ls.n_ext == 7 and ls.n_upd == 6 * LSTEPS and tr.learner.update_steps == 18 and tr.replay.written == 560
+    n_train = sum(1 for it in range(iters) if (it + 1) * E_ * T_ > START)
+    assert ls.n_ext == iters and ls.n_upd == n_train * LSTEPS and tr.learner.update_steps == n_train * LSTEPS and tr.replay.written == iters * E_ * T_
+    return ls
+
+
+def test_trainer_loop_at_baseline_config0_sizes():
+    """BASELINE configs[0]'s actor / learner sizes — 16 envs x 80 steps per rollout, batch 512 (reference config.py:108-120 defaults) — walked
+    link by link like the cases above (dqn, uniform replay; the ring of 4000 wraps in the fourth rollout)."""
+    _walk("dqn", "uniform", False, 1, False, False, None, CONFIG0, 5)
+
+
+@pytest.mark.parametrize("policy", ["uniform", "prioritize"])
+def test_free_running_trace_stays_within_the_recorded_drift(policy):
+    """The same walk WITHOUT copying the oracle's floating-point state over the device's after each update: 18 consecutive updates (target
+    sync every 4, ring wrapping twice, with ``prioritize`` the device's own losses feeding priorities and importance weights) each side on
+    its own.  Everything discrete must still be identical — ring bytes, actions, n-step rewards, sampled indices — and the drift of losses,
+    gradients, parameters and Adam moments is recorded per update (gpurun_out/test_stats/free_running_<policy>.json -> profiles/) and bounded
+    at a small multiple of what was observed on an MI355X (see FREE_BOUNDS)."""
+    ls = _walk("dqn", policy, False, 3, True, False, None, SMALL, 7, free_running=True)
+    assert len(ls.drift) == 18
+    worst = {k: max(d[k] for d in ls.drift) for k in ("loss_rel", "grad_of_max", "param_abs", "adam_m_of_max")}
+    print("free-running drift over 18 updates:", worst, "ReLU flips:", ls.relu_flips)
+    from test_gpu_engine import _record
+    _record(f"free_running_{policy}", {"worst": worst, "relu_flips": int(ls.relu_flips), "per_update": ls.drift})
+    for k, bound in FREE_BOUNDS.items():
+        assert worst[k] <= bound, f"{k}: {worst[k]:.3e} > {bound:.1e} ({worst})"
+
+
+# observed on MI355X (profiles/r03_free_running_*.json): bounds are ~4x the worst value seen
+FREE_BOUNDS = {"loss_rel": 2e-3, "grad_of_max": 2e-3, "param_abs": 2e-4, "adam_m_of_max": 2e-3}
 
 
 def test_launch_schedule_rollout_uses_the_weights_of_its_issue_time():
