@@ -77,46 +77,133 @@ def self_launch(args) -> int:
     return rc if rc != 0 or line is not None else 1
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity mask, further limited by a cgroup CPU quota when one is set (a GPU box hands
+    the container of one GPU a share of the host's cores; ``os.cpu_count()`` reports the whole machine)."""
+    n_aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    return {"os_cpu_count": os.cpu_count(), "sched_affinity": n_aff, "cgroup_quota": quota, "used": min(n_aff, quota) if quota else n_aff}
+
+
 def cpu_baseline(args, cfg):
-    """The CPU oracle (a port of the reference's algorithm, pinned by goldens) timed on this box's host cores on a
-    bounded sample of the same workload: actor forward on a 256-env batch and full updates at B=512, combined into the
-    time one Trainer iteration would take (sample_steps x act + learner_steps x update; env / lz4 / data-loader costs
-    the reference also pays are NOT included, so this flatters the CPU)."""
+    """SURVEY.md §8(d) "CPU baseline beside it": the CPU oracle (a port of the reference's algorithm, pinned by fixtures generated from the
+    reference) timed on this box's host cores, on a bounded sample of the same workload, outside the timed region.  torch's intra-op threads =
+    the cores this process may use (``host_cores``), not ``os.cpu_count()``.  Items:
+      (i)   one ``learner.train`` at B = 512 per algorithm (dqn, c51, qr at the bench's action count; iqn, fqf at Asterix's A = 9 as in BASELINE configs[3], [4]);
+      (ii)  the actor's Q-forward + argmax at E = 16 and E = 256;
+      (iii) the reference's replay (oracle.replay.ReferenceReplay): extend, uniform permutation sample of B = 512 rows, importance weights — bytes/s of 56 448-byte rows;
+      (iv)  one whole Trainer iteration at BASELINE configs[0]'s sizes (16 envs x 80 steps + 20 updates of B = 512, synthetic env on the CPU).
+    ``value`` = the bench workload's iteration composed from (i) and (ii): sample_steps x act(E) + learner_steps x update(algo); env stepping, lz4 and the
+    data-loader processes the reference also pays are NOT included, so this flatters the CPU."""
     import numpy as np
     import torch
 
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import recipe
-    from oracle import learner as olearner, nets
+    from oracle import learner as olearner, nets, replay as oreplay
     from oracle.losses import Hyper
+    from oracle.trainer import OracleTrainer
 
-    spec = recipe.NetSpec(cfg.learner.algo.name, cfg.action_dim, dueling=cfg.learner.dueling_head, noisy=False,
-                          num_atoms=cfg.learner.c51.num_atoms if cfg.learner.algo.name == "c51" else cfg.learner.qr.num_atoms)
-    if spec.algo in ("iqn", "fqf") or cfg.learner.noisy_net:
-        return None
+    cores = host_cores()
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(cores["used"])
     B, E = args.batch, args.num_envs
-    sd = recipe.make_state_dict(spec, 1)
-    ora = olearner.OracleLearner(spec, sd, sd, Hyper(double_q=cfg.learner.double_q, n_step=cfg.learner.n_step_q), batch_size=B)
-    frames = recipe.make_frames(B, 3, spec.obs_shape)
-    a, r, d, w = recipe.make_transitions(B, spec.action_dim, 4)
-    ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B))        # warm-up
-    n_upd, t0 = 0, time.time()
-    while n_upd < 3 or time.time() - t0 < 6.0:
-        ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B))
-        n_upd += 1
-    t_upd = (time.time() - t0) / n_upd
-    obs = torch.from_numpy(recipe.make_frames(E, 5, spec.obs_shape)[:, :4].copy())
-    with torch.no_grad():
-        nets.qval(ora.po, spec, nets.normalize(obs))
-        n_act, t0 = 0, time.time()
-        while n_act < 5 or time.time() - t0 < 4.0:
-            nets.qval(ora.po, spec, nets.normalize(obs)).argmax(-1)
-            n_act += 1
-    t_act = (time.time() - t0) / n_act
+    algo0 = cfg.learner.algo.name
+
+    def spec_of(algo):
+        A = 9 if algo in ("iqn", "fqf") and algo != algo0 else cfg.action_dim
+        duel = cfg.learner.dueling_head if algo == algo0 else False
+        return recipe.NetSpec(algo, A, dueling=duel, noisy=False, num_atoms=51 if algo == "c51" else 200)
+
+    def time_update(algo, budget_s):
+        spec = spec_of(algo)
+        sd = recipe.make_state_dict(spec, 1)
+        hp = Hyper(double_q=cfg.learner.double_q, n_step=cfg.learner.n_step_q) if algo == algo0 else Hyper()
+        ora = olearner.OracleLearner(spec, sd, sd, hp, batch_size=B)
+        frames = recipe.make_frames(B, 3, spec.obs_shape)
+        a, r, d, w = recipe.make_transitions(B, spec.action_dim, 4)
+        rand = None
+        if algo == "iqn":
+            g = recipe.gen(5)
+            rand = [g.random((B, n, 1), dtype=np.float32) for n in (hp.K, hp.N_dash, hp.N)]
+        run = lambda: ora.train(frames.reshape(B, -1), a, r, d.astype(np.float32), w, np.arange(B), rand=rand)
+        heavy = algo in ("iqn", "fqf")           # ~0.5 TFLOP per update: one untimed-warm-up-free run is the whole budget
+        if not heavy:
+            run()
+        n, t0 = 0, time.time()
+        while n < (1 if heavy else 3) or (not heavy and time.time() - t0 < budget_s):
+            run()
+            n += 1
+        return {"ms": round(1e3 * (time.time() - t0) / n, 1), "runs": n, "action_dim": spec.action_dim, "warm": not heavy}, ora, spec
+
+    items = {}
+    upd = {}
+    ora0 = spec0 = None
+    for algo in dict.fromkeys([algo0, "dqn", "c51", "qr", "iqn", "fqf"]):
+        if algo == "mdqn" and algo != algo0:
+            continue
+        upd[algo], ora, spec = time_update(algo, 4.0 if algo == algo0 else 2.0)
+        if algo == algo0:
+            ora0, spec0 = ora, spec
+    items["i_learner_train_B%d_ms" % B] = upd
+    act = {}
+    iqn_taus = None
+    for e in dict.fromkeys([16, E]):
+        obs = torch.from_numpy(recipe.make_frames(e, 5, spec0.obs_shape)[:, :4].copy())
+        with torch.no_grad():
+            f = lambda: nets.qval(ora0.po, spec0, nets.normalize(obs)).argmax(-1)
+            f()
+            n, t0 = 0, time.time()
+            while n < 5 or time.time() - t0 < 2.0:
+                f()
+                n += 1
+        act[e] = (time.time() - t0) / n
+    items["ii_actor_forward_ms"] = {f"E{e}": round(1e3 * t, 3) for e, t in act.items()}
+    # (iii) the reference's replay: deque of (blob, a, r, d) tuples + flat priority vector
+    row = 2 * int(np.prod(spec0.obs_shape))
+    rp = oreplay.ReferenceReplay(100_000, True)
+    blobs = recipe.make_frames(1280, 7, spec0.obs_shape)
+    chunk = [(blobs[i], 0, 0.0, False) for i in range(1280)]
+    n, t0 = 0, time.time()
+    while n < 8:
+        rp.extend([(b.copy(), a_, r_, d_) for (b, a_, r_, d_) in chunk])       # the copy stands for the reference's per-transition lz4 + bytes object
+        n += 1
+    t_ext = (time.time() - t0) / n
+    g = recipe.gen(9)
+    n, t0 = 0, time.time()
+    while n < 20:
+        idx = g.permutation(rp.top)[:B]
+        got = [rp[int(i)] for i in idx]
+        batch = np.stack([x[0].reshape(-1) for x in got])                       # collate: B rows -> one [B, 56448] array (trainer.py:63-72)
+        prio = np.array([x[4] for x in got], dtype=np.float32)
+        oreplay.is_weights(prio, float(torch.from_numpy(rp.priority).sum().item()), rp.top, rp.beta)
+        n += 1
+    t_smp = (time.time() - t0) / n
+    items["iii_reference_replay_GBps"] = {"extend": round(1280 * row / t_ext / 1e9, 3), "sample_B%d_plus_is_weights" % B: round(batch.shape[0] * row / t_smp / 1e9, 3),
+                                          "row_bytes": row, "note": "uncompressed rows; the reference additionally lz4-compresses on extend and decompresses in 2 DataLoader workers"}
+    # (iv) one whole Trainer iteration at BASELINE configs[0]'s sizes
+    spec_c0 = recipe.NetSpec("dqn", 4)
+    ot = OracleTrainer(spec_c0, recipe.make_state_dict(spec_c0, 1), num_envs=16, sample_steps=80, batch_size=512, replay_size=100_000, learner_steps=20,
+                       training_start_steps=0)
+    t0 = time.time()
+    ot.iteration()
+    t_c0 = time.time() - t0
+    items["iv_config0_iteration"] = {"ms": round(1e3 * t_c0, 1), "env_frames_per_sec": round(16 * 80 / t_c0, 1),
+                                     "what": "oracle Trainer iteration: 80 steps x 16 synthetic envs (actor forward, eps-greedy, n-step, extend) + 20 updates of B=512, "
+                                             "100 000-slot replay, first iteration (training_start_steps lowered to 0)"}
+    torch.set_num_threads(keep_threads)
+    t_upd, t_act = upd[algo0]["ms"] * 1e-3, act[E]
     t_iter = args.sample_steps * t_act + args.learner_steps * t_upd
-    return {"value": round(args.sample_steps * E / t_iter, 1), "unit": "env-frames/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_upd} oracle updates at B={B} ({t_upd*1e3:.1f} ms each) + {n_act} oracle actor forwards at E={E} ({t_act*1e3:.2f} ms each), "
-                      f"extrapolated to one iteration of {args.sample_steps} actor steps + {args.learner_steps} updates"}
+    return {"value": round(args.sample_steps * E / t_iter, 1), "unit": "env-frames/sec", "cores": cores["used"], "kind": "port", "host_cores": cores,
+            "sample": f"{upd[algo0]['runs']} oracle {algo0} updates at B={B} ({upd[algo0]['ms']:.1f} ms each) + oracle actor forwards at E={E} ({t_act*1e3:.2f} ms each), "
+                      f"extrapolated to one iteration of {args.sample_steps} actor steps + {args.learner_steps} updates; torch threads = {cores['used']}",
+            "items": items}
 
 
 def main():
@@ -190,7 +277,9 @@ def main():
         dt = float(t[0])
     # ---- roofline of the dominant kernel: the same iterations once more with the hipGraphs switched off, so that HIP events can
     # bracket every launch of that kernel on its stream (events cannot be read out of a replayed graph).  Not part of `value`.
-    probe_kernel = os.environ.get("A0_PROBE", "encoder_fused")
+    # the quantile networks (iqn / fqf) spend their time in the fc1-family GEMMs over B * N rows ("IQN/FQF fc1 + cosine-embed GEMMs:
+    # MFMA-bound"), every other configuration in the fused encoder
+    probe_kernel = os.environ.get("A0_PROBE", "dense_fwd" if cfg.learner.algo.name in ("iqn", "fqf") else "encoder_fused")
     pr = None
     if probe_kernel != "none":           # every rank repeats the iterations (they contain the gradient all-reduce); rank 0 records
         tr.learner.use_graph = False
@@ -198,7 +287,7 @@ def main():
         if args.entry == "launch":
             tr.overlap = False               # kernel timing without a second stream competing for the CUs
         if rank == 0:
-            tr.ops.probe_begin(probe_kernel, 64 + args.steps * (cfg.actor.sample_steps + 8 * cfg.learner.learner_steps))
+            tr.ops.probe_begin(probe_kernel, 64 + args.steps * (4 * cfg.actor.sample_steps + 16 * cfg.learner.learner_steps))
         for _ in range(args.steps):
             tr.run_iteration()
         torch.cuda.synchronize()
@@ -308,19 +397,27 @@ def main():
         if pr["kernel"] == "encoder_fused":
             f1, f2, f3 = 2.0 * 400 * 32 * 256, 2.0 * 81 * 64 * 512, 2.0 * 49 * 64 * 576
             issued_ratio = (3 * f1 + 9 * (f2 + f3)) / (f1 + f2 + f3)
+        enc = pr["kernel"] == "encoder_fused"
+        if not enc:
+            issued_ratio, traffic = 9.0, None             # nine bf16 products per MAC; no PMC pass of these kernels is committed for this round
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": traffic,
                 "issued_bf16": {"achieved": round(achieved * issued_ratio, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved * issued_ratio / 2500.0, 4),
-                                "note": "bf16 MFMA FLOPs the kernel issues (3 products per conv1 MAC, 9 per conv2 / conv3 MAC: 99.96 MFLOP per observation) against the dense "
-                                        "bf16 MFMA peak; `frac` above counts every MAC once against the fp32 MFMA peak"},
-                "traffic_note": f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                "note": ("bf16 MFMA FLOPs the kernel issues (3 products per conv1 MAC, 9 per conv2 / conv3 MAC: 99.96 MFLOP per observation) against the dense "
+                                         "bf16 MFMA peak" if enc else "bf16 MFMA FLOPs the kernel issues (9 cross products per MAC) against the dense bf16 MFMA peak") +
+                                        "; `frac` above counts every MAC once against the fp32 MFMA peak"},
+                "traffic_note": "not measured for this kernel (traffic is null)" if not enc else f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
                                 f"at --replay-size 100000 --steps 2 (tools/refresh_profiles.sh), read from profiles/{traffic_file}; "
                                 "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB (512 obs); the learner's online pass also stores act1/act2 for the backward pass",
                 "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation; u8 input, activations in LDS, weights streamed through registers; "
                           "all layers on v_mfma_f32_16x16x32_bf16 with operands split exactly into bf16 terms (bytes x 3 weight terms; 3 activation x 3 weight terms), fp32 accumulation; "
                           "FLOPs counted once, peak = fp32 MFMA, the bound of the fp32-chain variant A0_NO_X9=1)"
-                          if pr["kernel"] == "encoder_fused" else f"a0_igemm_kernel<{pr['kernel']}>",
+                          if pr["kernel"] == "encoder_fused" else
+                          f"a0_igemm_x9_kernel, every launch tagged {pr['kernel']} (the dense layers' GEMMs of this pass direction: fc1 512 x 3136 over B*N rows, the cosine "
+                          "embedding 3136 x 64, the heads; both fp32 operands split exactly into three bf16 terms, nine v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation; "
+                          "FLOPs = 2*M*N*K counted once, peak = fp32 MFMA)",
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
-                "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor) or 512 (learner) observations",
+                "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor) or 512 (learner) observations"
+                                               if pr["kernel"] == "encoder_fused" else f"2*M*N*K per launch; {pr['flop'] / max(pr['launches'], 1) / 1e9:.2f} GFLOP average over the launch mix",
                 "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off",
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
     out["roofline"] = roof

@@ -378,7 +378,9 @@ def check_update_fqf_own_fractions(ops, spec, hp, B, seed=61, bounds=None):
         lr_k = 0.0 if "fraction" in k else 5e-4
         far += int((err > 2e-5 + 0.2 * lr_k).sum()); tot += err.numel()
     m["params_far_share"] = far / tot
-    b = dict(q_loss_median=2e-4, q_loss_p99=5e-3, q_loss_max=5e-2, fraction_loss_median=2e-3, fraction_loss_p99=5e-2, grad_worst=2e-2, params_far_share=2e-2)
+    # observed (MI355X, B = 512, A = 9 / 18: profiles/r03_test_stats.json; CPU backend, B = 16): q_loss median 3.5e-7, p99 3.7e-6, max 5.9e-6; fraction
+    # loss median 3.3e-5, p99 1.5e-4; worst gradient tensor 8.4e-3 of its max (single ReLU / indicator flips); parameters far: 9.2e-5
+    b = dict(q_loss_median=5e-6, q_loss_p99=5e-5, q_loss_max=5e-4, fraction_loss_median=3e-4, fraction_loss_p99=2e-3, grad_worst=3e-2, params_far_share=2e-3)
     b.update(bounds or {})
     for k, v in b.items():
         assert m[k] <= v, f"{k} = {m[k]:.3e} exceeds {v:.1e} ({m})"

@@ -365,8 +365,9 @@ def test_free_running_trace_stays_within_the_recorded_drift(policy):
         assert worst[k] <= bound, f"{k}: {worst[k]:.3e} > {bound:.1e} ({worst})"
 
 
-# observed on MI355X (profiles/r03_free_running_*.json): bounds are ~4x the worst value seen
-FREE_BOUNDS = {"loss_rel": 2e-3, "grad_of_max": 2e-3, "param_abs": 2e-4, "adam_m_of_max": 2e-3}
+# observed on MI355X over the 18 updates (profiles/r03_test_stats.json: loss 9.4e-6, gradients 8.1e-6 of a tensor's max, parameters 4.6e-7
+# absolute, Adam m 5.7e-6): the bounds are ~5x the worst value seen
+FREE_BOUNDS = {"loss_rel": 5e-5, "grad_of_max": 5e-5, "param_abs": 3e-6, "adam_m_of_max": 3e-5}
 
 
 def test_launch_schedule_rollout_uses_the_weights_of_its_issue_time():
