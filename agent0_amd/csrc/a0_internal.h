@@ -36,6 +36,10 @@ bool a0_probe_start(int tag, hipStream_t st);
 // conv1_wgrad.hip: per-observation conv1 weight gradient on the bf16 pipe; returns the slab count (0 = unsupported shape)
 int a0_conv1_wgrad_fused_launch(const a0_frames_arg* f, int C, int H, int W, int B, const float* d1, float* slabs, hipStream_t st);
 void a0_probe_stop(hipStream_t st, double flops);
+// conv23_wgrad.hip: per-observation conv2 + conv3 weight gradients on the bf16 pipe (one launch); returns 1 if it ran, 0 = unsupported shape
+struct a0_net_core;
+int a0_conv23_wgrad_fused_launch(const a0_net_core& n, int B, const float* act1, const float* act2, const float* d2, const float* d3, float* slab2, float* slab3,
+                                 hipStream_t st);
 #endif
 #define A0_TAG_ENCODER_FUSED 12
 #define A0_TAG_ENCODER_DGRAD_FUSED 13

@@ -206,6 +206,17 @@ struct a0_hip_backend {
         }
         return g;
     }
+    bool conv23_wgrad_fused(const a0_net_core& n, int B, const float* act1, const float* act2, const float* d2, const float* d3, float* slab2, float* slab3) {
+        const bool probe = g_probe.tag != 0 && g_probe.tag == A0_TAG_CONV2_WGRAD && g_probe.used + 2 <= g_probe.ev.size();
+        if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
+        const int ran = a0_conv23_wgrad_fused_launch(n, B, act1, act2, d2, d3, slab2, slab3, st);
+        if (probe && ran) {
+            A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
+            g_probe.used += 2;
+            g_probe.flops += 2.0 * 64.0 * ((double)n.K2 * n.H2 * n.W2 + (double)n.K3 * n.H3 * n.W3) * B;
+        }
+        return ran != 0;
+    }
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
         hipLaunchKernelGGL(a0_reduce_slabs_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, nslab, out, count);
         A0_HIP_THROW(hipGetLastError());

@@ -112,6 +112,27 @@ static inline long long a0_dense_wgrad_scratch_impl(int R, int N, int K) {
     return s > 1 ? (long long)s * ((long long)N * K + N) : 0;
 }
 
+// conv23_wgrad.hip (per-observation conv2 / conv3 weight gradients, 84 x 84 geometry): groups of observations per layer.  A conv2 workgroup
+// (one half of the output channels) costs 4 tiles x 6 steps per observation and SIMD, a conv3 workgroup (one kernel row) 3 tiles x 4 steps;
+// 2*G2 + 3*G3 workgroups share the CUs, all resident at once.  Chosen: the smallest maximum of ceil(B/G) x cost, then the fewest slab bytes.
+static inline bool a0_c23w_plan(const a0_net_core& n, int B, int* G2, int* G3) {
+    static const bool off = getenv("A0_NO_CONV23_WGRAD_FUSED") != nullptr;
+    if (off || B < 1 || n.H1 != 20 || n.W1 != 20 || n.H2 != 9 || n.W2 != 9 || n.H3 != 7 || n.W3 != 7) return false;
+    const int ncu = 256, c2 = 24, c3 = 12;
+    long long best_cost = -1, best_bytes = 0;
+    auto ceil_div = [](int a, int b) { return (a + b - 1) / b; };
+    for (int g3 = 1; g3 <= B && 3 * g3 + 2 <= ncu; ++g3) {
+        int g2 = (ncu - 3 * g3) / 2;
+        if (g2 > B) g2 = B;
+        const long long t3 = (long long)ceil_div(B, g3) * c3, t2min = (long long)ceil_div(B, g2) * c2;
+        const long long cost = t3 > t2min ? t3 : t2min;
+        while (g2 > 1 && (long long)ceil_div(B, g2 - 1) * c2 <= cost) --g2;        // the fewest conv2 groups that still meet it
+        const long long bytes = (long long)g2 * 512 + (long long)g3 * 576;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && bytes < best_bytes)) { best_cost = cost; best_bytes = bytes; *G2 = g2; *G3 = g3; }
+    }
+    return best_cost >= 0;
+}
+
 // Slab regions of the three convolution weight gradients inside the caller's scratch buffer.  They are disjoint, so that the three
 // GEMMs can leave their partial sums behind and ONE reduction launch finishes all of them (a0_encoder_bwd_impl).  conv1 is sized for
 // the per-observation kernel (one slab per workgroup, at most 256) or the GEMM's splits, whichever is larger.
@@ -123,10 +144,13 @@ static inline a0_enc_slab_plan a0_encoder_slab_plan(const a0_net_core& n, int B)
     const int N[3] = {32, 64, 64};
     const int K[3] = {n.K1, n.K2, n.K3};
     long long off = 0;
+    int g23[3] = {0, 0, 0};
+    if (!a0_c23w_plan(n, B, &g23[1], &g23[2])) g23[1] = g23[2] = 0;
     for (int l = 2; l >= 0; --l) {
         p.splits[l] = l == 0 ? a0_wgrad_splits(1, (K[l] + 127) / 128, M[l]) : a0_conv_wgrad_splits(K[l], M[l]);
         int slabs = p.splits[l] > 1 ? p.splits[l] : 0;
         if (l == 0) { const int fused = B < 256 ? B : 256; if (fused > slabs) slabs = fused; }
+        else if (g23[l] > slabs) slabs = g23[l];             // the per-observation kernel's groups
         p.off[l] = off;
         off += (long long)slabs * ((long long)N[l] * K[l] + N[l]);
     }
@@ -250,7 +274,15 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
     const a0_enc_slab_plan plan = a0_encoder_slab_plan(n, B);
     a0_reduce_seg segs[3];
     int nseg = 0;
-    {   // conv3 weight gradient: dW3[64][K3] = sum_m d3[m][:]^T im2col(act2)[m][:]
+    // d2 already known (the learner's path: a0_net_encoder_dgrad_fused ran first): both weight gradients in ONE per-observation launch on the bf16 pipe
+    int G2 = 0, G3 = 0;
+    const bool fused23 = !with_dgrad && a0_c23w_plan(n, B, &G2, &G3) &&
+                         bk.conv23_wgrad_fused(n, B, act1, act2, d2, d3, slabs + plan.off[1], slabs + plan.off[2]);
+    if (fused23) {
+        segs[nseg++] = a0_reduce_seg{slabs + plan.off[2], 64LL * n.K3 + 64, G3, g3, 64LL * n.K3 + 64};
+        segs[nseg++] = a0_reduce_seg{slabs + plan.off[1], 64LL * n.K2 + 64, G2, g2, 64LL * n.K2 + 64};
+    }
+    if (!fused23) {   // conv3 weight gradient: dW3[64][K3] = sum_m d3[m][:]^T im2col(act2)[m][:]
         const int splits = plan.splits[2];
         const long long wc = 64LL * n.K3;
         float* sl = slabs + plan.off[2];
@@ -269,7 +301,7 @@ static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
         bk.tag = A0_TAG_CONV3_DGRAD;
         bk.template igemm<OpActKC, OpWtabXC, EpiDgrad, 4, 1, 1, 2>(a, b, e, M2, 64, 9 * 64, 1);
     }
-    {   // conv2 weight gradient
+    if (!fused23) {   // conv2 weight gradient
         const int splits = plan.splits[1];
         const long long wc = 64LL * n.K2;
         float* sl = slabs + plan.off[1];

@@ -71,6 +71,7 @@ struct host_backend {
         }
     }
     int conv1_wgrad_fused(const a0_net_core&, const a0_frames_arg&, int, const float*, float*) { return 0; }   // GPU-only fast path
+    bool conv23_wgrad_fused(const a0_net_core&, int, const float*, const float*, const float*, const float*, float*, float*) { return false; }   // GPU-only fast path
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
         for (long long i = 0; i < count; ++i) {
             float s = 0.f;

@@ -390,7 +390,7 @@ def test_fused_dgrad_matches_unfused():
     net = DeviceNet(hip, L, hip.net(4, 84, 84))
     net.load_state_dict(recipe.make_state_dict(spec, 5))
     assert net.fused_dgrad
-    for B in (3, 64, 300):      # 300: more observations than workgroups (the looping path), unevenly divided
+    for B in (1, 3, 64, 300, 512):      # 300: more observations than workgroups (the looping path), unevenly divided
         g = recipe.gen(B)
         frames = torch.from_numpy(g.integers(0, 256, B * 28224, dtype=np.uint8)).cuda()
         ws = Workspace(hip, L, B, grads=True)
@@ -406,7 +406,14 @@ def test_fused_dgrad_matches_unfused():
         hip.encoder_dgrad_fused(net.net, net.wt, ws.d3, ws.act1, ws.act2, B, ws.d2, ws.d1)
         hip.encoder_wgrad(net.net, net.encoder_weights(), frames, None, 28224, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, slabs)
         torch.cuda.synchronize()
-        for name, got, ref in (("d2", ws.d2, ref2), ("d1", ws.d1, ref1), ("grads", grads, refg)):
+        checks = [("d2", ws.d2, ref2), ("d1", ws.d1, ref1), ("grads", grads, refg)]
+        # ... and every convolution block on its own scale, weights and bias separately: a0_net_encoder_wgrad computes conv2 / conv3 with the
+        # per-observation kernel (conv23_wgrad.hip: LDS-resident operands, transposed fragment reads, groups of observations per slab), conv1
+        # with conv1_wgrad.hip; the reference side is the implicit-GEMM path
+        for name in ("conv1", "conv2", "conv3"):
+            blk = L.blocks[name]
+            checks += [(name + ".weight", grads[blk.w], refg[blk.w]), (name + ".bias", grads[blk.b], refg[blk.b])]
+        for name, got, ref in checks:
             scale = float(ref.abs().max())
             err = float((got - ref).abs().max())
             assert err <= 2e-5 * scale, (name, B, err, scale)
