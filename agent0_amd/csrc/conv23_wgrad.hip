@@ -15,15 +15,18 @@
 // Work split.  The accumulators stay in registers for the whole launch, so a workgroup's partial sums travel through HBM once, as a slab
 // that a0_reduce_segments adds up (deterministic, like every other weight gradient).  Slab bytes = workgroups per layer x layer size, so a
 // layer is cut into PARTS and each part runs over a strided subset ("group") of the observations:
-//   conv2: 2 parts (32 output channels each: 16 tiles of 32 x 32, two per wave), G2 groups -> slab region g of conv2 gets both halves;
+//   conv2: 4 parts = the parity classes (kh & 1, kw & 1) of the 4 x 4 stride-2 kernel.  A tap of class (a, b) only ever touches input pixels
+//          (ih, iw) with ih & 1 = a, iw & 1 = b, so a part needs a QUARTER of act1 — the 10 x 10 sub-image of its class, in which the taps of
+//          consecutive output columns are consecutive rows — and all of d2: 2 channel blocks x 4 taps = 8 tiles of 32 x 32, one per wave;
 //   conv3: 3 parts (one kernel row kh each: 2 channel blocks x 3 taps x 2 input-channel halves = 12 tiles; per SIMD one wave with two
-//          tiles and one with one), G3 groups.
-// 2*G2 + 3*G3 <= CUs; (G2, G3) balance the two kinds of workgroup (a0_c23w_plan).  One launch, 512 threads, 93 KB of LDS.
+//          tiles and one with one).
+// Either kind of workgroup costs 24 k-steps of nine MFMAs per observation and SIMD and holds 55 KB of LDS, so TWO are resident per CU:
+// while one stages its next observation (global -> registers is prefetched; split + LDS writes between two barriers) the other one's waves
+// keep the matrix pipe busy.  G groups per layer, 7 G <= 2 x CUs workgroups (a0_c23w_plan); slab region g of a layer receives all its parts.
 //
 // LDS images (bf16, three term planes each; every row is 64 bytes = 32 channels, so the 4 rows x 64 bytes a 32-lane half reads per
 // ds_read_b64_tr_b16 tile all 64 banks when the rows are consecutive):
-//   conv2  act1: [400 pixels][32 ci], pixel (ih, iw) at index ih*20 + (iw & 1)*10 + (iw >> 1): the stride-2 taps of consecutive output
-//                columns are consecutive rows;  d2: [96 rows][32 co of this half], rows 81..95 zero.
+//   conv2  act1 class image: [100 pixels][32 ci], pixel (ih, iw) at row (ih >> 1)*10 + (iw >> 1);  d2: [2 co halves][96 rows][32], rows 81..95 zero.
 //   conv3  act2: [2 ci halves][81 pixels][32];  d3: [2 co halves][64 rows][32], rows 49..63 zero.
 // Positions beyond the image (the zero rows of d) read a valid activation row: 0 * finite = 0.
 #include "a0_internal.h"
@@ -48,10 +51,10 @@ struct a0_c23w_args {
 
 template <int LAYER> struct a0q_geom;
 template <> struct a0q_geom<2> {
-    static constexpr int NPOS = 81, STEPS = 6, DROWS = 96, APIX = 400, CIN = 32, K = 512;
-    static constexpr int ACT_PLANE = APIX * A0Q_ROW, D_PLANE = DROWS * A0Q_ROW;          // bytes per term plane
-    static constexpr int ACT_F4 = 400 * 8, D_F4 = 81 * 8;                                // float4 pieces per observation (d: this half's 32 channels)
-    A0_D static int base_row(int p) { return 40 * (p / 9) + (p % 9); }                   // activation row of position p, tap (0, 0)
+    static constexpr int NPOS = 81, STEPS = 6, DROWS = 96, APIX = 100, CIN = 32, K = 512;
+    static constexpr int ACT_PLANE = APIX * A0Q_ROW, D_PLANE = 2 * DROWS * A0Q_ROW;      // bytes per term plane
+    static constexpr int ACT_F4 = 100 * 8, D_F4 = 81 * 16;                               // float4 pieces per observation (act: this parity class only)
+    A0_D static int base_row(int p) { return 10 * (p / 9) + (p % 9); }                   // class-image row of position p, first tap of the class
 };
 template <> struct a0q_geom<3> {
     static constexpr int NPOS = 49, STEPS = 4, DROWS = 64, APIX = 81, CIN = 64, K = 576;
@@ -59,8 +62,8 @@ template <> struct a0q_geom<3> {
     static constexpr int ACT_F4 = 81 * 16, D_F4 = 49 * 16;
     A0_D static int base_row(int p) { return 9 * (p / 7) + (p % 7); }
 };
-constexpr int A0Q_LDS_BYTES = 3 * (a0q_geom<2>::ACT_PLANE + a0q_geom<2>::D_PLANE);      // 95 232: the larger of the two images
-static_assert(3 * (a0q_geom<3>::ACT_PLANE + a0q_geom<3>::D_PLANE) <= A0Q_LDS_BYTES, "conv3 image fits");
+constexpr int A0Q_LDS_BYTES = 3 * (a0q_geom<2>::ACT_PLANE + a0q_geom<2>::D_PLANE);      // 56 064: the larger of the two images
+static_assert(3 * (a0q_geom<3>::ACT_PLANE + a0q_geom<3>::D_PLANE) <= A0Q_LDS_BYTES && 2 * A0Q_LDS_BYTES <= 160 * 1024, "conv3 image fits; two workgroups per CU");
 
 // exact three-term split of a float4, packed as 4 bf16 (8 bytes) per term
 A0_D void a0q_split4(const a0_f4& v, a0q_u32x2& hi, a0q_u32x2& mid, a0q_u32x2& lo) {
@@ -89,35 +92,29 @@ A0_D a0q_u32x4 a0q_frag(const unsigned char* plane, int off0, int off1) {
     return a0q_u32x4{a.x, a.y, b.x, b.y};
 }
 
-// The body of one workgroup: layer LAYER, part `part`, observations g, g + G, ...; NT tiles per wave is a wave-uniform run-time choice
-// made by the caller (conv3: 2 or 1), so the MFMA loop is instantiated per NT.
+// One observation's k-steps for NT tiles of one wave (NT is wave-uniform: conv3 has waves with two tiles and with one).  The fragments are
+// not double-buffered: four waves per SIMD (two workgroups per CU) cover the LDS latency, and the registers buy the second workgroup.
 template <int LAYER, int NT>
-A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, const int (&aoff)[a0q_geom<LAYER>::STEPS][2], const int (&boff)[a0q_geom<LAYER>::STEPS][2],
+A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, int aoff, const int (&boff)[a0q_geom<LAYER>::STEPS][2],
                         int a_blk, const int (&b_blk)[2], a0_acc16 (&acc)[2]) {
     typedef a0q_geom<LAYER> G;
     // term pairs in the order of increasing magnitude (lo*lo first, hi*hi last), as in igemm_x9.h
     constexpr int TA[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
     constexpr int TB[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0};
-    a0q_u32x4 a[2][3], b[2][NT][3];
-    auto fetch = [&](int slot, int s) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            a[slot][t] = a0q_frag(dpl + t * G::D_PLANE + a_blk, aoff[s][0], aoff[s][1]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[slot][j][t] = a0q_frag(act + t * G::ACT_PLANE + b_blk[j], boff[s][0], boff[s][1]);
-        }
-    };
-    fetch(0, 0);
 #pragma unroll
     for (int s = 0; s < G::STEPS; ++s) {
-        if (s + 1 < G::STEPS) fetch((s + 1) & 1, s + 1);          // the next step's fragments are in flight behind this step's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
+        a0q_u32x4 a[3], b[NT][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            a[t] = a0q_frag(dpl + t * G::D_PLANE + a_blk + s * 16 * A0Q_ROW, aoff, aoff + 4 * A0Q_ROW);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j][t] = a0q_frag(act + t * G::ACT_PLANE + b_blk[j], boff[s][0], boff[s][1]);
+        }
 #pragma unroll
         for (int q = 0; q < 9; ++q)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0q_bf16x8, a[s & 1][TA[q]]), __builtin_bit_cast(a0q_bf16x8, b[s & 1][j][TB[q]]), acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0q_bf16x8, a[TA[q]]), __builtin_bit_cast(a0q_bf16x8, b[j][TB[q]]), acc[j], 0, 0, 0);
     }
 }
 
@@ -134,13 +131,11 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
     // ---- this wave's tiles
     int nt, a_blk, b_blk[2], kcol[2], corow;
     if constexpr (LAYER == 2) {
-        nt = 2; a_blk = 0; corow = part * 32;                            // this half's 32 output channels
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int tap = 2 * wave + j, kh = tap >> 2, kw = tap & 3;
-            b_blk[j] = (kh * 20 + (kw & 1) * 10 + (kw >> 1)) * A0Q_ROW;   // row offset of the tap in the parity-split image
-            kcol[j] = tap * 32;
-        }
+        // part = parity class (a, b) = (part >> 1, part & 1); wave -> channel block wave & 1, tap (a + 2 th, b + 2 tw) with (th, tw) = wave >> 1
+        const int c = wave & 1, th = wave >> 2, tw = (wave >> 1) & 1, kh = (part >> 1) + 2 * th, kw = (part & 1) + 2 * tw;
+        nt = 1; a_blk = c * G::DROWS * A0Q_ROW; corow = c * 32;
+        b_blk[0] = b_blk[1] = (th * 10 + tw) * A0Q_ROW;                  // row offset of the tap in the class image
+        kcol[0] = kcol[1] = (kh * 4 + kw) * 32;
     } else {
         const int simd = wave & 3, first = 3 * simd + (wave >> 2) * 2;    // tiles {3s, 3s+1} for wave s, {3s+2} for wave s + 4
         nt = wave < 4 ? 2 : 1;
@@ -155,13 +150,13 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
     }
     // per-lane row offsets of the two transposed reads of every step (see a0q_frag); + the lane's 8-byte column group
     const int colb = 2 * (16 * ((lane >> 4) & 1) + 4 * (lane & 3));
-    int aoff[G::STEPS][2], boff[G::STEPS][2];
+    const int aoff = (8 * (lane >> 5) + ((lane & 15) >> 2)) * A0Q_ROW + colb;      // + (16 s + 4 h) rows: compile-time
+    int boff[G::STEPS][2];
 #pragma unroll
     for (int s = 0; s < G::STEPS; ++s)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int p = 16 * s + 8 * (lane >> 5) + ((lane & 15) >> 2) + 4 * h;
-            aoff[s][h] = p * A0Q_ROW + colb;
             boff[s][h] = G::base_row(p < G::NPOS ? p : G::NPOS - 1) * A0Q_ROW + colb;
         }
 
@@ -176,17 +171,19 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
     constexpr int RA = (G::ACT_F4 + A0Q_THREADS - 1) / A0Q_THREADS, RD = (G::D_F4 + A0Q_THREADS - 1) / A0Q_THREADS;
     a0_f4 ra[RA], rd[RD];
     auto load_raw = [&](int b) {
-        const a0_f4* sa = (const a0_f4*)((LAYER == 2 ? P.act1 : P.act2) + (long long)b * (G::APIX * G::CIN));
+        const float* sa = LAYER == 2 ? P.act1 + (long long)b * (400 * 32) : P.act2 + (long long)b * (81 * 64);
 #pragma unroll
-        for (int j = 0; j < RA; ++j) { const int i = tid + j * A0Q_THREADS; ra[j] = sa[i < G::ACT_F4 ? i : G::ACT_F4 - 1]; }
-        const float* sd = (LAYER == 2 ? P.d2 : P.d3) + (long long)b * (G::NPOS * 64);
-#pragma unroll
-        for (int j = 0; j < RD; ++j) {
+        for (int j = 0; j < RA; ++j) {
             int i = tid + j * A0Q_THREADS;
-            i = i < G::D_F4 ? i : G::D_F4 - 1;
-            if constexpr (LAYER == 2) rd[j] = *(const a0_f4*)(sd + (i >> 3) * 64 + part * 32 + (i & 7) * 4);
-            else rd[j] = *(const a0_f4*)(sd + i * 4);
+            i = i < G::ACT_F4 ? i : G::ACT_F4 - 1;
+            if constexpr (LAYER == 2) {       // pixel (2r + a, 2c + b) of the class image's row 10 r + c
+                const int px = i >> 3, r = px / 10, c = px - r * 10;
+                ra[j] = *(const a0_f4*)(sa + ((2 * r + (part >> 1)) * 20 + 2 * c + (part & 1)) * 32 + (i & 7) * 4);
+            } else ra[j] = *(const a0_f4*)(sa + i * 4);
         }
+        const a0_f4* sd = (const a0_f4*)((LAYER == 2 ? P.d2 : P.d3) + (long long)b * (G::NPOS * 64));
+#pragma unroll
+        for (int j = 0; j < RD; ++j) { const int i = tid + j * A0Q_THREADS; rd[j] = sd[i < G::D_F4 ? i : G::D_F4 - 1]; }
     };
     int b = g;
     if (b < P.B) load_raw(b);
@@ -198,7 +195,7 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
             const int i = tid + j * A0Q_THREADS;
             if (i < G::ACT_F4) {
                 int row, cb;
-                if constexpr (LAYER == 2) { const int px = i >> 3, ih = px / 20, iw = px - ih * 20; row = ih * 20 + (iw & 1) * 10 + (iw >> 1); cb = (i & 7) * 8; }
+                if constexpr (LAYER == 2) { row = i >> 3; cb = (i & 7) * 8; }
                 else { const int px = i >> 4, c4 = (i & 15) * 4; row = (c4 >> 5) * G::APIX + px; cb = (c4 & 31) * 2; }
                 a0q_u32x2 hi, mid, lo;
                 a0q_split4(ra[j], hi, mid, lo);
@@ -210,9 +207,7 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
         for (int j = 0; j < RD; ++j) {
             const int i = tid + j * A0Q_THREADS;
             if (i < G::D_F4) {
-                int row, cb;
-                if constexpr (LAYER == 2) { row = i >> 3; cb = (i & 7) * 8; }
-                else { const int c4 = (i & 15) * 4; row = (c4 >> 5) * G::DROWS + (i >> 4); cb = (c4 & 31) * 2; }
+                const int c4 = (i & 15) * 4, row = (c4 >> 5) * G::DROWS + (i >> 4), cb = (c4 & 31) * 2;
                 bsum[0] += rd[j].x; bsum[1] += rd[j].y; bsum[2] += rd[j].z; bsum[3] += rd[j].w;
                 a0q_u32x2 hi, mid, lo;
                 a0q_split4(rd[j], hi, mid, lo);
@@ -241,27 +236,30 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
         }
     }
     // bias: a thread's four channels are the same in all its pieces (the piece index advances by 512, a multiple of the pieces per row)
-    const bool has_bias = LAYER == 2 || part == 0;
+    const bool has_bias = part == 0;
     if (has_bias) {
         float* red = (float*)smem;                      // the images are dead (the loop ends with a barrier)
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[tid * 4 + e] = bsum[e];
         __syncthreads();
-        constexpr int CH = LAYER == 2 ? 32 : 64, TPR = CH / 4;        // threads per row of d pieces: tid % TPR selects the channel group
+        constexpr int CH = 64, TPR = CH / 4;        // threads per row of d pieces: tid % TPR selects the channel group
         if (tid < CH) {
             float s = 0.f;
             for (int t = tid >> 2; t < A0Q_THREADS; t += TPR) s += red[t * 4 + (tid & 3)];       // fixed order
-            out[64 * G::K + (LAYER == 2 ? part * 32 : 0) + tid] = s;
+            out[64 * G::K + tid] = s;
         }
     }
 }
 
-__global__ __launch_bounds__(A0Q_THREADS) void a0_conv23_wgrad_fused_kernel(a0_c23w_args P) {
+__global__ __launch_bounds__(A0Q_THREADS, 4) void a0_conv23_wgrad_fused_kernel(a0_c23w_args P) {      // four waves per SIMD: two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char a0q_smem[];
-    const int id = blockIdx.x, n2 = 2 * P.G2;
-    // the heavier conv2 workgroups first: they are resident from the start, the conv3 ones fill the remaining CUs
-    if (id < n2) a0q_body<2>(P, id & 1, id >> 1, P.G2, a0q_smem);
-    else a0q_body<3>(P, (id - n2) % 3, (id - n2) / 3, P.G3, a0q_smem);
+    // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  The seven parts of a group read the
+    // same observations (d2 four times, d3 and act2 three times), so all of them are given to ONE XCD: group g lives on XCD g % 8, and
+    // inside an XCD the workgroups run group by group, part by part (parts 0-3: conv2 classes, 4-6: conv3 kernel rows).
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, g = xcd + 8 * (k / 7), part = k % 7;
+    if (g >= P.G2) return;                                   // G2 == G3 (a0_c23w_plan); the grid is rounded up to whole XCD rows
+    if (part < 4) a0q_body<2>(P, part, g, P.G2, a0q_smem);
+    else a0q_body<3>(P, part - 4, g, P.G3, a0q_smem);
 }
 
 // returns 1 when the kernel ran (slab2: G2 slabs of 64*512 + 64 floats, slab3: G3 slabs of 64*576 + 64; a0_c23w_plan), 0 = shape not
@@ -277,7 +275,8 @@ int a0_conv23_wgrad_fused_launch(const a0_net_core& n, int B, const float* act1,
         A0_HIP_THROW(hipFuncSetAttribute((const void*)a0_conv23_wgrad_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A0Q_LDS_BYTES));
         configured = true;
     }
-    hipLaunchKernelGGL(a0_conv23_wgrad_fused_kernel, dim3(2 * G2 + 3 * G3), dim3(A0Q_THREADS), A0Q_LDS_BYTES, st, P);
+    if (G2 != G3) return 0;
+    hipLaunchKernelGGL(a0_conv23_wgrad_fused_kernel, dim3(8 * 7 * ((G2 + 7) / 8)), dim3(A0Q_THREADS), A0Q_LDS_BYTES, st, P);
     A0_HIP_THROW(hipGetLastError());
     return 1;
 }

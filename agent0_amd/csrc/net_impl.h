@@ -112,25 +112,16 @@ static inline long long a0_dense_wgrad_scratch_impl(int R, int N, int K) {
     return s > 1 ? (long long)s * ((long long)N * K + N) : 0;
 }
 
-// conv23_wgrad.hip (per-observation conv2 / conv3 weight gradients, 84 x 84 geometry): groups of observations per layer.  A conv2 workgroup
-// (one half of the output channels) costs 4 tiles x 6 steps per observation and SIMD, a conv3 workgroup (one kernel row) 3 tiles x 4 steps;
-// 2*G2 + 3*G3 workgroups share the CUs, all resident at once.  Chosen: the smallest maximum of ceil(B/G) x cost, then the fewest slab bytes.
+// conv23_wgrad.hip (per-observation conv2 / conv3 weight gradients, 84 x 84 geometry): groups of observations per layer.  conv2 is cut into
+// 4 parts, conv3 into 3, every (part, group) is one workgroup of equal cost per observation, and two workgroups share a CU: 7 G <= 2 x CUs;
+// a group's workgroups all run on XCD g % 8 (its L2 then serves the parts' common operands), so G is a multiple of 8 when it can be: 72.
 static inline bool a0_c23w_plan(const a0_net_core& n, int B, int* G2, int* G3) {
     static const bool off = getenv("A0_NO_CONV23_WGRAD_FUSED") != nullptr;
+    static const int gmax = getenv("A0_C23W_GROUPS") ? atoi(getenv("A0_C23W_GROUPS")) : ((2 * 256) / 7) / 8 * 8;      // tuning aid
     if (off || B < 1 || n.H1 != 20 || n.W1 != 20 || n.H2 != 9 || n.W2 != 9 || n.H3 != 7 || n.W3 != 7) return false;
-    const int ncu = 256, c2 = 24, c3 = 12;
-    long long best_cost = -1, best_bytes = 0;
-    auto ceil_div = [](int a, int b) { return (a + b - 1) / b; };
-    for (int g3 = 1; g3 <= B && 3 * g3 + 2 <= ncu; ++g3) {
-        int g2 = (ncu - 3 * g3) / 2;
-        if (g2 > B) g2 = B;
-        const long long t3 = (long long)ceil_div(B, g3) * c3, t2min = (long long)ceil_div(B, g2) * c2;
-        const long long cost = t3 > t2min ? t3 : t2min;
-        while (g2 > 1 && (long long)ceil_div(B, g2 - 1) * c2 <= cost) --g2;        // the fewest conv2 groups that still meet it
-        const long long bytes = (long long)g2 * 512 + (long long)g3 * 576;
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && bytes < best_bytes)) { best_cost = cost; best_bytes = bytes; *G2 = g2; *G3 = g3; }
-    }
-    return best_cost >= 0;
+    const int g = B < gmax ? B : gmax;
+    *G2 = g; *G3 = g;
+    return g >= 1;
 }
 
 // Slab regions of the three convolution weight gradients inside the caller's scratch buffer.  They are disjoint, so that the three
