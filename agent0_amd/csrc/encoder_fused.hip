@@ -1188,9 +1188,12 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
 A0_HD uint32_t a0_bf16_trunc(float f) { return __float_as_uint(f) >> 16; }
 A0_HD float a0_bf16_up(uint32_t h) { return __uint_as_float(h << 16); }
 // wt2 / state: optional second destination (the target network's copies), written only when state[4] ("sync now", optim.hip) is set.
+// commit (a0_adam_step_sync_wt): the folded Adam kernel left the new step count in state[5]; this kernel, the next on the stream, moves it
+// to state[1] and clears the NaN flag state[0] — words the Adam kernel's workgroups were still reading.
 __global__ void a0_conv_wt_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, float* __restrict__ wt, int K1,
-                                  float* __restrict__ wt2, const int* __restrict__ state) {
+                                  float* __restrict__ wt2, const int* __restrict__ state, int* __restrict__ commit) {
     const bool mirror = wt2 != nullptr && state[4] != 0;
+    if (commit != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { commit[1] = commit[5]; commit[0] = 0; }
     const int n1 = 48 * K1, n2 = 64 * 512, n3 = 64 * 576, n4 = 64 * 576, n5 = 4 * 32 * 256;      // n1: 32 channels x K1 x 3 terms x 2 bytes, in floats
     const int n6 = 96 * 512, n7 = 96 * 576;                                                       // conv2 / conv3 as three bf16 terms: 64 x K x 3 x 2 bytes
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1286,7 +1289,7 @@ extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float*
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh: bad argument");
     const long long n = a0_net_conv_wt_floats(C);
     hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->w1, w->w2, w->w3, wt, C * 64, (float*)nullptr,
-                       (const int*)nullptr);
+                       (const int*)nullptr, (int*)nullptr);
     return a0_fail_hip((int)hipGetLastError(), "a0_net_conv_wt_refresh");
 }
 
@@ -1295,8 +1298,16 @@ extern "C" int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float*
 extern "C" int a0_net_conv_wt_refresh_sync(const a0_encoder_weights* w, int C, float* wt, float* wt_target, const int* state, void* stream) {
     if (!w || !w->w1 || !w->w2 || !w->w3 || !wt || !wt_target || !state || C < 1) return a0_fail(A0_EINVAL, "a0_net_conv_wt_refresh_sync: bad argument");
     const long long n = a0_net_conv_wt_floats(C);
-    hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->w1, w->w2, w->w3, wt, C * 64, wt_target, state);
+    hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->w1, w->w2, w->w3, wt, C * 64, wt_target, state, (int*)nullptr);
     return a0_fail_hip((int)hipGetLastError(), "a0_net_conv_wt_refresh_sync");
+}
+
+// ... and with the step-counter commit of a0_adam_step_sync_wt (optim.hip)
+int a0_conv_wt_refresh_commit(const a0_encoder_weights* w, int C, float* wt, float* wt_target, int* state, hipStream_t st) {
+    if (!w || !w->w1 || !w->w2 || !w->w3) return a0_fail(A0_EINVAL, "a0_adam_step_sync_wt: encoder weights missing");
+    const long long n = a0_net_conv_wt_floats(C);
+    hipLaunchKernelGGL(a0_conv_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w->w1, w->w2, w->w3, wt, C * 64, wt_target, (const int*)state, state);
+    return a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync_wt");
 }
 
 static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_bytes) {

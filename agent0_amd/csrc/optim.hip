@@ -63,12 +63,39 @@ extern "C" int a0_adam_step(float* params, const float* grads, float* exp_avg, f
 // Adam with the target copy folded in: when the prep kernel decided "sync now" (update_steps % target_update_freq == 0, agent.py:160-161)
 // every element's NEW value is also written to the target buffer, over [0, n_total) — n_total > n covers blocks Adam does not own (FQF's
 // fraction net).  A skipped (NaN) step leaves the parameters alone but still syncs, like the reference.  == a0_adam_step + a0_target_sync.
+// FOLD: no a0_adam_prep_kernel in front.  Every workgroup derives the step's decisions and scalars itself from state[0] (NaN flag), state[1]
+// (update_steps BEFORE this step) and the data-parallel flag — words nobody writes during this kernel — and workgroup 0 publishes them:
+// state[2..4] as the prep kernel does, the scalars, and the NEW step count in state[5].  state[1] <- state[5] and state[0] <- 0 are
+// committed by the next kernel on the stream (a0_conv_wt_kernel with `commit`), because other workgroups of this one may still have to read them.
+struct a0_adam_fold { double lr, b1, b2; int target_freq; const float* extra_flag; int* state_w; float* scal_w; };
+template <bool FOLD>
 __global__ void a0_adam_sync_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                     long long n, const int* __restrict__ state, const float* __restrict__ scal,
-                                    float w1, float b2, float w2, float eps, float* __restrict__ target, long long n_total, int vec4) {
-    const bool skip = state[3] != 0, sync = state[4] != 0;
+                                    float w1, float b2, float w2, float eps, float* __restrict__ target, long long n_total, int vec4, a0_adam_fold F) {
+    bool skip, sync;
+    float step_size, bc2_sqrt;
+    if constexpr (FOLD) {
+        __shared__ float sh_f[2];
+        __shared__ int sh_i[2];
+        if (threadIdx.x == 0) {
+            const int sk = (state[0] != 0) || (F.extra_flag && F.extra_flag[0] != 0.f);
+            const int steps = state[1] + (sk ? 0 : 1);
+            const int t = steps > 0 ? steps : 1;
+            const float ss = (float)(F.lr / (1.0 - pow(F.b1, (double)t))), bc = (float)sqrt(1.0 - pow(F.b2, (double)t));
+            const int sy = (F.target_freq > 0 && (steps % F.target_freq) == 0) ? 1 : 0;
+            sh_f[0] = ss; sh_f[1] = bc; sh_i[0] = sk; sh_i[1] = sy;
+            if (blockIdx.x == 0) {
+                if (sk) F.state_w[2] += 1;
+                F.state_w[3] = sk; F.state_w[4] = sy; F.state_w[5] = steps;
+                F.scal_w[0] = ss; F.scal_w[1] = bc;
+            }
+        }
+        __syncthreads();
+        skip = sh_i[0] != 0; sync = sh_i[1] != 0; step_size = sh_f[0]; bc2_sqrt = sh_f[1];
+    } else {
+        skip = state[3] != 0; sync = state[4] != 0; step_size = scal[0]; bc2_sqrt = scal[1];
+    }
     if (skip && !sync) return;
-    const float step_size = scal[0], bc2_sqrt = scal[1];
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long end = sync ? n_total : n;
@@ -124,9 +151,31 @@ extern "C" int a0_adam_step_sync(float* params, const float* grads, float* exp_a
                      ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq) | ((uintptr_t)target)) % 16 == 0);
     long long blocks = ((vec4 ? n_total / 4 : n_total) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(a0_adam_sync_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4);
+    hipLaunchKernelGGL(a0_adam_sync_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4, a0_adam_fold{});
     return a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync");
+}
+
+// The optimizer tail of a network with fused-kernel weight copies, in TWO launches: Adam with the step's bookkeeping folded in (no one-thread
+// prep kernel in front), then the refresh of the online net's weight copies (mirrored into the target's on a sync step), which also commits
+// the step counter.  Same results as a0_adam_step_sync + a0_net_conv_wt_refresh_sync.
+int a0_conv_wt_refresh_commit(const a0_encoder_weights* w, int C, float* wt, float* wt_target, int* state, hipStream_t st);      // encoder_fused.hip
+extern "C" int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars,
+                                    double lr, double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total,
+                                    const float* extra_nan_flag, const a0_encoder_weights* w, int C, float* wt, float* wt_target, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !state || !scalars || !target || n < 1 || n_total < n || !w || !wt || !wt_target || C < 1)
+        return a0_fail(A0_EINVAL, "a0_adam_step_sync_wt: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int vec4 = ((n | n_total) % 4 == 0) &&
+                     ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq) | ((uintptr_t)target)) % 16 == 0);
+    long long blocks = ((vec4 ? n_total / 4 : n_total) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(a0_adam_sync_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const int*)state, (const float*)scalars,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4,
+                       a0_adam_fold{lr, beta1, beta2, target_update_freq, extra_nan_flag, state, scalars});
+    int e = a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync_wt");
+    if (e != A0_OK) return e;
+    return a0_conv_wt_refresh_commit(w, C, wt, wt_target, state, st);
 }
 
 // out[0] = 1.0f if this rank's NaN flag (state[0], set by the loss kernels) is up, else 0.0f — a float so that it can ride along in

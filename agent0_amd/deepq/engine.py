@@ -390,12 +390,14 @@ class DeviceLearner:
         if L.algo == "fqf":           # unconditional, like the reference's fqf_optimizer.step() in front of the NaN guard (agent.py:139-148)
             blk = L.blocks["frac"]
             ops.rmsprop_step(on.flat[blk.all], self.grads[blk.all], self.rms_sq, blk.size, self.lr / 2e4, 0.95, 1e-5, self.max_grad_norm, self.clip)
-        # three launches: Adam's scalars; Adam with the target copy folded in; the online conv copies, mirrored to the target's on a sync
         tail = self.grads[L.n_params_padded: L.n_params_padded + 1] if self._bucketed_hook() else None
-        ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
-                           self.target_update_freq, tg.flat, L.n_params_padded, tail)
         if on.fused:
-            ops.conv_wt_refresh_sync(on.encoder_weights(), L.C, on.wt, tg.wt, self.state)
+            # two launches: Adam with its bookkeeping and the target copy folded in; the online conv copies, mirrored to the target's on a sync
+            ops.adam_step_sync_wt(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
+                                  self.target_update_freq, tg.flat, L.n_params_padded, tail, on.encoder_weights(), L.C, on.wt, tg.wt)
+        else:
+            ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
+                               self.target_update_freq, tg.flat, L.n_params_padded, tail)
 
     def forward_dense(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
         """Forward passes, losses and the dense half of the backward pass (every gradient but the convolution blocks', which

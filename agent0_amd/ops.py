@@ -268,6 +268,15 @@ class HipOps:
                                          lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total,
                                          _req(extra_nan_flag, torch.float32, 1, "extra_nan_flag", optional=True), _stream()), "a0_adam_step_sync")
 
+    def adam_step_sync_wt(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag, w, C_, wt, wt_target):
+        ew = self._enc_w(w)
+        nw = self.conv_wt_floats(C_)
+        check(self.lib.a0_adam_step_sync_wt(_req(params, torch.float32, n_total, "params"), _req(grads, torch.float32, n, "grads"), _req(m, torch.float32, n, "m"),
+                                            _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
+                                            lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total,
+                                            _req(extra_nan_flag, torch.float32, 1, "extra_nan_flag", optional=True), C.addressof(ew), C_,
+                                            _req(wt, torch.float32, nw, "wt"), _req(wt_target, torch.float32, nw, "wt_target"), _stream()), "a0_adam_step_sync_wt")
+
     def nan_flag_export(self, state, out):
         check(self.lib.a0_nan_flag_export(_req(state, torch.int32, 8, "state"), _req(out, torch.float32, 1, "out"), _stream()), "a0_nan_flag_export")
 

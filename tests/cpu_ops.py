@@ -356,6 +356,10 @@ class CpuOps:
         self.adam_step(params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq)
         self.target_sync(target, params, n_total, state, False)
 
+    def adam_step_sync_wt(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag, w, C_, wt, wt_target):
+        self.adam_step_sync(params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag)
+        self.conv_wt_refresh_sync(w, C_, wt, wt_target, state)
+
     def dense_fwd_partial_slabs(self, R, N, K) -> int:
         return 1
 
