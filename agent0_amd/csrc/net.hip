@@ -411,6 +411,17 @@ __global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __rest
     for (int i = 0; i < 8; ++i) h[i] = 0.f;
     const float* sp = slabs + (long long)er * 512 + lane;
     int z = 0;
+    for (; z + 8 <= nslab; z += 8) {        // the actor's usual eight slabs: ONE trip, all 64 loads of a lane in flight together (same order of additions)
+        float t[8][8];
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[zz][i] = sp[(long long)(z + zz) * slab_stride + 64 * i];
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] += t[zz][i];
+    }
     for (; z + 4 <= nslab; z += 4) {
         float t[4][8];
 #pragma unroll
