@@ -391,21 +391,15 @@ extern "C" int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int
 // finishes fc1 (slab sum + bias + ReLU), evaluates the q head (A or A+1 rows of 512), applies the dueling combine, takes the first
 // maximum and makes the epsilon-greedy draw from the actor's Philox streams.  One wave per environment; replaces six launches
 // (reduce, head GEMM, reduce, dueling, select, egreedy) on the actor's critical path.
-#include "philox.h"
-__global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab, const float* __restrict__ b1,
-                                                             const float* __restrict__ W2, const float* __restrict__ b2, int A, int dueling, int E,
-                                                             unsigned long long seed, uint32_t stream_a, uint32_t stream_u, unsigned long long off_a,
-                                                             unsigned long long off_u, float eps, const long long* __restrict__ ctrl,
-                                                             const float* __restrict__ eps_ptr, int* __restrict__ action, float* __restrict__ qmax) {
-    __shared__ float raw[4][64];
-    extern __shared__ float w2s[];                       // the head's A(+1) rows of 512, staged once per workgroup
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 4 + wave;
+#include "synth_env.h"
+// One wave finishes fc1 for env `er` from the GEMM's slabs (slab sum + bias + ReLU, in slab order: bit-identical to a0_reduce_bias_act_kernel),
+// evaluates the q head rows staged in `w2s`, the dueling combine, the first maximum and the epsilon-greedy draw.  `raw`: 64 floats of LDS
+// owned by this wave.  Lane 0 returns the action and max_a q; call with all 64 lanes.
+A0_D void a0_qhead_wave(const float* __restrict__ slabs, long long slab_stride, int nslab, const float* __restrict__ b1, const float* __restrict__ w2s,
+                        const float* __restrict__ b2, int A, int dueling, int er, int lane, float* __restrict__ raw, unsigned long long seed, uint32_t stream_a,
+                        uint32_t stream_u, unsigned long long off_a, unsigned long long off_u, float eps, int& out_action, float& out_best) {
     const int NQ = A + (dueling ? 1 : 0);
-    for (int i = threadIdx.x; i < NQ * 128; i += 256) ((a0_f4*)w2s)[i] = ((const a0_f4*)W2)[i];
-    const int er = e < E ? e : E - 1;
-    // fc1: h[k] = relu(b1[k] + sum_z slab_z[e][k]) in slab order (bit-identical to a0_reduce_bias_act_kernel); lane holds k = lane + 64 i.
-    // All eight columns of a slab are requested before any is added, four slabs per trip: the loads overlap instead of queueing.
+    // lane holds k = lane + 64 i.  All eight columns of a slab are requested before any is added: the loads overlap instead of queueing.
     float h[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) h[i] = 0.f;
@@ -445,8 +439,6 @@ __global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __rest
         const float sv = h[i] + b1[lane + 64 * i];
         h[i] = sv < 0.f ? 0.f : sv;
     }
-    __syncthreads();
-    if (e >= E) return;
     for (int a = 0; a < NQ; ++a) {
         const float* w = w2s + a * 512;
         float sa = 0.f;
@@ -454,28 +446,89 @@ __global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __rest
         for (int i = 0; i < 8; ++i) sa = fmaf(h[i], w[lane + 64 * i], sa);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
-        if (lane == 0) raw[wave][a] = sa + b2[a];
+        if (lane == 0) raw[a] = sa + b2[a];
     }
     if (lane != 0) return;
     float mean = 0.f, v = 0.f;
     if (dueling) {
         float t = 0.f;
-        for (int a = 0; a < A; ++a) t += raw[wave][a];
+        for (int a = 0; a < A; ++a) t += raw[a];
         mean = t / (float)A;
-        v = raw[wave][A];
+        v = raw[A];
     }
     float best = 0.f;
     int besta = 0;
     for (int a = 0; a < A; ++a) {
-        const float q = dueling ? v + (raw[wave][a] - mean) : raw[wave][a];
+        const float q = dueling ? v + (raw[a] - mean) : raw[a];
         if (a == 0 || q > best) { best = q; besta = a; }
     }
+    const int ra = (int)(a0_philox_word(seed, stream_a, off_a + (unsigned long long)er) % (uint32_t)A);
+    const float u = (float)(a0_philox_word(seed, stream_u, off_u + (unsigned long long)er) >> 8) * 0x1.0p-24f;
+    out_action = (u > eps) ? besta : ra;
+    out_best = best;
+}
+
+__global__ __launch_bounds__(256) void a0_actor_qhead_kernel(const float* __restrict__ slabs, long long slab_stride, int nslab, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2, int A, int dueling, int E,
+                                                             unsigned long long seed, uint32_t stream_a, uint32_t stream_u, unsigned long long off_a,
+                                                             unsigned long long off_u, float eps, const long long* __restrict__ ctrl,
+                                                             const float* __restrict__ eps_ptr, int* __restrict__ action, float* __restrict__ qmax) {
+    __shared__ float raw[4][64];
+    extern __shared__ float w2s[];                       // the head's A(+1) rows of 512, staged once per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    const int NQ = A + (dueling ? 1 : 0);
+    for (int i = threadIdx.x; i < NQ * 128; i += 256) ((a0_f4*)w2s)[i] = ((const a0_f4*)W2)[i];
+    __syncthreads();
+    if (e >= E) return;
     if (ctrl) { off_a += (unsigned long long)ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)ctrl[A0_CTRL_RNG_UNIFORM]; }
     if (eps_ptr) eps = eps_ptr[0];
-    const int ra = (int)(a0_philox_word(seed, stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
-    const float u = (float)(a0_philox_word(seed, stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
-    action[e] = (u > eps) ? besta : ra;
-    qmax[e] = best;
+    int act = 0; float best = 0.f;
+    a0_qhead_wave(slabs, slab_stride, nslab, b1, w2s, b2, A, dueling, e, lane, raw[wave], seed, stream_a, stream_u, off_a, off_u, eps, act, best);
+    if (lane == 0) { action[e] = act; qmax[e] = best; }
+}
+
+// The actor tail AND the synthetic env's step in one launch, one workgroup per env (reference agent.py:25-39 followed by agent.py:52-81 for
+// that env): wave 0 finishes fc1, evaluates the head and draws the action exactly as a0_actor_qhead_kernel does, then its lane 0 does the
+// env's scalar work with that action (episode statistics, n-step bookkeeping, the replay row's a / R / D); meanwhile the other three waves
+// are already producing the new frame, the shifted stack and the replay row's frames — none of which needs the action — and wave 0 joins
+// them when it is done.  Same bytes as a0_actor_qhead + a0_env_synth_step_commit; one kernel boundary less on the actor's critical path,
+// and the env's 29 MB of HBM traffic overlaps the latency-bound head.
+struct a0_qenv_args {
+    const float* slabs; long long slab_stride; int nslab; const float *b1, *W2, *b2; int A, dueling, E;
+    unsigned long long rng_seed; uint32_t stream_a, stream_u; unsigned long long off_a, off_u; float eps; const long long* ctrl; const float* eps_ptr;
+    int* action; float* qmax;
+    unsigned long long env_seed; uint32_t rank, g; const uint8_t* obs_in; uint8_t* obs_out; float *ep_ret, *final_mask, *final_ret;
+    int n; long long steps; double gamma; int* ring_act; float *ring_rew, *ring_done; const uint8_t* obs0; uint8_t* frames; long long cap, start;
+    int* r_act; float *r_rew, *r_done;
+};
+__global__ __launch_bounds__(256) void a0_actor_qhead_env_kernel(a0_qenv_args P) {
+    __shared__ float raw[64];
+    extern __shared__ float w2s[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t e = blockIdx.x;
+    const int NQ = P.A + (P.dueling ? 1 : 0);
+    for (int i = threadIdx.x; i < NQ * 128; i += 256) ((a0_f4*)w2s)[i] = ((const a0_f4*)P.W2)[i];
+    uint32_t g = P.g; long long steps = P.steps, start = P.start; unsigned long long off_a = P.off_a, off_u = P.off_u; float eps = P.eps;
+    if (P.ctrl) {
+        g += (uint32_t)P.ctrl[A0_CTRL_ENV_STEP]; steps += P.ctrl[A0_CTRL_ACTOR_STEPS]; start += P.ctrl[A0_CTRL_REPLAY_SLOT];
+        off_a += (unsigned long long)P.ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)P.ctrl[A0_CTRL_RNG_UNIFORM];
+    }
+    if (P.eps_ptr) eps = P.eps_ptr[0];
+    const long long slot = (start + e) % P.cap;
+    const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
+    const bool term = (x.y % 500u) == 0u;
+    __syncthreads();
+    if (wave == 0) {
+        int act = 0; float best = 0.f;
+        a0_qhead_wave(P.slabs, P.slab_stride, P.nslab, P.b1, w2s, P.b2, P.A, P.dueling, (int)e, lane, raw, P.rng_seed, P.stream_a, P.stream_u, off_a, off_u, eps, act, best);
+        if (lane == 0) {
+            P.action[e] = act; P.qmax[e] = best;
+            a0_env_commit_scalars(x, e, P.E, P.n, steps, P.gamma, act, P.ep_ret, P.final_mask, P.final_ret, P.ring_act, P.ring_rew, P.ring_done, P.r_act, P.r_rew,
+                                  P.r_done, slot);
+        }
+    }
+    a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), threadIdx.x, 256);
 }
 
 extern "C" long long a0_actor_qhead_scratch(int E, int K) {
@@ -498,6 +551,39 @@ extern "C" int a0_actor_qhead(const float* feat, int E, int K, const float* W1, 
     a0_fc1_partial_launch(bk, a, bw, ep, E, 512, K, splits);
     hipLaunchKernelGGL(a0_actor_qhead_kernel, dim3((E + 3) / 4), dim3(256), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, scratch, (long long)E * 512, splits, b1, W2, b2, A, dueling, E,
                        seed, stream_a, stream_u, off_a, off_u, eps, ctrl, eps_ptr, action, qmax);
+    A0_HIP_THROW(hipGetLastError());
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_actor_qhead_env_step(const float* feat, int E, int K, const float* W1, const float* b1, const float* W2, const float* b2, int A, int dueling,
+                                       float* scratch, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                       unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                       unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                       float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                       const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream) {
+    A0_TRY
+    if (!feat || !W1 || !b1 || !W2 || !b2 || !scratch || !action || !qmax || E < 1 || K < 4 || (K & 3) || A < 1 || A + (dueling ? 1 : 0) > 24)
+        return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad argument (A + dueling <= 24: the head rows are staged in 48 KB of LDS)");
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad env argument");
+    if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: buffers must be 16-byte aligned");
+    a0_hip_backend bk{(hipStream_t)stream};
+    const int splits = a0_fc1_splits(E, 512, K);
+    a0_mat_src a{feat, K};
+    a0_mat_src bw{W1, K};
+    EpiSlab::Params ep{scratch, (long long)E * 512, 512};
+    bk.tag = A0_TAG_DENSE_FWD;
+    a0_fc1_partial_launch(bk, a, bw, ep, E, 512, K, splits);
+    a0_qenv_args P;
+    P.slabs = scratch; P.slab_stride = (long long)E * 512; P.nslab = splits; P.b1 = b1; P.W2 = W2; P.b2 = b2; P.A = A; P.dueling = dueling; P.E = E;
+    P.rng_seed = seed; P.stream_a = stream_a; P.stream_u = stream_u; P.off_a = off_a; P.off_u = off_u; P.eps = eps; P.ctrl = ctrl; P.eps_ptr = eps_ptr;
+    P.action = action; P.qmax = qmax;
+    P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
+    P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    hipLaunchKernelGGL(a0_actor_qhead_env_kernel, dim3(E), dim3(256), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, P);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
     A0_CATCH

@@ -1,0 +1,95 @@
+// Device functions of the synthetic vector env that more than one translation unit needs (synth_env.hip: the env's own kernels; net.hip: the
+// actor tail that also performs the env step).  Byte-exact twin of oracle/synth_env.c.
+#pragma once
+#include "a0_defs.h"
+#include "philox.h"
+
+#define A0_ENV_H 84
+#define A0_ENV_W 84
+#define A0_ENV_PIX (A0_ENV_H * A0_ENV_W)
+
+A0_D uint32_t a0_env_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix) {
+    const uint32_t y = pix / A0_ENV_W, x = pix - y * A0_ENV_W;
+    const uint32_t h = a0_env_mix32(base ^ (pix * 0x85EBCA77u));
+    uint8_t v = (((h >> 8) & 3u) == 0u) ? (uint8_t)(h & 255u) : (uint8_t)0;
+    if (y >= by && y < by + 8 && x >= bx && x < bx + 8) v = 255;
+    return v;
+}
+
+
+// n-step bookkeeping of one env and step (a0_nstep_kernel; truncated is always 0 for this env) and the emitted transition's (a, R, D)
+A0_D void a0_env_nstep_row(uint32_t e, int E, int n, long long steps, double gamma, float r, bool done, int a_now, int* __restrict__ ring_act,
+                           float* __restrict__ ring_rew, float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew,
+                           float* __restrict__ r_done, long long slot) {
+#pragma clang fp contract(off)      // R = R * gamma * (1 - d) + r in separately rounded steps, like numpy (agent.py:64-69) and oracle/core.py
+    const int cur = (int)(steps % n);
+    ring_act[(long long)cur * E + e] = a_now;
+    ring_rew[(long long)cur * E + e] = r;
+    ring_done[(long long)cur * E + e] = done ? 1.f : 0.f;
+    const long long have = steps + 1;
+    const int count = have < n ? (int)have : n;
+    double R = 0.0;
+    bool D = false;
+    for (int k = 0; k < count; ++k) {
+        const int idx = (int)(((steps - k) % n + n) % n);
+        const float dk = (k == 0) ? (done ? 1.f : 0.f) : ring_done[(long long)idx * E + e];
+        const float rk = (k == 0) ? r : ring_rew[(long long)idx * E + e];
+        D = D || (dk != 0.f);
+        R = R * gamma * (double)(1 - (dk != 0.f ? 1 : 0)) + (double)rk;
+    }
+    const int oldest = (int)(((steps - (count - 1)) % n + n) % n);
+    r_act[slot] = (count == 1) ? a_now : ring_act[(long long)oldest * E + e];
+    r_rew[slot] = (float)R;
+    r_done[slot] = D ? 1.f : 0.f;
+}
+
+// episode statistics + n-step row of env e at step g: what ONE thread per env does once the action is known
+A0_D void a0_env_commit_scalars(const a0_u4& x, uint32_t e, int E, int n, long long steps, double gamma, int a_now, float* __restrict__ ep_ret,
+                                float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act, float* __restrict__ ring_rew,
+                                float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done, long long slot) {
+#pragma clang fp contract(off)
+    const bool term = (x.y % 500u) == 0u;
+    const uint32_t rw = x.x % 1000u;
+    const float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+    const bool life = (!term) && ((x.z % 200u) == 0u);
+    const float ret = ep_ret[e] + r;
+    final_mask[e] = term ? 1.f : 0.f;
+    final_ret[e] = term ? ret : 0.f;
+    ep_ret[e] = term ? 0.f : ret;
+    a0_env_nstep_row(e, E, n, steps, gamma, r, term || life, a_now, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
+}
+
+// the frame work of env e at step g for the 16-byte groups j = j0, j0 + jstride, ...: new frame, stack shift into obs_out, and the replay row
+// [st (obs0) | st_next] at `row`
+A0_D void a0_env_commit_frames(unsigned long long seed, uint32_t e, uint32_t g, bool term, const uint8_t* __restrict__ obs_in, uint8_t* __restrict__ obs_out,
+                               const uint8_t* __restrict__ obs0, uint8_t* __restrict__ row, int j0, int jstride) {
+    const uint32_t base = (uint32_t)seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
+    const uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    const int q = A0_ENV_PIX / 16;
+    const uint4* in16 = (const uint4*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
+    const uint4* o016 = (const uint4*)(obs0 + (size_t)e * 4 * A0_ENV_PIX);
+    uint4* out16 = (uint4*)(obs_out + (size_t)e * 4 * A0_ENV_PIX);
+    uint4* row16 = (uint4*)row;
+    for (int j = j0; j < q; j += jstride) {
+        const uint4 i0 = in16[j], i1 = in16[q + j], i2 = in16[2 * q + j], i3 = in16[3 * q + j];
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = 16u * (uint32_t)j + 4u * (uint32_t)k;
+            w[k] = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
+                   ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
+        }
+        const uint4 nw = uint4{w[0], w[1], w[2], w[3]};
+        uint4 n0, n1, n2, n3;
+        if (term) { n0 = nw; n1 = nw; n2 = nw; n3 = nw; } else { n0 = i1; n1 = i2; n2 = i3; n3 = nw; }
+        out16[j] = n0; out16[q + j] = n1; out16[2 * q + j] = n2; out16[3 * q + j] = n3;
+        if (obs0 == obs_in) { row16[j] = i0; row16[q + j] = i1; row16[2 * q + j] = i2; row16[3 * q + j] = i3; }
+        else { row16[j] = o016[j]; row16[q + j] = o016[q + j]; row16[2 * q + j] = o016[2 * q + j]; row16[3 * q + j] = o016[3 * q + j]; }
+        row16[4 * q + j] = n0; row16[5 * q + j] = n1; row16[6 * q + j] = n2; row16[7 * q + j] = n3;
+    }
+}

@@ -3,26 +3,9 @@
 // available on the GPU box); honours the obs/reward/terminal/truncated/life_loss/episode-return contract that
 // agent0/deepq/agent.py:55-62,85-88 consumes.  It is NOT Atari.
 #include "a0_internal.h"
-#include "philox.h"
 
 #pragma clang fp contract(off)
-
-#define A0_ENV_H 84
-#define A0_ENV_W 84
-#define A0_ENV_PIX (A0_ENV_H * A0_ENV_W)
-
-A0_D uint32_t a0_env_mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x;
-}
-
-A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix) {
-    const uint32_t y = pix / A0_ENV_W, x = pix - y * A0_ENV_W;
-    const uint32_t h = a0_env_mix32(base ^ (pix * 0x85EBCA77u));
-    uint8_t v = (((h >> 8) & 3u) == 0u) ? (uint8_t)(h & 255u) : (uint8_t)0;
-    if (y >= by && y < by + 8 && x >= bx && x < bx + 8) v = 255;
-    return v;
-}
+#include "synth_env.h"
 
 // grid (chunks, E); each thread produces 4 consecutive pixels of the new frame and moves the matching 4-byte groups
 // of the three older frames.  g = step index since reset (identical for every env: they step in lockstep).
@@ -105,62 +88,10 @@ __global__ __launch_bounds__(256) void a0_env_step_commit_kernel(unsigned long l
     const long long slot = (start + e) % cap;
     const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)seed, (uint32_t)(seed >> 32) ^ rank);
     const bool term = (x.y % 500u) == 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t rw = x.x % 1000u;
-        const float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
-        const bool life = (!term) && ((x.z % 200u) == 0u);
-        const float ret = ep_ret[e] + r;
-        final_mask[e] = term ? 1.f : 0.f;
-        final_ret[e] = term ? ret : 0.f;
-        ep_ret[e] = term ? 0.f : ret;
-        // n-step bookkeeping (a0_nstep_kernel; truncated is always 0 for this env)
-        const bool done = term || life;
-        const int cur = (int)(steps % n);
-        const int a_now = action[e];
-        ring_act[(long long)cur * E + e] = a_now;
-        ring_rew[(long long)cur * E + e] = r;
-        ring_done[(long long)cur * E + e] = done ? 1.f : 0.f;
-        const long long have = steps + 1;
-        const int count = have < n ? (int)have : n;
-        double R = 0.0;
-        bool D = false;
-        for (int k = 0; k < count; ++k) {
-            const int idx = (int)(((steps - k) % n + n) % n);
-            const float dk = (k == 0) ? (done ? 1.f : 0.f) : ring_done[(long long)idx * E + e];
-            const float rk = (k == 0) ? r : ring_rew[(long long)idx * E + e];
-            D = D || (dk != 0.f);
-            R = R * gamma * (double)(1 - (dk != 0.f ? 1 : 0)) + (double)rk;
-        }
-        const int oldest = (int)(((steps - (count - 1)) % n + n) % n);
-        r_act[slot] = (count == 1) ? a_now : ring_act[(long long)oldest * E + e];
-        r_rew[slot] = (float)R;
-        r_done[slot] = D ? 1.f : 0.f;
-    }
-    const uint32_t base = (uint32_t)seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
-    const uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a0_env_commit_scalars(x, e, E, n, steps, gamma, action[e], ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
     // 16 bytes per lane: 441 lanes cover a frame (two workgroups per env); every load and store is a full-width vector access
-    const int q = A0_ENV_PIX / 16;
-    const uint4* in16 = (const uint4*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
-    const uint4* o016 = (const uint4*)(obs0 + (size_t)e * 4 * A0_ENV_PIX);
-    uint4* out16 = (uint4*)(obs_out + (size_t)e * 4 * A0_ENV_PIX);
-    uint4* row16 = (uint4*)(frames + slot * (8LL * A0_ENV_PIX));          // [st (4 frames) | st_next (4 frames)]
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < q; j += gridDim.x * blockDim.x) {
-        const uint4 i0 = in16[j], i1 = in16[q + j], i2 = in16[2 * q + j], i3 = in16[3 * q + j];
-        uint32_t w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t p = 16u * (uint32_t)j + 4u * (uint32_t)k;
-            w[k] = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
-                   ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
-        }
-        const uint4 nw = uint4{w[0], w[1], w[2], w[3]};
-        uint4 n0, n1, n2, n3;
-        if (term) { n0 = nw; n1 = nw; n2 = nw; n3 = nw; } else { n0 = i1; n1 = i2; n2 = i3; n3 = nw; }
-        out16[j] = n0; out16[q + j] = n1; out16[2 * q + j] = n2; out16[3 * q + j] = n3;
-        if (obs0 == obs_in) { row16[j] = i0; row16[q + j] = i1; row16[2 * q + j] = i2; row16[3 * q + j] = i3; }
-        else { row16[j] = o016[j]; row16[q + j] = o016[q + j]; row16[2 * q + j] = o016[2 * q + j]; row16[3 * q + j] = o016[3 * q + j]; }
-        row16[4 * q + j] = n0; row16[5 * q + j] = n1; row16[6 * q + j] = n2; row16[7 * q + j] = n3;
-    }
+    a0_env_commit_frames(seed, e, g, term, obs_in, obs_out, obs0, frames + slot * (8LL * A0_ENV_PIX), blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 extern "C" int a0_env_synth_step_commit(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,

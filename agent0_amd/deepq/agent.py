@@ -12,6 +12,8 @@ Mirrors /root/reference agent0/deepq/agent.py: ``Actor`` (16-93: ``act``, ``rese
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import numpy as np
@@ -85,17 +87,24 @@ class Actor:
         self.atoms = self.model.head.atoms.reshape(-1).contiguous() if self.L.algo == "c51" else None
         self._stage = None
         self.fused_commit = hasattr(self.envs, "step_commit") and (self.obs_bytes == 4 * 84 * 84)
+        # scalar heads on the synthetic env: the tail and the env step share one launch (a0_actor_qhead_env_step)
+        self.tail_env = self.fused_tail and self.fused_commit and hasattr(self.envs, "act_step_commit") and os.environ.get("A0_TAIL_ENV", "1") != "0"      # 0: tuning aid (same bytes)
 
     # ------------------------------------------------------------------ agent.py:25-39
-    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None, t: int = 0):
+    def _qhead_args(self, epsilon, ctrl, eps_ptr, t):
+        L, E, dev, rng = self.L, self.E, self.model._dev, self.rng
+        (W1, b1), (W2, b2) = dev.wb("fc1"), dev.wb("head")
+        return (self.ws.act3, E, L.feat, W1, b1, W2, b2, L.A, L.dueling, self._qh_scratch, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
+                rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+
+    def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None, t: int = 0, tail: bool = True):
+        """``tail=False``: the encoder only — the caller runs the scalar-head tail together with the env step (``_qhead_args``)."""
         L, ops, E, dev = self.L, self.ops, self.E, self.model._dev
         dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E, keep=False)
+        if not tail:
+            return
         if self.fused_tail:
-            rng = self.rng
-            (W1, b1), (W2, b2) = dev.wb("fc1"), dev.wb("head")
-            ops.actor_qhead(self.ws.act3, E, L.feat, W1, b1, W2, b2, L.A, L.dueling, self._qh_scratch, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
-                            rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action,
-                            self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+            ops.actor_qhead(*self._qhead_args(epsilon, ctrl, eps_ptr, t))
             return
         if self.dist_tail:
             rng = self.rng
@@ -144,7 +153,8 @@ class Actor:
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
                 self.model.reset_noise(rng=self.rng)
-            self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t)
+            merged = bound and not test and self.tail_env
+            self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t, tail=not merged)
             cur_obs = self.obs
             if self.n > 1 and self.env_history:
                 obs0 = self.envs.history(min(self.steps + 1, self.n) - 1)         # first observation of the emitted n-step transition
@@ -156,6 +166,14 @@ class Actor:
                 obs0 = self.ring_obs[oldest * E * self.obs_bytes:(oldest + 1) * E * self.obs_bytes]
             else:
                 obs0 = cur_obs
+            if merged:
+                # fc1's tail (head, argmax, epsilon-greedy) and the env step + n-step bookkeeping + replay row in ONE launch
+                rp = self.replay
+                self.obs = self.envs.act_step_commit(self._qhead_args(epsilon, ctrl, eps_ptr, t), self.stat_mask[t * E:(t + 1) * E], self.stat_ret[t * E:(t + 1) * E],
+                                                     self.n, self.steps, float(cfg.learner.discount), self.ring_act, self.ring_rew, self.ring_done, obs0, rp,
+                                                     (start + t * E) % rp.size)
+                self.steps += 1
+                continue
             if bound and not test and self.fused_commit:
                 # env step, n-step bookkeeping and the replay row in one launch (synthetic env)
                 rp = self.replay

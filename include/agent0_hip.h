@@ -275,6 +275,15 @@ long long a0_actor_qhead_scratch(int E, int K);
 int a0_actor_qhead(const float* feat, int E, int K, const float* W1, const float* b1, const float* W2, const float* b2, int A, int dueling,
                    float* scratch, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
                    unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax, void* stream);
+/* a0_actor_qhead + a0_env_synth_step_commit in two launches instead of three (the fc1 GEMM, then ONE kernel with a workgroup per env: one
+ * wave runs the tail and the env's scalar work with the chosen action while the others already write the new frame / stack / replay row).
+ * Arguments: those of a0_actor_qhead, then those of a0_env_synth_step_commit (the action is taken from, and written to, `action`). */
+int a0_actor_qhead_env_step(const float* feat, int E, int K, const float* W1, const float* b1, const float* W2, const float* b2, int A, int dueling,
+                            float* scratch, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                            unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                            unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                            float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                            const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
 /* out[t] = mean over e of x[t][e] (per-step mean max-Q of a rollout, agent.py:38,88) */
 int a0_mean_rows(const float* x, int T, int E, float* out, void* stream);
 
