@@ -73,6 +73,32 @@ for f, name in names.items():
             other[name] = {"error": str(e)}
 json.dump(other, open(os.path.join(DST, f"{tag}_other_configs.json"), "w"), indent=1)
 
+# ---- BASELINE configs[2..4] with their own kernel tables and roofline (tools/prof_configs.sh)
+cfg_lines = [f"# BASELINE configs[2..4] at full size ({tag}, MI355X gfx950, 1 GPU): bench line with the roofline of that configuration's dominant kernel + rocprofv3 kernel statistics", "",
+             "`R=" + tag + " bash tools/prof_configs.sh`: per configuration `python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry --steps 4 --warmup 2 --algo ...` once plain (the JSON line) "
+             "and once under `rocprofv3 --kernel-trace --stats` (the table; it covers the untimed replay fill, warm-up, the timed and the probe iterations).", ""]
+for short, title in (("c51", "configs[2] Breakout c51 double-Q + dueling + NoisyNet, n_step = 3, prioritized sum-tree replay"), ("iqn", "configs[3] Asterix iqn (iqr)"),
+                     ("fqf", "configs[4] Asterix fqf, one rank")):
+    bj, ks = os.path.join(SRC, f"{short}_bench.json"), os.path.join(SRC, f"{short}_kernel_stats.csv")
+    if not (os.path.exists(bj) and os.path.exists(ks)):
+        continue
+    d = last_json(bj)
+    json.dump(d, open(os.path.join(DST, f"{tag}_{short}_bench.json"), "w"), indent=1)
+    shutil.copy(ks, os.path.join(DST, f"{tag}_{short}_kernel_stats.csv"))
+    r = d.get("roofline") or {}
+    cfg_lines += [f"## {title}", "",
+                  f"* {d['value']:.0f} env-frames/s, {d['ms_per_step']} ms per iteration, {d['updates_per_sec']} updates/s (`{tag}_{short}_bench.json`).",
+                  f"* roofline of the dominant kernel family: {r.get('achieved')} {r.get('unit')} = {r.get('frac')} of the {r.get('peak')} fp32 MFMA peak over {r.get('launches')} launches "
+                  f"({r.get('avg_us')} us each; {str(r.get('kernel'))[:120]}...).", "",
+                  "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
+    rows_c = list(csv.DictReader(open(ks)))
+    for rr in rows_c[:14]:
+        nm = rr["Name"].split("(")[0].replace("void ", "")
+        cfg_lines.append(f"| `{nm}` | {rr['Calls']} | {float(rr['TotalDurationNs']) / 1e6:.2f} | {float(rr['AverageNs']) / 1e3:.1f} | {float(rr['Percentage']):.2f} |")
+    cfg_lines.append("")
+if len(cfg_lines) > 4:
+    open(os.path.join(DST, f"{tag}_configs_rocprof_summary.md"), "w").write("\n".join(cfg_lines))
+
 # ---- data-parallel rehearsal (one-rank RCCL group, A0_DP_FORCE=1) and the host-environment front-end, when their runs are there
 for src, dst in (("bench_dpforce.json", f"{tag}_bench_dqn_dp_rehearsal.json"), ("host_env.json", f"{tag}_host_env_front_end.json")):
     path = os.path.join(SRC, src)

@@ -1,12 +1,12 @@
 # Regenerates the evidence under gpurun_out/<round>/ (R=r02 by default) that profiles/ is built from: default bench line (+ the launch entry point), kernel-trace
 # stats of the same command, and the two PMC passes (FETCH_SIZE, WRITE_SIZE) for the HBM traffic of the fused kernels.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; R=${R:-r02}
-mkdir -p gpurun_out/${R:-r02}
-python3 bench.py > gpurun_out/${R:-r02}/bench.json 2> gpurun_out/${R:-r02}/bench.err
-python3 bench.py --entry launch --no-cpu-baseline --no-other-entry > gpurun_out/${R:-r02}/bench_launch.json 2> gpurun_out/${R:-r02}/bench_launch.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R:-r02}/prof -- python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry > gpurun_out/${R:-r02}/prof.log 2>&1
-A0_PROBE=none rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${R:-r02}/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/${R:-r02}/pmc_fetch.log 2>&1
-A0_PROBE=none rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${R:-r02}/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/${R:-r02}/pmc_write.log 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; R=${R:-r03}
+mkdir -p gpurun_out/${R:-r03}
+python3 bench.py > gpurun_out/${R:-r03}/bench.json 2> gpurun_out/${R:-r03}/bench.err
+python3 bench.py --entry launch --no-cpu-baseline --no-other-entry > gpurun_out/${R:-r03}/bench_launch.json 2> gpurun_out/${R:-r03}/bench_launch.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R:-r03}/prof -- python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry > gpurun_out/${R:-r03}/prof.log 2>&1
+A0_PROBE=none rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${R:-r03}/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/${R:-r03}/pmc_fetch.log 2>&1
+A0_PROBE=none rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${R:-r03}/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 > gpurun_out/${R:-r03}/pmc_write.log 2>&1
 R=$R python3 - <<'PY'
 import csv, glob, collections, json, os
 R = os.environ.get("R", "r02")
@@ -37,5 +37,5 @@ tr = {f"{k}|grid={g}": {"launches": len(v), "avg_us": sum(v) / len(v), "min_us":
 json.dump(tr, open(f"gpurun_out/{R}/fused_by_grid.json", "w"), indent=1)
 print(json.dumps(tr, indent=1))
 PY
-rm -rf gpurun_out/${R:-r02}/pmc_fetch gpurun_out/${R:-r02}/pmc_write
-f=$(ls gpurun_out/${R:-r02}/prof/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${R:-r02}/kernel_stats.csv; rm -rf gpurun_out/${R:-r02}/prof
+rm -rf gpurun_out/${R:-r03}/pmc_fetch gpurun_out/${R:-r03}/pmc_write
+f=$(ls gpurun_out/${R:-r03}/prof/*/*kernel_stats.csv | head -1); cp $f gpurun_out/${R:-r03}/kernel_stats.csv; rm -rf gpurun_out/${R:-r03}/prof
