@@ -84,6 +84,28 @@ static inline int a0_wgrad_splits(int gx, int gy, int R) {
     return splits;
 }
 
+// Deep weight gradients (the quantile networks' fc1 over B*N = 16 384 ... 32 768 rows): the GEMM runs on 128 x 128 eight-wave tiles, ONE
+// workgroup per CU, so its duration is (rounds of 256 workgroups) x (rows per split).  fc1 has 4 x 25 = 100 such tiles; the 64 x 128-tile
+// heuristic above gave 3 splits = 300 workgroups = TWO rounds of 10 923 rows (measured 1116 us at 32 768 rows, 94 TFLOP/s, while the forward
+// and data-gradient GEMMs of the same size run at 137-139).  Here the split count minimises rounds x rows-per-split plus the price of the
+// slabs (one slab = N*K*4 bytes written and read back: ~1 round-row unit per 4 MB at the measured rates): 5 splits = 500 workgroups = two
+// rounds of 6 554 rows.  A0_WGRAD_DEEP=0 restores the old choice (tuning aid).
+static inline int a0_wgrad_splits_deep(int N, int K, int R) {
+    static const int on = getenv("A0_WGRAD_DEEP") ? atoi(getenv("A0_WGRAD_DEEP")) : 1;
+    const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
+    if (!on || R < 4096 || N < 128 || K < 128) return 0;                       // not the deep, large case: the caller keeps a0_wgrad_splits
+    const double slab_rows = ((double)N * K * 4.0 / 4.0e6) * 20.0;             // one slab ~ 20 rows' worth of tile time per 4 MB (write + reduce read)
+    int best = 1; double best_cost = 1e300;
+    for (int sp = 1; sp <= 16; ++sp) {
+        const long long rows = (((R + 31) / 32 + sp - 1) / sp) * 32;
+        if (rows < 512) break;                                                 // keep every split deep (the split-operand kernel's condition)
+        const long long rounds = (tiles * sp + 255) / 256;
+        const double cost = (double)rounds * (double)rows + (sp > 1 ? sp * slab_rows : 0.0);
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
+
 // conv2 / conv3 weight gradients: 64 x 64 output tiles and a split count that gives two workgroups per CU, i.e. 400-650 reduction rows
 // and 25 MB of slabs instead of 200-330 rows and 40 MB with 64 x 128 tiles (106 vs 110 us for the three layers + reduction at B = 512,
 // tools/ubench_convwgrad.py).  A0_CONV_WGRAD_T64 = target workgroup count (tuning aid; 0 = the 64 x 128 tiles of a0_wgrad_splits).
@@ -107,8 +129,28 @@ static inline long long a0_dense_fwd_scratch_impl(int R, int N, int K) {
     return s > 1 ? (long long)s * R * N : 0;
 }
 
+// A deep weight gradient with a NARROW second dimension (the cosine embedding, [3136][64] over B*N rows): 64 x 64 tiles instead of 64 x 128
+// (whose second half would be empty) on four waves — two workgroups per CU — and as many splits as fill those 512 slots once
+// (measured at 32 768 rows: 352 us with 64 x 128 tiles and 11 splits = 37 TFLOP/s).
+static inline bool a0_wgrad_narrow_deep(int R, int N, int K) {
+    static const int on = getenv("A0_WGRAD_DEEP") ? atoi(getenv("A0_WGRAD_DEEP")) : 1;
+    return on && K <= 64 && N >= 256 && R >= 4096;
+}
+static inline int a0_dense_wgrad_splits(int R, int N, int K) {
+    if (a0_wgrad_narrow_deep(R, N, K)) {
+        const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+        int sp = 512 / tiles;
+        const int maxs = R / 512;                          // every split stays deep
+        if (sp > maxs) sp = maxs;
+        if (sp > 32) sp = 32;
+        return sp < 1 ? 1 : sp;
+    }
+    const int deep = a0_wgrad_splits_deep(N, K, R);
+    return deep > 0 ? deep : a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
+}
+
 static inline long long a0_dense_wgrad_scratch_impl(int R, int N, int K) {
-    int s = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
+    int s = a0_dense_wgrad_splits(R, N, K);
     return s > 1 ? (long long)s * ((long long)N * K + N) : 0;
 }
 
@@ -247,9 +289,10 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
         bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>(a, b, e, N, K, R, 1);
         return;
     }
-    const int splits = a0_wgrad_splits((N + 63) / 64, (K + 127) / 128, R);
+    const int splits = a0_dense_wgrad_splits(R, N, K);
     EpiWgradSlab::Params e{splits > 1 ? slabs : grad, splits > 1 ? wcount + N : 0, K, wcount};
-    bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
+    if (a0_wgrad_narrow_deep(R, N, K)) bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>(a, b, e, N, K, R, splits);
+    else bk.template igemm<OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 2>(a, b, e, N, K, R, splits);
     if (defer && splits > 1) *defer = a0_reduce_seg{slabs, wcount + N, splits, grad, wcount + N};
     else a0_finish_wgrad(bk, N, wcount, grad, slabs, splits);
 }

@@ -11,6 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401  (first: the library must bind to the HIP runtime PyTorch has loaded, as it does in the product's import order)
 from agent0_amd import _abi  # noqa: E402
 
 lib_path, script = os.path.abspath(sys.argv[1]), sys.argv[2]
