@@ -238,10 +238,12 @@ __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::
         char* a_dst = As + (buf ^ 1) * G::ABYTES;
         char* b_dst = Bs + (buf ^ 1) * G::BBYTES;
         a0_u32x4g a[2][MT][3], b[2][NT][3];
+        // LDS returns reads in issue order and the product groups start with the smallest terms (lo x lo): the lo planes are requested first,
+        // so the first MFMA waits for MT + NT fragments instead of for a whole k-step's
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 2; t >= 0; --t) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a[s][i][t] = SA::frag(ap + t * APL, abase, i, s);
 #pragma unroll
