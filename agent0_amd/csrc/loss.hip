@@ -215,6 +215,136 @@ __global__ __launch_bounds__(256) void a0_actor_dist_tail_kernel(const float* __
     qmax[e] = best;
 }
 
+// ---- the same tail AND the synthetic env's step in one launch, a workgroup per env (the distributional counterpart of
+// a0_actor_qhead_env_kernel, net.hip): all four waves sum the head's slabs into LDS (one column per thread: the same slab-order additions),
+// then wave 0 alone applies the dueling combine, takes the expectation and the first maximum, draws the action and does the env's scalar work
+// with it, while waves 1-3 already write the new frame, the shifted stack and the replay row.  Same bytes as a0_actor_dist_tail +
+// a0_env_synth_step_commit.
+#include "synth_env.h"
+struct a0_dtenv_args {
+    const float* slabs; long long slab_stride; int nslab; const float* bias; int ld, A, T, dueling, mode; const float* atoms; int E;
+    unsigned long long rng_seed; uint32_t stream_a, stream_u; unsigned long long off_a, off_u; float eps; const long long* ctrl; const float* eps_ptr;
+    int* action; float* qmax;
+    unsigned long long env_seed; uint32_t rank, g; const uint8_t* obs_in; uint8_t* obs_out; float *ep_ret, *final_mask, *final_ret;
+    int n; long long steps; double gamma; int* ring_act; float *ring_rew, *ring_done; const uint8_t* obs0; uint8_t* frames; long long cap, start;
+    int* r_act; float *r_rew, *r_done;
+};
+__global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_args P) {
+    extern __shared__ float xs[];                        // [A*T + T] head outputs of this env
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t e = blockIdx.x;
+    const int A = P.A, T = P.T, NC = A * T + (P.dueling ? T : 0);
+    uint32_t g = P.g; long long start = P.start;
+    if (P.ctrl) { g += (uint32_t)P.ctrl[A0_CTRL_ENV_STEP]; start += P.ctrl[A0_CTRL_REPLAY_SLOT]; }
+    const long long slot = (start + e) % P.cap;
+    const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
+    const bool term = (x.y % 500u) == 0u;
+    // head output = slab sum in slab order + bias: column c by thread c, c + 256, ... (all slabs of a column requested before any is added)
+    const float* sp = P.slabs + (long long)e * P.ld;
+    for (int c = threadIdx.x; c < NC; c += 256) {
+        float acc = 0.f;
+        for (int z = 0; z < P.nslab; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) t[zz] = (z + zz < P.nslab) ? sp[(long long)(z + zz) * P.slab_stride + c] : 0.f;
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+                if (z + zz < P.nslab) acc += t[zz];
+        }
+        xs[c] = acc + P.bias[c];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (P.dueling) {
+            for (int t = lane; t < T; t += 64) {
+                float s = 0.f;
+                for (int a = 0; a < A; ++a) s += xs[a * T + t];
+                const float mean = s / (float)A;
+                const float v = xs[A * T + t];
+                for (int a = 0; a < A; ++a) xs[a * T + t] = v + (xs[a * T + t] - mean);
+            }
+            // one wave: its LDS writes above are ordered before its LDS reads below (in-order LDS queue); the fence keeps the compiler from moving them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        float best = 0.f;
+        int besta = 0;
+        for (int a = 0; a < A; ++a) {
+            const float* p = xs + a * T;
+            float v;
+            if (P.mode == 1) {
+                float s = 0.f;
+                for (int t = lane; t < T; t += 64) s += p[t];
+                v = a0_wave_sum(s) / (float)T;
+            } else {
+                float mx = -INFINITY;
+                for (int t = lane; t < T; t += 64) mx = fmaxf(mx, p[t]);
+                mx = a0_wave_max(mx);
+                float se = 0.f, sz = 0.f;
+                for (int t = lane; t < T; t += 64) {
+                    float ex = expf(p[t] - mx);
+                    se += ex;
+                    sz += ex * P.atoms[t];
+                }
+                se = a0_wave_sum(se);
+                sz = a0_wave_sum(sz);
+                v = sz / se;
+            }
+            if (a == 0 || v > best) { best = v; besta = a; }   // first maximum wins, like torch.argmax on CPU
+        }
+        if (lane == 0) {
+            // one lane from here on: its many scalar arguments (streams, offsets, ring pointers, ...) are read through a VECTOR pointer to the
+            // kernel-argument block, so that they do not all have to be live in scalar registers next to the frame loop's
+            const a0_dtenv_args* Q = (const a0_dtenv_args*)__builtin_amdgcn_kernarg_segment_ptr();      // P is this kernel's only argument: offset 0
+            asm volatile("" : "+v"(Q));
+            long long steps = Q->steps; unsigned long long off_a = Q->off_a, off_u = Q->off_u; float eps = Q->eps;
+            const long long* ctrl = Q->ctrl;
+            if (ctrl) { steps += ctrl[A0_CTRL_ACTOR_STEPS]; off_a += (unsigned long long)ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)ctrl[A0_CTRL_RNG_UNIFORM]; }
+            if (Q->eps_ptr) eps = Q->eps_ptr[0];
+            const int ra = (int)(a0_philox_word(Q->rng_seed, Q->stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
+            const float u = (float)(a0_philox_word(Q->rng_seed, Q->stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
+            const int act = (u > eps) ? besta : ra;
+            Q->action[e] = act; Q->qmax[e] = best;
+            a0_env_commit_scalars(x, e, Q->E, Q->n, steps, Q->gamma, act, Q->ep_ret, Q->final_mask, Q->final_ret, Q->ring_act, Q->ring_rew, Q->ring_done, Q->r_act, Q->r_rew,
+                                  Q->r_done, slot);
+        }
+    }
+    a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), threadIdx.x, 256);
+}
+
+extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                           const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                           unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                           unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                           float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                           const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream) {
+    if (!slabs || !bias || !action || !qmax || E < 1 || A < 1 || T < 1 || nslab < 1 || ld < A * T + (dueling ? T : 0) || slab_stride < (long long)E * ld ||
+        (mode != 1 && mode != 2) || (mode == 2 && !atoms))
+        return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad argument");
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad env argument");
+    if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: buffers must be 16-byte aligned");
+    const size_t lds = (size_t)(A * T + T) * sizeof(float);
+    if (lds > 160 * 1024) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: head too wide for LDS");
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_actor_dist_tail_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: LDS");
+        configured = lds;
+    }
+    a0_dtenv_args P;
+    P.slabs = slabs; P.slab_stride = slab_stride; P.nslab = nslab; P.bias = bias; P.ld = ld; P.A = A; P.T = T; P.dueling = dueling; P.mode = mode; P.atoms = atoms; P.E = E;
+    P.rng_seed = seed; P.stream_a = stream_a; P.stream_u = stream_u; P.off_a = off_a; P.off_u = off_u; P.eps = eps; P.ctrl = ctrl; P.eps_ptr = eps_ptr;
+    P.action = action; P.qmax = qmax;
+    P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
+    P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail_env_step");
+}
+
 // mode 1: mean over the T quantiles (qr); mode 2: C51 expectation with `atoms` [T]
 extern "C" int a0_actor_dist_tail(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
                                   const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,

@@ -88,7 +88,7 @@ class Actor:
         self._stage = None
         self.fused_commit = hasattr(self.envs, "step_commit") and (self.obs_bytes == 4 * 84 * 84)
         # scalar heads on the synthetic env: the tail and the env step share one launch (a0_actor_qhead_env_step)
-        self.tail_env = self.fused_tail and self.fused_commit and hasattr(self.envs, "act_step_commit") and os.environ.get("A0_TAIL_ENV", "1") != "0"      # 0: tuning aid (same bytes)
+        self.tail_env = (self.fused_tail or self.dist_tail) and self.fused_commit and hasattr(self.envs, "act_step_commit") and os.environ.get("A0_TAIL_ENV", "1") != "0"      # 0: tuning aid (same bytes)
 
     # ------------------------------------------------------------------ agent.py:25-39
     def _qhead_args(self, epsilon, ctrl, eps_ptr, t):
@@ -97,8 +97,17 @@ class Actor:
         return (self.ws.act3, E, L.feat, W1, b1, W2, b2, L.A, L.dueling, self._qh_scratch, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
                 rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
 
+    def _dist_tail_args(self, epsilon, ctrl, eps_ptr, t):
+        """fc1 and the head GEMM's slabs (enqueued here), then the arguments of ``ops.actor_dist_tail``."""
+        L, ops, E, dev, rng = self.L, self.ops, self.E, self.model._dev, self.rng
+        dev._dense(self.ws.act3, L.feat, "fc1", self.ws.h, E, True)
+        Wh, bh = dev.wb("head")
+        ns = ops.dense_fwd_partial(self.ws.h, 512, Wh, E, L.Npad, 512, self._head_slabs)
+        return (self._head_slabs, ns, bh, L.Npad, L.A, L.T, L.dueling, 2 if L.algo == "c51" else 1, self.atoms, E, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
+                rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+
     def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None, t: int = 0, tail: bool = True):
-        """``tail=False``: the encoder only — the caller runs the scalar-head tail together with the env step (``_qhead_args``)."""
+        """``tail=False``: the encoder only — the caller runs the tail together with the env step (``_qhead_args`` / ``_dist_tail_args``)."""
         L, ops, E, dev = self.L, self.ops, self.E, self.model._dev
         dev.encode(self.ws, self.obs, None, self.obs_bytes, 0, E, keep=False)
         if not tail:
@@ -107,13 +116,7 @@ class Actor:
             ops.actor_qhead(*self._qhead_args(epsilon, ctrl, eps_ptr, t))
             return
         if self.dist_tail:
-            rng = self.rng
-            dev._dense(self.ws.act3, L.feat, "fc1", self.ws.h, E, True)
-            Wh, bh = dev.wb("head")
-            ns = ops.dense_fwd_partial(self.ws.h, 512, Wh, E, L.Npad, 512, self._head_slabs)
-            ops.actor_dist_tail(self._head_slabs, ns, bh, L.Npad, L.A, L.T, L.dueling, 2 if L.algo == "c51" else 1, self.atoms, E, rng.seed, rng.STREAM_EGREEDY_A,
-                                rng.STREAM_EGREEDY_U, rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action,
-                                self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+            ops.actor_dist_tail(*self._dist_tail_args(epsilon, ctrl, eps_ptr, t))
             return
         if L.algo == "fqf":
             dev.fqf_taus(self.ws, E)
@@ -169,9 +172,10 @@ class Actor:
             if merged:
                 # fc1's tail (head, argmax, epsilon-greedy) and the env step + n-step bookkeeping + replay row in ONE launch
                 rp = self.replay
-                self.obs = self.envs.act_step_commit(self._qhead_args(epsilon, ctrl, eps_ptr, t), self.stat_mask[t * E:(t + 1) * E], self.stat_ret[t * E:(t + 1) * E],
-                                                     self.n, self.steps, float(cfg.learner.discount), self.ring_act, self.ring_rew, self.ring_done, obs0, rp,
-                                                     (start + t * E) % rp.size)
+                targs = self._qhead_args(epsilon, ctrl, eps_ptr, t) if self.fused_tail else self._dist_tail_args(epsilon, ctrl, eps_ptr, t)
+                self.obs = self.envs.act_step_commit(targs, self.stat_mask[t * E:(t + 1) * E], self.stat_ret[t * E:(t + 1) * E], self.n, self.steps,
+                                                     float(cfg.learner.discount), self.ring_act, self.ring_rew, self.ring_done, obs0, rp, (start + t * E) % rp.size,
+                                                     dist=not self.fused_tail)
                 self.steps += 1
                 continue
             if bound and not test and self.fused_commit:

@@ -147,6 +147,14 @@ int a0_select_action(const float* x, long long sb, long long sa, long long st, i
 int a0_actor_dist_tail(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
                        const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
                        unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax, void* stream);
+/* a0_actor_dist_tail + a0_env_synth_step_commit in ONE launch (a workgroup per env; the distributional counterpart of a0_actor_qhead_env_step):
+ * arguments of a0_actor_dist_tail, then those of a0_env_synth_step_commit (the action is taken from, and written to, `action`). */
+int a0_actor_dist_tail_env_step(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
 
 /* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
 int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
