@@ -324,9 +324,83 @@ extern "C" int a0_sumtree_set_range(float* tree, long long cap2, long long start
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set_range");
 }
 
+// ---- the same update for a large tree in two launches and many workgroups.  Below the level of A0_ST_TOP nodes the tree is A0_ST_TOP
+// independent subtrees of S = cap2 / A0_ST_TOP leaves.  One WAVE per updated leaf rebuilds the whole subtree that leaf belongs to: it reads
+// the S leaves, applies EVERY update that falls into the subtree in batch order (a later duplicate wins, as in the single-workgroup
+// kernel) — so it does not depend on what other workgroups have written — and recomputes all S - 1 internal nodes as left + right in
+// registers / across lanes (untouched nodes come out unchanged, bit for bit).  Waves whose subtree an earlier entry of the batch already
+// names exit at once.  No level needs a global round trip; the top A0_ST_TOP levels follow in a second launch (a0_sumtree_top).  20 levels
+// x (store, fence, barrier, load) on one workgroup took 47-56 us for 512 leaves of a 1 M-leaf tree.
+template <int M>       // leaves per lane: S = 64 * M
+__global__ __launch_bounds__(64) void a0_sumtree_set_sub_kernel(float* __restrict__ tree, long long cap2, const long long* __restrict__ idx,
+                                                                 const float* __restrict__ val, int n, const int* __restrict__ state) {
+    if (state && state[3]) return;
+    constexpr int S = 64 * M, LS = __builtin_ctz(S);
+    __shared__ int sidx[1024];             // leaf indices fit 31 bits for every tree this path takes (S <= 1024: cap2 <= 2 M)
+    __shared__ float sval[1024];
+    __shared__ float leaf[S];
+    __shared__ int win[S];
+    const int lane = threadIdx.x, i = blockIdx.x;
+    for (int j = lane; j < n; j += 64) { sidx[j] = (int)idx[j]; sval[j] = val[j]; }
+    __syncthreads();                        // (one wave per workgroup: the barriers here only order its LDS accesses)
+    const int t = sidx[i] >> LS;                                        // this wave's subtree
+    bool dup = false;
+    for (int j = lane; j < i; j += 64) dup |= (sidx[j] >> LS) == t;
+    if (__any(dup)) return;                                             // an earlier entry names it: that wave does the work (wave-uniform)
+    const long long leaf0 = cap2 + (long long)t * S;
+    for (int k = lane; k < S; k += 64) { leaf[k] = tree[leaf0 + k]; win[k] = -1; }
+    __syncthreads();
+    // every update that falls into this subtree, in batch order: the LAST entry naming a leaf wins
+    for (int j = lane; j < n; j += 64) if ((sidx[j] >> LS) == t) atomicMax(&win[sidx[j] & (S - 1)], j);
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) if ((sidx[j] >> LS) == t && win[sidx[j] & (S - 1)] == j) leaf[sidx[j] & (S - 1)] = sval[j];
+    __syncthreads();
+    float v[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) { v[k] = leaf[lane * M + k]; tree[leaf0 + lane * M + k] = v[k]; }
+    // levels inside a lane
+    int level = 0;
+#pragma unroll
+    for (int w = M / 2; w >= 1; w /= 2) {
+        ++level;
+        const long long base = (cap2 >> level) + t * (S >> level) + (long long)lane * w;
+#pragma unroll
+        for (int k = 0; k < w; ++k) { v[k] = v[2 * k] + v[2 * k + 1]; tree[base + k] = v[k]; }
+    }
+    // levels across lanes: after step d the lanes with (lane & (2d - 1)) == 0 hold a node
+    float x = v[0];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        ++level;
+        const float o = __shfl_xor(x, d, 64);
+        x = x + o;                                                     // fp32 addition commutes: left + right either way
+        if ((lane & (2 * d - 1)) == 0) tree[(cap2 >> level) + t * (S >> level) + (lane / (2 * d))] = x;
+    }
+}
+
+__global__ __launch_bounds__(1024) void a0_sumtree_top_kernel(float* __restrict__ tree, const int* __restrict__ state) {
+    if (state && state[3]) return;
+    __shared__ float top[2 * A0_ST_TOP];
+    a0_sumtree_top(tree, A0_ST_TOP, top);
+}
+
 extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, void* stream) {
     if (!tree || !idx || !val || n < 1 || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_set: cap2 must be a power of two");
     if (n > 1024) return a0_fail(A0_EINVAL, "a0_sumtree_set: at most 1024 leaves per call (the indices are staged in one workgroup's LDS); split the batch in order");
+    const long long S = cap2 / A0_ST_TOP;        // leaves per subtree below the LDS-resident top
+    static const bool one_wg = getenv("A0_SUMTREE_ONE_WG") != nullptr;      // tuning aid: the single-workgroup kernel for every size
+    if (!one_wg && (S == 64 || S == 128 || S == 256 || S == 512 || S == 1024)) {
+        hipStream_t st = (hipStream_t)stream;
+        switch ((int)S) {
+            case 64: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<1>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
+            case 128: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<2>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
+            case 256: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<4>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
+            case 512: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<8>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
+            default: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<16>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
+        }
+        hipLaunchKernelGGL(a0_sumtree_top_kernel, dim3(1), dim3(1024), 0, st, tree, state);
+        return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set");
+    }
     int threads = 64; while (threads < n && threads < 1024) threads <<= 1;
     hipLaunchKernelGGL(a0_sumtree_set_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, tree, cap2, idx, val, n, state);
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set");
