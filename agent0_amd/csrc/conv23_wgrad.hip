@@ -20,7 +20,7 @@
 //          consecutive output columns are consecutive rows — and all of d2: 2 channel blocks x 4 taps = 8 tiles of 32 x 32, one per wave;
 //   conv3: 3 parts (one kernel row kh each: 2 channel blocks x 3 taps x 2 input-channel halves = 12 tiles; per SIMD one wave with two
 //          tiles and one with one).
-// Either kind of workgroup costs 24 k-steps of nine MFMAs per observation and SIMD and holds 55 KB of LDS, so TWO are resident per CU:
+// The two kinds of workgroup cost 2 x 5 resp. 3 x 3 k-steps of nine MFMAs (+ one fp32 MFMA per tile) per observation and SIMD and hold 55 KB of LDS, so TWO are resident per CU:
 // while one stages its next observation (global -> registers is prefetched; split + LDS writes between two barriers) the other one's waves
 // keep the matrix pipe busy.  G groups per layer, 7 G <= 2 x CUs workgroups (a0_c23w_plan); slab region g of a layer receives all its parts.
 //
@@ -28,7 +28,7 @@
 // ds_read_b64_tr_b16 tile all 64 banks when the rows are consecutive):
 //   conv2  act1 class image: [100 pixels][32 ci], pixel (ih, iw) at row (ih >> 1)*10 + (iw >> 1);  d2: [2 co halves][96 rows][32], rows 81..95 zero.
 //   conv3  act2: [2 ci halves][81 pixels][32];  d3: [2 co halves][64 rows][32], rows 49..63 zero.
-// Positions beyond the image (the zero rows of d) read a valid activation row: 0 * finite = 0.
+// The k-steps of 16 positions cover 80 / 48 of a layer's 81 / 49 positions; the last one runs through one fp32 MFMA (a0q_mma_steps).
 #include "a0_internal.h"
 #include "net_impl.h"
 
@@ -51,13 +51,13 @@ struct a0_c23w_args {
 
 template <int LAYER> struct a0q_geom;
 template <> struct a0q_geom<2> {
-    static constexpr int NPOS = 81, STEPS = 6, DROWS = 96, APIX = 100, CIN = 32, K = 512;
+    static constexpr int NPOS = 81, STEPS = 5, DROWS = 96, APIX = 100, CIN = 32, K = 512;       // 81 = 5 x 16 + 1
     static constexpr int ACT_PLANE = APIX * A0Q_ROW, D_PLANE = 2 * DROWS * A0Q_ROW;      // bytes per term plane
     static constexpr int ACT_F4 = 100 * 8, D_F4 = 81 * 16;                               // float4 pieces per observation (act: this parity class only)
     A0_D static int base_row(int p) { return 10 * (p / 9) + (p % 9); }                   // class-image row of position p, first tap of the class
 };
 template <> struct a0q_geom<3> {
-    static constexpr int NPOS = 49, STEPS = 4, DROWS = 64, APIX = 81, CIN = 64, K = 576;
+    static constexpr int NPOS = 49, STEPS = 3, DROWS = 64, APIX = 81, CIN = 64, K = 576;         // 49 = 3 x 16 + 1
     static constexpr int ACT_PLANE = 2 * APIX * A0Q_ROW, D_PLANE = 2 * DROWS * A0Q_ROW;
     static constexpr int ACT_F4 = 81 * 16, D_F4 = 49 * 16;
     A0_D static int base_row(int p) { return 9 * (p / 7) + (p % 7); }
@@ -98,6 +98,7 @@ template <int LAYER, int NT>
 A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, int aoff, const int (&boff)[a0q_geom<LAYER>::STEPS][2],
                         int a_blk, const int (&b_blk)[2], a0_acc16 (&acc)[2]) {
     typedef a0q_geom<LAYER> G;
+    const int lane = threadIdx.x & 63;
     // term pairs in the order of increasing magnitude (lo*lo first, hi*hi last), as in igemm_x9.h
     constexpr int TA[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
     constexpr int TB[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0};
@@ -115,6 +116,25 @@ A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, int 
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0q_bf16x8, a[TA[q]]), __builtin_bit_cast(a0q_bf16x8, b[j][TB[q]]), acc[j], 0, 0, 0);
+    }
+    // The ONE position the k-steps of 16 leave over (49 = 3 x 16 + 1, 81 = 5 x 16 + 1): a padded k-step would cost nine more MFMAs per tile
+    // (a fifth / a quarter of the work) for it.  Instead it goes through one v_mfma_f32_32x32x2_f32 — the exact fp32 chain, same accumulator
+    // layout — with the fp32 values put back together from their three bf16 terms (hi + mid + lo is exact): lanes 0-31 carry k = 0, the
+    // upper half (k = 1) carries zeros.
+    {
+        const int lrow = lane & 31;
+        const bool k0 = lane < 32;
+        auto f32_at = [](const unsigned char* p, int plane_bytes) {
+            const float hi = __uint_as_float((uint32_t)(*(const uint16_t*)p) << 16), mid = __uint_as_float((uint32_t)(*(const uint16_t*)(p + plane_bytes)) << 16),
+                        lo = __uint_as_float((uint32_t)(*(const uint16_t*)(p + 2 * plane_bytes)) << 16);
+            return (hi + mid) + lo;
+        };
+        const float av = f32_at(dpl + a_blk + (G::NPOS - 1) * A0Q_ROW + 2 * lrow, G::D_PLANE);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float bv = f32_at(act + b_blk[j] + G::base_row(G::NPOS - 1) * A0Q_ROW + 2 * lrow, G::ACT_PLANE);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0 ? av : 0.f, k0 ? bv : 0.f, acc[j], 0, 0, 0);
+        }
     }
 }
 
@@ -157,7 +177,7 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int p = 16 * s + 8 * (lane >> 5) + ((lane & 15) >> 2) + 4 * h;
-            boff[s][h] = G::base_row(p < G::NPOS ? p : G::NPOS - 1) * A0Q_ROW + colb;
+            boff[s][h] = G::base_row(p) * A0Q_ROW + colb;                 // p < 16 * STEPS = NPOS - 1: always a real position
         }
 
     a0_acc16 acc[2];
