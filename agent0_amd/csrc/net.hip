@@ -2,6 +2,7 @@
 // Replaces the ATen -> cuDNN/cuBLAS dispatches behind reference agent0/deepq/model.py:93-101 (ConvEncoder),
 // model.py:112-114 / 144-146 / 203-216 (dense layers of the heads) and their autograd backward (agent.py:153-155).
 #include "igemm_x9.h"
+#include "short_k_fwd.h"
 #include "a0_internal.h"
 #include "net_impl.h"
 
@@ -193,6 +194,16 @@ struct a0_hip_backend {
             g_probe.flops += 2.0 * (double)X * (double)Y * (double)K;
         }
     }
+    void short_k_fwd(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* Y, float* Y2, int R, int N, int relu) {
+        const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
+        if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
+        A0_HIP_THROW(a0_short_k_fwd_launch(st, X, ldx, W, b, M, group, Y, Y2, R, N, relu));
+        if (probe) {
+            A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
+            g_probe.used += 2;
+            g_probe.flops += 2.0 * (double)R * (double)N * 64.0;
+        }
+    }
     int conv1_wgrad_fused(const a0_net_core& n, const a0_frames_arg& f, int B, const float* d1, float* slabs) {
         static const bool off = getenv("A0_NO_CONV1_WGRAD_FUSED") != nullptr;
         if (off || !slabs) return 0;
@@ -319,12 +330,30 @@ extern "C" int a0_dense_fwd_mul(const float* X, int ldx, const float* W, const f
     if (!X || !W || !b || !M || !Y || R < 1 || group < 1 || (N & 3) || (K & 3) || (ldx & 3)) return a0_fail(A0_EINVAL, "a0_dense_fwd_mul: bad shape (N, K, ldx must be multiples of 4)");
     if (a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K) != 1) return a0_fail(A0_EINVAL, "a0_dense_fwd_mul: this shape runs as a split GEMM; use a0_dense_fwd + a0_hadamard_fwd");
     a0_hip_backend bk{(hipStream_t)stream};
+    bk.tag = A0_TAG_DENSE_FWD;
+    if (a0_short_k_shape(R, N, K, ldx)) { bk.short_k_fwd(X, ldx, W, b, M, group, Y, nullptr, R, N, relu); return A0_OK; }
     a0_mat_src a{X, ldx};
     a0_mat_src bw{W, K};
     EpiBiasActMul::Params e{Y, b, N, relu, M, group, a0_udiv_magic((unsigned)group)};
     bk.tag = A0_TAG_DENSE_FWD;
     if (N <= 32) bk.template igemm<OpMatKC, OpMatKC, EpiBiasActMul, 4, 1, 1, 1>(a, bw, e, R, N, K, 1);
     else bk.template igemm<OpMatKC, OpMatKC, EpiBiasActMul, 4, 1, 1, 2>(a, bw, e, R, N, K, 1);
+    return A0_OK;
+    A0_CATCH
+}
+
+// The same for a pass that IS differentiated: E = act(X W^T + b) is kept for the backward pass (a0_hadamard_bwd) and Y = E * M[r / group] is
+// written beside it in the same launch (a0_dense_fwd + a0_hadamard_fwd without re-reading E).  Only for the shapes of the short-reduction
+// kernel: a0_dense_fwd_mul_keep_ok tells.
+extern "C" int a0_dense_fwd_mul_keep_ok(int R, int N, int K, int ldx) { return a0_short_k_shape(R, N, K, ldx) ? 1 : 0; }
+
+extern "C" int a0_dense_fwd_mul_keep(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* E, float* Y, int R, int N, int K, int relu, void* stream) {
+    A0_TRY
+    if (!X || !W || !b || !M || !E || !Y || R < 1 || group < 1 || (N & 3)) return a0_fail(A0_EINVAL, "a0_dense_fwd_mul_keep: bad shape");
+    if (!a0_short_k_shape(R, N, K, ldx)) return a0_fail(A0_EINVAL, "a0_dense_fwd_mul_keep: not a short-reduction shape (a0_dense_fwd_mul_keep_ok); use a0_dense_fwd + a0_hadamard_fwd");
+    a0_hip_backend bk{(hipStream_t)stream};
+    bk.tag = A0_TAG_DENSE_FWD;
+    bk.short_k_fwd(X, ldx, W, b, M, group, E, Y, R, N, relu);
     return A0_OK;
     A0_CATCH
 }

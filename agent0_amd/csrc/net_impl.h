@@ -225,9 +225,18 @@ static void a0_encoder_fwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_w
 }
 
 // ------------------------------------------------------------------------------------------------ dense layers
+// Shapes of the short-reduction forward kernel (short_k_fwd.h): K = 64 exactly (the quantile networks' cosine embedding), rows of X
+// 16-byte aligned, enough rows and columns that the general kernel's tiles would be all prologue and epilogue.
+static inline bool a0_short_k_shape(int R, int N, int K, int ldx) {
+    static const bool off = getenv("A0_NO_SHORT_K") != nullptr;       // tuning aid
+    return !off && K == 64 && (ldx & 3) == 0 && ldx >= 64 && N >= 64 && R >= 256;
+}
+
 template <class BK>
 static void a0_dense_fwd_impl(BK& bk, const float* X, int ldx, const float* W, const float* b, float* Y, int R, int N, int K,
                               int relu, float* scratch) {
+    bk.tag = A0_TAG_DENSE_FWD;
+    if (a0_short_k_shape(R, N, K, ldx)) { bk.short_k_fwd(X, ldx, W, b, nullptr, 1, Y, nullptr, R, N, relu); return; }
     a0_mat_src a{X, ldx};
     a0_mat_src bw{W, K};
     const int splits = a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K);

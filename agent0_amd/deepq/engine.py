@@ -194,6 +194,10 @@ class DeviceNet:
             # a pass that is not differentiated: embedding x features in the GEMM's epilogue, the embedding never reaches HBM
             Wc, bc = self.wb("cos")
             ops.dense_fwd_mul(ws.cosx, L.num_cosines, Wc, bc, feat, n_tau, ws.x, R, L.feat, L.num_cosines, True)
+        elif ws.grads and ops.dense_fwd_mul_keep_ok(R, L.feat, L.num_cosines, L.num_cosines):
+            # the differentiated pass: the embedding is kept for the backward pass, embedding x features written beside it in the same launch
+            Wc, bc = self.wb("cos")
+            ops.dense_fwd_mul_keep(ws.cosx, L.num_cosines, Wc, bc, feat, n_tau, ws.emb, ws.x, R, L.feat, L.num_cosines, True)
         else:
             self._dense(ws.cosx, L.num_cosines, "cos", ws.emb, R, True)
             ops.hadamard_fwd(ws.emb, feat, ws.x, B, n_tau, L.feat)

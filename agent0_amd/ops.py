@@ -178,6 +178,14 @@ class HipOps:
                                         _req(M, torch.float32, ((R - 1) // group + 1) * N, "M"), group, _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu), _stream()),
               "a0_dense_fwd_mul")
 
+    def dense_fwd_mul_keep_ok(self, R, N, K, ldx) -> bool:
+        return bool(self.lib.a0_dense_fwd_mul_keep_ok(R, N, K, ldx))
+
+    def dense_fwd_mul_keep(self, X, ldx, W, b, M, group, E, Y, R, N, K, relu):
+        check(self.lib.a0_dense_fwd_mul_keep(_req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx, _req(W, torch.float32, N * K, "W"), _req(b, torch.float32, N, "b"),
+                                             _req(M, torch.float32, ((R - 1) // group + 1) * N, "M"), group, _req(E, torch.float32, R * N, "E"),
+                                             _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu), _stream()), "a0_dense_fwd_mul_keep")
+
     def dense_dgrad(self, dY, W, mask, dX, R, N, K):
         check(self.lib.a0_dense_dgrad(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"),
                                       _req(mask, torch.float32, R * K, "mask", optional=True), _req(dX, torch.float32, R * K, "dX"), R, N, K, _stream()), "a0_dense_dgrad")

@@ -114,6 +114,12 @@ int a0_dense_wgrad_multi(int n, const float* const* dY, const float* const* X, c
  * GEMM's epilogue, for passes that are not differentiated; only when a0_dense_fwd_scratch(R, N, K) == 0 (unsplit GEMM) */
 int a0_dense_fwd_mul(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* Y, int R, int N, int K, int relu, void* stream);
 
+/* the same for a pass that IS differentiated: E[r] = act(X[r] W^T + b) is kept for a0_hadamard_bwd and Y[r] = E[r] * M[r / group] is written in
+ * the same launch (replaces a0_dense_fwd + a0_hadamard_fwd on model.py:244-247).  Only for the shapes of the short-reduction kernel
+ * (K = 64, R >= 256, N >= 64): a0_dense_fwd_mul_keep_ok returns 1 for them, a0_dense_fwd_mul_keep fails with A0_EINVAL otherwise */
+int a0_dense_fwd_mul_keep_ok(int R, int N, int K, int ldx);
+int a0_dense_fwd_mul_keep(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* E, float* Y, int R, int N, int K, int relu, void* stream);
+
 /* a0_dense_fwd without its slab reduction: slab z of [R][N] at stride R*N holds X W^T over the z-th k range; the consumer kernel sums the
  * a0_dense_fwd_partial_slabs(R, N, K) slabs in order, adds the bias and applies the activation (a0_dqn_head_loss_slabs) */
 int a0_dense_fwd_partial_slabs(int R, int N, int K);

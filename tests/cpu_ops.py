@@ -340,6 +340,14 @@ class CpuOps:
         self.dense_fwd(X, ldx, W, b, tmp, R, N, K, relu, self.empty(max(self.dense_fwd_scratch(R, N, K), 1)))
         Y[: R * N] = (tmp.view(R // group, group, N) * M[: (R // group) * N].view(R // group, 1, N)).reshape(-1)
 
+    def dense_fwd_mul_keep_ok(self, R, N, K, ldx) -> bool:
+        return bool(self.lib.emul_short_k_shape(R, N, K, ldx))
+
+    def dense_fwd_mul_keep(self, X, ldx, W, b, M, group, E, Y, R, N, K, relu):
+        assert self.dense_fwd_mul_keep_ok(R, N, K, ldx)
+        self.dense_fwd(X, ldx, W, b, E, R, N, K, relu, None)
+        Y[: R * N] = (E[: R * N].view(R // group, group, N) * M[: (R // group) * N].view(R // group, 1, N)).reshape(-1)
+
     def dense_wgrad_multi_scratch(self, shapes) -> int:
         return max([self.dense_wgrad_scratch(R, N, K) for (R, N, K) in shapes] + [0])
 

@@ -70,6 +70,21 @@ struct host_backend {
                 }
         }
     }
+    void short_k_fwd(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* Y, float* Y2, int R, int N, int relu) {
+        for (int r = 0; r < R; ++r)
+            for (int c = 0; c < N; ++c) {
+                float v = 0.f;
+                for (int k = 0; k < 64; ++k) v = std::fmaf(X[(size_t)r * ldx + k], W[(size_t)c * 64 + k], v);
+                v += b[c];
+                if (relu) v = (v < 0.f) ? 0.f : v;
+                const size_t o = (size_t)r * N + c;
+                if (!M) Y[o] = v;
+                else {
+                    const float m = M[(size_t)(r / group) * N + c];
+                    if (Y2) { Y[o] = v; Y2[o] = v * m; } else Y[o] = v * m;
+                }
+            }
+    }
     int conv1_wgrad_fused(const a0_net_core&, const a0_frames_arg&, int, const float*, float*) { return 0; }   // GPU-only fast path
     bool conv23_wgrad_fused(const a0_net_core&, int, const float*, const float*, const float*, const float*, float*, float*) { return false; }   // GPU-only fast path
     void reduce_slabs(const float* slabs, long long slab_stride, int nslab, float* out, long long count) {
@@ -125,6 +140,7 @@ void emul_encoder_bwd(const host_net* n, const a0_encoder_weights* w, const a0_f
     host_backend bk;
     a0_encoder_bwd_impl(bk, n->core, *w, *f, B, a1, a2, d3, d2, d1, g1, g2, g3, slabs);
 }
+int emul_short_k_shape(int R, int N, int K, int ldx) { return a0_short_k_shape(R, N, K, ldx) ? 1 : 0; }
 long long emul_dense_fwd_scratch(int R, int N, int K) { return a0_dense_fwd_scratch_impl(R, N, K); }
 void emul_dense_fwd(const float* X, int ldx, const float* W, const float* b, float* Y, int R, int N, int K, int relu, float* scratch) {
     host_backend bk;

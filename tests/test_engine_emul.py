@@ -437,3 +437,23 @@ def test_full_size_check_machinery_on_the_small_geometry(ops, name):
     spec = CASES[name]
     stats = check_update_full_size(ops, spec, Hyper(double_q=(name != "fqf"), n_step=3, K=6, N=8, N_dash=5), 16)
     assert all(n > 0 for _, n, _ in stats.values())
+
+
+@pytest.mark.parametrize("name,dq,n", [("iqn", False, 1), ("fqf_duel", True, 3)])
+def test_quantile_update_through_the_kept_embedding_launch(name, dq, n):
+    """The differentiated pass of the quantile heads through dense_fwd_mul_keep (the embedding kept for the backward pass and its product with
+    the features written by one launch; on the GPU only for the short-reduction kernel's shapes): forced at the emulation's tiny shapes, the
+    update must still match the oracle — the host-side wiring of engine.DeviceNet.head."""
+    import cpu_ops
+    o = cpu_ops.CpuOps()
+    rows = []
+
+    def keep(X, ldx, W, b, M, group, E, Y, R, N, K, relu):
+        rows.append(R)
+        o.dense_fwd(X, ldx, W, b, E, R, N, K, relu, o.empty(max(o.dense_fwd_scratch(R, N, K), 1)))
+        Y[: R * N] = (E[: R * N].view(R // group, group, N) * M[: (R // group) * N].view(R // group, 1, N)).reshape(-1)
+
+    o.dense_fwd_mul_keep_ok = lambda R, N, K, ldx: True
+    o.dense_fwd_mul_keep = keep
+    check_update(o, name, 6, dq, n)
+    assert rows

@@ -517,3 +517,32 @@ def test_conv1_bf16_split_is_exact_and_fp32_accurate():
     e3_u = np.abs(ws_u.act3.cpu().numpy().astype(np.float64) - ref3).max()
     assert e3_f <= 3e-6 * s3 and e3_u <= 3e-6 * s3, (e3_f, e3_u, s3)
     assert e3_f <= 3.0 * e3_u + 2e-7 * s3, (e3_f, e3_u)
+
+
+@pytest.mark.parametrize("R,N,group,relu", [(8192, 3136, 32, True), (2048, 3136, 64, True), (300, 96, 5, True), (257, 64, 32, False), (1000, 200, 1, True)])
+def test_short_reduction_forward_kernel(hip, R, N, group, relu):
+    """short_k_fwd.h (K = 64: the quantile networks' cosine embedding, model.py:244-247) in its three modes against float64, ragged rows /
+    columns and groups that do not divide a 32-row block included; the kept embedding and the product must agree with the separate launches."""
+    K = 64
+    g = torch.Generator().manual_seed(R + N)
+    X = torch.randn(R, K, generator=g) * 0.7
+    W = torch.randn(N, K, generator=g) * 0.2
+    b = torch.randn(N, generator=g) * 0.1
+    G = (R + group - 1) // group
+    M = torch.randn(G, N, generator=g).abs()
+    assert hip.dense_fwd_mul_keep_ok(R, N, K, K)
+    ref = X.double() @ W.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0.0)
+    ref_mul = ref * M.double().repeat_interleave(group, 0)[:R]
+    dev = lambda t: t.contiguous().view(-1).to(hip.device)
+    Xd, Wd, bd, Md = dev(X), dev(W), dev(b), dev(M)
+    Y0, Y1, E, Y2 = (torch.full((R * N,), float("nan"), device=hip.device) for _ in range(4))
+    hip.dense_fwd(Xd, K, Wd, bd, Y0, R, N, K, relu, None)
+    hip.dense_fwd_mul(Xd, K, Wd, bd, Md, group, Y1, R, N, K, relu)
+    hip.dense_fwd_mul_keep(Xd, K, Wd, bd, Md, group, E, Y2, R, N, K, relu)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((Y0.cpu().double().view(R, N) - ref).abs().max()) <= 2e-6 * scale
+    assert float((Y1.cpu().double().view(R, N) - ref_mul).abs().max()) <= 2e-6 * float(ref_mul.abs().max())
+    assert torch.equal(E, Y0) and torch.equal(Y2, Y1)
