@@ -194,15 +194,9 @@ struct a0_hip_backend {
             g_probe.flops += 2.0 * (double)X * (double)Y * (double)K;
         }
     }
+    // (not part of the timing probe's dense_fwd family: bound by its output stream, not by the matrix pipe)
     void short_k_fwd(const float* X, int ldx, const float* W, const float* b, const float* M, int group, float* Y, float* Y2, int R, int N, int relu) {
-        const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
-        if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
         A0_HIP_THROW(a0_short_k_fwd_launch(st, X, ldx, W, b, M, group, Y, Y2, R, N, relu));
-        if (probe) {
-            A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
-            g_probe.used += 2;
-            g_probe.flops += 2.0 * (double)R * (double)N * 64.0;
-        }
     }
     int conv1_wgrad_fused(const a0_net_core& n, const a0_frames_arg& f, int B, const float* d1, float* slabs) {
         static const bool off = getenv("A0_NO_CONV1_WGRAD_FUSED") != nullptr;

@@ -412,8 +412,8 @@ def main():
                           "all layers on v_mfma_f32_16x16x32_bf16 with operands split exactly into bf16 terms (bytes x 3 weight terms; 3 activation x 3 weight terms), fp32 accumulation; "
                           "FLOPs counted once, peak = fp32 MFMA, the bound of the fp32-chain variant A0_NO_X9=1)"
                           if pr["kernel"] == "encoder_fused" else
-                          f"a0_igemm_x9_kernel, every launch tagged {pr['kernel']} (the dense layers' GEMMs of this pass direction: fc1 512 x 3136 over B*N rows, the cosine "
-                          "embedding 3136 x 64, the heads; both fp32 operands split exactly into three bf16 terms, nine v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation; "
+                          f"a0_igemm_x9_kernel, every launch tagged {pr['kernel']} (the dense layers' GEMMs of this pass direction: fc1 512 x 3136 over B*N rows and the heads; "
+                          "the cosine embedding 3136 x 64 runs in the store-bound a0_short_k_fwd_kernel and is not part of this family; both fp32 operands split exactly into three bf16 terms, nine v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation; "
                           "FLOPs = 2*M*N*K counted once, peak = fp32 MFMA)",
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
                 "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor) or 512 (learner) observations"
