@@ -181,6 +181,10 @@ class HostEnvPool:
                 raise TypeError(f"HostEnvPool.reset: only `seed` reaches the worker processes, got {sorted(kw)}")
             self._post(CMD_RESET, -1 if seed is None else int(seed))      # worker w resets its slice [lo, lo + k) with seed + lo
             self._wait_workers()
+            # the acknowledged word again, as a STEP word, written by the host in one store: from here on the DMA-written step words only ever
+            # change sequence-number bytes, so a copy that lands in pieces cannot show a worker the next number beside the old CMD_RESET
+            # (host_envs.accept_word)
+            self._np["ctl"][CTL_WORD] = ctl_word(CMD_STEP, self.seq)
         self._seq_d[0] = ctl_word(CMD_STEP, self.seq)
         self.g = 0
         half = self.seq & 1

@@ -29,6 +29,20 @@ def ctl_word(cmd: int, seq: int) -> int:
     return (int(cmd) << CMD_SHIFT) | (int(seq) & SEQ_MASK)
 
 
+def accept_word(word: int, seen: int):
+    """A worker's view of the control word: (cmd, seq) if it carries the NEXT sequence number, else None (keep polling).
+
+    Step words arrive by a device-to-host DMA copy of 8 bytes, and nothing guarantees that a blit kernel stores them as ONE 8-byte write: a
+    reader can see some bytes of the new word beside bytes of the old one.  Two rules make every such mixture harmless: (1) only
+    ``seen + 1`` is accepted — a torn sequence number is anything but that (or, when the bytes that changed have all arrived, already the
+    right value); (2) the parent re-writes the word as CMD_STEP itself once a reset has been acknowledged (HostEnvPool.reset), so the
+    command byte never changes under a DMA write and a torn word cannot pair the new number with a stale CMD_RESET."""
+    seq = int(word) & SEQ_MASK
+    if seq != ((int(seen) + 1) & SEQ_MASK):
+        return None
+    return int(word) >> CMD_SHIFT, seq
+
+
 N_SCAL = 7      # scalar rows per env and step: reward, terminated, truncated, life_loss, final mask, final return, advance (see record)
 
 
@@ -195,15 +209,17 @@ def worker_main(w, make_slice, lo, k, shm_name, E, obs_bytes, workers, spin_us, 
             # the sequence number arrives by DMA (steps) or from the parent (reset / close).  Inside a rollout the next command follows
             # within a few hundred microseconds (one actor step on the GPU + the upload): poll without sleeping for busy_us after each
             # command — a sleep costs ~60 us of timer slack per step, a sixth of the step — and fall back to sleeping between rollouts.
-            while (int(ctl[CTL_WORD]) & SEQ_MASK) == seen:
+            while True:
+                got = accept_word(int(ctl[CTL_WORD]), seen)          # ONE read: command and sequence number belong together
+                if got is not None:
+                    break
                 if time.perf_counter() < busy_until:
                     continue
                 time.sleep(spin_us * 1e-6)
                 spins += 1
                 if (spins & 0x3FFF) == 0 and os.getppid() != parent:
                     return                                   # the parent is gone (killed): do not poll a dead ring forever
-            word = int(ctl[CTL_WORD])                    # ONE read: command and sequence number belong together
-            seen, cmd = word & SEQ_MASK, word >> CMD_SHIFT
+            cmd, seen = got
             if cmd == CMD_CLOSE:
                 break
             half = seen & 1

@@ -255,3 +255,26 @@ def test_worker_handshake_is_one_word():
         del buf
     finally:
         shm.close(); shm.unlink()
+
+
+def test_worker_accepts_only_the_next_sequence_number():
+    """A step word is an 8-byte device-to-host DMA copy that may land in pieces.  accept_word takes a word only if it carries seen + 1: every
+    mixture of old and new bytes of the sequence number is either rejected or already the complete new value; and because HostEnvPool.reset
+    re-writes the acknowledged word as CMD_STEP from the host, the command byte never changes under a DMA write (the hazard: the next number
+    beside a stale CMD_RESET, i.e. a second reset instead of the first step)."""
+    import inspect
+    import itertools
+    from agent0_amd.common import env_pool
+    from agent0_amd.common.host_envs import CMD_RESET, CMD_STEP, accept_word, ctl_word
+    for seen in (0, 1, 254, 255, 256, 65535, (1 << 32) - 1, (1 << 40) + 255):
+        old, new = ctl_word(CMD_STEP, seen), ctl_word(CMD_STEP, seen + 1)
+        ob, nb = old.to_bytes(8, "little"), new.to_bytes(8, "little")
+        for pick in itertools.product((0, 1), repeat=8):                      # every byte-wise mixture of the old and the new word
+            w = int.from_bytes(bytes(nb[i] if pick[i] else ob[i] for i in range(8)), "little")
+            got = accept_word(w, seen)
+            assert got is None or got == (CMD_STEP, seen + 1), (seen, pick, got)
+        assert accept_word(new, seen) == (CMD_STEP, seen + 1)
+        assert accept_word(old, seen) is None and accept_word(ctl_word(CMD_STEP, seen + 2), seen) is None     # replayed / skipped numbers are not commands
+    assert accept_word(ctl_word(CMD_RESET, 8), 7) == (CMD_RESET, 8)
+    src = inspect.getsource(env_pool.HostEnvPool.reset)
+    assert src.index("self._wait_workers()") < src.index('self._np["ctl"][CTL_WORD] = ctl_word(CMD_STEP, self.seq)'), "reset() re-arms the word as CMD_STEP after the acknowledgement"
