@@ -12,6 +12,11 @@
 //   A0_XC operands (x contiguous in memory):  plane[32 k][x] exactly as fetched, pitch = 16 or 48 dwords mod 64; the k-major
 //          fragment is produced by the LDS itself: two ds_read_b64_tr_b16 (4 k x 16 x blocks, transposed per 16-lane group).
 // Either way one float4 of fetched data becomes three 8-byte LDS writes.
+//
+// Tile shapes: WM x WN waves of MT x NT blocks of 32 x 32, over k tiles of 16 KS.  KS = 2 (32 k, two k-steps per barrier) is the default; KS = 1 halves the
+// LDS per stage and makes room for the 256 x 128 tile (eight waves of 64 x 64: <4, 2, 2, 2, 1>, 110 KB double-buffered) that the backend picks for the
+// quantile networks' 16 384 / 32 768-row layers: per MFMA a quarter less staging (fetch, split, LDS store) and a third fewer fragment reads than
+// 128 x 128 x 32, the same 36 MFMAs per wave between barriers.
 #pragma once
 #include "igemm.h"
 
@@ -43,51 +48,53 @@ struct a0_x9_piece {
     }
 };
 
-template <int MODE, int BX> struct a0_x9_image;
-template <int BX> struct a0_x9_image<A0_KC, BX> {
-    static constexpr int PITCH = 80;                       // bytes per x row (32 bf16 + 16 B pad)
+// KS = k-steps of 16 per tile: 2 (tiles of 32 k, the default) or 1 (tiles of 16 k: half the LDS per stage, for the 256 x 128 workgroup tile)
+template <int MODE, int BX, int KS = 2> struct a0_x9_image;
+template <int BX, int KS> struct a0_x9_image<A0_KC, BX, KS> {
+    static constexpr int PITCH = 32 * KS + 16;             // bytes per x row (16 KS bf16 + 16 B pad): 80 / 48, an odd multiple of 16 -> conflict-free b128 reads
     static constexpr int PLANE = BX * PITCH;
 };
-template <int BX> struct a0_x9_image<A0_XC, BX> {
+template <int BX, int KS> struct a0_x9_image<A0_XC, BX, KS> {
     static constexpr int PDW = ((BX / 2) % 32 == 16) ? (BX / 2) : (BX / 2 + 16);   // dwords per k row: 16 mod 32, so 4 rows x 16 dwords tile the 64 banks
     static constexpr int PITCH = 4 * PDW;
-    static constexpr int PLANE = 32 * PITCH;
+    static constexpr int PLANE = 16 * KS * PITCH;
 };
 
 // global -> registers (the policies' branch-free loads, as in igemm.h) and registers -> term planes, both in PIECES of one float4 per
 // thread: the kernel threads a tile's pieces between its MFMAs, so the ~22 VALU instructions of a split run in the shadow of the
 // matrix pipe instead of in front of it.
-template <class OP, int BX, int NTH, int MODE = OP::MODE> struct a0_x9_stager;
+template <class OP, int BX, int NTH, int KS = 2, int MODE = OP::MODE> struct a0_x9_stager;
 
-template <class OP, int BX, int NTH> struct a0_x9_stager<OP, BX, NTH, A0_KC> {
-    static constexpr int RPP = NTH / 8;      // rows per pass: eight threads cover the 32 k of one row
+template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS, A0_KC> {
+    static constexpr int TPR = 4 * KS;       // threads per row: eight (four) threads cover the 32 (16) k of one row
+    static constexpr int RPP = NTH / TPR;    // rows per pass
     static constexpr int R = BX / RPP;
     static_assert(BX % RPP == 0, "tile rows per pass");
-    typedef a0_x9_image<A0_KC, BX> IM;
+    typedef a0_x9_image<A0_KC, BX, KS> IM;
     typename OP::Row rows[R];
     typename OP::KInfo ki;        // gather-table entry of the tile being fetched (looked up when the previous tile's last piece was fetched)
     struct Slot { typename OP::Raw raw[R]; unsigned okmask; };
     A0_D void init(const typename OP::Params& P, int x0, int X, int kb, int ke, int tid) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + (tid >> 3) + RPP * j, X);
-        ki = OP::kinfo(P, kb + 4 * (tid & 7), ke);
+        for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + tid / TPR + RPP * j, X);
+        ki = OP::kinfo(P, kb + 4 * (tid % TPR), ke);
     }
     // pieces of one tile are fetched in the order j = 0 .. R-1; the last one moves the k state on to the next tile
     A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
         bool ok;
         s.raw[j] = OP::load(P, rows[j], ki, ok);
         s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
-        if (j == R - 1) ki = OP::kinfo(P, k0 + 32 + 4 * (tid & 7), ke);
+        if (j == R - 1) ki = OP::kinfo(P, k0 + 16 * KS + 4 * (tid % TPR), ke);
     }
     template <bool RS> A0_D a0_f4 value(const Slot& s, int j, a0_f4&) const {
         static_assert(!RS, "row sums are taken from x-contiguous A operands");
         return OP::finish(s.raw[j], (s.okmask >> j) & 1u);
     }
     A0_D void store(const a0_x9_piece& pc, int j, char* lds, int tid) const {
-        const int r = (tid >> 3) + RPP * j;
+        const int r = tid / TPR + RPP * j;
         a0_u32x2g hi, mid, lo;
         pc.pack(hi, mid, lo);
-        char* p = lds + r * IM::PITCH + 8 * (tid & 7);
+        char* p = lds + r * IM::PITCH + 8 * (tid % TPR);
         *(a0_u32x2g*)(p) = hi;
         *(a0_u32x2g*)(p + IM::PLANE) = mid;
         *(a0_u32x2g*)(p + 2 * IM::PLANE) = lo;
@@ -99,11 +106,11 @@ template <class OP, int BX, int NTH> struct a0_x9_stager<OP, BX, NTH, A0_KC> {
     }
 };
 
-template <class OP, int BX, int NTH> struct a0_x9_stager<OP, BX, NTH, A0_XC> {
-    static constexpr int R = 8 * BX / NTH;
+template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS, A0_XC> {
+    static constexpr int R = 4 * KS * BX / NTH;
     static constexpr int Q = BX / 4;   // 16-byte groups per k row
-    static_assert((8 * BX) % NTH == 0 && NTH % Q == 0, "tile columns per pass");
-    typedef a0_x9_image<A0_XC, BX> IM;
+    static_assert((4 * KS * BX) % NTH == 0 && NTH % Q == 0, "tile columns per pass");
+    typedef a0_x9_image<A0_XC, BX, KS> IM;
     typename OP::XInfo xi[R];
     struct Slot { typename OP::Raw raw[R]; unsigned okmask; };
     A0_D void init(const typename OP::Params& P, int x0, int X, int, int, int tid) {
@@ -145,24 +152,25 @@ template <class OP, int BX, int NTH> struct a0_x9_stager<OP, BX, NTH, A0_XC> {
     }
 };
 
-template <class OA, class OB, int WM, int WN, int MT, int NT> struct a0_x9_geom {
+template <class OA, class OB, int WM, int WN, int MT, int NT, int KS = 2> struct a0_x9_geom {
     static constexpr int BX = WM * MT * 32, BY = WN * NT * 32;
-    static constexpr int ABYTES = 3 * a0_x9_image<OA::MODE, BX>::PLANE;
-    static constexpr int BBYTES = 3 * a0_x9_image<OB::MODE, BY>::PLANE;
+    static constexpr int ABYTES = 3 * a0_x9_image<OA::MODE, BX, KS>::PLANE;
+    static constexpr int BBYTES = 3 * a0_x9_image<OB::MODE, BY, KS>::PLANE;
     static constexpr int LDS_BYTES = 2 * (ABYTES + BBYTES);                 // double-buffered
 };
 
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::Params pa, typename OB::Params pb,
                                                            typename EP::Params pe, int X, int Y, int K, int kchunk, int gx, int gy) {
     static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
-    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT> G;
-    constexpr int BK = 32, BX = G::BX, BY = G::BY, NTH = WM * WN * 64;
-    typedef a0_x9_stager<OA, BX, NTH> SA;
-    typedef a0_x9_stager<OB, BY, NTH> SB;
-    constexpr int APL = a0_x9_image<OA::MODE, BX>::PLANE, BPL = a0_x9_image<OB::MODE, BY>::PLANE;
+    static_assert(KS == 1 || KS == 2, "tiles of 16 or 32 k");
+    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
+    constexpr int BK = 16 * KS, BX = G::BX, BY = G::BY, NTH = WM * WN * 64;
+    typedef a0_x9_stager<OA, BX, NTH, KS> SA;
+    typedef a0_x9_stager<OB, BY, NTH, KS> SB;
+    constexpr int APL = a0_x9_image<OA::MODE, BX, KS>::PLANE, BPL = a0_x9_image<OB::MODE, BY, KS>::PLANE;
     constexpr int RA = SA::R, RB = SB::R, NP = RA + RB;      // commit / fetch pieces per tile
-    constexpr int NG = 18;                                   // product groups per tile: 2 k-steps x 9 term pairs, MT*NT MFMAs each
+    constexpr int NG = 9 * KS;                               // product groups per tile: KS k-steps x 9 term pairs, MT*NT MFMAs each
     static_assert(!EP::ROWSUM_A || OA::MODE == A0_XC, "row sums need an x-contiguous A operand");
     extern __shared__ __attribute__((aligned(16))) char a0_x9_lds[];
     char* const As = a0_x9_lds;                       // [2 buffers][3 planes]
@@ -237,11 +245,11 @@ __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::
         const char* bp = Bs + buf * G::BBYTES;
         char* a_dst = As + (buf ^ 1) * G::ABYTES;
         char* b_dst = Bs + (buf ^ 1) * G::BBYTES;
-        a0_u32x4g a[2][MT][3], b[2][NT][3];
+        a0_u32x4g a[KS][MT][3], b[KS][NT][3];
         // LDS returns reads in issue order and the product groups start with the smallest terms (lo x lo): the lo planes are requested first,
         // so the first MFMA waits for MT + NT fragments instead of for a whole k-step's
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 2; t >= 0; --t) {
 #pragma unroll
@@ -316,11 +324,11 @@ __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::
         }
 }
 
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
 static inline hipError_t a0_igemm_x9_launch(hipStream_t st, const typename OA::Params& pa, const typename OB::Params& pb,
                                             const typename EP::Params& pe, int X, int Y, int K, int splits) {
-    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT> G;
-    auto kern = a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT>;
+    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
+    auto kern = a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS>;
     static bool configured = false;                       // per instantiation: more than 64 KB of dynamic LDS needs the attribute
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -328,8 +336,9 @@ static inline hipError_t a0_igemm_x9_launch(hipStream_t st, const typename OA::P
         configured = true;
     }
     if (splits < 1) splits = 1;
-    const int ktiles = (K + 31) / 32;
-    const int kchunk = ((ktiles + splits - 1) / splits) * 32;
+    constexpr int BK = 16 * KS;
+    const int ktiles = (K + BK - 1) / BK;
+    const int kchunk = ((ktiles + splits - 1) / splits) * BK;
     const int gx = (X + G::BX - 1) / G::BX, gy = (Y + G::BY - 1) / G::BY;
     hipLaunchKernelGGL(kern, dim3((unsigned)(gx * gy * splits)), dim3(WM * WN * 64), G::LDS_BYTES, st, pa, pb, pe, X, Y, K, kchunk, gx, gy);
     return hipGetLastError();

@@ -155,6 +155,10 @@ extern "C" int a0_gemm_mode(int mode) {
     return prev;
 }
 
+static const long long g_x9_huge_min = getenv("A0_X9_HUGE_MIN") ? atoll(getenv("A0_X9_HUGE_MIN")) : 250;   // tuning aid (a huge value switches the 256 x 128 tile off)
+template <class OP> struct a0_is_mat { static constexpr bool value = false; };
+template <> struct a0_is_mat<OpMatKC> { static constexpr bool value = true; };
+template <> struct a0_is_mat<OpMatXC> { static constexpr bool value = true; };
 // im2col-gathered B operands (conv weight gradients): their address arithmetic already fills the issue slots the splits would need
 template <class OP> struct a0_is_gather { static constexpr bool value = false; };
 template <> struct a0_is_gather<OpActXC> { static constexpr bool value = true; };
@@ -182,6 +186,20 @@ struct a0_hip_backend {
             constexpr bool wgrad_family = OA::MODE == A0_XC;
             const bool deep = K / sp >= 512;
             const bool large = X >= 128 && Y >= 128 && big >= g_x9_big_min && (deep || !wgrad_family);
+            // very large dense problems (the quantile networks' 32 768-row layers): 256 x 128 tiles of 16 k on eight waves, 64 x 64 per wave — a quarter less
+            // staging and a third fewer LDS fragment reads per MFMA than the 128 x 128 x 32 tile, the same 36 MFMAs per wave between barriers; taken when
+            // there is about a full round of such tiles (the actor's 8 192 rows would fill half the CUs and keep the smaller tile)
+            constexpr bool mats = a0_is_mat<OA>::value && a0_is_mat<OB>::value;
+            const long long huge = (long long)((X + 255) / 256) * ((Y + 127) / 128) * sp;
+            // ... and when they fill their rounds of 256 workgroups about as well as the smaller tiles fill theirs (the tile is worth ~5 %)
+            const double fill_huge = (double)huge / (256.0 * (double)((huge + 255) / 256)), fill_big = (double)big / (256.0 * (double)((big + 255) / 256));
+            if constexpr (mats) {
+                if (x9 && X >= 256 && Y >= 128 && huge >= g_x9_huge_min && fill_huge >= 0.93 * fill_big && (deep || !wgrad_family)) {
+                    A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 2, 2, 1>(st, pa, pb, pe, X, Y, K, splits)));
+                    if (probe) { A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st)); g_probe.used += 2; g_probe.flops += 2.0 * (double)X * (double)Y * (double)K; }
+                    return;
+                }
+            }
             if (x9 && large) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
             else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
             else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));
