@@ -98,13 +98,13 @@ class DeviceSynthVecEnv:
         self._cur = nxt
         return self._obs[nxt]
 
-    def act_step_commit(self, tail_args, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, replay, start_slot, dist: bool = False):
-        """``step_commit`` with the actor's tail in the same launch: ``tail_args`` are the arguments of ``ops.actor_qhead`` (scalar heads,
-        a0_actor_qhead_env_step) or, with ``dist``, of ``ops.actor_dist_tail`` (c51 / qr, a0_actor_dist_tail_env_step), both ending in
-        action, qmax, ctrl, eps_ptr; the action chosen there is the one this step takes."""
+    def act_step_commit(self, tail_args, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, replay, start_slot, kind: str = "qhead"):
+        """``step_commit`` with the actor's tail in the same launch: ``tail_args`` are the arguments of ``ops.actor_qhead`` (``kind="qhead"``: scalar heads,
+        a0_actor_qhead_env_step), of ``ops.actor_dist_tail`` (``"dist"``: c51 / qr, a0_actor_dist_tail_env_step) or of the quantile tail (``"quantile"``:
+        iqn / fqf, a0_actor_quantile_tail_env_step), all ending in action, qmax, ctrl, eps_ptr; the action chosen there is the one this step takes."""
         self.g += 1
         nxt = (self._cur + 1) % len(self._obs)
-        (self.ops.actor_dist_tail_env_step if dist else self.ops.actor_qhead_env_step)(*tail_args, self.seed, self.rank, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps,
+        {"qhead": self.ops.actor_qhead_env_step, "dist": self.ops.actor_dist_tail_env_step, "quantile": self.ops.actor_quantile_tail_env_step}[kind](*tail_args, self.seed, self.rank, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps,
                                       gamma, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done)
         self._cur = nxt
         return self._obs[nxt]

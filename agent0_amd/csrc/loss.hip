@@ -228,6 +228,9 @@ struct a0_dtenv_args {
     unsigned long long env_seed; uint32_t rank, g; const uint8_t* obs_in; uint8_t* obs_out; float *ep_ret, *final_mask, *final_ret;
     int n; long long steps; double gamma; int* ring_act; float *ring_rew, *ring_done; const uint8_t* obs0; uint8_t* frames; long long cap, start;
     int* r_act; float *r_rew, *r_done;
+    int kt;                  // 1: quantile networks (iqn / fqf) — the head's rows are (env, quantile), its columns the actions (+ value): element (a, t) of env e at
+                             //    slabs[(e * T + t) * ld + a], bias per column; 0: distributional heads (c51 / qr) — one row per env, columns (a, t)
+    const float* taus;       // mode 3 (fqf): [E][T + 1] fraction boundaries, value(a) = sum_t (tau[t + 1] - tau[t]) q(t, a)  (== a0_select_action_kernel mode 3)
 };
 __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_args P) {
     extern __shared__ float xs[];                        // [A*T + T] head outputs of this env
@@ -240,18 +243,20 @@ __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
     const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
     const bool term = (x.y % 500u) == 0u;
     // head output = slab sum in slab order + bias: column c by thread c, c + 256, ... (all slabs of a column requested before any is added)
-    const float* sp = P.slabs + (long long)e * P.ld;
+    const float* sp = P.slabs + (long long)e * (P.kt ? (long long)T * P.ld : (long long)P.ld);
     for (int c = threadIdx.x; c < NC; c += 256) {
+        int src = c, col = c;
+        if (P.kt) { const int a = c / T, q = c - a * T; src = q * P.ld + a; col = a; }      // LDS keeps the (a, t) order either way
         float acc = 0.f;
         for (int z = 0; z < P.nslab; z += 8) {
             float t[8];
 #pragma unroll
-            for (int zz = 0; zz < 8; ++zz) t[zz] = (z + zz < P.nslab) ? sp[(long long)(z + zz) * P.slab_stride + c] : 0.f;
+            for (int zz = 0; zz < 8; ++zz) t[zz] = (z + zz < P.nslab) ? sp[(long long)(z + zz) * P.slab_stride + src] : 0.f;
 #pragma unroll
             for (int zz = 0; zz < 8; ++zz)
                 if (z + zz < P.nslab) acc += t[zz];
         }
-        xs[c] = acc + P.bias[c];
+        xs[c] = acc + P.bias[col];
     }
     __syncthreads();
     if (wave == 0) {
@@ -277,6 +282,11 @@ __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
                 float s = 0.f;
                 for (int t = lane; t < T; t += 64) s += p[t];
                 v = a0_wave_sum(s) / (float)T;
+            } else if (P.mode == 3) {
+                const float* tau = P.taus + (long long)e * (T + 1);
+                float s = 0.f;
+                for (int t = lane; t < T; t += 64) s += (tau[t + 1] - tau[t]) * p[t];
+                v = a0_wave_sum(s);
             } else {
                 float mx = -INFINITY;
                 for (int t = lane; t < T; t += 64) mx = fmaxf(mx, p[t]);
@@ -341,8 +351,41 @@ extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_st
     P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
     P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    P.kt = 0; P.taus = nullptr;
     hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail_env_step");
+}
+
+// The quantile networks' actor tail (iqn: mean over the K sampled quantiles, mode 1; fqf: sum over the F fractions weighted by their widths, mode 3) and
+// the synthetic env's step in one launch: the head GEMM over E * T rows leaves its split-K slabs [nslab][E * T][ld] (a0_dense_fwd_partial); per env one
+// workgroup sums them in slab order and adds the bias (== a0_reduce_bias_act), applies the dueling combine per quantile (== a0_dueling_fwd), takes the
+// action values and the first maximum (== a0_select_action modes 1 / 3), draws epsilon-greedy (== a0_egreedy_rng) and steps the env (==
+// a0_env_synth_step_commit): five launches of reference agent.py:25-39 / 44-90's per-step work become one.
+extern "C" int a0_actor_quantile_tail_env_step(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                               const float* taus, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                               unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                               unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                               float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                               const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream) {
+    if (!slabs || !bias || !action || !qmax || E < 1 || A < 1 || T < 1 || nslab < 1 || ld < A + (dueling ? 1 : 0) || slab_stride < (long long)E * T * ld ||
+        (mode != 1 && mode != 3) || (mode == 3 && !taus))
+        return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: bad argument");
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: bad env argument");
+    if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: buffers must be 16-byte aligned");
+    const size_t lds = (size_t)(A * T + T) * sizeof(float);
+    if (lds > 64 * 1024) return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: head too wide for LDS");
+    a0_dtenv_args P;
+    P.slabs = slabs; P.slab_stride = slab_stride; P.nslab = nslab; P.bias = bias; P.ld = ld; P.A = A; P.T = T; P.dueling = dueling; P.mode = mode; P.atoms = nullptr; P.E = E;
+    P.rng_seed = seed; P.stream_a = stream_a; P.stream_u = stream_u; P.off_a = off_a; P.off_u = off_u; P.eps = eps; P.ctrl = ctrl; P.eps_ptr = eps_ptr;
+    P.action = action; P.qmax = qmax;
+    P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
+    P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    P.kt = 1; P.taus = taus;
+    hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_quantile_tail_env_step");
 }
 
 // mode 1: mean over the T quantiles (qr); mode 2: C51 expectation with `atoms` [T]

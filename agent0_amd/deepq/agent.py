@@ -64,7 +64,12 @@ class Actor:
         # distributional heads (c51, qr): head GEMM slabs -> one tail kernel (bias, dueling, expectation, argmax, epsilon-greedy)
         self.dist_tail = (not self.fused_tail) and self.L.algo in ("c51", "qr") and 4 * (self.L.A * self.L.T + self.L.T) * 4 <= 160 * 1024
         self._head_slabs = ops.empty(ops.dense_fwd_partial_slabs(E, self.L.Npad, 512) * E * self.L.Npad) if self.dist_tail else None
-        self.qmax_all = ops.zeros(T * E) if (self.fused_tail or self.dist_tail) else None
+        # quantile heads (iqn, fqf) on the device env: head GEMM slabs -> one kernel for the tail AND the env step (a0_actor_quantile_tail_env_step)
+        self.quant_tail = (self.L.algo in ("iqn", "fqf") and hasattr(self.envs, "act_step_commit") and self.obs_bytes == 4 * 84 * 84
+                           and ops.dense_fwd_scratch(E * n_tau, self.L.feat, self.L.num_cosines) == 0 and os.environ.get("A0_QUANT_TAIL", "1") != "0")     # 0: tuning aid (same bytes)
+        if self.quant_tail:
+            self._head_slabs = ops.empty(ops.dense_fwd_partial_slabs(E * n_tau, self.L.Npad, 512) * E * n_tau * self.L.Npad)
+        self.qmax_all = ops.zeros(T * E) if (self.fused_tail or self.dist_tail or self.quant_tail) else None
         self._qh_scratch = ops.empty(ops.actor_qhead_scratch(E, self.L.feat)) if self.fused_tail else None
         self.stat_mask, self.stat_ret = ops.zeros(T * E), ops.zeros(T * E)
         self.ring_act, self.ring_rew, self.ring_done = ops.zeros(self.n * E, dtype=torch.int32), ops.zeros(self.n * E), ops.zeros(self.n * E)
@@ -104,6 +109,20 @@ class Actor:
         Wh, bh = dev.wb("head")
         ns = ops.dense_fwd_partial(self.ws.h, 512, Wh, E, L.Npad, 512, self._head_slabs)
         return (self._head_slabs, ns, bh, L.Npad, L.A, L.T, L.dueling, 2 if L.algo == "c51" else 1, self.atoms, E, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
+                rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
+
+    def _quant_tail_args(self, epsilon, ctrl, eps_ptr, t):
+        """The quantile head up to the head GEMM's slabs (enqueued here), then the arguments of ``ops.actor_quantile_tail_env_step``."""
+        L, ops, E, dev, rng = self.L, self.ops, self.E, self.model._dev, self.rng
+        if L.algo == "fqf":
+            dev.fqf_taus(self.ws, E)
+            taus, aux, mode = self.ws.tau_hat, self.ws.tau_all, 3
+        else:
+            rng.uniform(rng.STREAM_TAUS, self.taus, E * self.n_tau)
+            taus, aux, mode = self.taus, None, 1
+        ns = dev.head_slabs(self.ws, E, taus, self.n_tau, self._head_slabs)
+        _, bh = dev.wb("head")
+        return (self._head_slabs, ns, bh, L.Npad, L.A, self.n_tau, L.dueling, mode, aux, E, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
                 rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
 
     def _act_device(self, epsilon: float, qs_slot: Optional[torch.Tensor], ctrl=None, eps_ptr=None, t: int = 0, tail: bool = True):
@@ -156,7 +175,7 @@ class Actor:
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
                 self.model.reset_noise(rng=self.rng)
-            merged = bound and not test and self.tail_env
+            merged = bound and not test and (self.tail_env or (self.quant_tail and self.fused_commit))
             self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t, tail=not merged)
             cur_obs = self.obs
             if self.n > 1 and self.env_history:
@@ -172,10 +191,11 @@ class Actor:
             if merged:
                 # fc1's tail (head, argmax, epsilon-greedy) and the env step + n-step bookkeeping + replay row in ONE launch
                 rp = self.replay
-                targs = self._qhead_args(epsilon, ctrl, eps_ptr, t) if self.fused_tail else self._dist_tail_args(epsilon, ctrl, eps_ptr, t)
+                kind = "qhead" if self.fused_tail else ("dist" if self.dist_tail else "quantile")
+                targs = {"qhead": self._qhead_args, "dist": self._dist_tail_args, "quantile": self._quant_tail_args}[kind](epsilon, ctrl, eps_ptr, t)
                 self.obs = self.envs.act_step_commit(targs, self.stat_mask[t * E:(t + 1) * E], self.stat_ret[t * E:(t + 1) * E], self.n, self.steps,
                                                      float(cfg.learner.discount), self.ring_act, self.ring_rew, self.ring_done, obs0, rp, (start + t * E) % rp.size,
-                                                     dist=not self.fused_tail)
+                                                     kind=kind)
                 self.steps += 1
                 continue
             if bound and not test and self.fused_commit:
@@ -202,7 +222,7 @@ class Actor:
                 stage["obs"][sl].copy_(obs0.view(E, -1)); stage["obs_next"][sl].copy_(obs_next.view(E, -1))
                 stage["act"][sl].copy_(self.out_act); stage["rew"][sl].copy_(self.out_rew); stage["done"][sl].copy_(self.out_done)
             self.obs = obs_next
-        if self.fused_tail or self.dist_tail:
+        if self.fused_tail or self.dist_tail or (self.quant_tail and bound and not test and self.fused_commit):
             ops.mean_rows(self.qmax_all, T, E, self.qs)          # per-step mean max-Q (agent.py:38,88), all steps at once
 
     def _graph_eligible(self, T, bound, test, state_dict) -> bool:

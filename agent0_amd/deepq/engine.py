@@ -206,6 +206,18 @@ class DeviceNet:
         ops.dueling_fwd(ws.raw, L.Npad, ws.q, R, L.A, 1, L.dueling)
         return ws.q
 
+    def head_slabs(self, ws: Workspace, B, taus: torch.Tensor, n_tau: int, slabs: torch.Tensor) -> int:
+        """Quantile heads of a pass that is not differentiated, up to the head GEMM's split-K slabs [ns][B * n_tau][Npad] (the consumer kernel finishes
+        the layer: a0_actor_quantile_tail_env_step).  Returns the slab count."""
+        L, ops = self.L, self.ops
+        R = B * n_tau
+        ops.cos_features(taus, ws.cosx, R, L.num_cosines)
+        Wc, bc = self.wb("cos")
+        ops.dense_fwd_mul(ws.cosx, L.num_cosines, Wc, bc, ws.act3, n_tau, ws.x, R, L.feat, L.num_cosines, True)
+        self._dense(ws.x, L.feat, "fc1", ws.h, R, True)
+        Wh, _ = self.wb("head")
+        return ops.dense_fwd_partial(ws.h, 512, Wh, R, L.Npad, 512, slabs)
+
     def fc1(self, ws: Workspace, B):
         """features -> relu(fc1) only (the fused DQN head kernel takes it from there)."""
         self._dense(ws.act3, self.L.feat, "fc1", ws.h, B, True)

@@ -411,6 +411,21 @@ class HipOps:
             _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
             _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), _stream()), "a0_actor_dist_tail_env_step")
 
+    def actor_quantile_tail_env_step(self, slabs, nslab, bias, ld, A, T, dueling, mode, taus, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl, eps_ptr,
+                                     env_seed, rank, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, frames, cap,
+                                     start_slot, r_act, r_rew, r_done):
+        nb = E * 4 * 84 * 84
+        check(self.lib.a0_actor_quantile_tail_env_step(
+            _req(slabs, torch.float32, nslab * E * T * ld, "slabs"), E * T * ld, nslab, _req(bias, torch.float32, A + (1 if dueling else 0), "bias"), ld, A, T, int(dueling),
+            mode, _req(taus, torch.float32, E * (T + 1), "taus", optional=(mode != 3)), E, seed, stream_a, stream_u, off_a, off_u, float(eps),
+            _req(ctrl, torch.int64, 8, "ctrl", optional=True), _req(eps_ptr, torch.float32, 1, "eps_ptr", optional=True),
+            _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax"),
+            env_seed, rank, g, _req(obs_in, torch.uint8, nb, "obs_in"), _req(obs_out, torch.uint8, nb, "obs_out"), _req(ep_ret, torch.float32, E, "ep_ret"),
+            _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), n, steps, float(gamma),
+            _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
+            _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
+            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), _stream()), "a0_actor_quantile_tail_env_step")
+
     def actor_qhead_scratch(self, E, K) -> int:
         return int(self.lib.a0_actor_qhead_scratch(E, K))
 

@@ -162,6 +162,17 @@ int a0_actor_dist_tail_env_step(const float* slabs, long long slab_stride, int n
                                 float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
                                 const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
 
+/* the quantile networks' counterpart (iqn: mode 1, mean over the T = K sampled quantiles; fqf: mode 3, sum over the T = F fractions weighted by their widths,
+ * taus [E][T + 1]): `slabs` are the split-K slabs [nslab][E * T][ld] of the head GEMM over (env, quantile) rows (a0_dense_fwd_partial), columns = actions
+ * (+ the dueling value); replaces a0_reduce_bias_act + a0_dueling_fwd + a0_select_action + a0_actor_egreedy_rng + a0_env_synth_step_commit of one actor
+ * step (reference agent.py:25-39 with model.py:253-257 / 280-284 behind it, and agent.py:44-90's per-step work), same arithmetic statement for statement */
+int a0_actor_quantile_tail_env_step(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                    const float* taus, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                    unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                    unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                    float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                    const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
+
 /* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
 int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
                 const float* done, const float* wgt, float gamma_n, int B, float* loss, float* dq, int* nan_flag, void* stream);

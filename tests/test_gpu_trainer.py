@@ -27,8 +27,9 @@ ROLLOUT_SPECS = dict(recipe.SPECS, fqf4=recipe.NetSpec("fqf", 4))
 
 @pytest.mark.parametrize("n_step,spec_name", [(1, "dqn"), (3, "dqn"), (1, "dqn_duel"), (3, "c51"), (1, "qr"), (1, "iqn_duel"), (3, "iqn_duel"), (3, "fqf4")])
 def test_actor_rollout_matches_oracle(n_step, spec_name):
-    """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the distributional tail, iqn / fqf the generic head + select +
-    egreedy kernels.  IQN draws K = 32 fresh taus per env and step (model.py:238, agent.py:25-28) from the actor's Philox tau stream — the
+    """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the distributional tail, iqn / fqf the quantile tail (head GEMM slabs ->
+    bias, dueling per quantile, mean / fraction-weighted sum, argmax, epsilon-greedy), each in one launch with the env step
+    (a0_actor_qhead_env_step / a0_actor_dist_tail_env_step / a0_actor_quantile_tail_env_step).  IQN draws K = 32 fresh taus per env and step (model.py:238, agent.py:25-28) from the actor's Philox tau stream — the
     oracle gets the same draws through ``taus_fn`` — and under hipGraph replay their offsets come from the device control block."""
     from agent0_amd.deepq.agent import Actor
     from agent0_amd.deepq.model import DeepQNet
@@ -44,7 +45,7 @@ def test_actor_rollout_matches_oracle(n_step, spec_name):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     replay = ReplayDataset(cfg, ops=model.ops)
     actor = Actor(cfg, model, replay=replay, rank=0)
-    assert actor.fused_tail == (spec.algo == "dqn")
+    assert actor.fused_tail == (spec.algo == "dqn") and actor.quant_tail == (spec.algo in ("iqn", "fqf"))
     # oracle twin: same env definition, same Philox draws (stream ids / offsets as DeviceRng assigns them)
     seed64 = (cfg.seed & 0xFFFFFFFF)
     step_no = [0]
