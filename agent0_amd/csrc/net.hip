@@ -36,7 +36,15 @@ __global__ void a0_reduce_bias_act_kernel(const float* __restrict__ slabs, long 
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; i < count; i += stride) {
         float s = 0.f;
-        for (int z = 0; z < nslab; ++z) s += slabs[(long long)z * slab_stride + i];
+        // eight slabs requested before any is added (additions still in slab order): 32 dependent-looking loads in a row cost a short, wide reduction 10 us
+        for (int z = 0; z < nslab; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) t[zz] = (z + zz < nslab) ? slabs[(long long)(z + zz) * slab_stride + i] : 0.f;
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+                if (z + zz < nslab) s += t[zz];
+        }
         s += bias[i % N];
         if (relu) s = (s < 0.f) ? 0.f : s;
         out[i] = s;
@@ -191,7 +199,8 @@ struct a0_hip_backend {
             // there is about a full round of such tiles (the actor's 8 192 rows would fill half the CUs and keep the smaller tile)
             constexpr bool mats = a0_is_mat<OA>::value && a0_is_mat<OB>::value;
             const long long huge = (long long)((X + 255) / 256) * ((Y + 127) / 128) * sp;
-            // ... and when they fill their rounds of 256 workgroups about as well as the smaller tiles fill theirs (the tile is worth ~5 %)
+            // ... and when they fill their rounds of 256 workgroups about as well as the smaller tiles fill theirs (the tile is worth ~5 %; relaxing this for
+            // fqf's 16 384-row data gradient, 1600 tiles = 6.25 rounds, or its 15 872-row pass, 248 tiles, gained nothing: 384.7 vs 385.3 us, 347.9 vs 342.8 us)
             const double fill_huge = (double)huge / (256.0 * (double)((huge + 255) / 256)), fill_big = (double)big / (256.0 * (double)((big + 255) / 256));
             if constexpr (mats) {
                 if (x9 && X >= 256 && Y >= 128 && huge >= g_x9_huge_min && fill_huge >= 0.93 * fill_big && (deep || !wgrad_family)) {

@@ -44,7 +44,8 @@ A0_D void a0_short_k_split8(const a0_f4& v0, const a0_f4& v1, a0_u32x4g& hi, a0_
 }
 
 // MODE 0: Y = act(.)   1: Y = act(.) * M   2: Y = act(.), Y2 = act(.) * M (the differentiated pass keeps the embedding for its backward)
-// GUARD = false: R % 32 == 0, N % 64 == 0 and whole 32-row blocks per group, checked by the launcher; the loop then holds nothing but
+// GUARD = false: R % 32 == 0, N % 64 == 0 and groups of at least 31 rows (a 32-row block then touches at most two groups: both M rows are fetched ahead and
+// selected per row), checked by the launcher; the loop then holds nothing but
 // straight-line loads and stores.  That matters because loads and stores return through ONE in-order counter (vmcnt): a unit's rows can
 // only be waited for together with every store issued before them.  With guarded stores anywhere in the loop the compiler cannot count the
 // stores that follow the loads and waits for ALL of them to be acknowledged before every unit (46 instead of 38 us at 8 192 rows); the same
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
     const int u0 = (int)(lunits * gw / nw), u1 = (int)(lunits * (gw + 1) / nw);
     if (gw >= nw || u0 >= u1) return;
     const int half = lane >> 5, l31 = lane & 31;
-    const bool uniform = MODE != 0 && (P.group & 31) == 0;      // a block of 32 rows lies in one group: one M row per block
+    const int last_group = MODE != 0 ? a0_udiv(P.R - 1, P.group, P.group_magic) : 0;
     const float floor_v = P.relu ? 0.f : -__builtin_inff();      // (v < floor) ? floor : v keeps NaN like torch.relu
 
     a0_u32x4g bf[2][4][3];
@@ -80,13 +81,18 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
         r = r < P.R ? r : P.R - 1;
         return P.X + (long long)r * P.ldx + 8 * half;
     };
-    // the M row of a block of 32 rows (uniform groups): fetched with the rows, two units ahead, for the same reason
-    auto request_m = [&](float (&mv)[2], int rblock) {
-        if (MODE != 0 && uniform) {
+    // the M rows of a block of 32 rows: with groups of at least 31 rows (checked by the launcher) a block touches at most TWO groups, g0 = group of its
+    // first row and g0 + 1; both rows are fetched with the block's X rows, one unit ahead, for the same reason (GUARD: per-row lookups in the epilogue instead)
+    auto request_m = [&](float (&mv)[2][2], int rblock) {
+        if (MODE != 0 && !GUARD) {
             if (rblock >= rb_hi) rblock = rb_lo;
-            const int g = a0_udiv(rblock * 32, P.group, P.group_magic);
+            const int g0 = a0_udiv(rblock * 32, P.group, P.group_magic), g1 = g0 < last_group ? g0 + 1 : g0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) mv[j] = P.M[(long long)g * P.N + (col[j] < P.N ? col[j] : P.N - 1)];
+            for (int j = 0; j < 2; ++j) {
+                const int c = col[j] < P.N ? col[j] : P.N - 1;
+                mv[0][j] = P.M[(long long)g0 * P.N + c];
+                mv[1][j] = P.M[(long long)g1 * P.N + c];
+            }
         }
     };
     auto request = [&](a0_f4 (&raw)[4][2], int rblock) {
@@ -95,8 +101,10 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
         for (int s = 0; s < 4; ++s) { raw[s][0] = *(const a0_f4*)(p + 16 * s); raw[s][1] = *(const a0_f4*)(p + 16 * s + 4); }
     };
     // one unit: rows of block rblock (in raw) times the resident strip; raw is refilled with the rows of block `refill` as its k-steps are consumed
-    auto unit = [&](a0_f4 (&raw)[4][2], float (&mv)[2], int rblock, int refill) {
-        const float mval[2] = {mv[0], mv[1]};
+    auto unit = [&](a0_f4 (&raw)[4][2], float (&mv)[2][2], int rblock, int refill) {
+        const float mval[2][2] = {{mv[0][0], mv[0][1]}, {mv[1][0], mv[1][1]}};
+        // first in-block row of the block's second group (32 or more: the whole block lies in one group)
+        const int bnd = MODE != 0 ? (a0_udiv(rblock * 32, P.group, P.group_magic) + 1) * P.group - rblock * 32 : 32;
         const float* pn = xrow(refill);
         a0_acc16 acc[2];
 #pragma unroll
@@ -138,9 +146,10 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
                     const unsigned o = oj + (unsigned)((r & 3) + 8 * (r >> 2)) * nb;
                     float v = acc[j][r] + bias_v[j];
                     v = (v < floor_v) ? floor_v : v;
+                    const float m = ((r & 3) + 8 * (r >> 2) + 4 * half < bnd) ? mval[0][j] : mval[1][j];
                     if (MODE == 0) *(float*)(y + o) = v;
-                    else if (MODE == 1) *(float*)(y + o) = v * mval[j];
-                    else { *(float*)(y + o) = v; *(float*)(y2 + o) = v * mval[j]; }
+                    else if (MODE == 1) *(float*)(y + o) = v * m;
+                    else { *(float*)(y + o) = v; *(float*)(y2 + o) = v * m; }
                 }
             }
         } else {
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
                     const long long o = (long long)row * P.N + col[j];
                     if (MODE == 0) P.Y[o] = v;
                     else {
-                        const float m = uniform ? mval[j] : P.M[(long long)a0_udiv(row, P.group, P.group_magic) * P.N + col[j]];
+                        const float m = P.M[(long long)a0_udiv(row, P.group, P.group_magic) * P.N + col[j]];
                         if (MODE == 1) P.Y[o] = v * m;
                         else { P.Y[o] = v; P.Y2[o] = v * m; }
                     }
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
     };
 
     a0_f4 raw_a[4][2];
-    float m_a[2] = {1.f, 1.f};
+    float m_a[2][2] = {{1.f, 1.f}, {1.f, 1.f}};
     request(raw_a, rb);
     for (int u = u0; u < u1; ++strip, rb = rb_lo) {
         // this strip of W: 64 rows x 64 k -> fragments of the three term planes
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
         // (and with it every store issued before that point of the trip)
         // (the M rows are per column: the first units of a strip fetch theirs here)
         request_m(m_a, rb);
-        asm volatile("" :: "v"(bias_v[0]), "v"(bias_v[1]), "v"(m_a[0]), "v"(m_a[1]));
+        asm volatile("" :: "v"(bias_v[0]), "v"(bias_v[1]), "v"(m_a[0][0]), "v"(m_a[0][1]), "v"(m_a[1][0]), "v"(m_a[1][1]));
         const int rb_end = (u1 - u < rb_hi - rb) ? rb + (u1 - u) : rb_hi;      // this wave's row blocks of the strip: [rb, rb_end)
         for (; rb < rb_end; ++rb, ++u) unit(raw_a, m_a, rb, rb + 1);
     }
@@ -205,7 +214,7 @@ static inline hipError_t a0_short_k_fwd_launch(hipStream_t st, const float* X, i
     if (wg >= 8) wg &= ~7;          // the kernel's XCD split wants whole rounds of eight workgroups
     if (wg < 1) wg = 1;
     const int mode = !M ? 0 : (Y2 ? 2 : 1);
-    const bool guard = (R & 31) != 0 || (N & 63) != 0 || (mode != 0 && (P.group & 31) != 0);
+    const bool guard = (R & 31) != 0 || (N & 63) != 0 || (mode != 0 && P.group < 31);       // groups of >= 31 rows: a 32-row block touches at most two of them
     const dim3 grid((unsigned)wg), block(256);
     if (guard) {
         if (mode == 0) hipLaunchKernelGGL((a0_short_k_fwd_kernel<0, true>), grid, block, 0, st, P);

@@ -519,10 +519,12 @@ def test_conv1_bf16_split_is_exact_and_fp32_accurate():
     assert e3_f <= 3.0 * e3_u + 2e-7 * s3, (e3_f, e3_u)
 
 
-@pytest.mark.parametrize("R,N,group,relu", [(8192, 3136, 32, True), (2048, 3136, 64, True), (300, 96, 5, True), (257, 64, 32, False), (1000, 200, 1, True)])
+@pytest.mark.parametrize("R,N,group,relu", [(8192, 3136, 32, True), (2048, 3136, 64, True), (300, 96, 5, True), (257, 64, 32, False), (1000, 200, 1, True),
+                                            (992, 3136, 31, True), (15872, 128, 31, True), (1056, 192, 33, True), (1280, 64, 40, False), (512, 64, 16, True)])
 def test_short_reduction_forward_kernel(hip, R, N, group, relu):
     """short_k_fwd.h (K = 64: the quantile networks' cosine embedding, model.py:244-247) in its three modes against float64, ragged rows /
-    columns and groups that do not divide a 32-row block included; the kept embedding and the product must agree with the separate launches."""
+    columns and groups that do not divide a 32-row block included (31 rows per group — fqf's F - 1 interior fractions — and 33 / 40 take the
+    straight-line kernel with two M rows per block, 5 / 16 / 1 the guarded one); the kept embedding and the product must agree with the separate launches."""
     K = 64
     g = torch.Generator().manual_seed(R + N)
     X = torch.randn(R, K, generator=g) * 0.7
