@@ -69,7 +69,15 @@ __global__ __launch_bounds__(256) void a0_reduce_segments_kernel(a0_reduce_multi
         a0_f4 s = a0_zero4();
         if (i4 < n4) {
             const a0_f4* p = (const a0_f4*)S.slabs + i4;
-            for (int z = g; z < S.nslab; z += 8) { const a0_f4 v = p[(long long)z * st4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            // four of this row group's slabs requested before any is added (same order of additions): the loads of a 72-slab segment overlap instead of queueing
+            for (int z = g; z < S.nslab; z += 32) {
+                a0_f4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (z + 8 * u < S.nslab) ? p[(long long)(z + 8 * u) * st4] : a0_zero4();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (z + 8 * u < S.nslab) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
         }
         red4[g][c] = s;
         __syncthreads();
