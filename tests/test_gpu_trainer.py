@@ -392,9 +392,24 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
     assert len(lines) == 1, "exactly one JSON line on stdout"
     launched = json.loads(lines[0])
     assert launched["n_gpus"] == 1 and launched["last_loss"] == plain["last_loss"] and "rehearsal" in launched["config"]["workload"]
-    # the in-graph exchange and the launcher cost nothing measurable: both data-parallel lines within 3 % of the plain one (same box, back to back)
-    for tag, line in (("A0_DP_FORCE", dp), ("--self-launch", launched)):
-        assert abs(line["value"] / plain["value"] - 1.0) <= 0.03, f"{tag}: {line['value']:.0f} vs plain {plain['value']:.0f} env-frames/s"
+    # the in-graph exchange and the launcher cost nothing measurable: both data-parallel lines within 3 % of the plain one (same box, back to back).
+    # A timing comparison of 0.2 s runs: one that misses is measured ONCE more, plain line and data-parallel line back to back again (consecutive bench
+    # runs on one box were seen to differ by up to 2.8 % on their own), and the second pair decides.
+    def within(line, ref):
+        return abs(line["value"] / ref["value"] - 1.0) <= 0.03
+
+    def run(env_):
+        r_ = subprocess.run(cmd if env_.get("_self") is None else cmd + ["--gpus", "1", "--self-launch"], env={k: v for k, v in env_.items() if k != "_self"},
+                            capture_output=True, text=True, timeout=600)
+        assert r_.returncode == 0, r_.stderr[-2000:]
+        return json.loads([ln for ln in r_.stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+    base = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for tag, line, env_ in (("A0_DP_FORCE", dp, dict(base, A0_DP_FORCE="1")), ("--self-launch", launched, dict(env, _self="1"))):
+        if not within(line, plain) or os.environ.get("A0_TEST_FORCE_RETIME") == "1":      # the variable exercises the second measurement itself
+            plain2, line2 = run(dict(base, A0_DP_FORCE="0")), run(env_)
+            assert within(line2, plain2), (f"{tag}: {line['value']:.0f} vs plain {plain['value']:.0f} env-frames/s, "
+                                           f"again {line2['value']:.0f} vs {plain2['value']:.0f}")
 
 
 def test_main_entry_point_at_baseline_config0_sizes(tmp_path):
