@@ -33,8 +33,12 @@ class DeviceSynthVecEnv:
     """obs (E,4,84,84) u8 on the GPU; ``step`` takes a device int32 action tensor and returns device tensors."""
 
     H = W = 84
+    TASKS = {"stream": 0, "block": 1}        # A0_ENV_TASK_* (include/agent0_hip.h): action-independent reward stream / the learnable block-quadrant task
 
-    def __init__(self, env_id: str, num_envs: int, seed: int = 42, rank: int = 0, ops=None):
+    def __init__(self, env_id: str, num_envs: int, seed: int = 42, rank: int = 0, ops=None, task: str = "stream"):
+        if task not in self.TASKS:
+            raise ValueError(f"env_task={task!r}: expected one of {sorted(self.TASKS)}")
+        self.task = self.TASKS[task]
         if ops is None:
             from agent0_amd.ops import HipOps
             ops = HipOps()
@@ -83,7 +87,7 @@ class DeviceSynthVecEnv:
         fm = self.final_mask if final_mask is None else final_mask
         fr = self.final_ret if final_ret is None else final_ret
         self.ops.env_step(self.seed, self.rank, self.E, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, self.reward,
-                          self.terminal, self.truncated, self.life_loss, fm, fr, ctrl)
+                          self.terminal, self.truncated, self.life_loss, fm, fr, ctrl, action=action, A=self.action_dim, task=self.task)
         self._cur = nxt
         info = {"life_loss": self.life_loss, "final_mask": fm, "final_ret": fr}
         return self._obs[nxt], self.reward, self.terminal, self.truncated, info
@@ -94,7 +98,7 @@ class DeviceSynthVecEnv:
         self.g += 1
         nxt = (self._cur + 1) % len(self._obs)
         self.ops.env_step_commit(self.seed, self.rank, self.E, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps, gamma,
-                                 action, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done, ctrl)
+                                 action, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done, ctrl, A=self.action_dim, task=self.task)
         self._cur = nxt
         return self._obs[nxt]
 
@@ -105,7 +109,7 @@ class DeviceSynthVecEnv:
         self.g += 1
         nxt = (self._cur + 1) % len(self._obs)
         {"qhead": self.ops.actor_qhead_env_step, "dist": self.ops.actor_dist_tail_env_step, "quantile": self.ops.actor_quantile_tail_env_step}[kind](*tail_args, self.seed, self.rank, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps,
-                                      gamma, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done)
+                                      gamma, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done, task=self.task)
         self._cur = nxt
         return self._obs[nxt]
 
@@ -124,13 +128,14 @@ def real_atari_available() -> bool:
     return True
 
 
-def make_atari(env_id: str, num_envs: int, episode_life: bool = True, seed: int = 42, rank: int = 0, ops=None, synthetic=None, num_workers=None):
-    """``synthetic=None``: the real Atari env (through the host env pool) when gymnasium + ale-py are importable, else the device-resident
+def make_atari(env_id: str, num_envs: int, episode_life: bool = True, seed: int = 42, rank: int = 0, ops=None, synthetic=None, num_workers=None, task: str = "stream"):
+    """``task``: reward task of the synthetic env (``cfg.env_task``: "stream" = the bench workload, "block" = learnable; ignored by the real Atari env).
+    ``synthetic=None``: the real Atari env (through the host env pool) when gymnasium + ale-py are importable, else the device-resident
     synthetic env.  ``num_workers``: env worker processes (default: one per 16 envs, at most 16; 0 = step in this process)."""
     if synthetic is None:
         synthetic = not real_atari_available()
     if synthetic:
-        return DeviceSynthVecEnv(env_id, num_envs, seed=seed, rank=rank, ops=ops)
+        return DeviceSynthVecEnv(env_id, num_envs, seed=seed, rank=rank, ops=ops, task=task)
     from .env_pool import HostEnvPool
 
     if num_workers is None:

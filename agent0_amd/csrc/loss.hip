@@ -230,6 +230,7 @@ struct a0_dtenv_args {
     int* r_act; float *r_rew, *r_done;
     int kt;                  // 1: quantile networks (iqn / fqf) — the head's rows are (env, quantile), its columns the actions (+ value): element (a, t) of env e at
                              //    slabs[(e * T + t) * ld + a], bias per column; 0: distributional heads (c51 / qr) — one row per env, columns (a, t)
+    int task;                // synthetic env's reward task (A0_ENV_TASK_*)
     const float* taus;       // mode 3 (fqf): [E][T + 1] fraction boundaries, value(a) = sum_t (tau[t + 1] - tau[t]) q(t, a)  (== a0_select_action_kernel mode 3)
 };
 __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_args P) {
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
             const float u = (float)(a0_philox_word(Q->rng_seed, Q->stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
             const int act = (u > eps) ? besta : ra;
             Q->action[e] = act; Q->qmax[e] = best;
-            a0_env_commit_scalars(x, e, Q->E, Q->n, steps, Q->gamma, act, Q->ep_ret, Q->final_mask, Q->final_ret, Q->ring_act, Q->ring_rew, Q->ring_done, Q->r_act, Q->r_rew,
+            a0_env_commit_scalars(x, e, g, Q->task, A, Q->E, Q->n, steps, Q->gamma, act, Q->ep_ret, Q->final_mask, Q->final_ret, Q->ring_act, Q->ring_rew, Q->ring_done, Q->r_act, Q->r_rew,
                                   Q->r_done, slot);
         }
     }
@@ -328,12 +329,12 @@ extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_st
                                            unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
                                            unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                                            float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
-                                           const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream) {
+                                           const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task, void* stream) {
     if (!slabs || !bias || !action || !qmax || E < 1 || A < 1 || T < 1 || nslab < 1 || ld < A * T + (dueling ? T : 0) || slab_stride < (long long)E * ld ||
         (mode != 1 && mode != 2) || (mode == 2 && !atoms))
         return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad argument");
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
-        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
         return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad env argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: buffers must be 16-byte aligned");
     const size_t lds = (size_t)(A * T + T) * sizeof(float);
@@ -350,7 +351,7 @@ extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_st
     P.action = action; P.qmax = qmax;
     P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
-    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
     P.kt = 0; P.taus = nullptr;
     hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail_env_step");
@@ -366,12 +367,12 @@ extern "C" int a0_actor_quantile_tail_env_step(const float* slabs, long long sla
                                                unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
                                                unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                                                float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
-                                               const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream) {
+                                               const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task, void* stream) {
     if (!slabs || !bias || !action || !qmax || E < 1 || A < 1 || T < 1 || nslab < 1 || ld < A + (dueling ? 1 : 0) || slab_stride < (long long)E * T * ld ||
         (mode != 1 && mode != 3) || (mode == 3 && !taus))
         return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: bad argument");
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
-        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
         return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: bad env argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: buffers must be 16-byte aligned");
     const size_t lds = (size_t)(A * T + T) * sizeof(float);
@@ -382,7 +383,7 @@ extern "C" int a0_actor_quantile_tail_env_step(const float* slabs, long long sla
     P.action = action; P.qmax = qmax;
     P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
-    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
     P.kt = 1; P.taus = taus;
     hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_quantile_tail_env_step");

@@ -559,6 +559,7 @@ struct a0_qenv_args {
     unsigned long long env_seed; uint32_t rank, g; const uint8_t* obs_in; uint8_t* obs_out; float *ep_ret, *final_mask, *final_ret;
     int n; long long steps; double gamma; int* ring_act; float *ring_rew, *ring_done; const uint8_t* obs0; uint8_t* frames; long long cap, start;
     int* r_act; float *r_rew, *r_done;
+    int task;
 };
 __global__ __launch_bounds__(256) void a0_actor_qhead_env_kernel(a0_qenv_args P) {
     __shared__ float raw[64];
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void a0_actor_qhead_env_kernel(a0_qenv_args P)
         a0_qhead_wave(P.slabs, P.slab_stride, P.nslab, P.b1, w2s, P.b2, P.A, P.dueling, (int)e, lane, raw, P.rng_seed, P.stream_a, P.stream_u, off_a, off_u, eps, act, best);
         if (lane == 0) {
             P.action[e] = act; P.qmax[e] = best;
-            a0_env_commit_scalars(x, e, P.E, P.n, steps, P.gamma, act, P.ep_ret, P.final_mask, P.final_ret, P.ring_act, P.ring_rew, P.ring_done, P.r_act, P.r_rew,
+            a0_env_commit_scalars(x, e, g, P.task, P.A, P.E, P.n, steps, P.gamma, act, P.ep_ret, P.final_mask, P.final_ret, P.ring_act, P.ring_rew, P.ring_done, P.r_act, P.r_rew,
                                   P.r_done, slot);
         }
     }
@@ -619,12 +620,12 @@ extern "C" int a0_actor_qhead_env_step(const float* feat, int E, int K, const fl
                                        unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
                                        unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                                        float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
-                                       const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream) {
+                                       const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task, void* stream) {
     A0_TRY
     if (!feat || !W1 || !b1 || !W2 || !b2 || !scratch || !action || !qmax || E < 1 || K < 4 || (K & 3) || A < 1 || A + (dueling ? 1 : 0) > 24)
         return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad argument (A + dueling <= 24: the head rows are staged in 48 KB of LDS)");
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
-        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
         return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad env argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: buffers must be 16-byte aligned");
     a0_hip_backend bk{(hipStream_t)stream};
@@ -640,7 +641,7 @@ extern "C" int a0_actor_qhead_env_step(const float* feat, int E, int K, const fl
     P.action = action; P.qmax = qmax;
     P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
-    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
     hipLaunchKernelGGL(a0_actor_qhead_env_kernel, dim3(E), dim3(256), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, P);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;

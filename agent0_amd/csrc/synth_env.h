@@ -13,6 +13,23 @@ A0_D uint32_t a0_env_mix32(uint32_t x) {
     return x;
 }
 
+// Reward of env e for the action `a` taken at step g (the step that produces frame(e, g)); `x` = the step's Philox draws.
+//   task 0 (A0_ENV_TASK_STREAM): x0 % 1000 < 50 -> -1, < 100 -> +1, else 0 — independent of the action (the bench workload)
+//   task 1 (A0_ENV_TASK_BLOCK):  the NEWEST frame of the observation the action was chosen on is frame(e, g - 1), whose bright 8x8 block sits at
+//        (by, bx) = ((3 (g-1) + 11 e) % 77, (5 (g-1) + 7 e) % 77); target = (2 [by >= 39] + [bx >= 39]) % A (the block's quadrant);
+//        +1 for the target action, -1 for (target + 1) % A, 0 otherwise — chance level 0, optimum +1 per step, learnable from the pixels
+A0_D float a0_env_reward(const a0_u4& x, int task, int A, uint32_t e, uint32_t g, int a) {
+    if (task == A0_ENV_TASK_BLOCK) {
+        const uint32_t gp = g - 1u;
+        const uint32_t by = (3u * gp + 11u * e) % 77u, bx = (5u * gp + 7u * e) % 77u;
+        const int target = (int)((2u * (by >= 39u ? 1u : 0u) + (bx >= 39u ? 1u : 0u)) % (uint32_t)A);
+        const int wrong = (target + 1) % A;
+        return a == target ? 1.0f : (a == wrong ? -1.0f : 0.0f);
+    }
+    const uint32_t rw = x.x % 1000u;
+    return rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+}
+
 A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix) {
     const uint32_t y = pix / A0_ENV_W, x = pix - y * A0_ENV_W;
     const uint32_t h = a0_env_mix32(base ^ (pix * 0x85EBCA77u));
@@ -49,13 +66,12 @@ A0_D void a0_env_nstep_row(uint32_t e, int E, int n, long long steps, double gam
 }
 
 // episode statistics + n-step row of env e at step g: what ONE thread per env does once the action is known
-A0_D void a0_env_commit_scalars(const a0_u4& x, uint32_t e, int E, int n, long long steps, double gamma, int a_now, float* __restrict__ ep_ret,
+A0_D void a0_env_commit_scalars(const a0_u4& x, uint32_t e, uint32_t g, int task, int A, int E, int n, long long steps, double gamma, int a_now, float* __restrict__ ep_ret,
                                 float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act, float* __restrict__ ring_rew,
                                 float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done, long long slot) {
 #pragma clang fp contract(off)
     const bool term = (x.y % 500u) == 0u;
-    const uint32_t rw = x.x % 1000u;
-    const float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+    const float r = a0_env_reward(x, task, A, e, g, a_now);
     const bool life = (!term) && ((x.z % 200u) == 0u);
     const float ret = ep_ret[e] + r;
     final_mask[e] = term ? 1.f : 0.f;

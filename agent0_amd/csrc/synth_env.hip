@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void a0_env_step_kernel(unsigned long long see
                                                            uint8_t* __restrict__ obs_out, float* __restrict__ ep_ret, float* __restrict__ reward,
                                                            float* __restrict__ terminal, float* __restrict__ truncated, float* __restrict__ life_loss,
                                                            float* __restrict__ final_mask, float* __restrict__ final_ret, int reset,
-                                                           const long long* __restrict__ ctrl) {
+                                                           const long long* __restrict__ ctrl, const int* __restrict__ action, int A, int task) {
     if (ctrl) g += (uint32_t)ctrl[A0_CTRL_ENV_STEP];
     const uint32_t e = blockIdx.y;
     bool term = reset != 0;
@@ -21,8 +21,7 @@ __global__ __launch_bounds__(256) void a0_env_step_kernel(unsigned long long see
         const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)seed, (uint32_t)(seed >> 32) ^ rank);
         term = (x.y % 500u) == 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            const uint32_t rw = x.x % 1000u;
-            const float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+            const float r = a0_env_reward(x, task, A, e, g, task == A0_ENV_TASK_BLOCK ? action[e] : 0);
             const bool life = (!term) && ((x.z % 200u) == 0u);
             reward[e] = r; terminal[e] = term ? 1.f : 0.f; truncated[e] = 0.f; life_loss[e] = life ? 1.f : 0.f;
             const float ret = ep_ret[e] + r;
@@ -53,17 +52,18 @@ __global__ __launch_bounds__(256) void a0_env_step_kernel(unsigned long long see
 extern "C" int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream) {
     if (!obs || !ep_ret || E < 1) return a0_fail(A0_EINVAL, "a0_env_synth_reset: bad argument");
     hipLaunchKernelGGL(a0_env_step_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, 0u, obs, obs, ep_ret,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1, (const long long*)nullptr);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 1, (const long long*)nullptr, (const int*)nullptr, 1, A0_ENV_TASK_STREAM);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_reset");
 }
 
 extern "C" int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
                                  float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
-                                 float* final_ret, const long long* ctrl, void* stream) {
-    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !reward || !terminal || !truncated || !life_loss || !final_mask || !final_ret || E < 1)
+                                 float* final_ret, const int* action, int A, int task, const long long* ctrl, void* stream) {
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !reward || !terminal || !truncated || !life_loss || !final_mask || !final_ret || E < 1 ||
+        (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK) || (task == A0_ENV_TASK_BLOCK && (!action || A < 1)))
         return a0_fail(A0_EINVAL, "a0_env_synth_step: bad argument (obs_in and obs_out must differ)");
     hipLaunchKernelGGL(a0_env_step_kernel, dim3(7, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal,
-                       truncated, life_loss, final_mask, final_ret, 0, ctrl);
+                       truncated, life_loss, final_mask, final_ret, 0, ctrl, action, A, task);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step");
 }
 
@@ -82,14 +82,14 @@ __global__ __launch_bounds__(256) void a0_env_step_commit_kernel(unsigned long l
                                                                   const int* __restrict__ action, int* __restrict__ ring_act, float* __restrict__ ring_rew,
                                                                   float* __restrict__ ring_done, const uint8_t* __restrict__ obs0, uint8_t* __restrict__ frames,
                                                                   long long cap, long long start, int* __restrict__ r_act, float* __restrict__ r_rew,
-                                                                  float* __restrict__ r_done, const long long* __restrict__ ctrl) {
+                                                                  float* __restrict__ r_done, const long long* __restrict__ ctrl, int A, int task) {
     if (ctrl) { g += (uint32_t)ctrl[A0_CTRL_ENV_STEP]; steps += ctrl[A0_CTRL_ACTOR_STEPS]; start += ctrl[A0_CTRL_REPLAY_SLOT]; }
     const uint32_t e = blockIdx.y;
     const long long slot = (start + e) % cap;
     const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)seed, (uint32_t)(seed >> 32) ^ rank);
     const bool term = (x.y % 500u) == 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        a0_env_commit_scalars(x, e, E, n, steps, gamma, action[e], ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
+        a0_env_commit_scalars(x, e, g, task, A, E, n, steps, gamma, action[e], ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
     // 16 bytes per lane: 441 lanes cover a frame (two workgroups per env); every load and store is a full-width vector access
     a0_env_commit_frames(seed, e, g, term, obs_in, obs_out, obs0, frames + slot * (8LL * A0_ENV_PIX), blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
@@ -97,12 +97,13 @@ __global__ __launch_bounds__(256) void a0_env_step_commit_kernel(unsigned long l
 extern "C" int a0_env_synth_step_commit(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                                         float* final_mask, float* final_ret, int n, long long steps, double gamma, const int* action, int* ring_act,
                                         float* ring_rew, float* ring_done, const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act,
-                                        float* r_rew, float* r_done, const long long* ctrl, void* stream) {
+                                        float* r_rew, float* r_done, int A, int task, const long long* ctrl, void* stream) {
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !action || !ring_act || !ring_rew || !ring_done || !obs0 || !frames ||
-        !r_act || !r_rew || !r_done || E < 1 || n < 1 || steps < 0 || cap < E || start_slot < 0)
+        !r_act || !r_rew || !r_done || E < 1 || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK) ||
+        (task == A0_ENV_TASK_BLOCK && A < 1))
         return a0_fail(A0_EINVAL, "a0_env_synth_step_commit: bad argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_env_synth_step_commit: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(a0_env_step_commit_kernel, dim3(2, E), dim3(256), 0, (hipStream_t)stream, seed, rank, E, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n,
-                       steps, gamma, action, ring_act, ring_rew, ring_done, obs0, frames, cap, start_slot % cap, r_act, r_rew, r_done, ctrl);
+                       steps, gamma, action, ring_act, ring_rew, ring_done, obs0, frames, cap, start_slot % cap, r_act, r_rew, r_done, ctrl, A, task);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_synth_step_commit");
 }

@@ -42,7 +42,7 @@ class Actor:
         self.cfg = cfg
         self.ops = ops = model.ops if model is not None else _ops_from(cfg, ops)
         self.rng = DeviceRng(ops, cfg.seed, rank)
-        self.envs = envs if envs is not None else make_atari(cfg.env_id, cfg.actor.num_envs, seed=cfg.seed, rank=rank, ops=ops)
+        self.envs = envs if envs is not None else make_atari(cfg.env_id, cfg.actor.num_envs, seed=cfg.seed, rank=rank, ops=ops, task=cfg.env_task)
         self.obs, _ = self.envs.reset()
         self.model = model if model is not None else DeepQNet(cfg, ops=ops)
         self.replay = replay

@@ -10,6 +10,9 @@ Additions (all default to the reference's behaviour being available):
                    sum-tree (what the north star builds).  False reproduces the reference, which despite its name
                    samples uniformly and only re-weights (quirks Q1/Q2/Q7 of SURVEY.md).
   learner.algo     accepts ``iqr`` (README spelling) as an alias of ``iqn`` (quirk Q10).
+  env_task         reward task of the device-resident synthetic env (include/agent0_hip.h A0_ENV_TASK_*): ``stream`` (default; an action-independent reward
+                   stream — the throughput workload) or ``block`` (learnable: +1 for naming the quadrant of the bright block in the newest frame,
+                   -1 for the next class; chance 0, optimum +1 per step) — what the learning tests train on.  Ignored by real Atari envs.
   device           ``cuda`` is the only supported device: this build has no CPU path (it raises instead).
   checkpoint       path of a checkpoint written by ``Trainer.save_checkpoint``; read when ``mode`` is ``finetune`` (resume training)
                    or ``play`` (evaluate only) — the reference declares those modes (config.py:26-29) but never implements them.
@@ -157,6 +160,7 @@ class ExpConfig:
     wandb: bool = True
     tb: bool = True
     checkpoint: str = ""
+    env_task: str = "stream"
     learner: LearnerConfig = field(default_factory=LearnerConfig)
     trainer: TrainerConfig = field(default_factory=TrainerConfig)
     actor: ActorConfig = field(default_factory=ActorConfig)

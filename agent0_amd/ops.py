@@ -398,7 +398,7 @@ class HipOps:
 
     def actor_dist_tail_env_step(self, slabs, nslab, bias, ld, A, T, dueling, mode, atoms, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl, eps_ptr,
                                  env_seed, rank, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, frames, cap,
-                                 start_slot, r_act, r_rew, r_done):
+                                 start_slot, r_act, r_rew, r_done, task=0):
         nb = E * 4 * 84 * 84
         check(self.lib.a0_actor_dist_tail_env_step(
             _req(slabs, torch.float32, nslab * E * ld, "slabs"), E * ld, nslab, _req(bias, torch.float32, ld, "bias"), ld, A, T, int(dueling),
@@ -409,11 +409,11 @@ class HipOps:
             _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), n, steps, float(gamma),
             _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
             _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
-            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), _stream()), "a0_actor_dist_tail_env_step")
+            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), int(task), _stream()), "a0_actor_dist_tail_env_step")
 
     def actor_quantile_tail_env_step(self, slabs, nslab, bias, ld, A, T, dueling, mode, taus, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl, eps_ptr,
                                      env_seed, rank, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, frames, cap,
-                                     start_slot, r_act, r_rew, r_done):
+                                     start_slot, r_act, r_rew, r_done, task=0):
         nb = E * 4 * 84 * 84
         check(self.lib.a0_actor_quantile_tail_env_step(
             _req(slabs, torch.float32, nslab * E * T * ld, "slabs"), E * T * ld, nslab, _req(bias, torch.float32, A + (1 if dueling else 0), "bias"), ld, A, T, int(dueling),
@@ -424,7 +424,7 @@ class HipOps:
             _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), n, steps, float(gamma),
             _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
             _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
-            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), _stream()), "a0_actor_quantile_tail_env_step")
+            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), int(task), _stream()), "a0_actor_quantile_tail_env_step")
 
     def actor_qhead_scratch(self, E, K) -> int:
         return int(self.lib.a0_actor_qhead_scratch(E, K))
@@ -439,7 +439,7 @@ class HipOps:
 
     def actor_qhead_env_step(self, feat, E, K, W1, b1, W2, b2, A, dueling, scratch, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl, eps_ptr,
                              env_seed, rank, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, frames, cap,
-                             start_slot, r_act, r_rew, r_done):
+                             start_slot, r_act, r_rew, r_done, task=0):
         nq = A + (1 if dueling else 0)
         nb = E * 4 * 84 * 84
         check(self.lib.a0_actor_qhead_env_step(
@@ -452,7 +452,7 @@ class HipOps:
             _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), n, steps, float(gamma),
             _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
             _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
-            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), _stream()), "a0_actor_qhead_env_step")
+            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), int(task), _stream()), "a0_actor_qhead_env_step")
 
     def mean_rows(self, x, T, E, out):
         check(self.lib.a0_mean_rows(_req(x, torch.float32, T * E, "x"), T, E, _req(out, torch.float32, T, "out"), _stream()), "a0_mean_rows")
@@ -548,16 +548,18 @@ class HipOps:
     def env_reset(self, seed, rank, E, obs, ep_ret):
         check(self.lib.a0_env_synth_reset(seed, rank, E, _req(obs, torch.uint8, E * 4 * 84 * 84, "obs"), _req(ep_ret, torch.float32, E, "ep_ret"), _stream()), "a0_env_synth_reset")
 
-    def env_step(self, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal, truncated, life_loss, final_mask, final_ret, ctrl=None):
+    def env_step(self, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal, truncated, life_loss, final_mask, final_ret, ctrl=None, action=None, A=1, task=0):
+        """``task`` 0: action-independent reward stream; 1: the learnable block task (needs ``action`` [E] int32 and the action count ``A``)."""
         n = E * 4 * 84 * 84
         check(self.lib.a0_env_synth_step(seed, rank, E, g, _req(obs_in, torch.uint8, n, "obs_in"), _req(obs_out, torch.uint8, n, "obs_out"),
                                          _req(ep_ret, torch.float32, E, "ep_ret"), _req(reward, torch.float32, E, "reward"), _req(terminal, torch.float32, E, "terminal"),
                                          _req(truncated, torch.float32, E, "truncated"), _req(life_loss, torch.float32, E, "life_loss"),
                                          _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"),
+                                         _req(action, torch.int32, E, "action", optional=(task == 0)), int(A), int(task),
                                          _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_env_synth_step")
 
     def env_step_commit(self, seed, rank, E, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, action, ring_act, ring_rew, ring_done, obs0,
-                        frames, cap, start_slot, r_act, r_rew, r_done, ctrl=None):
+                        frames, cap, start_slot, r_act, r_rew, r_done, ctrl=None, A=1, task=0):
         nb = E * 4 * 84 * 84
         check(self.lib.a0_env_synth_step_commit(seed, rank, E, g, _req(obs_in, torch.uint8, nb, "obs_in"), _req(obs_out, torch.uint8, nb, "obs_out"),
                                                 _req(ep_ret, torch.float32, E, "ep_ret"), _req(final_mask, torch.float32, E, "final_mask"),
@@ -565,7 +567,7 @@ class HipOps:
                                                 _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"),
                                                 _req(ring_done, torch.float32, n * E, "ring_done"), _req(obs0, torch.uint8, nb, "obs0"),
                                                 _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
-                                                _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
+                                                _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), int(A), int(task),
                                                 _req(ctrl, torch.int64, 8, "ctrl", optional=True), _stream()), "a0_env_synth_step_commit")
 
     # ------------------------------------------------------------------ data-parallel gradient exchange (RCCL, include/agent0_hip.h a0_dp_*)

@@ -160,7 +160,7 @@ int a0_actor_dist_tail_env_step(const float* slabs, long long slab_stride, int n
                                 unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
                                 unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                                 float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
-                                const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
+                                const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task, void* stream);
 
 /* the quantile networks' counterpart (iqn: mode 1, mean over the T = K sampled quantiles; fqf: mode 3, sum over the T = F fractions weighted by their widths,
  * taus [E][T + 1]): `slabs` are the split-K slabs [nslab][E * T][ld] of the head GEMM over (env, quantile) rows (a0_dense_fwd_partial), columns = actions
@@ -171,7 +171,7 @@ int a0_actor_quantile_tail_env_step(const float* slabs, long long slab_stride, i
                                     unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
                                     unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                                     float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
-                                    const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
+                                    const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task, void* stream);
 
 /* DQNLearner.train_step (agent.py:173-190): loss [B], dq [B][A] = d(sum_b w_b loss_b)/dq */
 int a0_loss_dqn(const float* q, const float* q_next, int A, const int* act, const int* a_star, const float* rew,
@@ -308,7 +308,7 @@ int a0_actor_qhead_env_step(const float* feat, int E, int K, const float* W1, co
                             unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
                             unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                             float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
-                            const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, void* stream);
+                            const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task, void* stream);
 /* out[t] = mean over e of x[t][e] (per-step mean max-Q of a rollout, agent.py:38,88) */
 int a0_mean_rows(const float* x, int T, int E, float* out, void* stream);
 
@@ -336,17 +336,22 @@ int a0_rng_uniform_ctrl(unsigned long long seed, unsigned int stream_id, unsigne
                         int ctrl_idx, void* stream);
 int a0_rng_normal_ctrl(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float stdv, float* out, long long n,
                        const long long* ctrl, int ctrl_idx, void* stream);
+/* Synthetic env (oracle/synth_env.c defines it).  `task` selects the reward: A0_ENV_TASK_STREAM = an action-independent stream (P(-1, +1, 0) = .05, .05, .9:
+ * the bench workload), A0_ENV_TASK_BLOCK = learnable: +1 when the action equals the quadrant (mod A) of the bright 8x8 block in the newest frame of the
+ * observation it was chosen on, -1 for the next class, 0 otherwise (chance level 0, optimum +1 per step).  Terminals / life losses do not depend on it. */
+#define A0_ENV_TASK_STREAM 0
+#define A0_ENV_TASK_BLOCK 1
 int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream);
 int a0_env_synth_step(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out,
                       float* ep_ret, float* reward, float* terminal, float* truncated, float* life_loss, float* final_mask,
-                      float* final_ret, const long long* ctrl, void* stream);
+                      float* final_ret, const int* action, int A, int task, const long long* ctrl, void* stream);
 /* a0_env_synth_step + a0_actor_nstep (agent.py:57-73) + a0_replay_insert (agent.py:78-81, replay.py:45-53) in one launch for rollouts
  * driven by the synthetic env: obs0 = first observation of the emitted transition (obs_in for n = 1).  ctrl adds its ENV_STEP,
  * ACTOR_STEPS and REPLAY_SLOT words to g, steps and start_slot. */
 int a0_env_synth_step_commit(unsigned long long seed, unsigned int rank, int E, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
                              float* final_mask, float* final_ret, int n, long long steps, double gamma, const int* action, int* ring_act,
                              float* ring_rew, float* ring_done, const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act,
-                             float* r_rew, float* r_done, const long long* ctrl, void* stream);
+                             float* r_rew, float* r_done, int A, int task, const long long* ctrl, void* stream);
 
 /* ---------------------------------------------------------------- data-parallel gradient exchange (no reference counterpart)
  * One process per GPU; every rank holds a full replica and SUM-reduces its flat fp32 gradient buffer once per update over RCCL/xGMI.  The

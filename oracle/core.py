@@ -158,9 +158,13 @@ class SynthVecEnv:
 
     H = W = 84
 
-    def __init__(self, num_envs: int, seed: int = 42, rank: int = 0, action_dim: int = 4, env_offset: int = 0):
-        """``env_offset``: this object is envs [env_offset, env_offset + num_envs) of a larger vector env (a slice owned by one worker)."""
+    TASKS = {"stream": 0, "block": 1}
+
+    def __init__(self, num_envs: int, seed: int = 42, rank: int = 0, action_dim: int = 4, env_offset: int = 0, task: str = "stream"):
+        """``env_offset``: this object is envs [env_offset, env_offset + num_envs) of a larger vector env (a slice owned by one worker).
+        ``task``: "stream" = action-independent rewards, "block" = the learnable task (oracle/synth_env.c)."""
         self.E, self.seed, self.rank, self.action_dim, self.e0 = num_envs, seed, rank, action_dim, env_offset
+        self.task = self.TASKS[task]
         self.g = np.zeros(num_envs, dtype=np.uint32)
         self.ep_ret = np.zeros(num_envs, dtype=np.float32)
         self.obs = np.zeros((num_envs, 4, 84, 84), dtype=np.uint8)
@@ -178,7 +182,8 @@ class SynthVecEnv:
         life = np.empty(self.E, dtype=np.uint8)
         fmask = np.empty(self.E, dtype=np.uint8)
         fret = np.empty(self.E, dtype=np.float32)
-        lib().a0o_env_step_at(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.e0), C.c_int64(self.E), _p(a), _p(self.g), _p(self.ep_ret),
+        lib().a0o_env_step_task_at(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.e0), C.c_int64(self.E), _p(a), C.c_int32(self.action_dim), C.c_int32(self.task),
+                                _p(self.g), _p(self.ep_ret),
                            _p(self.obs), _p(out), _p(rew), _p(term), _p(trunc), _p(life), _p(fmask), _p(fret))
         self.obs = out
         info = {"life_loss": life.astype(bool)}
@@ -192,6 +197,21 @@ class SynthVecEnv:
 
     def close(self):
         pass
+
+
+def env_terminals(seed: int, rank: int, E: int, steps: int, env_offset: int = 0) -> np.ndarray:
+    """bool [steps, E]: env e terminates at step g = row + 1 (action-independent)."""
+    out = np.empty((steps, E), dtype=np.uint8)
+    lib().a0o_env_terminals(C.c_uint64(seed), C.c_uint32(rank), C.c_int64(env_offset), C.c_int64(E), C.c_int64(steps), _p(out))
+    return out.astype(bool)
+
+
+def env_block_target(e, g_prev, A: int):
+    """The block task's rewarded action for an observation whose newest frame is frame(e, g_prev) (oracle/synth_env.c)."""
+    e, g_prev = np.asarray(e, dtype=np.uint32), np.asarray(g_prev, dtype=np.uint32)
+    by = (np.uint32(3) * g_prev + np.uint32(11) * e) % np.uint32(77)
+    bx = (np.uint32(5) * g_prev + np.uint32(7) * e) % np.uint32(77)
+    return ((2 * (by >= 39).astype(np.int64) + (bx >= 39).astype(np.int64)) % A).astype(np.int64)
 
 
 def env_frame(seed: int, e: int, g: int) -> np.ndarray:

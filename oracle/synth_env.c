@@ -10,7 +10,11 @@
  *   frame(e,g)[y][x] = lit ? (h & 255) : 0,   h = mix(seed ^ mix(e*0x9E3779B1 + g) ^ ((y*84+x)*0x85EBCA77)),
  *                      lit = ((h >> 8) & 3) == 0;  an 8x8 block of 255 at (by,bx) = ((3g+11e)%77, (5g+7e)%77)
  *   draws (x0..x3) = philox4x32_10(ctr = (e, g, 0, 0x454E56), key = (seed_lo, seed_hi ^ rank))
- *   reward   = x0%1000 < 50 ? -1 : x0%1000 < 100 ? +1 : 0          P = (0.05, 0.05, 0.90)
+ *   reward   = task 0 ("stream"): x0%1000 < 50 ? -1 : x0%1000 < 100 ? +1 : 0     P = (0.05, 0.05, 0.90), independent of the action (bench workload)
+ *              task 1 ("block"):  the newest frame of the observation the action was chosen on is frame(e, g-1); its block sits at
+ *                                 (by, bx) = ((3(g-1)+11e)%77, (5(g-1)+7e)%77); target = (2[by >= 39] + [bx >= 39]) % A (the block's quadrant);
+ *                                 +1 for action == target, -1 for action == (target+1) % A, else 0: chance level 0, optimum +1 per step.
+ *                                 Exists so that LEARNING can be tested (the reference's acceptance evidence is learning curves, README.md:62-112).
  *   terminal = x1 % 500 == 0;  life_loss = !terminal && x2 % 200 == 0;  truncated = 0
  *   obs'     = terminal ? 4 x frame(e,g) : shift(obs) + frame(e,g)
  */
@@ -55,10 +59,21 @@ void a0o_env_reset(uint64_t seed, uint32_t rank, int64_t E, uint32_t* g, float* 
     a0o_env_reset_at(seed, rank, 0, E, g, ep_ret, obs);
 }
 
-void a0o_env_step_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,
+float a0o_env_reward(uint32_t x0, int32_t task, int32_t A, uint32_t e, uint32_t g, int32_t a) {
+    if (task == 1) {
+        uint32_t gp = g - 1u;
+        uint32_t by = (3u * gp + 11u * e) % 77u, bx = (5u * gp + 7u * e) % 77u;
+        int32_t target = (int32_t)((2u * (by >= 39u ? 1u : 0u) + (bx >= 39u ? 1u : 0u)) % (uint32_t)A);
+        int32_t wrong = (target + 1) % A;
+        return a == target ? 1.0f : (a == wrong ? -1.0f : 0.0f);
+    }
+    uint32_t rw = x0 % 1000u;
+    return rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+}
+
+void a0o_env_step_task_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, const int32_t* action, int32_t A, int32_t task, uint32_t* g, float* ep_ret,
                      const uint8_t* obs_in, uint8_t* obs_out, float* reward, uint8_t* terminal, uint8_t* truncated,
                      uint8_t* life_loss, uint8_t* final_mask, float* final_ret) {
-    (void)action;
     for (int64_t e = 0; e < E; ++e) {
         uint32_t gg = g[e] + 1u;
         g[e] = gg;
@@ -66,8 +81,7 @@ void a0o_env_step_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, const 
         uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ rank};
         uint32_t x[4];
         a0o_philox4x32_10(ctr, key, x);
-        uint32_t rw = x[0] % 1000u;
-        float r = rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
+        float r = a0o_env_reward(x[0], task, A, (uint32_t)(e0 + e), gg, task == 1 ? action[e] : 0);
         uint8_t term = (x[1] % 500u) == 0u;
         uint8_t life = (!term) && ((x[2] % 200u) == 0u);
         reward[e] = r; terminal[e] = term; truncated[e] = 0; life_loss[e] = life;
@@ -85,6 +99,25 @@ void a0o_env_step_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, const 
             memcpy(out + 3 * A0O_PIX, fr, A0O_PIX);
         }
     }
+}
+
+/* terminal[(g - 1) * E + e] = does env e0 + e terminate at step g, g = 1 .. steps (terminals do not depend on actions): lets a test turn the episode returns
+ * a training run reports (in step-major, env-major order) into per-step rewards */
+void a0o_env_terminals(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, int64_t steps, uint8_t* terminal) {
+    for (int64_t g = 1; g <= steps; ++g)
+        for (int64_t e = 0; e < E; ++e) {
+            uint32_t ctr[4] = {(uint32_t)(e0 + e), (uint32_t)g, 0u, 0x454E56u};
+            uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ rank};
+            uint32_t x[4];
+            a0o_philox4x32_10(ctr, key, x);
+            terminal[(g - 1) * E + e] = (x[1] % 500u) == 0u;
+        }
+}
+
+void a0o_env_step_at(uint64_t seed, uint32_t rank, int64_t e0, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,
+                     const uint8_t* obs_in, uint8_t* obs_out, float* reward, uint8_t* terminal, uint8_t* truncated,
+                     uint8_t* life_loss, uint8_t* final_mask, float* final_ret) {
+    a0o_env_step_task_at(seed, rank, e0, E, action, 1, 0, g, ep_ret, obs_in, obs_out, reward, terminal, truncated, life_loss, final_mask, final_ret);
 }
 
 void a0o_env_step(uint64_t seed, uint32_t rank, int64_t E, const int32_t* action, uint32_t* g, float* ep_ret,

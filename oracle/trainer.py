@@ -128,7 +128,7 @@ class OracleTrainer:
                  training_start_steps: int, policy: str = "uniform", sumtree: bool = True, n_step: int = 1, double_q: bool = False, seed: int = 42,
                  rank: int = 0, discount: float = 0.99, lr: float = 5e-4, target_update_freq: int = 500, alpha: float = 0.5, prio_eps: float = 0.01,
                  beta0: float = 0.4, total_steps: int = int(1e7), exploration_steps: int = int(1e6), min_eps: float = 0.01, launch: bool = False,
-                 reset_noise_freq: int = 4, actor_noise=None, learner_noise=None):
+                 reset_noise_freq: int = 4, actor_noise=None, learner_noise=None, env_task: str = "stream"):
         """NoisyNet (spec.noisy): the N(0, 0.1^2) draws are supplied by the caller, like every other random number — ``actor_noise()`` returns the
         draws of the actor's next ``reset_noise`` (agent.py:49-50: every reset_noise_freq steps), ``learner_noise()`` the (online, target) draws
         of the next ``train`` (agent.py:125-127); each a list [noise_in, noise_out_weight, noise_out_bias] per NoisyLinear in module order."""
@@ -152,7 +152,7 @@ class OracleTrainer:
             a = (self.actor_rng.u32(STREAM_EGREEDY_A, E_) % A).astype(np.int64)
             return a, self.actor_rng.uniform(STREAM_EGREEDY_U, E_)
 
-        env = core.SynthVecEnv(num_envs, seed=seed, rank=rank, action_dim=A)
+        env = core.SynthVecEnv(num_envs, seed=seed, rank=rank, action_dim=A, task=env_task)
         # main schedule: the actor shares the learner's model (trainer.py:41-44); launch schedule: it owns a copy, refreshed per rollout
         def noisy_reset(p):      # NoisyLinear.reset_noise on the actor's model (agent.py:49-50, model.py:73-83)
             from . import nets

@@ -100,9 +100,14 @@ def test_rng_streams(hip):
     assert np.array_equal(ri.cpu().numpy(), (core.rng_u32(8, 2, 0, n) % 18).astype(np.int32))
 
 
-def test_synth_env_bytes(hip):
+@pytest.mark.parametrize("task,A", [("stream", 4), ("block", 4), ("block", 9), ("block", 18)])
+def test_synth_env_bytes(hip, task, A):
+    """a0_env_synth_step against oracle/synth_env.c, both reward tasks; on the block task the actions cycle through right / wrong / neutral classes."""
     E = 5
-    env = core.SynthVecEnv(E, seed=42, rank=3)
+    env = core.SynthVecEnv(E, seed=42, rank=3, action_dim=A, task=task)
+    tid = core.SynthVecEnv.TASKS[task]
+    act = hip.zeros(E, dtype=torch.int32)
+    n_pos = n_neg = 0
     obs_c, _ = env.reset()
     obs = [hip.zeros(E * 4 * 84 * 84, dtype=torch.uint8), hip.zeros(E * 4 * 84 * 84, dtype=torch.uint8)]
     ep = hip.zeros(E)
@@ -111,8 +116,11 @@ def test_synth_env_bytes(hip):
     assert np.array_equal(obs[0].cpu().numpy().reshape(E, 4, 84, 84), obs_c)
     n_term = 0
     for t in range(1, 1200):
-        o, r, term, trunc, info = env.step(np.zeros(E))
-        hip.env_step(42, 3, E, t, obs[(t - 1) % 2], obs[t % 2], ep, *f)
+        a = (core.env_block_target(np.arange(E), np.full(E, t - 1), A) + (np.arange(E) + t) % 3) % A        # target, target + 1 (wrong), target + 2
+        act.copy_(torch.from_numpy(a.astype(np.int32)))
+        o, r, term, trunc, info = env.step(a)
+        n_pos += int((r > 0).sum()); n_neg += int((r < 0).sum())
+        hip.env_step(42, 3, E, t, obs[(t - 1) % 2], obs[t % 2], ep, *f, action=act, A=A, task=tid)
         if t < 40 or term.any():
             assert np.array_equal(obs[t % 2].cpu().numpy().reshape(E, 4, 84, 84), o), f"obs at step {t}"
         assert np.array_equal(f[0].cpu().numpy(), r.astype(np.float32))
@@ -124,6 +132,8 @@ def test_synth_env_bytes(hip):
             assert np.array_equal(f[5].cpu().numpy(), fr) and np.array_equal(f[4].cpu().numpy() != 0, term)
     assert n_term > 0
     assert np.array_equal(ep.cpu().numpy(), env.ep_ret)
+    if task == "block":
+        assert n_pos > 1500 and n_neg > 1500        # a third of the actions each (A = 4 ... 18: target + 2 is never rewarded)
 
 
 @pytest.mark.parametrize("n_step", [1, 3])

@@ -49,7 +49,7 @@ def device_noise(net):
     return out
 
 
-def _build(algo, policy, sumtree, n_step, double_q, launch, ls=None, spec_name=None, dims=SMALL):
+def _build(algo, policy, sumtree, n_step, double_q, launch, ls=None, spec_name=None, dims=SMALL, env_task="stream"):
     from agent0_amd.deepq.config import parse_overrides
     from agent0_amd.deepq.trainer import Trainer
     E_, T_, B_, SIZE, LSTEPS, START, TFREQ = dims
@@ -58,7 +58,7 @@ def _build(algo, policy, sumtree, n_step, double_q, launch, ls=None, spec_name=N
     over = [f"learner.algo={algo}", f"actor.num_envs={E_}", f"actor.sample_steps={T_}", f"learner.batch_size={B_}", f"replay.size={SIZE}",
             f"learner.learner_steps={ls}", f"trainer.training_start_steps={START}", f"learner.target_update_freq={TFREQ}", f"learner.n_step_q={n_step}",
             f"learner.double_q={str(double_q).lower()}", f"replay.policy={policy}", f"replay.sumtree={str(sumtree).lower()}", "trainer.exploration_steps=100",
-            f"trainer.total_steps={total}", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs"]
+            f"trainer.total_steps={total}", "wandb=false", "tb=false", "logdir=gpurun_out/test_logs", f"env_task={env_task}"]
     spec = recipe.SPECS[spec_name or algo]
     if spec.action_dim == 9:
         over.append("env_id=Asterix")                    # nine actions (BASELINE configs[3])
@@ -90,7 +90,7 @@ def _build(algo, policy, sumtree, n_step, double_q, launch, ls=None, spec_name=N
     ora = OracleTrainer(spec, sd, num_envs=E_, sample_steps=T_, batch_size=B_, replay_size=SIZE, learner_steps=ls, training_start_steps=START, policy=policy,
                         sumtree=sumtree, n_step=n_step, double_q=double_q, seed=cfg.seed, target_update_freq=TFREQ, total_steps=total, exploration_steps=100,
                         launch=launch, reset_noise_freq=cfg.learner.reset_noise_freq, actor_noise=(lambda: actor_q.pop(0)) if spec.noisy else None,
-                        learner_noise=(lambda: learner_box.pop(0)) if spec.noisy else None)
+                        learner_noise=(lambda: learner_box.pop(0)) if spec.noisy else None, env_task=env_task)
     ora._learner_box = learner_box
     return tr, ora, spec
 
@@ -317,9 +317,17 @@ def test_trainer_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_s
     _walk(algo, policy, sumtree, n_step, double_q, launch, spec_name, SMALL, 7)
 
 
-def _walk(algo, policy, sumtree, n_step, double_q, launch, spec_name, dims, iters, free_running=False):
+@pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,launch,spec_name", [CASES[1], CASES[7], CASES[8], CASES[11]])
+def test_trainer_loop_on_the_learnable_block_task(algo, policy, sumtree, n_step, double_q, launch, spec_name):
+    """The same walk on ``env_task=block`` (rewards depend on the actions just chosen; what tests/test_gpu_learning.py trains on): scalar, distributional
+    and quantile actor tails, n-step 1 and 3, both schedules."""
+    ls = _walk(algo, policy, sumtree, n_step, double_q, launch, spec_name, SMALL, 7, env_task="block")
+    assert float(ls.rp.rew.abs().sum()) > 0
+
+
+def _walk(algo, policy, sumtree, n_step, double_q, launch, spec_name, dims, iters, free_running=False, env_task="stream"):
     E_, T_, B_, SIZE, LSTEPS, START, TFREQ = dims
-    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch, spec_name=spec_name, dims=dims)
+    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, launch, spec_name=spec_name, dims=dims, env_task=env_task)
     ls = LockStep(tr, ora, spec, tfreq=TFREQ, free_running=free_running)
     loose = free_running or spec.algo == "fqf"
     for it in range(iters):

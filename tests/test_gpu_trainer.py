@@ -25,12 +25,17 @@ def make_cfg(algo="dqn", E=4, **kw):
 ROLLOUT_SPECS = dict(recipe.SPECS, fqf4=recipe.NetSpec("fqf", 4))
 
 
-@pytest.mark.parametrize("n_step,spec_name", [(1, "dqn"), (3, "dqn"), (1, "dqn_duel"), (3, "c51"), (1, "qr"), (1, "iqn_duel"), (3, "iqn_duel"), (3, "fqf4")])
-def test_actor_rollout_matches_oracle(n_step, spec_name):
+@pytest.mark.parametrize("n_step,spec_name,task", [(1, "dqn", "stream"), (3, "dqn", "stream"), (1, "dqn_duel", "stream"), (3, "c51", "stream"), (1, "qr", "stream"),
+                                                  (1, "iqn_duel", "stream"), (3, "iqn_duel", "stream"), (3, "fqf4", "stream"),
+                                                  (3, "dqn", "block"), (1, "dqn_duel", "block"), (3, "c51", "block"), (1, "iqn_duel", "block"), (3, "fqf4", "block"),
+                                                  (3, "dqn", "block-unmerged")])
+def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the distributional tail, iqn / fqf the quantile tail (head GEMM slabs ->
     bias, dueling per quantile, mean / fraction-weighted sum, argmax, epsilon-greedy), each in one launch with the env step
     (a0_actor_qhead_env_step / a0_actor_dist_tail_env_step / a0_actor_quantile_tail_env_step).  IQN draws K = 32 fresh taus per env and step (model.py:238, agent.py:25-28) from the actor's Philox tau stream — the
-    oracle gets the same draws through ``taus_fn`` — and under hipGraph replay their offsets come from the device control block."""
+    oracle gets the same draws through ``taus_fn`` — and under hipGraph replay their offsets come from the device control block.
+    ``task=block``: the learnable reward task (the reward depends on the action the tail has just chosen: the three merged kernels and, ``block-unmerged``,
+    a0_env_synth_step_commit behind a separate tail)."""
     from agent0_amd.deepq.agent import Actor
     from agent0_amd.deepq.model import DeepQNet
     from agent0_amd.deepq.replay import ReplayDataset
@@ -38,7 +43,10 @@ def test_actor_rollout_matches_oracle(n_step, spec_name):
 
     E, T = 4, 12
     spec = ROLLOUT_SPECS[spec_name]
-    cfg = make_cfg(spec.algo, E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8,
+    if task == "block-unmerged":
+        monkeypatch.setenv("A0_TAIL_ENV", "0")
+        task = "block"
+    cfg = make_cfg(spec.algo, E, **{"env_task": task, "learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8,
                                      "learner.dueling_head": str(bool(spec.dueling)).lower(), **({"learner.qr.num_atoms": spec.num_atoms} if spec.algo == "qr" else {})})
     model = DeepQNet(cfg)
     sd = recipe.make_state_dict(spec, 11)
@@ -66,7 +74,7 @@ def test_actor_rollout_matches_oracle(n_step, spec_name):
         tau_call[0] += 1
         return torch.from_numpy(core.rng_uniform(seed64, DeviceRng.STREAM_TAUS, off, n).reshape(E_, K, 1))
 
-    env = core.SynthVecEnv(E, seed=cfg.seed, rank=0)
+    env = core.SynthVecEnv(E, seed=cfg.seed, rank=0, action_dim=4, task=task)
     ora = oactor.OracleActor(env, olearner.to_params(sd), spec, n_step=n_step, sample_steps=6, draw=draw, taus_fn=taus_fn if spec.algo == "iqn" else None)
     eps = np.float32(0.35)
     for call in range(6):           # calls 0-1 run eagerly, call 2 captures the rollout into a hipGraph, calls 3-5 replay it

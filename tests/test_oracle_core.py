@@ -139,3 +139,34 @@ def test_synth_env_contract():
     env4.reset()
     c = [env4.step(np.zeros(6))[1] for _ in range(50)]
     assert np.array_equal(np.stack(a), np.stack(c)) and not np.array_equal(np.stack(a), np.stack(b))
+
+
+@pytest.mark.parametrize("A", [4, 9, 18])
+def test_synth_env_block_task_is_readable_from_the_pixels(A):
+    """``task="block"`` (the learnable reward task): the rewarded action is the quadrant (mod A) of the bright 8x8 block in the NEWEST frame of the observation
+    the action is chosen on — located here from the pixels alone — the next class costs -1, everything else 0; terminals are those of the stream task."""
+    E = 6
+    env = core.SynthVecEnv(E, seed=42, rank=0, action_dim=A, task="block")
+    ref = core.SynthVecEnv(E, seed=42, rank=0, action_dim=A)
+    obs, _ = env.reset()
+    ref.reset()
+    terms = core.env_terminals(42, 0, E, 80)
+    for t in range(1, 81):
+        tgt = []
+        for e in range(E):
+            fr = obs[e, 3]
+            solid = [(y, x) for y in range(77) for x in range(77) if fr[y, x] == 255 and (fr[y:y + 8, x:x + 8] == 255).all()]
+            assert len(solid) >= 1
+            y, x = solid[0]
+            tgt.append((2 * (y >= 39) + (x >= 39)) % A)
+        tgt = np.array(tgt)
+        assert np.array_equal(tgt, core.env_block_target(np.arange(E), np.full(E, t - 1), A))
+        a = (tgt + np.arange(E) % 3) % A
+        obs, r, term, trunc, info = env.step(a)
+        want = np.where(np.arange(E) % 3 == 0, 1.0, np.where(np.arange(E) % 3 == 1, -1.0, 0.0))
+        if A == 1:
+            want[:] = 1.0
+        assert np.array_equal(r, want)
+        o2, r2, term2, _, info2 = ref.step(a)
+        assert np.array_equal(obs, o2) and np.array_equal(term, term2) and np.array_equal(info["life_loss"], info2["life_loss"])
+        assert np.array_equal(term, terms[t - 1])
