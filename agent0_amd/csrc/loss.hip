@@ -231,21 +231,76 @@ struct a0_dtenv_args {
     int kt;                  // 1: quantile networks (iqn / fqf) — the head's rows are (env, quantile), its columns the actions (+ value): element (a, t) of env e at
                              //    slabs[(e * T + t) * ld + a], bias per column; 0: distributional heads (c51 / qr) — one row per env, columns (a, t)
     int task;                // synthetic env's reward task (A0_ENV_TASK_*)
+    int vec4;                // kt == 0 and rows / slabs / bias 16-byte aligned: the slab sum runs 16 bytes wide over the padded row
     const float* taus;       // mode 3 (fqf): [E][T + 1] fraction boundaries, value(a) = sum_t (tau[t + 1] - tau[t]) q(t, a)  (== a0_select_action_kernel mode 3)
 };
-__global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_args P) {
-    extern __shared__ float xs[];                        // [A*T + T] head outputs of this env
+// Round 4: EIGHT waves, no workgroup barrier.  Wave 0 is the tail alone (it sums the head's slabs for itself: for row-per-env heads 16 bytes per lane and slab
+// over the padded row, all slabs requested before any is added), waves 1-7 are 448 lanes for the 441 sixteen-byte groups of a frame, each issuing its four
+// loads and twelve stores once and at once (was: 256 lanes, two or three trips, wave 0 joining after the tail; 16.4 us -> profiles/r04_experiments.md).
+__global__ __launch_bounds__(512) void a0_actor_dist_tail_env_kernel(a0_dtenv_args P) {
+    extern __shared__ float xs[];                        // [max(A*T + T, ld)] head outputs of this env
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t e = blockIdx.x;
     const int A = P.A, T = P.T, NC = A * T + (P.dueling ? T : 0);
     uint32_t g = P.g; long long start = P.start;
     if (P.ctrl) { g += (uint32_t)P.ctrl[A0_CTRL_ENV_STEP]; start += P.ctrl[A0_CTRL_REPLAY_SLOT]; }
     const long long slot = (start + e) % P.cap;
-    const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
+    // the env's Philox draws on the VECTOR unit (every lane the same): on uniform inputs the compiler runs the ten rounds on the scalar unit and keeps their
+    // partial products in scalar registers for the rest of the kernel (the source of its scalar-register spills)
+    uint32_t e_v = e;
+    asm volatile("" : "+v"(e_v));
+    const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
     const bool term = (x.y % 500u) == 0u;
-    // head output = slab sum in slab order + bias: column c by thread c, c + 256, ... (all slabs of a column requested before any is added)
+    if (wave != 0) {
+        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448);
+        return;
+    }
+    // everything the env's scalar work will need from memory is requested now, ahead of the slab loads: the control words, epsilon, the env's running
+    // return and the n-step ring's previous entries (a0_env_commit_prefetch) — the arithmetic behind the action then never waits for memory again
+    long long steps = P.steps; unsigned long long off_a = P.off_a, off_u = P.off_u; float eps = P.eps;
+    if (P.ctrl) { steps += P.ctrl[A0_CTRL_ACTOR_STEPS]; off_a += (unsigned long long)P.ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)P.ctrl[A0_CTRL_RNG_UNIFORM]; }
+    if (P.eps_ptr) eps = P.eps_ptr[0];
+    a0_env_pre Z;
+    a0_env_commit_prefetch(Z, e, P.E, P.n, steps, P.ep_ret, P.ring_act, P.ring_rew, P.ring_done);
+    a0_env_pre_to_vgpr(Z);
+    const a0_env_out O = a0_env_out_vgpr(P.ep_ret, P.final_mask, P.final_ret, P.ring_act, P.ring_rew, P.ring_done, P.r_act, P.r_rew, P.r_done);
+    A0_TO_VGPR(steps); A0_TO_VGPR(off_a); A0_TO_VGPR(off_u); A0_TO_VGPR(eps);
+    int n_v = P.n, E_v = P.E, task_v = P.task; double gamma_v = P.gamma; unsigned long long seed_v = P.rng_seed; uint32_t sa_v = P.stream_a, su_v = P.stream_u;
+    int* action_v = P.action; float* qmax_v = P.qmax;
+    A0_TO_VGPR(n_v); A0_TO_VGPR(E_v); A0_TO_VGPR(task_v); A0_TO_VGPR(gamma_v); A0_TO_VGPR(seed_v); A0_TO_VGPR(sa_v); A0_TO_VGPR(su_v); A0_TO_VGPR(action_v); A0_TO_VGPR(qmax_v);
+    // head output = slab sum in slab order + bias (all slabs of a column requested before any is added)
     const float* sp = P.slabs + (long long)e * (P.kt ? (long long)T * P.ld : (long long)P.ld);
-    for (int c = threadIdx.x; c < NC; c += 256) {
+    if (P.vec4) {
+        // 16 bytes per lane and slab: one padded row per env (kt = 0), or the env's T rows of ld columns, one contiguous block (kt = 1: stored transposed
+        // into the (a, t) order the tail reads); the pad columns are summed too and never read
+        const int ld4 = P.ld >> 2, n4 = P.kt ? T * ld4 : ld4;
+        const long long st4 = P.slab_stride >> 2;
+        for (int c4 = lane; c4 < n4; c4 += 64) {
+            const a0_f4* p4 = (const a0_f4*)sp + c4;
+            a0_f4 acc = a0_zero4();
+            for (int z = 0; z < P.nslab; z += 8) {
+                a0_f4 t[8];
+#pragma unroll
+                for (int zz = 0; zz < 8; ++zz) t[zz] = (z + zz < P.nslab) ? p4[(long long)(z + zz) * st4] : a0_zero4();
+#pragma unroll
+                for (int zz = 0; zz < 8; ++zz)
+                    if (z + zz < P.nslab) { acc.x += t[zz].x; acc.y += t[zz].y; acc.z += t[zz].z; acc.w += t[zz].w; }
+            }
+            if (!P.kt) {
+                const a0_f4 bv = ((const a0_f4*)P.bias)[c4];            // the bias block is ld long for row-per-env heads
+                acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+                ((a0_f4*)xs)[c4] = acc;
+                continue;
+            }
+            const int q = c4 / ld4, a0 = 4 * (c4 - q * ld4);
+            const int NQ = A + (P.dueling ? 1 : 0);
+            if (a0 < NQ) xs[a0 * T + q] = acc.x + P.bias[a0];
+            if (a0 + 1 < NQ) xs[(a0 + 1) * T + q] = acc.y + P.bias[a0 + 1];
+            if (a0 + 2 < NQ) xs[(a0 + 2) * T + q] = acc.z + P.bias[a0 + 2];
+            if (a0 + 3 < NQ) xs[(a0 + 3) * T + q] = acc.w + P.bias[a0 + 3];
+        }
+    } else
+    for (int c = lane; c < NC; c += 64) {
         int src = c, col = c;
         if (P.kt) { const int a = c / T, q = c - a * T; src = q * P.ld + a; col = a; }      // LDS keeps the (a, t) order either way
         float acc = 0.f;
@@ -259,8 +314,11 @@ __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
         }
         xs[c] = acc + P.bias[col];
     }
-    __syncthreads();
-    if (wave == 0) {
+    // one wave: its LDS writes above are ordered before its LDS reads below (in-order LDS queue); the fences keep the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
         if (P.dueling) {
             for (int t = lane; t < T; t += 64) {
                 float s = 0.f;
@@ -305,23 +363,14 @@ __global__ __launch_bounds__(256) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
             if (a == 0 || v > best) { best = v; besta = a; }   // first maximum wins, like torch.argmax on CPU
         }
         if (lane == 0) {
-            // one lane from here on: its many scalar arguments (streams, offsets, ring pointers, ...) are read through a VECTOR pointer to the
-            // kernel-argument block, so that they do not all have to be live in scalar registers next to the frame loop's
-            const a0_dtenv_args* Q = (const a0_dtenv_args*)__builtin_amdgcn_kernarg_segment_ptr();      // P is this kernel's only argument: offset 0
-            asm volatile("" : "+v"(Q));
-            long long steps = Q->steps; unsigned long long off_a = Q->off_a, off_u = Q->off_u; float eps = Q->eps;
-            const long long* ctrl = Q->ctrl;
-            if (ctrl) { steps += ctrl[A0_CTRL_ACTOR_STEPS]; off_a += (unsigned long long)ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)ctrl[A0_CTRL_RNG_UNIFORM]; }
-            if (Q->eps_ptr) eps = Q->eps_ptr[0];
-            const int ra = (int)(a0_philox_word(Q->rng_seed, Q->stream_a, off_a + (unsigned long long)e) % (uint32_t)A);
-            const float u = (float)(a0_philox_word(Q->rng_seed, Q->stream_u, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
+            const int ra = (int)(a0_philox_word(seed_v, sa_v, off_a + (unsigned long long)e) % (uint32_t)A);
+            const float u = (float)(a0_philox_word(seed_v, su_v, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
             const int act = (u > eps) ? besta : ra;
-            Q->action[e] = act; Q->qmax[e] = best;
-            a0_env_commit_scalars(x, e, g, Q->task, A, Q->E, Q->n, steps, Q->gamma, act, Q->ep_ret, Q->final_mask, Q->final_ret, Q->ring_act, Q->ring_rew, Q->ring_done, Q->r_act, Q->r_rew,
-                                  Q->r_done, slot);
+            action_v[e] = act; qmax_v[e] = best;
+            a0_env_commit_finish(Z, x, e, g, task_v, A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
+                                 O.r_done, slot);
         }
     }
-    a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), threadIdx.x, 256);
 }
 
 extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
@@ -337,7 +386,8 @@ extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_st
         !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
         return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad env argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: buffers must be 16-byte aligned");
-    const size_t lds = (size_t)(A * T + T) * sizeof(float);
+    const bool vec4 = !(ld & 3) && !(slab_stride & 3) && !((((uintptr_t)slabs) | ((uintptr_t)bias)) & 15);
+    const size_t lds = (size_t)((A * T + T) > ld || !vec4 ? (A * T + T) : ld) * sizeof(float);
     if (lds > 160 * 1024) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: head too wide for LDS");
     static size_t configured = 0;
     if (lds > configured) {
@@ -352,8 +402,8 @@ extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_st
     P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
     P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
-    P.kt = 0; P.taus = nullptr;
-    hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
+    P.kt = 0; P.taus = nullptr; P.vec4 = vec4 ? 1 : 0;
+    hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(512), lds, (hipStream_t)stream, P);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail_env_step");
 }
 
@@ -385,7 +435,8 @@ extern "C" int a0_actor_quantile_tail_env_step(const float* slabs, long long sla
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
     P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
     P.kt = 1; P.taus = taus;
-    hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(256), lds, (hipStream_t)stream, P);
+    P.vec4 = (!(ld & 3) && !(slab_stride & 3) && !((((uintptr_t)slabs) | ((uintptr_t)bias)) & 15)) ? 1 : 0;
+    hipLaunchKernelGGL(a0_actor_dist_tail_env_kernel, dim3(E), dim3(512), lds, (hipStream_t)stream, P);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_quantile_tail_env_step");
 }
 
@@ -813,6 +864,227 @@ extern "C" int a0_loss_c51(const float* logits, const float* tgt_logits, int A, 
     hipLaunchKernelGGL(a0_c51_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, tgt_logits, A, T, act, a_star, rew, done, wgt,
                        atoms, gamma_n, vmin, vmax, delta, B, loss, dlogits, m_out, nan_flag);
     return a0_fail_hip((int)hipGetLastError(), "a0_loss_c51");
+}
+
+// ------------------------------------------------------------------------------------------------ C51: head tail + loss from the head GEMMs' slabs
+// Round 4.  C51Learner.train_step (reference agent.py:219-269) from the head GEMMs on, in ONE launch: the online head GEMM over [s ; s'] rows (s' only
+// under double-Q) and the target head GEMM over s' leave their split-K slabs (a0_dense_fwd_partial); per sample one wave
+//   sums them in slab order and adds the bias                                    (== a0_reduce_bias_act_kernel, three times)
+//   applies the dueling combine per atom                                         (== a0_dueling_fwd_kernel, three times; model.py:163-177)
+//   takes the expectation under softmax and its first maximum                    (== a0_select_action_kernel mode 2; agent.py:225-231)
+//   projects the target distribution at that action and takes the cross entropy  (== a0_c51_loss_kernel; agent.py:233-267)
+//   forms d loss / d logits and carries it back through the dueling combine      (== a0_dueling_bwd_kernel)
+// — nine launches of ~5 us of latency each — statement for statement the same arithmetic, so the update's numbers do not change.  Four samples per
+// workgroup; the workgroup first stages the 3 x (A + 1) x T head outputs of its samples in LDS (every thread a few columns, all slabs of a column
+// requested before any is added), then each wave works on its sample with one lane per atom.
+struct a0_c51hl_args {
+    const float* s_on; long long stride_on; int nslab_on;      // online head slabs [nslab_on][R_on][ld]: rows [0, B) = s, rows [sel_off, sel_off + B) = s'
+    const float* s_tg; long long stride_tg; int nslab_tg;      // target head slabs [nslab_tg][B][ld] on s'
+    int sel_off;                                               // < 0: no double-Q (the greedy next action comes from the target's own expectation)
+    const float *bias_on, *bias_tg; int ld, A, T, dueling;
+    const int* act; const float *rew, *done, *wgt, *atoms; float gamma_n, vmin, vmax, delta; int B;
+    float *loss, *draw, *q_on_out, *q_tg_out, *m_out; int* a_star_out; int* nan_flag;
+};
+__global__ __launch_bounds__(256) void a0_c51_head_loss_slabs_kernel(a0_c51hl_args P) {
+    extern __shared__ float xs[];                  // [4 samples][3 passes: online(s), target(s'), online(s')][ld]
+    __shared__ __attribute__((aligned(16))) int s_lo[4][64], s_up[4][64];
+    __shared__ __attribute__((aligned(16))) float s_wl[4][64], s_wu[4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int A = P.A, T = P.T, NQ = A + (P.dueling ? 1 : 0), NC = NQ * T, ld = P.ld;
+    const int b0 = blockIdx.x * 4;
+    // this wave's sample: its scalars are requested before the staging loads, so that nothing in the arithmetic below waits for memory again
+    const int bme = (b0 + wave) < P.B ? b0 + wave : P.B - 1;
+    const int act_b = P.act[bme];
+    const float rew_b = P.rew[bme], done_b = P.done[bme], wgt_b = P.wgt[bme];
+    const float atom = lane < T ? P.atoms[lane] : 0.f;
+    // staging: 16 bytes per lane and slab over the padded row (ld columns: the pad columns are summed too and never read), two row pieces x eight slabs
+    // requested before anything is added — ~2 us of L2 / MALL latency per dependent batch is what this phase costs, so it is cut to two or three batches
+    const int npass = P.sel_off < 0 ? 2 : 3;
+    const int ld4 = ld >> 2, per = 4 * ld4, total = npass * per;
+    for (int it0 = threadIdx.x; it0 < total; it0 += 512) {
+        a0_f4 t[2][8];
+        int ns[2], dst[2];
+        const a0_f4* bp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = it0 + 256 * u;
+            const bool valid = it < total;
+            const int p = valid ? it / per : 0, r = valid ? it - p * per : 0;
+            const int sidx = r / ld4, c4 = r - sidx * ld4;
+            int b = b0 + sidx;
+            b = b < P.B ? b : P.B - 1;
+            const float* base = (p == 1) ? P.s_tg : P.s_on;
+            const long long st4 = ((p == 1) ? P.stride_tg : P.stride_on) >> 2;
+            ns[u] = valid ? ((p == 1) ? P.nslab_tg : P.nslab_on) : 0;
+            const a0_f4* sp = (const a0_f4*)(base + (long long)(((p == 2) ? P.sel_off : 0) + b) * ld) + c4;
+            bp[u] = (const a0_f4*)((p == 1) ? P.bias_tg : P.bias_on) + c4;
+            dst[u] = (sidx * 3 + p) * ld + 4 * c4;
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) t[u][zz] = (zz < ns[u]) ? sp[(long long)zz * st4] : a0_zero4();
+            // more than eight slabs (never the case for a 512-deep head): the rest joins slab by slab below
+            if (ns[u] > 8) {
+                a0_f4 acc = a0_zero4();
+#pragma unroll
+                for (int zz = 0; zz < 8; ++zz) { acc.x += t[u][zz].x; acc.y += t[u][zz].y; acc.z += t[u][zz].z; acc.w += t[u][zz].w; }
+                for (int z = 8; z < ns[u]; ++z) { const a0_f4 v = sp[(long long)z * st4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+                t[u][0] = acc;
+                ns[u] = 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (it0 + 256 * u >= total) continue;
+            a0_f4 acc = a0_zero4();
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+                if (zz < ns[u]) { acc.x += t[u][zz].x; acc.y += t[u][zz].y; acc.z += t[u][zz].z; acc.w += t[u][zz].w; }
+            const a0_f4 bv = *bp[u];
+            acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+            *(a0_f4*)(xs + dst[u]) = acc;
+        }
+    }
+    __syncthreads();
+    const int b = b0 + wave;
+    if (b >= P.B) return;
+    float* X = xs + (long long)wave * 3 * ld;      // pass p of this wave's sample at X + p * ld
+    const int t = lane;
+    const bool on = t < T;
+    if (P.dueling && on) {
+        for (int p = 0; p < npass; ++p) {
+            float* x = X + p * ld;
+            float s = 0.f;
+#pragma unroll 4
+            for (int a = 0; a < A; ++a) s += x[a * T + t];
+            const float mean = s / (float)A;
+            const float v = x[A * T + t];
+#pragma unroll 4
+            for (int a = 0; a < A; ++a) x[a * T + t] = v + (x[a * T + t] - mean);
+        }
+    }
+    // each lane reads back only what it wrote itself (column t of every action), so no fence is needed up to here
+    if (on) {
+        if (P.q_on_out) for (int a = 0; a < A; ++a) P.q_on_out[((long long)b * A + a) * T + t] = X[a * T + t];
+        if (P.q_tg_out) for (int a = 0; a < A; ++a) P.q_tg_out[((long long)b * A + a) * T + t] = X[ld + a * T + t];
+    }
+    // greedy next action: expectation of the selecting network's distribution, first maximum (a0_select_action_kernel, mode 2)
+    const float* xsel = X + (P.sel_off < 0 ? 1 : 2) * ld;
+    float best = 0.f;
+    int a_star = 0;
+    for (int a = 0; a < A; ++a) {
+        const float xv = on ? xsel[a * T + t] : -INFINITY;
+        const float mx = a0_wave_max(xv);
+        float se = 0.f, sz = 0.f;
+        if (on) {
+            const float ex = expf(xv - mx);
+            se += ex;
+            sz += ex * atom;
+        }
+        se = a0_wave_sum(se);
+        sz = a0_wave_sum(sz);
+        const float v = sz / se;
+        if (a == 0 || v > best) { best = v; a_star = a; }
+    }
+    if (P.a_star_out && lane == 0) P.a_star_out[b] = a_star;
+    // projection of the target distribution at a* (a0_c51_loss_kernel)
+    const float xt = on ? X[ld + a_star * T + t] : -INFINITY;
+    const float mxt = a0_wave_max(xt);
+    const float et = on ? expf(xt - mxt) : 0.f;
+    const float pr = et / a0_wave_sum(et);
+    float tz = rew_b + (P.gamma_n * (1.f - done_b)) * atom;
+    tz = fminf(fmaxf(tz, P.vmin), P.vmax);
+    const float bp = (tz - P.vmin) / P.delta;
+    int lo = (int)floorf(bp), up = (int)ceilf(bp);
+    if (up > 0 && lo == up) lo -= 1;
+    if (lo < T - 1 && lo == up) up += 1;
+    s_lo[wave][t] = on ? lo : -1;
+    s_up[wave][t] = on ? up : -1;
+    s_wl[wave][t] = pr * ((float)up - bp);
+    s_wu[wave][t] = pr * (bp - (float)lo);
+    // one wave: its LDS writes above are ordered before its LDS reads below (in-order LDS queue); the fences keep the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float m = 0.f;
+    if (on) {
+        // ascending atom order, as in a0_c51_loss_kernel; four table entries per LDS read (entries k >= T hold -1 and never match)
+        const int4* lo4 = (const int4*)s_lo[wave];
+        const int4* up4 = (const int4*)s_up[wave];
+        const a0_f4* wl4 = (const a0_f4*)s_wl[wave];
+        const a0_f4* wu4 = (const a0_f4*)s_wu[wave];
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4)
+            if (4 * k4 < T) {
+                const int4 L = lo4[k4]; const a0_f4 Wv = wl4[k4];
+                if (L.x == t) m += Wv.x;
+                if (L.y == t) m += Wv.y;
+                if (L.z == t) m += Wv.z;
+                if (L.w == t) m += Wv.w;
+            }
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4)
+            if (4 * k4 < T) {
+                const int4 U = up4[k4]; const a0_f4 Wv = wu4[k4];
+                if (U.x == t) m += Wv.x;
+                if (U.y == t) m += Wv.y;
+                if (U.z == t) m += Wv.z;
+                if (U.w == t) m += Wv.w;
+            }
+    }
+    if (P.m_out && on) P.m_out[(long long)b * T + t] = m;
+    const int a = act_b;
+    const float xo = on ? X[a * T + t] : -INFINITY;
+    const float mxo = a0_wave_max(xo);
+    const float eo = on ? expf(xo - mxo) : 0.f;
+    const float so = a0_wave_sum(eo);
+    const float logp = xo - mxo - logf(so);
+    const float l = -a0_wave_sum(on ? m * logp : 0.f);
+    const float msum = a0_wave_sum(m);
+    if (lane == 0) {
+        P.loss[b] = l;
+        if (l != l) atomicOr(P.nan_flag, 1);
+    }
+    // d loss / d logits at the taken action, back through the dueling combine (a0_dueling_bwd_kernel), straight into the head GEMM's output gradient
+    float* o = P.draw + (long long)b * ld;
+    if (on) {
+        const float g = wgt_b * ((eo / so) * msum - m);
+        float sdl = 0.f;
+        for (int k = 0; k < A; ++k) sdl += (k == a) ? g : 0.f;
+        for (int k = 0; k < A; ++k) {
+            float out = (k == a) ? g : 0.f;
+            if (P.dueling) out -= sdl / (float)A;
+            o[k * T + t] = out;
+        }
+        if (P.dueling) o[A * T + t] = sdl;
+    }
+    for (int c = NC + lane; c < ld; c += 64) o[c] = 0.f;
+}
+
+extern "C" int a0_c51_head_loss_slabs(const float* slabs_on, long long stride_on, int nslab_on, int rows_on, const float* slabs_tg, long long stride_tg, int nslab_tg,
+                                      int sel_off, const float* bias_on, const float* bias_tg, int ld, int A, int T, int dueling, const int* act, const float* rew,
+                                      const float* done, const float* wgt, const float* atoms, float gamma_n, float vmin, float vmax, int B, float* loss, float* draw,
+                                      float* q_on_out, float* q_tg_out, float* m_out, int* a_star_out, int* nan_flag, void* stream) {
+    const int NQ = A + (dueling ? 1 : 0);
+    if (!slabs_on || !slabs_tg || !bias_on || !bias_tg || !act || !rew || !done || !wgt || !atoms || !loss || !draw || !nan_flag || B < 1 || A < 1 || T < 2 || T > 64 ||
+        ld < NQ * T || nslab_on < 1 || nslab_tg < 1 || rows_on < B || stride_on < (long long)rows_on * ld || stride_tg < (long long)B * ld ||
+        (sel_off >= 0 && (sel_off < B || sel_off + B > rows_on)))
+        return a0_fail(A0_EINVAL, "a0_c51_head_loss_slabs: bad argument (2 <= num_atoms <= 64; the s' rows of the online slabs must lie behind the s rows)");
+    const size_t lds = (size_t)4 * 3 * ld * sizeof(float);
+    if (lds > 150 * 1024) return a0_fail(A0_EINVAL, "a0_c51_head_loss_slabs: head too wide for LDS");
+    if ((ld & 3) || (stride_on & 3) || (stride_tg & 3) || ((((uintptr_t)slabs_on) | ((uintptr_t)slabs_tg) | ((uintptr_t)bias_on) | ((uintptr_t)bias_tg)) & 15))
+        return a0_fail(A0_EINVAL, "a0_c51_head_loss_slabs: slabs and biases must be 16-byte aligned, ld and the slab strides multiples of 4 floats");
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_c51_head_loss_slabs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_c51_head_loss_slabs: LDS");
+        configured = lds;
+    }
+    a0_c51hl_args P;
+    P.s_on = slabs_on; P.stride_on = stride_on; P.nslab_on = nslab_on; P.s_tg = slabs_tg; P.stride_tg = stride_tg; P.nslab_tg = nslab_tg; P.sel_off = sel_off;
+    P.bias_on = bias_on; P.bias_tg = bias_tg; P.ld = ld; P.A = A; P.T = T; P.dueling = dueling; P.act = act; P.rew = rew; P.done = done; P.wgt = wgt; P.atoms = atoms;
+    P.gamma_n = gamma_n; P.vmin = vmin; P.vmax = vmax; P.delta = (float)(((double)vmax - (double)vmin) / (double)(T - 1)); P.B = B;
+    P.loss = loss; P.draw = draw; P.q_on_out = q_on_out; P.q_tg_out = q_tg_out; P.m_out = m_out; P.a_star_out = a_star_out; P.nan_flag = nan_flag;
+    hipLaunchKernelGGL(a0_c51_head_loss_slabs_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, P);
+    return a0_fail_hip((int)hipGetLastError(), "a0_c51_head_loss_slabs");
 }
 
 // ------------------------------------------------------------------------------------------------ quantile Huber

@@ -51,6 +51,35 @@ __global__ void a0_reduce_bias_act_kernel(const float* __restrict__ slabs, long 
     }
 }
 
+// a0_reduce_bias_act_kernel for up to four layers of the same width in ONE launch (round 4: the three fc1 passes of a distributional update — online on s,
+// online on s', target on s' — each leave their own split-K slabs; their reductions are independent and each is a 4.7 us launch of pure latency on
+// its own).  Same arithmetic per element as the single-layer kernel: slabs added in slab order, eight requested at a time, then the bias, then the ReLU.
+struct a0_rba_seg { const float* slabs; long long slab_stride; int nslab; const float* bias; float* out; int rows; };
+struct a0_rba_multi_args { a0_rba_seg seg[4]; int n, N, relu; };
+__global__ __launch_bounds__(256) void a0_reduce_bias_act_multi_kernel(a0_rba_multi_args A) {
+    const int si = blockIdx.y;
+    const a0_rba_seg S = A.seg[si];
+    const int N4 = A.N >> 2;
+    const long long count4 = (long long)S.rows * N4, st4 = S.slab_stride >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
+        a0_f4 s = a0_zero4();
+        const a0_f4* p = (const a0_f4*)S.slabs + i;
+        for (int z = 0; z < S.nslab; z += 8) {
+            a0_f4 t[8];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) t[zz] = (z + zz < S.nslab) ? p[(long long)(z + zz) * st4] : a0_zero4();
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+                if (z + zz < S.nslab) { s.x += t[zz].x; s.y += t[zz].y; s.z += t[zz].z; s.w += t[zz].w; }
+        }
+        const a0_f4 b = ((const a0_f4*)S.bias)[i % N4];
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        if (A.relu) { s.x = s.x < 0.f ? 0.f : s.x; s.y = s.y < 0.f ? 0.f : s.y; s.z = s.z < 0.f ? 0.f : s.z; s.w = s.w < 0.f ? 0.f : s.w; }
+        ((a0_f4*)S.out)[i] = s;
+    }
+}
+
 // Up to four slab reductions in one launch: workgroup g serves 128 outputs of the segment its index falls into — 32 lanes x 16 bytes wide,
 // eight row groups striding over the slabs and combined in a fixed order through LDS (deterministic); a segment whose base, stride or
 // count is not a multiple of four floats takes the scalar path (32 outputs per workgroup).
@@ -423,6 +452,24 @@ static void a0_fc1_partial_launch(BK& bk, const a0_mat_src& a, const a0_mat_src&
     }
 }
 
+extern "C" int a0_reduce_bias_act_multi(int n, const float* const* slabs, const long long* slab_stride, const int* nslab, const float* const* bias, float* const* out,
+                                       const int* rows, int N, int relu, void* stream) {
+    if (n < 1 || n > 4 || !slabs || !slab_stride || !nslab || !bias || !out || !rows || N < 4 || (N & 3)) return a0_fail(A0_EINVAL, "a0_reduce_bias_act_multi: bad argument (1..4 layers, N a multiple of 4)");
+    a0_rba_multi_args A;
+    A.n = n; A.N = N; A.relu = relu;
+    int maxrows = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!slabs[i] || !bias[i] || !out[i] || rows[i] < 1 || nslab[i] < 1 || (slab_stride[i] & 3) || slab_stride[i] < (long long)rows[i] * N ||
+            ((((uintptr_t)slabs[i]) | ((uintptr_t)bias[i]) | ((uintptr_t)out[i])) & 15))
+            return a0_fail(A0_EINVAL, "a0_reduce_bias_act_multi: bad layer (16-byte aligned buffers, slab stride a multiple of 4 floats)");
+        A.seg[i] = a0_rba_seg{slabs[i], slab_stride[i], nslab[i], bias[i], out[i], rows[i]};
+        if (rows[i] > maxrows) maxrows = rows[i];
+    }
+    for (int i = n; i < 4; ++i) A.seg[i] = A.seg[0];
+    hipLaunchKernelGGL(a0_reduce_bias_act_multi_kernel, dim3(a0_grid_for((long long)maxrows * (N >> 2)), n), dim3(256), 0, (hipStream_t)stream, A);
+    return a0_fail_hip((int)hipGetLastError(), "a0_reduce_bias_act_multi");
+}
+
 extern "C" int a0_dense_fwd_partial_slabs(int R, int N, int K) {
     const int s = N <= 32 ? a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K) : a0_fc1_splits(R, N, K);
     return s < 1 ? 1 : s;
@@ -561,13 +608,15 @@ struct a0_qenv_args {
     int* r_act; float *r_rew, *r_done;
     int task;
 };
-__global__ __launch_bounds__(256) void a0_actor_qhead_env_kernel(a0_qenv_args P) {
+// Round 4: EIGHT waves.  Wave 0 is the tail alone (it also stages the head's rows for itself: no workgroup barrier anywhere in the kernel), waves 1-7 are 448
+// lanes for the 441 sixteen-byte groups of a frame: every lane issues its four loads and twelve stores ONCE and at once, instead of two or three trips of
+// 256 lanes that wave 0 joined only after the tail (11.1 -> see profiles/r04_experiments.md).
+__global__ __launch_bounds__(512) void a0_actor_qhead_env_kernel(a0_qenv_args P) {
     __shared__ float raw[64];
     extern __shared__ float w2s[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t e = blockIdx.x;
     const int NQ = P.A + (P.dueling ? 1 : 0);
-    for (int i = threadIdx.x; i < NQ * 128; i += 256) ((a0_f4*)w2s)[i] = ((const a0_f4*)P.W2)[i];
     uint32_t g = P.g; long long steps = P.steps, start = P.start; unsigned long long off_a = P.off_a, off_u = P.off_u; float eps = P.eps;
     if (P.ctrl) {
         g += (uint32_t)P.ctrl[A0_CTRL_ENV_STEP]; steps += P.ctrl[A0_CTRL_ACTOR_STEPS]; start += P.ctrl[A0_CTRL_REPLAY_SLOT];
@@ -575,19 +624,39 @@ __global__ __launch_bounds__(256) void a0_actor_qhead_env_kernel(a0_qenv_args P)
     }
     if (P.eps_ptr) eps = P.eps_ptr[0];
     const long long slot = (start + e) % P.cap;
-    const a0_u4 x = a0_philox4x32_10(e, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
+    // the env's Philox draws on the VECTOR unit (every lane the same): on uniform inputs the compiler runs the ten rounds on the scalar unit and keeps their
+    // partial products in scalar registers for the rest of the kernel (the source of its scalar-register spills)
+    uint32_t e_v = e;
+    asm volatile("" : "+v"(e_v));
+    const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
     const bool term = (x.y % 500u) == 0u;
-    __syncthreads();
-    if (wave == 0) {
+    if (wave != 0) {
+        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448);
+        return;
+    }
+    {
+        // the env's scalar work needs the running return and the n-step ring's previous entries: requested now, ahead of the head's loads
+        a0_env_pre Z;
+        a0_env_commit_prefetch(Z, e, P.E, P.n, steps, P.ep_ret, P.ring_act, P.ring_rew, P.ring_done);
+        a0_env_pre_to_vgpr(Z);
+        const a0_env_out O = a0_env_out_vgpr(P.ep_ret, P.final_mask, P.final_ret, P.ring_act, P.ring_rew, P.ring_done, P.r_act, P.r_rew, P.r_done);
+        A0_TO_VGPR(steps); A0_TO_VGPR(off_a); A0_TO_VGPR(off_u); A0_TO_VGPR(eps);
+        int n_v = P.n, E_v = P.E, task_v = P.task; double gamma_v = P.gamma; int* action_v = P.action; float* qmax_v = P.qmax;
+        A0_TO_VGPR(n_v); A0_TO_VGPR(E_v); A0_TO_VGPR(task_v); A0_TO_VGPR(gamma_v); A0_TO_VGPR(action_v); A0_TO_VGPR(qmax_v);
+#pragma unroll 4
+        for (int i = lane; i < NQ * 128; i += 64) ((a0_f4*)w2s)[i] = ((const a0_f4*)P.W2)[i];
+        // one wave: its LDS writes above are ordered before its LDS reads below (in-order LDS queue); the fences keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int act = 0; float best = 0.f;
         a0_qhead_wave(P.slabs, P.slab_stride, P.nslab, P.b1, w2s, P.b2, P.A, P.dueling, (int)e, lane, raw, P.rng_seed, P.stream_a, P.stream_u, off_a, off_u, eps, act, best);
         if (lane == 0) {
-            P.action[e] = act; P.qmax[e] = best;
-            a0_env_commit_scalars(x, e, g, P.task, P.A, P.E, P.n, steps, P.gamma, act, P.ep_ret, P.final_mask, P.final_ret, P.ring_act, P.ring_rew, P.ring_done, P.r_act, P.r_rew,
-                                  P.r_done, slot);
+            action_v[e] = act; qmax_v[e] = best;
+            a0_env_commit_finish(Z, x, e, g, task_v, P.A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
+                                 O.r_done, slot);
         }
     }
-    a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), threadIdx.x, 256);
 }
 
 extern "C" long long a0_actor_qhead_scratch(int E, int K) {
@@ -642,7 +711,7 @@ extern "C" int a0_actor_qhead_env_step(const float* feat, int E, int K, const fl
     P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
     P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
     P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
-    hipLaunchKernelGGL(a0_actor_qhead_env_kernel, dim3(E), dim3(256), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, P);
+    hipLaunchKernelGGL(a0_actor_qhead_env_kernel, dim3(E), dim3(512), (size_t)(A + (dueling ? 1 : 0)) * 512 * sizeof(float), (hipStream_t)stream, P);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
     A0_CATCH

@@ -39,45 +39,102 @@ A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix)
 }
 
 
-// n-step bookkeeping of one env and step (a0_nstep_kernel; truncated is always 0 for this env) and the emitted transition's (a, R, D)
-A0_D void a0_env_nstep_row(uint32_t e, int E, int n, long long steps, double gamma, float r, bool done, int a_now, int* __restrict__ ring_act,
-                           float* __restrict__ ring_rew, float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew,
-                           float* __restrict__ r_done, long long slot) {
+// n-step bookkeeping of one env and step (a0_nstep_kernel; truncated is always 0 for this env) and the emitted transition's (a, R, D).
+// Split in two so that a fused kernel can request everything this needs from memory EARLY (a0_env_commit_prefetch: the env's running return, the ring
+// entries of the previous n - 1 steps, the oldest action) and do the arithmetic once the action is known (a0_env_commit_finish) without waiting for
+// memory again; a0_env_commit_scalars is the two back to back.  Up to eight ring entries are prefetched, deeper n-step windows load the rest in the loop.
+struct a0_env_pre { float ep_prev; float dk[8], rk[8]; int act_old, count; };
+
+A0_D void a0_env_commit_prefetch(a0_env_pre& Z, uint32_t e, int E, int n, long long steps, const float* __restrict__ ep_ret, const int* __restrict__ ring_act,
+                                 const float* __restrict__ ring_rew, const float* __restrict__ ring_done) {
+    const long long have = steps + 1;
+    Z.count = have < n ? (int)have : n;
+    Z.ep_prev = ep_ret[e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        Z.dk[k] = 0.f; Z.rk[k] = 0.f;
+        if (k < Z.count) {
+            const int idx = (int)(((steps - k) % n + n) % n);
+            Z.dk[k] = ring_done[(long long)idx * E + e];
+            Z.rk[k] = ring_rew[(long long)idx * E + e];
+        }
+    }
+    Z.dk[0] = 0.f; Z.rk[0] = 0.f;
+    const int oldest = (int)(((steps - (Z.count - 1)) % n + n) % n);
+    Z.act_old = (Z.count > 1) ? ring_act[(long long)oldest * E + e] : 0;      // a slot other than the one this step writes (count <= n)
+}
+
+// The prefetched values and the pointers of the scalar work are wave-uniform, so the compiler keeps them in SCALAR registers from the prefetch to the end of
+// the kernel — more than there are; moved to vector registers (of which these kernels use a third) they cost nothing.
+#define A0_TO_VGPR(x) asm volatile("" : "+v"(x))
+A0_D void a0_env_pre_to_vgpr(a0_env_pre& Z) {
+    A0_TO_VGPR(Z.ep_prev); A0_TO_VGPR(Z.act_old); A0_TO_VGPR(Z.count);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { A0_TO_VGPR(Z.dk[k]); A0_TO_VGPR(Z.rk[k]); }
+}
+// the output pointers of a0_env_commit_finish, held in vector registers
+struct a0_env_out { float *ep_ret, *final_mask, *final_ret; int* ring_act; float *ring_rew, *ring_done; int* r_act; float *r_rew, *r_done; };
+A0_D a0_env_out a0_env_out_vgpr(float* ep_ret, float* final_mask, float* final_ret, int* ring_act, float* ring_rew, float* ring_done, int* r_act, float* r_rew, float* r_done) {
+    a0_env_out O{ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done};
+    A0_TO_VGPR(O.ep_ret); A0_TO_VGPR(O.final_mask); A0_TO_VGPR(O.final_ret); A0_TO_VGPR(O.ring_act); A0_TO_VGPR(O.ring_rew); A0_TO_VGPR(O.ring_done);
+    A0_TO_VGPR(O.r_act); A0_TO_VGPR(O.r_rew); A0_TO_VGPR(O.r_done);
+    return O;
+}
+
+A0_D void a0_env_nstep_row_pre(const a0_env_pre& Z, uint32_t e, int E, int n, long long steps, double gamma, float r, bool done, int a_now, int* __restrict__ ring_act,
+                               float* __restrict__ ring_rew, float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew,
+                               float* __restrict__ r_done, long long slot) {
 #pragma clang fp contract(off)      // R = R * gamma * (1 - d) + r in separately rounded steps, like numpy (agent.py:64-69) and oracle/core.py
     const int cur = (int)(steps % n);
     ring_act[(long long)cur * E + e] = a_now;
     ring_rew[(long long)cur * E + e] = r;
     ring_done[(long long)cur * E + e] = done ? 1.f : 0.f;
-    const long long have = steps + 1;
-    const int count = have < n ? (int)have : n;
+    const int count = Z.count;
     double R = 0.0;
     bool D = false;
-    for (int k = 0; k < count; ++k) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < count) {
+            const float dk = (k == 0) ? (done ? 1.f : 0.f) : Z.dk[k];
+            const float rk = (k == 0) ? r : Z.rk[k];
+            D = D || (dk != 0.f);
+            R = R * gamma * (double)(1 - (dk != 0.f ? 1 : 0)) + (double)rk;
+        }
+    }
+    for (int k = 8; k < count; ++k) {
         const int idx = (int)(((steps - k) % n + n) % n);
-        const float dk = (k == 0) ? (done ? 1.f : 0.f) : ring_done[(long long)idx * E + e];
-        const float rk = (k == 0) ? r : ring_rew[(long long)idx * E + e];
+        const float dk = ring_done[(long long)idx * E + e];
+        const float rk = ring_rew[(long long)idx * E + e];
         D = D || (dk != 0.f);
         R = R * gamma * (double)(1 - (dk != 0.f ? 1 : 0)) + (double)rk;
     }
-    const int oldest = (int)(((steps - (count - 1)) % n + n) % n);
-    r_act[slot] = (count == 1) ? a_now : ring_act[(long long)oldest * E + e];
+    r_act[slot] = (count == 1) ? a_now : Z.act_old;
     r_rew[slot] = (float)R;
     r_done[slot] = D ? 1.f : 0.f;
 }
 
 // episode statistics + n-step row of env e at step g: what ONE thread per env does once the action is known
-A0_D void a0_env_commit_scalars(const a0_u4& x, uint32_t e, uint32_t g, int task, int A, int E, int n, long long steps, double gamma, int a_now, float* __restrict__ ep_ret,
-                                float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act, float* __restrict__ ring_rew,
-                                float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done, long long slot) {
+A0_D void a0_env_commit_finish(const a0_env_pre& Z, const a0_u4& x, uint32_t e, uint32_t g, int task, int A, int E, int n, long long steps, double gamma, int a_now,
+                               float* __restrict__ ep_ret, float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act,
+                               float* __restrict__ ring_rew, float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew,
+                               float* __restrict__ r_done, long long slot) {
 #pragma clang fp contract(off)
     const bool term = (x.y % 500u) == 0u;
     const float r = a0_env_reward(x, task, A, e, g, a_now);
     const bool life = (!term) && ((x.z % 200u) == 0u);
-    const float ret = ep_ret[e] + r;
+    const float ret = Z.ep_prev + r;
     final_mask[e] = term ? 1.f : 0.f;
     final_ret[e] = term ? ret : 0.f;
     ep_ret[e] = term ? 0.f : ret;
-    a0_env_nstep_row(e, E, n, steps, gamma, r, term || life, a_now, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
+    a0_env_nstep_row_pre(Z, e, E, n, steps, gamma, r, term || life, a_now, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
+}
+
+A0_D void a0_env_commit_scalars(const a0_u4& x, uint32_t e, uint32_t g, int task, int A, int E, int n, long long steps, double gamma, int a_now, float* __restrict__ ep_ret,
+                                float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act, float* __restrict__ ring_rew,
+                                float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done, long long slot) {
+    a0_env_pre Z;
+    a0_env_commit_prefetch(Z, e, E, n, steps, ep_ret, ring_act, ring_rew, ring_done);
+    a0_env_commit_finish(Z, x, e, g, task, A, E, n, steps, gamma, a_now, ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
 }
 
 // the frame work of env e at step g for the 16-byte groups j = j0, j0 + jstride, ...: new frame, stack shift into obs_out, and the replay row

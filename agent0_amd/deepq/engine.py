@@ -12,6 +12,7 @@ Reference mapping (paths relative to the reference repo):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -464,6 +465,37 @@ class DeviceLearner:
             ops.dqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
                                     L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state, wo.dh)
             have_dh = True           # ... and the head's backward-data pass: dh is written by the same kernel
+            have_draw = True
+        elif algo == "c51" and hasattr(ops, "c51_head_loss_slabs") and os.environ.get("A0_C51_SEPARATE", "0") != "1":      # 1: tuning aid (same numbers, the nine separate launches)
+            # three fc1 GEMMs (their split-K slabs finished by ONE reduction launch), the online head as ONE GEMM over [s ; s'] rows, the target head, and
+            # one launch for everything behind them (a0_c51_head_loss_slabs: slab sums, dueling, greedy next action, projection + cross entropy, head gradient)
+            dq_ = self.double_q
+            ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
+            if getattr(self, "_c51_buf", None) is None:
+                R_on = 2 * B if dq_ else B
+                nh_on, nh_tg = ops.dense_fwd_partial_slabs(R_on, L.Npad, 512), ops.dense_fwd_partial_slabs(B, L.Npad, 512)
+                self._c51_buf = dict(fc1=[ops.empty(ns * B * 512) for _ in range(3 if dq_ else 2)], h_on=ops.empty(R_on * 512),
+                                     hs_on=ops.empty(nh_on * R_on * L.Npad), hs_tg=ops.empty(nh_tg * B * L.Npad), R_on=R_on)
+                wo.h = self._c51_buf["h_on"][: B * 512]                  # h(s) of the online network: what the backward pass reads
+            buf = self._c51_buf
+            (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
+            (Wh_o, bh_o), (Wh_t, bh_t) = on.wb("head"), tg.wb("head")
+            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+            ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, buf["fc1"][1])
+            layers = [(buf["fc1"][0], ns, bf_o, buf["h_on"][: B * 512], B), (buf["fc1"][1], ns, bf_t, wt.h, B)]
+            if dq_:
+                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
+                ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][2])
+                layers.append((buf["fc1"][2], ns, bf_o, buf["h_on"][B * 512:], B))
+            on.encode(wo, frames, slot, sample_stride, 0, B)
+            ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][0])
+            ops.reduce_bias_act_multi(layers, 512, True)
+            R_on = buf["R_on"]
+            nh_on = ops.dense_fwd_partial(buf["h_on"], 512, Wh_o, R_on, L.Npad, 512, buf["hs_on"])
+            nh_tg = ops.dense_fwd_partial(wt.h, 512, Wh_t, B, L.Npad, 512, buf["hs_tg"])
+            ops.c51_head_loss_slabs(buf["hs_on"], nh_on, R_on, buf["hs_tg"], nh_tg, B if dq_ else -1, bh_o, bh_t, L.Npad, L.A, L.T, L.dueling, act, rew, done, wgt,
+                                    self.atoms, self.gamma_n, self.vmin, self.vmax, B, self.loss, wo.draw, self.state, q_on=wo.q, q_tg=wt.q, m_out=self.m_proj,
+                                    a_star=self.a_star)
             have_draw = True
         elif algo in ("dqn", "c51", "qr"):
             tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)

@@ -390,6 +390,30 @@ class HipOps:
                                               _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"),
                                               _req(dh, torch.float32, B * 512, "dh", optional=True), _stream()), "a0_dqn_head_loss_slabs")
 
+    def reduce_bias_act_multi(self, layers, N, relu=True):
+        """layers: [(slabs, nslab, bias, out, rows)] (at most four, all of width N): out = act(sum of the layer's split-K slabs + bias), one launch."""
+        n = len(layers)
+        PP, II, LL = C.c_void_p * n, C.c_int * n, C.c_longlong * n
+        check(self.lib.a0_reduce_bias_act_multi(n, PP(*[_req(l[0], torch.float32, l[1] * l[4] * N, "slabs") for l in layers]), LL(*[l[4] * N for l in layers]),
+                                                II(*[l[1] for l in layers]), PP(*[_req(l[2], torch.float32, N, "bias") for l in layers]),
+                                                PP(*[_req(l[3], torch.float32, l[4] * N, "out") for l in layers]), II(*[l[4] for l in layers]), N, int(relu), _stream()),
+              "a0_reduce_bias_act_multi")
+
+    def c51_head_loss_slabs(self, s_on, nslab_on, rows_on, s_tg, nslab_tg, sel_off, bias_on, bias_tg, ld, A, T, dueling, act, rew, done, wgt, atoms, gamma_n, vmin, vmax, B,
+                            loss, draw, state, q_on=None, q_tg=None, m_out=None, a_star=None):
+        """C51Learner.train_step from the head GEMMs' slabs on (a0_c51_head_loss_slabs): online slabs [nslab_on][rows_on][ld] (rows [0, B) = s, [sel_off, sel_off + B) = s'
+        under double-Q, sel_off < 0 otherwise), target slabs [nslab_tg][B][ld]."""
+        nb = ld
+        check(self.lib.a0_c51_head_loss_slabs(_req(s_on, torch.float32, nslab_on * rows_on * ld, "slabs_on"), rows_on * ld, nslab_on, rows_on,
+                                              _req(s_tg, torch.float32, nslab_tg * B * ld, "slabs_tg"), B * ld, nslab_tg, int(sel_off),
+                                              _req(bias_on, torch.float32, nb, "bias_on"), _req(bias_tg, torch.float32, nb, "bias_tg"), ld, A, T, int(dueling),
+                                              _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                              _req(wgt, torch.float32, B, "wgt"), _req(atoms, torch.float32, T, "atoms"), float(gamma_n), float(vmin), float(vmax), B,
+                                              _req(loss, torch.float32, B, "loss"), _req(draw, torch.float32, B * ld, "draw"),
+                                              _req(q_on, torch.float32, B * A * T, "q_on", optional=True), _req(q_tg, torch.float32, B * A * T, "q_tg", optional=True),
+                                              _req(m_out, torch.float32, B * T, "m_out", optional=True), _req(a_star, torch.int32, B, "a_star", optional=True),
+                                              _req(state, torch.int32, 4, "state"), _stream()), "a0_c51_head_loss_slabs")
+
     def actor_dist_tail(self, slabs, nslab, bias, ld, A, T, dueling, mode, atoms, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl=None, eps_ptr=None):
         check(self.lib.a0_actor_dist_tail(_req(slabs, torch.float32, nslab * E * ld, "slabs"), E * ld, nslab, _req(bias, torch.float32, ld, "bias"), ld, A, T, int(dueling),
                                           mode, _req(atoms, torch.float32, T, "atoms", optional=(mode != 2)), E, seed, stream_a, stream_u, off_a, off_u, float(eps),

@@ -124,6 +124,11 @@ int a0_dense_fwd_mul_keep(const float* X, int ldx, const float* W, const float* 
  * a0_dense_fwd_partial_slabs(R, N, K) slabs in order, adds the bias and applies the activation (a0_dqn_head_loss_slabs) */
 int a0_dense_fwd_partial_slabs(int R, int N, int K);
 int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int R, int N, int K, float* slabs, void* stream);
+/* The reduction a0_dense_fwd performs behind its split-K GEMM, for up to four layers of the same width N in ONE launch: out[i] = act(sum_z slabs[i][z] + bias[i])
+ * (slabs added in slab order: bit-identical to a0_dense_fwd).  The three fc1 passes of a distributional update (agent.py:219-231: online on s, online on s',
+ * target on s') finish in one launch instead of three.  Host arrays of n entries; every buffer 16-byte aligned, slab strides multiples of 4 floats. */
+int a0_reduce_bias_act_multi(int n, const float* const* slabs, const long long* slab_stride, const int* nslab, const float* const* bias, float* const* out,
+                             const int* rows, int N, int relu, void* stream);
 
 /* measurement hook for bench.py: HIP events around every launch of the GEMM tagged `tag` (1 conv1 fwd, 2 conv2 fwd, 3 conv3 fwd,
  * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad, 12 fused encoder), recorded on the
@@ -194,6 +199,17 @@ int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const f
 /* MDQNLearner.train_step (agent.py:194-215): q_next = target(next_obs), q_cur_tgt = target(obs), both [B][A] */
 int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,
                  const float* wgt, float gamma_n, float tau, float lo, int B, float* loss, float* dq, int* nan_flag, void* stream);
+/* C51Learner.train_step (agent.py:219-269) from the head GEMMs' split-K slabs on, one launch: slab sums + bias (a0_dense_fwd's reduction), dueling combine per
+ * atom (model.py:163-177), greedy next action from the expectation under softmax (agent.py:225-231), projection of the target distribution and cross entropy
+ * (a0_loss_c51), d loss / d logits carried back through the dueling combine into `draw` [B][ld] — the gradient w.r.t. the online head GEMM's output on s.
+ * slabs_on [nslab_on][rows_on][ld]: the ONLINE head over rows [0, B) = s and, under double-Q, rows [sel_off, sel_off + B) = s' (one GEMM over both, they share
+ * the weights); sel_off < 0: no double-Q, the target's own expectation selects.  slabs_tg [nslab_tg][B][ld]: the target head on s'.  Optional outputs:
+ * q_on_out / q_tg_out [B][A][T] (the combined logits), m_out [B][T] (projected target), a_star_out [B].  Same arithmetic, statement for statement, as
+ * a0_dense_fwd's reduction + a0_dueling_fwd + a0_select_action + a0_loss_c51 + a0_dueling_bwd. */
+int a0_c51_head_loss_slabs(const float* slabs_on, long long stride_on, int nslab_on, int rows_on, const float* slabs_tg, long long stride_tg, int nslab_tg,
+                           int sel_off, const float* bias_on, const float* bias_tg, int ld, int A, int T, int dueling, const int* act, const float* rew,
+                           const float* done, const float* wgt, const float* atoms, float gamma_n, float vmin, float vmax, int B, float* loss, float* draw,
+                           float* q_on_out, float* q_tg_out, float* m_out, int* a_star_out, int* nan_flag, void* stream);
 /* C51Learner.train_step (agent.py:219-269): logits / tgt_logits [B][A][T]; m_out (optional) = projected target [B][T] */
 int a0_loss_c51(const float* logits, const float* tgt_logits, int A, int T, const int* act, const int* a_star,
                 const float* rew, const float* done, const float* wgt, const float* atoms, float gamma_n,

@@ -375,6 +375,31 @@ class CpuOps:
         self.dense_fwd(X, ldx, W, torch.zeros(N), slabs, R, N, K, False, self.empty(max(self.dense_fwd_scratch(R, N, K), 1)))
         return 1
 
+    def reduce_bias_act_multi(self, layers, N, relu=True):
+        for slabs, nslab, bias, out, rows in layers:
+            v = slabs[: nslab * rows * N].view(nslab, rows, N).sum(0) + bias[:N]
+            out[: rows * N] = (torch.relu(v) if relu else v).reshape(-1)
+
+    def c51_head_loss_slabs(self, s_on, nslab_on, rows_on, s_tg, nslab_tg, sel_off, bias_on, bias_tg, ld, A, T, dueling, act, rew, done, wgt, atoms, gamma_n, vmin, vmax, B,
+                            loss, draw, state, q_on=None, q_tg=None, m_out=None, a_star=None):
+        """The composition the HIP kernel replaces: slab sums + bias, dueling, greedy next action, C51 loss, dueling backward."""
+        raw_on = s_on[: nslab_on * rows_on * ld].view(nslab_on, rows_on, ld).sum(0) + bias_on[:ld]
+        raw_tg = s_tg[: nslab_tg * B * ld].view(nslab_tg, B, ld).sum(0) + bias_tg[:ld]
+        q_o = q_on if q_on is not None else torch.empty(B * A * T)
+        q_t = q_tg if q_tg is not None else torch.empty(B * A * T)
+        self.dueling_fwd(raw_on[:B].reshape(-1).contiguous(), ld, q_o, B, A, T, dueling)
+        self.dueling_fwd(raw_tg.reshape(-1).contiguous(), ld, q_t, B, A, T, dueling)
+        a_s = a_star if a_star is not None else torch.zeros(B, dtype=torch.int32)
+        if sel_off >= 0:
+            q_s = torch.empty(B * A * T)
+            self.dueling_fwd(raw_on[sel_off: sel_off + B].reshape(-1).contiguous(), ld, q_s, B, A, T, dueling)
+            self.select_action(q_s, A * T, T, 1, B, A, T, 2, atoms, a_s, None, None)
+        else:
+            self.select_action(q_t, A * T, T, 1, B, A, T, 2, atoms, a_s, None, None)
+        dq = torch.zeros(B * A * T)
+        self.loss_c51(q_o, q_t, A, T, act, a_s, rew, done, wgt, atoms, gamma_n, vmin, vmax, B, loss, dq, m_out, state)
+        self.dueling_bwd(dq, draw, ld, B, A, T, dueling)
+
     def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
                             draw, state, dh=None):
         def fc1(slabs, bias):

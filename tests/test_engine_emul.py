@@ -288,6 +288,11 @@ def check_update_full_size(ops, spec, hp, B, seed=61, lr=5e-4):
         taus, nets.TAU_LOG = nets.TAU_LOG, None
         rand_np = [x.numpy() for pair in taus for x in pair]
     D = lambda t: t.to(ops.device)
+    no = nt = None
+    if spec.noisy:          # NoisyNet: both sides get the same injected N(0, 0.1^2) draws (agent.py:125-127 resets both networks' noise per train call)
+        no, nt = noise_draws(spec, 80), noise_draws(spec, 90)
+        install_noise(dev.online, no)
+        install_noise(dev.target, nt)
     out = dev.update(D(torch.from_numpy(frames).reshape(-1)), None, 2 * int(np.prod(spec.obs_shape)), D(torch.from_numpy(a.astype(np.int32))), D(torch.from_numpy(r)),
                      D(torch.from_numpy(d.astype(np.float32))), D(torch.from_numpy(w)),
                      rand=None if rand_np is None else [D(torch.from_numpy(np.ascontiguousarray(x).reshape(-1).copy())) for x in rand_np])
@@ -295,7 +300,7 @@ def check_update_full_size(ops, spec, hp, B, seed=61, lr=5e-4):
     ora = olearner.OracleLearner(spec, sd_o, sd_t, hp, batch_size=B, lr=lr, target_update_freq=1)
     nets.RELU_MASKS, nets.RELU_STATS = device_relu_masks(dev, L, B), {}
     try:
-        res = ora.train(*args, rand=rand_np if spec.algo == "iqn" else None)
+        res = ora.train(*args, rand=rand_np if spec.algo == "iqn" else None, noise_online=no, noise_target=nt)
     finally:
         nets.RELU_MASKS = None
     stats = dict(nets.RELU_STATS)

@@ -298,9 +298,14 @@ def _record(name, payload):
         pass
 
 
-@pytest.mark.parametrize("algo,A,dq,n,duel", [("dqn", 4, False, 1, False), ("c51", 4, True, 3, False), ("iqn", 9, True, 3, False), ("fqf", 9, False, 1, False),
-                                              ("dqn", 18, True, 1, True), ("fqf", 18, True, 3, True), ("fqf", 9, True, 3, True)])
-def test_update_full_size(hip, algo, A, dq, n, duel):
+@pytest.mark.parametrize("algo,A,dq,n,duel,noisy", [("dqn", 4, False, 1, False, False), ("c51", 4, True, 3, False, False), ("iqn", 9, True, 3, False, False),
+                                                    ("fqf", 9, False, 1, False, False), ("dqn", 18, True, 1, True, False), ("fqf", 18, True, 3, True, False),
+                                                    ("fqf", 9, True, 3, True, False),
+                                                    # BASELINE configs[2] as configured: rainbow-lite = c51 + double-Q + dueling + NoisyNet, n = 3 (model.py:137-177,28-87)
+                                                    ("c51", 4, True, 3, True, True), ("c51", 4, False, 1, True, False), ("c51", 18, True, 3, True, True),
+                                                    # QR at full size: 512 x 200 x 200 quantile pairs, the largest quantile-Huber instance (agent.py:272-293)
+                                                    ("qr", 4, True, 3, False, False), ("qr", 4, False, 1, True, True)])
+def test_update_full_size(hip, algo, A, dq, n, duel, noisy):
     """BASELINE configs[1..4] at their real geometry — 84x84 observations, B = 512; Breakout's A = 4 for dqn / c51, Asterix's A = 9 with
     IQN N = N' = 64, K = 32 and FQF F = 32 — one whole update against the oracle: per-sample losses, every gradient tensor (the
     cosine-embedding weight gradient, Hadamard backward and the fc1 GEMMs over B*64 = 32 768 rows included), parameters and target after
@@ -310,9 +315,10 @@ def test_update_full_size(hip, algo, A, dq, n, duel):
     from oracle.losses import Hyper
     # the last three: the reference's own suite configuration (README.md:62-112, atari8_double_duel_prior: fqf + double-Q + dueling) at
     # Asterix's A = 9 and Seaquest's A = 18, and the 18-action dueling dqn head (upper range of the head/loss kernel's A + dueling <= 24 path)
-    stats = E.check_update_full_size(hip, recipe.NetSpec(algo, A, dueling=duel, **({"num_atoms": 51} if algo == "c51" else {})), Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), 512)
+    atoms = {"c51": {"num_atoms": 51}, "qr": {"num_atoms": 200}}.get(algo, {})
+    stats = E.check_update_full_size(hip, recipe.NetSpec(algo, A, dueling=duel, noisy=noisy, **atoms), Hyper(double_q=dq, n_step=n, K=32, N=64, N_dash=64), 512)
     print({k: (v[0], v[1], f"{v[2]:.1e}") for k, v in stats.items()})
-    _record(f"relu_decisions_{algo}_a{A}_duel{int(duel)}_dq{int(dq)}_n{n}_b512",
+    _record(f"relu_decisions_{algo}_a{A}_duel{int(duel)}_dq{int(dq)}_n{n}{'_noisy' if noisy else ''}_b512",
             {k: {"differ": int(v[0]), "of": int(v[1]), "largest_preactivation_rel": float(v[2])} for k, v in stats.items()})
 
 
@@ -548,3 +554,67 @@ def test_short_reduction_forward_kernel(hip, R, N, group, relu):
     assert float((Y0.cpu().double().view(R, N) - ref).abs().max()) <= 2e-6 * scale
     assert float((Y1.cpu().double().view(R, N) - ref_mul).abs().max()) <= 2e-6 * float(ref_mul.abs().max())
     assert torch.equal(E, Y0) and torch.equal(Y2, Y1)
+
+
+@pytest.mark.parametrize("A,T,dueling,double_q,B", [(4, 51, True, True, 512), (4, 51, False, False, 37), (18, 51, True, True, 65), (6, 11, True, False, 9), (3, 64, False, True, 130)])
+def test_c51_head_loss_from_slabs_equals_the_separate_kernels(hip, A, T, dueling, double_q, B):
+    """a0_c51_head_loss_slabs (round 4: one launch from the head GEMMs' split-K slabs to loss + head gradient) against the launches it replaces — slab
+    reduction, a0_dueling_fwd x3, a0_select_action, a0_loss_c51, a0_dueling_bwd — on the same slabs: the same arithmetic statement for statement, so every
+    output must be BIT-identical (torch.equal), ragged last workgroup and padded head columns included; and a0_reduce_bias_act_multi against a0_dense_fwd's
+    own reduction."""
+    g = recipe.gen(A * 1000 + T + B)
+    NQ = A + (1 if dueling else 0)
+    ld = (NQ * T + 31) // 32 * 32
+    R_on = 2 * B if double_q else B
+    ns_on, ns_tg = 5, 3
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
+    s_on = D(g.standard_normal((ns_on, R_on, ld)).astype(np.float32))
+    s_tg = D(g.standard_normal((ns_tg, B, ld)).astype(np.float32))
+    b_on, b_tg = D(g.standard_normal(ld).astype(np.float32)), D(g.standard_normal(ld).astype(np.float32))
+    a, r, d, w = recipe.make_transitions(B, A, 5)
+    act, rew, done, wgt = D(a.astype(np.int32)), D(r), D(d.astype(np.float32)), D(w)
+    atoms = torch.linspace(-10.0, 10.0, T).to(hip.device)
+    state = hip.zeros(8, dtype=torch.int32)
+    loss, draw = hip.empty(B), hip.empty(B * ld).fill_(7.0)
+    q_on, q_tg, m_out, a_star = hip.empty(B * A * T), hip.empty(B * A * T), hip.empty(B * T), hip.zeros(B, dtype=torch.int32)
+    hip.c51_head_loss_slabs(s_on.reshape(-1), ns_on, R_on, s_tg.reshape(-1), ns_tg, B if double_q else -1, b_on, b_tg, ld, A, T, dueling, act, rew, done, wgt, atoms,
+                            0.97, -10.0, 10.0, B, loss, draw, state, q_on=q_on, q_tg=q_tg, m_out=m_out, a_star=a_star)
+    # the separate launches on the same inputs
+    def reduce(slabs, bias):
+        acc = torch.zeros_like(slabs[0])
+        for z in range(slabs.shape[0]):
+            acc = acc + slabs[z]                # slab order
+        return (acc + bias).contiguous()
+    raw_on, raw_tg = reduce(s_on, b_on), reduce(s_tg, b_tg)
+    q1, q2, q3 = hip.empty(B * A * T), hip.empty(B * A * T), hip.empty(B * A * T)
+    hip.dueling_fwd(raw_on[:B].reshape(-1), ld, q1, B, A, T, dueling)
+    hip.dueling_fwd(raw_tg.reshape(-1), ld, q2, B, A, T, dueling)
+    a2 = hip.zeros(B, dtype=torch.int32)
+    if double_q:
+        hip.dueling_fwd(raw_on[B:].reshape(-1).contiguous(), ld, q3, B, A, T, dueling)
+        hip.select_action(q3, A * T, T, 1, B, A, T, 2, atoms, a2, None, None)
+    else:
+        hip.select_action(q2, A * T, T, 1, B, A, T, 2, atoms, a2, None, None)
+    loss2, dq2, m2, draw2 = hip.empty(B), hip.zeros(B * A * T), hip.empty(B * T), hip.empty(B * ld)
+    hip.loss_c51(q1, q2, A, T, act, a2, rew, done, wgt, atoms, 0.97, -10.0, 10.0, B, loss2, dq2, m2, state)
+    hip.dueling_bwd(dq2, draw2, ld, B, A, T, dueling)
+    torch.cuda.synchronize()
+    assert torch.equal(q_on, q1) and torch.equal(q_tg, q2), "combined logits"
+    assert torch.equal(a_star, a2), "greedy next action"
+    assert torch.equal(m_out, m2), "projected target distribution"
+    assert torch.equal(loss, loss2), "per-sample loss"
+    assert torch.equal(draw, draw2), "gradient w.r.t. the raw head output"
+    assert int(state[0]) == 0
+    # the multi-layer reduction: three layers of different slab counts in one launch == per-layer sums in slab order + bias + ReLU
+    N = 512
+    layers, want = [], []
+    for i, (ns, rows) in enumerate([(8, B), (3, B), (5, max(B // 2, 1))]):
+        sl = D(g.standard_normal((ns, rows, N)).astype(np.float32))
+        bias = D(g.standard_normal(N).astype(np.float32))
+        out = hip.empty(rows * N)
+        layers.append((sl.reshape(-1), ns, bias, out, rows))
+        want.append(torch.relu(reduce(sl, bias)).reshape(-1))
+    hip.reduce_bias_act_multi(layers, N, True)
+    torch.cuda.synchronize()
+    for (_, _, _, out, _), wv in zip(layers, want):
+        assert torch.equal(out, wv)
