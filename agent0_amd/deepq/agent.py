@@ -357,7 +357,26 @@ class BaseLearner:
         return int(self.engine.state[1])
 
     # ------------------------------------------------------------------ hot path: batch addressed by ring slots
-    def train_batch(self, frames: torch.Tensor, slot: Optional[torch.Tensor], row_bytes: int, act, rew, done, weights, rand=None):
+    def target_stage_batch(self, frames: torch.Tensor, slot: torch.Tensor, row_bytes: int, parity: int):
+        """The target network's pass of the update that will consume this batch (``train_batch(..., tstage=parity)``), enqueued on the CURRENT stream —
+        the Trainer's pipelined update block calls it on a second stream while the previous update is in flight.  Replayed from a hipGraph per parity."""
+        eng = self.engine
+        if not self.use_graph:
+            return eng.target_stage(frames, slot, row_bytes, parity)
+        key = ("tstage", frames.data_ptr(), slot.data_ptr(), row_bytes, parity)
+        g = self._graphs.get(key)
+        if g is None:
+            if self._graph_warm.get(key, 0) < 2:
+                self._graph_warm[key] = self._graph_warm.get(key, 0) + 1
+                return eng.target_stage(frames, slot, row_bytes, parity)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, **graph_capture_kwargs()):
+                eng.target_stage(frames, slot, row_bytes, parity)
+            self._graphs[key] = g
+        g.replay()
+
+    def train_batch(self, frames: torch.Tensor, slot: Optional[torch.Tensor], row_bytes: int, act, rew, done, weights, rand=None, tstage=None):
         """``rand`` (parity tests): the update's random / proposed fractions handed in instead of drawn here — see DeviceLearner.forward_dense;
         the tensors must be persistent device buffers (the update is replayed from a hipGraph that holds their addresses)."""
         cfg = self.cfg
@@ -368,10 +387,10 @@ class BaseLearner:
             for t in self._taus:
                 self.rng.uniform(self.rng.STREAM_TAUS, t, t.numel())
             rand = self._taus
-        out = self._update(frames, slot, row_bytes, act, rew, done, weights, rand)
+        out = self._update(frames, slot, row_bytes, act, rew, done, weights, rand, tstage)
         return out if isinstance(out, tuple) else (out, None)
 
-    def _update(self, frames, slot, row_bytes, act, rew, done, weights, rand):
+    def _update(self, frames, slot, row_bytes, act, rew, done, weights, rand, tstage=None):
         """engine.update, replayed from hipGraphs when the caller keeps handing in the same device buffers (the Trainer's hot loop
         does: the replay's persistent batch tensors).  The whole update is ONE graph — under data parallelism too: the gradient exchange
         (dist.RcclGradAllReduce -> a0_dp_allreduce) is a stream-ordered launch like any other and is captured with it, the dense bucket's
@@ -380,20 +399,20 @@ class BaseLearner:
         around its eager calls."""
         eng = self.engine
         if not self.use_graph:
-            return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+            return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand, tstage=tstage)
         hooked = eng.grad_hook is not None and not getattr(eng.grad_hook, "in_graph", False)
-        key = (frames.data_ptr(), None if slot is None else slot.data_ptr(), row_bytes, act.data_ptr(), rew.data_ptr(), done.data_ptr(), weights.data_ptr(), hooked)
+        key = (frames.data_ptr(), None if slot is None else slot.data_ptr(), row_bytes, act.data_ptr(), rew.data_ptr(), done.data_ptr(), weights.data_ptr(), hooked, tstage)
         g = self._graphs.get(key)
         if g is None:
-            if len(self._graphs) >= 4 or self._graph_warm.get(key, 0) < 2:       # two eager runs first: every lazy allocation has happened
+            if len(self._graphs) >= 8 or self._graph_warm.get(key, 0) < 2:       # two eager runs first: every lazy allocation has happened
                 self._graph_warm[key] = self._graph_warm.get(key, 0) + 1
-                return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+                return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand, tstage=tstage)
             mode = graph_capture_kwargs()
             g_f, g_e, g_apply = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if hooked else None), (torch.cuda.CUDAGraph() if hooked else None)
             torch.cuda.synchronize()
             try:
                 with torch.cuda.graph(g_f, **mode):
-                    out = eng.forward_dense(frames, slot, row_bytes, act, rew, done, weights, rand)
+                    out = eng.forward_dense(frames, slot, row_bytes, act, rew, done, weights, rand, tstage=tstage)
                     if not hooked:                                # the whole update is one graph, in-graph exchange included
                         eng.exchange_begin()
                         eng.backward_encoder()
@@ -407,7 +426,7 @@ class BaseLearner:
                 print(f"agent0_amd: capturing the gradient exchange into the update's hipGraph failed ({e}); splitting the update around it", file=sys.stderr)
                 eng.grad_hook.in_graph = False
                 torch.cuda.synchronize()
-                return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand)
+                return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand, tstage=tstage)
             if hooked:
                 with torch.cuda.graph(g_e, **mode):
                     eng.backward_encoder()

@@ -363,10 +363,11 @@ class DeviceLearner:
             ops.encoder_bwd(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
 
     # ------------------------------------------------------------------ the update
-    def update(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
+    def update(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None, tstage: Optional[int] = None):
         """One BaseLearner.train step (agent.py:124-169) on a batch that stays on the device: forward + backward, the data-parallel
-        gradient exchange when a ``grad_hook`` is installed, optimizer step."""
-        out = self.forward_dense(frames, slot, sample_stride, act, rew, done, wgt, rand)
+        gradient exchange when a ``grad_hook`` is installed, optimizer step.  ``tstage``: the target network's pass on this batch has already
+        run into the buffers of that parity (``target_stage``)."""
+        out = self.forward_dense(frames, slot, sample_stride, act, rew, done, wgt, rand, tstage=tstage)
         self.exchange_begin()
         self.backward_encoder()
         self.exchange_end()
@@ -416,7 +417,34 @@ class DeviceLearner:
             ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
                                self.target_update_freq, tg.flat, L.n_params_padded, tail)
 
-    def forward_dense(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None):
+    # ------------------------------------------------------------------ the target network's pass as a stage of its own
+    @property
+    def target_stage_supported(self) -> bool:
+        """The target network's forward pass on the next observations (encoder + fc1 GEMM: agent.py:176 / 222) depends on neither the online weights nor the
+        previous update's gradients, so the Trainer may run it for batch k + 1 on a second stream while update k is in flight — for the paths whose
+        tail consumes the target's fc1 slabs (dqn's and c51's fused heads) and without NoisyNet (whose per-update noise draws are ordered on the host)."""
+        L = self.L
+        if L.noisy or not self.online.fused:
+            return False
+        return (L.algo == "dqn" and L.A + (1 if L.dueling else 0) <= 24) or (L.algo == "c51" and hasattr(self.ops, "c51_head_loss_slabs") and os.environ.get("A0_C51_SEPARATE", "0") != "1")
+
+    def _tstage_buf(self, p: int):
+        if getattr(self, "_tst", None) is None:
+            self._tst = {}
+        if p not in self._tst:
+            ns = self.ops.dense_fwd_partial_slabs(self.B, 512, self.L.feat)
+            self._tst[p] = (self.ops.empty(self.B * self.L.feat), self.ops.empty(ns * self.B * 512))
+        return self._tst[p]
+
+    def target_stage(self, frames, slot, sample_stride, p: int):
+        """target(next_obs) up to the fc1 GEMM's split-K slabs, into the buffers of parity ``p`` (what ``forward_dense(..., tstage=p)`` then consumes)."""
+        L, ops, B, tg = self.L, self.ops, self.B, self.target
+        act3, slabs = self._tstage_buf(p)
+        Wf_t, _ = tg.wb("fc1")
+        ops.encoder_fwd_fused(tg.net, tg.wt, tg.encoder_weights(), frames, slot, sample_stride, self.obs_bytes, B, None, None, act3)
+        ops.dense_fwd_partial(act3, L.feat, Wf_t, B, 512, L.feat, slabs)
+
+    def forward_dense(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None, tstage: Optional[int] = None):
         """Forward passes, losses and the dense half of the backward pass (every gradient but the convolution blocks', which
         backward_encoder adds); no parameter is modified (FQF's fraction net aside, which the reference also steps separately,
         agent.py:140-147).
@@ -431,6 +459,8 @@ class DeviceLearner:
         L, ops, B = self.L, self.ops, self.B
         on, tg = self.online, self.target
         nxt = self.obs_bytes
+        if tstage is not None and not self.target_stage_supported:
+            raise ValueError("tstage: this learner's target pass cannot run as a separate stage")
         if L.noisy:
             on.compose_noise()
             tg.compose_noise()
@@ -455,14 +485,18 @@ class DeviceLearner:
             if getattr(self, "_fc1_slabs", None) is None or self._fc1_slabs[0].numel() < ns * B * 512:
                 self._fc1_slabs = [ops.empty(ns * B * 512) for _ in range(3 if self.double_q else 2)]
             (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
-            ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, self._fc1_slabs[1])
+            s_tg = self._fc1_slabs[1]
+            if tstage is None:
+                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+            else:
+                s_tg = self._tstage_buf(tstage)[1]
             if self.double_q:
                 on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
             on.encode(wo, frames, slot, sample_stride, 0, B)
             ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
-            ops.dqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
+            ops.dqn_head_loss_slabs(self._fc1_slabs[0], s_tg, self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
                                     L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state, wo.dh)
             have_dh = True           # ... and the head's backward-data pass: dh is written by the same kernel
             have_draw = True
@@ -480,9 +514,13 @@ class DeviceLearner:
             buf = self._c51_buf
             (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
             (Wh_o, bh_o), (Wh_t, bh_t) = on.wb("head"), tg.wb("head")
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
-            ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, buf["fc1"][1])
-            layers = [(buf["fc1"][0], ns, bf_o, buf["h_on"][: B * 512], B), (buf["fc1"][1], ns, bf_t, wt.h, B)]
+            s_tg = buf["fc1"][1]
+            if tstage is None:
+                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+            else:
+                s_tg = self._tstage_buf(tstage)[1]
+            layers = [(buf["fc1"][0], ns, bf_o, buf["h_on"][: B * 512], B), (s_tg, ns, bf_t, wt.h, B)]
             if dq_:
                 on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][2])

@@ -275,9 +275,21 @@ class ReplayDataset:
                 self.ops.is_weights(self._prio, B, self._psum, self.top, float(self.beta), self._w)
         return Batch(self._idx_out, self._slot, self._act, self._rew, self._done, self._prio, self._w)
 
-    def sample(self, B: Optional[int] = None) -> Batch:
+    def sample(self, B: Optional[int] = None, buf: int = 0) -> Batch:
+        """``buf=1``: the batch goes to a second set of device buffers (uniform replay only) — the Trainer's pipelined update block draws batch k + 1 and runs
+        the target network on it while update k, which still reads batch k's slots, is in flight."""
         B = B or self.B
         assert B == self.B
+        if buf:
+            if self.prioritize:
+                raise ValueError("a second batch buffer exists for uniform replay only (prioritized sampling depends on the previous update's priorities)")
+            if getattr(self, "_alt", None) is None:
+                ops = self.ops
+                self._alt = (ops.zeros(B, dtype=torch.int64), ops.zeros(B, dtype=torch.int32), ops.zeros(B, dtype=torch.int32), ops.zeros(B), ops.zeros(B), ops.zeros(B))
+            io, sl, ac, rw, dn, pr = self._alt
+            start, n_perm, seed = self._next_uniform(B, draw=False)
+            self.ops.replay_sample_slots(start, n_perm, seed, self.top, self.head, self.size, self.act, self.rew, self.done, None, B, io, sl, ac, rw, dn, pr)
+            return Batch(io, sl, ac, rw, dn, pr, self._w)
         if self.use_sumtree and B <= 1024:
             # stratified draws, descent, slot + metadata and importance weights in one launch
             rng = self.rng

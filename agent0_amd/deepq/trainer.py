@@ -145,6 +145,7 @@ class Trainer:
             if "rms_sq" in blob and hasattr(eng, "rms_sq"):
                 eng.rms_sq.copy_(blob["rms_sq"])
             self.frame_count = int(blob.get("frame_count", 0))
+            self._updates_done = None
 
     # ------------------------------------------------------------------ trainer.py:74-119
     def step(self, transitions, returns, qmax):
@@ -161,7 +162,9 @@ class Trainer:
         self.frame_count += self.num_transitions
         n_upd = 0
         has_frac = False
-        if len(self.replay) > cfg.trainer.training_start_steps:
+        if len(self.replay) > cfg.trainer.training_start_steps and self._pipeline_ok():
+            n_upd = self._update_block_pipelined()
+        elif len(self.replay) > cfg.trainer.training_start_steps:
             rp = self.replay
             if self._loss_means.numel() < cfg.learner.learner_steps:       # learner_steps changed after construction
                 self._loss_means = self.ops.zeros(cfg.learner.learner_steps)
@@ -179,8 +182,68 @@ class Trainer:
                 n_upd += 1
         if n_upd:
             self.Ls.extend(self._loss_means[:n_upd].cpu().tolist())        # the one device->host read of the update block
+            # the device's update count (NaN-skipped steps do not count) for the next block's pipelining decision: read here, where the host has just waited
+            # for the block anyway, so that the next block can be enqueued behind the rollout without a stop
+            self._updates_done = int(self.learner.engine.state[1]) if self._pipeline_candidate() else None
             if has_frac:
                 self.FLs.extend(self._floss_means[:n_upd].cpu().tolist())
+
+    # ------------------------------------------------------------------ the update block with the target network's passes one update ahead
+    def _pipeline_candidate(self) -> bool:
+        cfg, ln = self.cfg, self.learner
+        # OFF by default: measured slower than the strictly serial block on MI355X (profiles/r04_experiments.md) — kept as a tested option
+        return (os.environ.get("A0_PIPELINE_TARGET", "0") == "1" and cfg.replay.policy != ReplayEnum.prioritize and cfg.learner.learner_steps >= 2
+                and bool(getattr(ln.engine, "target_stage_supported", False)) and ln.use_graph)
+
+    def _pipeline_ok(self) -> bool:
+        """Uniform replay (the next batch does not depend on this update's priorities), a learner whose target pass can run as a stage of its own, the
+        hot-loop entry points not wrapped by a test harness, and no target sync inside this block: Adam's fused target copy at the end of update k would race
+        with the target pass of batch k + 1 — such a block (one in target_update_freq / learner_steps) runs strictly in order."""
+        cfg, ln = self.cfg, self.learner
+        if not self._pipeline_candidate():
+            return False
+        if "sample" in vars(self.replay) or "train_batch" in vars(ln) or "update_priority" in vars(self.replay):      # instance-level wrappers (tests/test_gpu_trace.py)
+            return False
+        if getattr(self, "_updates_done", None) is None:
+            self._updates_done = int(ln.engine.state[1])          # one small read per block; NaN-skipped steps do not count, so the device's number is the one to use
+        c0, L, f = self._updates_done, int(cfg.learner.learner_steps), int(cfg.learner.target_update_freq)
+        return (c0 + L) // f == c0 // f                           # no multiple of f in (c0, c0 + L]: no sync in this block, however many steps a NaN skips
+
+    def _update_block_pipelined(self) -> int:
+        """trainer.py:83-104's loop with the same work in the same per-update order, except that batch k + 1 is drawn and pushed through the TARGET network
+        (encoder + fc1 GEMM, ~70 us for dqn at B = 512) on a second stream while update k runs: those kernels fill the CUs that update k's latency-bound
+        launches (512-row GEMMs, head / loss, reductions, Adam) leave idle.  Two sets of batch and target-stage buffers alternate; update k + 1 waits for its
+        stage through an event, the stage of batch k + 2 waits for update k (the last reader of the buffers it overwrites).  Numbers are unchanged."""
+        cfg, rp, ln = self.cfg, self.replay, self.learner
+        L, B = int(cfg.learner.learner_steps), cfg.learner.batch_size
+        if self._loss_means.numel() < L:
+            self._loss_means = self.ops.zeros(L)
+        if getattr(self, "_tstream", None) is None:
+            prio = os.environ.get("A0_TSTREAM_PRIO")
+            self._tstream = torch.cuda.Stream() if prio is None else torch.cuda.Stream(priority=int(prio))
+            self._tev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._mev = torch.cuda.Event()
+        self.pipelined_blocks = getattr(self, "pipelined_blocks", 0) + 1
+        cur = torch.cuda.current_stream()
+        batches = [None, None]
+        batches[0] = rp.sample(buf=0)
+        ln.target_stage_batch(rp.frames, batches[0].slot, rp.row_bytes, 0)          # the first batch's stage has nothing to hide behind: same stream
+        for i in range(L):
+            p = i & 1
+            if i + 1 < L:
+                q = p ^ 1
+                self._mev.record(cur)                     # update i - 1 (last reader of parity q's buffers) is complete on the main stream here
+                self._tstream.wait_event(self._mev)
+                with torch.cuda.stream(self._tstream):
+                    batches[q] = rp.sample(buf=q)
+                    ln.target_stage_batch(rp.frames, batches[q].slot, rp.row_bytes, q)
+                    self._tev[q].record(self._tstream)
+            if i > 0:
+                cur.wait_event(self._tev[p])
+            b = batches[p]
+            q_loss, _ = ln.train_batch(rp.frames, b.slot, rp.row_bytes, b.act, b.rew, b.done, b.weights, tstage=p)
+            self.ops.mean_rows(q_loss, 1, B, self._loss_means[i:i + 1])
+        return L
 
     def _result(self):
         """The result dict of trainer.py:111-118."""

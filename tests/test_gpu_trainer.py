@@ -451,3 +451,33 @@ def test_main_entry_point_at_baseline_config0_sizes(tmp_path):
     ck = torch.load(os.path.join(runs[0], "final.pth"), map_location="cpu", weights_only=True)
     assert int(ck["state"][1]) == (32 - first_loss) * 20 and int(ck["frame_count"]) == 32 * 1280, "20 updates per iteration (learner_steps, config.py:112)"
     assert ck["model"]["encoder.convs.0.weight"].shape == (32, 4, 8, 8) and ck["model"]["head.q_head.weight"].shape == (4, 512)
+
+
+@pytest.mark.parametrize("launch", [False, True], ids=["main", "launch"])
+@pytest.mark.parametrize("algo,extra", [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3}),
+                                        ("c51", {"learner.double_q": "true", "learner.dueling_head": "true"}), ("c51", {})])
+def test_pipelined_target_pass_changes_no_number(algo, extra, launch, monkeypatch):
+    """Round 4: under uniform replay the Trainer draws batch k + 1 and runs the TARGET network on it on a second stream while update k is in flight
+    (Trainer._update_block_pipelined; blocks that contain a target sync run strictly in order).  Same kernels on the same inputs: losses, online and target
+    parameters and Adam moments must be BIT-identical to the strictly serial block, across blocks with and without a sync, on both schedules."""
+    from agent0_amd.deepq.trainer import Trainer
+
+    def run(pipe):
+        monkeypatch.setenv("A0_PIPELINE_TARGET", "1" if pipe else "0")
+        cfg = make_cfg(algo, 8, **{"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 5, "trainer.training_start_steps": 100,
+                                    "learner.target_update_freq": 7, **extra})
+        tr = Trainer(cfg, use_lp=launch)
+        for _ in range(10):
+            tr.run_iteration()
+        if launch:
+            tr.actors[1].sample_finish(tr._pending)
+        torch.cuda.synchronize()
+        eng = tr.learner.engine
+        return tr, list(tr.Ls), eng.online.flat.clone(), eng.target.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), tr.replay.frames.clone()
+
+    tr0, l0, p0, t0, m0, v0, f0 = run(False)
+    tr1, l1, p1, t1, m1, v1, f1 = run(True)
+    assert getattr(tr0, "pipelined_blocks", 0) == 0
+    assert 3 <= tr1.pipelined_blocks < len(l1) // 5, "some blocks pipelined, the ones with a target sync not"
+    assert l0 == l1 and len(l0) == 45
+    assert torch.equal(p0, p1) and torch.equal(t0, t1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(f0, f1)
