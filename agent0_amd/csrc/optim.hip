@@ -310,15 +310,15 @@ __global__ void a0_noisy_grad_sigma_kernel(const float* __restrict__ gmu, float*
     }
 }
 
-// Up to three NoisyLinear modules (first_dense, q_head, value_head) in one launch: workgroups [first_block[m], first_block[m+1]) serve module m.
+// Up to six NoisyLinear modules (first_dense, q_head, value_head of the online AND the target network: round 4) in one launch: workgroups [first_block[m], first_block[m+1]) serve module m.
 struct a0_noisy_mod { const float* mu; const float* sigma; float* out; int N, K, r0, r1; const float* noise_in; const float* noise_out_w; const float* noise_out_b; };
-struct a0_noisy_multi_args { a0_noisy_mod mod[3]; int first_block[4]; };
+struct a0_noisy_multi_args { a0_noisy_mod mod[6]; int first_block[7]; };
 
 template <bool GRAD>
 __global__ void a0_noisy_multi_kernel(a0_noisy_multi_args A) {
     int mi = 0;
 #pragma unroll
-    for (int k = 1; k < 3; ++k) mi += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
+    for (int k = 1; k < 6; ++k) mi += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
     const a0_noisy_mod M = A.mod[mi];
     const int nblk = A.first_block[mi + 1] - A.first_block[mi];
     const long long rows = M.r1 - M.r0;
@@ -341,15 +341,15 @@ __global__ void a0_noisy_multi_kernel(a0_noisy_multi_args A) {
     }
 }
 
-// nmod <= 3 modules; arrays are host arrays.  grad = 0: eff[m] = mu[m] + sigma[m] * eps (a0_noisy_compose per module);
+// nmod <= 6 modules; arrays are host arrays.  grad = 0: eff[m] = mu[m] + sigma[m] * eps (a0_noisy_compose per module);
 // grad = 1: gsigma[m] (passed as eff) = gmu[m] (passed as mu) * eps (a0_noisy_grad_sigma per module; sigma unused).
 extern "C" int a0_noisy_multi(int grad, int nmod, const float* const* mu, const float* const* sigma, float* const* eff, const int* N, const int* K, const int* r0,
                               const int* r1, const float* const* noise_in, const float* const* noise_out_w, const float* const* noise_out_b, void* stream) {
-    if (nmod < 1 || nmod > 3 || !mu || !eff || !N || !K || !r0 || !r1 || !noise_in || !noise_out_w || !noise_out_b || (!grad && !sigma))
+    if (nmod < 1 || nmod > 6 || !mu || !eff || !N || !K || !r0 || !r1 || !noise_in || !noise_out_w || !noise_out_b || (!grad && !sigma))
         return a0_fail(A0_EINVAL, "a0_noisy_multi: bad argument");
     a0_noisy_multi_args A;
     int blocks = 0;
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 6; ++m) {
         A.first_block[m] = blocks;
         if (m < nmod) {
             if (!mu[m] || !eff[m] || (!grad && !sigma[m]) || !noise_in[m] || !noise_out_w[m] || !noise_out_b[m] || N[m] < 1 || K[m] < 1 || r0[m] < 0 || r1[m] <= r0[m] || r1[m] > N[m])
@@ -362,7 +362,7 @@ extern "C" int a0_noisy_multi(int grad, int nmod, const float* const* mu, const 
             A.mod[m] = a0_noisy_mod{nullptr, nullptr, nullptr, 1, 1, 0, 0, nullptr, nullptr, nullptr};
         }
     }
-    for (int m = nmod + 1; m <= 3; ++m) A.first_block[m] = 0x7fffffff;       // unused modules are never selected
+    for (int m = nmod + 1; m <= 6; ++m) A.first_block[m] = 0x7fffffff;       // unused modules are never selected
     A.first_block[nmod] = blocks;                                              // end of the last real module
     if (grad) hipLaunchKernelGGL(a0_noisy_multi_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(a0_noisy_multi_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);

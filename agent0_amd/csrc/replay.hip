@@ -333,7 +333,10 @@ extern "C" int a0_sumtree_set_range(float* tree, long long cap2, long long start
 // x (store, fence, barrier, load) on one workgroup took 47-56 us for 512 leaves of a 1 M-leaf tree.
 template <int M>       // leaves per lane: S = 64 * M
 __global__ __launch_bounds__(64) void a0_sumtree_set_sub_kernel(float* __restrict__ tree, long long cap2, const long long* __restrict__ idx,
-                                                                 const float* __restrict__ val, int n, const int* __restrict__ state) {
+                                                                 const float* __restrict__ val, int n, const int* __restrict__ state,
+                                                                 const float* __restrict__ loss, float eps, float alpha, float* __restrict__ pstate) {
+    // loss != NULL (round 4, a0_sumtree_set_from_loss): the values are (loss + eps)^alpha, formed here while the batch is staged (== a0_sumtree_prio_kernel:
+    // one launch less per prioritized update), and workgroup 0 keeps max_p; val is unused then
     if (state && state[3]) return;
     constexpr int S = 64 * M, LS = __builtin_ctz(S);
     __shared__ int sidx[1024];             // leaf indices fit 31 bits for every tree this path takes (S <= 1024: cap2 <= 2 M)
@@ -341,7 +344,17 @@ __global__ __launch_bounds__(64) void a0_sumtree_set_sub_kernel(float* __restric
     __shared__ float leaf[S];
     __shared__ int win[S];
     const int lane = threadIdx.x, i = blockIdx.x;
-    for (int j = lane; j < n; j += 64) { sidx[j] = (int)idx[j]; sval[j] = val[j]; }
+    if (loss) {
+        float mx = -INFINITY;
+        for (int j = lane; j < n; j += 64) { const float l = loss[j]; sidx[j] = (int)idx[j]; sval[j] = a0_prio_pow(l + eps, alpha); mx = fmaxf(mx, l); }
+        if (i == 0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (lane == 0) pstate[0] = fmaxf(pstate[0], mx);
+        }
+    } else {
+        for (int j = lane; j < n; j += 64) { sidx[j] = (int)idx[j]; sval[j] = val[j]; }
+    }
     __syncthreads();                        // (one wave per workgroup: the barriers here only order its LDS accesses)
     const int t = sidx[i] >> LS;                                        // this wave's subtree
     bool dup = false;
@@ -384,21 +397,40 @@ __global__ __launch_bounds__(1024) void a0_sumtree_top_kernel(float* __restrict_
     a0_sumtree_top(tree, A0_ST_TOP, top);
 }
 
+static bool a0_sumtree_sub_path(long long cap2) {
+    const long long S = cap2 / A0_ST_TOP;        // leaves per subtree below the LDS-resident top
+    static const bool one_wg = getenv("A0_SUMTREE_ONE_WG") != nullptr;      // tuning aid: the single-workgroup kernel for every size
+    return !one_wg && (S == 64 || S == 128 || S == 256 || S == 512 || S == 1024);
+}
+static void a0_sumtree_sub_launch(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, const float* loss, float eps, float alpha,
+                                  float* pstate, hipStream_t st) {
+    switch ((int)(cap2 / A0_ST_TOP)) {
+        case 64: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<1>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
+        case 128: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<2>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
+        case 256: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<4>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
+        case 512: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<8>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
+        default: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<16>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
+    }
+    hipLaunchKernelGGL(a0_sumtree_top_kernel, dim3(1), dim3(1024), 0, st, tree, state);
+}
+
+// replay.py:55-59 on the sum-tree in TWO launches (was three): leaf[idx] = (loss + eps)^alpha in batch order, max_p = max(max_p, max loss), subtrees, then the top.
+// Trees whose subtrees the per-wave kernel does not cover (a0_sumtree_set_from_loss_ok == 0) take a0_priority_from_loss + a0_sumtree_set.
+extern "C" int a0_sumtree_set_from_loss_ok(long long cap2) { return (cap2 >= 1 && !(cap2 & (cap2 - 1)) && a0_sumtree_sub_path(cap2)) ? 1 : 0; }
+
+extern "C" int a0_sumtree_set_from_loss(float* tree, long long cap2, const long long* idx, const float* loss, int n, float eps, float alpha, float* pstate, const int* state,
+                                        void* stream) {
+    if (!tree || !idx || !loss || !pstate || n < 1 || n > 1024 || cap2 < 1 || (cap2 & (cap2 - 1)) || !a0_sumtree_sub_path(cap2))
+        return a0_fail(A0_EINVAL, "a0_sumtree_set_from_loss: bad argument (at most 1024 leaves per call, a tree a0_sumtree_set_from_loss_ok accepts)");
+    a0_sumtree_sub_launch(tree, cap2, idx, nullptr, n, state, loss, eps, alpha, pstate, (hipStream_t)stream);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set_from_loss");
+}
+
 extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, void* stream) {
     if (!tree || !idx || !val || n < 1 || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_set: cap2 must be a power of two");
     if (n > 1024) return a0_fail(A0_EINVAL, "a0_sumtree_set: at most 1024 leaves per call (the indices are staged in one workgroup's LDS); split the batch in order");
-    const long long S = cap2 / A0_ST_TOP;        // leaves per subtree below the LDS-resident top
-    static const bool one_wg = getenv("A0_SUMTREE_ONE_WG") != nullptr;      // tuning aid: the single-workgroup kernel for every size
-    if (!one_wg && (S == 64 || S == 128 || S == 256 || S == 512 || S == 1024)) {
-        hipStream_t st = (hipStream_t)stream;
-        switch ((int)S) {
-            case 64: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<1>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
-            case 128: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<2>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
-            case 256: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<4>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
-            case 512: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<8>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
-            default: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<16>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state); break;
-        }
-        hipLaunchKernelGGL(a0_sumtree_top_kernel, dim3(1), dim3(1024), 0, st, tree, state);
+    if (a0_sumtree_sub_path(cap2)) {
+        a0_sumtree_sub_launch(tree, cap2, idx, val, n, state, nullptr, 0.f, 0.f, nullptr, (hipStream_t)stream);
         return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set");
     }
     int threads = 64; while (threads < n && threads < 1024) threads <<= 1;
@@ -471,6 +503,32 @@ extern "C" int a0_sumtree_sample(const float* tree, long long cap2, const float*
 }
 
 
+// The descent of a0_sumtree_sample_kernel, two levels per memory round trip: the four grandchildren of node n are the 16 aligned bytes tree[4n .. 4n + 3],
+// and because every internal node IS left + right of its children (the tree is only ever recomputed from children, never updated by delta), the children's
+// values are gc0 + gc1 and gc2 + gc3 bit for bit — so one 16-byte load replaces two dependent 8-byte ones and the comparisons see the same numbers.
+// A 1 M-leaf tree is 20 dependent L2 round trips deep (~0.8 us each for a lone workgroup); this makes it 10.
+A0_D long long a0_sumtree_descend(const float* __restrict__ tree, long long cap2, float u) {
+    long long n = 1;
+    while (4 * n <= cap2) {              // at least two levels below n
+        const a0_f4 g = *(const a0_f4*)(tree + 4 * n);
+        const float left = g.x + g.y, right = g.z + g.w;
+        if (u < left || !(right > 0.0f)) {
+            n = 2 * n;
+            if (u < g.x || !(g.y > 0.0f)) { n = 2 * n; } else { u -= g.x; n = 2 * n + 1; }
+        } else {
+            u -= left;
+            n = 2 * n + 1;
+            if (u < g.z || !(g.w > 0.0f)) { n = 2 * n; } else { u -= g.z; n = 2 * n + 1; }
+        }
+    }
+    while (n < cap2) {
+        const float left = tree[2 * n];
+        const float right = tree[2 * n + 1];
+        if (u < left || !(right > 0.0f)) { n = 2 * n; } else { u -= left; n = 2 * n + 1; }
+    }
+    return n;
+}
+
 // ------------------------------------------------------------------------------------------------ prioritized batch in one launch
 // The stratified uniforms (element b of the sampler's Philox stream: the value a0_rng_uniform would write), the sum-tree descent, the
 // slot / metadata lookup and the importance weights w = (top * p / total)^-beta / (max w + 1e-8) (trainer.py:91-94) for one batch:
@@ -486,13 +544,8 @@ __global__ __launch_bounds__(1024) void a0_sumtree_batch_kernel(unsigned long lo
     float mx = 0.f;
     for (int k = threadIdx.x; k < B; k += blockDim.x) {
         const float xi = (float)(a0_philox_word(seed, stream, offset + (unsigned long long)k) >> 8) * 0x1.0p-24f;
-        float u = ((float)k + xi) * seg;
-        long long n = 1;
-        while (n < cap2) {
-            const float left = tree[2 * n];
-            const float right = tree[2 * n + 1];
-            if (u < left || !(right > 0.0f)) { n = 2 * n; } else { u -= left; n = 2 * n + 1; }
-        }
+        const float u = ((float)k + xi) * seg;
+        const long long n = a0_sumtree_descend(tree, cap2, u);
         const long long li = (n - cap2) % cap;          // sum-tree leaves are addressed by ring slot (head = 0): logical index == slot
         const long long sl = li;
         const float p = tree[n];

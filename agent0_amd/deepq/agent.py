@@ -381,8 +381,13 @@ class BaseLearner:
         the tensors must be persistent device buffers (the update is replayed from a hipGraph that holds their addresses)."""
         cfg = self.cfg
         if cfg.learner.noisy_net:
-            self.model.reset_noise(compose=False)            # DeviceLearner.forward_dense composes both nets' effective weights
-            self.model_target.reset_noise(compose=False)
+            eng = self.engine
+            if eng.noise_joint is not None:
+                # the two resets of agent.py:125-127 (online, then target) as ONE fill of the joint buffer: the same Philox draws as two fills
+                self.rng.normal(self.rng.STREAM_NOISE, 0.1, eng.noise_joint, eng.noise_joint.numel())
+            else:
+                self.model.reset_noise(compose=False)            # DeviceLearner.forward_dense composes both nets' effective weights
+                self.model_target.reset_noise(compose=False)
         if rand is None and self._taus is not None:
             for t in self._taus:
                 self.rng.uniform(self.rng.STREAM_TAUS, t, t.numel())

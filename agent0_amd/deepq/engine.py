@@ -75,11 +75,23 @@ class DeviceNet:
             self.noise.setdefault(prefix, {})[leaf] = self.noise_buf[off:off + n]
             off += (n + 3) // 4 * 4
         self.noise_len = off
+        self._noise_sizes = sizes
         self._scratch: Optional[torch.Tensor] = None
         # fused per-observation encoder (encoder_fused.hip): needs k-major copies of the conv weights, refreshed when they change
         self.fused = bool(ops.fused_supported(L.C, L.H, L.W))
         self.fused_dgrad = self.fused and bool(ops.dgrad_fused_supported(L.C, L.H, L.W))
         self.wt = ops.zeros(ops.conv_wt_floats(L.C)) if self.fused else None
+
+    def adopt_noise_buf(self, buf: torch.Tensor):
+        """Move the noise vectors into ``buf`` (noise_len floats of a buffer the caller owns): the learner puts its two networks' vectors back to back, in
+        draw order, so that ONE normal fill serves both resets of a train call (agent.py:125-127)."""
+        assert buf.numel() >= self.noise_len
+        buf[: self.noise_len].copy_(self.noise_buf[: self.noise_len])
+        self.noise_buf = buf[: self.noise_len]
+        off = 0
+        for prefix, leaf, n in self._noise_sizes:
+            self.noise[prefix][leaf] = buf[off:off + n]
+            off += (n + 3) // 4 * 4
 
     def refresh_wt(self):
         if self.fused:
@@ -112,14 +124,18 @@ class DeviceNet:
         f, B = self.flat, self.L.blocks
         return {"w1": f[B["conv1"].w], "b1": f[B["conv1"].b], "w2": f[B["conv2"].w], "b2": f[B["conv2"].b], "w3": f[B["conv3"].w], "b3": f[B["conv3"].b]}
 
-    def compose_noise(self):
-        """NoisyLinear.reset_noise's weight_epsilon/bias_epsilon + forward composition (model.py:54-62,78-83)."""
+    def compose_mods(self):
         L = self.L
         mods = []
         for prefix, block, r0, r1, in_f in L.noise_modules:
             mu, sg, ef = L.blocks[block + ".mu"], L.blocks[block + ".sigma"], L.eff[block]
             nz = self.noise[prefix]
             mods.append((self.flat[mu.all], self.flat[sg.all], self.eff[ef.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
+        return mods
+
+    def compose_noise(self):
+        """NoisyLinear.reset_noise's weight_epsilon/bias_epsilon + forward composition (model.py:54-62,78-83)."""
+        mods = self.compose_mods()
         if mods:
             self.ops.noisy_multi(False, mods)              # the two or three modules in one launch
 
@@ -254,6 +270,13 @@ class DeviceLearner:
         self.net = ops.net(L.C, L.H, L.W)
         self.online = DeviceNet(ops, L, self.net)
         self.target = DeviceNet(ops, L, self.net)
+        self.noise_joint = None
+        if L.noisy and self.online.noise_len % 4 == 0:
+            # both networks' noise vectors back to back in the order a train call draws them (online, then target: agent.py:125-127)
+            n = self.online.noise_len
+            self.noise_joint = ops.zeros(2 * n)
+            self.online.adopt_noise_buf(self.noise_joint[:n])
+            self.target.adopt_noise_buf(self.noise_joint[n:])
         self.grads = ops.zeros(L.n_params_padded + 4)     # tail slot [n_params_padded]: the NaN flag as a float, reduced with the dense bucket
         self.adam_m = ops.zeros(L.n_params_padded)
         self.adam_v = ops.zeros(L.n_params_padded)
@@ -462,8 +485,12 @@ class DeviceLearner:
         if tstage is not None and not self.target_stage_supported:
             raise ValueError("tstage: this learner's target pass cannot run as a separate stage")
         if L.noisy:
-            on.compose_noise()
-            tg.compose_noise()
+            mods = on.compose_mods() + tg.compose_mods()
+            if len(mods) <= 6:
+                ops.noisy_multi(False, mods)            # both networks' effective weights in one launch
+            else:
+                on.compose_noise()
+                tg.compose_noise()
         algo = L.algo
         wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
         frac = None

@@ -222,7 +222,10 @@ class ReplayDataset:
         B = ids.numel()
         ids = ids.to(self.ops.device, torch.int64).contiguous()
         pr = priorities.to(self.ops.device, torch.float32).contiguous()
-        if self.use_sumtree:
+        if self.use_sumtree and B <= 1024 and self.ops.sumtree_set_from_loss_ok(self.cap2):
+            # priorities formed inside the per-subtree kernel: two launches (subtrees, top) instead of three
+            self.ops.sumtree_set_from_loss(self.tree, self.cap2, ids, pr, B, float(rc.eps), float(rc.alpha), self._pstate, state)
+        elif self.use_sumtree:
             if self._val.numel() < B:
                 self._val = self.ops.zeros(B)
             self.ops.priority_from_loss(pr, B, float(rc.eps), float(rc.alpha), self._val, self._pstate, state)

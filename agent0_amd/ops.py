@@ -308,7 +308,7 @@ class HipOps:
 
     # ------------------------------------------------------------------ replay
     def noisy_multi(self, grad: bool, mods):
-        """mods: [(mu, sigma, out, N, K, r0, r1, noise_in, noise_out_w, noise_out_b)] (at most three NoisyLinear modules), one launch."""
+        """mods: [(mu, sigma, out, N, K, r0, r1, noise_in, noise_out_w, noise_out_b)] (at most six NoisyLinear modules), one launch."""
         n = len(mods)
         PP, II = C.c_void_p * n, C.c_int * n
         blk = lambda t, m, nm: _req(t, torch.float32, m[3] * m[4] + m[3], nm)
@@ -521,6 +521,14 @@ class HipOps:
     def sumtree_sample(self, tree, cap2, xi, B, out_idx, out_p):
         check(self.lib.a0_sumtree_sample(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(xi, torch.float32, B, "xi"), B,
                                          _req(out_idx, torch.int64, B, "out_idx"), _req(out_p, torch.float32, B, "out_p"), _stream()), "a0_sumtree_sample")
+
+    def sumtree_set_from_loss_ok(self, cap2) -> bool:
+        return bool(self.lib.a0_sumtree_set_from_loss_ok(cap2))
+
+    def sumtree_set_from_loss(self, tree, cap2, idx, loss, n, eps, alpha, pstate, state=None):
+        check(self.lib.a0_sumtree_set_from_loss(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(loss, torch.float32, n, "loss"), n,
+                                                float(eps), float(alpha), _req(pstate, torch.float32, 1, "pstate"), _req(state, torch.int32, 8, "state", optional=True), _stream()),
+              "a0_sumtree_set_from_loss")
 
     def priority_from_loss(self, loss, n, eps, alpha, val, pstate, state=None):
         check(self.lib.a0_priority_from_loss(_req(loss, torch.float32, n, "loss"), n, eps, alpha, _req(val, torch.float32, n, "val"), _req(pstate, torch.float32, 1, "pstate"),

@@ -305,6 +305,11 @@ int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsign
                             int* act, float* rew, float* done, float* prio, float* w, void* stream_h);
 /* val = (loss + eps)^alpha, pstate[0] = max(pstate[0], max loss) (replay.py:55-59); no-op when state && state[3] (NaN-skipped update) */
 int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, const int* state, void* stream);
+/* a0_priority_from_loss + a0_sumtree_set in two launches instead of three (replay.py:55-59 on the sum-tree): the per-subtree kernel forms (loss + eps)^alpha while it
+ * stages the batch and keeps pstate[0] = max_p; n <= 1024; for trees with a0_sumtree_set_from_loss_ok(cap2) == 1 (64 ... 1024 leaves per subtree below the top 2048 nodes) */
+int a0_sumtree_set_from_loss_ok(long long cap2);
+int a0_sumtree_set_from_loss(float* tree, long long cap2, const long long* idx, const float* loss, int n, float eps, float alpha, float* pstate, const int* state,
+                             void* stream);
 
 /* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */
 int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action,
