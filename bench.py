@@ -268,13 +268,22 @@ def main():
     last = None
     for _ in range(args.steps):
         last = tr.run_iteration()
+    torch.cuda.synchronize()
+    dt_local = time.time() - t0          # this rank's own K steps, before it waits for the others: diagnoses a straggler from the one JSON line
     barrier()
     dt = time.time() - t0
+    per_rank = None
     if dp:
         import torch.distributed as dist
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+        loc = torch.zeros(world, device="cuda", dtype=torch.float64)
+        loc[rank] = dt_local
+        dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+        ms = [round(1e3 * float(x) / args.steps, 3) for x in loc.tolist()]
+        per_rank = {"min": min(ms), "max": max(ms), "ranks": ms,
+                    "note": "each rank's own time for the K steps up to its local synchronize, before the closing barrier; ms_per_step is the max over ranks of the barrier-to-barrier time"}
     # ---- roofline of the dominant kernel: the same iterations once more with the hipGraphs switched off, so that HIP events can
     # bracket every launch of that kernel on its stream (events cannot be read out of a replayed graph).  Not part of `value`.
     # the quantile networks (iqn / fqf) spend their time in the fc1-family GEMMs over B * N rows ("IQN/FQF fc1 + cosine-embed GEMMs:
@@ -374,6 +383,7 @@ def main():
                                "RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)")),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
                    "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}", "gradient_exchange": exchange},
+        "per_rank_ms_per_step": per_rank, "gradient_exchange": exchange,
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),
         "at_reference_update_ratio": ratio320, "other_entry": other,
@@ -399,13 +409,17 @@ def main():
             issued_ratio = (3 * f1 + 9 * (f2 + f3)) / (f1 + f2 + f3)
         enc = pr["kernel"] == "encoder_fused"
         if not enc:
-            issued_ratio, traffic = 9.0, None             # nine bf16 products per MAC; no PMC pass of these kernels is committed for this round
+            issued_ratio, traffic = 9.0, None             # nine bf16 products per MAC
+            try:      # per-launch mean of the family's HBM bytes from the committed PMC passes of this configuration (tools/pmc_quantile.sh)
+                traffic = round(json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["dense_fwd"][cfg.learner.algo.name]["dense_fwd_gemm"]["hbm_bytes"])
+            except Exception:
+                pass
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": traffic,
                 "issued_bf16": {"achieved": round(achieved * issued_ratio, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved * issued_ratio / 2500.0, 4),
                                 "note": ("bf16 MFMA FLOPs the kernel issues (3 products per conv1 MAC, 9 per conv2 / conv3 MAC: 99.96 MFLOP per observation) against the dense "
                                          "bf16 MFMA peak" if enc else "bf16 MFMA FLOPs the kernel issues (9 cross products per MAC) against the dense bf16 MFMA peak") +
                                         "; `frac` above counts every MAC once against the fp32 MFMA peak"},
-                "traffic_note": "not measured for this kernel (traffic is null)" if not enc else f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
+                "traffic_note": ("not measured for this kernel (traffic is null)" if traffic is None else f"NOT measured in this run: mean HBM bytes per launch of the family (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_quantile.sh), read from profiles/{traffic_file}") if not enc else f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
                                 f"at --replay-size 100000 --steps 2 (tools/refresh_profiles.sh), read from profiles/{traffic_file}; "
                                 "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB (512 obs); the learner's online pass also stores act1/act2 for the backward pass",
                 "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation; u8 input, activations in LDS, weights streamed through registers; "

@@ -32,7 +32,12 @@ sys.path.insert(0, HERE)
 import numpy as np
 import torch
 
+import pinned
 import recipe
+
+PINNED = os.environ.get("A0_PINNED") == "1"      # python tests/golden/pinned.py gen: the CPU-independent code path (fixture group G6P)
+if PINNED:
+    pinned.configure()
 from recipe import NetSpec, SPECS
 
 REF = os.environ.get("A0_REFERENCE", "/root/reference")
@@ -203,6 +208,8 @@ def wanted(name: str) -> bool:
 def save(name, **arrays):
     path = os.path.join(HERE, f"{name}.npz")
     meta = dict(torch_version=np.array(torch.__version__), numpy_version=np.array(np.__version__))
+    if PINNED:
+        meta["pinned_env"] = np.array(" ".join(f"{k}={v}" for k, v in sorted(pinned.ENV.items())) + " torch.set_num_threads(1) torch.backends.mkldnn.enabled=False")
     np.savez_compressed(path, **meta, **arrays)
     OUT[name] = sum(np.asarray(a).nbytes for a in arrays.values())
     print(f"  wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KiB, {len(arrays)} arrays)")
@@ -407,14 +414,17 @@ def g5_huber():
 
 
 # --------------------------------------------------------------------------- G6 full train() step
-def g6_train():
-    print("G6 full learner.train(): post-step parameter fingerprints")
+def g6_train(pinned_fqf: bool = False):
+    """``pinned_fqf`` (group G6P): the FQF cases only, three consecutive steps, in the CPU-independent mode of tests/golden/pinned.py, as g6p_*.npz."""
+    print("G6 full learner.train(): post-step parameter fingerprints" + (" — pinned FQF cases" if pinned_fqf else ""))
+    if pinned_fqf and not PINNED:
+        raise SystemExit("g6p must run in pinned mode: python tests/golden/pinned.py gen")
     cases = [("dqn", 16, False, 1), ("dqn_duel", 16, True, 3), ("c51_duel_noisy", 16, True, 3), ("c51", 16, False, 1),
              ("qr", 16, False, 1), ("iqn", 16, False, 1), ("fqf", 16, False, 1), ("mdqn", 16, False, 1),
              ("dqn_tiny", 32, True, 1), ("c51_tiny", 32, True, 3), ("dqn", 512, False, 1),
              ("fqf_duel", 16, True, 3), ("dqn_duel_a18", 16, True, 1), ("fqf_duel_a18", 16, True, 3)]
     for name, B, dq, ns in cases:
-        if not wanted(name):
+        if not wanted(name) or (pinned_fqf and SPECS[name].algo != "fqf"):
             continue
         spec = SPECS[name]
         cfg = ref_cfg(spec, B, double_q=dq, n_step=ns)
@@ -426,7 +436,7 @@ def g6_train():
             learner = Learner(cfg)
             load_recipe_weights(learner.model, spec, seed=11)
             load_recipe_weights(learner.model_target, spec, seed=12)
-            n_steps = 2 if B <= 32 else 1
+            n_steps = 3 if pinned_fqf else (2 if B <= 32 else 1)
             for step in range(n_steps):
                 frames = recipe.make_frames(B, seed=61 + step, obs_shape=spec.obs_shape)
                 actions, rewards, terminals, weights = recipe.make_transitions(B, spec.action_dim, seed=62 + step)
@@ -448,7 +458,7 @@ def g6_train():
                 for k, p in learner.model_target.named_parameters():
                     arrays[f"s{step}::target::{k}"] = recipe.checksum(t2n(p))
                 arrays[f"s{step}::update_steps"] = np.array(learner.update_steps)
-        save(f"g6_{name}_b{B}_dq{int(dq)}_n{ns}", **arrays)
+        save(f"g6{'p' if pinned_fqf else ''}_{name}_b{B}_dq{int(dq)}_n{ns}", **arrays)
 
 
 # --------------------------------------------------------------------------- G7 actor
@@ -651,10 +661,12 @@ def g10_noisy():
 
 def main():
     torch.manual_seed(0)
-    torch.set_num_threads(8)
+    torch.set_num_threads(1 if PINNED else 8)
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    if PINNED and which != ["g6p"]:
+        raise SystemExit("pinned mode generates group g6p only")
     table = dict(g1=g1_forward, g2=g2_layers, g3=g3_losses, g4=g4_c51_projection, g5=g5_huber, g6=g6_train,
-                 g7=g7_actor, g8=g8_replay, g9=g9_schedules, g10=g10_noisy)
+                 g7=g7_actor, g8=g8_replay, g9=g9_schedules, g10=g10_noisy, g6p=lambda: g6_train(pinned_fqf=True))
     for w in which:
         table[w]()
     print("done; total payload bytes:", sum(OUT.values()))

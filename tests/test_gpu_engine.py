@@ -5,6 +5,8 @@ cases pinned by fixtures generated from the reference itself (tests/golden/g3_*,
 Tolerances: the MFMA accumulates a k-ordered fp32 fmaf chain, torch CPU uses blocked/vectorised sums, so results agree
 to a few fp32 ulp of the accumulated magnitude: rtol 5e-5 / atol 5e-6 on losses and Q-values (stated per assert).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -214,7 +216,7 @@ def test_golden_train_steps(hip, case):
                 # of the tensor's max, profiles/r02_grad_accuracy.txt).  The fixture cannot be re-evaluated with the device's decisions, so
                 # its convolution fingerprints get that width here; test_update_full_size[dqn] makes the same comparison against the
                 # oracle WITH the decisions injected, at 3e-5.
-                flip = 2e-3 * float(grads[parts[2]].abs().max()) if (B >= 256 and "convs" in k) else 0.0
+                flip = float(os.environ.get("A0_TEST_FLIP", "2e-4")) * float(grads[parts[2]].abs().max()) if (B >= 256 and "convs" in k) else 0.0
                 assert np.all(np.abs(got[2:] - want_k[2:]) <= 3e-4 * scale / np.sqrt(max(grads[parts[2]].numel(), 1)) + 2e-4 * np.abs(want_k[2:]) + 1e-7 + flip), (k, got, want_k)
             elif parts[1] in ("param", "target"):
                 src = params if parts[1] == "param" else target
@@ -618,3 +620,75 @@ def test_c51_head_loss_from_slabs_equals_the_separate_kernels(hip, A, T, dueling
     torch.cuda.synchronize()
     for (_, _, _, out, _), wv in zip(layers, want):
         assert torch.equal(out, wv)
+
+
+G6P_GPU = ["fqf_b16_dq0_n1", "fqf_duel_b16_dq1_n3", "fqf_duel_a18_b16_dq1_n3"]
+
+
+@pytest.mark.parametrize("case", G6P_GPU)
+def test_golden_fqf_train_steps_pinned(hip, case):
+    """Round 4: THREE consecutive reference ``FQFLearner.train()`` calls against the REFERENCE's numbers at the tight tolerances every other
+    learner is held to.  The ordinary G6 fixtures cannot serve from the second step on — torch's CPU kernels round differently on this host than on the build
+    container that recorded them, and FQF amplifies that (test_golden_train_steps) — so these fixtures (g6p_*) were recorded with torch on a CPU-independent code
+    path (tests/golden/pinned.py), and the oracle, run the same way in a child process, must first reproduce them ON THIS MACHINE; then the HIP path, fed the
+    fractions of that oracle run (cos(pi i tau) amplifies an ulp of tau ~200x: both sides evaluate q at the same fractions, as in every FQF parity test) and
+    continued from its post-step state after each step, is compared with the FIXTURE: losses rtol 5e-5, gradient and parameter fingerprints as for G6."""
+    from util import pinned_oracle
+    name, B, dq, n = _case(case)
+    spec = SPECS[name]
+    g = golden(f"g6p_{case}")
+    o = pinned_oracle(case)
+    # Does the oracle, run in the pinned mode on THIS host, reproduce the reference's recorded numbers?  On the build container it does, bit for bit, over all
+    # three steps (tests/test_oracle_golden.py::test_g6p_pinned_fqf_train_steps).  Measured on the GPU box's host (round 4): NOT quite — 5e-6 of the loss already
+    # at step 0, i.e. MKL's reproducibility mode does not extend across CPU vendors — so there the tight comparison is against this machine's pinned oracle and
+    # the fixture is held loosely, exactly like test_golden_train_steps does from the second step on; where the host does reproduce it, the fixture itself is
+    # the tight reference for all three steps.
+    dev_q = max(float(np.abs(o[f"s{s}::q_loss"] - g[f"s{s}::q_loss"]).max() / np.abs(g[f"s{s}::q_loss"]).mean()) for s in range(3))
+    dev_f = max(float(np.abs(o[f"s{s}::fraction_loss"] - g[f"s{s}::fraction_loss"]).max() / np.abs(g[f"s{s}::fraction_loss"]).mean()) for s in range(3))
+    pinned_here = dev_q <= 1e-6 and dev_f <= 1e-6
+    _record(f"fqf_pinned_oracle_vs_reference_{case}", {"q_loss_max_rel_dev": dev_q, "fraction_loss_max_rel_dev": dev_f, "host_reproduces_fixture": pinned_here})
+    ref = g if pinned_here else o
+    L, dev = _device_learner(hip, spec, B, dq, n, target_update_freq=2)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x).reshape(-1).copy()).to(hip.device)
+    T = lambda prefix, s: {k.split("::")[2]: torch.from_numpy(v) for k, v in o.items() if k.startswith(f"s{s}::{prefix}::")}
+    for s in range(3):
+        frames, a, r, d, w = _batch(hip, spec, B, 61 + s, 62 + s)
+        rand = [D(o[f"s{s}::{nm}_{i}"]) for i in range(2) for nm in ("taus", "tau_hats")]
+        loss, frac = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w, rand=rand)
+        assert_close(loss[:B], ref[f"s{s}::q_loss"], 5e-5, 5e-6, f"s{s} q_loss")
+        assert_close(frac[:B], ref[f"s{s}::fraction_loss"], 5e-5, 2e-5, f"s{s} fraction_loss")
+        assert_close(loss[:B], g[f"s{s}::q_loss"], 1e-3, 1e-4, f"s{s} q_loss vs the reference's fixture (loose on a host that does not reproduce it)")
+        assert_close(frac[:B], g[f"s{s}::fraction_loss"], 5e-3, 5e-4, f"s{s} fraction_loss vs the reference's fixture (loose on a host that does not reproduce it)")
+        assert int(dev.state[1]) == int(g[f"s{s}::update_steps"])
+        grads = L.unpack(dev.grads)
+        params, target = dev.online.state_dict(), dev.target.state_dict()
+        n_cmp = 0
+        for k in g.files:
+            parts = k.split("::")
+            if parts[0] != f"s{s}" or len(parts) < 3 or k not in ref:
+                continue
+            want_k = ref[k]
+            if parts[1] == "grad" and parts[2] in grads:
+                got = recipe.checksum(grads[parts[2]].cpu().numpy())
+                scale = max(want_k[1], 1e-6)
+                assert abs(got[1] - want_k[1]) <= 3e-4 * scale, (k, got[1], want_k[1])
+                assert np.all(np.abs(got[2:] - want_k[2:]) <= 3e-4 * scale / np.sqrt(max(grads[parts[2]].numel(), 1)) + 2e-4 * np.abs(want_k[2:]) + 1e-7), (k, got, want_k)
+                n_cmp += 1
+            elif parts[1] in ("param", "target"):
+                src = params if parts[1] == "param" else target
+                if parts[2] not in src:
+                    continue
+                got = recipe.checksum(src[parts[2]].cpu().numpy())
+                assert abs(got[1] - want_k[1]) <= 1e-5 * max(want_k[1], 1e-6), (k, got[1], want_k[1])
+                assert np.all(np.abs(got[2:] - want_k[2:]) <= 5e-5 + 1e-4 * np.abs(want_k[2:])), (k, got[2:], want_k[2:])
+                n_cmp += 1
+        assert n_cmp > 30
+        if s < 2:      # continue from the pinned oracle's post-step state (== the reference's, by the check above): every step from a common state
+            po, pt = T("po", s), T("pt", s)
+            L.pack(po, dev.online.flat)
+            L.pack(pt, dev.target.flat)
+            dev.online.refresh_wt(); dev.target.refresh_wt()
+            fk = [k for k in po if "fraction" in k]
+            zeros = {k: torch.zeros_like(po[k]) for k in fk}
+            L.pack({**T("adam_m", s), **zeros}, dev.adam_m)
+            L.pack({**T("adam_v", s), **zeros}, dev.adam_v)

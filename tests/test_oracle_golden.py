@@ -336,3 +336,29 @@ def test_g10_noisy_linear():
     assert_close(p["l.weight_epsilon"], g["weight_epsilon"], 1e-6, 1e-8, "weight_epsilon")
     assert_close(p["l.bias_epsilon"], g["bias_epsilon"], 1e-6, 1e-8, "bias_epsilon")
     assert_close(nets.dense(p, "l", torch.from_numpy(g["x"]), True), g["y"], 1e-5, 1e-6, "noisy linear out")
+
+
+# ----------------------------------------------------------------------------- G6P: FQF train steps in the CPU-independent mode
+G6P = ["fqf_b16_dq0_n1", "fqf_duel_b16_dq1_n3", "fqf_duel_a18_b16_dq1_n3"]
+
+
+@pytest.mark.parametrize("case", G6P)
+def test_g6p_pinned_fqf_train_steps(case):
+    """Three consecutive reference ``FQFLearner.train()`` calls recorded in the CPU-independent mode of tests/golden/pinned.py (scalar ATen kernels, MKL's
+    reproducibility mode, one thread, no oneDNN) against the oracle run in the same mode in a child process: in that mode the reference's numbers do not depend on
+    the host CPU — the ordinary G6 fixtures' FQF numbers do from the second step on — and the oracle reproduces them to the last bit."""
+    from util import pinned_oracle
+    g = golden(f"g6p_{case}")
+    o = pinned_oracle(case)
+    assert str(o["cpu_capability"]).upper().startswith("DEFAULT") and "ATEN_CPU_CAPABILITY=default" in str(g["pinned_env"])
+    for s in range(3):
+        assert int(o[f"s{s}::update_steps"]) == int(g[f"s{s}::update_steps"])
+        assert_close(o[f"s{s}::q_loss"], g[f"s{s}::q_loss"], 1e-6, 1e-7, f"s{s} q_loss")
+        assert_close(o[f"s{s}::fraction_loss"], g[f"s{s}::fraction_loss"], 1e-6, 1e-7, f"s{s} fraction_loss")
+        n = 0
+        for k in g.files:
+            parts = k.split("::")
+            if parts[0] == f"s{s}" and len(parts) == 3 and parts[1] in ("grad", "param", "target") and k in o:
+                assert_close(o[k], g[k], 1e-6, 1e-7 * max(float(np.abs(g[k]).max()), 1.0), k)
+                n += 1
+        assert n > 30

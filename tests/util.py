@@ -43,3 +43,18 @@ def assert_mostly_close(got, want, atol, max_bad_frac, max_rel_l2, what=""):
     frac = bad.mean() if bad.size else 0.0
     rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)
     assert frac <= max_bad_frac and rel <= max_rel_l2, f"{what}: {bad.sum()}/{bad.size} elements outside {atol} (allowed {max_bad_frac:.3%}), rel-L2 {rel:.3e} (allowed {max_rel_l2})"
+
+
+def pinned_oracle(case: str):
+    """The oracle's FQF steps of G6 case ``case`` computed in a child process in the CPU-independent mode (tests/golden/pinned.py, tests/pinned_oracle.py)."""
+    import os, sys, tempfile
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import pinned
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "out.npz")
+        r = pinned.run([os.path.join(here, "pinned_oracle.py"), case, path], capture_output=True, text=True)
+        assert r.returncode == 0, f"pinned oracle child failed:\n{r.stdout}\n{r.stderr}"
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}

@@ -32,6 +32,18 @@ for k in list(pm):
     if k.startswith("envcommit:"):
         g = k.split(":")[1]
         cal_r, cal_w = kb(f"envcommit:{g}", "FETCH_SIZE"), kb(f"envcommit:{g}", "WRITE_SIZE")
+# calibration kernels that still run (round 4): a0_sample_gather_kernel copies B = 512 rows of 56 448 B (28.90 MB in, 28.90 MB out, bench.py's replay-sample
+# measurement); a0_actor_qhead_env_kernel reads 256 observations (7.23 MB) and writes the new stack + the replay row (21.68 MB) per actor step
+calib = {}
+for name, rd, wr, what in (("gather", 512 * 2 * OBS, 512 * 2 * OBS, "a0_sample_gather_kernel: 512 rows x 56 448 B copied"),
+                           ("qenv", E256 * OBS, E256 * 3 * OBS, "a0_actor_qhead_env_kernel: 256 observations read, new stacks + replay rows written")):
+    for k in list(pm):
+        if k.startswith(name + ":") and k.endswith(":FETCH_SIZE"):
+            g = k.split(":")[1]
+            r_, w_ = kb(f"{name}:{g}", "FETCH_SIZE"), kb(f"{name}:{g}", "WRITE_SIZE")
+            if r_ and w_:
+                calib[name] = {"kernel": what, "algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr, "FETCH_SIZE_bytes_raw": r_, "WRITE_SIZE_bytes_raw": w_,
+                               "read_correction_implied": round(rd / r_, 3), "write_correction_implied": round(wr / w_, 3), "launches": pm[k]["n"]}
 traffic = {
     "kernels": "a0_encoder_fused_kernel<7,3,2,84,true[,true]> (enc: one observation per workgroup for the actor's 256, looping for the learner's 512), a0_encoder_dgrad_fused_x9_kernel (dgrad); "
                "a0_env_step_commit_kernel as the calibration kernel",
@@ -40,6 +52,7 @@ traffic = {
     "corrections": "counter unit KB; FETCH_SIZE x2 on gfx950 (64 B counted per 128-B request on wide coalesced reads), WRITE_SIZE x1.  Calibration on "
                    f"a0_env_step_commit_kernel, which reads 256 x 28 224 B = {E256 * OBS / 1e6:.2f} MB and writes 256 x (28 224 + 56 448) B = {E256 * 3 * OBS / 1e6:.2f} MB per launch: "
                    + (f"FETCH_SIZE x2 = {2 * cal_r / 1e6:.2f} MB, WRITE_SIZE = {cal_w / 1e6:.2f} MB" if cal_r and cal_w else "not captured in this run"),
+    "calibration": calib,
     "per_launch": {},
 }
 for n_obs, grid in ((256, 256 * 512), (512, "loop")):       # "loop": the looping instantiation, which the bench uses for its 512-observation launches only
@@ -55,6 +68,10 @@ r, w = kb(f"dgrad:{256 * 512}", "FETCH_SIZE"), kb(f"dgrad:{256 * 512}", "WRITE_S
 if r is not None and w is not None:
     traffic["dgrad_per_launch_512"] = {"hbm_read_bytes": 2 * r, "hbm_write_bytes": w,
                                        "algorithmic_bytes": {"read": 512 * (49 * 64 + 81 * 64 + 400 * 32) * 4, "write": 512 * (81 * 64 + 400 * 32) * 4}}
+# ---- the quantile configurations' dense forward GEMMs and the short-reduction kernel (tools/pmc_quantile.sh)
+qp = os.path.join(SRC, "pmc_quantile.json")
+if os.path.exists(qp):
+    traffic["dense_fwd"] = json.load(open(qp))
 json.dump(traffic, open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
 # ---- the other BASELINE configurations

@@ -18,7 +18,8 @@ for name in ("fetch", "write"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            key = "enc" if "a0_encoder_fused_kernel" in k else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else None
+            key = ("enc" if "a0_encoder_fused_kernel" in k else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else
+                   "gather" if "a0_sample_gather_kernel" in k else "qenv" if "a0_actor_qhead_env_kernel" in k else None)
             gs = r["Grid_Size"]
             if key == "enc" and looping(k): gs = "loop"          # the looping instantiation (launches of more observations than CUs: the learner's 512)
             if key: acc[(key, gs)][r["Counter_Name"]].append(float(r["Counter_Value"]))
