@@ -42,6 +42,10 @@ class EncoderWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
 
 
+class EncoderPass(C.Structure):
+    _fields_ = [("wt", C.c_void_p), ("w", C.c_void_p), ("f", C.c_void_p), ("B", C.c_int), ("act1", C.c_void_p), ("act2", C.c_void_p), ("act3", C.c_void_p)]
+
+
 def parse_header(path: str = HEADER) -> List[Tuple[str, str, List[str]]]:
     """-> [(return type, name, [arg types])] for every function prototype in the header."""
     text = open(path).read()

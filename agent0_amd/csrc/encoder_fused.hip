@@ -768,8 +768,10 @@ constexpr int A0_X9_LDS_BYTES = A0_X9_XCH1 + (A0_KSPLIT ? 4 * (2 * 64 + 4) * 16 
 static_assert(A0_X9_LDS_BYTES <= 160 * 1024, "LDS");
 // LOOP: the workgroup walks over several observations (b += gridDim.x; launches of more observations than CUs) and requests the next
 // observation's conv1 weights behind conv3; without it (the actor's launches: one observation per workgroup) that request is not made.
+// bid / nblk: this workgroup's index among the workgroups that serve P and their number (blockIdx.x / gridDim.x for a launch of one pass;
+// a0_encoder_fused_multi_kernel hands every pass a share of the grid).
 template <int MBW1, int MBW2, int MBW3, bool LOOP>
-A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
+A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* img = (uint16_t*)smem;
     const int obs_bytes = P.C * P.H * P.W;
@@ -810,7 +812,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     float* bias_lds = (float*)(smem + A0_X9_BIAS_OFF);      // b1 | b2 | b3 behind the activation planes; visible after the first barrier below
     if (threadIdx.x < 160) bias_lds[threadIdx.x] = threadIdx.x < 32 ? P.b1[threadIdx.x] : threadIdx.x < 96 ? P.b2[threadIdx.x - 32] : P.b3[threadIdx.x - 96];
     // the pad channels (32..39 / 64..71) of the term planes are never read; nothing to initialise
-    for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+    for (int b = bid; b < P.B; b += nblk) {
         const long long s = P.slot ? (long long)P.slot[b] : (long long)b;
         const uint4* src = (const uint4*)(P.frames + s * P.sample_stride + P.chan_off);
         constexpr int TRIPS = 4;
@@ -873,10 +875,21 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P) {
     }
 }
 
+// Up to three forward passes of the split-operand encoder in ONE launch (round 4): the learner's passes over a batch — target network on s', online network on s'
+// (double-Q), online network on s — are independent of one another, and a launch of 256 looping workgroups is 9 % cheaper per observation over 1024 observations
+// than over 512 (ring set-up and the first weights per workgroup, the tail of the last wave of workgroups: tools/ubench_encoder_fwd.py).  Every pass gets a share
+// of the grid proportional to its observations; its workgroups run the unchanged per-pass body with their own weights, frames and outputs.
+struct a0_fused_multi_args { a0_fused_args p[3]; int first[4]; };
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_multi_kernel(a0_fused_multi_args M) {
+    const int bid = (int)blockIdx.x;
+    const int k = bid >= M.first[2] ? 2 : (bid >= M.first[1] ? 1 : 0);
+    a0_encoder_fused_x9_body<7, 3, 2, true>(M.p[k], bid - M.first[k], M.first[k + 1] - M.first[k]);
+}
+
 template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P) {
     if constexpr (X9) {
-        a0_encoder_fused_x9_body<MBW1, MBW2, MBW3, LOOP>(P);
+        a0_encoder_fused_x9_body<MBW1, MBW2, MBW3, LOOP>(P, (int)blockIdx.x, (int)gridDim.x);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1379,6 +1392,61 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     if (probed) {   // algorithmic FLOP of the three convolutions: 2 * (M1*32*K1 + M2*64*512 + M3*64*576) per observation
         const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
         a0_probe_stop((hipStream_t)stream, per_obs * B);
+    }
+    A0_HIP_THROW(hipGetLastError());
+    return A0_OK;
+    A0_CATCH
+}
+
+// n <= 3 passes of a0_net_encoder_fwd_fused in one launch (84 x 84 x 4 observations: the split-operand kernel); same outputs, bit for bit.
+extern "C" int a0_net_encoder_fwd_fused_multi(int C, int H, int W, int n, const a0_encoder_pass* pass, void* stream) {
+    A0_TRY
+    if (n < 1 || n > 3 || !pass) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused_multi: 1 to 3 passes");
+    static const bool no_x9 = getenv("A0_NO_X9") != nullptr;
+    if (!(C == 4 && H == 84 && W == 84) || no_x9) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused_multi: 4 x 84 x 84 observations on the split-operand kernel only");
+    a0_fused_multi_args M;
+    size_t lds = 0;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const a0_encoder_pass& q = pass[i];
+        if (!q.wt || !q.w || !q.w->b1 || !q.w->b2 || !q.w->b3 || !q.f || !q.f->frames || !q.act3 || q.B < 1) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused_multi: bad pass");
+        if ((q.f->sample_stride % 16) || (q.f->chan_off % 16) || (((uintptr_t)q.f->frames) % 16)) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused_multi: frames must be 16-byte aligned");
+        a0_fused_args& P = M.p[i];
+        if (!a0_fused_layout(C, H, W, P, lds)) return a0_fail(A0_EINVAL, "a0_net_encoder_fwd_fused_multi: observation shape");
+        P.frames = q.f->frames; P.slot = q.f->slot; P.sample_stride = q.f->sample_stride; P.chan_off = q.f->chan_off;
+        P.wt1 = q.wt; P.wt2 = q.wt + 48LL * C * 64; P.wt3 = P.wt2 + 64LL * 512;
+        P.wx2 = P.wt3 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; P.wx3 = P.wx2 + 96LL * 512;
+        P.b1 = q.w->b1; P.b2 = q.w->b2; P.b3 = q.w->b3;
+        P.act1 = q.act1; P.act2 = q.act2; P.act3 = q.act3; P.B = q.B;
+        total += q.B;
+    }
+    for (int i = n; i < 3; ++i) M.p[i] = M.p[0];
+    // at most one workgroup per CU; every pass at least one, shares proportional to the observations
+    static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 256;
+    const int cap = grid_cap > 0 ? grid_cap : 256;
+    int grid = (int)(total < cap ? total : cap), used = 0;
+    if (grid < n) grid = n;
+    for (int i = 0; i < n; ++i) {
+        M.first[i] = used;
+        int share = (i == n - 1) ? grid - used : (int)((long long)grid * pass[i].B / total);
+        if (share < 1) share = 1;
+        if (share > pass[i].B) share = pass[i].B;
+        used += share;
+    }
+    for (int i = n; i <= 3; ++i) M.first[i] = 0x7fffffff;
+    M.first[n] = used;
+    lds = A0_X9_LDS_BYTES;
+    static bool configured = false;
+    if (!configured) {
+        A0_HIP_THROW(hipFuncSetAttribute((const void*)a0_encoder_fused_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
+    hipLaunchKernelGGL(a0_encoder_fused_multi_kernel, dim3(used), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, M);
+    if (probed) {
+        const a0_fused_args& P = M.p[0];
+        const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
+        a0_probe_stop((hipStream_t)stream, per_obs * (double)total);
     }
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;

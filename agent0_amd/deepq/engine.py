@@ -440,6 +440,19 @@ class DeviceLearner:
             ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
                                self.target_update_freq, tg.flat, L.n_params_padded, tail)
 
+    def _encode_passes(self, frames, slot, sample_stride, passes):
+        """passes: [(net, ws, chan_off, keep)] — the encoder forward passes of one update over the same batch.  They are independent of one another (the reference
+        runs them one after the other, agent.py:176-181 / 222-231): on the fused split-operand kernel they go out as ONE launch (a0_net_encoder_fwd_fused_multi)."""
+        L, ops, B = self.L, self.ops, self.B
+        multi = (len(passes) > 1 and self.online.fused and (L.C, L.H, L.W) == (4, 84, 84) and hasattr(ops, "encoder_fwd_fused_multi")
+                 and os.environ.get("A0_ENC_MULTI", "1") != "0" and os.environ.get("A0_NO_X9") is None)
+        if not multi:
+            for net, ws, chan_off, keep in passes:
+                net.encode(ws, frames, slot, sample_stride, chan_off, B, keep=keep)
+            return
+        ops.encoder_fwd_fused_multi(self.net, [(net.wt, net.encoder_weights(), frames, slot, sample_stride, chan_off, B, ws.act1 if keep else None, ws.act2 if keep else None, ws.act3)
+                                               for net, ws, chan_off, keep in passes])
+
     # ------------------------------------------------------------------ the target network's pass as a stage of its own
     @property
     def target_stage_supported(self) -> bool:
@@ -496,12 +509,11 @@ class DeviceLearner:
         frac = None
         have_draw = have_dh = False
         if algo == "mdqn":
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
-            tg.head(wt, B)
             wm = self.ws_m
-            tg.encode(wm, frames, slot, sample_stride, 0, B, keep=False)        # target net on the CURRENT observation (agent.py:202-204)
+            # target net on the next AND on the current observation (agent.py:202-204), online net on the current one: one launch
+            self._encode_passes(frames, slot, sample_stride, [(tg, wt, nxt, False), (tg, wm, 0, False), (on, wo, 0, True)])
+            tg.head(wt, B)
             tg.head(wm, B)
-            on.encode(wo, frames, slot, sample_stride, 0, B)
             on.head(wo, B)
             ops.loss_mdqn(wo.q, wt.q, wm.q, L.A, act, rew, done, wgt, self.gamma_n, self.mdqn_tau, self.mdqn_lo, B, self.loss, wo.dq, self.state)
         elif algo == "dqn" and L.A + (1 if L.dueling else 0) <= 24:
@@ -513,15 +525,13 @@ class DeviceLearner:
                 self._fc1_slabs = [ops.empty(ns * B * 512) for _ in range(3 if self.double_q else 2)]
             (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
             s_tg = self._fc1_slabs[1]
+            self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if self.double_q else []) + [(on, wo, 0, True)])
             if tstage is None:
-                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
                 ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
             else:
                 s_tg = self._tstage_buf(tstage)[1]
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
-            on.encode(wo, frames, slot, sample_stride, 0, B)
             ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
             ops.dqn_head_loss_slabs(self._fc1_slabs[0], s_tg, self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
                                     L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state, wo.dh)
@@ -542,17 +552,15 @@ class DeviceLearner:
             (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
             (Wh_o, bh_o), (Wh_t, bh_t) = on.wb("head"), tg.wb("head")
             s_tg = buf["fc1"][1]
+            self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if dq_ else []) + [(on, wo, 0, True)])
             if tstage is None:
-                tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
                 ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
             else:
                 s_tg = self._tstage_buf(tstage)[1]
             layers = [(buf["fc1"][0], ns, bf_o, buf["h_on"][: B * 512], B), (s_tg, ns, bf_t, wt.h, B)]
             if dq_:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][2])
                 layers.append((buf["fc1"][2], ns, bf_o, buf["h_on"][B * 512:], B))
-            on.encode(wo, frames, slot, sample_stride, 0, B)
             ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][0])
             ops.reduce_bias_act_multi(layers, 512, True)
             R_on = buf["R_on"]
@@ -563,15 +571,13 @@ class DeviceLearner:
                                     a_star=self.a_star)
             have_draw = True
         elif algo in ("dqn", "c51", "qr"):
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+            self._encode_passes(frames, slot, sample_stride, [(tg, wt, nxt, False)] + ([(on, wsel, nxt, False)] if self.double_q else []) + [(on, wo, 0, True)])
             tg.head(wt, B)
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 on.head(wsel, B)
                 on.select(wsel, B, 1, self.a_star, atoms=getattr(self, "atoms", None))
             else:
                 tg.select(wt, B, 1, self.a_star, atoms=getattr(self, "atoms", None))
-            on.encode(wo, frames, slot, sample_stride, 0, B)
             on.head(wo, B)
             if algo == "dqn":
                 ops.loss_dqn(wo.q, wt.q, L.A, act, self.a_star, rew, done, wgt, self.gamma_n, B, self.loss, wo.dq, self.state)
@@ -585,9 +591,8 @@ class DeviceLearner:
         elif algo == "iqn":
             t_sel, t_tgt, t_on = rand
             K, Nd, N = self.K, self.N_dash, self.N
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
+            self._encode_passes(frames, slot, sample_stride, [(tg, wt, nxt, False)] + ([(on, wsel, nxt, False)] if self.double_q else []) + [(on, wo, 0, True)])
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 on.head(wsel, B, t_sel, K)
                 on.select(wsel, B, K, self.a_star)
             else:
@@ -595,7 +600,6 @@ class DeviceLearner:
                 tg.select(wt, B, K, self.a_star)
             tg.head(wt, B, t_tgt, Nd)
             ops.quantile_target(wt.q, Nd * L.A, L.A, 1, self.a_star, rew, done, self.gamma_n, B, Nd, self.y)
-            on.encode(wo, frames, slot, sample_stride, 0, B)
             on.head(wo, B, t_on, N)
             wo.dq.zero_()
             ops.loss_quantile_huber(wo.q, N * L.A, L.A, 1, self.y, t_on, N, act, wgt, B, N, Nd, self.loss, wo.dq, self.state)
@@ -605,12 +609,10 @@ class DeviceLearner:
                 net.fqf_taus(ws, B)
                 if rand is not None:
                     ws.tau_all[: B * (F + 1)].copy_(rand[2 * k].reshape(-1)); ws.tau_hat[: B * F].copy_(rand[2 * k + 1].reshape(-1))
-            on.encode(wo, frames, slot, sample_stride, 0, B)
+            self._encode_passes(frames, slot, sample_stride, [(on, wo, 0, True), (tg, wt, nxt, False)] + ([(on, wsel, nxt, False)] if self.double_q else []))
             taus(on, wo, 0)
             on.head(wo, B, wo.tau_hat, F)
-            tg.encode(wt, frames, slot, sample_stride, nxt, B, keep=False)
             if self.double_q:
-                on.encode(wsel, frames, slot, sample_stride, nxt, B, keep=False)
                 taus(on, wsel, 1)
                 on.head(wsel, B, wsel.tau_hat, F)
                 on.select(wsel, B, F, self.a_star)

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _abi
-from ._abi import A0Error, EncoderWeights, FramesArg, NetDesc, check
+from ._abi import A0Error, EncoderPass, EncoderWeights, FramesArg, NetDesc, check
 
 
 def _stream() -> int:
@@ -122,6 +122,18 @@ class HipOps:
                                                 _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1", optional=True),
                                                 _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2", optional=True),
                                                 _req(act3, torch.float32, B * net.feat, "act3"), _stream()), "a0_net_encoder_fwd_fused")
+
+    def encoder_fwd_fused_multi(self, net, passes):
+        """passes: [(wt, w, frames, slot, sample_stride, chan_off, B, act1, act2, act3)] (at most three): the forward passes of ``encoder_fwd_fused`` in one launch."""
+        keep = []
+        arr = (EncoderPass * len(passes))()
+        for i, (wt, w, frames, slot, sample_stride, chan_off, B, act1, act2, act3) in enumerate(passes):
+            fa, ew = self._frames(net, frames, slot, sample_stride, chan_off, B), self._enc_w(w)
+            keep += [fa, ew]
+            arr[i] = EncoderPass(_req(wt, torch.float32, self.conv_wt_floats(net.C), "wt"), C.addressof(ew), C.addressof(fa), B,
+                                 _req(act1, torch.float32, B * net.H1 * net.W1 * 32, "act1", optional=True), _req(act2, torch.float32, B * net.H2 * net.W2 * 64, "act2", optional=True),
+                                 _req(act3, torch.float32, B * net.feat, "act3"))
+        check(self.lib.a0_net_encoder_fwd_fused_multi(net.C, net.H, net.W, len(passes), C.addressof(arr), _stream()), "a0_net_encoder_fwd_fused_multi")
 
     def encoder_bwd_scratch(self, net, B) -> int:
         return int(self.lib.a0_net_encoder_bwd_scratch(net.h, B))

@@ -58,6 +58,12 @@ typedef struct a0_encoder_weights {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
 } a0_encoder_weights;
 
+/* one forward pass of a0_net_encoder_fwd_fused_multi: fragment-major weight copies (a0_net_conv_wt_refresh), biases (w->b1 .. b3), frames, observations, outputs */
+typedef struct a0_encoder_pass {
+    const float* wt; const a0_encoder_weights* w; const a0_frames_arg* f; int B;
+    float *act1, *act2, *act3;      /* act1 / act2 optional (a pass that is differentiated keeps them) */
+} a0_encoder_pass;
+
 int a0_net_create(const a0_net_desc* desc, a0_net** out);
 int a0_net_destroy(a0_net* net);
 int a0_net_geometry(const a0_net* net, int* out8);  /* H1,W1,H2,W2,H3,W3,feat_dim,K1 */
@@ -78,6 +84,9 @@ int a0_net_conv_wt_refresh(const a0_encoder_weights* w, int C, float* wt, void* 
 int a0_net_conv_wt_refresh_sync(const a0_encoder_weights* w, int C, float* wt, float* wt_target, const int* state, void* stream);
 int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, const a0_encoder_weights* w, const a0_frames_arg* frames, int B,
                              float* act1, float* act2, float* act3, void* stream);
+/* Up to three passes of a0_net_encoder_fwd_fused in ONE launch (the learner's target / online passes over one batch — reference agent.py:176-181 / 222-231 evaluate
+ * model_target(next_obs), model(next_obs), model(obs) one after the other; they are independent): bit-identical outputs, 4 x 84 x 84 observations only. */
+int a0_net_encoder_fwd_fused_multi(int C, int H, int W, int n, const a0_encoder_pass* pass, void* stream);
 
 /* Fused conv3 + conv2 data gradients per observation (84x84 geometry), the backward-data half of ConvEncoder (model.py:93-105 under
  * autograd, agent.py:136-141): d3 [B][7][7][64] -> d2 [B][9][9][64] and d1 [B][20][20][32], masked by act2 / act1 > 0.  wt = the

@@ -657,8 +657,10 @@ def test_golden_fqf_train_steps_pinned(hip, case):
         loss, frac = dev.update(frames, None, 2 * int(np.prod(spec.obs_shape)), a, r, d, w, rand=rand)
         assert_close(loss[:B], ref[f"s{s}::q_loss"], 5e-5, 5e-6, f"s{s} q_loss")
         assert_close(frac[:B], ref[f"s{s}::fraction_loss"], 5e-5, 2e-5, f"s{s} fraction_loss")
-        assert_close(loss[:B], g[f"s{s}::q_loss"], 1e-3, 1e-4, f"s{s} q_loss vs the reference's fixture (loose on a host that does not reproduce it)")
-        assert_close(frac[:B], g[f"s{s}::fraction_loss"], 5e-3, 5e-4, f"s{s} fraction_loss vs the reference's fixture (loose on a host that does not reproduce it)")
+        if s == 0:      # from the common initial state the reference's numbers hold on any host (loosely where the host does not reproduce them: measured
+            # on the GPU box, the pinned oracle itself is 5e-6 off the fixture at step 0, 1.5e-3 / 4.4e-2 of the two losses by step 2 — FQF's amplification)
+            assert_close(loss[:B], g[f"s{s}::q_loss"], 1e-3, 1e-4, f"s{s} q_loss vs the reference's fixture")
+            assert_close(frac[:B], g[f"s{s}::fraction_loss"], 5e-3, 5e-4, f"s{s} fraction_loss vs the reference's fixture")
         assert int(dev.state[1]) == int(g[f"s{s}::update_steps"])
         grads = L.unpack(dev.grads)
         params, target = dev.online.state_dict(), dev.target.state_dict()
@@ -692,3 +694,39 @@ def test_golden_fqf_train_steps_pinned(hip, case):
             zeros = {k: torch.zeros_like(po[k]) for k in fk}
             L.pack({**T("adam_m", s), **zeros}, dev.adam_m)
             L.pack({**T("adam_v", s), **zeros}, dev.adam_v)
+
+
+@pytest.mark.parametrize("Bs", [(512, 512), (512, 512, 512), (100, 37, 512), (3, 1), (700, 64, 2)])
+def test_encoder_passes_in_one_launch_equal_separate_launches(hip, Bs):
+    """a0_net_encoder_fwd_fused_multi (round 4): up to three forward passes — own weights, own frames / slot gather / row half, own outputs — share one launch of at
+    most 256 looping workgroups.  Each pass must produce exactly the bytes of its own a0_net_encoder_fwd_fused launch (torch.equal on act1 / act2 / act3), for
+    equal and very unequal pass sizes (every pass keeps at least one workgroup) and for passes that do not store act1 / act2."""
+    from agent0_amd.deepq.engine import DeviceNet, Workspace
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec("dqn", 4)
+    L = NetLayout.from_spec(spec)
+    nets_ = []
+    for seed in (11, 12):
+        n = DeviceNet(hip, L, hip.net(4, 84, 84))
+        n.load_state_dict(recipe.make_state_dict(spec, seed))
+        nets_.append(n)
+    cap = max(Bs) + 5
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(-1).contiguous()
+    passes, want = [], []
+    for i, B in enumerate(Bs):
+        net = nets_[i % 2]
+        slot = None if i == 1 else torch.from_numpy(recipe.gen(6 + i).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+        chan_off = 28224 if i != 2 else 0
+        keep = i == len(Bs) - 1
+        ws, ws2 = Workspace(hip, L, B), Workspace(hip, L, B)
+        for w_ in (ws, ws2):
+            w_.act1.fill_(-7.0); w_.act2.fill_(-7.0); w_.act3.fill_(-7.0)
+        hip.encoder_fwd_fused(net.net, net.wt, net.encoder_weights(), ring, slot, 2 * 28224, chan_off, B, ws.act1 if keep else None, ws.act2 if keep else None, ws.act3)
+        passes.append((net.wt, net.encoder_weights(), ring, slot, 2 * 28224, chan_off, B, ws2.act1 if keep else None, ws2.act2 if keep else None, ws2.act3))
+        want.append((ws, ws2, keep))
+    hip.encoder_fwd_fused_multi(nets_[0].net, passes)
+    torch.cuda.synchronize()
+    for i, (ws, ws2, keep) in enumerate(want):
+        assert torch.equal(ws.act3, ws2.act3), f"pass {i}: features"
+        assert torch.equal(ws.act1, ws2.act1) and torch.equal(ws.act2, ws2.act2), f"pass {i}: stored activations (or untouched buffers)"
+        assert float(ws2.act3.min()) >= 0.0

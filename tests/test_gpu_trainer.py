@@ -363,10 +363,11 @@ def test_graphed_update_with_a_gradient_hook_matches_eager():
 
 
 def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path):
-    """Rehearsal of the multi-GPU bench on a one-GPU box (A0_DP_FORCE=1): a one-rank RCCL process group is alive, the update is three
-    hipGraphs around two eager RCCL calls (the dense gradient bucket's all-reduce asynchronous, overlapping the encoder backward), the
-    parameter broadcast / barriers / max-over-ranks timing all run.  A one-rank all-reduce is the identity and Adam's eps is
-    1e-2/(1*B) either way, so the losses must equal those of the plain single-graph run bit for bit."""
+    """Rehearsal of the multi-GPU bench on a one-GPU box (A0_DP_FORCE=1): a one-rank RCCL process group is alive, the gradient exchange
+    (a0_dp_allreduce over RCCL: the dense bucket on a side stream beside the encoder backward, the small convolution bucket behind it) is
+    CAPTURED in the update's single hipGraph (asserted below: "captured in the update's hipGraph"), the parameter broadcast / barriers /
+    max-over-ranks timing all run and the line carries the per-rank times.  A one-rank all-reduce is the identity and Adam's eps is
+    1e-2/(1*B) either way, so the losses must equal those of the plain run bit for bit."""
     import json
     import subprocess
     import sys
@@ -391,6 +392,9 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
     assert dp["last_loss"] == plain["last_loss"], (dp["last_loss"], plain["last_loss"])
     # the exchange goes through the C-ABI (a0_dp_allreduce over RCCL) and is part of the update's single hipGraph
     assert dp["config"]["gradient_exchange"].startswith("RcclGradAllReduce") and "captured" in dp["config"]["gradient_exchange"], dp["config"]["gradient_exchange"]
+    # one JSON line is enough to diagnose a scaling run: the exchange in use and every rank's own step time beside the max-over-ranks one
+    assert dp["gradient_exchange"] == dp["config"]["gradient_exchange"] and len(dp["per_rank_ms_per_step"]["ranks"]) == 1
+    assert 0 < dp["per_rank_ms_per_step"]["min"] <= dp["per_rank_ms_per_step"]["max"] <= dp["ms_per_step"] * 1.02 and plain["per_rank_ms_per_step"] is None
     # ``python bench.py --gpus N`` with no launcher environment: bench.py starts torch.distributed.run itself, as a child (here N = 1)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(A0_DP_FORCE="1", A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
