@@ -36,7 +36,7 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
-from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_ARG, CTL_DONE0, CTL_WORD, N_SCAL, HostSynthSlice, VectorizedSingles, block_layout,  # noqa: F401
+from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_ARG, CTL_DONE0, CTL_WORD, N_SCAL, HostSynthSlice, OffsetSlices, VectorizedSingles, block_layout,  # noqa: F401
                         block_views, ctl_word, record, worker_main)
 
 
@@ -192,6 +192,12 @@ class HostEnvPool:
         return self._obs[half], {}
 
     def step(self, action: torch.Tensor, final_mask: Optional[torch.Tensor] = None, final_ret: Optional[torch.Tensor] = None, ctrl=None):
+        self.step_send(action)
+        return self.step_recv(final_mask, final_ret)
+
+    def step_send(self, action: torch.Tensor):
+        """First half of ``step``: hand the actions to the workers (two DMA copies in stream order) and return at once — the workers step while the caller
+        does something else (``HostEnvGroups``: the other group's inference).  In-process stepping (no workers) does the env step here."""
         self.seq += 1
         self.g += 1
         half = self.seq & 1
@@ -206,7 +212,11 @@ class HostEnvPool:
             ev.record(cur)
             ev.synchronize()                     # in-process stepping has to wait for the action here (worker mode: the workers poll instead)
             record(self._np, half, 0, self.E, *self._local.step(self._np["act"].copy()))
-        else:
+
+    def step_recv(self, final_mask: Optional[torch.Tensor] = None, final_ret: Optional[torch.Tensor] = None):
+        """Second half of ``step``: wait for the workers (CPU work only), enqueue the upload, return the device tensors."""
+        half = self.seq & 1
+        if self.W != 0:
             self._wait_workers()                 # CPU work only: the env steps themselves
         self._upload(half, scalars=True)
         sc = self._scal_d[half]
@@ -219,6 +229,8 @@ class HostEnvPool:
         return self._obs[half], sc[0], sc[1], sc[2], info
 
     def close(self):
+        if getattr(self, "_np", None) is None and not self._procs and self._local is None:
+            return
         if self._local is not None:
             self._local.close()
             self._local = None
@@ -247,3 +259,52 @@ class HostEnvPool:
             self.close()
         except Exception:      # noqa: BLE001 — interpreter shutdown
             pass
+
+
+class HostEnvGroups:
+    """The vector env as ``groups`` consecutive ranges of envs, each a ``HostEnvPool`` of its own (own workers, own page-locked ring, own copy stream), so that
+    the actor can step one group on the CPU while the GPU infers the other — what the reference gets from running ``num_actors`` actor processes beside each
+    other (agent0/deepq/launch.py:30-61, 166-172), without giving up the single replay ring and its transition order: the actor writes group g's transitions of
+    step t to the slots a one-group rollout would have used (``Actor._rollout_groups``), so the ring holds the same bytes in the same order.
+    Worker processes are divided between the groups (at least one each)."""
+
+    def __init__(self, make_slice: Callable[[int, int], object], num_envs: int, groups: int = 2, num_workers: int = 4, ops=None, **kw):
+        if ops is None:
+            from agent0_amd.ops import HipOps
+            ops = HipOps()
+        groups = int(groups)
+        if groups < 2 or num_envs < groups:
+            raise ValueError("HostEnvGroups: at least two groups of at least one env each")
+        self.ops, self.E = ops, int(num_envs)
+        bounds = [round(i * self.E / groups) for i in range(groups + 1)]
+        per = 0 if num_workers == 0 else max(1, int(num_workers) // groups)
+        self.offsets = bounds[:-1]
+        self.pools = [HostEnvPool(OffsetSlices(make_slice, bounds[i]), bounds[i + 1] - bounds[i], num_workers=per, ops=ops, **kw) for i in range(groups)]
+        p0 = self.pools[0]
+        self.obs_shape, self.obs_bytes, self.action_dim = p0.obs_shape, p0.obs_bytes, p0.action_dim
+        self.observation_space = _Space(shape=(self.E,) + self.obs_shape)
+        self.action_space = _Space(n=self.action_dim)
+        self.has_life_loss = p0.has_life_loss
+
+    @property
+    def full_uploads(self):
+        return sum(p.full_uploads for p in self.pools)
+
+    @property
+    def pcie_bytes_per_step(self):
+        return sum(p.pcie_bytes_per_step for p in self.pools)
+
+    @property
+    def newest_frame(self):
+        return self.pools[0].newest_frame
+
+    def reset(self, **kw):
+        seed = kw.get("seed")
+        out = []
+        for p, off in zip(self.pools, self.offsets):
+            out.append(p.reset(**({} if seed is None else {"seed": int(seed) + off}))[0])
+        return out, {}
+
+    def close(self):
+        for p in self.pools:
+            p.close()

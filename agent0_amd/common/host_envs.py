@@ -322,3 +322,14 @@ class AtariSlice:
         return VectorizedSingles([self.single(e0 + i) for i in range(k)], clip_reward=True, seeds=[self.seed + e0 + i for i in range(k)])
 
 
+
+
+class OffsetSlices:
+    """``make_slice`` of one group of a larger vector env (env_pool.HostEnvGroups): local env range [lo, lo + k) -> global range [e0 + lo, e0 + lo + k).
+    Lives here, in the numpy-only module, because worker processes unpickle it."""
+
+    def __init__(self, make_slice, e0: int):
+        self.make_slice, self.e0 = make_slice, int(e0)
+
+    def __call__(self, lo: int, k: int):
+        return self.make_slice(self.e0 + lo, k)

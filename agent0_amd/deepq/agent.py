@@ -43,7 +43,7 @@ class Actor:
         self.ops = ops = model.ops if model is not None else _ops_from(cfg, ops)
         self.rng = DeviceRng(ops, cfg.seed, rank)
         self.envs = envs if envs is not None else make_atari(cfg.env_id, cfg.actor.num_envs, seed=cfg.seed, rank=rank, ops=ops, task=cfg.env_task)
-        self.obs, _ = self.envs.reset()
+        self.obs, _ = self.envs.reset()             # a list of per-group observations for a grouped host env (env_pool.HostEnvGroups)
         self.model = model if model is not None else DeepQNet(cfg, ops=ops)
         self.replay = replay
         self.L = self.model.L
@@ -94,6 +94,22 @@ class Actor:
         self.fused_commit = hasattr(self.envs, "step_commit") and (self.obs_bytes == 4 * 84 * 84)
         # scalar heads on the synthetic env: the tail and the env step share one launch (a0_actor_qhead_env_step)
         self.tail_env = (self.fused_tail or self.dist_tail) and self.fused_commit and hasattr(self.envs, "act_step_commit") and os.environ.get("A0_TAIL_ENV", "1") != "0"      # 0: tuning aid (same bytes)
+        # a host env split into groups (env_pool.HostEnvGroups): per-group workspaces and n-step state; the CPU steps one group while the GPU infers the other
+        self.groups = None
+        if hasattr(self.envs, "pools"):
+            if not (self.fused_tail or self.dist_tail) or cfg.learner.noisy_net:
+                raise ValueError("a grouped host env needs a scalar or distributional head without NoisyNet (per-step noise resets and the quantile heads' tau draws are "
+                                 "ordered over the whole env batch); use one group")
+            self.groups = []
+            for pool, off in zip(self.envs.pools, self.envs.offsets):
+                k = pool.E
+                g = dict(pool=pool, off=off, E=k, ws=Workspace(ops, self.L, k, 1), action=self.action[off:off + k],
+                         ring_act=ops.zeros(self.n * k, dtype=torch.int32), ring_rew=ops.zeros(self.n * k), ring_done=ops.zeros(self.n * k),
+                         out_act=ops.zeros(k, dtype=torch.int32), out_rew=ops.zeros(k), out_done=ops.zeros(k),
+                         scratch=ops.empty(ops.actor_qhead_scratch(k, self.L.feat)) if self.fused_tail else None,
+                         slabs=ops.empty(ops.dense_fwd_partial_slabs(k, self.L.Npad, 512) * k * self.L.Npad) if self.dist_tail else None,
+                         ring_obs=ops.zeros(self.ring_len * k * self.obs_bytes, dtype=torch.uint8) if self.n > 1 else None)
+                self.groups.append(g)
 
     # ------------------------------------------------------------------ agent.py:25-39
     def _qhead_args(self, epsilon, ctrl, eps_ptr, t):
@@ -225,6 +241,60 @@ class Actor:
         if self.fused_tail or self.dist_tail or (self.quant_tail and bound and not test and self.fused_commit):
             ops.mean_rows(self.qmax_all, T, E, self.qs)          # per-step mean max-Q (agent.py:38,88), all steps at once
 
+    # ------------------------------------------------------------------ grouped host envs: CPU stepping of one group beside the GPU's inference of the other
+    def _group_infer_send(self, g, obs, epsilon, t, offs):
+        """Actor.act for group ``g`` on its observations (agent.py:25-39), then the actions go to the group's workers without waiting for them."""
+        L, ops, dev, rng, k, off = self.L, self.ops, self.model._dev, self.rng, g["E"], g["off"]
+        E = self.E
+        dev.encode(g["ws"], obs, None, self.obs_bytes, 0, k, keep=False)
+        qmax = self.qmax_all[t * E + off:t * E + off + k]
+        if self.fused_tail:
+            (W1, b1), (W2, b2) = dev.wb("fc1"), dev.wb("head")
+            ops.actor_qhead(g["ws"].act3, k, L.feat, W1, b1, W2, b2, L.A, L.dueling, g["scratch"], rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
+                            offs[0] + off, offs[1] + off, float(epsilon), g["action"], qmax)
+        else:
+            dev._dense(g["ws"].act3, L.feat, "fc1", g["ws"].h, k, True)
+            Wh, bh = dev.wb("head")
+            ns = ops.dense_fwd_partial(g["ws"].h, 512, Wh, k, L.Npad, 512, g["slabs"])
+            ops.actor_dist_tail(g["slabs"], ns, bh, L.Npad, L.A, L.T, L.dueling, 2 if L.algo == "c51" else 1, self.atoms, k, rng.seed, rng.STREAM_EGREEDY_A,
+                                rng.STREAM_EGREEDY_U, offs[0] + off, offs[1] + off, float(epsilon), g["action"], qmax)
+        g["pool"].step_send(g["action"])
+
+    def _rollout_groups(self, epsilon, T, start):
+        """Actor.sample's loop (agent.py:48-88) over a grouped host env: while group A's worker processes step their envs, the GPU runs Actor.act for group B,
+        and vice versa (the overlap the reference gets from ``num_actors`` actor processes, launch.py:30-61).  Every env sees exactly what it would see in
+        a one-group rollout — its own observations, the epsilon-greedy draws at its own offset of the step's Philox block, its own n-step window — and
+        group g's transitions of step t land in the ring slots [start + t E + off_g, ...): the same bytes in the same order (tests/test_gpu_trainer.py)."""
+        cfg, ops, E, rng, rp = self.cfg, self.ops, self.E, self.rng, self.replay
+        R, gamma = self.ring_len, float(cfg.learner.discount)
+        reserve = lambda: (rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E))
+        offs = reserve()
+        for gi, g in enumerate(self.groups):                      # step 0's actions: nothing to overlap with yet
+            self._group_infer_send(g, self.obs[gi], epsilon, 0, offs)
+        for t in range(T):
+            nxt_offs = reserve() if t + 1 < T else None
+            for gi, g in enumerate(self.groups):
+                k, off = g["E"], g["off"]
+                cur_obs = self.obs[gi]
+                if self.n > 1:
+                    slot = self.steps % R
+                    g["ring_obs"][slot * k * self.obs_bytes:(slot + 1) * k * self.obs_bytes].copy_(cur_obs)
+                    oldest = (self.steps - (min(self.steps + 1, self.n) - 1)) % R
+                    obs0 = g["ring_obs"][oldest * k * self.obs_bytes:(oldest + 1) * k * self.obs_bytes]
+                else:
+                    obs0 = cur_obs
+                sl = slice(t * E + off, t * E + off + k)
+                obs_next, reward, terminal, truncated, info = g["pool"].step_recv(self.stat_mask[sl], self.stat_ret[sl])      # waits for THIS group's workers only
+                ops.actor_nstep(k, self.n, self.steps, gamma, g["action"], reward, terminal, truncated, info.get("life_loss"), g["ring_act"], g["ring_rew"], g["ring_done"],
+                                g["out_act"], g["out_rew"], g["out_done"], None)
+                ops.replay_insert(rp.frames, rp.size, self.obs_bytes, (start + t * E + off) % rp.size, k, obs0, obs_next, g["out_act"], g["out_rew"], g["out_done"],
+                                  rp.act, rp.rew, rp.done, None)
+                self.obs[gi] = obs_next
+                if nxt_offs is not None:                            # the next step's actions for this group, while the other group's workers are stepping
+                    self._group_infer_send(g, obs_next, epsilon, t + 1, nxt_offs)
+            self.steps += 1
+        ops.mean_rows(self.qmax_all, T, E, self.qs)
+
     def _graph_eligible(self, T, bound, test, state_dict) -> bool:
         cfg = self.cfg
         return (self.use_graph and bound and not test and state_dict is None and hasattr(self.envs, "_cur") and T % len(self.envs._obs) == 0
@@ -297,7 +367,11 @@ class Actor:
                                     "act": ops.zeros(T * E, dtype=torch.int32), "rew": ops.zeros(T * E), "done": ops.zeros(T * E)}
         start = self.replay.write_cursor() if bound else 0
         frames_out = []
-        if self._graph_eligible(T, bound, test, state_dict):
+        if self.groups is not None:
+            if not bound:
+                raise NotImplementedError("a grouped host env serves training rollouts into a replay ring (test / staged rollouts: use one group)")
+            self._rollout_groups(epsilon, T, start)
+        elif self._graph_eligible(T, bound, test, state_dict):
             self._rollout_graphed(epsilon, T, start)
         else:
             self._rollout(epsilon, T, start, bound, test, st, frames_out)

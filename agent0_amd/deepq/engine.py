@@ -542,28 +542,29 @@ class DeviceLearner:
             # one launch for everything behind them (a0_c51_head_loss_slabs: slab sums, dueling, greedy next action, projection + cross entropy, head gradient)
             dq_ = self.double_q
             ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
+            R_on = 2 * B if dq_ else B
+            ns_on = ops.dense_fwd_partial_slabs(R_on, 512, L.feat)
             if getattr(self, "_c51_buf", None) is None:
-                R_on = 2 * B if dq_ else B
                 nh_on, nh_tg = ops.dense_fwd_partial_slabs(R_on, L.Npad, 512), ops.dense_fwd_partial_slabs(B, L.Npad, 512)
-                self._c51_buf = dict(fc1=[ops.empty(ns * B * 512) for _ in range(3 if dq_ else 2)], h_on=ops.empty(R_on * 512),
+                self._c51_buf = dict(fc1_on=ops.empty(ns_on * R_on * 512), fc1_tg=ops.empty(ns * B * 512), h_on=ops.empty(R_on * 512), act3_on=ops.empty(R_on * L.feat),
                                      hs_on=ops.empty(nh_on * R_on * L.Npad), hs_tg=ops.empty(nh_tg * B * L.Npad), R_on=R_on)
                 wo.h = self._c51_buf["h_on"][: B * 512]                  # h(s) of the online network: what the backward pass reads
+                # the online network's features of s and (double-Q) of s' back to back: fc1 and the head run over both as ONE GEMM each (same weights)
+                wo.act3 = self._c51_buf["act3_on"][: B * L.feat]
+                if dq_:
+                    wsel.act3 = self._c51_buf["act3_on"][B * L.feat:]
             buf = self._c51_buf
             (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
             (Wh_o, bh_o), (Wh_t, bh_t) = on.wb("head"), tg.wb("head")
-            s_tg = buf["fc1"][1]
+            s_tg = buf["fc1_tg"]
             self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if dq_ else []) + [(on, wo, 0, True)])
             if tstage is None:
                 ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
             else:
                 s_tg = self._tstage_buf(tstage)[1]
-            layers = [(buf["fc1"][0], ns, bf_o, buf["h_on"][: B * 512], B), (s_tg, ns, bf_t, wt.h, B)]
-            if dq_:
-                ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][2])
-                layers.append((buf["fc1"][2], ns, bf_o, buf["h_on"][B * 512:], B))
-            ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, buf["fc1"][0])
+            ops.dense_fwd_partial(buf["act3_on"], L.feat, Wf_o, R_on, 512, L.feat, buf["fc1_on"])
+            layers = [(buf["fc1_on"], ns_on, bf_o, buf["h_on"], R_on), (s_tg, ns, bf_t, wt.h, B)]
             ops.reduce_bias_act_multi(layers, 512, True)
-            R_on = buf["R_on"]
             nh_on = ops.dense_fwd_partial(buf["h_on"], 512, Wh_o, R_on, L.Npad, 512, buf["hs_on"])
             nh_tg = ops.dense_fwd_partial(wt.h, 512, Wh_t, B, L.Npad, 512, buf["hs_tg"])
             ops.c51_head_loss_slabs(buf["hs_on"], nh_on, R_on, buf["hs_tg"], nh_tg, B if dq_ else -1, bh_o, bh_t, L.Npad, L.A, L.T, L.dueling, act, rew, done, wgt,

@@ -298,6 +298,43 @@ def test_host_env_pool_matches_device_env(workers, newest):
     assert float(outs[0][3].sum()) > 0, "the run contains done flags (life losses), so the flag path is exercised"
 
 
+@pytest.mark.parametrize("algo,n_step,workers,groups", [("dqn", 3, 4, 2), ("dqn", 1, 0, 2), ("c51", 1, 6, 3), ("dqn", 3, 2, 2)])
+def test_grouped_host_env_rollouts_match_the_device_env(algo, n_step, workers, groups):
+    """Round 4 (N1): env_pool.HostEnvGroups splits the host vector env into groups with their own worker processes; the actor steps one group on the CPU while the
+    GPU infers the other (Actor._rollout_groups — what the reference gets from num_actors actor processes, launch.py:30-61).  Every env must see exactly what it
+    sees in a one-group rollout: replay rows (bytes, actions, n-step rewards, dones) in the same slots, episode returns in the same order and per-step max-Q equal
+    to those of the DEVICE-resident env, for scalar and distributional heads, n-step 1 and 3, uneven groups (8 envs in 3 groups) and in-process stepping."""
+    import host_slices
+    from agent0_amd.common.env_pool import HostEnvGroups
+    from agent0_amd.deepq.agent import Actor
+    from agent0_amd.deepq.model import DeepQNet
+    from agent0_amd.deepq.replay import ReplayDataset
+    E = 8
+    outs = []
+    spec = recipe.NetSpec(algo, 4)
+    for host in (False, True):
+        cfg = make_cfg(algo, E, **{"learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 300, "learner.batch_size": 8})
+        model = DeepQNet(cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(spec, 11).items()})
+        replay = ReplayDataset(cfg, ops=model.ops)
+        envs = HostEnvGroups(host_slices.synth_slice(cfg.seed, 0), E, groups=groups, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops) if host else None
+        actor = Actor(cfg, model, replay=replay, rank=0, envs=envs)
+        assert (actor.groups is not None) == host
+        rs_all, qs_all = [], []
+        for _ in range(5):
+            data, rs, qs = actor.sample(0.3)
+            replay.extend(data)
+            rs_all += rs
+            qs_all += qs
+        n = 5 * 6 * E
+        outs.append((replay.frames[: n * replay.row_bytes].clone(), replay.act[:n].clone(), replay.rew[:n].clone(), replay.done[:n].clone(), rs_all, qs_all))
+        actor.close()
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5]
+    assert float(outs[0][3].sum()) > 0
+
+
 @pytest.mark.parametrize("algo,extra", [("dqn", []), ("c51", ["learner.noisy_net=true", "learner.n_step_q=3", "replay.policy=prioritize"])])
 def test_launch_mode_overlap_is_race_free(algo, extra):
     """Trainer(use_lp=True) — the launch.py schedule: rollout k+1 with a weight snapshot runs on a second stream while the update block

@@ -1,7 +1,8 @@
 """PCIe-inclusive throughput of the host-environment front-end (env_pool.HostEnvPool) on BASELINE configs[1]'s shapes: 256 envs x 80 steps
 per rollout, Breakout dqn, observations stepped on the host by worker processes, uploaded through the page-locked ring.  Prints one JSON
 line: actor-only env-frames/s, the full iteration (rollout + 20 updates of batch 512) and the bytes that cross PCIe per step.
-usage: python tools/bench_host_env.py [workers] [iterations] [device_frame_stack 1|0]"""
+usage: python tools/bench_host_env.py [workers] [iterations] [device_frame_stack 1|0] [groups]      (groups >= 2: env_pool.HostEnvGroups — the CPU steps one group
+while the GPU infers the other)"""
 import json
 import os
 import sys
@@ -11,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 
-from agent0_amd.common.env_pool import HostEnvPool, HostSynthSlice
+from agent0_amd.common.env_pool import HostEnvGroups, HostEnvPool, HostSynthSlice
 from agent0_amd.deepq import agent as agents
 from agent0_amd.deepq.config import parse_overrides
 from agent0_amd.deepq.trainer import Trainer
@@ -20,11 +21,13 @@ def main():
     workers = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     newest = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+    groups = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     cfg = parse_overrides(["env_id=Breakout", "actor.num_envs=256", "replay.size=100000", "learner.batch_size=512", "wandb=false", "tb=false",
                            f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}"])
     cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
     tr = Trainer(cfg)
-    pool = HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops, newest_frame=newest)
+    pool = (HostEnvGroups(HostSynthSlice(cfg.seed), 256, groups=groups, num_workers=workers, ops=tr.ops, newest_frame=newest) if groups > 1 else
+            HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops, newest_frame=newest))
     tr.actors[1] = agents.Actor(cfg, tr.learner.model, replay=tr.replay, ops=tr.ops, rank=0, envs=pool)
     start = cfg.trainer.training_start_steps
     cfg.trainer.training_start_steps = 1 << 62
@@ -36,7 +39,7 @@ def main():
     torch.cuda.synchronize()
     t_act = (time.time() - t0) / iters
     whole = (pool.full_uploads - whole0) / (iters * cfg.actor.sample_steps)
-    per_step = pool.pcie_bytes_per_step + whole * pool.obs_bytes
+    per_step = pool.pcie_bytes_per_step + whole * (pool.obs_bytes if groups == 1 else pool.pools[0].obs_bytes)
     cfg.trainer.training_start_steps = 1000
     for _ in range(3):
         tr.run_iteration()
@@ -47,7 +50,7 @@ def main():
     torch.cuda.synchronize()
     t_full = (time.time() - t0) / iters
     n = cfg.actor.sample_steps * cfg.actor.num_envs
-    print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "host_cores": os.cpu_count(),
+    print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "groups": groups, "host_cores": os.cpu_count(),
                       "device_frame_stack": pool.newest_frame, "whole_stack_uploads_per_step": round(whole, 3),
                       "actor_only_env_frames_per_sec": round(n / t_act, 1), "actor_only_ms_per_rollout": round(1e3 * t_act, 2),
                       "iteration_env_frames_per_sec": round(n / t_full, 1), "iteration_ms": round(1e3 * t_full, 2),
