@@ -395,8 +395,12 @@ def main():
     try:      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
         traffic_file = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # newest round
         pm = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["per_launch"]
-        n_act, n_lrn = cfg.actor.sample_steps, 2 * cfg.learner.learner_steps
-        traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["512"]["hbm_bytes"]) / (n_act + n_lrn))
+        if "1024" in pm:      # round 4: the update's two forward passes (target on s', online on s: 2 x 512 observations) are ONE launch
+            n_act, n_lrn = cfg.actor.sample_steps, cfg.learner.learner_steps
+            traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["1024"]["hbm_bytes"]) / (n_act + n_lrn))
+        else:
+            n_act, n_lrn = cfg.actor.sample_steps, 2 * cfg.learner.learner_steps
+            traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["512"]["hbm_bytes"]) / (n_act + n_lrn))
     except Exception:
         pass
     if pr is not None and pr["launches"] and pr["ms"] > 0:
@@ -421,7 +425,7 @@ def main():
                                         "; `frac` above counts every MAC once against the fp32 MFMA peak"},
                 "traffic_note": ("not measured for this kernel (traffic is null)" if traffic is None else f"NOT measured in this run: mean HBM bytes per launch of the family (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_quantile.sh), read from profiles/{traffic_file}") if not enc else f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
                                 f"at --replay-size 100000 --steps 2 (tools/refresh_profiles.sh), read from profiles/{traffic_file}; "
-                                "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB (512 obs); the learner's online pass also stores act1/act2 for the backward pass",
+                                "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB per 512 obs (the learner's two passes of an update share one launch of 1024); the learner's online pass also stores act1/act2 for the backward pass",
                 "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation; u8 input, activations in LDS, weights streamed through registers; "
                           "all layers on v_mfma_f32_16x16x32_bf16 with operands split exactly into bf16 terms (bytes x 3 weight terms; 3 activation x 3 weight terms), fp32 accumulation; "
                           "FLOPs counted once, peak = fp32 MFMA, the bound of the fp32-chain variant A0_NO_X9=1)"
@@ -430,7 +434,7 @@ def main():
                           "the cosine embedding 3136 x 64 runs in the store-bound a0_short_k_fwd_kernel and is not part of this family; both fp32 operands split exactly into three bf16 terms, nine v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation; "
                           "FLOPs = 2*M*N*K counted once, peak = fp32 MFMA)",
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
-                "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor) or 512 (learner) observations"
+                "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor launch) or x 1024 (learner launch: the update's target and online passes of 512 observations in one launch; 1536 with double-Q)"
                                                if pr["kernel"] == "encoder_fused" else f"2*M*N*K per launch; {pr['flop'] / max(pr['launches'], 1) / 1e9:.2f} GFLOP average over the launch mix",
                 "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off",
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}

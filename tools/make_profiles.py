@@ -55,7 +55,7 @@ traffic = {
     "calibration": calib,
     "per_launch": {},
 }
-for n_obs, grid in ((256, 256 * 512), (512, "loop")):       # "loop": the looping instantiation, which the bench uses for its 512-observation launches only
+for n_obs, grid in ((256, 256 * 512), (512, "loop"), (1024, "multi")):       # "loop": the looping instantiation (one pass of 512); "multi": round 4, the update's two passes of 512 in one launch
     r, w = kb(f"enc:{grid}", "FETCH_SIZE"), kb(f"enc:{grid}", "WRITE_SIZE")
     if r is None or w is None:
         continue
@@ -63,7 +63,8 @@ for n_obs, grid in ((256, 256 * 512), (512, "loop")):       # "loop": the loopin
         "observations": n_obs, "hbm_read_bytes": 2 * r, "hbm_write_bytes": w, "hbm_bytes": 2 * r + w,
         "algorithmic_bytes_min": n_obs * (OBS + 49 * 64 * 4) + 470016,
         "note": "actor launches: observations in (7.2 MB), conv features out (3.2 MB, exact), bf16-term weights (0.47 MB, fetched once per XCD L2)" if n_obs == 256 else
-                "learner launches, average of the online pass (also stores act1/act2 for the backward pass: +36.8 MB) and the target pass (features only)"}
+                ("learner launches, average of the online pass (also stores act1/act2 for the backward pass: +36.8 MB) and the target pass (features only)" if n_obs == 512 else
+                 "learner launches since round 4: the target pass on s' (features only) and the online pass on s (also stores act1/act2 for the backward pass: +36.8 MB) in ONE launch")}
 r, w = kb(f"dgrad:{256 * 512}", "FETCH_SIZE"), kb(f"dgrad:{256 * 512}", "WRITE_SIZE")        # 256 looping workgroups for 512 observations
 if r is not None and w is not None:
     traffic["dgrad_per_launch_512"] = {"hbm_read_bytes": 2 * r, "hbm_write_bytes": w,

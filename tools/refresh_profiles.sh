@@ -18,10 +18,11 @@ for name in ("fetch", "write"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            key = ("enc" if "a0_encoder_fused_kernel" in k else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else
+            key = ("enc" if ("a0_encoder_fused_kernel" in k or "a0_encoder_fused_multi_kernel" in k) else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else
                    "gather" if "a0_sample_gather_kernel" in k else "qenv" if "a0_actor_qhead_env_kernel" in k else None)
             gs = r["Grid_Size"]
-            if key == "enc" and looping(k): gs = "loop"          # the looping instantiation (launches of more observations than CUs: the learner's 512)
+            if key == "enc" and "a0_encoder_fused_multi_kernel" in k: gs = "multi"     # round 4: the learner's forward passes of one update in one launch (2 x 512 observations for dqn)
+            elif key == "enc" and looping(k): gs = "loop"          # the looping instantiation (launches of more observations than CUs: the learner's 512)
             if key: acc[(key, gs)][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for (key, gs), d in sorted(acc.items()):
             for c, v in d.items():
@@ -32,8 +33,8 @@ per = collections.defaultdict(list)
 for f in glob.glob(f"gpurun_out/{R}/prof/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "a0_encoder_fused_kernel" in k or "a0_encoder_dgrad_fused" in k:
-            per[(k.split("(")[0][:48], "loop" if ("a0_encoder_fused_kernel" in k and looping(k)) else r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        if "a0_encoder_fused_kernel" in k or "a0_encoder_dgrad_fused" in k or "a0_encoder_fused_multi_kernel" in k:
+            per[(k.split("(")[0][:48], "multi" if "a0_encoder_fused_multi_kernel" in k else "loop" if ("a0_encoder_fused_kernel" in k and looping(k)) else r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tr = {f"{k}|grid={g}": {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)} for (k, g), v in per.items()}
 json.dump(tr, open(f"gpurun_out/{R}/fused_by_grid.json", "w"), indent=1)
 print(json.dumps(tr, indent=1))
