@@ -67,7 +67,7 @@ extern "C" int a0_adam_step(float* params, const float* grads, float* exp_avg, f
 // (update_steps BEFORE this step) and the data-parallel flag — words nobody writes during this kernel — and workgroup 0 publishes them:
 // state[2..4] as the prep kernel does, the scalars, and the NEW step count in state[5].  state[1] <- state[5] and state[0] <- 0 are
 // committed by the next kernel on the stream (a0_conv_wt_kernel with `commit`), because other workgroups of this one may still have to read them.
-struct a0_adam_fold { double lr, b1, b2; int target_freq; const float* extra_flag; int* state_w; float* scal_w; };
+struct a0_adam_fold { double lr, b1, b2; int target_freq; const float* extra_flag; int* state_w; float* scal_w; const float* loss; int loss_n; float* loss_ring; int ring_cap; };
 template <bool FOLD>
 __global__ void a0_adam_sync_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                     long long n, const int* __restrict__ state, const float* __restrict__ scal,
@@ -77,6 +77,18 @@ __global__ void a0_adam_sync_kernel(float* __restrict__ p, const float* __restri
     if constexpr (FOLD) {
         __shared__ float sh_f[2];
         __shared__ int sh_i[2];
+        // round 4: workgroup 0 also takes the batch mean of this update's per-sample losses (the Trainer's `loss` statistic, trainer.py:99,111-113) into a ring
+        // slot indexed by the free-running call counter state[6] — the same reduction, statement for statement, as a0_mean_rows_kernel, whose launch per update
+        // (4.8 us of pure latency) it replaces; skipped steps are recorded too (their mean is whatever the loss kernel wrote, NaN included)
+        if (blockIdx.x == 0 && F.loss) {
+            __shared__ float red[256];
+            float s = 0.f;
+            for (int e = threadIdx.x; e < F.loss_n; e += 256) s += F.loss[e];
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+            if (threadIdx.x == 0) { const int c = F.state_w[6]; F.loss_ring[c % F.ring_cap] = red[0] / (float)F.loss_n; F.state_w[6] = c + 1; }
+        }
         if (threadIdx.x == 0) {
             const int sk = (state[0] != 0) || (F.extra_flag && F.extra_flag[0] != 0.f);
             const int steps = state[1] + (sk ? 0 : 1);
@@ -152,7 +164,7 @@ extern "C" int a0_adam_step_sync(float* params, const float* grads, float* exp_a
     long long blocks = ((vec4 ? n_total / 4 : n_total) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(a0_adam_sync_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, state, scalars,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4, a0_adam_fold{});
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4, a0_adam_fold{0.0, 0.0, 0.0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1});
     return a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync");
 }
 
@@ -162,9 +174,11 @@ extern "C" int a0_adam_step_sync(float* params, const float* grads, float* exp_a
 int a0_conv_wt_refresh_commit(const a0_encoder_weights* w, int C, float* wt, float* wt_target, int* state, hipStream_t st);      // encoder_fused.hip
 extern "C" int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars,
                                     double lr, double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total,
-                                    const float* extra_nan_flag, const a0_encoder_weights* w, int C, float* wt, float* wt_target, void* stream) {
+                                    const float* extra_nan_flag, const a0_encoder_weights* w, int C, float* wt, float* wt_target, const float* loss, int loss_n,
+                                    float* loss_ring, int ring_cap, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !state || !scalars || !target || n < 1 || n_total < n || !w || !wt || !wt_target || C < 1)
         return a0_fail(A0_EINVAL, "a0_adam_step_sync_wt: bad argument");
+    if (loss && (!loss_ring || loss_n < 1 || ring_cap < 1)) return a0_fail(A0_EINVAL, "a0_adam_step_sync_wt: loss statistics need a ring of at least one slot");
     hipStream_t st = (hipStream_t)stream;
     const int vec4 = ((n | n_total) % 4 == 0) &&
                      ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq) | ((uintptr_t)target)) % 16 == 0);
@@ -172,7 +186,7 @@ extern "C" int a0_adam_step_sync_wt(float* params, const float* grads, float* ex
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(a0_adam_sync_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (const int*)state, (const float*)scalars,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, target, n_total, vec4,
-                       a0_adam_fold{lr, beta1, beta2, target_update_freq, extra_nan_flag, state, scalars});
+                       a0_adam_fold{lr, beta1, beta2, target_update_freq, extra_nan_flag, state, scalars, loss, loss_n, loss_ring, ring_cap > 0 ? ring_cap : 1});
     int e = a0_fail_hip((int)hipGetLastError(), "a0_adam_step_sync_wt");
     if (e != A0_OK) return e;
     return a0_conv_wt_refresh_commit(w, C, wt, wt_target, state, st);

@@ -425,6 +425,9 @@ class BaseLearner:
         self._ones = torch.ones(B, device=ops.device)
         self.use_graph = True
         self._graphs, self._graph_warm = {}, {}
+        # updates issued through this learner (eager or replayed): the device keeps the same count in state[6] and files each update's mean loss under it
+        # (DeviceLearner.loss_ring), so the Trainer can read a block's means back in one copy
+        self.updates_issued = 0
 
     @property
     def update_steps(self) -> int:
@@ -477,6 +480,7 @@ class BaseLearner:
         torch.distributed fallback) splits the update into three graphs — forward + dense backward | encoder backward | optimizer step —
         around its eager calls."""
         eng = self.engine
+        self.updates_issued += 1
         if not self.use_graph:
             return eng.update(frames, slot, row_bytes, act, rew, done, weights, rand=rand, tstage=tstage)
         hooked = eng.grad_hook is not None and not getattr(eng.grad_hook, "in_graph", False)

@@ -282,6 +282,8 @@ class DeviceLearner:
         self.adam_v = ops.zeros(L.n_params_padded)
         self.state = ops.zeros(8, dtype=torch.int32)
         self.scalars = ops.zeros(4)
+        # batch means of the last 1024 updates' per-sample losses, written by the Adam launch itself (a0_adam_step_sync_wt: ring slot = state[6] % 1024)
+        self.loss_ring = ops.zeros(1024)
         self.discount, self.n_step, self.double_q = discount, n_step, double_q
         self.gamma_n = float(discount ** n_step)
         self.lr, self.target_update_freq = lr, target_update_freq
@@ -435,7 +437,7 @@ class DeviceLearner:
         if on.fused:
             # two launches: Adam with its bookkeeping and the target copy folded in; the online conv copies, mirrored to the target's on a sync
             ops.adam_step_sync_wt(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
-                                  self.target_update_freq, tg.flat, L.n_params_padded, tail, on.encoder_weights(), L.C, on.wt, tg.wt)
+                                  self.target_update_freq, tg.flat, L.n_params_padded, tail, on.encoder_weights(), L.C, on.wt, tg.wt, self.loss, self.B, self.loss_ring)
         else:
             ops.adam_step_sync(on.flat, self.grads, self.adam_m, self.adam_v, L.n_adam, self.state, self.scalars, self.lr, 0.9, 0.999, self.adam_eps,
                                self.target_update_freq, tg.flat, L.n_params_padded, tail)

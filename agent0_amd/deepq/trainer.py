@@ -146,6 +146,7 @@ class Trainer:
                 eng.rms_sq.copy_(blob["rms_sq"])
             self.frame_count = int(blob.get("frame_count", 0))
             self._updates_done = None
+            self.learner.updates_issued = int(eng.state[6])      # the device's count of loss-ring entries travels with the state block
 
     # ------------------------------------------------------------------ trainer.py:74-119
     def step(self, transitions, returns, qmax):
@@ -162,6 +163,7 @@ class Trainer:
         self.frame_count += self.num_transitions
         n_upd = 0
         has_frac = False
+        self._ring0 = None
         if len(self.replay) > cfg.trainer.training_start_steps and self._pipeline_ok():
             n_upd = self._update_block_pipelined()
         elif len(self.replay) > cfg.trainer.training_start_steps:
@@ -169,19 +171,21 @@ class Trainer:
             if self._loss_means.numel() < cfg.learner.learner_steps:       # learner_steps changed after construction
                 self._loss_means = self.ops.zeros(cfg.learner.learner_steps)
                 self._floss_means = self.ops.zeros(cfg.learner.learner_steps)
+            ring0 = self._loss_ring_start()
             for i in range(cfg.learner.learner_steps):
                 b = rp.sample()
                 q_loss, f_loss = self.learner.train_batch(rp.frames, b.slot, rp.row_bytes, b.act, b.rew, b.done, b.weights)
                 if cfg.replay.policy == ReplayEnum.prioritize:
                     rp.update_priority(b.idx, q_loss, state=self.learner.engine.state)
                 B = cfg.learner.batch_size
-                self.ops.mean_rows(q_loss, 1, B, self._loss_means[i:i + 1])      # one launch; read back once per update block
+                if ring0 is None:
+                    self.ops.mean_rows(q_loss, 1, B, self._loss_means[i:i + 1])      # one launch; read back once per update block
                 if f_loss is not None:
                     self.ops.mean_rows(f_loss, 1, B, self._floss_means[i:i + 1])
                     has_frac = True
                 n_upd += 1
         if n_upd:
-            self.Ls.extend(self._loss_means[:n_upd].cpu().tolist())        # the one device->host read of the update block
+            self.Ls.extend(self._block_loss_means(n_upd))                   # the one device->host read of the update block
             # the device's update count (NaN-skipped steps do not count) for the next block's pipelining decision: read here, where the host has just waited
             # for the block anyway, so that the next block can be enqueued behind the rollout without a stop
             self._updates_done = int(self.learner.engine.state[1]) if self._pipeline_candidate() else None
@@ -189,6 +193,23 @@ class Trainer:
                 self.FLs.extend(self._floss_means[:n_upd].cpu().tolist())
 
     # ------------------------------------------------------------------ the update block with the target network's passes one update ahead
+    def _loss_ring_start(self):
+        """The per-update loss means come out of the Adam launch (DeviceLearner.loss_ring, slot = update count % ring length) when the fused optimizer tail runs and
+        the block fits the ring; returns the first slot of the block about to be issued, or None (then a0_mean_rows per update fills ``_loss_means``)."""
+        ln = self.learner
+        eng = ln.engine
+        ring = getattr(eng, "loss_ring", None)
+        ok = (ring is not None and eng.online.fused and hasattr(ln, "updates_issued") and self.cfg.learner.learner_steps <= ring.numel()
+              and "train_batch" not in vars(ln) and os.environ.get("A0_LOSS_RING", "1") != "0")
+        self._ring0 = ln.updates_issued if ok else None
+        return self._ring0
+
+    def _block_loss_means(self, n_upd: int):
+        if getattr(self, "_ring0", None) is None:
+            return self._loss_means[:n_upd].cpu().tolist()
+        ring = self.learner.engine.loss_ring.cpu()
+        return [float(ring[(self._ring0 + i) % ring.numel()]) for i in range(n_upd)]
+
     def _pipeline_candidate(self) -> bool:
         cfg, ln = self.cfg, self.learner
         # OFF by default: measured slower than the strictly serial block on MI355X (profiles/r04_experiments.md) — kept as a tested option
@@ -225,6 +246,7 @@ class Trainer:
             self._mev = torch.cuda.Event()
         self.pipelined_blocks = getattr(self, "pipelined_blocks", 0) + 1
         cur = torch.cuda.current_stream()
+        ring0 = self._loss_ring_start()
         batches = [None, None]
         batches[0] = rp.sample(buf=0)
         ln.target_stage_batch(rp.frames, batches[0].slot, rp.row_bytes, 0)          # the first batch's stage has nothing to hide behind: same stream
@@ -242,7 +264,8 @@ class Trainer:
                 cur.wait_event(self._tev[p])
             b = batches[p]
             q_loss, _ = ln.train_batch(rp.frames, b.slot, rp.row_bytes, b.act, b.rew, b.done, b.weights, tstage=p)
-            self.ops.mean_rows(q_loss, 1, B, self._loss_means[i:i + 1])
+            if ring0 is None:
+                self.ops.mean_rows(q_loss, 1, B, self._loss_means[i:i + 1])
         return L
 
     def _result(self):

@@ -288,14 +288,18 @@ class HipOps:
                                          lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total,
                                          _req(extra_nan_flag, torch.float32, 1, "extra_nan_flag", optional=True), _stream()), "a0_adam_step_sync")
 
-    def adam_step_sync_wt(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag, w, C_, wt, wt_target):
+    def adam_step_sync_wt(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag, w, C_, wt, wt_target, loss=None, loss_n=0,
+                          loss_ring=None):
+        """``loss`` [loss_n] + ``loss_ring``: the Adam launch also writes the batch mean of the per-sample losses to ring slot state[6] % len(ring)."""
         ew = self._enc_w(w)
         nw = self.conv_wt_floats(C_)
         check(self.lib.a0_adam_step_sync_wt(_req(params, torch.float32, n_total, "params"), _req(grads, torch.float32, n, "grads"), _req(m, torch.float32, n, "m"),
                                             _req(v, torch.float32, n, "v"), n, _req(state, torch.int32, 8, "state"), _req(scalars, torch.float32, 2, "scalars"),
                                             lr, b1, b2, eps, target_freq, _req(target, torch.float32, n_total, "target"), n_total,
                                             _req(extra_nan_flag, torch.float32, 1, "extra_nan_flag", optional=True), C.addressof(ew), C_,
-                                            _req(wt, torch.float32, nw, "wt"), _req(wt_target, torch.float32, nw, "wt_target"), _stream()), "a0_adam_step_sync_wt")
+                                            _req(wt, torch.float32, nw, "wt"), _req(wt_target, torch.float32, nw, "wt_target"),
+                                            _req(loss, torch.float32, max(loss_n, 1), "loss", optional=True), int(loss_n), _req(loss_ring, torch.float32, 1, "loss_ring", optional=True),
+                                            0 if loss_ring is None else int(loss_ring.numel()), _stream()), "a0_adam_step_sync_wt")
 
     def nan_flag_export(self, state, out):
         check(self.lib.a0_nan_flag_export(_req(state, torch.int32, 8, "state"), _req(out, torch.float32, 1, "out"), _stream()), "a0_nan_flag_export")

@@ -241,7 +241,8 @@ int a0_fqf_fraction_loss(const float* q, const float* qh, const float* taus, con
                          int ldl, float* loss, float* dlogits, const float* logits, void* stream);
 
 /* ---------------------------------------------------------------- optimizer / target sync (agent.py:102-106,152-161,333-338) */
-/* state: int[8] device block: [0] nan flag (set by losses) [1] update_steps [2] skipped [3] skip_now [4] sync_now [5] scratch of a0_adam_step_sync_wt */
+/* state: int[8] device block: [0] nan flag (set by losses) [1] update_steps [2] skipped [3] skip_now [4] sync_now [5] scratch of a0_adam_step_sync_wt
+ * [6] calls of a0_adam_step_sync_wt with a loss ring (free-running: the ring slot of the next call is state[6] % ring_cap) */
 int a0_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state,
                  float* scalars2, double lr, double beta1, double beta2, double eps, int target_update_freq, void* stream);
 /* a0_adam_step with the target copy of agent.py:160-161 folded into the same pass: when update_steps % target_update_freq == 0 after this
@@ -253,10 +254,11 @@ int a0_adam_step_sync(float* params, const float* grads, float* exp_avg, float* 
 /* The optimizer tail of a network whose convolutions run in the fused kernels, two launches instead of three: a0_adam_step_sync with the step's
  * bookkeeping (NaN skip, step count, bias corrections, "sync now": agent.py:152-161) derived inside the Adam kernel, then
  * a0_net_conv_wt_refresh_sync of the online copies `wt` (mirrored into `wt_target` on a sync step), which also commits the step count.
- * state[5] is scratch.  Same results as the two calls it replaces. */
+ * state[5] is scratch.  Same results as the two calls it replaces.  loss (optional, [loss_n]): the update's per-sample losses; their batch mean — the Trainer's
+ * `loss` statistic, trainer.py:99,111-113, == a0_mean_rows — is written to loss_ring[state[6] % ring_cap] by the Adam launch itself (one launch per update less). */
 int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars2, double lr,
                          double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, const float* extra_nan_flag,
-                         const a0_encoder_weights* w, int C, float* wt, float* wt_target, void* stream);
+                         const a0_encoder_weights* w, int C, float* wt, float* wt_target, const float* loss, int loss_n, float* loss_ring, int ring_cap, void* stream);
 /* data parallelism: this rank's NaN flag as a float (1.0 / 0.0) that rides at the tail of a SUM-reduced gradient bucket; the reduced value
  * comes back through extra_nan_flag (nonzero = some rank saw a NaN: every rank skips the step), NULL on one GPU */
 int a0_nan_flag_export(const int* state, float* out, void* stream);

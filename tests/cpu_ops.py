@@ -364,7 +364,12 @@ class CpuOps:
         self.adam_step(params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq)
         self.target_sync(target, params, n_total, state, False)
 
-    def adam_step_sync_wt(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag, w, C_, wt, wt_target):
+    def adam_step_sync_wt(self, params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag, w, C_, wt, wt_target, loss=None, loss_n=0,
+                          loss_ring=None):
+        if loss is not None:
+            c = int(state[6])
+            loss_ring[c % loss_ring.numel()] = loss[:loss_n].mean()
+            state[6] = c + 1
         self.adam_step_sync(params, grads, m, v, n, state, scalars, lr, b1, b2, eps, target_freq, target, n_total, extra_nan_flag)
         self.conv_wt_refresh_sync(w, C_, wt, wt_target, state)
 

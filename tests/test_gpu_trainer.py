@@ -522,3 +522,26 @@ def test_pipelined_target_pass_changes_no_number(algo, extra, launch, monkeypatc
     assert 3 <= tr1.pipelined_blocks < len(l1) // 5, "some blocks pipelined, the ones with a target sync not"
     assert l0 == l1 and len(l0) == 45
     assert torch.equal(p0, p1) and torch.equal(t0, t1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(f0, f1)
+
+
+@pytest.mark.parametrize("algo", ["dqn", "c51", "iqr"])
+def test_loss_statistic_from_the_adam_launch_equals_mean_rows(algo, monkeypatch):
+    """Round 4: the Trainer's per-update `loss` statistic (trainer.py:99,111-113) is taken by workgroup 0 of the Adam launch into a ring (a0_adam_step_sync_wt,
+    DeviceLearner.loss_ring) instead of by an a0_mean_rows launch per update — the same reduction statement for statement, so the recorded means must be
+    bit-identical, ring wrap-around (1024 slots) aside, and everything else (parameters) untouched."""
+    from agent0_amd.deepq.trainer import Trainer
+
+    def run(ring):
+        monkeypatch.setenv("A0_LOSS_RING", "1" if ring else "0")
+        cfg = make_cfg(algo, 8, **{"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 7, "trainer.training_start_steps": 100,
+                                    "learner.target_update_freq": 5, **({"env_id": "Asterix"} if algo == "iqr" else {})})
+        tr = Trainer(cfg)
+        for _ in range(8):
+            tr.run_iteration()
+        torch.cuda.synchronize()
+        return list(tr.Ls), tr.learner.engine.online.flat.clone(), int(tr.learner.engine.state[6]), tr.learner.updates_issued
+
+    l0, p0, c0, u0 = run(False)
+    l1, p1, c1, u1 = run(True)
+    assert len(l0) == 7 * 7 and l0 == l1 and torch.equal(p0, p1)
+    assert c0 == u0 == c1 == u1 == 49, "the device's ring counter and the host's count of issued updates stay in step"
