@@ -36,7 +36,8 @@ for k in list(pm):
 # measurement); a0_actor_qhead_env_kernel reads 256 observations (7.23 MB) and writes the new stack + the replay row (21.68 MB) per actor step
 calib = {}
 for name, rd, wr, what in (("gather", 512 * 2 * OBS, 512 * 2 * OBS, "a0_sample_gather_kernel: 512 rows x 56 448 B copied"),
-                           ("qenv", E256 * OBS, E256 * 3 * OBS, "a0_actor_qhead_env_kernel: 256 observations read, new stacks + replay rows written")):
+                           ("qenv", E256 * OBS + 8 * E256 * 512 * 4, E256 * 3 * OBS, "a0_actor_qhead_env_kernel: 256 observations + the fc1 GEMM's eight split-K slabs (4.19 MB) read, "
+                                    "new stacks + replay rows written")):
     for k in list(pm):
         if k.startswith(name + ":") and k.endswith(":FETCH_SIZE"):
             g = k.split(":")[1]
@@ -118,13 +119,20 @@ if len(cfg_lines) > 4:
     open(os.path.join(DST, f"{tag}_configs_rocprof_summary.md"), "w").write("\n".join(cfg_lines))
 
 # ---- data-parallel rehearsal (one-rank RCCL group, A0_DP_FORCE=1) and the host-environment front-end, when their runs are there
-for src, dst in (("bench_dpforce.json", f"{tag}_bench_dqn_dp_rehearsal.json"), ("host_env.json", f"{tag}_host_env_front_end.json")):
+for src, dst in (("bench_dpforce.json", f"{tag}_bench_dqn_dp_rehearsal.json"), ("host_env.json", f"{tag}_host_env_front_end.json"),
+                 ("host_env_2groups.json", f"{tag}_host_env_front_end_2groups.json")):
     path = os.path.join(SRC, src)
     if os.path.exists(path):
         try:
             json.dump(last_json(path), open(os.path.join(DST, dst), "w"), indent=1)
         except Exception as e:      # noqa: BLE001
             print("skipped", src, e)
+
+for src, dst in (("suite8.json", f"{tag}_fqf_suite8.json"), ("pmc_encoder.txt", f"{tag}_pmc_encoder.txt")):
+    if os.path.exists(os.path.join(SRC, src)):
+        shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
+if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_learning.json")):
+    shutil.copy(os.path.join(ROOT, "gpurun_out", f"{tag}_learning.json"), os.path.join(DST, f"{tag}_learning.json"))
 
 # ---- summary table
 rows = list(csv.DictReader(open(os.path.join(SRC, "kernel_stats.csv"))))

@@ -34,8 +34,10 @@ for algo in ("iqn", "fqf"):
         e = {"launches": len(next(iter(d.values()))), "counters_mean": {c: round(v, 1) for c, v in m.items()}}
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             e["hbm_read_bytes"] = 2 * 1024.0 * m["FETCH_SIZE"]; e["hbm_write_bytes"] = 1024.0 * m["WRITE_SIZE"]; e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"]:
-            e["matrix_pipe_busy_of_sq_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"], 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
+            # MFMA-busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md, PMC units): busy share of the kernel's SIMD-cycles
+            e["matrix_pipe_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * 128.0), 4)
+            e["matrix_pipe_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"
         res[key] = e
     out[algo] = res
 json.dump(out, open(f"gpurun_out/{R}/pmc_quantile.json", "w"), indent=1)
