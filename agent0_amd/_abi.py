@@ -42,6 +42,11 @@ class EncoderWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
 
 
+class LearnerDesc(C.Structure):
+    _fields_ = [("A", C.c_int), ("dueling", C.c_int), ("double_q", C.c_int), ("B", C.c_int), ("n_step", C.c_int), ("discount", C.c_double), ("lr", C.c_double),
+                ("adam_eps", C.c_double), ("target_update_freq", C.c_int)]
+
+
 class EncoderPass(C.Structure):
     _fields_ = [("wt", C.c_void_p), ("w", C.c_void_p), ("f", C.c_void_p), ("B", C.c_int), ("act1", C.c_void_p), ("act2", C.c_void_p), ("act3", C.c_void_p)]
 

@@ -1,0 +1,178 @@
+// a0_learner: one DQN-family learner — online + target parameters, gradients, Adam moments and every workspace — as ONE opaque handle whose HBM the
+// library owns, and BaseLearner.train (reference agent0/deepq/agent.py:124-169 with DQNLearner.train_step 173-190 behind it) as ONE C call per update.
+//
+// Everything a0_learner_update does is a sequence of the entry points declared above it in include/agent0_hip.h, in exactly the order
+// agent0_amd/deepq/engine.py issues them for the same configuration (so the two are bit-identical: tests/test_gpu_engine.py::test_native_learner_...);
+// what this file adds is the part a non-Python host would otherwise have to re-implement: the packed parameter layout (deepq/layout.py), buffer
+// sizes, split-K slab bookkeeping and the call order.  SURVEY.md §8(b) "ownership": opaque handle, library-owned HBM, caller passes borrowed device
+// pointers valid for the call, no allocation and no host synchronisation after a0_learner_create.
+//
+// Scope: the scalar-head learners on 4 x 84 x 84 observations (dqn; dueling; double-Q; n-step through discount^n) — BASELINE configs[1], the bench
+// line.  The distributional / quantile learners stay with the per-kernel entry points (INTEGRATION.md options A / B).
+#include "a0_internal.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+struct Blk { long long off; int N, K; long long w() const { return off; } long long b() const { return off + (long long)N * K; } long long size() const { return (long long)N * K + N; } };
+
+inline long long ceil_to(long long x, long long m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct a0_learner {
+    a0_learner_desc d;
+    a0_net* net = nullptr;
+    int C = 4, H = 84, W = 84, H1 = 20, W1 = 20, H2 = 9, W2 = 9, feat = 3136, Npad = 32, NQ = 0;
+    Blk conv1, conv2, conv3, fc1, head;
+    long long n_adam = 0, n_pad = 0, wt_floats = 0;
+    float gamma_n = 0.f;
+    int ns_fc1 = 1;
+    long long slab_off[2] = {0, 0};
+    // library-owned HBM
+    float *online = nullptr, *target = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *scalars = nullptr, *loss_ring = nullptr;
+    float *wt_on = nullptr, *wt_tg = nullptr;
+    int* state = nullptr;
+    float *act1 = nullptr, *act2 = nullptr, *act3_o = nullptr, *act3_t = nullptr, *act3_s = nullptr;
+    float *fc1_slabs[3] = {nullptr, nullptr, nullptr};
+    float *h = nullptr, *q_o = nullptr, *q_t = nullptr, *draw = nullptr, *dh = nullptr, *d3 = nullptr, *d2 = nullptr, *d1 = nullptr, *loss = nullptr, *slabs = nullptr;
+    std::vector<void*> owned;
+
+    template <class T> T* alloc(long long n, bool zero = false) {
+        void* p = nullptr;
+        A0_HIP_THROW(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+        owned.push_back(p);
+        if (zero) A0_HIP_THROW(hipMemset(p, 0, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+        return (T*)p;
+    }
+    ~a0_learner() {
+        for (void* p : owned) (void)hipFree(p);
+        if (net) a0_net_destroy(net);
+    }
+    a0_encoder_weights enc(const float* flat) const { return a0_encoder_weights{flat + conv1.w(), flat + conv1.b(), flat + conv2.w(), flat + conv2.b(), flat + conv3.w(), flat + conv3.b()}; }
+};
+
+#define A0_CHECK(call) do { int a0_rc_ = (call); if (a0_rc_ != A0_OK) return a0_rc_; } while (0)
+
+extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
+    A0_TRY
+    if (!d || !out) return a0_fail(A0_EINVAL, "a0_learner_create: null argument");
+    if (d->A < 1 || d->A + (d->dueling ? 1 : 0) > 24 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1)
+        return a0_fail(A0_EINVAL, "a0_learner_create: bad description (scalar heads with A + dueling <= 24 actions)");
+    a0_learner* L = new a0_learner();
+    try {
+        L->d = *d;
+        a0_net_desc nd{4, 84, 84};
+        if (a0_net_create(&nd, &L->net) != A0_OK) { delete L; return A0_EINVAL; }
+        L->NQ = d->A + (d->dueling ? 1 : 0);
+        L->Npad = (int)ceil_to(L->NQ, 32);
+        long long off = 0;
+        auto add = [&](Blk& b, int N, int K) { b = Blk{off, N, K}; off += b.size(); };
+        add(L->conv1, 32, L->C * 64); add(L->conv2, 64, 512); add(L->conv3, 64, 576); add(L->fc1, 512, L->feat); add(L->head, L->Npad, 512);      // deepq/layout.py
+        L->n_adam = off;
+        L->n_pad = ceil_to(off, 4);
+        L->wt_floats = a0_net_conv_wt_floats(L->C);
+        L->gamma_n = (float)std::pow(d->discount, (double)d->n_step);
+        const int B = d->B;
+        L->online = L->alloc<float>(L->n_pad, true); L->target = L->alloc<float>(L->n_pad, true);
+        L->grads = L->alloc<float>(L->n_pad + 4, true); L->m = L->alloc<float>(L->n_pad, true); L->v = L->alloc<float>(L->n_pad, true);
+        L->state = L->alloc<int>(8, true); L->scalars = L->alloc<float>(4, true); L->loss_ring = L->alloc<float>(1024, true);
+        L->wt_on = L->alloc<float>(L->wt_floats, true); L->wt_tg = L->alloc<float>(L->wt_floats, true);
+        L->act1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->act2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64);
+        L->act3_o = L->alloc<float>((long long)B * L->feat); L->act3_t = L->alloc<float>((long long)B * L->feat);
+        if (d->double_q) L->act3_s = L->alloc<float>((long long)B * L->feat);
+        L->ns_fc1 = a0_dense_fwd_partial_slabs(B, 512, L->feat);
+        for (int i = 0; i < (d->double_q ? 3 : 2); ++i) L->fc1_slabs[i] = L->alloc<float>((long long)L->ns_fc1 * B * 512);
+        L->h = L->alloc<float>((long long)B * 512); L->q_o = L->alloc<float>((long long)B * d->A); L->q_t = L->alloc<float>((long long)B * d->A);
+        L->draw = L->alloc<float>((long long)B * L->Npad); L->dh = L->alloc<float>((long long)B * 512); L->d3 = L->alloc<float>((long long)B * L->feat);
+        L->d2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64); L->d1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->loss = L->alloc<float>(B);
+        // one slab scratch for the dense weight gradients (disjoint regions, one reduction launch) and, after them, the encoder's
+        const long long s_head = ceil_to(a0_dense_wgrad_scratch(B, L->Npad, 512), 4), s_fc1 = ceil_to(a0_dense_wgrad_scratch(B, 512, L->feat), 4);
+        L->slab_off[0] = 0; L->slab_off[1] = s_head;
+        long long n_slab = a0_net_encoder_bwd_scratch(L->net, B);
+        if (s_head + s_fc1 > n_slab) n_slab = s_head + s_fc1;
+        L->slabs = L->alloc<float>(n_slab > 4 ? n_slab : 4);
+    } catch (...) { delete L; throw; }
+    *out = L;
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_learner_destroy(a0_learner* L) { delete L; return A0_OK; }
+
+extern "C" long long a0_learner_param_floats(const a0_learner* L) { return L ? L->n_pad : 0; }
+
+extern "C" int a0_learner_set_params(a0_learner* L, const float* online_packed, const float* target_packed, void* stream) {
+    A0_TRY
+    if (!L || !online_packed) return a0_fail(A0_EINVAL, "a0_learner_set_params: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    A0_HIP_THROW(hipMemcpyAsync(L->online, online_packed, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));
+    A0_HIP_THROW(hipMemcpyAsync(L->target, target_packed ? target_packed : online_packed, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));      // target = deepcopy(model), agent.py:100
+    a0_encoder_weights wo = L->enc(L->online), wtg = L->enc(L->target);
+    A0_CHECK(a0_net_conv_wt_refresh(&wo, L->C, L->wt_on, stream));
+    A0_CHECK(a0_net_conv_wt_refresh(&wtg, L->C, L->wt_tg, stream));
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_learner_get(const a0_learner* L, float* online_out, float* target_out, float* adam_m_out, float* adam_v_out, int* state_out8, void* stream) {
+    A0_TRY
+    if (!L) return a0_fail(A0_EINVAL, "a0_learner_get: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    if (online_out) A0_HIP_THROW(hipMemcpyAsync(online_out, L->online, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));
+    if (target_out) A0_HIP_THROW(hipMemcpyAsync(target_out, L->target, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));
+    if (adam_m_out) A0_HIP_THROW(hipMemcpyAsync(adam_m_out, L->m, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));
+    if (adam_v_out) A0_HIP_THROW(hipMemcpyAsync(adam_v_out, L->v, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));
+    if (state_out8) A0_HIP_THROW(hipMemcpyAsync(state_out8, L->state, 8 * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return A0_OK;
+    A0_CATCH
+}
+
+// BaseLearner.train (agent.py:124-169): frames = u8 replay rows st || st_next of `row_bytes` bytes each, addressed through `slot` (ring slots of the sampled
+// batch; NULL = dense batch), act / rew / done / wgt [B] on the device.  loss_out (optional) receives the per-sample losses [B] (what the caller feeds to
+// update_priority, trainer.py:103-104).  NaN skip, step counter and target sync are decided on the device (state words as in a0_adam_step_sync_wt).
+extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int* slot, long long row_bytes, const int* act, const float* rew, const float* done,
+                                 const float* wgt, float* loss_out, void* stream) {
+    A0_TRY
+    if (!L || !frames || !act || !rew || !done || !wgt) return a0_fail(A0_EINVAL, "a0_learner_update: null argument");
+    const int B = L->d.B, A = L->d.A, dq = L->d.double_q ? 1 : 0, obs = L->C * L->H * L->W;
+    if (row_bytes < 2LL * obs) return a0_fail(A0_EINVAL, "a0_learner_update: a replay row holds st || st_next (2 x C x H x W bytes)");
+    float* on = L->online; float* tg = L->target;
+    a0_encoder_weights w_on = L->enc(on), w_tg = L->enc(tg);
+    // ---- forward: the target pass on s', the online pass on s' (double-Q) and the online pass on s as ONE encoder launch, then their fc1 GEMMs (split-K slabs)
+    a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
+    a0_encoder_pass passes[3];
+    int np = 0;
+    passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->act3_t};
+    if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
+    passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
+    A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
+    A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, tg + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[1], stream));
+    if (dq) A0_CHECK(a0_dense_fwd_partial(L->act3_s, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[2], stream));
+    A0_CHECK(a0_dense_fwd_partial(L->act3_o, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[0], stream));
+    // ---- heads of both networks, dueling, argmax, Huber loss, head gradient and the head's backward-data pass in one launch (agent.py:173-190)
+    A0_CHECK(a0_dqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], dq ? L->fc1_slabs[2] : nullptr, (long long)B * 512, L->ns_fc1, on + L->fc1.b(), tg + L->fc1.b(), L->h,
+                                    on + L->head.w(), on + L->head.b(), tg + L->head.w(), tg + L->head.b(), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, B,
+                                    L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
+    // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
+    A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), L->act3_o, L->d3, B, 512, L->feat, stream));
+    {
+        const float* dY[2] = {L->draw, L->dh};
+        const float* X[2] = {L->h, L->act3_o};
+        const int ldx[2] = {512, L->feat}, R[2] = {B, B}, N[2] = {L->Npad, 512}, K[2] = {512, L->feat};
+        float* G[2] = {L->grads + L->head.off, L->grads + L->fc1.off};
+        A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, stream));
+    }
+    A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
+    A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,
+                                  L->slabs, stream));
+    if (loss_out) A0_HIP_THROW(hipMemcpyAsync(loss_out, L->loss, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
+    const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;
+    A0_CHECK(a0_adam_step_sync_wt(on, L->grads, L->m, L->v, L->n_adam, L->state, L->scalars, L->d.lr, 0.9, 0.999, eps, L->d.target_update_freq, tg, L->n_pad, nullptr, &w_on, L->C,
+                                  L->wt_on, L->wt_tg, L->loss, B, L->loss_ring, 1024, stream));
+    return A0_OK;
+    A0_CATCH
+}

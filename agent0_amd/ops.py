@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import _abi
-from ._abi import A0Error, EncoderPass, EncoderWeights, FramesArg, NetDesc, check
+from ._abi import A0Error, EncoderPass, EncoderWeights, FramesArg, LearnerDesc, NetDesc, check
 
 
 def _stream() -> int:
@@ -58,6 +58,47 @@ class Net:
             pass
 
 
+class NativeLearner:
+    """``a0_learner``: a whole scalar-head learner (dqn; dueling; double-Q) behind one handle whose HBM the library owns; ``update`` is BaseLearner.train as ONE
+    C call (include/agent0_hip.h).  What a non-Python host binds; here it exists for the parity test against the per-kernel composition of deepq/engine.py."""
+
+    def __init__(self, lib, A, dueling, double_q, B, n_step=1, discount=0.99, lr=5e-4, adam_eps=0.0, target_update_freq=500):
+        self.lib, self.B = lib, B
+        desc = LearnerDesc(int(A), int(bool(dueling)), int(bool(double_q)), int(B), int(n_step), float(discount), float(lr), float(adam_eps), int(target_update_freq))
+        h = C.c_void_p()
+        check(lib.a0_learner_create(C.addressof(desc), C.addressof(h)), "a0_learner_create")
+        self.h = h
+        self.n = int(lib.a0_learner_param_floats(h))
+
+    def set_params(self, online, target=None):
+        check(self.lib.a0_learner_set_params(self.h, _req(online, torch.float32, self.n, "online"), _req(target, torch.float32, self.n, "target", optional=True), _stream()),
+              "a0_learner_set_params")
+
+    def get(self):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        on, tg, m, v = (torch.empty(self.n, device=dev) for _ in range(4))
+        st = torch.zeros(8, dtype=torch.int32, device=dev)
+        check(self.lib.a0_learner_get(self.h, on.data_ptr(), tg.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), _stream()), "a0_learner_get")
+        return on, tg, m, v, st
+
+    def update(self, frames, slot, row_bytes, act, rew, done, wgt, loss_out=None):
+        B = self.B
+        check(self.lib.a0_learner_update(self.h, _req(frames, torch.uint8, row_bytes, "frames"), _req(slot, torch.int32, B, "slot", optional=True), int(row_bytes),
+                                         _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"), _req(wgt, torch.float32, B, "wgt"),
+                                         _req(loss_out, torch.float32, B, "loss_out", optional=True), _stream()), "a0_learner_update")
+
+    def close(self):
+        if self.h is not None:
+            self.lib.a0_learner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 — interpreter shutdown
+            pass
+
+
 class HipOps:
     name = "hip"
 
@@ -76,6 +117,9 @@ class HipOps:
 
     def net(self, C_, H, W) -> Net:
         return Net(self.lib, C_, H, W)
+
+    def native_learner(self, **kw) -> NativeLearner:
+        return NativeLearner(self.lib, **kw)
 
     # ------------------------------------------------------------------ encoder
     def _frames(self, net, frames, slot, sample_stride, chan_off, B):

@@ -259,6 +259,32 @@ int a0_adam_step_sync(float* params, const float* grads, float* exp_avg, float* 
 int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int* state, float* scalars2, double lr,
                          double beta1, double beta2, double eps, int target_update_freq, float* target, long long n_total, const float* extra_nan_flag,
                          const a0_encoder_weights* w, int C, float* wt, float* wt_target, const float* loss, int loss_n, float* loss_ring, int ring_cap, void* stream);
+/* ---------------------------------------------------------------- a whole learner behind one handle (opaque handles, library-owned HBM)
+ * BaseLearner (agent.py:97-169) with DQNLearner.train_step (173-190) for scalar heads on 4 x 84 x 84 observations — BASELINE configs[1]: online + target parameters
+ * in the packed layout (agent0_amd/deepq/layout.py: conv1 | conv2 | conv3 | fc1 | head, each [W (N x K) | b (N)], head rows padded to a multiple of 32), gradients,
+ * Adam moments, status words and every workspace live in HBM that a0_learner_create allocates and a0_learner_destroy frees; a0_learner_update is BaseLearner.train —
+ * forward passes, loss, backward, Adam(lr, eps = adam_eps or 1e-2 / B), NaN guard, update counter, target copy every target_update_freq updates — as ONE call that
+ * enqueues the same launches, in the same order, as the per-kernel entry points above (bit-identical results), never allocates and never synchronises.
+ * The other learners (c51 / qr / iqn / fqf / mdqn) are composed from the per-kernel entry points (agent0_amd/deepq/engine.py shows the order). */
+typedef struct a0_learner a0_learner;
+typedef struct a0_learner_desc {
+    int A, dueling, double_q;         /* cfg.action_dim, learner.dueling_head, learner.double_q (config.py:72-95) */
+    int B, n_step;                    /* learner.batch_size, learner.n_step_q */
+    double discount, lr, adam_eps;    /* learner.discount, learner.learning_rate; adam_eps <= 0: the reference's 1e-2 / B (agent.py:105) */
+    int target_update_freq;           /* learner.target_update_freq (agent.py:160-161) */
+} a0_learner_desc;
+int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
+int a0_learner_destroy(a0_learner* learner);
+long long a0_learner_param_floats(const a0_learner* learner);
+/* parameters in the packed layout (device pointers, a0_learner_param_floats floats each); target_packed = NULL: target = copy of online (agent.py:100) */
+int a0_learner_set_params(a0_learner* learner, const float* online_packed, const float* target_packed, void* stream);
+/* copies of what the handle holds (any pointer may be NULL): parameters, target parameters, Adam moments (param_floats each), the eight status words */
+int a0_learner_get(const a0_learner* learner, float* online_out, float* target_out, float* adam_m_out, float* adam_v_out, int* state_out8, void* stream);
+/* frames: u8 replay rows st || st_next of row_bytes bytes, read through slot [B] (ring slots of the sampled batch; NULL = rows 0 .. B-1); act int32, rew / done /
+ * wgt fp32 [B]; loss_out (optional, [B]): the per-sample losses, i.e. what update_priority takes (trainer.py:103-104) */
+int a0_learner_update(a0_learner* learner, const uint8_t* frames, const int* slot, long long row_bytes, const int* act, const float* rew, const float* done,
+                      const float* wgt, float* loss_out, void* stream);
+
 /* data parallelism: this rank's NaN flag as a float (1.0 / 0.0) that rides at the tail of a SUM-reduced gradient bucket; the reduced value
  * comes back through extra_nan_flag (nonzero = some rank saw a NaN: every rank skips the step), NULL on one GPU */
 int a0_nan_flag_export(const int* state, float* out, void* stream);

@@ -730,3 +730,61 @@ def test_encoder_passes_in_one_launch_equal_separate_launches(hip, Bs):
         assert torch.equal(ws.act3, ws2.act3), f"pass {i}: features"
         assert torch.equal(ws.act1, ws2.act1) and torch.equal(ws.act2, ws2.act2), f"pass {i}: stored activations (or untouched buffers)"
         assert float(ws2.act3.min()) >= 0.0
+
+
+@pytest.mark.parametrize("A,dueling,double_q,n_step,gather", [(4, False, False, 1, True), (4, True, True, 3, True), (18, True, False, 1, False), (6, False, True, 1, True)])
+def test_native_learner_handle_equals_the_per_kernel_composition(hip, A, dueling, double_q, n_step, gather):
+    """``a0_learner_*`` (round 4; SURVEY §8(b): opaque handle, library-owned HBM, BaseLearner.train as ONE C call): the handle's update must leave exactly the
+    parameters, target parameters, Adam moments, status words and per-sample losses that agent0_amd/deepq/engine.py's composition of the per-kernel entry points
+    leaves — torch.equal after each of five updates from the same packed parameters on the same batches (ring-slot gather and dense batch), across a target sync
+    (target_update_freq = 3), for plain / dueling / double-Q heads and n-step discounting."""
+    from agent0_amd.deepq.engine import DeviceLearner
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec("dqn", A, dueling=dueling)
+    L = NetLayout.from_spec(spec)
+    B, cap = 64, 200
+    dev = DeviceLearner(hip, L, B, n_step=n_step, double_q=double_q, target_update_freq=3)
+    dev.online.load_state_dict(recipe.make_state_dict(spec, 11))
+    dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
+    nat = hip.native_learner(A=A, dueling=dueling, double_q=double_q, B=B, n_step=n_step, discount=0.99, lr=5e-4, target_update_freq=3)
+    assert nat.n == L.n_params_padded
+    nat.set_params(dev.online.flat, dev.target.flat)
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(-1).contiguous()
+    loss_n = hip.empty(B)
+    for s in range(5):
+        slot = torch.from_numpy(recipe.gen(40 + s).permutation(cap)[:B].astype(np.int32)).to(hip.device) if gather else None
+        a_np, r_np, d_np, w_np = recipe.make_transitions(B, A, 70 + s)
+        a, r, d, w = (torch.from_numpy(x).to(hip.device) for x in (a_np.astype(np.int32), r_np, d_np.astype(np.float32), w_np))
+        loss_e = dev.update(ring, slot, 2 * 28224, a, r, d, w).clone()
+        nat.update(ring, slot, 2 * 28224, a, r, d, w, loss_out=loss_n)
+        torch.cuda.synchronize()
+        on, tg, m, v, st = nat.get()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_n, loss_e[:B]), f"update {s}: per-sample losses"
+        assert torch.equal(on, dev.online.flat) and torch.equal(tg, dev.target.flat), f"update {s}: parameters / target"
+        assert torch.equal(m, dev.adam_m) and torch.equal(v, dev.adam_v), f"update {s}: Adam moments"
+        assert torch.equal(st, dev.state), f"update {s}: status words {st.tolist()} vs {dev.state.tolist()}"
+    assert int(st[1]) == 5 and not torch.equal(on, tg)
+    nat.close()
+
+
+def test_plain_c_host_drives_a_learner_through_the_c_abi(tmp_path):
+    """The drop-in boundary is a C-ABI: tests/c_host_demo.c — plain C, include/agent0_hip.h and the HIP runtime, no Python, no torch — creates an a0_learner, loads
+    parameters, runs three dueling double-Q n-step updates (one a0_learner_update call each) and reads the state back.  Compiled here with gcc (the HIP runtime's C API) against the in-tree
+    library and run as a child process."""
+    import json, os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no C compiler / ROCm headers on this box")
+    exe = str(tmp_path / "c_host_demo")
+    lib = os.path.join(root, "agent0_amd", "lib")
+    r = subprocess.run([gcc, "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "c_host_demo.c"), "-I/opt/rocm/include", "-I", os.path.join(root, "include"), "-L", lib,
+                        "-lagent0_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["update_steps"] == 3 and out["nan_skipped"] == 0 and out["finite"] == 1 and out["param_floats"] > 1_600_000
+    assert out["moved_l1"] > 0 and out["mean_loss"] > 0
+    assert out["online_minus_target_l1"] > 0, "the target was synced after update 2 and the online network moved once more"
