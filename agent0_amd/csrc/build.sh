@@ -6,7 +6,7 @@ OUT="${HERE}/../lib"
 mkdir -p "${OUT}" "${HERE}/_obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"${HERE}/../../include")
-SRCS=(core net encoder_fused conv1_wgrad conv23_wgrad loss quantile optim replay rng synth_env actor dp learner)
+SRCS=(core net encoder_fused conv1_wgrad conv23_wgrad loss quantile optim replay rng synth_env actor dp learner runtime)
 pids=()
 for s in "${SRCS[@]}"; do
   src="${HERE}/${s}.hip"; obj="${HERE}/_obj/${s}.o"

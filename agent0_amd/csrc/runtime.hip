@@ -1,0 +1,291 @@
+// The rest of the actor -> replay -> learner loop behind opaque handles with library-owned HBM, so that a host in ANY language can run
+// BASELINE configs[1] with a handful of C calls per iteration (tests/c_host_demo.c does, in plain C):
+//
+//   a0_rbuf   ReplayDataset (reference agent0/deepq/replay.py:14-59 + the sampling of trainer.py:63-72,91-96): the HBM ring of st || st_next rows with its
+//             metadata, the sampler state (uniform: the DataLoader's shuffled epochs as a Feistel permutation; prioritized: the sum-tree) and the schedules
+//   a0_actor  Actor (agent.py:19-90) on the device-resident synthetic env: observations, n-step ring, episode statistics; one call = one sample_steps rollout
+//             whose transitions land in the replay ring
+//
+// Host-side bookkeeping (cursors, epochs, Philox offsets, beta) is the part of agent0_amd/deepq/{replay,agent}.py and common/utils.py that these handles
+// restate in C++; every device operation is one of the entry points declared above them in include/agent0_hip.h, in the order the Python classes issue
+// them — the rings, parameters and statistics of a run driven through the handles are bit-identical to the Python Trainer's
+// (tests/test_gpu_trainer.py::test_native_handles_run_the_loop_like_the_python_trainer).
+#include "learner_state.h"
+
+namespace {
+
+// agent0_amd/common/utils.py DeviceRng: per-stream running offsets, every reservation rounded up to a multiple of four draws
+struct Rng {
+    unsigned long long seed = 0;
+    unsigned long long off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void init(unsigned long long s, unsigned rank) { seed = (s & 0xFFFFFFFFull) | ((unsigned long long)(rank & 0xFFFFu) << 32); }
+    unsigned long long reserve(int stream, long long n) { const unsigned long long o = off[stream]; off[stream] += (unsigned long long)((n + 3) / 4 * 4); return o; }
+    unsigned next_seed32(int stream) { const unsigned long long o = reserve(stream, 4); return (unsigned)((seed * 0x9E3779B1ull + o * 0x85EBCA77ull + (unsigned long long)stream) & 0xFFFFFFFFull); }
+};
+constexpr int STREAM_EGREEDY_U = 1, STREAM_EGREEDY_A = 2, STREAM_SUMTREE = 5, STREAM_PERM = 6;
+
+struct Owned {
+    std::vector<void*> ptrs;
+    template <class T> T* alloc(long long n, bool zero = true) {
+        void* p = nullptr;
+        A0_HIP_THROW(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+        ptrs.push_back(p);
+        if (zero) A0_HIP_THROW(hipMemset(p, 0, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+        return (T*)p;
+    }
+    ~Owned() { for (void* p : ptrs) (void)hipFree(p); }
+};
+
+// max_p^alpha as the new leaves' value (replay.py:51-52: `max_p ** alpha`, in float64 like torch's `.double() ** alpha`)
+__global__ void a0_pow_scalar_kernel(const float* __restrict__ p, double alpha, float* __restrict__ out) {
+    const double x = (double)p[0];
+    out[0] = (float)(alpha == 0.5 ? sqrt(x) : pow(x, alpha));
+}
+__global__ void a0_fill_one_kernel(float* __restrict__ p, long long n, float v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// ================================================================================================ replay
+struct a0_rbuf {
+    a0_rbuf_desc d;
+    long long size = 0, top = 0, written = 0, cap2 = 1;
+    int obs_bytes = 0, B = 0;
+    long long row_bytes = 0;
+    bool prio = false;
+    double beta_use = 0.0, sched_cur = 0.0, beta_inc = 0.0;      // importance exponent in use / LinearSchedule(beta0, 1, total_steps).current / its increment per transition
+    struct { bool open = false; long long top = 0, nb = 0, pos = 0; unsigned seed = 0; } ep;
+    Rng rng;
+    Owned mem;
+    uint8_t* frames = nullptr;
+    int* act = nullptr; float *rew = nullptr, *done = nullptr;
+    float *tree = nullptr, *pstate = nullptr, *val = nullptr, *ones = nullptr;
+    long long* b_idx = nullptr; int *b_slot = nullptr, *b_act = nullptr; float *b_rew = nullptr, *b_done = nullptr, *b_prio = nullptr, *b_w = nullptr;
+    long long head() const { return written > size ? written % size : 0; }
+};
+
+extern "C" int a0_rbuf_create(const a0_rbuf_desc* d, a0_rbuf** out) {
+    A0_TRY
+    if (!d || !out) return a0_fail(A0_EINVAL, "a0_rbuf_create: null argument");
+    if (d->size < 2 || d->obs_bytes < 16 || (d->obs_bytes % 16) || d->B < 1 || d->B > d->size || (d->prioritize && (d->B > 1024 || !(d->alpha > 0.0) || d->total_steps < 1)))
+        return a0_fail(A0_EINVAL, "a0_rbuf_create: bad description (observation bytes a multiple of 16; prioritized batches of at most 1024)");
+    a0_rbuf* R = new a0_rbuf();
+    try {
+        R->d = *d; R->size = d->size; R->obs_bytes = d->obs_bytes; R->row_bytes = 2LL * d->obs_bytes; R->B = d->B; R->prio = d->prioritize != 0;
+        R->rng.init(d->seed, 0);
+        R->frames = R->mem.alloc<uint8_t>(R->size * R->row_bytes, false);
+        R->act = R->mem.alloc<int>(R->size); R->rew = R->mem.alloc<float>(R->size); R->done = R->mem.alloc<float>(R->size);
+        const int B = d->B;
+        R->b_idx = R->mem.alloc<long long>(B); R->b_slot = R->mem.alloc<int>(B); R->b_act = R->mem.alloc<int>(B); R->b_rew = R->mem.alloc<float>(B);
+        R->b_done = R->mem.alloc<float>(B); R->b_prio = R->mem.alloc<float>(B); R->b_w = R->mem.alloc<float>(B); R->ones = R->mem.alloc<float>(B);
+        R->pstate = R->mem.alloc<float>(1); R->val = R->mem.alloc<float>(4);
+        hipLaunchKernelGGL(a0_fill_one_kernel, dim3((B + 255) / 256), dim3(256), 0, 0, R->ones, (long long)B, 1.0f);
+        hipLaunchKernelGGL(a0_fill_one_kernel, dim3(1), dim3(256), 0, 0, R->pstate, 1LL, 1.0f);           // max_p = 1 (replay.py:20)
+        if (R->prio) {
+            while (R->cap2 < R->size) R->cap2 <<= 1;
+            R->tree = R->mem.alloc<float>(2 * R->cap2);
+            R->beta_use = R->sched_cur = d->beta0;                                                         // LinearSchedule(beta0, 1, total_steps), utils.py:12-28
+            R->beta_inc = (1.0 - d->beta0) / (double)d->total_steps;
+        }
+        A0_HIP_THROW(hipDeviceSynchronize());
+    } catch (...) { delete R; throw; }
+    *out = R;
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_rbuf_destroy(a0_rbuf* R) { delete R; return A0_OK; }
+extern "C" long long a0_rbuf_len(const a0_rbuf* R) { return R ? R->top : 0; }
+extern "C" long long a0_rbuf_write_cursor(const a0_rbuf* R) { return R ? R->written % R->size : 0; }
+extern "C" int a0_rbuf_info(const a0_rbuf* R, long long* top, long long* written, double* beta) {
+    if (!R) return a0_fail(A0_EINVAL, "a0_rbuf_info: null handle");
+    if (top) *top = R->top;
+    if (written) *written = R->written;
+    if (beta) *beta = R->beta_use;
+    return A0_OK;
+}
+
+extern "C" int a0_rbuf_buffers(a0_rbuf* R, uint8_t** frames, int** act, float** rew, float** done, float** tree, float** max_p) {
+    if (!R) return a0_fail(A0_EINVAL, "a0_rbuf_buffers: null handle");
+    if (frames) *frames = R->frames;
+    if (act) *act = R->act;
+    if (rew) *rew = R->rew;
+    if (done) *done = R->done;
+    if (tree) *tree = R->tree;
+    if (max_p) *max_p = R->pstate;
+    return A0_OK;
+}
+
+// copies of what the ring holds into caller buffers (any pointer may be NULL; device pointers): rows [0, rows) of frames / act / rew / done, the sum-tree, max_p
+extern "C" int a0_rbuf_read(const a0_rbuf* R, long long rows, uint8_t* frames_out, int* act_out, float* rew_out, float* done_out, float* tree_out, float* max_p_out, void* stream) {
+    A0_TRY
+    if (!R || rows < 0 || rows > R->size) return a0_fail(A0_EINVAL, "a0_rbuf_read: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (frames_out) A0_HIP_THROW(hipMemcpyAsync(frames_out, R->frames, (size_t)(rows * R->row_bytes), hipMemcpyDeviceToDevice, st));
+    if (act_out) A0_HIP_THROW(hipMemcpyAsync(act_out, R->act, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
+    if (rew_out) A0_HIP_THROW(hipMemcpyAsync(rew_out, R->rew, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
+    if (done_out) A0_HIP_THROW(hipMemcpyAsync(done_out, R->done, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
+    if (tree_out && R->tree) A0_HIP_THROW(hipMemcpyAsync(tree_out, R->tree, (size_t)(2 * R->cap2) * 4, hipMemcpyDeviceToDevice, st));
+    if (max_p_out) A0_HIP_THROW(hipMemcpyAsync(max_p_out, R->pstate, 4, hipMemcpyDeviceToDevice, st));
+    return A0_OK;
+    A0_CATCH
+}
+
+// ReplayDataset.extend (replay.py:45-53) for n transitions an actor has already written into the ring at the write cursor: counters, and for prioritized
+// replay the new leaves at max_p^alpha (one ring range, one launch) and the beta schedule's step (the value BEFORE the increment is the one in use)
+extern "C" int a0_rbuf_commit(a0_rbuf* R, long long n, void* stream) {
+    A0_TRY
+    if (!R || n < 1) return a0_fail(A0_EINVAL, "a0_rbuf_commit: bad argument");
+    R->written += n;
+    R->top = R->top + n < R->size ? R->top + n : R->size;
+    if (R->prio) {
+        hipLaunchKernelGGL(a0_pow_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, R->pstate, R->d.alpha, R->val);
+        const long long k = n < R->size ? n : R->size;
+        A0_CHECK(a0_sumtree_set_range(R->tree, R->cap2, (R->written - k) % R->size, k, R->size, R->val, stream));
+        R->beta_use = R->sched_cur;                               // beta = beta_schedule(n): the schedule's value BEFORE it advances (utils.py:25-28)
+        const double nxt = R->sched_cur + R->beta_inc * (double)n;
+        R->sched_cur = nxt < 1.0 ? nxt : 1.0;
+    }
+    return A0_OK;
+    A0_CATCH
+}
+
+// One batch (trainer.py:63-72 / 91-96): uniform — element pos * B + b of the epoch's permutation of range(top) (an epoch is opened when the previous one has
+// no whole batch left BUT ONE: the reference's prefetcher never returns its last batch, utils.py:51-56) — or proportional from the sum-tree with importance
+// weights.  The pointers in `out` are the handle's persistent batch buffers (valid until the next sample).
+extern "C" int a0_rbuf_sample(a0_rbuf* R, a0_batch* out, void* stream) {
+    A0_TRY
+    if (!R || !out) return a0_fail(A0_EINVAL, "a0_rbuf_sample: null argument");
+    const int B = R->B;
+    if (R->prio) {
+        const unsigned long long off = R->rng.reserve(STREAM_SUMTREE, B);
+        A0_CHECK(a0_sumtree_sample_batch(R->rng.seed, STREAM_SUMTREE, off, R->tree, R->cap2, B, R->top, R->size, (float)R->beta_use, R->act, R->rew, R->done, R->b_idx, R->b_slot,
+                                         R->b_act, R->b_rew, R->b_done, R->b_prio, R->b_w, stream));
+        *out = a0_batch{R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, R->b_w};
+        return A0_OK;
+    }
+    if (!R->ep.open || R->ep.pos + 1 >= R->ep.nb) {
+        R->ep.top = R->top; R->ep.nb = (R->top + B - 1) / B; R->ep.pos = 0; R->ep.seed = R->rng.next_seed32(STREAM_PERM); R->ep.open = true;
+        if (R->ep.nb < 2) { R->ep.open = false; return a0_fail(A0_EINVAL, "a0_rbuf_sample: the ring holds fewer than two batches (the reference's fetcher cannot return one either)"); }
+    }
+    const long long start = R->ep.pos * B;
+    R->ep.pos += 1;
+    A0_CHECK(a0_replay_sample_slots((unsigned long long)start, (unsigned long long)R->ep.top, R->ep.seed, R->top, R->head(), R->size, R->act, R->rew, R->done, nullptr, B,
+                                    R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, stream));
+    *out = a0_batch{R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, R->ones};
+    return A0_OK;
+    A0_CATCH
+}
+
+// ReplayDataset.update_priority (replay.py:55-59) with the last batch's indices: leaf = (loss + eps)^alpha, max_p = max(max_p, max loss); a no-op for uniform
+// replay and when the learner skipped the update on a NaN (learner_state[3], agent.py:152-158 / trainer.py:103)
+extern "C" int a0_rbuf_update_priority(a0_rbuf* R, const float* loss, const int* learner_state, void* stream) {
+    A0_TRY
+    if (!R || !loss) return a0_fail(A0_EINVAL, "a0_rbuf_update_priority: null argument");
+    if (!R->prio) return A0_OK;
+    if (a0_sumtree_set_from_loss_ok(R->cap2)) return a0_sumtree_set_from_loss(R->tree, R->cap2, R->b_idx, loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->pstate, learner_state, stream);
+    A0_CHECK(a0_priority_from_loss(loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->b_prio, R->pstate, learner_state, stream));
+    return a0_sumtree_set(R->tree, R->cap2, R->b_idx, R->b_prio, R->B, learner_state, stream);
+    A0_CATCH
+}
+
+// ================================================================================================ actor
+struct a0_actor {
+    a0_actor_desc d;
+    int E = 0, T = 0, n = 1, K = 2, cur = 0, feat = 3136, obs_bytes = 4 * 84 * 84;
+    unsigned g = 0;
+    long long steps = 0;
+    Rng rng;
+    Owned mem;
+    std::vector<uint8_t*> obs;
+    float *ep_ret = nullptr, *qmax_all = nullptr, *stat_mask = nullptr, *stat_ret = nullptr, *qs = nullptr, *ring_rew = nullptr, *ring_done = nullptr, *act3 = nullptr, *scratch = nullptr;
+    int *action = nullptr, *ring_act = nullptr;
+    std::vector<float> h_mask, h_ret;
+};
+
+extern "C" int a0_actor_create(const a0_actor_desc* d, a0_actor** out) {
+    A0_TRY
+    if (!d || !out) return a0_fail(A0_EINVAL, "a0_actor_create: null argument");
+    if (d->E < 1 || d->T < 1 || d->A < 1 || d->A + (d->dueling ? 1 : 0) > 24 || d->n_step < 1 || !(d->discount > 0.0) || (d->env_task != A0_ENV_TASK_STREAM && d->env_task != A0_ENV_TASK_BLOCK))
+        return a0_fail(A0_EINVAL, "a0_actor_create: bad description");
+    a0_actor* a = new a0_actor();
+    try {
+        a->d = *d; a->E = d->E; a->T = d->T; a->n = d->n_step;
+        a->rng.init(d->seed, d->rank);
+        // observation buffers: two for 1-step transitions; for n-step the last n observations stay addressable (n + 1 buffers, or the next divisor of the rollout
+        // length so that the buffer pattern of a rollout repeats: agent0_amd/deepq/agent.py, DeviceSynthVecEnv.set_history)
+        a->K = 2;
+        if (a->n > 1) {
+            a->K = a->n + 1;
+            for (int r = a->n + 1; r < 2 * a->n + 3; ++r) if (a->T % r == 0) { a->K = r; break; }
+        }
+        const long long E = a->E, T = a->T;
+        for (int i = 0; i < a->K; ++i) a->obs.push_back(a->mem.alloc<uint8_t>(E * a->obs_bytes));
+        a->ep_ret = a->mem.alloc<float>(E); a->qmax_all = a->mem.alloc<float>(T * E); a->stat_mask = a->mem.alloc<float>(T * E); a->stat_ret = a->mem.alloc<float>(T * E);
+        a->qs = a->mem.alloc<float>(T); a->action = a->mem.alloc<int>(E);
+        a->ring_act = a->mem.alloc<int>((long long)a->n * E); a->ring_rew = a->mem.alloc<float>((long long)a->n * E); a->ring_done = a->mem.alloc<float>((long long)a->n * E);
+        a->act3 = a->mem.alloc<float>(E * a->feat); a->scratch = a->mem.alloc<float>(a0_actor_qhead_scratch(a->E, a->feat));
+        a->h_mask.resize((size_t)(T * E)); a->h_ret.resize((size_t)(T * E));
+        if (a0_env_synth_reset(d->seed, d->rank, a->E, a->obs[0], a->ep_ret, nullptr) != A0_OK) { delete a; return A0_EINVAL; }      // Actor.__init__: self.obs = envs.reset()
+        A0_HIP_THROW(hipDeviceSynchronize());
+    } catch (...) { delete a; throw; }
+    *out = a;
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_actor_destroy(a0_actor* a) { delete a; return A0_OK; }
+
+// Actor.sample (agent.py:44-90) with the learner's online network: T steps of [encoder, fc1 GEMM, tail + env step + n-step bookkeeping + replay row], the
+// rows written straight into the ring at its write cursor (call a0_rbuf_commit(replay, T * E) afterwards: ReplayDataset.extend), then the per-step mean max-Q.
+// Asynchronous like everything else; a0_actor_collect waits and returns the statistics.
+extern "C" int a0_actor_rollout(a0_actor* a, const a0_learner* L, a0_rbuf* R, float epsilon, void* stream) {
+    A0_TRY
+    if (!a || !L || !R) return a0_fail(A0_EINVAL, "a0_actor_rollout: null argument");
+    if (L->d.A != a->d.A || (L->d.dueling != 0) != (a->d.dueling != 0) || R->obs_bytes != a->obs_bytes || R->size < a->E)
+        return a0_fail(A0_EINVAL, "a0_actor_rollout: actor, learner and replay were created for different shapes");
+    const int E = a->E, A = a->d.A;
+    const long long start = R->written % R->size;
+    a0_encoder_weights w = L->enc(L->online);
+    for (int t = 0; t < a->T; ++t) {
+        const uint8_t* cur_obs = a->obs[a->cur];
+        a0_frames_arg f{cur_obs, nullptr, (long long)a->obs_bytes, 0};
+        A0_CHECK(a0_net_encoder_fwd_fused(L->C, L->H, L->W, L->wt_on, &w, &f, E, nullptr, nullptr, a->act3, stream));
+        const long long back = (a->steps + 1 < a->n ? a->steps + 1 : a->n) - 1;                 // first observation of the emitted n-step transition
+        const uint8_t* obs0 = a->obs[((a->cur - back) % a->K + a->K) % a->K];
+        const unsigned long long off_a = a->rng.reserve(STREAM_EGREEDY_A, E), off_u = a->rng.reserve(STREAM_EGREEDY_U, E);
+        const int nxt = (a->cur + 1) % a->K;
+        a->g += 1;
+        A0_CHECK(a0_actor_qhead_env_step(a->act3, E, a->feat, L->online + L->fc1.w(), L->online + L->fc1.b(), L->online + L->head.w(), L->online + L->head.b(), A, a->d.dueling ? 1 : 0,
+                                         a->scratch, a->rng.seed, STREAM_EGREEDY_A, STREAM_EGREEDY_U, off_a, off_u, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E,
+                                         a->d.seed, a->d.rank, a->g, cur_obs, a->obs[nxt], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
+                                         a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,
+                                         a->d.env_task, stream));
+        a->cur = nxt;
+        a->steps += 1;
+    }
+    return a0_mean_rows(a->qmax_all, a->T, E, a->qs, stream);
+    A0_CATCH
+}
+
+// Waits for the stream, then hands back what Actor.sample returns besides the transitions (agent.py:85-90): the per-step mean max-Q (qs_host [T]) and the
+// returns of the episodes that finished during the rollout, in the reference's order (step-major, env-major); *n_returns = how many there were (at most
+// max_returns are stored).  The one device -> host read of a rollout.
+extern "C" int a0_actor_collect(a0_actor* a, float* qs_host, float* returns_host, int max_returns, int* n_returns, void* stream) {
+    A0_TRY
+    if (!a) return a0_fail(A0_EINVAL, "a0_actor_collect: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)a->T * a->E;
+    if (qs_host) A0_HIP_THROW(hipMemcpyAsync(qs_host, a->qs, (size_t)a->T * 4, hipMemcpyDeviceToHost, st));
+    A0_HIP_THROW(hipMemcpyAsync(a->h_mask.data(), a->stat_mask, n * 4, hipMemcpyDeviceToHost, st));
+    A0_HIP_THROW(hipMemcpyAsync(a->h_ret.data(), a->stat_ret, n * 4, hipMemcpyDeviceToHost, st));
+    A0_HIP_THROW(hipStreamSynchronize(st));
+    int k = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (a->h_mask[i] != 0.f) { if (returns_host && k < max_returns) returns_host[k] = a->h_ret[i]; ++k; }
+    if (n_returns) *n_returns = k;
+    return A0_OK;
+    A0_CATCH
+}

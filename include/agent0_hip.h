@@ -285,6 +285,49 @@ int a0_learner_get(const a0_learner* learner, float* online_out, float* target_o
 int a0_learner_update(a0_learner* learner, const uint8_t* frames, const int* slot, long long row_bytes, const int* act, const float* rew, const float* done,
                       const float* wgt, float* loss_out, void* stream);
 
+/* ---------------------------------------------------------------- the rest of the loop behind handles: replay ring and actor (csrc/runtime.hip)
+ * a0_rbuf = ReplayDataset (replay.py:14-59) + the sampling of trainer.py:63-72,91-96: the HBM ring of st || st_next rows (2 * obs_bytes each) with its metadata,
+ * uniform sampling (the DataLoader's shuffled epochs as a Feistel permutation, last batch of an epoch never returned: utils.py:51-56) or, prioritize != 0,
+ * proportional sampling from the sum-tree with importance weights and the beta schedule; `seed` is the sampler's Philox seed (the Python classes use cfg.seed + 104729).
+ * The reference-faithful flat priority vector (replay.sumtree=false: quirks Q1 / Q2 / Q7) exists in the Python classes only. */
+typedef struct a0_rbuf a0_rbuf;
+typedef struct a0_rbuf_desc {
+    long long size; int obs_bytes, B, prioritize;      /* replay.size, C*H*W, learner.batch_size, replay.policy == prioritize (sum-tree) */
+    double alpha, eps, beta0; long long total_steps;   /* replay.alpha / eps / beta0 (config.py:118-124), trainer.total_steps (the beta schedule's length) */
+    unsigned long long seed;
+} a0_rbuf_desc;
+typedef struct a0_batch { const long long* idx; const int* slot; const int* act; const float* rew; const float* done; const float* prio; const float* weights; } a0_batch;
+int a0_rbuf_create(const a0_rbuf_desc* desc, a0_rbuf** out);
+int a0_rbuf_destroy(a0_rbuf* replay);
+long long a0_rbuf_len(const a0_rbuf* replay);
+long long a0_rbuf_write_cursor(const a0_rbuf* replay);
+int a0_rbuf_info(const a0_rbuf* replay, long long* top, long long* written, double* beta);
+/* the ring's device buffers (any pointer may be NULL): frames [size][2 * obs_bytes] u8, act int32 / rew / done fp32 [size], the sum-tree [2 * cap2] and max_p [1] */
+int a0_rbuf_buffers(a0_rbuf* replay, uint8_t** frames, int** act, float** rew, float** done, float** tree, float** max_p);
+/* copies into caller buffers (device pointers, any may be NULL): rows [0, rows) of frames / act / rew / done, the sum-tree (2 * cap2 floats), max_p */
+int a0_rbuf_read(const a0_rbuf* replay, long long rows, uint8_t* frames_out, int* act_out, float* rew_out, float* done_out, float* tree_out, float* max_p_out, void* stream);
+/* ReplayDataset.extend for n transitions already written into the ring at the write cursor (a0_actor_rollout does that) */
+int a0_rbuf_commit(a0_rbuf* replay, long long n, void* stream);
+/* one batch into the handle's persistent batch buffers (device pointers in *out, valid until the next sample) */
+int a0_rbuf_sample(a0_rbuf* replay, a0_batch* out, void* stream);
+/* ReplayDataset.update_priority with the last batch's indices and the learner's per-sample losses; learner_state: a0_learner_get's status words or NULL */
+int a0_rbuf_update_priority(a0_rbuf* replay, const float* loss, const int* learner_state, void* stream);
+
+/* a0_actor = Actor (agent.py:19-90) on the device-resident synthetic env for scalar heads: observations, epsilon-greedy Philox streams (seed, rank), n-step ring,
+ * episode statistics.  a0_actor_rollout = Actor.sample: T steps acting with the learner's online network, transitions written into the replay ring at its write
+ * cursor (then a0_rbuf_commit(replay, T * E)); a0_actor_collect waits for the stream and returns qs [T] and the finished episodes' returns (host memory). */
+typedef struct a0_actor a0_actor;
+typedef struct a0_actor_desc {
+    int E, T, A, dueling, n_step;                      /* actor.num_envs, actor.sample_steps, cfg.action_dim, learner.dueling_head, learner.n_step_q */
+    double discount;                                   /* learner.discount */
+    unsigned long long seed; unsigned int rank;        /* cfg.seed, this process's rank */
+    int env_task;                                      /* A0_ENV_TASK_* */
+} a0_actor_desc;
+int a0_actor_create(const a0_actor_desc* desc, a0_actor** out);
+int a0_actor_destroy(a0_actor* actor);
+int a0_actor_rollout(a0_actor* actor, const a0_learner* learner, a0_rbuf* replay, float epsilon, void* stream);
+int a0_actor_collect(a0_actor* actor, float* qs_host, float* returns_host, int max_returns, int* n_returns, void* stream);
+
 /* data parallelism: this rank's NaN flag as a float (1.0 / 0.0) that rides at the tail of a SUM-reduced gradient bucket; the reduced value
  * comes back through extra_nan_flag (nonzero = some rank saw a NaN: every rank skips the step), NULL on one GPU */
 int a0_nan_flag_export(const int* state, float* out, void* stream);

@@ -1,0 +1,78 @@
+/* BASELINE configs[1] — Breakout-shaped dqn, 256 vectorized envs x 80 steps + 20 updates of batch 512 per iteration — run by a host that is NOT Python: plain C
+ * against include/agent0_hip.h, the three handles a0_actor / a0_rbuf / a0_learner (library-owned HBM) and the loop of trainer.py:74-119,171-184 written out.
+ * usage: c_host_loop [iterations] [replay_size] [env_task 0|1]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
+#include <hip/hip_runtime_api.h>      /* gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include "agent0_hip.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s failed (%d): %s\n", #x, rc_, a0_last_error()); return 1; } } while (0)
+#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static unsigned lcg(unsigned* s) { *s = *s * 1664525u + 1013904223u; return *s >> 8; }
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20;
+    const long long size = argc > 2 ? atoll(argv[2]) : 100000;
+    const int task = argc > 3 ? atoi(argv[3]) : A0_ENV_TASK_STREAM;
+    const int E = 256, T = 80, B = 512, LSTEPS = 20, A = 4, OBS = 4 * 84 * 84;
+    const long long start_steps = size < 100000 ? size / 2 : 100000, exploration = 1000000;
+    const double min_eps = 0.01;
+    a0_learner_desc ld = {A, 0, 0, B, 1, 0.99, 5e-4, 0.0, 500};
+    a0_rbuf_desc rd = {size, OBS, B, 0, 0.5, 0.01, 0.4, 10000000, 42 + 104729};
+    a0_actor_desc ad = {E, T, A, 0, 1, 0.99, 42, 0, task};
+    a0_learner* L = NULL; a0_rbuf* R = NULL; a0_actor* ac = NULL;
+    CHECK(a0_learner_create(&ld, &L)); CHECK(a0_rbuf_create(&rd, &R)); CHECK(a0_actor_create(&ad, &ac));
+    /* small random initial weights (a real host would load a packed checkpoint: agent0_amd/deepq/layout.py) */
+    const long long n = a0_learner_param_floats(L);
+    float* hp = (float*)malloc((size_t)n * sizeof(float));
+    unsigned seed = 7u;
+    for (long long i = 0; i < n; ++i) hp[i] = ((float)(lcg(&seed) % 2001) - 1000.0f) * 2e-5f;
+    float* dp = NULL; float* dloss = NULL;
+    HIP(hipMalloc((void**)&dp, (size_t)n * 4)); HIP(hipMalloc((void**)&dloss, B * 4));
+    HIP(hipMemcpy(dp, hp, (size_t)n * 4, hipMemcpyHostToDevice));
+    CHECK(a0_learner_set_params(L, dp, NULL, NULL));
+    uint8_t* ring = NULL;
+    CHECK(a0_rbuf_buffers(R, &ring, NULL, NULL, NULL, NULL, NULL));
+    float* qs = (float*)malloc(T * sizeof(float)); float* rets = (float*)malloc((size_t)T * E * sizeof(float));
+    long long frames = 0, updates = 0, episodes = 0;
+    double ret_sum = 0.0, t0 = 0.0, qmax = 0.0;
+    int timed = 0;
+    for (int it = 0; timed < iters; ++it) {
+        const double eps = frames > exploration ? min_eps : (1.0 - (double)frames / (double)exploration) + min_eps;      /* trainer.py:46-50 */
+        CHECK(a0_actor_rollout(ac, L, R, (float)eps, NULL));
+        CHECK(a0_rbuf_commit(R, (long long)T * E, NULL));
+        frames += (long long)T * E;
+        const int training = a0_rbuf_len(R) > start_steps;
+        if (training) {
+            if (timed == 0 && t0 == 0.0) { HIP(hipDeviceSynchronize()); t0 = now(); }
+            for (int u = 0; u < LSTEPS; ++u) {
+                a0_batch b;
+                CHECK(a0_rbuf_sample(R, &b, NULL));
+                CHECK(a0_learner_update(L, ring, b.slot, 2LL * OBS, b.act, b.rew, b.done, b.weights, dloss, NULL));
+                CHECK(a0_rbuf_update_priority(R, dloss, NULL, NULL));
+                ++updates;
+            }
+        }
+        int nret = 0;
+        CHECK(a0_actor_collect(ac, qs, rets, T * E, &nret, NULL));      /* the one device -> host read of the iteration */
+        for (int k = 0; k < nret; ++k) { ret_sum += rets[k]; ++episodes; }
+        qmax = qs[T - 1];
+        if (training) ++timed;
+    }
+    HIP(hipDeviceSynchronize());
+    const double dt = now() - t0;
+    float hl[512];
+    HIP(hipMemcpy(hl, dloss, B * 4, hipMemcpyDeviceToHost));
+    double mean = 0.0; int finite = 1;
+    for (int b = 0; b < B; ++b) { mean += hl[b] / B; if (!isfinite(hl[b])) finite = 0; }
+    printf("{\"host\": \"plain C (tests/c_host_loop.c)\", \"iterations_timed\": %d, \"ms_per_iteration\": %.3f, \"env_frames_per_sec\": %.1f, \"frames\": %lld, \"updates\": %lld, "
+           "\"episodes\": %lld, \"mean_return\": %.4f, \"last_mean_loss\": %.6g, \"last_qmax\": %.5g, \"finite\": %d, \"replay_size\": %lld, \"env_task\": %d}\n",
+           timed, 1e3 * dt / timed, (double)timed * T * E / dt, frames, updates, episodes, episodes ? ret_sum / (double)episodes : 0.0, mean, qmax, finite, size, task);
+    CHECK(a0_actor_destroy(ac)); CHECK(a0_rbuf_destroy(R)); CHECK(a0_learner_destroy(L));
+    return 0;
+}

@@ -545,3 +545,114 @@ def test_loss_statistic_from_the_adam_launch_equals_mean_rows(algo, monkeypatch)
     l1, p1, c1, u1 = run(True)
     assert len(l0) == 7 * 7 and l0 == l1 and torch.equal(p0, p1)
     assert c0 == u0 == c1 == u1 == 49, "the device's ring counter and the host's count of issued updates stay in step"
+
+
+@pytest.mark.parametrize("extra", [{}, {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3},
+                                   {"replay.policy": "prioritize", "learner.n_step_q": 3, "env_task": "block"}], ids=["dqn-uniform", "duel-double-n3", "prioritized-n3-block"])
+def test_native_handles_run_the_loop_like_the_python_trainer(extra):
+    """Round 4 (opaque handles, library-owned HBM): ``a0_actor`` / ``a0_rbuf`` / ``a0_learner`` (csrc/runtime.hip, learner.hip) restate the host-side
+    bookkeeping of the Python classes — cursors, shuffled epochs, Philox offsets, beta, epsilon — in C++, so that a host needs a handful of C calls per iteration.
+    Driven here through ctypes with the loop of trainer.py:74-119,171-184 written out, from the Python Trainer's initial weights: after eight iterations (ring
+    wrap, target syncs, uniform and sum-tree replay, n-step 1 and 3, both reward tasks) the replay ring, the sum-tree, max_p, the parameters, the target, the update
+    counter, every episode return and every per-step max-Q must be BIT-identical to the Python Trainer's."""
+    import ctypes as C
+    from agent0_amd import _abi
+    from agent0_amd.deepq.trainer import Trainer, epsilon_schedule
+
+    class RbufDesc(C.Structure):
+        _fields_ = [("size", C.c_longlong), ("obs_bytes", C.c_int), ("B", C.c_int), ("prioritize", C.c_int), ("alpha", C.c_double), ("eps", C.c_double), ("beta0", C.c_double),
+                    ("total_steps", C.c_longlong), ("seed", C.c_ulonglong)]
+
+    class ActorDesc(C.Structure):
+        _fields_ = [("E", C.c_int), ("T", C.c_int), ("A", C.c_int), ("dueling", C.c_int), ("n_step", C.c_int), ("discount", C.c_double), ("seed", C.c_ulonglong), ("rank", C.c_uint),
+                    ("env_task", C.c_int)]
+
+    class Batch(C.Structure):
+        _fields_ = [(n, C.c_void_p) for n in ("idx", "slot", "act", "rew", "done", "prio", "weights")]
+
+    E, T, B, SIZE, LS, START, TF = 8, 10, 32, 200, 5, 100, 7
+    cfg = make_cfg("dqn", E, **{"actor.sample_steps": T, "replay.size": SIZE, "learner.batch_size": B, "learner.learner_steps": LS, "trainer.training_start_steps": START,
+                                "learner.target_update_freq": TF, "trainer.exploration_steps": 300, **extra})
+    tr = Trainer(cfg)
+    eng = tr.learner.engine
+    lib, ok = _abi.load(), _abi.check
+    st = torch.cuda.current_stream().cuda_stream
+    prio, duel, dq, n = cfg.replay.policy.name == "prioritize", bool(cfg.learner.dueling_head), bool(cfg.learner.double_q), int(cfg.learner.n_step_q)
+    nat = tr.ops.native_learner(A=4, dueling=duel, double_q=dq, B=B, n_step=n, discount=cfg.learner.discount, lr=cfg.learner.learning_rate, target_update_freq=TF)
+    nat.set_params(eng.online.flat, eng.target.flat)
+    rd = RbufDesc(SIZE, 4 * 84 * 84, B, int(prio), cfg.replay.alpha, cfg.replay.eps, cfg.replay.beta0, cfg.trainer.total_steps, cfg.seed + 104729)
+    rb = C.c_void_p()
+    ok(lib.a0_rbuf_create(C.addressof(rd), C.addressof(rb)), "a0_rbuf_create")
+    ad = ActorDesc(E, T, 4, int(duel), n, cfg.learner.discount, cfg.seed, 0, {"stream": 0, "block": 1}[cfg.env_task])
+    ac = C.c_void_p()
+    ok(lib.a0_actor_create(C.addressof(ad), C.addressof(ac)), "a0_actor_create")
+    eps_fn = epsilon_schedule(cfg)
+    loss_dev, state_dev = tr.ops.empty(B), tr.ops.zeros(8, dtype=torch.int32)
+    frame_count, n_rs, n_qs, n_Ls = 0, [], [], []
+    qs_h, rs_h, nret = (C.c_float * T)(), (C.c_float * (T * E))(), C.c_int()
+    for it in range(8):
+        res = tr.run_iteration()
+        # ---- the same iteration through the handles (trainer.py:176-182 -> 74-119)
+        ok(lib.a0_actor_rollout(ac, nat.h, rb, C.c_float(eps_fn(frame_count)), st), "a0_actor_rollout")
+        ok(lib.a0_rbuf_commit(rb, T * E, st), "a0_rbuf_commit")
+        frame_count += T * E
+        if lib.a0_rbuf_len(rb) > START:
+            for _ in range(LS):
+                b = Batch()
+                ok(lib.a0_rbuf_sample(rb, C.addressof(b), st), "a0_rbuf_sample")
+                ok(lib.a0_learner_update(nat.h, _rbuf_frames(lib, rb), b.slot, 2 * 4 * 84 * 84, b.act, b.rew, b.done, b.weights, loss_dev.data_ptr(), st), "a0_learner_update")
+                if prio:
+                    ok(lib.a0_learner_get(nat.h, None, None, None, None, state_dev.data_ptr(), st), "a0_learner_get")
+                    ok(lib.a0_rbuf_update_priority(rb, loss_dev.data_ptr(), state_dev.data_ptr(), st), "a0_rbuf_update_priority")
+                n_Ls.append(float(loss_dev.mean()))
+        ok(lib.a0_actor_collect(ac, qs_h, rs_h, T * E, C.addressof(nret), st), "a0_actor_collect")
+        n_qs += list(qs_h)
+        n_rs += list(rs_h)[: nret.value]
+        assert frame_count == res["frames"]
+    torch.cuda.synchronize()
+    rp = tr.replay
+    frames, act, rew, done = torch.empty_like(rp.frames), torch.empty_like(rp.act), torch.empty_like(rp.rew), torch.empty_like(rp.done)
+    tree = torch.empty_like(rp.tree) if prio else None
+    max_p = tr.ops.zeros(1)
+    ok(lib.a0_rbuf_read(rb, SIZE, frames.data_ptr(), act.data_ptr(), rew.data_ptr(), done.data_ptr(), None if tree is None else tree.data_ptr(), max_p.data_ptr(), st), "a0_rbuf_read")
+    on, tg, m, v, state = nat.get()
+    torch.cuda.synchronize()
+    assert torch.equal(frames, rp.frames) and torch.equal(act, rp.act) and torch.equal(rew, rp.rew) and torch.equal(done, rp.done), "replay ring"
+    if prio:
+        assert torch.equal(tree, rp.tree) and float(max_p[0]) == rp.max_p, "sum-tree / max_p"
+        beta = C.c_double()
+        ok(lib.a0_rbuf_info(rb, None, None, C.addressof(beta)), "a0_rbuf_info")
+        assert beta.value == rp.beta
+    assert torch.equal(on, eng.online.flat) and torch.equal(tg, eng.target.flat) and torch.equal(m, eng.adam_m) and torch.equal(v, eng.adam_v), "parameters / target / Adam moments"
+    assert int(state[1]) == tr.learner.update_steps == 7 * LS and int(state[1]) // TF >= 4
+    assert n_rs == [float(x) for x in tr.Rs], "episode returns, in the reference's order"
+    assert np.array_equal(np.array(n_qs, dtype=np.float32), np.array(tr.Qs, dtype=np.float32)), "per-step mean max-Q"
+    assert np.allclose(n_Ls, tr.Ls, rtol=1e-6, atol=0) and len(n_Ls) == 7 * LS
+    lib.a0_actor_destroy(ac); lib.a0_rbuf_destroy(rb); nat.close()
+
+
+def _rbuf_frames(lib, rb):
+    import ctypes as C
+    p = C.c_void_p()
+    _ = lib.a0_rbuf_buffers(rb, C.addressof(p), None, None, None, None, None)
+    return p
+
+
+def test_plain_c_host_runs_baseline_config1(tmp_path):
+    """tests/c_host_loop.c: BASELINE configs[1]'s workload (256 envs x 80 steps + 20 updates of batch 512 per iteration; a 40 000-slot ring here) driven from
+    plain C through the a0_actor / a0_rbuf / a0_learner handles — no Python, no torch in the process.  Compiled with gcc against the in-tree library, run as a child."""
+    import json, os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no C compiler / ROCm headers on this box")
+    exe, lib = str(tmp_path / "c_host_loop"), os.path.join(root, "agent0_amd", "lib")
+    r = subprocess.run([gcc, "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "c_host_loop.c"), "-I/opt/rocm/include", "-I", os.path.join(root, "include"), "-L", lib,
+                        "-lagent0_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, "12", "40000", "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(out)
+    assert out["iterations_timed"] == 12 and out["updates"] == 12 * 20 and out["finite"] == 1 and out["episodes"] > 100
+    assert out["env_frames_per_sec"] > 5e5, "a C host has no reason to be slower than the Python one"

@@ -9,7 +9,7 @@ SRC="${ROOT}/agent0_amd/csrc"; OBJ="${SRC}/_obj_${NAME}"; OUT="${ROOT}/tools/var
 mkdir -p "${OBJ}" "${OUT}"
 FLAGS=(-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I"${ROOT}/include" "$@" "-DA0_BUILD_VARIANT=\"${NAME}: $*\"")
 pids=()
-for s in core net encoder_fused conv1_wgrad conv23_wgrad loss quantile optim replay rng synth_env actor dp learner; do
+for s in core net encoder_fused conv1_wgrad conv23_wgrad loss quantile optim replay rng synth_env actor dp learner runtime; do
   /opt/rocm/bin/hipcc "${FLAGS[@]}" -c "${SRC}/${s}.hip" -o "${OBJ}/${s}.o" & pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
