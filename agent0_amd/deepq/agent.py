@@ -401,6 +401,29 @@ class Actor:
             return frames_out, rs, qs
         return self.block_of(pending), rs, qs
 
+    def stats_async(self, pending):
+        """The statistics of an issued rollout on their way to page-locked host buffers, stream-ordered behind it (and ahead of the next rollout, which reuses the
+        device buffers); ``stats_finish`` waits for exactly these copies, not for whatever was enqueued afterwards."""
+        T = pending[0]
+        n = T * self.E
+        host = self.__dict__.setdefault("_stat_host", {})
+        out = []
+        for name, src in (("qs", self.qs[:T]), ("mask", self.stat_mask[:n]), ("ret", self.stat_ret[:n])):
+            key = (name, src.numel())
+            if key not in host:
+                host[key] = torch.empty(src.numel(), dtype=src.dtype).pin_memory()
+            host[key].copy_(src, non_blocking=True)
+            out.append(host[key])
+        ev = torch.cuda.Event()
+        ev.record()
+        return (ev, out)
+
+    def stats_finish(self, handle):
+        """(returns, per-step mean max-Q) as ``sample_finish`` reports them."""
+        ev, (qs, mask, ret) = handle
+        ev.synchronize()
+        return ret.numpy()[mask.numpy() != 0].tolist(), qs.tolist()
+
     def close(self):
         self.envs.close()
 

@@ -155,7 +155,7 @@ class Trainer:
         self._step_device(transitions)
         return self._result()
 
-    def _step_device(self, transitions):
+    def _step_device(self, transitions, defer: bool = False):
         """trainer.py:76-110 without the host-side statistics: commit the rollout, run the update block.  Everything here is enqueued on the
         stream; nothing waits for the device except the one read of the block's loss means at the end."""
         cfg = self.cfg
@@ -184,6 +184,8 @@ class Trainer:
                     self.ops.mean_rows(f_loss, 1, B, self._floss_means[i:i + 1])
                     has_frac = True
                 n_upd += 1
+        if defer:
+            return self._block_stats_async(n_upd, has_frac)
         if n_upd:
             self.Ls.extend(self._block_loss_means(n_upd))                   # the one device->host read of the update block
             # the device's update count (NaN-skipped steps do not count) for the next block's pipelining decision: read here, where the host has just waited
@@ -191,6 +193,41 @@ class Trainer:
             self._updates_done = int(self.learner.engine.state[1]) if self._pipeline_candidate() else None
             if has_frac:
                 self.FLs.extend(self._floss_means[:n_upd].cpu().tolist())
+        return None
+
+    # ------------------------------------------------------------------ statistics read-back that does not stop the stream (run_iteration(prefetch=True))
+    def _block_stats_async(self, n_upd: int, has_frac: bool):
+        """Enqueue the copies of the block's loss means into page-locked host buffers (stream-ordered behind the block, ahead of whatever is enqueued next);
+        ``_block_stats_finish`` reads them once the caller has waited for an event recorded after this call."""
+        if not n_upd:
+            return (0, None, None, None)
+        host = self.__dict__.setdefault("_stat_host", {})
+        ring0 = getattr(self, "_ring0", None)
+        src = self.learner.engine.loss_ring if ring0 is not None else self._loss_means
+        key = ("ring" if ring0 is not None else "means", src.numel())
+        if key not in host:
+            host[key] = torch.empty(src.numel(), dtype=src.dtype).pin_memory()
+        host[key].copy_(src, non_blocking=True)
+        fl = None
+        if has_frac:
+            fk = ("fmeans", self._floss_means.numel())
+            if fk not in host:
+                host[fk] = torch.empty(self._floss_means.numel(), dtype=self._floss_means.dtype).pin_memory()
+            host[fk].copy_(self._floss_means, non_blocking=True)
+            fl = host[fk]
+        self._updates_done = None
+        return (n_upd, ring0, host[key], fl)
+
+    def _block_stats_finish(self, handle):
+        n_upd, ring0, buf, fl = handle
+        if not n_upd:
+            return
+        if ring0 is None:
+            self.Ls.extend(buf[:n_upd].tolist())
+        else:
+            self.Ls.extend(float(buf[(ring0 + i) % buf.numel()]) for i in range(n_upd))
+        if fl is not None:
+            self.FLs.extend(fl[:n_upd].tolist())
 
     # ------------------------------------------------------------------ the update block with the target network's passes one update ahead
     def _loss_ring_start(self):
@@ -374,23 +411,38 @@ class Trainer:
         result.update(fps=self.num_transitions / (time.time() - tic))
         return result
 
-    def run_iteration(self):
-        """One pass of the loop body of trainer.py:176-182; returns the result dict including fps."""
+    def run_iteration(self, prefetch: bool = False):
+        """One pass of the loop body of trainer.py:176-182; returns the result dict including fps.
+
+        ``prefetch=True`` (``run()`` for every iteration but the last, bench.py's ``main`` schedule): the NEXT iteration's rollout is enqueued before the host
+        waits for this iteration's statistics, which travel through page-locked buffers behind an event — same kernels in the same stream order with the same
+        arguments (the next epsilon depends on the frame count only), so every number is the one the unpipelined loop produces
+        (tests/test_gpu_trainer.py::test_prefetched_rollouts_change_no_number), but the GPU does not idle while Python collects statistics, logs and builds the
+        next launch.  A rollout issued ahead is consumed by the next call (whatever its ``prefetch``), or booked into the replay by ``final()``."""
         if self.use_lp:
             return self.run_iteration_lp()
         tic = time.time()
-        epsilon = self.epsilon_fn(self.frame_count)
         # Same work in the same stream order as ``step(*actor.sample(eps))`` — the update block's kernels are ordered behind the rollout's — but
         # the host does not stop between them: the rollout's statistics (episode returns, per-step max-Q: one small read-back) are collected
         # after the update block has been enqueued instead of before, so the GPU never waits for Python at the rollout / update boundary.
         actor = self.actors[1]
-        pending = actor.sample_async(epsilon)
-        self._step_device(actor.block_of(pending))
-        _, returns, qmax = actor.sample_finish(pending)
+        pending, self._prefetched = getattr(self, "_prefetched", None), None
+        if pending is None:
+            pending = actor.sample_async(self.epsilon_fn(self.frame_count))
+        if not prefetch:
+            self._step_device(actor.block_of(pending))
+            _, returns, qmax = actor.sample_finish(pending)
+        else:
+            blk = self._step_device(actor.block_of(pending), defer=True)
+            st = actor.stats_async(pending)                                     # ahead of the next rollout, which overwrites the statistics buffers
+            self._prefetched = actor.sample_async(self.epsilon_fn(self.frame_count))
+            returns, qmax = actor.stats_finish(st)
+            self._block_stats_finish(blk)
         self.Qs.extend(qmax)
         self.Rs.extend(returns)
         result = self._result()
-        torch.cuda.synchronize()
+        if not prefetch:
+            torch.cuda.synchronize()
         result.update(fps=self.num_transitions / (time.time() - tic))
         return result
 
@@ -404,14 +456,22 @@ class Trainer:
             return self.final(save=False)
         remaining = max(cfg.trainer.total_steps - self.frame_count, 0)
         trainer_steps = remaining // self.num_transitions + 1
-        for _ in range(trainer_steps):
-            self.logging(self.run_iteration())
+        ahead = os.environ.get("A0_PREFETCH_ROLLOUT", "1") != "0"
+        for i in range(trainer_steps):
+            self.logging(self.run_iteration(prefetch=ahead and i + 1 < trainer_steps))
         self.final()
 
     def final(self, save: bool = True):
         if self.use_lp and self._pending is not None:
             self.actors[1].sample_finish(self._pending)      # drain the rollout still in flight
             self._pending = None
+        if getattr(self, "_prefetched", None) is not None:   # a rollout issued ahead by run_iteration(prefetch=True) and never consumed: book it, so that replay and counters agree with the device
+            pending, self._prefetched = self._prefetched, None
+            transitions, returns, qmax = self.actors[1].sample_finish(pending)
+            self.replay.extend(transitions)
+            self.frame_count += self.num_transitions
+            self.Qs.extend(qmax)
+            self.Rs.extend(returns)
         try:
             if self.primary:
                 self.test()

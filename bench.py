@@ -253,8 +253,11 @@ def main():
     torch.cuda.synchronize()
     t_fill = time.time() - t_fill
     cfg.trainer.training_start_steps = min(start_steps, cfg.replay.size - 1)
+    # the `main` schedule issues iteration i + 1's rollout before it waits for iteration i's statistics (Trainer.run does the same): same stream order, same
+    # numbers; the timed region then holds K update blocks and K rollouts (2 .. K + 1; rollout 1 was issued by the last warm-up step and is complete at the barrier)
+    ahead = os.environ.get("A0_PREFETCH_ROLLOUT", "1") != "0"           # (ignored by the `launch` schedule, whose rollouts are in flight during the update block anyway)
     for _ in range(args.warmup):
-        tr.run_iteration()
+        tr.run_iteration(prefetch=ahead)
 
     def barrier():
         torch.cuda.synchronize()
@@ -267,7 +270,7 @@ def main():
     t0 = time.time()
     last = None
     for _ in range(args.steps):
-        last = tr.run_iteration()
+        last = tr.run_iteration(prefetch=ahead)
     torch.cuda.synchronize()
     dt_local = time.time() - t0          # this rank's own K steps, before it waits for the others: diagnoses a straggler from the one JSON line
     barrier()
@@ -326,11 +329,11 @@ def main():
             tr.overlap = True
         keep_L = cfg.learner.learner_steps
         cfg.learner.learner_steps = 320
-        tr.run_iteration()
+        tr.run_iteration(prefetch=ahead)
         torch.cuda.synchronize()
         t1 = time.time()
         for _ in range(3):
-            tr.run_iteration()
+            tr.run_iteration(prefetch=ahead)
         torch.cuda.synchronize()
         d1 = (time.time() - t1) / 3
         cfg.learner.learner_steps = keep_L
@@ -347,11 +350,11 @@ def main():
             tr2.run_iteration()
         cfg2.trainer.training_start_steps = min(start_steps, cfg2.replay.size - 1)
         for _ in range(max(args.warmup, 3)):          # eager runs, then graph capture
-            tr2.run_iteration()
+            tr2.run_iteration(prefetch=ahead)
         torch.cuda.synchronize()
         t2 = time.time()
         for _ in range(args.steps):
-            tr2.run_iteration()
+            tr2.run_iteration(prefetch=ahead)
         torch.cuda.synchronize()
         d2 = (time.time() - t2) / args.steps
         other = {"entry": "agent0.deepq." + ("main" if args.entry == "launch" else "launch"), "value": round(per_iter / d2, 1), "unit": "env-frames/sec",
@@ -382,7 +385,8 @@ def main():
                                f"(full), obs 4x84x84 u8, per-rank shards, " + ("independent replicas: one game per rank, no gradient exchange" if args.replicas else
                                "RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)")),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
-                   "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}", "gradient_exchange": exchange},
+                   "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}", "rollout_prefetch": bool(ahead and args.entry == "main"),
+                   "gradient_exchange": exchange},
         "per_rank_ms_per_step": per_rank, "gradient_exchange": exchange,
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
         "device": arch, "replay_fill_s": round(t_fill, 2),

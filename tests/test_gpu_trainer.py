@@ -524,6 +524,45 @@ def test_pipelined_target_pass_changes_no_number(algo, extra, launch, monkeypatc
     assert torch.equal(p0, p1) and torch.equal(t0, t1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(f0, f1)
 
 
+@pytest.mark.parametrize("algo,extra", [("dqn", {}), ("dqn", {"replay.policy": "prioritize", "learner.n_step_q": 3}), ("c51", {"learner.noisy_net": "true"}),
+                                        ("fqf", {"env_id": "Asterix"})], ids=["dqn", "dqn-per-n3", "c51-noisy", "fqf"])
+def test_prefetched_rollouts_change_no_number(algo, extra, monkeypatch):
+    """Round 4: ``run_iteration(prefetch=True)`` (Trainer.run, bench.py's `main` schedule) enqueues iteration i + 1's rollout before the host waits for iteration
+    i's statistics, which come back through page-locked buffers behind an event.  The stream sees the same launches in the same order with the same arguments,
+    so losses, max-Q and return statistics, parameters, Adam moments and the replay ring must be BIT-identical to the loop that stops at every iteration —
+    including an epsilon schedule that moves (the next epsilon is a function of the frame count only) and a rollout issued ahead and booked by ``final()``."""
+    from agent0_amd.deepq.trainer import Trainer
+
+    def run(ahead):
+        cfg = make_cfg(algo, 8, **{"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 5, "trainer.training_start_steps": 100,
+                                    "learner.target_update_freq": 7, "trainer.exploration_steps": 600, **extra})
+        tr = Trainer(cfg)
+        res = []
+        for i in range(10):
+            res.append(tr.run_iteration(prefetch=ahead and i != 4))       # iteration 5 consumes a prefetched rollout, iteration 6 issues its own
+        if not ahead:
+            tr.replay.extend(tr.actors[1].sample(tr.epsilon_fn(tr.frame_count))[0])      # what final() books for the prefetching loop: one more rollout
+            tr.frame_count += tr.num_transitions
+        else:
+            assert tr._prefetched is not None
+            pending, tr._prefetched = tr._prefetched, None
+            tr.replay.extend(tr.actors[1].sample_finish(pending)[0])
+            tr.frame_count += tr.num_transitions
+        torch.cuda.synchronize()
+        eng = tr.learner.engine
+        keep = [{k: v for k, v in r.items() if k != "fps"} for r in res]
+        return (keep, list(tr.Ls), list(tr.FLs), list(tr.Qs), list(tr.Rs), tr.frame_count, len(tr.replay), eng.online.flat.clone(), eng.target.flat.clone(),
+                eng.adam_m.clone(), eng.adam_v.clone(), tr.replay.frames.clone())
+
+    a = run(False)
+    b = run(True)
+    assert len(a[1]) == 45 and (algo != "fqf" or len(a[2]) == 45)
+    for x, y in zip(a[:7], b[:7]):
+        assert x == y
+    for x, y in zip(a[7:], b[7:]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("algo", ["dqn", "c51", "iqr"])
 def test_loss_statistic_from_the_adam_launch_equals_mean_rows(algo, monkeypatch):
     """Round 4: the Trainer's per-update `loss` statistic (trainer.py:99,111-113) is taken by workgroup 0 of the Adam launch into a ring (a0_adam_step_sync_wt,
