@@ -403,7 +403,7 @@ static bool a0_sumtree_sub_path(long long cap2) {
     return !one_wg && (S == 64 || S == 128 || S == 256 || S == 512 || S == 1024);
 }
 static void a0_sumtree_sub_launch(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, const float* loss, float eps, float alpha,
-                                  float* pstate, hipStream_t st) {
+                                  float* pstate, hipStream_t st, bool defer_top = false) {
     switch ((int)(cap2 / A0_ST_TOP)) {
         case 64: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<1>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
         case 128: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<2>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
@@ -411,7 +411,7 @@ static void a0_sumtree_sub_launch(float* tree, long long cap2, const long long* 
         case 512: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<8>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
         default: hipLaunchKernelGGL(a0_sumtree_set_sub_kernel<16>, dim3(n), dim3(64), 0, st, tree, cap2, idx, val, n, state, loss, eps, alpha, pstate); break;
     }
-    hipLaunchKernelGGL(a0_sumtree_top_kernel, dim3(1), dim3(1024), 0, st, tree, state);
+    if (!defer_top) hipLaunchKernelGGL(a0_sumtree_top_kernel, dim3(1), dim3(1024), 0, st, tree, state);
 }
 
 // replay.py:55-59 on the sum-tree in TWO launches (was three): leaf[idx] = (loss + eps)^alpha in batch order, max_p = max(max_p, max loss), subtrees, then the top.
@@ -419,11 +419,20 @@ static void a0_sumtree_sub_launch(float* tree, long long cap2, const long long* 
 extern "C" int a0_sumtree_set_from_loss_ok(long long cap2) { return (cap2 >= 1 && !(cap2 & (cap2 - 1)) && a0_sumtree_sub_path(cap2)) ? 1 : 0; }
 
 extern "C" int a0_sumtree_set_from_loss(float* tree, long long cap2, const long long* idx, const float* loss, int n, float eps, float alpha, float* pstate, const int* state,
-                                        void* stream) {
+                                        int defer_top, void* stream) {
     if (!tree || !idx || !loss || !pstate || n < 1 || n > 1024 || cap2 < 1 || (cap2 & (cap2 - 1)) || !a0_sumtree_sub_path(cap2))
         return a0_fail(A0_EINVAL, "a0_sumtree_set_from_loss: bad argument (at most 1024 leaves per call, a tree a0_sumtree_set_from_loss_ok accepts)");
-    a0_sumtree_sub_launch(tree, cap2, idx, nullptr, n, state, loss, eps, alpha, pstate, (hipStream_t)stream);
+    a0_sumtree_sub_launch(tree, cap2, idx, nullptr, n, state, loss, eps, alpha, pstate, (hipStream_t)stream, defer_top != 0);
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_set_from_loss");
+}
+
+// The launch a0_sumtree_set_from_loss(defer_top = 1) leaves out, for a reader of the top levels other than a0_sumtree_sample_batch(rebuild_top = 1) and
+// a0_sumtree_set_range (both recompute the top from level A0_ST_TOP themselves).  Idempotent.
+extern "C" int a0_sumtree_top_rebuild(float* tree, long long cap2, void* stream) {
+    if (!tree || cap2 < 1 || (cap2 & (cap2 - 1))) return a0_fail(A0_EINVAL, "a0_sumtree_top_rebuild: bad argument");
+    if (cap2 < 2 * A0_ST_TOP) return a0_sumtree_rebuild(tree, cap2, stream);
+    hipLaunchKernelGGL(a0_sumtree_top_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree, (const int*)nullptr);
+    return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_top_rebuild");
 }
 
 extern "C" int a0_sumtree_set(float* tree, long long cap2, const long long* idx, const float* val, int n, const int* state, void* stream) {
@@ -507,8 +516,7 @@ extern "C" int a0_sumtree_sample(const float* tree, long long cap2, const float*
 // and because every internal node IS left + right of its children (the tree is only ever recomputed from children, never updated by delta), the children's
 // values are gc0 + gc1 and gc2 + gc3 bit for bit — so one 16-byte load replaces two dependent 8-byte ones and the comparisons see the same numbers.
 // A 1 M-leaf tree is 20 dependent L2 round trips deep (~0.8 us each for a lone workgroup); this makes it 10.
-A0_D long long a0_sumtree_descend(const float* __restrict__ tree, long long cap2, float u) {
-    long long n = 1;
+A0_D long long a0_sumtree_descend(const float* __restrict__ tree, long long cap2, float& u, long long n = 1) {
     while (4 * n <= cap2) {              // at least two levels below n
         const a0_f4 g = *(const a0_f4*)(tree + 4 * n);
         const float left = g.x + g.y, right = g.z + g.w;
@@ -533,19 +541,37 @@ A0_D long long a0_sumtree_descend(const float* __restrict__ tree, long long cap2
 // The stratified uniforms (element b of the sampler's Philox stream: the value a0_rng_uniform would write), the sum-tree descent, the
 // slot / metadata lookup and the importance weights w = (top * p / total)^-beta / (max w + 1e-8) (trainer.py:91-94) for one batch:
 // == a0_rng_uniform + a0_sumtree_sample + a0_replay_lookup + a0_is_weights, statement for statement.  Single workgroup, B <= 1024.
-__global__ __launch_bounds__(1024) void a0_sumtree_batch_kernel(unsigned long long seed, uint32_t stream, unsigned long long offset, const float* __restrict__ tree,
+__global__ __launch_bounds__(1024) void a0_sumtree_batch_kernel(unsigned long long seed, uint32_t stream, unsigned long long offset, float* __restrict__ tree,
                                                                  long long cap2, int B, long long top, long long cap, float beta, const int* __restrict__ r_act,
                                                                  const float* __restrict__ r_rew, const float* __restrict__ r_done, long long* __restrict__ idx_out,
                                                                  int* __restrict__ slot_out, int* __restrict__ act, float* __restrict__ rew, float* __restrict__ done,
-                                                                 float* __restrict__ prio, float* __restrict__ w) {
+                                                                 float* __restrict__ prio, float* __restrict__ w, int rebuild_top) {
     __shared__ float red[1024];
-    const float total = tree[1];
+    // Round 4: the levels with at most A0_ST_TOP nodes are staged in LDS first — recomputed from level A0_ST_TOP exactly as a0_sumtree_top does (and written back when
+    // `rebuild_top`: the launch a0_sumtree_set_from_loss(defer_top = 1) left out; recomputing a top that is up to date changes no bit) — and the descent walks them
+    // there: eleven of a 1 M-leaf tree's twenty levels cost LDS reads instead of five dependent L2 round trips, and the prioritized update is two launches
+    // (subtrees; top + next batch) instead of three.  Same comparisons on the same node values: every node IS left + right of its children.
+    __shared__ float top_l[2 * A0_ST_TOP];
+    const long long s0 = cap2 < A0_ST_TOP ? cap2 : A0_ST_TOP;
+    for (long long p = threadIdx.x; p < s0; p += blockDim.x) top_l[s0 + p] = tree[s0 + p];
+    __syncthreads();
+    for (long long span = s0 >> 1; span >= 1; span >>= 1) {
+        for (long long p = span + threadIdx.x; p < 2 * span; p += blockDim.x) top_l[p] = top_l[2 * p] + top_l[2 * p + 1];
+        __syncthreads();
+    }
+    if (rebuild_top) for (long long p = 1 + threadIdx.x; p < s0; p += blockDim.x) tree[p] = top_l[p];
+    const float total = top_l[1];
     const float seg = total / (float)B;
     float mx = 0.f;
     for (int k = threadIdx.x; k < B; k += blockDim.x) {
         const float xi = (float)(a0_philox_word(seed, stream, offset + (unsigned long long)k) >> 8) * 0x1.0p-24f;
-        const float u = ((float)k + xi) * seg;
-        const long long n = a0_sumtree_descend(tree, cap2, u);
+        float u = ((float)k + xi) * seg;
+        long long n = 1;
+        while (n < s0) {
+            const float left = top_l[2 * n], right = top_l[2 * n + 1];
+            if (u < left || !(right > 0.0f)) { n = 2 * n; } else { u -= left; n = 2 * n + 1; }
+        }
+        n = a0_sumtree_descend(tree, cap2, u, n);
         const long long li = (n - cap2) % cap;          // sum-tree leaves are addressed by ring slot (head = 0): logical index == slot
         const long long sl = li;
         const float p = tree[n];
@@ -563,15 +589,15 @@ __global__ __launch_bounds__(1024) void a0_sumtree_batch_kernel(unsigned long lo
     for (int k = threadIdx.x; k < B; k += blockDim.x) w[k] = w[k] / denom;
 }
 
-extern "C" int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, const float* tree, long long cap2, int B, long long top,
+extern "C" int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, float* tree, long long cap2, int B, long long top,
                                        long long cap, float beta, const int* r_act, const float* r_rew, const float* r_done, long long* idx_out, int* slot_out,
-                                       int* act, float* rew, float* done, float* prio, float* w, void* stream_h) {
+                                       int* act, float* rew, float* done, float* prio, float* w, int rebuild_top, void* stream_h) {
     if (!tree || !r_act || !r_rew || !r_done || !idx_out || !slot_out || !act || !rew || !done || !prio || !w || B < 1 || B > 1024 || top < 1 || cap < top ||
         cap2 < cap || (cap2 & (cap2 - 1)) || cap > 2147483647LL)
         return a0_fail(A0_EINVAL, "a0_sumtree_sample_batch: bad argument");
     int threads = 64; while (threads < B && threads < 1024) threads <<= 1;
     hipLaunchKernelGGL(a0_sumtree_batch_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream_h, seed, stream, offset, tree, cap2, B, top, cap, beta, r_act, r_rew, r_done,
-                       idx_out, slot_out, act, rew, done, prio, w);
+                       idx_out, slot_out, act, rew, done, prio, w, rebuild_top);
     return a0_fail_hip((int)hipGetLastError(), "a0_sumtree_sample_batch");
 }
 

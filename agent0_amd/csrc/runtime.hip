@@ -62,6 +62,7 @@ struct a0_rbuf {
     uint8_t* frames = nullptr;
     int* act = nullptr; float *rew = nullptr, *done = nullptr;
     float *tree = nullptr, *pstate = nullptr, *val = nullptr, *ones = nullptr;
+    bool top_stale = false;        // update_priority left tree[1 .. 2047] to the next sample's launch (a0_sumtree_set_from_loss(defer_top)); a0_rbuf_read brings them up to date
     long long* b_idx = nullptr; int *b_slot = nullptr, *b_act = nullptr; float *b_rew = nullptr, *b_done = nullptr, *b_prio = nullptr, *b_w = nullptr;
     long long head() const { return written > size ? written % size : 0; }
 };
@@ -113,7 +114,7 @@ extern "C" int a0_rbuf_buffers(a0_rbuf* R, uint8_t** frames, int** act, float** 
     if (act) *act = R->act;
     if (rew) *rew = R->rew;
     if (done) *done = R->done;
-    if (tree) *tree = R->tree;
+    if (tree) *tree = R->tree;       // (levels with < 2048 nodes may be stale after a0_rbuf_update_priority until the next a0_rbuf_sample / a0_rbuf_commit: use a0_rbuf_read for a consistent copy)
     if (max_p) *max_p = R->pstate;
     return A0_OK;
 }
@@ -127,6 +128,7 @@ extern "C" int a0_rbuf_read(const a0_rbuf* R, long long rows, uint8_t* frames_ou
     if (act_out) A0_HIP_THROW(hipMemcpyAsync(act_out, R->act, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
     if (rew_out) A0_HIP_THROW(hipMemcpyAsync(rew_out, R->rew, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
     if (done_out) A0_HIP_THROW(hipMemcpyAsync(done_out, R->done, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
+    if (tree_out && R->tree && R->top_stale) A0_CHECK(a0_sumtree_top_rebuild(R->tree, R->cap2, stream));      // (the flag stays: idempotent, and R is const here)
     if (tree_out && R->tree) A0_HIP_THROW(hipMemcpyAsync(tree_out, R->tree, (size_t)(2 * R->cap2) * 4, hipMemcpyDeviceToDevice, st));
     if (max_p_out) A0_HIP_THROW(hipMemcpyAsync(max_p_out, R->pstate, 4, hipMemcpyDeviceToDevice, st));
     return A0_OK;
@@ -144,6 +146,7 @@ extern "C" int a0_rbuf_commit(a0_rbuf* R, long long n, void* stream) {
         hipLaunchKernelGGL(a0_pow_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, R->pstate, R->d.alpha, R->val);
         const long long k = n < R->size ? n : R->size;
         A0_CHECK(a0_sumtree_set_range(R->tree, R->cap2, (R->written - k) % R->size, k, R->size, R->val, stream));
+        R->top_stale = false;
         R->beta_use = R->sched_cur;                               // beta = beta_schedule(n): the schedule's value BEFORE it advances (utils.py:25-28)
         const double nxt = R->sched_cur + R->beta_inc * (double)n;
         R->sched_cur = nxt < 1.0 ? nxt : 1.0;
@@ -162,7 +165,8 @@ extern "C" int a0_rbuf_sample(a0_rbuf* R, a0_batch* out, void* stream) {
     if (R->prio) {
         const unsigned long long off = R->rng.reserve(STREAM_SUMTREE, B);
         A0_CHECK(a0_sumtree_sample_batch(R->rng.seed, STREAM_SUMTREE, off, R->tree, R->cap2, B, R->top, R->size, (float)R->beta_use, R->act, R->rew, R->done, R->b_idx, R->b_slot,
-                                         R->b_act, R->b_rew, R->b_done, R->b_prio, R->b_w, stream));
+                                         R->b_act, R->b_rew, R->b_done, R->b_prio, R->b_w, R->top_stale ? 1 : 0, stream));
+        R->top_stale = false;
         *out = a0_batch{R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, R->b_w};
         return A0_OK;
     }
@@ -185,7 +189,10 @@ extern "C" int a0_rbuf_update_priority(a0_rbuf* R, const float* loss, const int*
     A0_TRY
     if (!R || !loss) return a0_fail(A0_EINVAL, "a0_rbuf_update_priority: null argument");
     if (!R->prio) return A0_OK;
-    if (a0_sumtree_set_from_loss_ok(R->cap2)) return a0_sumtree_set_from_loss(R->tree, R->cap2, R->b_idx, loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->pstate, learner_state, stream);
+    if (a0_sumtree_set_from_loss_ok(R->cap2)) {
+        R->top_stale = true;
+        return a0_sumtree_set_from_loss(R->tree, R->cap2, R->b_idx, loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->pstate, learner_state, 1, stream);
+    }
     A0_CHECK(a0_priority_from_loss(loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->b_prio, R->pstate, learner_state, stream));
     return a0_sumtree_set(R->tree, R->cap2, R->b_idx, R->b_prio, R->B, learner_state, stream);
     A0_CATCH

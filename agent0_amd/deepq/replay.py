@@ -20,6 +20,8 @@ from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 
 from agent0_amd.common.utils import DeviceRng, LinearSchedule
@@ -108,7 +110,11 @@ class ReplayDataset:
             self.cap2 = 1
             while self.cap2 < self.size:
                 self.cap2 <<= 1
-            self.tree = ops.zeros(2 * self.cap2)
+            self._tree = ops.zeros(2 * self.cap2)
+            # update_priority leaves the levels with < 2048 nodes to the next batch's launch (a0_sumtree_set_from_loss(defer_top) / a0_sumtree_sample_batch(rebuild_top)):
+            # `tree` — what every other reader goes through — brings them up to date first
+            self._top_stale = False
+            self._defer_top = os.environ.get("A0_SUMTREE_DEFER_TOP", "1") != "0"
             self._new_idx = None
             self._val = ops.zeros(max(B, 1))
 
@@ -200,7 +206,8 @@ class ReplayDataset:
             if self.use_sumtree:
                 val = (self._pstate[0:1].double() ** self.cfg.replay.alpha).float()
                 k = min(n, self.size)                     # one launch: the new leaves are a ring range
-                self.ops.sumtree_set_range(self.tree, self.cap2, (self.written - k) % self.size, k, self.size, val)
+                self.ops.sumtree_set_range(self._tree, self.cap2, (self.written - k) % self.size, k, self.size, val)
+                self._top_stale = False          # the range kernel recomputes every level above 2048 nodes from that level
             else:
                 self.ops.priority_tail(self.priority, self.size, min(n, self.size), self._pstate, float(self.cfg.replay.alpha))
             self.beta = self.beta_schedule(n)
@@ -214,6 +221,21 @@ class ReplayDataset:
         return row, int(self.act[slot]), float(self.rew[slot]), bool(self.done[slot] != 0), pr.cpu(), idx
 
     # ------------------------------------------------------------------ priorities
+    _tree = None
+    _top_stale = False
+
+    @property
+    def tree(self) -> torch.Tensor:
+        """The sum-tree [2 * cap2] with every level up to date."""
+        if self._top_stale:
+            self.ops.sumtree_top_rebuild(self._tree, self.cap2)
+            self._top_stale = False
+        return self._tree
+
+    @tree.setter
+    def tree(self, t: torch.Tensor):
+        self._tree, self._top_stale = t, False
+
     def update_priority(self, ids: torch.Tensor, priorities: torch.Tensor, state: Optional[torch.Tensor] = None):
         """replay.py:55-59: priority[ids] = (loss + eps)^alpha; max_p = max(max_p, max loss).  ``state``: the learner's status words — when
         the update these losses come from was skipped on a NaN (agent.py:152-158 returns None and trainer.py:103 then skips the call), the
@@ -224,7 +246,8 @@ class ReplayDataset:
         pr = priorities.to(self.ops.device, torch.float32).contiguous()
         if self.use_sumtree and B <= 1024 and self.ops.sumtree_set_from_loss_ok(self.cap2):
             # priorities formed inside the per-subtree kernel: two launches (subtrees, top) instead of three
-            self.ops.sumtree_set_from_loss(self.tree, self.cap2, ids, pr, B, float(rc.eps), float(rc.alpha), self._pstate, state)
+            self.ops.sumtree_set_from_loss(self._tree, self.cap2, ids, pr, B, float(rc.eps), float(rc.alpha), self._pstate, state, defer_top=self._defer_top)
+            self._top_stale = self._defer_top
         elif self.use_sumtree:
             if self._val.numel() < B:
                 self._val = self.ops.zeros(B)
@@ -296,8 +319,9 @@ class ReplayDataset:
         if self.use_sumtree and B <= 1024:
             # stratified draws, descent, slot + metadata and importance weights in one launch
             rng = self.rng
-            self.ops.sumtree_sample_batch(rng.seed, rng.STREAM_SUMTREE, rng.reserve(rng.STREAM_SUMTREE, B), self.tree, self.cap2, B, self.top, self.size, float(self.beta),
-                                          self.act, self.rew, self.done, self._idx, self._slot, self._act, self._rew, self._done, self._prio, self._w)
+            stale, self._top_stale = self._top_stale, False
+            self.ops.sumtree_sample_batch(rng.seed, rng.STREAM_SUMTREE, rng.reserve(rng.STREAM_SUMTREE, B), self._tree, self.cap2, B, self.top, self.size, float(self.beta),
+                                          self.act, self.rew, self.done, self._idx, self._slot, self._act, self._rew, self._done, self._prio, self._w, rebuild_top=stale)
             idx = self._idx
         elif self.use_sumtree:
             self.rng.uniform(self.rng.STREAM_SUMTREE, self._xi, B)

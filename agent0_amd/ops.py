@@ -564,12 +564,12 @@ class HipOps:
         check(self.lib.a0_sumtree_set(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(val, torch.float32, n, "val"), n,
                                       _req(state, torch.int32, 8, "state", optional=True), _stream()), "a0_sumtree_set")
 
-    def sumtree_sample_batch(self, seed, stream, offset, tree, cap2, B, top, cap, beta, r_act, r_rew, r_done, idx_out, slot_out, act, rew, done, prio, w):
+    def sumtree_sample_batch(self, seed, stream, offset, tree, cap2, B, top, cap, beta, r_act, r_rew, r_done, idx_out, slot_out, act, rew, done, prio, w, rebuild_top=False):
         check(self.lib.a0_sumtree_sample_batch(seed, stream, offset, _req(tree, torch.float32, 2 * cap2, "tree"), cap2, B, top, cap, float(beta),
                                                _req(r_act, torch.int32, cap, "r_act"), _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"),
                                                _req(idx_out, torch.int64, B, "idx_out"), _req(slot_out, torch.int32, B, "slot_out"), _req(act, torch.int32, B, "act"),
                                                _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"), _req(prio, torch.float32, B, "prio"),
-                                               _req(w, torch.float32, B, "w"), _stream()), "a0_sumtree_sample_batch")
+                                               _req(w, torch.float32, B, "w"), 1 if rebuild_top else 0, _stream()), "a0_sumtree_sample_batch")
 
     def sumtree_set_range(self, tree, cap2, start, n, size, val):
         check(self.lib.a0_sumtree_set_range(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, start, n, size, _req(val, torch.float32, 1, "val"), _stream()),
@@ -585,9 +585,13 @@ class HipOps:
     def sumtree_set_from_loss_ok(self, cap2) -> bool:
         return bool(self.lib.a0_sumtree_set_from_loss_ok(cap2))
 
-    def sumtree_set_from_loss(self, tree, cap2, idx, loss, n, eps, alpha, pstate, state=None):
+    def sumtree_top_rebuild(self, tree, cap2):
+        check(self.lib.a0_sumtree_top_rebuild(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _stream()), "a0_sumtree_top_rebuild")
+
+    def sumtree_set_from_loss(self, tree, cap2, idx, loss, n, eps, alpha, pstate, state=None, defer_top=False):
         check(self.lib.a0_sumtree_set_from_loss(_req(tree, torch.float32, 2 * cap2, "tree"), cap2, _req(idx, torch.int64, n, "idx"), _req(loss, torch.float32, n, "loss"), n,
-                                                float(eps), float(alpha), _req(pstate, torch.float32, 1, "pstate"), _req(state, torch.int32, 8, "state", optional=True), _stream()),
+                                                float(eps), float(alpha), _req(pstate, torch.float32, 1, "pstate"), _req(state, torch.int32, 8, "state", optional=True),
+                                                1 if defer_top else 0, _stream()),
               "a0_sumtree_set_from_loss")
 
     def priority_from_loss(self, loss, n, eps, alpha, val, pstate, state=None):

@@ -380,16 +380,22 @@ int a0_sumtree_rebuild(float* tree, long long cap2, void* stream);
 int a0_sumtree_sample(const float* tree, long long cap2, const float* xi, int B, long long* out_idx, float* out_p, void* stream);
 /* one prioritized batch in one launch: stratified uniforms from the sampler's Philox stream, sum-tree descent, slot + metadata lookup and
  * importance weights (trainer.py:91-94); == a0_rng_uniform + a0_sumtree_sample + a0_replay_lookup + a0_is_weights.  B <= 1024. */
-int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, const float* tree, long long cap2, int B, long long top,
+int a0_sumtree_sample_batch(unsigned long long seed, unsigned int stream, unsigned long long offset, float* tree, long long cap2, int B, long long top,
                             long long cap, float beta, const int* r_act, const float* r_rew, const float* r_done, long long* idx_out, int* slot_out,
-                            int* act, float* rew, float* done, float* prio, float* w, void* stream_h);
+                            int* act, float* rew, float* done, float* prio, float* w, int rebuild_top, void* stream_h);
+/* (round 4) the kernel stages the levels with <= 2048 nodes in LDS — recomputed from level 2048 (or the leaves of a smaller tree) — and walks them there;
+ * rebuild_top = 1 also writes them back: the launch a0_sumtree_set_from_loss(defer_top = 1) left out, so that replay.py:55-59 followed by the next
+ * trainer.py:63-72 batch is two launches */
 /* val = (loss + eps)^alpha, pstate[0] = max(pstate[0], max loss) (replay.py:55-59); no-op when state && state[3] (NaN-skipped update) */
 int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, float* val, float* pstate, const int* state, void* stream);
 /* a0_priority_from_loss + a0_sumtree_set in two launches instead of three (replay.py:55-59 on the sum-tree): the per-subtree kernel forms (loss + eps)^alpha while it
  * stages the batch and keeps pstate[0] = max_p; n <= 1024; for trees with a0_sumtree_set_from_loss_ok(cap2) == 1 (64 ... 1024 leaves per subtree below the top 2048 nodes) */
 int a0_sumtree_set_from_loss_ok(long long cap2);
 int a0_sumtree_set_from_loss(float* tree, long long cap2, const long long* idx, const float* loss, int n, float eps, float alpha, float* pstate, const int* state,
-                             void* stream);
+                             int defer_top, void* stream);
+/* defer_top = 1: leaves and subtrees only (one launch); tree[1 .. 2047] are stale until a0_sumtree_sample_batch(rebuild_top = 1), a0_sumtree_set_range (which
+ * recomputes the top from level 2048 anyway) or a0_sumtree_top_rebuild has run — every other reader of the top levels must be preceded by one of them */
+int a0_sumtree_top_rebuild(float* tree, long long cap2, void* stream);
 
 /* ---------------------------------------------------------------- actor (agent0/deepq/agent.py:25-39,57-73) */
 int a0_actor_egreedy(const int* greedy, const int* rand_action, const float* u, float eps, int E, int* action,

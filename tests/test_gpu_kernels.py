@@ -407,6 +407,53 @@ def test_nan_skipped_update_leaves_the_sumtree_alone(hip):
     assert torch.isfinite(b.weights).all() and float(b.weights.max()) <= 1.0
 
 
+@pytest.mark.parametrize("size", [200_000, 1_000_000])
+def test_deferred_top_of_the_sumtree_changes_no_number(hip, size, monkeypatch):
+    """Round 4: update_priority writes leaves and subtrees only (a0_sumtree_set_from_loss(defer_top = 1)); the levels with < 2048 nodes are recomputed by the NEXT
+    batch's launch (a0_sumtree_sample_batch(rebuild_top = 1), which also walks those levels in LDS), by the rollout's range insert, or by the ``tree`` property for any
+    other reader.  Batches (indices, slots, priorities, importance weights), max_p and the whole tree must be bit-identical to the three-launch sequence over rounds of
+    sample / update / extend, and the tree equal to the oracle's after the same sets."""
+    from agent0_amd.deepq.replay import TransitionBlock
+    B = 512
+
+    def run(defer):
+        monkeypatch.setenv("A0_SUMTREE_DEFER_TOP", "1" if defer else "0")
+        rp = _filled_replay(hip, size, B)
+        assert rp._defer_top == defer and hip.sumtree_set_from_loss_ok(rp.cap2)
+        g = recipe.gen(77)
+        out, stale = [], []
+        for r in range(6):
+            b = rp.sample()
+            out += [b.idx.clone(), b.slot.clone(), b.prio.clone(), b.weights.clone()]
+            loss = g.uniform(0, 3, B).astype(np.float32)
+            if r == 2:
+                loss[:] = 0.0                   # a round of equal priorities
+            rp.update_priority(b.idx, D(hip, loss))
+            stale.append(rp._top_stale)
+            if r == 3:
+                rp.extend(TransitionBlock(4096, start=rp.written % size))      # the range insert recomputes the top itself
+                assert not rp._top_stale
+            if r == 4:
+                out.append(rp._tree.clone())    # raw: stale top levels in the deferring run
+                out.append(rp.tree.clone())     # through the property: up to date
+                assert not rp._top_stale
+        out += [rp.tree.clone(), rp._pstate.clone()]
+        return rp, out, stale
+
+    rp0, a, s0 = run(False)
+    rp1, b, s1 = run(True)
+    assert s0 == [False] * 6 and s1 == [True] * 6
+    raw0, raw1 = a.pop(20), b.pop(20)
+    assert torch.equal(raw0[2048:], raw1[2048:]) and not torch.equal(raw0[:2048], raw1[:2048]), "only the levels with < 2048 nodes were deferred"
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    t = core.SumTree(size)
+    t.tree[:] = 0
+    t.tree[t.cap2:] = rp1.tree[rp1.cap2:].cpu().numpy()
+    t.rebuild()
+    assert np.array_equal(t.tree[1:], rp1.tree.cpu().numpy()[1:])
+
+
 def test_priority_update_of_a_batch_larger_than_one_workgroup(hip):
     """B = 2048 > the 1024 leaves a0_sumtree_set stages in LDS: ReplayDataset.update_priority splits the batch in order (a later duplicate
     still wins across the split); the C entry point itself refuses n > 1024.  Tree bytes against the oracle's set on the same pairs."""
