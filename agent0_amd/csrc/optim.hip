@@ -355,6 +355,42 @@ __global__ void a0_noisy_multi_kernel(a0_noisy_multi_args A) {
     }
 }
 
+// The same, four k per lane: 16-byte loads and stores, 32-bit index arithmetic (the element-wise kernel spends its time in a 64-bit division per element; this one
+// runs at the HBM rate).  Every element is formed by the same expression as above; needs K % 4 == 0 and 16-byte aligned blocks / noise vectors (the packed layout's).
+template <bool GRAD>
+__global__ __launch_bounds__(256) void a0_noisy_multi_v4_kernel(a0_noisy_multi_args A) {
+    int mi = 0;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) mi += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
+    const a0_noisy_mod M = A.mod[mi];
+    const unsigned nblk = (unsigned)(A.first_block[mi + 1] - A.first_block[mi]);
+    const unsigned rows = (unsigned)(M.r1 - M.r0), K4 = (unsigned)M.K >> 2, nw = rows * K4, total = nw + rows;
+    const unsigned stride = nblk * 256u;
+    for (unsigned i = ((unsigned)blockIdx.x - (unsigned)A.first_block[mi]) * 256u + threadIdx.x; i < total; i += stride) {
+        if (i < nw) {
+            const unsigned n = i / K4, k4 = i - n * K4;
+            const long long off = (long long)(M.r0 + (int)n) * M.K + 4 * k4;
+            const float eo = a0_noise_f(M.noise_out_w[n]);
+            const a0_f4 ni = *(const a0_f4*)(M.noise_in + 4 * k4);
+            const float e0 = eo * a0_noise_f(ni.x), e1 = eo * a0_noise_f(ni.y), e2 = eo * a0_noise_f(ni.z), e3 = eo * a0_noise_f(ni.w);
+            const a0_f4 mu = *(const a0_f4*)(M.mu + off);
+            a0_f4 o;
+            if (GRAD) { o.x = mu.x * e0; o.y = mu.y * e1; o.z = mu.z * e2; o.w = mu.w * e3; }
+            else {
+                const a0_f4 sg = *(const a0_f4*)(M.sigma + off);
+                o.x = mu.x + sg.x * e0; o.y = mu.y + sg.y * e1; o.z = mu.z + sg.z * e2; o.w = mu.w + sg.w * e3;
+            }
+            *(a0_f4*)(M.out + off) = o;
+        } else {
+            const unsigned n = i - nw;
+            const long long off = (long long)M.N * M.K + M.r0 + (int)n;
+            const float e = a0_noise_f(M.noise_out_b[n]);
+            if (GRAD) M.out[off] = M.mu[off] * e;
+            else M.out[off] = M.mu[off] + M.sigma[off] * e;
+        }
+    }
+}
+
 // nmod <= 6 modules; arrays are host arrays.  grad = 0: eff[m] = mu[m] + sigma[m] * eps (a0_noisy_compose per module);
 // grad = 1: gsigma[m] (passed as eff) = gmu[m] (passed as mu) * eps (a0_noisy_grad_sigma per module; sigma unused).
 extern "C" int a0_noisy_multi(int grad, int nmod, const float* const* mu, const float* const* sigma, float* const* eff, const int* N, const int* K, const int* r0,
@@ -363,13 +399,18 @@ extern "C" int a0_noisy_multi(int grad, int nmod, const float* const* mu, const 
         return a0_fail(A0_EINVAL, "a0_noisy_multi: bad argument");
     a0_noisy_multi_args A;
     int blocks = 0;
+    static const bool scalar_only = getenv("A0_NOISY_SCALAR") != nullptr;       // tuning aid: the element-wise kernel
+    bool v4 = !scalar_only;
+    for (int m = 0; m < nmod && v4; ++m)
+        v4 = mu[m] && eff[m] && noise_in[m] && K[m] % 4 == 0 && (long long)N[m] * K[m] < (1LL << 31) &&
+             (((uintptr_t)mu[m] | (uintptr_t)eff[m] | (uintptr_t)noise_in[m] | (grad ? 0 : (uintptr_t)sigma[m])) & 15) == 0;
     for (int m = 0; m < 6; ++m) {
         A.first_block[m] = blocks;
         if (m < nmod) {
             if (!mu[m] || !eff[m] || (!grad && !sigma[m]) || !noise_in[m] || !noise_out_w[m] || !noise_out_b[m] || N[m] < 1 || K[m] < 1 || r0[m] < 0 || r1[m] <= r0[m] || r1[m] > N[m])
                 return a0_fail(A0_EINVAL, "a0_noisy_multi: bad module");
             A.mod[m] = a0_noisy_mod{mu[m], grad ? nullptr : sigma[m], eff[m], N[m], K[m], r0[m], r1[m], noise_in[m], noise_out_w[m], noise_out_b[m]};
-            long long b = ((long long)(r1[m] - r0[m]) * (K[m] + 1) + 255) / 256;
+            long long b = v4 ? ((long long)(r1[m] - r0[m]) * (K[m] / 4 + 1) + 255) / 256 : ((long long)(r1[m] - r0[m]) * (K[m] + 1) + 255) / 256;
             if (b > 2048) b = 2048;
             blocks += (int)b;
         } else {
@@ -378,7 +419,9 @@ extern "C" int a0_noisy_multi(int grad, int nmod, const float* const* mu, const 
     }
     for (int m = nmod + 1; m <= 6; ++m) A.first_block[m] = 0x7fffffff;       // unused modules are never selected
     A.first_block[nmod] = blocks;                                              // end of the last real module
-    if (grad) hipLaunchKernelGGL(a0_noisy_multi_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
+    if (v4 && grad) hipLaunchKernelGGL(a0_noisy_multi_v4_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
+    else if (v4) hipLaunchKernelGGL(a0_noisy_multi_v4_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
+    else if (grad) hipLaunchKernelGGL(a0_noisy_multi_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(a0_noisy_multi_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
     return a0_fail_hip((int)hipGetLastError(), "a0_noisy_multi");
 }
