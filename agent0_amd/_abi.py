@@ -47,6 +47,14 @@ class LearnerDesc(C.Structure):
                 ("adam_eps", C.c_double), ("target_update_freq", C.c_int)]
 
 
+class ReduceSeg(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("slab_stride", C.c_longlong), ("nslab", C.c_int), ("out", C.c_void_p), ("count", C.c_longlong)]
+
+
+class PendingReduce(C.Structure):
+    _fields_ = [("seg", ReduceSeg * 4), ("n", C.c_int)]
+
+
 class EncoderPass(C.Structure):
     _fields_ = [("wt", C.c_void_p), ("w", C.c_void_p), ("f", C.c_void_p), ("B", C.c_int), ("act1", C.c_void_p), ("act2", C.c_void_p), ("act3", C.c_void_p)]
 

@@ -46,8 +46,9 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
         // one slab scratch for the dense weight gradients (disjoint regions, one reduction launch) and, after them, the encoder's
         const long long s_head = ceil_to(a0_dense_wgrad_scratch(B, L->Npad, 512), 4), s_fc1 = ceil_to(a0_dense_wgrad_scratch(B, 512, L->feat), 4);
         L->slab_off[0] = 0; L->slab_off[1] = s_head;
-        long long n_slab = a0_net_encoder_bwd_scratch(L->net, B);
-        if (s_head + s_fc1 > n_slab) n_slab = s_head + s_fc1;
+        // (the dense layers' slab reductions ride in the encoder's reduction launch, a0_pending_reduce: the encoder's slabs start behind theirs)
+        L->enc_slab_off = s_head + s_fc1;
+        const long long n_slab = L->enc_slab_off + a0_net_encoder_bwd_scratch(L->net, B);
         L->slabs = L->alloc<float>(n_slab > 4 ? n_slab : 4);
     } catch (...) { delete L; throw; }
     *out = L;
@@ -113,16 +114,18 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
                                     L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
     // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
     A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), L->act3_o, L->d3, B, 512, L->feat, stream));
+    a0_pending_reduce pend;
+    pend.n = 0;
     {
         const float* dY[2] = {L->draw, L->dh};
         const float* X[2] = {L->h, L->act3_o};
         const int ldx[2] = {512, L->feat}, R[2] = {B, B}, N[2] = {L->Npad, 512}, K[2] = {512, L->feat};
         float* G[2] = {L->grads + L->head.off, L->grads + L->fc1.off};
-        A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, stream));
+        A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, &pend, stream));
     }
     A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
     A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,
-                                  L->slabs, stream));
+                                  L->slabs + L->enc_slab_off, &pend, stream));
     if (loss_out) A0_HIP_THROW(hipMemcpyAsync(loss_out, L->loss, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
     const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;

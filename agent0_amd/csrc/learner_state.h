@@ -17,7 +17,7 @@ struct a0_learner {
     long long n_adam = 0, n_pad = 0, wt_floats = 0;
     float gamma_n = 0.f;
     int ns_fc1 = 1;
-    long long slab_off[2] = {0, 0};
+    long long slab_off[2] = {0, 0}, enc_slab_off = 0;
     // library-owned HBM
     float *online = nullptr, *target = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *scalars = nullptr, *loss_ring = nullptr;
     float *wt_on = nullptr, *wt_tg = nullptr;

@@ -83,12 +83,12 @@ __global__ __launch_bounds__(256) void a0_reduce_bias_act_multi_kernel(a0_rba_mu
 // Up to four slab reductions in one launch: workgroup g serves 128 outputs of the segment its index falls into — 32 lanes x 16 bytes wide,
 // eight row groups striding over the slabs and combined in a fixed order through LDS (deterministic); a segment whose base, stride or
 // count is not a multiple of four floats takes the scalar path (32 outputs per workgroup).
-struct a0_reduce_multi_args { a0_reduce_seg seg[4]; int first_block[5]; int vec[4]; };
+struct a0_reduce_multi_args { a0_reduce_seg seg[8]; int first_block[9]; int vec[8]; };
 __global__ __launch_bounds__(256) void a0_reduce_segments_kernel(a0_reduce_multi_args A) {
     __shared__ a0_f4 red4[8][33];
     int si = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) si += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
+    for (int k = 1; k < 8; ++k) si += ((int)blockIdx.x >= A.first_block[k]) ? 1 : 0;
     const a0_reduce_seg S = A.seg[si];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long blk = (long long)((int)blockIdx.x - A.first_block[si]);
@@ -291,10 +291,10 @@ struct a0_hip_backend {
         A0_HIP_THROW(hipGetLastError());
     }
     void reduce_segments(const a0_reduce_seg* segs, int nseg) {
-        if (nseg < 1 || nseg > 4) throw std::runtime_error("reduce_segments: 1..4 segments");
+        if (nseg < 1 || nseg > 8) throw std::runtime_error("reduce_segments: 1..8 segments");
         a0_reduce_multi_args A;
         int blocks = 0;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             A.first_block[k] = blocks;
             A.vec[k] = 0;
             if (k < nseg) {
@@ -305,8 +305,8 @@ struct a0_hip_backend {
                 A.seg[k] = a0_reduce_seg{nullptr, 0, 0, nullptr, 0};
             }
         }
-        A.first_block[4] = blocks;
-        for (int k = nseg; k < 4; ++k) A.first_block[k] = 0x7fffffff;        // unused segments are never selected
+        A.first_block[8] = blocks;
+        for (int k = nseg; k < 8; ++k) A.first_block[k] = 0x7fffffff;        // unused segments are never selected
         hipLaunchKernelGGL(a0_reduce_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A);
         A0_HIP_THROW(hipGetLastError());
     }
@@ -759,7 +759,7 @@ extern "C" int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* g
 // Up to four dense weight gradients whose slab reductions share ONE launch (head + fc1 [+ cosine embedding]): layer i uses
 // slabs + slab_off[i] (a0_dense_wgrad_scratch(R[i], N[i], K[i]) floats each).  Same results as four a0_dense_wgrad calls.
 extern "C" int a0_dense_wgrad_multi(int n, const float* const* dY, const float* const* X, const int* ldx, float* const* grad, const int* R, const int* N, const int* K,
-                                    float* slabs, const long long* slab_off, void* stream) {
+                                    float* slabs, const long long* slab_off, a0_pending_reduce* pend, void* stream) {
     A0_TRY
     if (n < 1 || n > 4 || !dY || !X || !ldx || !grad || !R || !N || !K || !slab_off) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: 1..4 layers");
     a0_hip_backend bk{(hipStream_t)stream};
@@ -772,18 +772,23 @@ extern "C" int a0_dense_wgrad_multi(int n, const float* const* dY, const float* 
         a0_dense_wgrad_impl(bk, dY[i], X[i], ldx[i], grad[i], R[i], N[i], K[i], slabs ? slabs + slab_off[i] : nullptr, &seg);
         if (seg.nslab > 0) segs[nseg++] = seg;
     }
-    if (nseg > 0) bk.reduce_segments(segs, nseg);
+    if (pend) {        // left to the next a0_net_encoder_wgrad(..., pend, ...)
+        if (pend->n < 0 || pend->n + nseg > 4) return a0_fail(A0_EINVAL, "a0_dense_wgrad_multi: more than four pending reductions");
+        for (int k = 0; k < nseg; ++k) pend->seg[pend->n++] = segs[k];
+    } else if (nseg > 0) bk.reduce_segments(segs, nseg);
     return A0_OK;
     A0_CATCH
 }
 
 extern "C" int a0_net_encoder_wgrad(const a0_net* n, const a0_encoder_weights* w, const a0_frames_arg* f, int B, const float* act1, const float* act2,
-                                    const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, void* stream) {
+                                    const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, const a0_pending_reduce* pend,
+                                    void* stream) {
     A0_TRY
     if (!n || !w || !f || !f->frames || !act1 || !act2 || !d3 || !d2 || !d1 || !g1 || !g2 || !g3 || B < 1) return a0_fail(A0_EINVAL, "a0_net_encoder_wgrad: null argument");
     if (a0_encoder_bwd_scratch_impl(n->core, B) > 0 && !slabs) return a0_fail(A0_EINVAL, "a0_net_encoder_wgrad: needs slab scratch");
+    if (pend && (pend->n < 0 || pend->n > 4)) return a0_fail(A0_EINVAL, "a0_net_encoder_wgrad: bad pending reductions");
     a0_hip_backend bk{(hipStream_t)stream};
-    a0_encoder_bwd_impl(bk, n->core, *w, *f, B, act1, act2, d3, const_cast<float*>(d2), const_cast<float*>(d1), g1, g2, g3, slabs, false);
+    a0_encoder_bwd_impl(bk, n->core, *w, *f, B, act1, act2, d3, const_cast<float*>(d2), const_cast<float*>(d1), g1, g2, g3, slabs, false, pend);
     return A0_OK;
     A0_CATCH
 }

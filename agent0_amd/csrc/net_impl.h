@@ -20,7 +20,7 @@ enum { A0_TAG_NONE = 0, A0_TAG_CONV1_FWD = 1, A0_TAG_CONV2_FWD = 2, A0_TAG_CONV3
        A0_TAG_DENSE_WGRAD = 6, A0_TAG_CONV3_WGRAD = 7, A0_TAG_CONV3_DGRAD = 8, A0_TAG_CONV2_WGRAD = 9, A0_TAG_CONV2_DGRAD = 10, A0_TAG_CONV1_WGRAD = 11 };
 
 // one slab reduction: out[i] = sum_z slabs[z * slab_stride + i], i < count
-struct a0_reduce_seg { const float* slabs; long long slab_stride; int nslab; float* out; long long count; };
+// a0_reduce_seg, a0_pending_reduce: include/agent0_hip.h
 
 // weight-gradient epilogue: slab z of the layer's [W | b] block.  ROWSUM_A: the GEMM's A operand is dY^T, so the sums of its rows
 // over the k range of the split ARE the bias gradient; the kernel produces them as a by-product (from the LDS tiles it stages
@@ -311,12 +311,13 @@ static void a0_dense_wgrad_impl(BK& bk, const float* dY, const float* X, int ldx
 template <class BK>
 static void a0_encoder_bwd_impl(BK& bk, const a0_net_core& n, const a0_encoder_weights& w, const a0_frames_arg& f, int B,
                                 const float* act1, const float* act2, const float* d3, float* d2, float* d1,
-                                float* g1, float* g2, float* g3, float* slabs, bool with_dgrad = true) {
+                                float* g1, float* g2, float* g3, float* slabs, bool with_dgrad = true, const a0_pending_reduce* pend = nullptr) {
     // with_dgrad == false: d2 / d1 already hold the data gradients (a0_net_encoder_dgrad_fused); only the weight gradients run
     const int M3 = B * n.H3 * n.W3, M2 = B * n.H2 * n.W2, M1 = B * n.H1 * n.W1;
     const a0_enc_slab_plan plan = a0_encoder_slab_plan(n, B);
-    a0_reduce_seg segs[3];
+    a0_reduce_seg segs[8];
     int nseg = 0;
+    if (pend) for (int k = 0; k < pend->n && k < 4; ++k) segs[nseg++] = pend->seg[k];      // reductions other launches left to this one (a0_dense_wgrad_multi)
     // d2 already known (the learner's path: a0_net_encoder_dgrad_fused ran first): both weight gradients in ONE per-observation launch on the bf16 pipe
     int G2 = 0, G3 = 0;
     const bool fused23 = !with_dgrad && a0_c23w_plan(n, B, &G2, &G3) &&

@@ -328,6 +328,13 @@ class DeviceLearner:
         # head + fc1 (+ cosine embedding) reduce in disjoint regions of one launch
         shapes = [(self.ws_o.R, L.Npad, 512), (self.ws_o.R, 512, L.feat)] + ([(self.ws_o.R, L.feat, L.num_cosines)] if L.quantile else [])
         n_slab = max(n_slab, ops.dense_wgrad_multi_scratch(shapes))
+        # Round 4: without a gradient hook the dense layers' slab reductions ride in the encoder weight gradients' reduction launch (a0_pending_reduce: one launch less
+        # per update, same sums) — their slabs then have to survive until that launch, so the encoder's get a region of their own behind them
+        self._enc_slab_off, self._defer_dense = 0, False
+        if hasattr(ops, "pending_reduce") and self.online.fused and self.online.fused_dgrad and os.environ.get("A0_DEFER_DENSE_REDUCE", "1") != "0":
+            self._enc_slab_off, self._defer_dense = ops.dense_wgrad_multi_scratch(shapes), True
+            n_slab = max(n_slab, self._enc_slab_off + ops.encoder_bwd_scratch(self.net, B))
+        self._pend = None
         self.slabs = ops.empty(n_slab)
         self.obs_bytes = L.C * L.H * L.W
         self.grad_hook = None       # data parallelism: callable(grads, state) run between backward and the optimizer (dist.GradAllReduce)
@@ -365,14 +372,22 @@ class DeviceLearner:
             ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
             ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
             wg.append((ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines))
-        ops.dense_wgrad_multi(wg, self.slabs)
-        if L.noisy:
-            mods = []
-            for prefix, block, r0, r1, in_f in L.noise_modules:
-                mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
-                nz = on.noise[prefix]
-                mods.append((self.grads[mu.all], None, self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
-            ops.noisy_multi(True, mods)
+        # data parallelism exchanges the dense range right after this call: its reductions cannot wait for the encoder's launch then
+        defer = self._defer_dense and self.grad_hook is None
+        self._pend = ops.pending_reduce() if defer else None
+        ops.dense_wgrad_multi(wg, self.slabs, **({"pend": self._pend} if defer else {}))
+        if L.noisy and not defer:
+            self._noisy_sigma_grads()
+
+    def _noisy_sigma_grads(self):
+        """d sigma = d eff * eps for every NoisyLinear module, from the (reduced) gradients in the mu blocks."""
+        L, on = self.L, self.online
+        mods = []
+        for prefix, block, r0, r1, in_f in L.noise_modules:
+            mu, sg = L.blocks[block + ".mu"], L.blocks[block + ".sigma"]
+            nz = on.noise[prefix]
+            mods.append((self.grads[mu.all], None, self.grads[sg.all], mu.N, mu.K, r0, r1, nz["noise_in"], nz["noise_out_weight"], nz["noise_out_bias"]))
+        self.ops.noisy_multi(True, mods)
 
     def backward_encoder(self):
         """d3 -> the three convolution blocks' gradients (flat range [0, L.conv_end)); the second half of the backward pass, on the
@@ -383,7 +398,14 @@ class DeviceLearner:
         if on.fused and on.fused_dgrad:
             # both data gradients per observation in one kernel (LDS-resident d2), then the three weight-gradient GEMMs
             ops.encoder_dgrad_fused(self.net, on.wt, ws.d3, ws.act1, ws.act2, B, ws.d2, ws.d1)
-            ops.encoder_wgrad(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
+            pend, self._pend = self._pend, None
+            if pend is not None:
+                ops.encoder_wgrad(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs[self._enc_slab_off:],
+                                  pend=pend)
+                if L.noisy:
+                    self._noisy_sigma_grads()
+            else:
+                ops.encoder_wgrad(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
         else:
             ops.encoder_bwd(self.net, on.encoder_weights(), frames, slot, stride, 0, B, ws.act1, ws.act2, ws.d3, ws.d2, ws.d1, g1, g2, g3, self.slabs)
 

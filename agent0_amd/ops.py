@@ -204,7 +204,14 @@ class HipOps:
                                                   _req(d2, torch.float32, B * net.H2 * net.W2 * 64, "d2"), _req(d1, torch.float32, B * net.H1 * net.W1 * 32, "d1"),
                                                   _stream()), "a0_net_encoder_dgrad_fused")
 
-    def encoder_wgrad(self, net, w, frames, slot, sample_stride, chan_off, B, act1, act2, d3, d2, d1, g1, g2, g3, slabs):
+    def pending_reduce(self):
+        """An empty a0_pending_reduce: dense_wgrad_multi(..., pend=p) appends its slab reductions, encoder_wgrad(..., pend=p) launches them with its own."""
+        from ._abi import PendingReduce
+        p = PendingReduce()
+        p.n = 0
+        return p
+
+    def encoder_wgrad(self, net, w, frames, slot, sample_stride, chan_off, B, act1, act2, d3, d2, d1, g1, g2, g3, slabs, pend=None):
         fa = self._frames(net, frames, slot, sample_stride, chan_off, B)
         ew = self._enc_w(w)
         need = self.encoder_bwd_scratch(net, B)
@@ -214,7 +221,7 @@ class HipOps:
             _req(d3, torch.float32, B * net.feat, "d3"), _req(d2, torch.float32, B * net.H2 * net.W2 * 64, "d2"),
             _req(d1, torch.float32, B * net.H1 * net.W1 * 32, "d1"),
             _req(g1, torch.float32, 32 * net.K1 + 32, "g1"), _req(g2, torch.float32, 64 * net.K2 + 64, "g2"), _req(g3, torch.float32, 64 * net.K3 + 64, "g3"),
-            _req(slabs, torch.float32, need, "slabs", optional=(need == 0)), _stream()), "a0_net_encoder_wgrad")
+            _req(slabs, torch.float32, need, "slabs", optional=(need == 0)), None if pend is None else C.addressof(pend), _stream()), "a0_net_encoder_wgrad")
 
     # ------------------------------------------------------------------ dense
     def dense_fwd_scratch(self, R, N, K) -> int:
@@ -691,8 +698,8 @@ class HipOps:
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
                   "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}
 
-    def dense_wgrad_multi(self, layers, slabs):
-        """layers: [(dY, X, ldx, grad, R, N, K)] (at most four); their slab reductions run as one launch."""
+    def dense_wgrad_multi(self, layers, slabs, pend=None):
+        """layers: [(dY, X, ldx, grad, R, N, K)] (at most four); their slab reductions run as one launch — or, with ``pend``, in the next encoder_wgrad(pend=...)'s."""
         n = len(layers)
         offs, total = [], 0
         for (_, _, _, _, R, N, K) in layers:
@@ -704,7 +711,7 @@ class HipOps:
         X = PP(*[_req(l[1], torch.float32, (l[4] - 1) * l[2] + l[6], "X") for l in layers])
         G = PP(*[_req(l[3], torch.float32, l[5] * l[6] + l[5], "grad") for l in layers])
         check(self.lib.a0_dense_wgrad_multi(n, dY, X, II(*[l[2] for l in layers]), G, II(*[l[4] for l in layers]), II(*[l[5] for l in layers]), II(*[l[6] for l in layers]),
-                                            _req(slabs, torch.float32, total, "slabs", optional=(total == 0)), (C.c_longlong * n)(*offs), _stream()), "a0_dense_wgrad_multi")
+                                            _req(slabs, torch.float32, total, "slabs", optional=(total == 0)), (C.c_longlong * n)(*offs), None if pend is None else C.addressof(pend), _stream()), "a0_dense_wgrad_multi")
 
     def dense_wgrad_multi_scratch(self, shapes) -> int:
         return sum((self.dense_wgrad_scratch(R, N, K) + 3) // 4 * 4 for (R, N, K) in shapes)

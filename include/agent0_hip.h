@@ -53,6 +53,10 @@ typedef struct a0_frames_arg {
     int chan_off;               /* 0 = st, 4*H*W = st_next half of a replay row (agent0/deepq/agent.py:132-135) */
 } a0_frames_arg;
 
+/* one pending slab reduction: out[i] = sum_z slabs[z * slab_stride + i], i < count (z ascending: deterministic) */
+typedef struct a0_reduce_seg { const float* slabs; long long slab_stride; int nslab; float* out; long long count; } a0_reduce_seg;
+typedef struct a0_pending_reduce { a0_reduce_seg seg[4]; int n; } a0_pending_reduce;
+
 /* packed conv weights: w1 [32][C*8*8] in (c,kh,kw) order, w2 [64][4*4*32] and w3 [64][3*3*64] in (kh,kw,c) order */
 typedef struct a0_encoder_weights {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
@@ -104,7 +108,8 @@ int a0_net_encoder_bwd(const a0_net* net, const a0_encoder_weights* w, const a0_
 
 /* the three weight-gradient GEMMs of a0_net_encoder_bwd alone: d2 / d1 are inputs (from a0_net_encoder_dgrad_fused) */
 int a0_net_encoder_wgrad(const a0_net* net, const a0_encoder_weights* w, const a0_frames_arg* frames, int B, const float* act1, const float* act2,
-                         const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, void* stream);
+                         const float* d3, const float* d2, const float* d1, float* g1, float* g2, float* g3, float* slabs, const a0_pending_reduce* pend,
+                         void* stream);
 
 /* nn.Linear / NoisyLinear forward+backward (model.py:54-62,112-114): Y = act(X W^T + b), W [N][K] row-major.
  * N, K, ldx multiples of 4.  scratch sizes from the *_scratch functions (0 => may pass NULL). */
@@ -117,7 +122,10 @@ int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, in
 /* n <= 4 dense weight gradients (the head's and fc1's, + the cosine embedding's) whose slab reductions share one launch; layer i reduces in
  * slabs + slab_off[i] (a0_dense_wgrad_scratch floats each, disjoint).  The pointer / shape arrays are host arrays. */
 int a0_dense_wgrad_multi(int n, const float* const* dY, const float* const* X, const int* ldx, float* const* grad_w_b, const int* R, const int* N, const int* K,
-                         float* slabs, const long long* slab_off, void* stream);
+                         float* slabs, const long long* slab_off, a0_pending_reduce* pend, void* stream);
+/* (round 4) pend != NULL: the slab reductions are NOT launched but appended to *pend (set pend->n = 0 before the first call); the next
+ * a0_net_encoder_wgrad(..., pend, ...) adds them to its own reduction launch — one launch less per update.  Until then the gradients of the deferred layers are
+ * not final and their slabs (slabs + slab_off[i]) must stay untouched: give the encoder a slab region of its own. */
 
 /* Y[r] = act(X[r] W^T + b) * M[r / group]: the IQN / FQF embedding relu(cosine_emb(...)) times the state features (model.py:244-247) in the
  * GEMM's epilogue, for passes that are not differentiated; only when a0_dense_fwd_scratch(R, N, K) == 0 (unsplit GEMM) */

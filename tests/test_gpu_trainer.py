@@ -563,6 +563,34 @@ def test_prefetched_rollouts_change_no_number(algo, extra, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("algo,extra", [("dqn", {}), ("c51", {"learner.noisy_net": "true", "learner.dueling_head": "true", "replay.policy": "prioritize"}),
+                                        ("iqr", {"env_id": "Asterix"}), ("fqf", {"env_id": "Asterix", "learner.double_q": "true"})], ids=["dqn", "c51-noisy-duel-per", "iqr", "fqf"])
+def test_dense_reductions_in_the_encoder_launch_change_no_number(algo, extra, monkeypatch):
+    """Round 4: without a gradient hook the slab reductions of the dense weight gradients (head, fc1, cosine embedding) are not launched by a0_dense_wgrad_multi but
+    handed (a0_pending_reduce) to the encoder weight gradients' reduction launch, and NoisyNet's sigma gradients follow it: one launch less per update, the same sums
+    in the same order.  Losses, parameters and Adam moments must be BIT-identical to the two-launch sequence."""
+    from agent0_amd.deepq.trainer import Trainer
+
+    def run(defer):
+        monkeypatch.setenv("A0_DEFER_DENSE_REDUCE", "1" if defer else "0")
+        # batch 256: large enough for the head's and fc1's weight gradients to be split into slabs
+        cfg = make_cfg(algo, 8, **{"actor.sample_steps": 40, "replay.size": 1600, "learner.batch_size": 256, "learner.learner_steps": 5, "trainer.training_start_steps": 300,
+                                    "learner.target_update_freq": 7, **extra})
+        tr = Trainer(cfg)
+        eng = tr.learner.engine
+        assert eng._defer_dense == defer and (not defer or eng._enc_slab_off > 0)
+        for _ in range(6):
+            tr.run_iteration()
+        torch.cuda.synchronize()
+        return list(tr.Ls), list(tr.FLs), eng.online.flat.clone(), eng.target.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.grads.clone()
+
+    a = run(False)
+    b = run(True)
+    assert len(a[0]) == 30 and a[0] == b[0] and a[1] == b[1]
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("algo", ["dqn", "c51", "iqr"])
 def test_loss_statistic_from_the_adam_launch_equals_mean_rows(algo, monkeypatch):
     """Round 4: the Trainer's per-update `loss` statistic (trainer.py:99,111-113) is taken by workgroup 0 of the Adam launch into a ring (a0_adam_step_sync_wt,
