@@ -7,26 +7,57 @@
 // sizes, split-K slab bookkeeping and the call order.  SURVEY.md §8(b) "ownership": opaque handle, library-owned HBM, caller passes borrowed device
 // pointers valid for the call, no allocation and no host synchronisation after a0_learner_create.
 //
-// Scope: the scalar-head learners on 4 x 84 x 84 observations (dqn; dueling; double-Q; n-step through discount^n) — BASELINE configs[1], the bench
-// line.  The distributional / quantile learners stay with the per-kernel entry points (INTEGRATION.md options A / B).
+// Scope: on 4 x 84 x 84 observations, the scalar-head learners (dqn; dueling; double-Q; n-step through discount^n) — BASELINE configs[1], the bench line — and
+// the categorical one (c51, also with NoisyLinear layers: BASELINE configs[2], rainbow-lite).  The quantile learners stay with the per-kernel entry points
+// (INTEGRATION.md options A / B).
 #include "learner_state.h"
 
 extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
     A0_TRY
     if (!d || !out) return a0_fail(A0_EINVAL, "a0_learner_create: null argument");
-    if (d->A < 1 || d->A + (d->dueling ? 1 : 0) > 24 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1)
-        return a0_fail(A0_EINVAL, "a0_learner_create: bad description (scalar heads with A + dueling <= 24 actions)");
+    if (d->A < 1 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1 || (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51))
+        return a0_fail(A0_EINVAL, "a0_learner_create: bad description");
+    if (d->algo == A0_ALGO_DQN && (d->A + (d->dueling ? 1 : 0) > 24 || d->noisy))
+        return a0_fail(A0_EINVAL, "a0_learner_create: the dqn handle covers scalar heads with A + dueling <= 24 actions without NoisyNet");
+    if (d->algo == A0_ALGO_C51 && (d->num_atoms < 2 || d->num_atoms > 64 || !(d->vmax > d->vmin)))
+        return a0_fail(A0_EINVAL, "a0_learner_create: c51 needs 2 <= num_atoms <= 64 and vmin < vmax");
     a0_learner* L = new a0_learner();
     try {
         L->d = *d;
         a0_net_desc nd{4, 84, 84};
         if (a0_net_create(&nd, &L->net) != A0_OK) { delete L; return A0_EINVAL; }
+        const bool c51 = d->algo == A0_ALGO_C51;
+        L->T = c51 ? d->num_atoms : 1;
+        L->Nq = d->A * L->T;
+        L->V = d->dueling ? L->T : 0;
         L->NQ = d->A + (d->dueling ? 1 : 0);
-        L->Npad = (int)ceil_to(L->NQ, 32);
+        L->Npad = (int)ceil_to(L->Nq + L->V, 32);
         long long off = 0;
         auto add = [&](Blk& b, int N, int K) { b = Blk{off, N, K}; off += b.size(); };
-        add(L->conv1, 32, L->C * 64); add(L->conv2, 64, 512); add(L->conv3, 64, 576); add(L->fc1, 512, L->feat); add(L->head, L->Npad, 512);      // deepq/layout.py
+        add(L->conv1, 32, L->C * 64); add(L->conv2, 64, 512); add(L->conv3, 64, 576);                                                              // deepq/layout.py
+        if (d->noisy) { add(L->fc1, 512, L->feat); add(L->fc1_sigma, 512, L->feat); add(L->head, L->Npad, 512); add(L->head_sigma, L->Npad, 512); }
+        else { add(L->fc1, 512, L->feat); add(L->head, L->Npad, 512); }
         L->n_adam = off;
+        if (d->noisy) {
+            // composed weights [fc1 | head] per network; noise vectors per NoisyLinear module in the reference's module order (first_dense, q_head, value_head), each
+            // (noise_in, noise_out_weight, noise_out_bias) padded to four floats — the layout one Philox fill of the whole buffer reproduces (engine.py DeviceNet)
+            L->eff_fc1 = Blk{0, 512, L->feat};
+            L->eff_head = Blk{L->eff_fc1.size(), L->Npad, 512};
+            L->n_eff = L->eff_fc1.size() + L->eff_head.size();
+            long long no = 0;
+            auto mod = [&](int block, int r0, int r1, int in_f) {
+                a0_noise_mod m{block, r0, r1, in_f, 0, 0, 0};
+                m.off_in = no; no += ceil_to(in_f, 4);
+                m.off_w = no; no += ceil_to(r1 - r0, 4);
+                m.off_b = no; no += ceil_to(r1 - r0, 4);
+                L->mods[L->n_mods++] = m;
+            };
+            mod(0, 0, 512, L->feat);
+            mod(1, 0, L->Nq, 512);
+            if (d->dueling) mod(1, L->Nq, L->Nq + L->V, 512);
+            L->noise_len = no;
+            L->rng.init(d->seed, 0);
+        }
         L->n_pad = ceil_to(off, 4);
         L->wt_floats = a0_net_conv_wt_floats(L->C);
         L->gamma_n = (float)std::pow(d->discount, (double)d->n_step);
@@ -36,11 +67,15 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
         L->state = L->alloc<int>(8, true); L->scalars = L->alloc<float>(4, true); L->loss_ring = L->alloc<float>(1024, true);
         L->wt_on = L->alloc<float>(L->wt_floats, true); L->wt_tg = L->alloc<float>(L->wt_floats, true);
         L->act1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->act2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64);
-        L->act3_o = L->alloc<float>((long long)B * L->feat); L->act3_t = L->alloc<float>((long long)B * L->feat);
-        if (d->double_q) L->act3_s = L->alloc<float>((long long)B * L->feat);
+        L->act3_t = L->alloc<float>((long long)B * L->feat);
         L->ns_fc1 = a0_dense_fwd_partial_slabs(B, 512, L->feat);
-        for (int i = 0; i < (d->double_q ? 3 : 2); ++i) L->fc1_slabs[i] = L->alloc<float>((long long)L->ns_fc1 * B * 512);
-        L->h = L->alloc<float>((long long)B * 512); L->q_o = L->alloc<float>((long long)B * d->A); L->q_t = L->alloc<float>((long long)B * d->A);
+        if (!c51) {
+            L->act3_o = L->alloc<float>((long long)B * L->feat);
+            if (d->double_q) L->act3_s = L->alloc<float>((long long)B * L->feat);
+            for (int i = 0; i < (d->double_q ? 3 : 2); ++i) L->fc1_slabs[i] = L->alloc<float>((long long)L->ns_fc1 * B * 512);
+            L->h = L->alloc<float>((long long)B * 512);
+        }
+        L->q_o = L->alloc<float>((long long)B * d->A * L->T); L->q_t = L->alloc<float>((long long)B * d->A * L->T);
         L->draw = L->alloc<float>((long long)B * L->Npad); L->dh = L->alloc<float>((long long)B * 512); L->d3 = L->alloc<float>((long long)B * L->feat);
         L->d2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64); L->d1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->loss = L->alloc<float>(B);
         // one slab scratch for the dense weight gradients (disjoint regions, one reduction launch) and, after them, the encoder's
@@ -50,6 +85,32 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
         L->enc_slab_off = s_head + s_fc1;
         const long long n_slab = L->enc_slab_off + a0_net_encoder_bwd_scratch(L->net, B);
         L->slabs = L->alloc<float>(n_slab > 4 ? n_slab : 4);
+        if (d->noisy) {
+            L->eff_on = L->alloc<float>(L->n_eff, true); L->eff_tg = L->alloc<float>(L->n_eff, true);
+            L->noise = L->alloc<float>(2 * L->noise_len, true);
+        }
+        if (c51) {
+            const int dq = d->double_q ? 1 : 0;
+            L->R_on = dq ? 2 * B : B;
+            L->ns_on = a0_dense_fwd_partial_slabs(L->R_on, 512, L->feat);
+            L->nh_on = a0_dense_fwd_partial_slabs(L->R_on, L->Npad, 512);
+            L->nh_tg = a0_dense_fwd_partial_slabs(B, L->Npad, 512);
+            L->act3_on = L->alloc<float>((long long)L->R_on * L->feat);
+            // the online network's features of s and (double-Q) of s' back to back: fc1 and the head run over both as ONE GEMM each (same weights)
+            L->act3_o = L->act3_on;
+            if (dq) L->act3_s = L->act3_on + (long long)B * L->feat;
+            L->fc1_on = L->alloc<float>((long long)L->ns_on * L->R_on * 512); L->fc1_tg = L->alloc<float>((long long)L->ns_fc1 * B * 512);
+            L->h_on = L->alloc<float>((long long)L->R_on * 512); L->h_tg = L->alloc<float>((long long)B * 512);
+            L->h = L->h_on;                                  // h(s) of the online network: what the backward pass reads
+            L->hs_on = L->alloc<float>((long long)L->nh_on * L->R_on * L->Npad); L->hs_tg = L->alloc<float>((long long)L->nh_tg * B * L->Npad);
+            L->atoms = L->alloc<float>(L->T); L->m_proj = L->alloc<float>((long long)B * L->T); L->a_star = L->alloc<int>(B, true);
+            // torch.linspace(vmin, vmax, T) in fp32 as ATen's vectorised CPU kernel computes it (RangeFactories: step = (end - start) / (steps - 1); fma(step, i, start)
+            // below the middle, fma(-step, steps - 1 - i, end) above).  A host whose torch build rounds differently hands its own values to a0_learner_set_support.
+            std::vector<float> at((size_t)L->T);
+            const float lo = (float)d->vmin, hi = (float)d->vmax, step = (hi - lo) / (float)(L->T - 1);
+            for (int i = 0; i < L->T; ++i) at[(size_t)i] = i < L->T / 2 ? std::fmaf(step, (float)i, lo) : std::fmaf(-step, (float)(L->T - 1 - i), hi);
+            A0_HIP_THROW(hipMemcpy(L->atoms, at.data(), (size_t)L->T * 4, hipMemcpyHostToDevice));
+        }
     } catch (...) { delete L; throw; }
     *out = L;
     return A0_OK;
@@ -69,6 +130,14 @@ extern "C" int a0_learner_set_params(a0_learner* L, const float* online_packed, 
     a0_encoder_weights wo = L->enc(L->online), wtg = L->enc(L->target);
     A0_CHECK(a0_net_conv_wt_refresh(&wo, L->C, L->wt_on, stream));
     A0_CHECK(a0_net_conv_wt_refresh(&wtg, L->C, L->wt_tg, stream));
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_learner_set_support(a0_learner* L, const float* atoms_host) {
+    A0_TRY
+    if (!L || !atoms_host || !L->atoms) return a0_fail(A0_EINVAL, "a0_learner_set_support: a c51 handle and a host array of num_atoms floats");
+    A0_HIP_THROW(hipMemcpy(L->atoms, atoms_host, (size_t)L->T * 4, hipMemcpyHostToDevice));
     return A0_OK;
     A0_CATCH
 }
@@ -97,8 +166,59 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     if (row_bytes < 2LL * obs) return a0_fail(A0_EINVAL, "a0_learner_update: a replay row holds st || st_next (2 x C x H x W bytes)");
     float* on = L->online; float* tg = L->target;
     a0_encoder_weights w_on = L->enc(on), w_tg = L->enc(tg);
-    // ---- forward: the target pass on s', the online pass on s' (double-Q) and the online pass on s as ONE encoder launch, then their fc1 GEMMs (split-K slabs)
+    if (L->d.noisy) {
+        // BaseLearner.train (agent.py:125-127): reset_noise of the online, then of the target network — ONE Philox fill of the joint buffer (the same draws as two
+        // fills: every vector is padded to the offsets' stride of four) — and both networks' effective weights in one launch
+        const long long nn = 2 * L->noise_len;
+        A0_CHECK(a0_rng_normal(L->rng.seed, 4 /* STREAM_NOISE */, L->rng.reserve(4, nn), 0.1f, L->noise, nn, stream));
+        const float *mu[6], *sg[6], *nin[6], *nw[6], *nb[6];
+        float* eff[6];
+        int N[6], K[6], r0[6], r1[6], nm = 0;
+        for (int net = 0; net < 2; ++net) {
+            const float* flat = net ? tg : on;
+            float* e = net ? L->eff_tg : L->eff_on;
+            const float* nz = L->noise + (net ? L->noise_len : 0);
+            for (int k = 0; k < L->n_mods; ++k, ++nm) {
+                const a0_noise_mod& m = L->mods[k];
+                const Blk &bm = m.block ? L->head : L->fc1, &bs = m.block ? L->head_sigma : L->fc1_sigma, &be = m.block ? L->eff_head : L->eff_fc1;
+                mu[nm] = flat + bm.off; sg[nm] = flat + bs.off; eff[nm] = e + be.off; N[nm] = bm.N; K[nm] = bm.K; r0[nm] = m.r0; r1[nm] = m.r1;
+                nin[nm] = nz + m.off_in; nw[nm] = nz + m.off_w; nb[nm] = nz + m.off_b;
+            }
+        }
+        A0_CHECK(a0_noisy_multi(0, nm, mu, sg, eff, N, K, r0, r1, nin, nw, nb, stream));
+    }
+    a0_pending_reduce pend;
+    pend.n = 0;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
+    if (L->d.algo == A0_ALGO_C51) {
+        // ---- C51Learner.train_step (agent.py:218-268), in the order of agent0_amd/deepq/engine.py's c51 path: the three encoder passes in one launch; the online
+        // fc1 over [s ; s'] rows as ONE GEMM and the target's, their slabs finished by one reduction launch; the two head GEMMs; and one launch for everything behind
+        // them (slab sums, dueling, greedy next action, projection, cross entropy, head gradient)
+        a0_encoder_pass passes[3];
+        int np = 0;
+        passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->act3_t};
+        if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
+        passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
+        A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
+        A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, L->Wf(true), B, 512, L->feat, L->fc1_tg, stream));
+        A0_CHECK(a0_dense_fwd_partial(L->act3_on, L->feat, L->Wf(false), L->R_on, 512, L->feat, L->fc1_on, stream));
+        {
+            const float* sl[2] = {L->fc1_on, L->fc1_tg};
+            const long long st[2] = {(long long)L->R_on * 512, (long long)B * 512};
+            const int ns[2] = {L->ns_on, L->ns_fc1}, rows[2] = {L->R_on, B};
+            const float* bias[2] = {L->bf(false), L->bf(true)};
+            float* out[2] = {L->h_on, L->h_tg};
+            A0_CHECK(a0_reduce_bias_act_multi(2, sl, st, ns, bias, out, rows, 512, 1, stream));
+        }
+        A0_CHECK(a0_dense_fwd_partial(L->h_on, 512, L->Wh(false), L->R_on, L->Npad, 512, L->hs_on, stream));
+        A0_CHECK(a0_dense_fwd_partial(L->h_tg, 512, L->Wh(true), B, L->Npad, 512, L->hs_tg, stream));
+        A0_CHECK(a0_c51_head_loss_slabs(L->hs_on, (long long)L->R_on * L->Npad, L->nh_on, L->R_on, L->hs_tg, (long long)B * L->Npad, L->nh_tg, dq ? B : -1, L->bh(false), L->bh(true),
+                                        L->Npad, A, L->T, L->d.dueling ? 1 : 0, act, rew, done, wgt, L->atoms, L->gamma_n, (float)L->d.vmin, (float)L->d.vmax, B, L->loss, L->draw,
+                                        L->q_o, L->q_t, L->m_proj, L->a_star, L->state, stream));
+        // the head's data gradient (the scalar-head kernel above folds it in; the distributional one does not)
+        A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->h, L->dh, B, L->Npad, 512, stream));
+    } else {
+    // ---- forward: the target pass on s', the online pass on s' (double-Q) and the online pass on s as ONE encoder launch, then their fc1 GEMMs (split-K slabs)
     a0_encoder_pass passes[3];
     int np = 0;
     passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->act3_t};
@@ -112,10 +232,9 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     A0_CHECK(a0_dqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], dq ? L->fc1_slabs[2] : nullptr, (long long)B * 512, L->ns_fc1, on + L->fc1.b(), tg + L->fc1.b(), L->h,
                                     on + L->head.w(), on + L->head.b(), tg + L->head.w(), tg + L->head.b(), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, B,
                                     L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
+    }
     // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
-    A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), L->act3_o, L->d3, B, 512, L->feat, stream));
-    a0_pending_reduce pend;
-    pend.n = 0;
+    A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
     {
         const float* dY[2] = {L->draw, L->dh};
         const float* X[2] = {L->h, L->act3_o};
@@ -126,6 +245,18 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
     A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,
                                   L->slabs + L->enc_slab_off, &pend, stream));
+    if (L->d.noisy) {      // d sigma = d eff * eps, from the reduced gradients in the mu blocks (model.py:78-87 differentiated)
+        const float *gmu[3], *nin[3], *nw[3], *nb[3];
+        float* gs[3];
+        int N[3], K[3], r0[3], r1[3];
+        for (int k = 0; k < L->n_mods; ++k) {
+            const a0_noise_mod& m = L->mods[k];
+            const Blk &bm = m.block ? L->head : L->fc1, &bs = m.block ? L->head_sigma : L->fc1_sigma;
+            gmu[k] = L->grads + bm.off; gs[k] = L->grads + bs.off; N[k] = bm.N; K[k] = bm.K; r0[k] = m.r0; r1[k] = m.r1;
+            nin[k] = L->noise + m.off_in; nw[k] = L->noise + m.off_w; nb[k] = L->noise + m.off_b;
+        }
+        A0_CHECK(a0_noisy_multi(1, L->n_mods, gmu, nullptr, gs, N, K, r0, r1, nin, nw, nb, stream));
+    }
     if (loss_out) A0_HIP_THROW(hipMemcpyAsync(loss_out, L->loss, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
     const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;

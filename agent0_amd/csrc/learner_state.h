@@ -9,11 +9,40 @@ struct Blk { long long off; int N, K; long long w() const { return off; } long l
 
 static inline long long ceil_to(long long x, long long m) { return (x + m - 1) / m * m; }
 
+// agent0_amd/common/utils.py DeviceRng: per-stream running offsets, every reservation rounded up to a multiple of four draws
+struct a0_host_rng {
+    unsigned long long seed = 0;
+    unsigned long long off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void init(unsigned long long s, unsigned rank) { seed = (s & 0xFFFFFFFFull) | ((unsigned long long)(rank & 0xFFFFu) << 32); }
+    unsigned long long reserve(int stream, long long n) { const unsigned long long o = off[stream]; off[stream] += (unsigned long long)((n + 3) / 4 * 4); return o; }
+    unsigned next_seed32(int stream) { const unsigned long long o = reserve(stream, 4); return (unsigned)((seed * 0x9E3779B1ull + o * 0x85EBCA77ull + (unsigned long long)stream) & 0xFFFFFFFFull); }
+};
+
+struct a0_noise_mod { int block; int r0, r1, in_f; long long off_in, off_w, off_b; };      // block: 0 = fc1, 1 = head; offsets into one network's noise buffer
+
 struct a0_learner {
     a0_learner_desc d;
     a0_net* net = nullptr;
     int C = 4, H = 84, W = 84, H1 = 20, W1 = 20, H2 = 9, W2 = 9, feat = 3136, Npad = 32, NQ = 0;
-    Blk conv1, conv2, conv3, fc1, head;
+    Blk conv1, conv2, conv3, fc1, head;      // noisy: fc1 / head are the mu blocks
+    // ---- distributional / NoisyNet extension (A0_ALGO_C51)
+    int T = 1, Nq = 0, V = 0;
+    Blk fc1_sigma, head_sigma;               // NoisyNet: the sigma blocks (layout.py: fc1.mu | fc1.sigma | head.mu | head.sigma)
+    Blk eff_fc1, eff_head;                   // offsets into one network's composed-weight scratch
+    long long n_eff = 0, noise_len = 0;
+    int n_mods = 0;
+    a0_noise_mod mods[3];
+    a0_host_rng rng;
+    float *eff_on = nullptr, *eff_tg = nullptr, *noise = nullptr;       // noise: [online | target], noise_len floats each
+    float *atoms = nullptr, *m_proj = nullptr;
+    int* a_star = nullptr;
+    float *act3_on = nullptr, *fc1_on = nullptr, *fc1_tg = nullptr, *h_on = nullptr, *h_tg = nullptr, *hs_on = nullptr, *hs_tg = nullptr;
+    int R_on = 0, ns_on = 1, nh_on = 1, nh_tg = 1;
+    // effective (W, b) of a dense layer of the online / target network
+    const float* Wf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.w() : (tg ? target : online) + fc1.w(); }
+    const float* bf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.b() : (tg ? target : online) + fc1.b(); }
+    const float* Wh(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_head.w() : (tg ? target : online) + head.w(); }
+    const float* bh(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_head.b() : (tg ? target : online) + head.b(); }
     long long n_adam = 0, n_pad = 0, wt_floats = 0;
     float gamma_n = 0.f;
     int ns_fc1 = 1;

@@ -59,16 +59,24 @@ class Net:
 
 
 class NativeLearner:
-    """``a0_learner``: a whole scalar-head learner (dqn; dueling; double-Q) behind one handle whose HBM the library owns; ``update`` is BaseLearner.train as ONE
+    """``a0_learner``: a whole learner (dqn; c51, also with NoisyLinear layers; dueling; double-Q; n-step) behind one handle whose HBM the library owns; ``update`` is BaseLearner.train as ONE
     C call (include/agent0_hip.h).  What a non-Python host binds; here it exists for the parity test against the per-kernel composition of deepq/engine.py."""
 
-    def __init__(self, lib, A, dueling, double_q, B, n_step=1, discount=0.99, lr=5e-4, adam_eps=0.0, target_update_freq=500):
-        self.lib, self.B = lib, B
-        desc = LearnerDesc(int(A), int(bool(dueling)), int(bool(double_q)), int(B), int(n_step), float(discount), float(lr), float(adam_eps), int(target_update_freq))
+    ALGOS = {"dqn": 0, "c51": 1}
+
+    def __init__(self, lib, A, dueling, double_q, B, n_step=1, discount=0.99, lr=5e-4, adam_eps=0.0, target_update_freq=500, algo="dqn", num_atoms=51, vmin=-10.0,
+                 vmax=10.0, noisy=False, seed=0):
+        self.lib, self.B, self.T = lib, B, int(num_atoms)
+        desc = LearnerDesc(int(A), int(bool(dueling)), int(bool(double_q)), int(B), int(n_step), float(discount), float(lr), float(adam_eps), int(target_update_freq),
+                           self.ALGOS[algo], int(num_atoms), float(vmin), float(vmax), int(bool(noisy)), int(seed) & 0xFFFFFFFFFFFFFFFF)
         h = C.c_void_p()
         check(lib.a0_learner_create(C.addressof(desc), C.addressof(h)), "a0_learner_create")
         self.h = h
         self.n = int(lib.a0_learner_param_floats(h))
+
+    def set_support(self, atoms):
+        a = (C.c_float * self.T)(*[float(x) for x in atoms])
+        check(self.lib.a0_learner_set_support(self.h, a), "a0_learner_set_support")
 
     def set_params(self, online, target=None):
         check(self.lib.a0_learner_set_params(self.h, _req(online, torch.float32, self.n, "online"), _req(target, torch.float32, self.n, "target", optional=True), _stream()),

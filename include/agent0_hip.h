@@ -273,13 +273,22 @@ int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, floa
  * Adam moments, status words and every workspace live in HBM that a0_learner_create allocates and a0_learner_destroy frees; a0_learner_update is BaseLearner.train —
  * forward passes, loss, backward, Adam(lr, eps = adam_eps or 1e-2 / B), NaN guard, update counter, target copy every target_update_freq updates — as ONE call that
  * enqueues the same launches, in the same order, as the per-kernel entry points above (bit-identical results), never allocates and never synchronises.
- * The other learners (c51 / qr / iqn / fqf / mdqn) are composed from the per-kernel entry points (agent0_amd/deepq/engine.py shows the order). */
+ * algo = A0_ALGO_C51 (round 4): C51Learner.train_step (agent.py:218-268) — BASELINE configs[2], with NoisyLinear layers (model.py:28-87; packed as fc1.mu | fc1.sigma |
+ * head.mu | head.sigma, composed weights and the noise vectors in HBM of the handle, both networks' noise redrawn per update from Philox stream 4 of `seed` exactly
+ * as BaseLearner.train does, agent.py:125-127), dueling, double-Q and n-step.  The quantile learners (qr / iqn / fqf) and mdqn are composed from the per-kernel
+ * entry points (agent0_amd/deepq/engine.py shows the order). */
+#define A0_ALGO_DQN 0
+#define A0_ALGO_C51 1
 typedef struct a0_learner a0_learner;
 typedef struct a0_learner_desc {
     int A, dueling, double_q;         /* cfg.action_dim, learner.dueling_head, learner.double_q (config.py:72-95) */
     int B, n_step;                    /* learner.batch_size, learner.n_step_q */
     double discount, lr, adam_eps;    /* learner.discount, learner.learning_rate; adam_eps <= 0: the reference's 1e-2 / B (agent.py:105) */
     int target_update_freq;           /* learner.target_update_freq (agent.py:160-161) */
+    int algo;                         /* A0_ALGO_* */
+    int num_atoms; double vmin, vmax; /* c51: learner.c51.num_atoms / vmin / vmax (config.py:97-101); the support is torch.linspace(vmin, vmax, num_atoms) */
+    int noisy;                        /* learner.noisy_net */
+    unsigned long long seed;          /* the learner's Philox seed (the Python classes use cfg.seed + 15485863); noise draws only */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
 int a0_learner_destroy(a0_learner* learner);
@@ -288,6 +297,8 @@ long long a0_learner_param_floats(const a0_learner* learner);
 int a0_learner_set_params(a0_learner* learner, const float* online_packed, const float* target_packed, void* stream);
 /* copies of what the handle holds (any pointer may be NULL): parameters, target parameters, Adam moments (param_floats each), the eight status words */
 int a0_learner_get(const a0_learner* learner, float* online_out, float* target_out, float* adam_m_out, float* adam_v_out, int* state_out8, void* stream);
+/* c51: the support atoms [num_atoms] from HOST memory, for a caller that holds the exact values its reference run used (default: linspace in fp32, torch's formula) */
+int a0_learner_set_support(a0_learner* learner, const float* atoms_host);
 /* frames: u8 replay rows st || st_next of row_bytes bytes, read through slot [B] (ring slots of the sampled batch; NULL = rows 0 .. B-1); act int32, rew / done /
  * wgt fp32 [B]; loss_out (optional, [B]): the per-sample losses, i.e. what update_priority takes (trainer.py:103-104) */
 int a0_learner_update(a0_learner* learner, const uint8_t* frames, const int* slot, long long row_bytes, const int* act, const float* rew, const float* done,

@@ -768,6 +768,56 @@ def test_native_learner_handle_equals_the_per_kernel_composition(hip, A, dueling
     nat.close()
 
 
+@pytest.mark.parametrize("A,dueling,double_q,n_step,noisy,B", [(4, False, False, 1, False, 64), (4, True, True, 3, True, 64), (18, True, True, 3, True, 32), (6, False, True, 1, True, 64),
+                                                              (4, True, True, 3, True, 512)], ids=["c51", "rainbow-lite", "rainbow-lite-a18", "c51-noisy-dq", "rainbow-lite-b512"])
+def test_native_c51_learner_handle_equals_the_per_kernel_composition(hip, A, dueling, double_q, n_step, noisy, B):
+    """The a0_learner handle with algo = A0_ALGO_C51 (BASELINE configs[2]: c51 + NoisyNet + dueling + double-Q + n-step): one a0_learner_update call per update — the
+    joint Philox noise fill of both networks (agent.py:125-127), the composed weights, the three encoder passes, the 2B-row online fc1 / head GEMMs, projection +
+    cross entropy, backward, the sigma gradients, Adam with the target sync — must leave exactly what the Python classes leave: BaseLearner's noise draws
+    (DeviceRng, stream 4) + DeviceLearner.update.  torch.equal on losses, parameters, target, Adam moments and status words after each of five updates across a
+    target sync; the default support equals torch.linspace's."""
+    from agent0_amd.common.utils import DeviceRng
+    from agent0_amd.deepq.engine import DeviceLearner
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec("c51", A, dueling=dueling, noisy=noisy)
+    L = NetLayout.from_spec(spec)
+    cap = max(200, B + 40)
+    dev = DeviceLearner(hip, L, B, n_step=n_step, double_q=double_q, target_update_freq=3)
+    dev.online.load_state_dict(recipe.make_state_dict(spec, 11))
+    dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
+    seed = 42 + 15485863
+    rng = DeviceRng(hip, seed)
+    nat = hip.native_learner(A=A, dueling=dueling, double_q=double_q, B=B, n_step=n_step, discount=0.99, lr=5e-4, target_update_freq=3, algo="c51", num_atoms=L.T, vmin=dev.vmin,
+                             vmax=dev.vmax, noisy=noisy, seed=seed)
+    assert nat.n == L.n_params_padded
+    nat.set_params(dev.online.flat, dev.target.flat)
+    if A == 6:
+        nat.set_support(dev.atoms.cpu().tolist())          # the caller's own support values (the other cases run on the handle's default: torch.linspace's)
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(-1).contiguous()
+    loss_n = hip.empty(B)
+    for s in range(5):
+        slot = torch.from_numpy(recipe.gen(40 + s).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+        a_np, r_np, d_np, w_np = recipe.make_transitions(B, A, 70 + s)
+        a, r, d, w = (torch.from_numpy(x).to(hip.device) for x in (a_np.astype(np.int32), r_np, d_np.astype(np.float32), w_np))
+        if noisy:
+            assert dev.noise_joint is not None
+            rng.normal(rng.STREAM_NOISE, 0.1, dev.noise_joint, dev.noise_joint.numel())         # BaseLearner.train_batch
+        loss_e = dev.update(ring, slot, 2 * 28224, a, r, d, w).clone()
+        nat.update(ring, slot, 2 * 28224, a, r, d, w, loss_out=loss_n)
+        torch.cuda.synchronize()
+        on, tg, m, v, st = nat.get()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_n, loss_e[:B]), f"update {s}: per-sample losses (max diff {float((loss_n - loss_e[:B]).abs().max())})"
+        assert torch.equal(on, dev.online.flat) and torch.equal(tg, dev.target.flat), f"update {s}: parameters / target"
+        assert torch.equal(m, dev.adam_m) and torch.equal(v, dev.adam_v), f"update {s}: Adam moments"
+        assert torch.equal(st, dev.state), f"update {s}: status words {st.tolist()} vs {dev.state.tolist()}"
+    assert int(st[1]) == 5 and not torch.equal(on, tg) and float(loss_n.min()) > 0.0
+    if noisy:
+        sg = L.blocks["fc1.sigma"]
+        assert float(m[sg.all].abs().max()) > 0.0, "the sigma blocks are trained"
+    nat.close()
+
+
 def test_plain_c_host_drives_a_learner_through_the_c_abi(tmp_path):
     """The drop-in boundary is a C-ABI: tests/c_host_demo.c — plain C, include/agent0_hip.h and the HIP runtime, no Python, no torch — creates an a0_learner, loads
     parameters, runs three dueling double-Q n-step updates (one a0_learner_update call each) and reads the state back.  Compiled here with gcc (the HIP runtime's C API) against the in-tree
