@@ -88,6 +88,12 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
         if (d->noisy) {
             L->eff_on = L->alloc<float>(L->n_eff, true); L->eff_tg = L->alloc<float>(L->n_eff, true);
             L->noise = L->alloc<float>(2 * L->noise_len, true);
+            // BaseLearner.__init__ builds the online and the target network, and a NoisyLinear draws its first noise when it is built (model.py:44-52): the two
+            // networks' first draws come off the learner's stream here, so that the updates' draws continue where the Python classes' do
+            const unsigned long long o = L->rng.reserve(4, L->noise_len);
+            (void)L->rng.reserve(4, L->noise_len);
+            if (a0_rng_normal(L->rng.seed, 4, o, 0.1f, L->noise, 2 * L->noise_len, nullptr) != A0_OK) { delete L; return A0_EINVAL; }
+            A0_HIP_THROW(hipDeviceSynchronize());
         }
         if (c51) {
             const int dq = d->double_q ? 1 : 0;

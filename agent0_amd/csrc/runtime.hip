@@ -203,12 +203,15 @@ struct a0_actor {
     float *ep_ret = nullptr, *qmax_all = nullptr, *stat_mask = nullptr, *stat_ret = nullptr, *qs = nullptr, *ring_rew = nullptr, *ring_done = nullptr, *act3 = nullptr, *scratch = nullptr;
     int *action = nullptr, *ring_act = nullptr;
     std::vector<float> h_mask, h_ret;
+    // distributional heads (c51): fc1 output, the head GEMM's split-K slabs, fc1's split-K scratch — sized at the first rollout from the learner's shapes
+    float *h = nullptr, *head_slabs = nullptr, *fwd_scratch = nullptr;
+    int dist_Npad = 0;
 };
 
 extern "C" int a0_actor_create(const a0_actor_desc* d, a0_actor** out) {
     A0_TRY
     if (!d || !out) return a0_fail(A0_EINVAL, "a0_actor_create: null argument");
-    if (d->E < 1 || d->T < 1 || d->A < 1 || d->A + (d->dueling ? 1 : 0) > 24 || d->n_step < 1 || !(d->discount > 0.0) || (d->env_task != A0_ENV_TASK_STREAM && d->env_task != A0_ENV_TASK_BLOCK))
+    if (d->E < 1 || d->T < 1 || d->A < 1 || d->n_step < 1 || d->reset_noise_freq < 0 || !(d->discount > 0.0) || (d->env_task != A0_ENV_TASK_STREAM && d->env_task != A0_ENV_TASK_BLOCK))
         return a0_fail(A0_EINVAL, "a0_actor_create: bad description");
     a0_actor* a = new a0_actor();
     try {
@@ -241,21 +244,70 @@ extern "C" int a0_actor_destroy(a0_actor* a) { delete a; return A0_OK; }
 // Actor.sample (agent.py:44-90) with the learner's online network: T steps of [encoder, fc1 GEMM, tail + env step + n-step bookkeeping + replay row], the
 // rows written straight into the ring at its write cursor (call a0_rbuf_commit(replay, T * E) afterwards: ReplayDataset.extend), then the per-step mean max-Q.
 // Asynchronous like everything else; a0_actor_collect waits and returns the statistics.
-extern "C" int a0_actor_rollout(a0_actor* a, const a0_learner* L, a0_rbuf* R, float epsilon, void* stream) {
+// the online network's effective weights from its parameters and the noise vectors it currently holds (DeviceNet.compose_noise)
+static int a0_actor_compose(const a0_learner* L, void* stream) {
+    const float *mu[3], *sg[3], *nin[3], *nw[3], *nb[3];
+    float* eff[3];
+    int N[3], K[3], r0[3], r1[3];
+    for (int k = 0; k < L->n_mods; ++k) {
+        const a0_noise_mod& m = L->mods[k];
+        const Blk &bm = m.block ? L->head : L->fc1, &bs = m.block ? L->head_sigma : L->fc1_sigma, &be = m.block ? L->eff_head : L->eff_fc1;
+        mu[k] = L->online + bm.off; sg[k] = L->online + bs.off; eff[k] = L->eff_on + be.off; N[k] = bm.N; K[k] = bm.K; r0[k] = m.r0; r1[k] = m.r1;
+        nin[k] = L->noise + m.off_in; nw[k] = L->noise + m.off_w; nb[k] = L->noise + m.off_b;
+    }
+    return a0_noisy_multi(0, L->n_mods, mu, sg, eff, N, K, r0, r1, nin, nw, nb, stream);
+}
+
+extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float epsilon, void* stream) {
     A0_TRY
     if (!a || !L || !R) return a0_fail(A0_EINVAL, "a0_actor_rollout: null argument");
     if (L->d.A != a->d.A || (L->d.dueling != 0) != (a->d.dueling != 0) || R->obs_bytes != a->obs_bytes || R->size < a->E)
         return a0_fail(A0_EINVAL, "a0_actor_rollout: actor, learner and replay were created for different shapes");
-    if (L->d.algo != A0_ALGO_DQN) return a0_fail(A0_EINVAL, "a0_actor_rollout: the actor handle acts with scalar heads (the distributional actors: a0_actor_dist_tail_env_step)");
     const int E = a->E, A = a->d.A;
+    const bool dist = L->d.algo == A0_ALGO_C51;
+    const int freq = a->d.reset_noise_freq > 0 ? a->d.reset_noise_freq : 4;
+    if (dist && (a->h == nullptr || a->dist_Npad != L->Npad)) {
+        if (a->h != nullptr) return a0_fail(A0_EINVAL, "a0_actor_rollout: this actor was sized for another head");
+        a->h = a->mem.alloc<float>((long long)E * 512);
+        a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs(E, L->Npad, 512) * E * L->Npad);
+        const long long sc = a0_dense_fwd_scratch(E, 512, L->feat);
+        a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
+        a->dist_Npad = L->Npad;
+    }
     const long long start = R->written % R->size;
     a0_encoder_weights w = L->enc(L->online);
+    // NoisyLinear.forward composes mu + sigma * eps with the parameters as they are NOW (model.py:54-62): a rollout that does not start on a noise reset
+    // recomposes the copies once (agent0_amd/deepq/agent.py Actor._rollout)
+    if (L->d.noisy && a->steps % freq != 0) A0_CHECK(a0_actor_compose(L, stream));
     for (int t = 0; t < a->T; ++t) {
+        if (L->d.noisy && a->steps % freq == 0) {      // agent.py:52-53: self.model.reset_noise() every reset_noise_freq steps, from the ACTOR's stream
+            A0_CHECK(a0_rng_normal(a->rng.seed, 4 /* STREAM_NOISE */, a->rng.reserve(4, L->noise_len), 0.1f, L->noise, L->noise_len, stream));
+            A0_CHECK(a0_actor_compose(L, stream));
+        }
         const uint8_t* cur_obs = a->obs[a->cur];
         a0_frames_arg f{cur_obs, nullptr, (long long)a->obs_bytes, 0};
         A0_CHECK(a0_net_encoder_fwd_fused(L->C, L->H, L->W, L->wt_on, &w, &f, E, nullptr, nullptr, a->act3, stream));
         const long long back = (a->steps + 1 < a->n ? a->steps + 1 : a->n) - 1;                 // first observation of the emitted n-step transition
         const uint8_t* obs0 = a->obs[((a->cur - back) % a->K + a->K) % a->K];
+        if (dist) {
+            // fc1, the head GEMM's slabs, then ONE launch: slab sum + bias, dueling, expectation over the support, first-max argmax, epsilon-greedy, env step,
+            // n-step bookkeeping and the replay row (Actor._dist_tail_args + act_step_commit(kind = "dist"))
+            A0_CHECK(a0_dense_fwd(a->act3, L->feat, L->Wf(false), L->bf(false), a->h, E, 512, L->feat, 1, a->fwd_scratch, stream));
+            const int ns = a0_dense_fwd_partial_slabs(E, L->Npad, 512);
+            A0_CHECK(a0_dense_fwd_partial(a->h, 512, L->Wh(false), E, L->Npad, 512, a->head_slabs, stream));
+            const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);
+            const int nx = (a->cur + 1) % a->K;
+            a->g += 1;
+            A0_CHECK(a0_actor_dist_tail_env_step(a->head_slabs, (long long)E * L->Npad, ns, L->bh(false), L->Npad, A, L->T, a->d.dueling ? 1 : 0, 2, L->atoms, E, a->rng.seed,
+                                                 STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed, a->d.rank,
+                                                 a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps, a->d.discount,
+                                                 a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,
+                                                 a->d.env_task, stream));
+            a->cur = nx;
+            a->steps += 1;
+            continue;
+        }
+        if (A + (a->d.dueling ? 1 : 0) > 24) return a0_fail(A0_EINVAL, "a0_actor_rollout: scalar heads with A + dueling <= 24 actions");
         const unsigned long long off_a = a->rng.reserve(STREAM_EGREEDY_A, E), off_u = a->rng.reserve(STREAM_EGREEDY_U, E);
         const int nxt = (a->cur + 1) % a->K;
         a->g += 1;

@@ -332,7 +332,7 @@ int a0_rbuf_sample(a0_rbuf* replay, a0_batch* out, void* stream);
 /* ReplayDataset.update_priority with the last batch's indices and the learner's per-sample losses; learner_state: a0_learner_get's status words or NULL */
 int a0_rbuf_update_priority(a0_rbuf* replay, const float* loss, const int* learner_state, void* stream);
 
-/* a0_actor = Actor (agent.py:19-90) on the device-resident synthetic env for scalar heads: observations, epsilon-greedy Philox streams (seed, rank), n-step ring,
+/* a0_actor = Actor (agent.py:19-90) on the device-resident synthetic env for the heads a0_learner covers (scalar; categorical with or without NoisyNet): observations, epsilon-greedy Philox streams (seed, rank), n-step ring,
  * episode statistics.  a0_actor_rollout = Actor.sample: T steps acting with the learner's online network, transitions written into the replay ring at its write
  * cursor (then a0_rbuf_commit(replay, T * E)); a0_actor_collect waits for the stream and returns qs [T] and the finished episodes' returns (host memory). */
 typedef struct a0_actor a0_actor;
@@ -341,10 +341,13 @@ typedef struct a0_actor_desc {
     double discount;                                   /* learner.discount */
     unsigned long long seed; unsigned int rank;        /* cfg.seed, this process's rank */
     int env_task;                                      /* A0_ENV_TASK_* */
+    int reset_noise_freq;                              /* learner.reset_noise_freq (NoisyNet learners; 0 = the reference's default 4) */
 } a0_actor_desc;
 int a0_actor_create(const a0_actor_desc* desc, a0_actor** out);
 int a0_actor_destroy(a0_actor* actor);
-int a0_actor_rollout(a0_actor* actor, const a0_learner* learner, a0_rbuf* replay, float epsilon, void* stream);
+/* (the learner is not const: like the reference's single-process main, the actor acts with the learner's own network object — a NoisyNet actor redraws that
+ * network's noise every reset_noise_freq steps from ITS Philox stream 4 and recomposes the effective weights, agent.py:52-53) */
+int a0_actor_rollout(a0_actor* actor, a0_learner* learner, a0_rbuf* replay, float epsilon, void* stream);
 int a0_actor_collect(a0_actor* actor, float* qs_host, float* returns_host, int max_returns, int* n_returns, void* stream);
 
 /* data parallelism: this rank's NaN flag as a float (1.0 / 0.0) that rides at the tail of a SUM-reduced gradient bucket; the reduced value

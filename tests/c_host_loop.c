@@ -1,6 +1,7 @@
-/* BASELINE configs[1] — Breakout-shaped dqn, 256 vectorized envs x 80 steps + 20 updates of batch 512 per iteration — run by a host that is NOT Python: plain C
- * against include/agent0_hip.h, the three handles a0_actor / a0_rbuf / a0_learner (library-owned HBM) and the loop of trainer.py:74-119,171-184 written out.
- * usage: c_host_loop [iterations] [replay_size] [env_task 0|1]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
+/* BASELINE configs[1] — Breakout-shaped dqn, 256 vectorized envs x 80 steps + 20 updates of batch 512 per iteration — or configs[2] — c51 rainbow-lite: NoisyNet,
+ * dueling, double-Q, 3-step returns, prioritized replay — run by a host that is NOT Python: plain C against include/agent0_hip.h, the three handles
+ * a0_actor / a0_rbuf / a0_learner (library-owned HBM) and the loop of trainer.py:74-119,171-184 written out.
+ * usage: c_host_loop [iterations] [replay_size] [env_task 0|1] [config 1|2]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
 #include <hip/hip_runtime_api.h>      /* gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include */
 #include <math.h>
 #include <stdio.h>
@@ -22,9 +23,11 @@ int main(int argc, char** argv) {
     const int E = 256, T = 80, B = 512, LSTEPS = 20, A = 4, OBS = 4 * 84 * 84;
     const long long start_steps = size < 100000 ? size / 2 : 100000, exploration = 1000000;
     const double min_eps = 0.01;
-    a0_learner_desc ld = {A, 0, 0, B, 1, 0.99, 5e-4, 0.0, 500};
-    a0_rbuf_desc rd = {size, OBS, B, 0, 0.5, 0.01, 0.4, 10000000, 42 + 104729};
-    a0_actor_desc ad = {E, T, A, 0, 1, 0.99, 42, 0, task};
+    const int config = argc > 4 ? atoi(argv[4]) : 1;
+    const int rainbow = config == 2;
+    a0_learner_desc ld = {A, rainbow, rainbow, B, rainbow ? 3 : 1, 0.99, 5e-4, 0.0, 500, rainbow ? A0_ALGO_C51 : A0_ALGO_DQN, 51, -10.0, 10.0, rainbow, 42 + 15485863};
+    a0_rbuf_desc rd = {size, OBS, B, rainbow, 0.5, 0.01, 0.4, 10000000, 42 + 104729};
+    a0_actor_desc ad = {E, T, A, rainbow, rainbow ? 3 : 1, 0.99, 42, 0, task, 4};
     a0_learner* L = NULL; a0_rbuf* R = NULL; a0_actor* ac = NULL;
     CHECK(a0_learner_create(&ld, &L)); CHECK(a0_rbuf_create(&rd, &R)); CHECK(a0_actor_create(&ad, &ac));
     /* small random initial weights (a real host would load a packed checkpoint: agent0_amd/deepq/layout.py) */
@@ -71,8 +74,10 @@ int main(int argc, char** argv) {
     double mean = 0.0; int finite = 1;
     for (int b = 0; b < B; ++b) { mean += hl[b] / B; if (!isfinite(hl[b])) finite = 0; }
     printf("{\"host\": \"plain C (tests/c_host_loop.c)\", \"iterations_timed\": %d, \"ms_per_iteration\": %.3f, \"env_frames_per_sec\": %.1f, \"frames\": %lld, \"updates\": %lld, "
-           "\"episodes\": %lld, \"mean_return\": %.4f, \"last_mean_loss\": %.6g, \"last_qmax\": %.5g, \"finite\": %d, \"replay_size\": %lld, \"env_task\": %d}\n",
-           timed, 1e3 * dt / timed, (double)timed * T * E / dt, frames, updates, episodes, episodes ? ret_sum / (double)episodes : 0.0, mean, qmax, finite, size, task);
+           "\"episodes\": %lld, \"mean_return\": %.4f, \"last_mean_loss\": %.6g, \"last_qmax\": %.5g, \"finite\": %d, \"replay_size\": %lld, \"env_task\": %d, "
+           "\"config\": \"%s\"}\n",
+           timed, 1e3 * dt / timed, (double)timed * T * E / dt, frames, updates, episodes, episodes ? ret_sum / (double)episodes : 0.0, mean, qmax, finite, size, task,
+           rainbow ? "BASELINE configs[2]: c51 + NoisyNet + dueling + double-Q + 3-step + prioritized replay" : "BASELINE configs[1]: dqn, uniform replay");
     CHECK(a0_actor_destroy(ac)); CHECK(a0_rbuf_destroy(R)); CHECK(a0_learner_destroy(L));
     return 0;
 }

@@ -787,6 +787,8 @@ def test_native_c51_learner_handle_equals_the_per_kernel_composition(hip, A, due
     dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
     seed = 42 + 15485863
     rng = DeviceRng(hip, seed)
+    if noisy:
+        rng.reserve(rng.STREAM_NOISE, dev.online.noise_len); rng.reserve(rng.STREAM_NOISE, dev.target.noise_len)      # BaseLearner.__init__: both networks' first noise
     nat = hip.native_learner(A=A, dueling=dueling, double_q=double_q, B=B, n_step=n_step, discount=0.99, lr=5e-4, target_update_freq=3, algo="c51", num_atoms=L.T, vmin=dev.vmin,
                              vmax=dev.vmax, noisy=noisy, seed=seed)
     assert nat.n == L.n_params_padded
