@@ -12,9 +12,20 @@
 // (INTEGRATION.md options A / B).
 #include "learner_state.h"
 
-extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
+extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) { return a0_learner_create_on(d, nullptr, out); }
+
+extern "C" int a0_learner_set_rng(a0_learner* L, int stream_id, unsigned long long offset) {
+    if (!L || stream_id < 0 || stream_id > 7 || (offset & 3)) return a0_fail(A0_EINVAL, "a0_learner_set_rng: stream 0..7, offset a multiple of four");
+    L->rng.off[stream_id] = offset;
+    return A0_OK;
+}
+
+extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_buffers* bufs, a0_learner** out) {
     A0_TRY
     if (!d || !out) return a0_fail(A0_EINVAL, "a0_learner_create: null argument");
+    const a0_learner_buffers none{};
+    const a0_learner_buffers& U = bufs ? *bufs : none;
+    if (U.loss_ring && U.loss_ring_cap < 1) return a0_fail(A0_EINVAL, "a0_learner_create_on: loss_ring_cap");
     if (d->A < 1 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1 || (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51))
         return a0_fail(A0_EINVAL, "a0_learner_create: bad description");
     if (d->algo == A0_ALGO_DQN && (d->A + (d->dueling ? 1 : 0) > 24 || d->noisy))
@@ -62,10 +73,12 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
         L->wt_floats = a0_net_conv_wt_floats(L->C);
         L->gamma_n = (float)std::pow(d->discount, (double)d->n_step);
         const int B = d->B;
-        L->online = L->alloc<float>(L->n_pad, true); L->target = L->alloc<float>(L->n_pad, true);
-        L->grads = L->alloc<float>(L->n_pad + 4, true); L->m = L->alloc<float>(L->n_pad, true); L->v = L->alloc<float>(L->n_pad, true);
-        L->state = L->alloc<int>(8, true); L->scalars = L->alloc<float>(4, true); L->loss_ring = L->alloc<float>(1024, true);
-        L->wt_on = L->alloc<float>(L->wt_floats, true); L->wt_tg = L->alloc<float>(L->wt_floats, true);
+        L->online = U.online ? U.online : L->alloc<float>(L->n_pad, true); L->target = U.target ? U.target : L->alloc<float>(L->n_pad, true);
+        L->grads = U.grads ? U.grads : L->alloc<float>(L->n_pad + 4, true);
+        L->m = U.adam_m ? U.adam_m : L->alloc<float>(L->n_pad, true); L->v = U.adam_v ? U.adam_v : L->alloc<float>(L->n_pad, true);
+        L->state = U.state ? U.state : L->alloc<int>(8, true); L->scalars = U.scalars ? U.scalars : L->alloc<float>(4, true);
+        L->loss_ring = U.loss_ring ? U.loss_ring : L->alloc<float>(1024, true); L->loss_ring_cap = U.loss_ring ? U.loss_ring_cap : 1024;
+        L->wt_on = U.wt_online ? U.wt_online : L->alloc<float>(L->wt_floats, true); L->wt_tg = U.wt_target ? U.wt_target : L->alloc<float>(L->wt_floats, true);
         L->act1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->act2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64);
         L->act3_t = L->alloc<float>((long long)B * L->feat);
         L->ns_fc1 = a0_dense_fwd_partial_slabs(B, 512, L->feat);
@@ -86,7 +99,9 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
         const long long n_slab = L->enc_slab_off + a0_net_encoder_bwd_scratch(L->net, B);
         L->slabs = L->alloc<float>(n_slab > 4 ? n_slab : 4);
         if (d->noisy) {
-            L->eff_on = L->alloc<float>(L->n_eff, true); L->eff_tg = L->alloc<float>(L->n_eff, true);
+            L->eff_on = U.eff_online ? U.eff_online : L->alloc<float>(L->n_eff, true); L->eff_tg = U.eff_target ? U.eff_target : L->alloc<float>(L->n_eff, true);
+            if (U.noise) L->noise = U.noise;      // the caller's vectors as they are; its stream position comes through a0_learner_set_rng
+            else {
             L->noise = L->alloc<float>(2 * L->noise_len, true);
             // BaseLearner.__init__ builds the online and the target network, and a NoisyLinear draws its first noise when it is built (model.py:44-52): the two
             // networks' first draws come off the learner's stream here, so that the updates' draws continue where the Python classes' do
@@ -94,6 +109,7 @@ extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) {
             (void)L->rng.reserve(4, L->noise_len);
             if (a0_rng_normal(L->rng.seed, 4, o, 0.1f, L->noise, 2 * L->noise_len, nullptr) != A0_OK) { delete L; return A0_EINVAL; }
             A0_HIP_THROW(hipDeviceSynchronize());
+            }
         }
         if (c51) {
             const int dq = d->double_q ? 1 : 0;
@@ -267,7 +283,7 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
     const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;
     A0_CHECK(a0_adam_step_sync_wt(on, L->grads, L->m, L->v, L->n_adam, L->state, L->scalars, L->d.lr, 0.9, 0.999, eps, L->d.target_update_freq, tg, L->n_pad, nullptr, &w_on, L->C,
-                                  L->wt_on, L->wt_tg, L->loss, B, L->loss_ring, 1024, stream));
+                                  L->wt_on, L->wt_tg, L->loss, B, L->loss_ring, L->loss_ring_cap, stream));
     return A0_OK;
     A0_CATCH
 }

@@ -47,6 +47,7 @@ struct a0_learner {
     float gamma_n = 0.f;
     int ns_fc1 = 1;
     long long slab_off[2] = {0, 0}, enc_slab_off = 0;
+    int loss_ring_cap = 1024;
     // library-owned HBM
     float *online = nullptr, *target = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *scalars = nullptr, *loss_ring = nullptr;
     float *wt_on = nullptr, *wt_tg = nullptr;

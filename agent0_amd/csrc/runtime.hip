@@ -60,7 +60,9 @@ struct a0_rbuf {
     long long head() const { return written > size ? written % size : 0; }
 };
 
-extern "C" int a0_rbuf_create(const a0_rbuf_desc* d, a0_rbuf** out) {
+extern "C" int a0_rbuf_create(const a0_rbuf_desc* d, a0_rbuf** out) { return a0_rbuf_create_on(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out); }
+
+extern "C" int a0_rbuf_create_on(const a0_rbuf_desc* d, uint8_t* frames, int* act, float* rew, float* done, float* tree, float* max_p, a0_rbuf** out) {
     A0_TRY
     if (!d || !out) return a0_fail(A0_EINVAL, "a0_rbuf_create: null argument");
     if (d->size < 2 || d->obs_bytes < 16 || (d->obs_bytes % 16) || d->B < 1 || d->B > d->size || (d->prioritize && (d->B > 1024 || !(d->alpha > 0.0) || d->total_steps < 1)))
@@ -69,17 +71,17 @@ extern "C" int a0_rbuf_create(const a0_rbuf_desc* d, a0_rbuf** out) {
     try {
         R->d = *d; R->size = d->size; R->obs_bytes = d->obs_bytes; R->row_bytes = 2LL * d->obs_bytes; R->B = d->B; R->prio = d->prioritize != 0;
         R->rng.init(d->seed, 0);
-        R->frames = R->mem.alloc<uint8_t>(R->size * R->row_bytes, false);
-        R->act = R->mem.alloc<int>(R->size); R->rew = R->mem.alloc<float>(R->size); R->done = R->mem.alloc<float>(R->size);
+        R->frames = frames ? frames : R->mem.alloc<uint8_t>(R->size * R->row_bytes, false);
+        R->act = act ? act : R->mem.alloc<int>(R->size); R->rew = rew ? rew : R->mem.alloc<float>(R->size); R->done = done ? done : R->mem.alloc<float>(R->size);
         const int B = d->B;
         R->b_idx = R->mem.alloc<long long>(B); R->b_slot = R->mem.alloc<int>(B); R->b_act = R->mem.alloc<int>(B); R->b_rew = R->mem.alloc<float>(B);
         R->b_done = R->mem.alloc<float>(B); R->b_prio = R->mem.alloc<float>(B); R->b_w = R->mem.alloc<float>(B); R->ones = R->mem.alloc<float>(B);
-        R->pstate = R->mem.alloc<float>(1); R->val = R->mem.alloc<float>(4);
+        R->pstate = max_p ? max_p : R->mem.alloc<float>(1); R->val = R->mem.alloc<float>(4);
         hipLaunchKernelGGL(a0_fill_one_kernel, dim3((B + 255) / 256), dim3(256), 0, 0, R->ones, (long long)B, 1.0f);
-        hipLaunchKernelGGL(a0_fill_one_kernel, dim3(1), dim3(256), 0, 0, R->pstate, 1LL, 1.0f);           // max_p = 1 (replay.py:20)
+        if (!max_p) hipLaunchKernelGGL(a0_fill_one_kernel, dim3(1), dim3(256), 0, 0, R->pstate, 1LL, 1.0f);           // max_p = 1 (replay.py:20)
         if (R->prio) {
             while (R->cap2 < R->size) R->cap2 <<= 1;
-            R->tree = R->mem.alloc<float>(2 * R->cap2);
+            R->tree = tree ? tree : R->mem.alloc<float>(2 * R->cap2);
             R->beta_use = R->sched_cur = d->beta0;                                                         // LinearSchedule(beta0, 1, total_steps), utils.py:12-28
             R->beta_inc = (1.0 - d->beta0) / (double)d->total_steps;
         }
@@ -203,6 +205,14 @@ struct a0_actor {
     float *ep_ret = nullptr, *qmax_all = nullptr, *stat_mask = nullptr, *stat_ret = nullptr, *qs = nullptr, *ring_rew = nullptr, *ring_done = nullptr, *act3 = nullptr, *scratch = nullptr;
     int *action = nullptr, *ring_act = nullptr;
     std::vector<float> h_mask, h_ret;
+    float *p_mask = nullptr, *p_ret = nullptr, *p_qs = nullptr;       // page-locked: a0_actor_collect_begin / _end
+    hipEvent_t stats_ev = nullptr;
+    ~a0_actor() {
+        if (p_mask) (void)hipHostFree(p_mask);
+        if (p_ret) (void)hipHostFree(p_ret);
+        if (p_qs) (void)hipHostFree(p_qs);
+        if (stats_ev) (void)hipEventDestroy(stats_ev);
+    }
     // distributional heads (c51): fc1 output, the head GEMM's split-K slabs, fc1's split-K scratch — sized at the first rollout from the learner's shapes
     float *h = nullptr, *head_slabs = nullptr, *fwd_scratch = nullptr;
     int dist_Npad = 0;
@@ -338,6 +348,39 @@ extern "C" int a0_actor_collect(a0_actor* a, float* qs_host, float* returns_host
     int k = 0;
     for (size_t i = 0; i < n; ++i)
         if (a->h_mask[i] != 0.f) { if (returns_host && k < max_returns) returns_host[k] = a->h_ret[i]; ++k; }
+    if (n_returns) *n_returns = k;
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_actor_collect_begin(a0_actor* a, void* stream) {
+    A0_TRY
+    if (!a) return a0_fail(A0_EINVAL, "a0_actor_collect_begin: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)a->T * a->E;
+    if (!a->p_mask) {
+        A0_HIP_THROW(hipHostMalloc((void**)&a->p_mask, n * 4, hipHostMallocDefault));
+        A0_HIP_THROW(hipHostMalloc((void**)&a->p_ret, n * 4, hipHostMallocDefault));
+        A0_HIP_THROW(hipHostMalloc((void**)&a->p_qs, (size_t)a->T * 4, hipHostMallocDefault));
+        A0_HIP_THROW(hipEventCreateWithFlags(&a->stats_ev, hipEventDisableTiming));
+    }
+    A0_HIP_THROW(hipMemcpyAsync(a->p_qs, a->qs, (size_t)a->T * 4, hipMemcpyDeviceToHost, st));
+    A0_HIP_THROW(hipMemcpyAsync(a->p_mask, a->stat_mask, n * 4, hipMemcpyDeviceToHost, st));
+    A0_HIP_THROW(hipMemcpyAsync(a->p_ret, a->stat_ret, n * 4, hipMemcpyDeviceToHost, st));
+    A0_HIP_THROW(hipEventRecord(a->stats_ev, st));
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_actor_collect_end(a0_actor* a, float* qs_host, float* returns_host, int max_returns, int* n_returns) {
+    A0_TRY
+    if (!a || !a->stats_ev) return a0_fail(A0_EINVAL, "a0_actor_collect_end: no a0_actor_collect_begin before it");
+    A0_HIP_THROW(hipEventSynchronize(a->stats_ev));
+    const size_t n = (size_t)a->T * a->E;
+    if (qs_host) for (int t = 0; t < a->T; ++t) qs_host[t] = a->p_qs[t];
+    int k = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (a->p_mask[i] != 0.f) { if (returns_host && k < max_returns) returns_host[k] = a->p_ret[i]; ++k; }
     if (n_returns) *n_returns = k;
     return A0_OK;
     A0_CATCH

@@ -1,0 +1,208 @@
+"""The actor -> replay -> learner loop of ``Trainer.run_iteration`` issued by the library's own handles (``a0_actor`` / ``a0_rbuf`` / ``a0_learner``,
+csrc/runtime.hip + learner.hip) instead of by Python: one C call per rollout, per batch, per update.
+
+Why: the launches of a rollout (240) and of an update block (20 x ~16) cost a fast native host ~2 us each and are issued back to back; replayed from hipGraphs by
+the Python classes they run 2.4 % (BASELINE configs[1]) to 5 % (configs[2]) slower on the same box (profiles/r04_experiments.md), and issued one by one from Python
+much slower than that.  The handles are created OVER the buffers the Python classes already hold (``a0_learner_create_on`` / ``a0_rbuf_create_on``): parameters,
+target, Adam moments, status words, loss ring, weight copies, NoisyNet buffers, replay ring, sum-tree — so ``state_dict()``, checkpoints, the test actor and every
+reader of ``trainer.replay`` keep seeing the live data, with no copies in either direction.  What the handles own themselves: the actor's env state and Philox
+offsets, the sampler's state (epochs / beta), the workspaces.
+
+Scope = what the handles cover (include/agent0_hip.h): dqn (A + dueling <= 24, no NoisyNet) and c51 (any) on 4 x 84 x 84 observations, the device-resident env,
+uniform or sum-tree replay, one GPU, the ``main`` schedule.  Everything else — and any Trainer whose hot-loop methods a test harness has wrapped — stays on the Python
+classes.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from agent0_amd import _abi
+from .config import ReplayEnum
+
+
+class _RbufDesc(C.Structure):
+    _fields_ = [("size", C.c_longlong), ("obs_bytes", C.c_int), ("B", C.c_int), ("prioritize", C.c_int), ("alpha", C.c_double), ("eps", C.c_double), ("beta0", C.c_double),
+                ("total_steps", C.c_longlong), ("seed", C.c_ulonglong)]
+
+
+class _ActorDesc(C.Structure):
+    _fields_ = [("E", C.c_int), ("T", C.c_int), ("A", C.c_int), ("dueling", C.c_int), ("n_step", C.c_int), ("discount", C.c_double), ("seed", C.c_ulonglong), ("rank", C.c_uint),
+                ("env_task", C.c_int), ("reset_noise_freq", C.c_int)]
+
+
+class _LearnerBuffers(C.Structure):
+    _fields_ = [("online", C.c_void_p), ("target", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("state", C.c_void_p), ("scalars", C.c_void_p),
+                ("loss_ring", C.c_void_p), ("loss_ring_cap", C.c_int), ("wt_online", C.c_void_p), ("wt_target", C.c_void_p), ("eff_online", C.c_void_p), ("eff_target", C.c_void_p),
+                ("noise", C.c_void_p)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("idx", "slot", "act", "rew", "done", "prio", "weights")]
+
+
+def _wrapped(obj) -> bool:
+    """An instance-level function on one of the hot-loop objects: a test harness intercepting calls (tests/test_gpu_trace.py)."""
+    return any(type(v).__name__ in ("function", "method") for k, v in vars(obj).items() if k != "epsilon_fn")
+
+
+def eligible(tr) -> Optional[str]:
+    """None when the Trainer's configuration is one the handles cover, else the reason it is not."""
+    from agent0_amd.common.atari_wrappers import DeviceSynthVecEnv
+    cfg = tr.cfg
+    lc = cfg.learner
+    if os.environ.get("A0_NATIVE_LOOP", "1") == "0":
+        return "A0_NATIVE_LOOP=0"
+    if tr.use_lp:
+        return "the launch schedule keeps its second stream in Python"
+    algo = lc.algo.name
+    if algo == "dqn":
+        if lc.noisy_net or cfg.action_dim + (1 if lc.dueling_head else 0) > 24:
+            return "dqn handle: no NoisyNet, A + dueling <= 24"
+    elif algo != "c51":
+        return f"no handle for {algo}"
+    if tuple(cfg.obs_shape) != (4, 84, 84):
+        return "observations other than 4 x 84 x 84"
+    actor = tr.actors[1]
+    if not isinstance(actor.envs, DeviceSynthVecEnv) or actor.groups is not None:
+        return "host environments"
+    rp = tr.replay
+    if rp.prioritize and not rp.use_sumtree:
+        return "the reference-faithful flat priority vector"
+    if rp.prioritize and lc.batch_size > 1024:
+        return "prioritized batches above 1024"
+    eng = tr.learner.engine
+    if not (eng.online.fused and eng.online.fused_dgrad) or tr.ops.gemm_mode() != 1 or not getattr(eng, "_defer_dense", False):
+        return "a tuning mode of the Python composition"
+    if lc.learner_steps > eng.loss_ring.numel() or lc.max_grad_norm > 0:
+        return "block longer than the loss ring / gradient clipping"
+    if algo == "c51" and not (2 <= lc.c51.num_atoms <= 64):
+        return "support size"
+    return None
+
+
+class NativeLoop:
+    def __init__(self, tr):
+        self.tr = tr
+        cfg, ops = tr.cfg, tr.ops
+        lc, rc = cfg.learner, cfg.replay
+        self.lib, self.ok = _abi.load(), _abi.check
+        lib, ok = self.lib, self.ok
+        eng, rp, actor = tr.learner.engine, tr.replay, tr.actors[1]
+        L = eng.L
+        self.E, self.T, self.B = int(cfg.actor.num_envs), int(cfg.actor.sample_steps), int(lc.batch_size)
+        self.prio = rp.prioritize
+        # ---- learner over the engine's buffers
+        desc = _abi.LearnerDesc(int(cfg.action_dim), int(bool(lc.dueling_head)), int(bool(lc.double_q)), self.B, int(lc.n_step_q), float(lc.discount), float(lc.learning_rate),
+                                float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1}[lc.algo.name], int(lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
+                                int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF)
+        p = lambda t: None if t is None else t.data_ptr()
+        bufs = _LearnerBuffers(p(eng.online.flat), p(eng.target.flat), p(eng.grads), p(eng.adam_m), p(eng.adam_v), p(eng.state), p(eng.scalars), p(eng.loss_ring),
+                               int(eng.loss_ring.numel()), p(eng.online.wt), p(eng.target.wt), p(eng.online.eff), p(eng.target.eff), p(eng.noise_joint))
+        self.learner = C.c_void_p()
+        ok(lib.a0_learner_create_on(C.addressof(desc), C.addressof(bufs), C.addressof(self.learner)), "a0_learner_create_on")
+        assert int(lib.a0_learner_param_floats(self.learner)) == L.n_params_padded
+        if lc.algo.name == "c51":
+            atoms = (C.c_float * L.T)(*[float(x) for x in eng.atoms.cpu().tolist()])
+            ok(lib.a0_learner_set_support(self.learner, atoms), "a0_learner_set_support")
+        if lc.noisy_net:
+            rng = tr.learner.rng
+            ok(lib.a0_learner_set_rng(self.learner, rng.STREAM_NOISE, C.c_ulonglong(rng.offsets.get(rng.STREAM_NOISE, 0))), "a0_learner_set_rng")
+        # ---- replay over the ReplayDataset's ring
+        rd = _RbufDesc(int(rp.size), int(rp.obs_bytes), self.B, int(self.prio), float(rc.alpha), float(rc.eps), float(rc.beta0), int(cfg.trainer.total_steps), int(cfg.seed) + 104729)
+        self.rbuf = C.c_void_p()
+        ok(lib.a0_rbuf_create_on(C.addressof(rd), p(rp.frames), p(rp.act), p(rp.rew), p(rp.done), p(rp._tree) if self.prio else None, p(rp._pstate), C.addressof(self.rbuf)),
+           "a0_rbuf_create_on")
+        # ---- actor (its own env state: the Python Actor's stays where the constructor left it)
+        ad = _ActorDesc(self.E, self.T, int(cfg.action_dim), int(bool(lc.dueling_head)), int(lc.n_step_q), float(lc.discount), int(cfg.seed), int(tr.rank),
+                        {"stream": 0, "block": 1}[cfg.env_task], int(lc.reset_noise_freq))
+        self.actor = C.c_void_p()
+        ok(lib.a0_actor_create(C.addressof(ad), C.addressof(self.actor)), "a0_actor_create")
+        self.loss_dev = ops.empty(self.B)
+        self._qs, self._rs, self._nret = (C.c_float * self.T)(), (C.c_float * (self.T * self.E))(), C.c_int()
+        self._pending_rollout = False
+        self.frames_ptr = p(rp.frames)
+        self.row_bytes = int(rp.row_bytes)
+
+    # ------------------------------------------------------------------ pieces of one iteration
+    def _rollout(self, st):
+        tr, lib = self.tr, self.lib
+        self.ok(lib.a0_actor_rollout(self.actor, self.learner, self.rbuf, C.c_float(tr.epsilon_fn(tr.frame_count)), st), "a0_actor_rollout")
+
+    def _commit(self, st):
+        tr, rp = self.tr, self.tr.replay
+        n = self.T * self.E
+        self.ok(self.lib.a0_rbuf_commit(self.rbuf, n, st), "a0_rbuf_commit")
+        tr.frame_count += n
+        rp.written += n                                   # the ReplayDataset's counters follow (its buffers ARE the handle's)
+        rp.top = min(rp.top + n, rp.size)
+        if self.prio:
+            beta = C.c_double()
+            self.ok(self.lib.a0_rbuf_info(self.rbuf, None, None, C.addressof(beta)), "a0_rbuf_info")
+            rp.beta = beta.value
+
+    def _block(self, st) -> int:
+        tr, lib, ok = self.tr, self.lib, self.ok
+        cfg = tr.cfg
+        if int(lib.a0_rbuf_len(self.rbuf)) <= cfg.trainer.training_start_steps:
+            return 0
+        eng, ln = tr.learner.engine, tr.learner
+        b = _Batch()
+        n = int(cfg.learner.learner_steps)
+        for _ in range(n):
+            ok(lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
+            ok(lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, self.loss_dev.data_ptr(), st), "a0_learner_update")
+            if self.prio:
+                ok(lib.a0_rbuf_update_priority(self.rbuf, self.loss_dev.data_ptr(), eng.state.data_ptr(), st), "a0_rbuf_update_priority")
+        tr._ring0 = ln.updates_issued                     # the Adam launch wrote the block's batch-mean losses to ring slots ring0 .. ring0 + n - 1
+        ln.updates_issued += n
+        if self.prio:
+            tr.replay._top_stale = True                   # the handle defers the tree's top levels to its next sample; ReplayDataset.tree brings them up to date for other readers
+        return n
+
+    # ------------------------------------------------------------------ Trainer.run_iteration
+    def run_iteration(self, prefetch: bool = False):
+        tr, lib, ok = self.tr, self.lib, self.ok
+        st = torch.cuda.current_stream().cuda_stream
+        tic = time.time()
+        if not self._pending_rollout:
+            self._rollout(st)
+        self._pending_rollout = False
+        self._commit(st)
+        n_upd = self._block(st)
+        blk = tr._block_stats_async(n_upd, False)         # loss ring -> page-locked buffer, stream-ordered behind the block
+        ok(lib.a0_actor_collect_begin(self.actor, st), "a0_actor_collect_begin")
+        if prefetch:
+            self._rollout(st)                             # the next iteration's rollout before the host waits for this one's statistics
+            self._pending_rollout = True
+        ok(lib.a0_actor_collect_end(self.actor, self._qs, self._rs, self.T * self.E, C.addressof(self._nret)), "a0_actor_collect_end")
+        tr._block_stats_finish(blk)
+        tr.Qs.extend(np.ctypeslib.as_array(self._qs).tolist())
+        tr.Rs.extend(np.ctypeslib.as_array(self._rs)[: self._nret.value].tolist())
+        result = tr._result()
+        if not prefetch:
+            torch.cuda.synchronize()
+        result.update(fps=tr.num_transitions / (time.time() - tic))
+        return result
+
+    def drain(self):
+        """A rollout issued ahead and never consumed: book it (Trainer.final)."""
+        if self._pending_rollout:
+            st = torch.cuda.current_stream().cuda_stream
+            self._pending_rollout = False
+            self._commit(st)
+            self.ok(self.lib.a0_actor_collect(self.actor, self._qs, self._rs, self.T * self.E, C.addressof(self._nret), st), "a0_actor_collect")
+            self.tr.Qs.extend(np.ctypeslib.as_array(self._qs).tolist())
+            self.tr.Rs.extend(np.ctypeslib.as_array(self._rs)[: self._nret.value].tolist())
+
+    def close(self):
+        torch.cuda.synchronize()
+        for h, fn in ((self.actor, self.lib.a0_actor_destroy), (self.rbuf, self.lib.a0_rbuf_destroy), (self.learner, self.lib.a0_learner_destroy)):
+            if h is not None and h.value:
+                fn(h)
+        self.actor = self.rbuf = self.learner = None

@@ -411,6 +411,25 @@ class Trainer:
         result.update(fps=self.num_transitions / (time.time() - tic))
         return result
 
+    def _native_loop(self):
+        """The library's own handles over this Trainer's buffers (deepq/native_loop.py) when the configuration is one they cover, nothing has wrapped the hot-loop
+        methods and no gradient hook is installed; decided at the first iteration, and final from then on (the handles own the actor's and the sampler's state)."""
+        nl = getattr(self, "_nl", None)
+        if nl is False:
+            return None
+        from . import native_loop
+        ok_now = self.learner.engine.grad_hook is None and not any(native_loop._wrapped(o) for o in (self, self.replay, self.learner, self.actors[1]))
+        if nl is None:
+            why = native_loop.eligible(self)
+            if why is not None or not ok_now or getattr(self, "_prefetched", None) is not None or self.frame_count != 0 or self.actors[1].steps != 0:
+                self._nl = False
+                self.native_loop_reason = why or "hot-loop methods wrapped, a gradient hook, or a run already under way"
+                return None
+            nl = self._nl = native_loop.NativeLoop(self)
+        elif not ok_now:
+            raise RuntimeError("Trainer: a gradient hook or a method wrapper was installed after the native loop had taken over the run")
+        return nl
+
     def run_iteration(self, prefetch: bool = False):
         """One pass of the loop body of trainer.py:176-182; returns the result dict including fps.
 
@@ -421,6 +440,9 @@ class Trainer:
         next launch.  A rollout issued ahead is consumed by the next call (whatever its ``prefetch``), or booked into the replay by ``final()``."""
         if self.use_lp:
             return self.run_iteration_lp()
+        nl = self._native_loop()
+        if nl is not None:
+            return nl.run_iteration(prefetch)
         tic = time.time()
         # Same work in the same stream order as ``step(*actor.sample(eps))`` — the update block's kernels are ordered behind the rollout's — but
         # the host does not stop between them: the rollout's statistics (episode returns, per-step max-Q: one small read-back) are collected
@@ -465,6 +487,8 @@ class Trainer:
         if self.use_lp and self._pending is not None:
             self.actors[1].sample_finish(self._pending)      # drain the rollout still in flight
             self._pending = None
+        if getattr(self, "_nl", None):
+            self._nl.drain()
         if getattr(self, "_prefetched", None) is not None:   # a rollout issued ahead by run_iteration(prefetch=True) and never consumed: book it, so that replay and counters agree with the device
             pending, self._prefetched = self._prefetched, None
             transitions, returns, qmax = self.actors[1].sample_finish(pending)
@@ -481,6 +505,9 @@ class Trainer:
                     self.save_checkpoint(os.path.join(self.cfg.logdir, "final.pth"))
                 except OSError:
                     pass
+        if getattr(self, "_nl", None):
+            self._nl.close()
+            self._nl = False
         for actor in self.actors:
             if actor is not None:
                 actor.close()

@@ -386,6 +386,8 @@ def main():
                                "RCCL grad all-reduce" + ("" if world > 1 else " (one-rank group: rehearsal)" if dp else " (inactive at 1 GPU)")),
                    "learner_steps": cfg.learner.learner_steps, "num_envs": cfg.actor.num_envs, "batch_size": cfg.learner.batch_size,
                    "replay_size": cfg.replay.size, "parallelism": (f"replicas{world}" if args.replicas else f"dp{world}"), "entry": f"agent0.deepq.{args.entry}", "rollout_prefetch": bool(ahead and args.entry == "main"),
+                   "host_loop": ("library handles over the Python classes' buffers (deepq/native_loop.py: eager launches from native code)" if getattr(tr, "_nl", None)
+                                 else "Python classes + hipGraphs"),
                    "gradient_exchange": exchange},
         "per_rank_ms_per_step": per_rank, "gradient_exchange": exchange,
         "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),

@@ -291,6 +291,23 @@ typedef struct a0_learner_desc {
     unsigned long long seed;          /* the learner's Philox seed (the Python classes use cfg.seed + 15485863); noise draws only */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
+/* The same handle over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the
+ * parameters — the Python classes' flat tensors, a checkpointing layer — hand the update loop to the library without copies (agent0_amd/deepq/native_loop.py).  Sizes:
+ * online / target / adam_m / adam_v a0_learner_param_floats floats (known from a throw-away handle or deepq/layout.py), grads 4 more, state 8 ints, scalars 4,
+ * loss_ring loss_ring_cap floats (the per-update batch-mean loss lands in slot state[6] % cap), wt_* a0_net_conv_wt_floats(4), eff_* the composed NoisyNet weights
+ * [fc1 | head] and noise [online | target] the noise vectors (layout: a0_learner_desc above).  Borrowed buffers are used as they are: no initial noise is drawn into a
+ * borrowed `noise` (a0_learner_set_rng tells the handle where the caller's stream stands). */
+typedef struct a0_learner_buffers {
+    float *online, *target, *grads, *adam_m, *adam_v;
+    int* state;
+    float* scalars;
+    float* loss_ring; int loss_ring_cap;
+    float *wt_online, *wt_target;
+    float *eff_online, *eff_target, *noise;
+} a0_learner_buffers;
+int a0_learner_create_on(const a0_learner_desc* desc, const a0_learner_buffers* buffers, a0_learner** out);
+/* the next draw offset of one of the learner's Philox streams (4 = NoisyNet noise) */
+int a0_learner_set_rng(a0_learner* learner, int stream_id, unsigned long long offset);
 int a0_learner_destroy(a0_learner* learner);
 long long a0_learner_param_floats(const a0_learner* learner);
 /* parameters in the packed layout (device pointers, a0_learner_param_floats floats each); target_packed = NULL: target = copy of online (agent.py:100) */
@@ -317,6 +334,9 @@ typedef struct a0_rbuf_desc {
 } a0_rbuf_desc;
 typedef struct a0_batch { const long long* idx; const int* slot; const int* act; const float* rew; const float* done; const float* prio; const float* weights; } a0_batch;
 int a0_rbuf_create(const a0_rbuf_desc* desc, a0_rbuf** out);
+/* over ring buffers the caller already holds (each may be NULL: library-owned): frames [size * 2 * obs_bytes] u8, act i32 / rew / done f32 [size], tree f32
+ * [2 * 2^ceil(log2 size)] (prioritized), max_p f32 [1] (must hold the caller's current max priority: 1 for an empty ring) */
+int a0_rbuf_create_on(const a0_rbuf_desc* desc, uint8_t* frames, int* act, float* rew, float* done, float* tree, float* max_p, a0_rbuf** out);
 int a0_rbuf_destroy(a0_rbuf* replay);
 long long a0_rbuf_len(const a0_rbuf* replay);
 long long a0_rbuf_write_cursor(const a0_rbuf* replay);
@@ -349,6 +369,10 @@ int a0_actor_destroy(a0_actor* actor);
  * network's noise every reset_noise_freq steps from ITS Philox stream 4 and recomposes the effective weights, agent.py:52-53) */
 int a0_actor_rollout(a0_actor* actor, a0_learner* learner, a0_rbuf* replay, float epsilon, void* stream);
 int a0_actor_collect(a0_actor* actor, float* qs_host, float* returns_host, int max_returns, int* n_returns, void* stream);
+/* a0_actor_collect in two halves, so that the next rollout can be enqueued before the host waits: _begin enqueues the copies of the statistics into page-locked
+ * buffers of the handle and records an event (call it BEFORE the next a0_actor_rollout, which reuses the device buffers); _end waits for that event only */
+int a0_actor_collect_begin(a0_actor* actor, void* stream);
+int a0_actor_collect_end(a0_actor* actor, float* qs_host, float* returns_host, int max_returns, int* n_returns);
 
 /* data parallelism: this rank's NaN flag as a float (1.0 / 0.0) that rides at the tail of a SUM-reduced gradient bucket; the reduced value
  * comes back through extra_nan_flag (nonzero = some rank saw a NaN: every rank skips the step), NULL on one GPU */

@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
+# The suite exercises the Python classes' composition of the per-kernel entry points (what the oracle comparisons walk link by link); the library's own loop over
+# the same buffers (agent0_amd/deepq/native_loop.py, the production default for the configurations it covers) is switched on by the tests that compare it, bit for
+# bit, with that composition (tests/test_gpu_trainer.py::test_native_loop_*).
+os.environ.setdefault("A0_NATIVE_LOOP", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 

@@ -705,6 +705,50 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     lib.a0_actor_destroy(ac); lib.a0_rbuf_destroy(rb); nat.close()
 
 
+@pytest.mark.parametrize("algo,extra", [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
+                                        ("c51", {"env_task": "block"}), ("c51", RAINBOW), ("c51", {**RAINBOW, "learner.reset_noise_freq": 3, "env_task": "block"})],
+                         ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block"])
+def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
+    """agent0_amd/deepq/native_loop.py: for the configurations the handles cover, ``Trainer.run_iteration`` hands the loop to a0_actor / a0_rbuf / a0_learner created
+    OVER the Python classes' own buffers (a0_learner_create_on / a0_rbuf_create_on) — one C call per rollout, batch and update, eager launches from native code.
+    The same launches in the same order: after ten iterations (with and without the next rollout issued ahead, ring wrap, target syncs, a rollout booked by
+    final()) every statistic, the parameters, the target, the Adam moments, the status words, the replay ring, the sum-tree, max_p and beta must be BIT-identical
+    to the run of the Python classes — and the Python views (``state_dict()``, ``len(replay)``, ``replay.tree``) must show the live data without a copy."""
+    from agent0_amd.deepq.native_loop import NativeLoop
+    from agent0_amd.deepq.trainer import Trainer
+
+    def run(native):
+        monkeypatch.setenv("A0_NATIVE_LOOP", "1" if native else "0")
+        cfg = make_cfg(algo, 8, **{"actor.sample_steps": 12, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 5, "trainer.training_start_steps": 100,
+                                    "learner.target_update_freq": 7, "trainer.exploration_steps": 600, **extra})
+        tr = Trainer(cfg)
+        res = []
+        for i in range(10):
+            res.append({k: v for k, v in tr.run_iteration(prefetch=(i % 3 != 1)).items() if k != "fps"})
+        assert isinstance(tr._nl, NativeLoop) if native else tr._nl is False, getattr(tr, "native_loop_reason", None)
+        sd = {k: v.clone() for k, v in tr.learner.model.state_dict().items()}
+        eng, rp = tr.learner.engine, tr.replay
+        n_len = len(rp)
+        tree = rp.tree.clone() if rp.prioritize else torch.zeros(1)
+        out = (res, list(tr.Ls), list(tr.Qs), list(tr.Rs), tr.frame_count, n_len, rp.written, float(rp.beta) if rp.prioritize else 0.0, rp.max_p if rp.prioritize else 1.0,
+               eng.online.flat.clone(), eng.target.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.state.clone(), rp.frames.clone(), rp.act.clone(), rp.rew.clone(),
+               rp.done.clone(), tree, sd)
+        tr.test = lambda: None
+        tr.final(save=False)                       # books the rollout issued ahead, closes the handles
+        return out + (tr.frame_count, list(tr.Qs), len(rp))
+
+    a = run(False)
+    b = run(True)
+    assert len(a[1]) == 9 * 5 and a[4] == 10 * 96
+    for i, (x, y) in enumerate(zip(a, b)):
+        if isinstance(x, torch.Tensor):
+            assert torch.equal(x, y), f"item {i}"
+        elif isinstance(x, dict):
+            assert x.keys() == y.keys() and all(torch.equal(x[k], y[k]) for k in x), f"item {i}: state_dict()"
+        else:
+            assert x == y, f"item {i}"
+
+
 def _rbuf_frames(lib, rb):
     import ctypes as C
     p = C.c_void_p()
