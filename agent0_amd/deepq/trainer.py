@@ -426,6 +426,8 @@ class Trainer:
                 self.native_loop_reason = why or "hot-loop methods wrapped, a gradient hook, or a run already under way"
                 return None
             nl = self._nl = native_loop.NativeLoop(self)
+            if self.primary:
+                self.logger.info("host loop: library handles over this Trainer's buffers (agent0_amd/deepq/native_loop.py); A0_NATIVE_LOOP=0 keeps the Python classes in charge")
         elif not ok_now:
             raise RuntimeError("Trainer: a gradient hook or a method wrapper was installed after the native loop had taken over the run")
         return nl

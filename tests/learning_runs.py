@@ -71,11 +71,14 @@ def run(algo: str, extra=None, frames: int = 4_000_000, launch: bool = False, E:
                 curve.append((int(res["frames"]), round(rps, 4)))
     wall = time.time() - tic
     assert len(tr.Rs) <= len(lengths)
+    host_loop = "native handles" if getattr(tr, "_nl", None) else "python classes"
+    if getattr(tr, "_nl", None):
+        tr._nl.close()
     for actor in tr.actors:
         if actor is not None:
             actor.close()
     tail = curve[-1][1] if curve else float("nan")
-    return {"algo": algo, "extra": {k: str(v) for k, v in extra.items()}, "schedule": "launch" if launch else "main", "sabotage": sabotage, "frames": iters * T * E,
+    return {"host_loop": host_loop, "algo": algo, "extra": {k: str(v) for k, v in extra.items()}, "schedule": "launch" if launch else "main", "sabotage": sabotage, "frames": iters * T * E,
             "A": int(cfg.action_dim), "min_eps": float(cfg.actor.min_eps), "final_reward_per_step": tail, "loss": None if res["loss"] is None else float(res["loss"]),
             "qmax": None if res["qmax"] is None else float(res["qmax"]), "wall_s": round(wall, 1), "curve": curve}
 

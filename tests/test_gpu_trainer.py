@@ -461,7 +461,8 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
                                            f"again {line2['value']:.0f} vs {plain2['value']:.0f}")
 
 
-def test_main_entry_point_at_baseline_config0_sizes(tmp_path):
+@pytest.mark.parametrize("native", ["0", "1"], ids=["python-classes", "native-loop"])
+def test_main_entry_point_at_baseline_config0_sizes(tmp_path, native):
     """BASELINE configs[0] — "Breakout dqn, agent0.deepq.main, 16 envs, 100k replay" — as a child process through the reference's entry point
     with the reference's default sizes (config.py:108-120: 16 envs x 80 steps, batch 512, 20 updates per iteration, replay 100 000) on the
     GPU (``device=cpu`` raises by design: there is no CPU product path); only ``training_start_steps`` and ``total_steps`` are lowered so that
@@ -476,6 +477,7 @@ def test_main_entry_point_at_baseline_config0_sizes(tmp_path):
     cmd = [sys.executable, "-m", "agent0.deepq.main", "env_id=Breakout", "learner.algo=dqn", "actor.num_envs=16", "replay.size=100000",
            "trainer.training_start_steps=5000", "trainer.total_steps=40000", "trainer.test_episodes=4", "device=cuda", "wandb=false", "tb=false", f"logdir={logdir}"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["A0_NATIVE_LOOP"] = native       # "1": the loop issued by the library's handles over the Trainer's buffers (the default outside this suite)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     runs = glob.glob(os.path.join(logdir, "*-Breakout-dqn-42-*"))
@@ -489,6 +491,7 @@ def test_main_entry_point_at_baseline_config0_sizes(tmp_path):
     assert any(x["return_train"] != "" for x in rows) and all(x["qmax"] != "" for x in rows)
     log = open(os.path.join(runs[0], "msg.log")).read()
     assert "TEST --->" in log and "nan" not in log.lower()
+    assert ("host loop: library handles" in log) == (native == "1")
     ck = torch.load(os.path.join(runs[0], "final.pth"), map_location="cpu", weights_only=True)
     assert int(ck["state"][1]) == (32 - first_loss) * 20 and int(ck["frame_count"]) == 32 * 1280, "20 updates per iteration (learner_steps, config.py:112)"
     assert ck["model"]["encoder.convs.0.weight"].shape == (32, 4, 8, 8) and ck["model"]["head.q_head.weight"].shape == (4, 512)
