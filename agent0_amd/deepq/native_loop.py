@@ -1,9 +1,9 @@
 """The actor -> replay -> learner loop of ``Trainer.run_iteration`` issued by the library's own handles (``a0_actor`` / ``a0_rbuf`` / ``a0_learner``,
 csrc/runtime.hip + learner.hip) instead of by Python: one C call per rollout, per batch, per update.
 
-Why: the launches of a rollout (240) and of an update block (20 x ~16) cost a fast native host ~2 us each and are issued back to back; replayed from hipGraphs by
-the Python classes they run 2.4 % (BASELINE configs[1]) to 5 % (configs[2]) slower on the same box (profiles/r04_experiments.md), and issued one by one from Python
-much slower than that.  The handles are created OVER the buffers the Python classes already hold (``a0_learner_create_on`` / ``a0_rbuf_create_on``): parameters,
+Why: the launches of a rollout (240) and of an update block (20 x ~16) cost a fast native host ~2 us each and are issued back to back — no graph capture, no warm-up
+runs, no graph cache, and 0 - 0.8 % faster than replaying them from hipGraphs (alternating same-box runs, profiles/r04_experiments.md); issued one by one from Python
+they would be much slower than either.  The handles are created OVER the buffers the Python classes already hold (``a0_learner_create_on`` / ``a0_rbuf_create_on``): parameters,
 target, Adam moments, status words, loss ring, weight copies, NoisyNet buffers, replay ring, sum-tree — so ``state_dict()``, checkpoints, the test actor and every
 reader of ``trainer.replay`` keep seeing the live data, with no copies in either direction.  What the handles own themselves: the actor's env state and Philox
 offsets, the sampler's state (epochs / beta), the workspaces.
