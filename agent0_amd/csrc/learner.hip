@@ -156,6 +156,12 @@ extern "C" int a0_learner_set_params(a0_learner* L, const float* online_packed, 
     A0_CATCH
 }
 
+extern "C" int a0_learner_loss_buffer(const a0_learner* L, float** loss_dev) {
+    if (!L || !loss_dev) return a0_fail(A0_EINVAL, "a0_learner_loss_buffer: null argument");
+    *loss_dev = L->loss;
+    return A0_OK;
+}
+
 extern "C" int a0_learner_set_support(a0_learner* L, const float* atoms_host) {
     A0_TRY
     if (!L || !atoms_host || !L->atoms) return a0_fail(A0_EINVAL, "a0_learner_set_support: a c51 handle and a host array of num_atoms floats");

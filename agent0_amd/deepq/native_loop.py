@@ -123,7 +123,9 @@ class NativeLoop:
                         {"stream": 0, "block": 1}[cfg.env_task], int(lc.reset_noise_freq))
         self.actor = C.c_void_p()
         ok(lib.a0_actor_create(C.addressof(ad), C.addressof(self.actor)), "a0_actor_create")
-        self.loss_dev = ops.empty(self.B)
+        lp = C.c_void_p()
+        ok(lib.a0_learner_loss_buffer(self.learner, C.addressof(lp)), "a0_learner_loss_buffer")
+        self.loss_ptr = lp                                # the learner's own per-sample losses: update_priority reads them in place
         self._qs, self._rs, self._nret = (C.c_float * self.T)(), (C.c_float * (self.T * self.E))(), C.c_int()
         self._pending_rollout = False
         self.frames_ptr = p(rp.frames)
@@ -156,9 +158,9 @@ class NativeLoop:
         n = int(cfg.learner.learner_steps)
         for _ in range(n):
             ok(lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
-            ok(lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, self.loss_dev.data_ptr(), st), "a0_learner_update")
+            ok(lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, None, st), "a0_learner_update")
             if self.prio:
-                ok(lib.a0_rbuf_update_priority(self.rbuf, self.loss_dev.data_ptr(), eng.state.data_ptr(), st), "a0_rbuf_update_priority")
+                ok(lib.a0_rbuf_update_priority(self.rbuf, self.loss_ptr, eng.state.data_ptr(), st), "a0_rbuf_update_priority")
         tr._ring0 = ln.updates_issued                     # the Adam launch wrote the block's batch-mean losses to ring slots ring0 .. ring0 + n - 1
         ln.updates_issued += n
         if self.prio:

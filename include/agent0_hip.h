@@ -314,6 +314,9 @@ long long a0_learner_param_floats(const a0_learner* learner);
 int a0_learner_set_params(a0_learner* learner, const float* online_packed, const float* target_packed, void* stream);
 /* copies of what the handle holds (any pointer may be NULL): parameters, target parameters, Adam moments (param_floats each), the eight status words */
 int a0_learner_get(const a0_learner* learner, float* online_out, float* target_out, float* adam_m_out, float* adam_v_out, int* state_out8, void* stream);
+/* the handle's own buffer of per-sample losses [B] of the last update (device pointer, valid for the handle's lifetime): what a0_rbuf_update_priority takes without
+ * the copy a non-NULL loss_out of a0_learner_update costs */
+int a0_learner_loss_buffer(const a0_learner* learner, float** loss_dev);
 /* c51: the support atoms [num_atoms] from HOST memory, for a caller that holds the exact values its reference run used (default: linspace in fp32, torch's formula) */
 int a0_learner_set_support(a0_learner* learner, const float* atoms_host);
 /* frames: u8 replay rows st || st_next of row_bytes bytes, read through slot [B] (ring slots of the sampled batch; NULL = rows 0 .. B-1); act int32, rew / done /

@@ -36,7 +36,8 @@ int main(int argc, char** argv) {
     unsigned seed = 7u;
     for (long long i = 0; i < n; ++i) hp[i] = ((float)(lcg(&seed) % 2001) - 1000.0f) * 2e-5f;
     float* dp = NULL; float* dloss = NULL;
-    HIP(hipMalloc((void**)&dp, (size_t)n * 4)); HIP(hipMalloc((void**)&dloss, B * 4));
+    HIP(hipMalloc((void**)&dp, (size_t)n * 4));
+    CHECK(a0_learner_loss_buffer(L, &dloss));
     HIP(hipMemcpy(dp, hp, (size_t)n * 4, hipMemcpyHostToDevice));
     CHECK(a0_learner_set_params(L, dp, NULL, NULL));
     uint8_t* ring = NULL;
@@ -56,8 +57,8 @@ int main(int argc, char** argv) {
             for (int u = 0; u < LSTEPS; ++u) {
                 a0_batch b;
                 CHECK(a0_rbuf_sample(R, &b, NULL));
-                CHECK(a0_learner_update(L, ring, b.slot, 2LL * OBS, b.act, b.rew, b.done, b.weights, dloss, NULL));
-                CHECK(a0_rbuf_update_priority(R, dloss, NULL, NULL));
+                CHECK(a0_learner_update(L, ring, b.slot, 2LL * OBS, b.act, b.rew, b.done, b.weights, NULL, NULL));
+                CHECK(a0_rbuf_update_priority(R, dloss, NULL, NULL));      /* the learner's own loss buffer: no copy */
                 ++updates;
             }
         }
