@@ -160,8 +160,8 @@ template <class OA, class OB, int WM, int WN, int MT, int NT, int KS = 2> struct
 };
 
 template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
-__global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::Params pa, typename OB::Params pb,
-                                                           typename EP::Params pe, int X, int Y, int K, int kchunk, int gx, int gy) {
+__device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, const typename OB::Params& pb,
+                                                 const typename EP::Params& pe, int X, int Y, int K, int kchunk, int gx, int gy) {
     static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
     static_assert(KS == 1 || KS == 2, "tiles of 16 or 32 k");
     typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
@@ -322,6 +322,42 @@ __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::
                 if (x < X && y < Y) EP::store(pe, x, y, acc[i][j][r], z);
             }
         }
+}
+
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
+__global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::Params pa, typename OB::Params pb,
+                                                           typename EP::Params pe, int X, int Y, int K, int kchunk, int gx, int gy) {
+    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS>(pa, pb, pe, X, Y, K, kchunk, gx, gy);
+}
+
+// Up to three GEMMs of ONE shape (own operands and outputs each) in one launch: blockIdx.y names the problem.  The point is not the launch it saves but the split: a
+// 512-row fc1 pass alone needs K cut eight ways to fill 256 CUs, and the ~10 us of ramp, prologue and slab epilogue then weigh as much as its k loop; two or three
+// passes side by side fill the chip with half or a third of the splits — each workgroup's k loop is two or three times as long, the fixed part is paid once
+// (the learner's target / online fc1 passes of one update: 2 x 17.1 us -> one launch; and the consumer sums half as many slabs).
+template <class OA, class OB, class EP> struct a0_x9_group { typename OA::Params pa[3]; typename OB::Params pb[3]; typename EP::Params pe[3]; };
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
+__global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_group_kernel(a0_x9_group<OA, OB, EP> G, int X, int Y, int K, int kchunk, int gx, int gy) {
+    const int g = blockIdx.y;
+    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS>(G.pa[g], G.pb[g], G.pe[g], X, Y, K, kchunk, gx, gy);
+}
+
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
+static inline hipError_t a0_igemm_x9_group_launch(hipStream_t st, int n, const a0_x9_group<OA, OB, EP>& grp, int X, int Y, int K, int splits) {
+    typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
+    auto kern = a0_igemm_x9_group_kernel<OA, OB, EP, WM, WN, MT, NT, KS>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    if (splits < 1) splits = 1;
+    constexpr int BK = 16 * KS;
+    const int ktiles = (K + BK - 1) / BK;
+    const int kchunk = ((ktiles + splits - 1) / splits) * BK;
+    const int gx = (X + G::BX - 1) / G::BX, gy = (Y + G::BY - 1) / G::BY;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx * gy * splits), (unsigned)n), dim3(WM * WN * 64), G::LDS_BYTES, st, grp, X, Y, K, kchunk, gx, gy);
+    return hipGetLastError();
 }
 
 template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>

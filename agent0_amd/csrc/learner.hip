@@ -253,11 +253,20 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
     passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
     A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
-    A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, tg + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[1], stream));
-    if (dq) A0_CHECK(a0_dense_fwd_partial(L->act3_s, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[2], stream));
-    A0_CHECK(a0_dense_fwd_partial(L->act3_o, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[0], stream));
+    int ns = L->ns_fc1;
+    const int n_fc1 = dq ? 3 : 2;
+    if (a0_dense_fwd_partial_multi_ok(n_fc1, B, 512, L->feat)) {      // the passes' fc1 GEMMs as one launch (fewer, deeper splits each)
+        const float* Xs[3] = {L->act3_o, L->act3_t, L->act3_s};
+        const float* Ws[3] = {on + L->fc1.w(), tg + L->fc1.w(), on + L->fc1.w()};
+        A0_CHECK(a0_dense_fwd_partial_multi(n_fc1, Xs, L->feat, Ws, B, 512, L->feat, L->fc1_slabs, stream));
+        ns = a0_dense_fwd_partial_multi_slabs(n_fc1, B, 512, L->feat);
+    } else {
+        A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, tg + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[1], stream));
+        if (dq) A0_CHECK(a0_dense_fwd_partial(L->act3_s, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[2], stream));
+        A0_CHECK(a0_dense_fwd_partial(L->act3_o, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[0], stream));
+    }
     // ---- heads of both networks, dueling, argmax, Huber loss, head gradient and the head's backward-data pass in one launch (agent.py:173-190)
-    A0_CHECK(a0_dqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], dq ? L->fc1_slabs[2] : nullptr, (long long)B * 512, L->ns_fc1, on + L->fc1.b(), tg + L->fc1.b(), L->h,
+    A0_CHECK(a0_dqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], dq ? L->fc1_slabs[2] : nullptr, (long long)B * 512, ns, on + L->fc1.b(), tg + L->fc1.b(), L->h,
                                     on + L->head.w(), on + L->head.b(), tg + L->head.w(), tg + L->head.b(), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, B,
                                     L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
     }

@@ -490,6 +490,43 @@ extern "C" int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int
     A0_CATCH
 }
 
+// n = 2 or 3 passes of one dense layer shape — X[i] [R][ldx] x W[i]^T [N][K] -> slabs[i] [splits][R][N] — as ONE launch (a0_igemm_x9_group_kernel): the chip is
+// filled with a half / a third of the splits a single pass needs, so every workgroup's k loop is that much longer and the fixed cost of a launch is paid once.  The
+// slabs differ from a0_dense_fwd_partial's (fewer, deeper partial sums: another association of the same fp32 additions); a0_dense_fwd_partial_multi_slabs tells the
+// consumer how many there are.  Split-operand GEMM mode only.
+static int a0_fwd_multi_splits(int n, int R, int N, int K) {
+    const int blocks = n * ((R + 127) / 128) * ((N + 63) / 64);
+    int splits = blocks < 256 ? 256 / blocks : 1;
+    const int maxs = (K / 32) / 2;
+    if (splits > maxs) splits = maxs;
+    return splits < 1 ? 1 : splits;
+}
+extern "C" int a0_dense_fwd_partial_multi_ok(int n, int R, int N, int K) {
+    static const bool off = getenv("A0_NO_FWD_MULTI") != nullptr;       // tuning aid
+    return (!off && g_gemm_x9 != 0 && (n == 2 || n == 3) && R >= 257 && R <= 4096 && N > 32 && !(N & 3) && !(K & 3)) ? 1 : 0;
+}
+extern "C" int a0_dense_fwd_partial_multi_slabs(int n, int R, int N, int K) { return a0_fwd_multi_splits(n, R, N, K); }
+
+extern "C" int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx, const float* const* W, int R, int N, int K, float* const* slabs, void* stream) {
+    A0_TRY
+    if (!X || !W || !slabs || (ldx & 3) || !a0_dense_fwd_partial_multi_ok(n, R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_fwd_partial_multi: shapes a0_dense_fwd_partial_multi_ok accepts");
+    a0_x9_group<OpMatKC, OpMatKC, EpiSlab> grp;
+    for (int i = 0; i < 3; ++i) {
+        const int j = i < n ? i : 0;
+        if (!X[j] || !W[j] || !slabs[j]) return a0_fail(A0_EINVAL, "a0_dense_fwd_partial_multi: null operand");
+        grp.pa[i] = a0_mat_src{X[j], ldx};
+        grp.pb[i] = a0_mat_src{W[j], K};
+        grp.pe[i] = EpiSlab::Params{slabs[j], (long long)R * N, N};
+    }
+    const int splits = a0_fwd_multi_splits(n, R, N, K);
+    const bool probe = g_probe.tag != 0 && g_probe.tag == A0_TAG_DENSE_FWD && g_probe.used + 2 <= g_probe.ev.size();
+    if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], (hipStream_t)stream));
+    A0_HIP_THROW((a0_igemm_x9_group_launch<OpMatKC, OpMatKC, EpiSlab, 4, 2, 1, 1>((hipStream_t)stream, n, grp, R, N, K, splits)));      // 128 x 64 tiles, eight waves
+    if (probe) { A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], (hipStream_t)stream)); g_probe.used += 2; g_probe.flops += 2.0 * n * (double)R * (double)N * (double)K; }
+    return A0_OK;
+    A0_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ fused actor tail (dqn / mdqn)
 // Everything between the conv features and the chosen action of Actor.act (reference agent.py:25-39 with model.py:108-131 behind
 // it), for scalar-valued heads: fc1 runs as the usual split-K implicit GEMM, but its slabs are consumed directly by ONE kernel that

@@ -550,13 +550,19 @@ class DeviceLearner:
             (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
             s_tg = self._fc1_slabs[1]
             self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if self.double_q else []) + [(on, wo, 0, True)])
-            if tstage is None:
-                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+            n_fc1 = 3 if self.double_q else 2
+            if tstage is None and hasattr(ops, "dense_fwd_partial_multi") and ops.dense_fwd_partial_multi_ok(n_fc1, B, 512, L.feat):
+                # the passes' fc1 GEMMs as ONE launch: together they fill the chip with a half / a third of the splits each would need alone
+                ns = ops.dense_fwd_partial_multi([wo.act3, wt.act3] + ([wsel.act3] if self.double_q else []), L.feat, [Wf_o, Wf_t] + ([Wf_o] if self.double_q else []),
+                                                 B, 512, L.feat, self._fc1_slabs[:n_fc1])
             else:
-                s_tg = self._tstage_buf(tstage)[1]
-            if self.double_q:
-                ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
-            ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
+                if tstage is None:
+                    ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+                else:
+                    s_tg = self._tstage_buf(tstage)[1]
+                if self.double_q:
+                    ops.dense_fwd_partial(wsel.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[2])
+                ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
             ops.dqn_head_loss_slabs(self._fc1_slabs[0], s_tg, self._fc1_slabs[2] if self.double_q else None, ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt,
                                     L.A, L.dueling, L.Npad, act, rew, done, wgt, self.gamma_n, B, self.loss, wo.q, wt.q, wo.draw, self.state, wo.dh)
             have_dh = True           # ... and the head's backward-data pass: dh is written by the same kernel

@@ -451,6 +451,18 @@ class HipOps:
                                             _req(slabs, torch.float32, ns * R * N, "slabs"), _stream()), "a0_dense_fwd_partial")
         return ns
 
+    def dense_fwd_partial_multi_ok(self, n, R, N, K) -> bool:
+        return bool(self.lib.a0_dense_fwd_partial_multi_ok(n, R, N, K))
+
+    def dense_fwd_partial_multi(self, Xs, ldx, Ws, R, N, K, slabs):
+        """n = 2 or 3 passes of one layer shape in one launch (a0_dense_fwd_partial_multi); returns the slab count every pass leaves."""
+        n = len(Xs)
+        ns = int(self.lib.a0_dense_fwd_partial_multi_slabs(n, R, N, K))
+        PP = C.c_void_p * n
+        check(self.lib.a0_dense_fwd_partial_multi(n, PP(*[_req(x, torch.float32, (R - 1) * ldx + K, "X") for x in Xs]), ldx, PP(*[_req(w, torch.float32, N * K, "W") for w in Ws]),
+                                                  R, N, K, PP(*[_req(sl, torch.float32, ns * R * N, "slabs") for sl in slabs]), _stream()), "a0_dense_fwd_partial_multi")
+        return ns
+
     def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
                             draw, state, dh=None):
         nq = A + (1 if dueling else 0)

@@ -141,6 +141,12 @@ int a0_dense_fwd_mul_keep(const float* X, int ldx, const float* W, const float* 
  * a0_dense_fwd_partial_slabs(R, N, K) slabs in order, adds the bias and applies the activation (a0_dqn_head_loss_slabs) */
 int a0_dense_fwd_partial_slabs(int R, int N, int K);
 int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int R, int N, int K, float* slabs, void* stream);
+/* (round 4) n = 2 or 3 passes of ONE layer shape with their own inputs, weights and slab buffers — the target / online fc1 passes of an update (agent.py:176-181) — in one
+ * launch: fewer, deeper splits per pass (a0_dense_fwd_partial_multi_slabs of them; the partial sums associate differently from a0_dense_fwd_partial's) because the passes
+ * fill the chip together.  Host arrays of device pointers; shapes: a0_dense_fwd_partial_multi_ok */
+int a0_dense_fwd_partial_multi_ok(int n, int R, int N, int K);
+int a0_dense_fwd_partial_multi_slabs(int n, int R, int N, int K);
+int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx, const float* const* W, int R, int N, int K, float* const* slabs, void* stream);
 /* The reduction a0_dense_fwd performs behind its split-K GEMM, for up to four layers of the same width N in ONE launch: out[i] = act(sum_z slabs[i][z] + bias[i])
  * (slabs added in slab order: bit-identical to a0_dense_fwd).  The three fc1 passes of a distributional update (agent.py:219-231: online on s, online on s',
  * target on s') finish in one launch instead of three.  Host arrays of n entries; every buffer 16-byte aligned, slab strides multiples of 4 floats. */

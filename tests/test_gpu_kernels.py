@@ -351,6 +351,32 @@ def test_noisy_multi_equals_per_module_kernels(hip):
         assert torch.equal(eff_a, eff_b) and torch.equal(gs_a, gs_b)
 
 
+@pytest.mark.parametrize("n,R", [(2, 512), (3, 512), (2, 300), (3, 1024)])
+def test_grouped_fc1_passes_equal_the_separate_gemms(hip, n, R):
+    """a0_dense_fwd_partial_multi (round 4): two or three passes of one layer shape — own inputs, weights, slab buffers — as ONE launch with a half / a third of the splits
+    each pass would take alone.  Every product is still exact (three bf16 terms per operand, nine cross products, fp32 accumulation); only the association of the
+    partial sums changes with the split.  Checked: the slab sums of every pass against an fp64 GEMM (fp32-accumulation accuracy) and against the single-pass
+    kernel's (a few ulp of the accumulated magnitude), no cross-talk between the passes, ragged row counts."""
+    N, K = 512, 3136
+    assert hip.dense_fwd_partial_multi_ok(n, R, N, K)
+    g = recipe.gen(n * R)
+    Xs = [D(hip, g.standard_normal((R, K)).astype(np.float32)) for _ in range(n)]
+    Ws = [D(hip, (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)) for _ in range(n)]
+    ns1 = hip.dense_fwd_partial_slabs(R, N, K)
+    slabs = [hip.empty(ns1 * R * N).fill_(float("nan")) for _ in range(n)]
+    ns = hip.dense_fwd_partial_multi(Xs, K, Ws, R, N, K, slabs)
+    assert 1 <= ns < ns1, "fewer, deeper splits than a pass on its own"
+    for i in range(n):
+        got = slabs[i][: ns * R * N].view(ns, R, N).double().sum(0)
+        want = Xs[i].double() @ Ws[i].double().t()
+        ref = hip.empty(ns1 * R * N)
+        hip.dense_fwd_partial(Xs[i], K, Ws[i], R, N, K, ref)
+        single = ref.view(ns1, R, N).double().sum(0)
+        err, err1 = float((got - want).abs().max()), float((single - want).abs().max())
+        assert err < 2e-5 and err < 4 * err1 + 1e-6, f"pass {i}: {err} against fp64 (single-pass kernel: {err1})"
+        assert torch.isfinite(slabs[i][: ns * R * N]).all() and (ns == ns1 or torch.isnan(slabs[i][ns * R * N:]).all())
+
+
 def test_sumtree_sample_batch_equals_separate_kernels(hip):
     """a0_sumtree_sample_batch (draws + descent + lookup + importance weights, one launch) against a0_rng_uniform + a0_sumtree_sample +
     a0_replay_lookup + a0_is_weights: identical indices, slots, metadata, priorities and weights."""
