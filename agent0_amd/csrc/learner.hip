@@ -228,19 +228,42 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
         passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
         A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
-        A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, L->Wf(true), B, 512, L->feat, L->fc1_tg, stream));
-        A0_CHECK(a0_dense_fwd_partial(L->act3_on, L->feat, L->Wf(false), L->R_on, 512, L->feat, L->fc1_on, stream));
+        // the passes (online on s, online on s' under double-Q, target on s') are GEMMs of one shape each for fc1 and for the head: one grouped launch per layer, the
+        // online passes' rows interleaved into the [splits][R_on][N] buffers the reduction and the loss kernel read
+        const int npass = dq ? 3 : 2;
+        int ns_on = L->ns_on, ns_tg = L->ns_fc1, nh_on = L->nh_on, nh_tg = L->nh_tg;
+        const bool grouped = a0_dense_fwd_partial_multi_ok(npass, B, 512, L->feat) && a0_dense_fwd_partial_multi_ok(npass, B, L->Npad, 512);
+        if (grouped) {
+            const float* Xs[3] = {L->act3_on, dq ? L->act3_s : L->act3_t, L->act3_t};
+            const float* Ws[3] = {L->Wf(false), dq ? L->Wf(false) : L->Wf(true), L->Wf(true)};
+            float* sl[3] = {L->fc1_on, dq ? L->fc1_on + (long long)B * 512 : L->fc1_tg, L->fc1_tg};
+            const long long st[3] = {(long long)L->R_on * 512, dq ? (long long)L->R_on * 512 : (long long)B * 512, (long long)B * 512};
+            A0_CHECK(a0_dense_fwd_partial_multi(npass, Xs, L->feat, Ws, B, 512, L->feat, sl, st, stream));
+            ns_on = ns_tg = a0_dense_fwd_partial_multi_slabs(npass, B, 512, L->feat);
+        } else {
+            A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, L->Wf(true), B, 512, L->feat, L->fc1_tg, stream));
+            A0_CHECK(a0_dense_fwd_partial(L->act3_on, L->feat, L->Wf(false), L->R_on, 512, L->feat, L->fc1_on, stream));
+        }
         {
             const float* sl[2] = {L->fc1_on, L->fc1_tg};
             const long long st[2] = {(long long)L->R_on * 512, (long long)B * 512};
-            const int ns[2] = {L->ns_on, L->ns_fc1}, rows[2] = {L->R_on, B};
+            const int ns[2] = {ns_on, ns_tg}, rows[2] = {L->R_on, B};
             const float* bias[2] = {L->bf(false), L->bf(true)};
             float* out[2] = {L->h_on, L->h_tg};
             A0_CHECK(a0_reduce_bias_act_multi(2, sl, st, ns, bias, out, rows, 512, 1, stream));
         }
-        A0_CHECK(a0_dense_fwd_partial(L->h_on, 512, L->Wh(false), L->R_on, L->Npad, 512, L->hs_on, stream));
-        A0_CHECK(a0_dense_fwd_partial(L->h_tg, 512, L->Wh(true), B, L->Npad, 512, L->hs_tg, stream));
-        A0_CHECK(a0_c51_head_loss_slabs(L->hs_on, (long long)L->R_on * L->Npad, L->nh_on, L->R_on, L->hs_tg, (long long)B * L->Npad, L->nh_tg, dq ? B : -1, L->bh(false), L->bh(true),
+        if (grouped) {
+            const float* Xs[3] = {L->h_on, dq ? L->h_on + (long long)B * 512 : L->h_tg, L->h_tg};
+            const float* Ws[3] = {L->Wh(false), dq ? L->Wh(false) : L->Wh(true), L->Wh(true)};
+            float* sl[3] = {L->hs_on, dq ? L->hs_on + (long long)B * L->Npad : L->hs_tg, L->hs_tg};
+            const long long st[3] = {(long long)L->R_on * L->Npad, dq ? (long long)L->R_on * L->Npad : (long long)B * L->Npad, (long long)B * L->Npad};
+            A0_CHECK(a0_dense_fwd_partial_multi(npass, Xs, 512, Ws, B, L->Npad, 512, sl, st, stream));
+            nh_on = nh_tg = a0_dense_fwd_partial_multi_slabs(npass, B, L->Npad, 512);
+        } else {
+            A0_CHECK(a0_dense_fwd_partial(L->h_on, 512, L->Wh(false), L->R_on, L->Npad, 512, L->hs_on, stream));
+            A0_CHECK(a0_dense_fwd_partial(L->h_tg, 512, L->Wh(true), B, L->Npad, 512, L->hs_tg, stream));
+        }
+        A0_CHECK(a0_c51_head_loss_slabs(L->hs_on, (long long)L->R_on * L->Npad, nh_on, L->R_on, L->hs_tg, (long long)B * L->Npad, nh_tg, dq ? B : -1, L->bh(false), L->bh(true),
                                         L->Npad, A, L->T, L->d.dueling ? 1 : 0, act, rew, done, wgt, L->atoms, L->gamma_n, (float)L->d.vmin, (float)L->d.vmax, B, L->loss, L->draw,
                                         L->q_o, L->q_t, L->m_proj, L->a_star, L->state, stream));
         // the head's data gradient (the scalar-head kernel above folds it in; the distributional one does not)
@@ -258,7 +281,7 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     if (a0_dense_fwd_partial_multi_ok(n_fc1, B, 512, L->feat)) {      // the passes' fc1 GEMMs as one launch (fewer, deeper splits each)
         const float* Xs[3] = {L->act3_o, L->act3_t, L->act3_s};
         const float* Ws[3] = {on + L->fc1.w(), tg + L->fc1.w(), on + L->fc1.w()};
-        A0_CHECK(a0_dense_fwd_partial_multi(n_fc1, Xs, L->feat, Ws, B, 512, L->feat, L->fc1_slabs, stream));
+        A0_CHECK(a0_dense_fwd_partial_multi(n_fc1, Xs, L->feat, Ws, B, 512, L->feat, L->fc1_slabs, nullptr, stream));
         ns = a0_dense_fwd_partial_multi_slabs(n_fc1, B, 512, L->feat);
     } else {
         A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, tg + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[1], stream));

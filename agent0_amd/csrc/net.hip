@@ -507,7 +507,8 @@ extern "C" int a0_dense_fwd_partial_multi_ok(int n, int R, int N, int K) {
 }
 extern "C" int a0_dense_fwd_partial_multi_slabs(int n, int R, int N, int K) { return a0_fwd_multi_splits(n, R, N, K); }
 
-extern "C" int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx, const float* const* W, int R, int N, int K, float* const* slabs, void* stream) {
+extern "C" int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx, const float* const* W, int R, int N, int K, float* const* slabs, const long long* slab_stride,
+                                          void* stream) {
     A0_TRY
     if (!X || !W || !slabs || (ldx & 3) || !a0_dense_fwd_partial_multi_ok(n, R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_fwd_partial_multi: shapes a0_dense_fwd_partial_multi_ok accepts");
     a0_x9_group<OpMatKC, OpMatKC, EpiSlab> grp;
@@ -516,7 +517,10 @@ extern "C" int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx,
         if (!X[j] || !W[j] || !slabs[j]) return a0_fail(A0_EINVAL, "a0_dense_fwd_partial_multi: null operand");
         grp.pa[i] = a0_mat_src{X[j], ldx};
         grp.pb[i] = a0_mat_src{W[j], K};
-        grp.pe[i] = EpiSlab::Params{slabs[j], (long long)R * N, N};
+        // slab_stride (optional): floats between a pass's consecutive slabs — two passes may interleave their rows in one buffer [splits][2R][N] (stride 2 R N, bases R N apart)
+        const long long stride = slab_stride ? slab_stride[j] : (long long)R * N;
+        if (stride < (long long)R * N || (stride & 3)) return a0_fail(A0_EINVAL, "a0_dense_fwd_partial_multi: slab stride");
+        grp.pe[i] = EpiSlab::Params{slabs[j], stride, N};
     }
     const int splits = a0_fwd_multi_splits(n, R, N, K);
     const bool probe = g_probe.tag != 0 && g_probe.tag == A0_TAG_DENSE_FWD && g_probe.used + 2 <= g_probe.ev.size();

@@ -588,15 +588,34 @@ class DeviceLearner:
             (Wh_o, bh_o), (Wh_t, bh_t) = on.wb("head"), tg.wb("head")
             s_tg = buf["fc1_tg"]
             self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if dq_ else []) + [(on, wo, 0, True)])
-            if tstage is None:
-                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+            npass = 3 if dq_ else 2
+            grouped = (tstage is None and hasattr(ops, "dense_fwd_partial_multi") and ops.dense_fwd_partial_multi_ok(npass, B, 512, L.feat)
+                       and ops.dense_fwd_partial_multi_ok(npass, B, L.Npad, 512))
+            if grouped:
+                # the passes (online on s, online on s' under double-Q, target on s') are GEMMs of one shape each for fc1 and for the head: ONE grouped launch per layer,
+                # the online passes' rows interleaved into the [splits][R_on][N] buffers the reduction and the loss kernel read
+                a3, f1 = buf["act3_on"], buf["fc1_on"]
+                Xs = [a3[: B * L.feat]] + ([a3[B * L.feat:]] if dq_ else []) + [wt.act3]
+                sl = [f1] + ([f1[B * 512:]] if dq_ else []) + [s_tg]
+                st = [R_on * 512] * (npass - 1) + [B * 512]
+                ns_on = ns = ops.dense_fwd_partial_multi(Xs, L.feat, [Wf_o] * (npass - 1) + [Wf_t], B, 512, L.feat, sl, st)
             else:
-                s_tg = self._tstage_buf(tstage)[1]
-            ops.dense_fwd_partial(buf["act3_on"], L.feat, Wf_o, R_on, 512, L.feat, buf["fc1_on"])
+                if tstage is None:
+                    ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+                else:
+                    s_tg = self._tstage_buf(tstage)[1]
+                ops.dense_fwd_partial(buf["act3_on"], L.feat, Wf_o, R_on, 512, L.feat, buf["fc1_on"])
             layers = [(buf["fc1_on"], ns_on, bf_o, buf["h_on"], R_on), (s_tg, ns, bf_t, wt.h, B)]
             ops.reduce_bias_act_multi(layers, 512, True)
-            nh_on = ops.dense_fwd_partial(buf["h_on"], 512, Wh_o, R_on, L.Npad, 512, buf["hs_on"])
-            nh_tg = ops.dense_fwd_partial(wt.h, 512, Wh_t, B, L.Npad, 512, buf["hs_tg"])
+            if grouped:
+                h, hs = buf["h_on"], buf["hs_on"]
+                Xs = [h[: B * 512]] + ([h[B * 512:]] if dq_ else []) + [wt.h]
+                sl = [hs] + ([hs[B * L.Npad:]] if dq_ else []) + [buf["hs_tg"]]
+                st = [R_on * L.Npad] * (npass - 1) + [B * L.Npad]
+                nh_on = nh_tg = ops.dense_fwd_partial_multi(Xs, 512, [Wh_o] * (npass - 1) + [Wh_t], B, L.Npad, 512, sl, st)
+            else:
+                nh_on = ops.dense_fwd_partial(buf["h_on"], 512, Wh_o, R_on, L.Npad, 512, buf["hs_on"])
+                nh_tg = ops.dense_fwd_partial(wt.h, 512, Wh_t, B, L.Npad, 512, buf["hs_tg"])
             ops.c51_head_loss_slabs(buf["hs_on"], nh_on, R_on, buf["hs_tg"], nh_tg, B if dq_ else -1, bh_o, bh_t, L.Npad, L.A, L.T, L.dueling, act, rew, done, wgt,
                                     self.atoms, self.gamma_n, self.vmin, self.vmax, B, self.loss, wo.draw, self.state, q_on=wo.q, q_tg=wt.q, m_out=self.m_proj,
                                     a_star=self.a_star)

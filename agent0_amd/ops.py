@@ -454,13 +454,16 @@ class HipOps:
     def dense_fwd_partial_multi_ok(self, n, R, N, K) -> bool:
         return bool(self.lib.a0_dense_fwd_partial_multi_ok(n, R, N, K))
 
-    def dense_fwd_partial_multi(self, Xs, ldx, Ws, R, N, K, slabs):
-        """n = 2 or 3 passes of one layer shape in one launch (a0_dense_fwd_partial_multi); returns the slab count every pass leaves."""
+    def dense_fwd_partial_multi(self, Xs, ldx, Ws, R, N, K, slabs, strides=None):
+        """n = 2 or 3 passes of one layer shape in one launch (a0_dense_fwd_partial_multi); returns the slab count every pass leaves.  ``strides``: floats between
+        a pass's consecutive slabs (default R * N) — two passes may interleave their rows in one [splits][2R][N] buffer."""
         n = len(Xs)
         ns = int(self.lib.a0_dense_fwd_partial_multi_slabs(n, R, N, K))
         PP = C.c_void_p * n
+        st = None if strides is None else (C.c_longlong * n)(*[int(x) for x in strides])
+        need = [((ns - 1) * (R * N if strides is None else int(strides[i])) + R * N) for i in range(n)]
         check(self.lib.a0_dense_fwd_partial_multi(n, PP(*[_req(x, torch.float32, (R - 1) * ldx + K, "X") for x in Xs]), ldx, PP(*[_req(w, torch.float32, N * K, "W") for w in Ws]),
-                                                  R, N, K, PP(*[_req(sl, torch.float32, ns * R * N, "slabs") for sl in slabs]), _stream()), "a0_dense_fwd_partial_multi")
+                                                  R, N, K, PP(*[_req(sl, torch.float32, need[i], "slabs") for i, sl in enumerate(slabs)]), st, _stream()), "a0_dense_fwd_partial_multi")
         return ns
 
     def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,

@@ -146,7 +146,8 @@ int a0_dense_fwd_partial(const float* X, int ldx, const float* W, int R, int N, 
  * fill the chip together.  Host arrays of device pointers; shapes: a0_dense_fwd_partial_multi_ok */
 int a0_dense_fwd_partial_multi_ok(int n, int R, int N, int K);
 int a0_dense_fwd_partial_multi_slabs(int n, int R, int N, int K);
-int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx, const float* const* W, int R, int N, int K, float* const* slabs, void* stream);
+int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx, const float* const* W, int R, int N, int K, float* const* slabs, const long long* slab_stride,
+                               void* stream);      /* slab_stride (optional, per pass): floats between consecutive slabs, default R * N — passes may share one [splits][2R][N] buffer */
 /* The reduction a0_dense_fwd performs behind its split-K GEMM, for up to four layers of the same width N in ONE launch: out[i] = act(sum_z slabs[i][z] + bias[i])
  * (slabs added in slab order: bit-identical to a0_dense_fwd).  The three fc1 passes of a distributional update (agent.py:219-231: online on s, online on s',
  * target on s') finish in one launch instead of three.  Host arrays of n entries; every buffer 16-byte aligned, slab strides multiples of 4 floats. */
