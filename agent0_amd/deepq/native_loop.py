@@ -202,7 +202,15 @@ class NativeLoop:
             self.tr.Qs.extend(np.ctypeslib.as_array(self._qs).tolist())
             self.tr.Rs.extend(np.ctypeslib.as_array(self._rs)[: self._nret.value].tolist())
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 — interpreter shutdown
+            pass
+
     def close(self):
+        if self.actor is None and self.rbuf is None and self.learner is None:
+            return
         torch.cuda.synchronize()
         for h, fn in ((self.actor, self.lib.a0_actor_destroy), (self.rbuf, self.lib.a0_rbuf_destroy), (self.learner, self.lib.a0_learner_destroy)):
             if h is not None and h.value:

@@ -421,7 +421,7 @@ class Trainer:
         ok_now = self.learner.engine.grad_hook is None and not any(native_loop._wrapped(o) for o in (self, self.replay, self.learner, self.actors[1]))
         if nl is None:
             why = native_loop.eligible(self)
-            if why is not None or not ok_now or getattr(self, "_prefetched", None) is not None or self.frame_count != 0 or self.actors[1].steps != 0:
+            if why is not None or not ok_now or getattr(self, "_prefetched", None) is not None or self.replay.written != 0 or self.actors[1].steps != 0:
                 self._nl = False
                 self.native_loop_reason = why or "hot-loop methods wrapped, a gradient hook, or a run already under way"
                 return None

@@ -752,6 +752,34 @@ def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
             assert x == y, f"item {i}"
 
 
+def test_native_loop_resumes_from_a_checkpoint(tmp_path, monkeypatch):
+    """A run under the native loop saves the reference-keyed checkpoint from the buffers the handles work on (no copy back), and a fresh Trainer that loaded it —
+    frame counter, weights, Adam moments, update counter restored — hands ITS loop to the handles too and continues: epsilon from the restored frame count, the
+    update counter counting on, finite losses."""
+    from agent0_amd.deepq.native_loop import NativeLoop
+    from agent0_amd.deepq.trainer import Trainer
+    monkeypatch.setenv("A0_NATIVE_LOOP", "1")
+    base = {"actor.sample_steps": 10, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 3, "trainer.training_start_steps": 50, "logdir": str(tmp_path / "run"),
+            **RAINBOW}
+    tr = Trainer(make_cfg("c51", 8, **base))
+    for _ in range(4):
+        tr.run_iteration(prefetch=True)
+    assert isinstance(tr._nl, NativeLoop) and tr.learner.update_steps == 12
+    tr.test = lambda: None
+    tr.final(save=False)
+    path = tr.save_checkpoint(str(tmp_path / "ck.pth"))
+    tr2 = Trainer(make_cfg("c51", 8, **{**base, "seed": 7}))
+    tr2.load_checkpoint(path)
+    e1, e2 = tr.learner.engine, tr2.learner.engine
+    assert torch.equal(e1.online.flat, e2.online.flat) and torch.equal(e1.adam_v, e2.adam_v) and tr2.frame_count == tr.frame_count == 5 * 80
+    res = [tr2.run_iteration(prefetch=(i != 2)) for i in range(3)]
+    assert isinstance(tr2._nl, NativeLoop), getattr(tr2, "native_loop_reason", None)
+    assert tr2.learner.update_steps == 12 + 3 * 3, "the update counter counts on from the checkpoint's"
+    assert res[-1]["frames"] == 8 * 80 and np.isfinite(res[-1]["loss"]) and not torch.equal(e1.online.flat, e2.online.flat)
+    tr2.test = lambda: None
+    tr2.final(save=False)
+
+
 def _rbuf_frames(lib, rb):
     import ctypes as C
     p = C.c_void_p()
