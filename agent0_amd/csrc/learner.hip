@@ -26,8 +26,11 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
     const a0_learner_buffers none{};
     const a0_learner_buffers& U = bufs ? *bufs : none;
     if (U.loss_ring && U.loss_ring_cap < 1) return a0_fail(A0_EINVAL, "a0_learner_create_on: loss_ring_cap");
-    if (d->A < 1 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1 || (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51))
+    if (d->A < 1 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1 ||
+        (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51 && d->algo != A0_ALGO_IQN))
         return a0_fail(A0_EINVAL, "a0_learner_create: bad description");
+    if (d->algo == A0_ALGO_IQN && (d->noisy || d->iqn_K < 1 || d->iqn_N < 1 || d->iqn_N_dash < 1 || d->A + (d->dueling ? 1 : 0) > 32))
+        return a0_fail(A0_EINVAL, "a0_learner_create: iqn needs K, N, N' >= 1, no NoisyNet, A + dueling <= 32");
     if (d->algo == A0_ALGO_DQN && (d->A + (d->dueling ? 1 : 0) > 24 || d->noisy))
         return a0_fail(A0_EINVAL, "a0_learner_create: the dqn handle covers scalar heads with A + dueling <= 24 actions without NoisyNet");
     if (d->algo == A0_ALGO_C51 && (d->num_atoms < 2 || d->num_atoms > 64 || !(d->vmax > d->vmin)))
@@ -48,6 +51,8 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         add(L->conv1, 32, L->C * 64); add(L->conv2, 64, 512); add(L->conv3, 64, 576);                                                              // deepq/layout.py
         if (d->noisy) { add(L->fc1, 512, L->feat); add(L->fc1_sigma, 512, L->feat); add(L->head, L->Npad, 512); add(L->head_sigma, L->Npad, 512); }
         else { add(L->fc1, 512, L->feat); add(L->head, L->Npad, 512); }
+        const bool iqn = d->algo == A0_ALGO_IQN;
+        if (iqn) add(L->cos, L->feat, 64);
         L->n_adam = off;
         if (d->noisy) {
             // composed weights [fc1 | head] per network; noise vectors per NoisyLinear module in the reference's module order (first_dense, q_head, value_head), each
@@ -89,13 +94,16 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             L->h = L->alloc<float>((long long)B * 512);
         }
         L->q_o = L->alloc<float>((long long)B * d->A * L->T); L->q_t = L->alloc<float>((long long)B * d->A * L->T);
-        L->draw = L->alloc<float>((long long)B * L->Npad); L->dh = L->alloc<float>((long long)B * 512); L->d3 = L->alloc<float>((long long)B * L->feat);
+        const long long Rg = iqn ? (long long)B * d->iqn_N : (long long)B;           // rows of the differentiated pass
+        L->draw = L->alloc<float>(Rg * L->Npad); L->dh = L->alloc<float>(Rg * 512); L->d3 = L->alloc<float>((long long)B * L->feat);
         L->d2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64); L->d1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->loss = L->alloc<float>(B);
         // one slab scratch for the dense weight gradients (disjoint regions, one reduction launch) and, after them, the encoder's
-        const long long s_head = ceil_to(a0_dense_wgrad_scratch(B, L->Npad, 512), 4), s_fc1 = ceil_to(a0_dense_wgrad_scratch(B, 512, L->feat), 4);
+        const long long s_head = ceil_to(a0_dense_wgrad_scratch((int)Rg, L->Npad, 512), 4), s_fc1 = ceil_to(a0_dense_wgrad_scratch((int)Rg, 512, L->feat), 4);
+        const long long s_cos = iqn ? ceil_to(a0_dense_wgrad_scratch((int)Rg, L->feat, 64), 4) : 0;
         L->slab_off[0] = 0; L->slab_off[1] = s_head;
+        L->slab_off3[0] = 0; L->slab_off3[1] = s_head; L->slab_off3[2] = s_head + s_fc1;
         // (the dense layers' slab reductions ride in the encoder's reduction launch, a0_pending_reduce: the encoder's slabs start behind theirs)
-        L->enc_slab_off = s_head + s_fc1;
+        L->enc_slab_off = s_head + s_fc1 + s_cos;
         const long long n_slab = L->enc_slab_off + a0_net_encoder_bwd_scratch(L->net, B);
         L->slabs = L->alloc<float>(n_slab > 4 ? n_slab : 4);
         if (d->noisy) {
@@ -133,10 +141,51 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             for (int i = 0; i < L->T; ++i) at[(size_t)i] = i < L->T / 2 ? std::fmaf(step, (float)i, lo) : std::fmaf(-step, (float)(L->T - 1 - i), hi);
             A0_HIP_THROW(hipMemcpy(L->atoms, at.data(), (size_t)L->T * 4, hipMemcpyHostToDevice));
         }
+        if (iqn) {
+            const int K = d->iqn_K, N = d->iqn_N, Nd = d->iqn_N_dash;
+            L->rng.init(d->seed, 0);
+            L->a_star = L->alloc<int>(B, true);
+            long long sc = 4;
+            auto ws = [&](a0_learner::QWs& w, int n_tau, float* act3, bool grads) {
+                w.n_tau = n_tau; w.R = (long long)B * n_tau; w.act3 = act3;
+                w.h = L->alloc<float>(w.R * 512); w.raw = L->alloc<float>(w.R * L->Npad); w.q = L->alloc<float>(w.R * d->A);
+                w.cosx = L->alloc<float>(w.R * 64); w.emb = L->alloc<float>(w.R * L->feat); w.x = L->alloc<float>(w.R * L->feat);
+                if (grads) { w.dq = L->alloc<float>(w.R * d->A, true); w.dx = L->alloc<float>(w.R * L->feat); w.demb = L->alloc<float>(w.R * L->feat); }
+                for (int r : {B * K, B * Nd, B * N}) {
+                    if (r > w.R) continue;
+                    const long long a = a0_dense_fwd_scratch(r, L->feat, 64), b2 = a0_dense_fwd_scratch(r, 512, L->feat), c = a0_dense_fwd_scratch(r, L->Npad, 512);
+                    sc = std::max(sc, std::max(a, std::max(b2, c)));
+                }
+            };
+            ws(L->qo, N, L->act3_o, true);
+            ws(L->qt, Nd > K ? Nd : K, L->act3_t, false);
+            if (d->double_q) ws(L->qs, K, L->act3_s, false);
+            L->fwd_scratch = L->alloc<float>(sc);
+            L->t_sel = L->alloc<float>(ceil_to((long long)B * K, 4)); L->t_tgt = L->alloc<float>(ceil_to((long long)B * Nd, 4)); L->t_on = L->alloc<float>(ceil_to((long long)B * N, 4));
+            L->y = L->alloc<float>((long long)B * Nd);
+        }
     } catch (...) { delete L; throw; }
     *out = L;
     return A0_OK;
     A0_CATCH
+}
+
+// IQNHead.forward (model.py:235-251) for `n_tau` fractions per sample: cosine features, the embedding times the state features (in the embedding GEMM's epilogue where the
+// shape allows; kept for the backward pass when the pass is differentiated), fc1, the head, the dueling combine — DeviceNet.head of agent0_amd/deepq/engine.py
+static int a0_iqn_head(a0_learner* L, const float* flat, a0_learner::QWs& w, const float* taus, int n_tau, bool grads, void* stream) {
+    const int B = L->d.B, A = L->d.A;
+    const int R = B * n_tau;
+    const float *Wc = flat + L->cos.w(), *bc = flat + L->cos.b(), *Wf = flat + L->fc1.w(), *bf = flat + L->fc1.b(), *Wh = flat + L->head.w(), *bh = flat + L->head.b();
+    A0_CHECK(a0_cos_features(taus, w.cosx, R, 64, stream));
+    if (!grads && a0_dense_fwd_scratch(R, L->feat, 64) == 0) A0_CHECK(a0_dense_fwd_mul(w.cosx, 64, Wc, bc, w.act3, n_tau, w.x, R, L->feat, 64, 1, stream));
+    else if (grads && a0_dense_fwd_mul_keep_ok(R, L->feat, 64, 64)) A0_CHECK(a0_dense_fwd_mul_keep(w.cosx, 64, Wc, bc, w.act3, n_tau, w.emb, w.x, R, L->feat, 64, 1, stream));
+    else {
+        A0_CHECK(a0_dense_fwd(w.cosx, 64, Wc, bc, w.emb, R, L->feat, 64, 1, L->fwd_scratch, stream));
+        A0_CHECK(a0_hadamard_fwd(w.emb, w.act3, w.x, B, n_tau, L->feat, stream));
+    }
+    A0_CHECK(a0_dense_fwd(w.x, L->feat, Wf, bf, w.h, R, 512, L->feat, 1, L->fwd_scratch, stream));
+    A0_CHECK(a0_dense_fwd(w.h, 512, Wh, bh, w.raw, R, L->Npad, 512, 0, L->fwd_scratch, stream));
+    return a0_dueling_fwd(w.raw, L->Npad, w.q, R, A, 1, L->d.dueling ? 1 : 0, stream);
 }
 
 extern "C" int a0_learner_destroy(a0_learner* L) { delete L; return A0_OK; }
@@ -218,7 +267,45 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     a0_pending_reduce pend;
     pend.n = 0;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
-    if (L->d.algo == A0_ALGO_C51) {
+    if (L->d.algo == A0_ALGO_IQN) {
+        // ---- IQNLearner.train_step (agent.py:296-331) in the order of agent0_amd/deepq/engine.py's iqn path.  The update's three tau draws first (BaseLearner.train_batch:
+        // K, N', N fractions per sample, Philox stream 3)
+        const int K = L->d.iqn_K, N = L->d.iqn_N, Nd = L->d.iqn_N_dash;
+        A0_CHECK(a0_rng_uniform(L->rng.seed, 3, L->rng.reserve(3, (long long)B * K), L->t_sel, (long long)B * K, stream));
+        A0_CHECK(a0_rng_uniform(L->rng.seed, 3, L->rng.reserve(3, (long long)B * Nd), L->t_tgt, (long long)B * Nd, stream));
+        A0_CHECK(a0_rng_uniform(L->rng.seed, 3, L->rng.reserve(3, (long long)B * N), L->t_on, (long long)B * N, stream));
+        a0_encoder_pass passes[3];
+        int np = 0;
+        passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->act3_t};
+        if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
+        passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
+        A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
+        if (dq) {        // greedy next action from the online network's K-sample mean (agent.py:303-306)
+            A0_CHECK(a0_iqn_head(L, on, L->qs, L->t_sel, K, false, stream));
+            A0_CHECK(a0_select_action(L->qs.q, (long long)K * A, 1, A, B, A, K, 1, nullptr, L->a_star, nullptr, nullptr, stream));
+        } else {
+            A0_CHECK(a0_iqn_head(L, tg, L->qt, L->t_sel, K, false, stream));
+            A0_CHECK(a0_select_action(L->qt.q, (long long)K * A, 1, A, B, A, K, 1, nullptr, L->a_star, nullptr, nullptr, stream));
+        }
+        A0_CHECK(a0_iqn_head(L, tg, L->qt, L->t_tgt, Nd, false, stream));
+        A0_CHECK(a0_quantile_target(L->qt.q, (long long)Nd * A, A, 1, L->a_star, rew, done, L->gamma_n, B, Nd, L->y, stream));
+        A0_CHECK(a0_iqn_head(L, on, L->qo, L->t_on, N, true, stream));
+        A0_HIP_THROW(hipMemsetAsync(L->qo.dq, 0, (size_t)L->qo.R * A * 4, (hipStream_t)stream));
+        A0_CHECK(a0_loss_quantile_huber(L->qo.q, (long long)N * A, A, 1, L->y, L->t_on, N, act, wgt, B, N, Nd, L->loss, L->qo.dq, L->state, stream));
+        // ---- dense backward over the B * N rows of the differentiated pass (DeviceLearner._backward_dense, quantile branch)
+        const int R = (int)L->qo.R;
+        A0_CHECK(a0_dueling_bwd(L->qo.dq, L->draw, L->Npad, R, A, 1, L->d.dueling ? 1 : 0, stream));
+        A0_CHECK(a0_dense_dgrad(L->draw, on + L->head.w(), L->qo.h, L->dh, R, L->Npad, 512, stream));
+        A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), nullptr, L->qo.dx, R, 512, L->feat, stream));
+        A0_CHECK(a0_hadamard_bwd(L->qo.dx, L->qo.emb, L->act3_o, L->qo.demb, L->d3, B, N, L->feat, stream));
+        {
+            const float* dY[3] = {L->draw, L->dh, L->qo.demb};
+            const float* X[3] = {L->qo.h, L->qo.x, L->qo.cosx};
+            const int ldx[3] = {512, L->feat, 64}, Rr[3] = {R, R, R}, Nn[3] = {L->Npad, 512, L->feat}, Kk[3] = {512, L->feat, 64};
+            float* G[3] = {L->grads + L->head.off, L->grads + L->fc1.off, L->grads + L->cos.off};
+            A0_CHECK(a0_dense_wgrad_multi(3, dY, X, ldx, G, Rr, Nn, Kk, L->slabs, L->slab_off3, &pend, stream));
+        }
+    } else if (L->d.algo == A0_ALGO_C51) {
         // ---- C51Learner.train_step (agent.py:218-268), in the order of agent0_amd/deepq/engine.py's c51 path: the three encoder passes in one launch; the online
         // fc1 over [s ; s'] rows as ONE GEMM and the target's, their slabs finished by one reduction launch; the two head GEMMs; and one launch for everything behind
         // them (slab sums, dueling, greedy next action, projection, cross entropy, head gradient)
@@ -294,8 +381,8 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
                                     L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
     }
     // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
+    if (L->d.algo != A0_ALGO_IQN) {
     A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
-    {
         const float* dY[2] = {L->draw, L->dh};
         const float* X[2] = {L->h, L->act3_o};
         const int ldx[2] = {512, L->feat}, R[2] = {B, B}, N[2] = {L->Npad, 512}, K[2] = {512, L->feat};

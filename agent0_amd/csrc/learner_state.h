@@ -38,6 +38,12 @@ struct a0_learner {
     int* a_star = nullptr;
     float *act3_on = nullptr, *fc1_on = nullptr, *fc1_tg = nullptr, *h_on = nullptr, *h_tg = nullptr, *hs_on = nullptr, *hs_tg = nullptr;
     int R_on = 0, ns_on = 1, nh_on = 1, nh_tg = 1;
+    // ---- implicit quantile networks (A0_ALGO_IQN)
+    Blk cos;                                                 // cosine embedding [feat][64]
+    struct QWs { int n_tau = 0; long long R = 0; float *h = nullptr, *raw = nullptr, *q = nullptr, *cosx = nullptr, *emb = nullptr, *x = nullptr, *act3 = nullptr;
+                 float *dq = nullptr, *dx = nullptr, *demb = nullptr; } qo, qt, qs;      // online on s (differentiated), target on s', online on s' (double-Q)
+    float *t_sel = nullptr, *t_tgt = nullptr, *t_on = nullptr, *y = nullptr, *fwd_scratch = nullptr;
+    long long slab_off3[3] = {0, 0, 0};
     // effective (W, b) of a dense layer of the online / target network
     const float* Wf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.w() : (tg ? target : online) + fc1.w(); }
     const float* bf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.b() : (tg ? target : online) + fc1.b(); }

@@ -286,6 +286,8 @@ int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, floa
  * entry points (agent0_amd/deepq/engine.py shows the order). */
 #define A0_ALGO_DQN 0
 #define A0_ALGO_C51 1
+#define A0_ALGO_IQN 2   /* IQNLearner.train_step (agent.py:296-331) with the cosine-embedding head (model.py:203-257): packed layout conv1 | conv2 | conv3 | fc1 | head | cos;
+                         * the three tau draws of an update (K, N', N per sample, in that order) come from Philox stream 3 of `seed` as BaseLearner's do */
 typedef struct a0_learner a0_learner;
 typedef struct a0_learner_desc {
     int A, dueling, double_q;         /* cfg.action_dim, learner.dueling_head, learner.double_q (config.py:72-95) */
@@ -295,7 +297,8 @@ typedef struct a0_learner_desc {
     int algo;                         /* A0_ALGO_* */
     int num_atoms; double vmin, vmax; /* c51: learner.c51.num_atoms / vmin / vmax (config.py:97-101); the support is torch.linspace(vmin, vmax, num_atoms) */
     int noisy;                        /* learner.noisy_net */
-    unsigned long long seed;          /* the learner's Philox seed (the Python classes use cfg.seed + 15485863); noise draws only */
+    unsigned long long seed;          /* the learner's Philox seed (the Python classes use cfg.seed + 15485863): noise and tau draws */
+    int iqn_K, iqn_N, iqn_N_dash;     /* iqn: learner.iqn.K / N / N_dash (config.py:103-109); 64 cosines */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
 /* The same handle over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the

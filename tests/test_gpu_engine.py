@@ -820,6 +820,52 @@ def test_native_c51_learner_handle_equals_the_per_kernel_composition(hip, A, due
     nat.close()
 
 
+@pytest.mark.parametrize("A,dueling,double_q,n_step,B,KNN", [(9, False, False, 1, 32, (32, 64, 64)), (9, True, True, 3, 16, (32, 64, 64)), (4, False, True, 1, 8, (8, 16, 24)),
+                                                              (9, False, False, 1, 512, (32, 64, 64))], ids=["iqn", "iqn-duel-double-n3", "iqn-small-taus", "iqn-b512"])
+def test_native_iqn_learner_handle_equals_the_per_kernel_composition(hip, A, dueling, double_q, n_step, B, KNN):
+    """The a0_learner handle with algo = A0_ALGO_IQN (BASELINE configs[3]): the three tau draws of an update (Philox stream 3 of the learner's seed, in BaseLearner's
+    order K, N', N), the cosine-embedding heads, the greedy next action, the quantile target, the quantile Huber loss, the backward pass over B * N rows with the
+    embedding's weight gradient, Adam with the target sync — one a0_learner_update call, torch.equal to DeviceRng + DeviceLearner.update on losses, parameters, target,
+    Adam moments and status words after each of four updates across a target sync."""
+    from agent0_amd.common.utils import DeviceRng
+    from agent0_amd.deepq.engine import DeviceLearner
+    from agent0_amd.deepq.layout import NetLayout
+    K, N, Nd = KNN
+    spec = recipe.NetSpec("iqn", A, dueling=dueling)
+    L = NetLayout.from_spec(spec)
+    cap = max(200, B + 40)
+    dev = DeviceLearner(hip, L, B, n_step=n_step, double_q=double_q, target_update_freq=3, K=K, N=N, N_dash=Nd)
+    dev.online.load_state_dict(recipe.make_state_dict(spec, 11))
+    dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
+    seed = 42 + 15485863
+    rng = DeviceRng(hip, seed)
+    nat = hip.native_learner(A=A, dueling=dueling, double_q=double_q, B=B, n_step=n_step, discount=0.99, lr=5e-4, target_update_freq=3, algo="iqn", seed=seed, K=K, N=N, N_dash=Nd)
+    assert nat.n == L.n_params_padded
+    nat.set_params(dev.online.flat, dev.target.flat)
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(-1).contiguous()
+    loss_n = hip.empty(B)
+    taus = [hip.empty(B * n) for n in (K, Nd, N)]
+    for s in range(4):
+        slot = torch.from_numpy(recipe.gen(40 + s).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+        a_np, r_np, d_np, w_np = recipe.make_transitions(B, A, 70 + s)
+        a, r, d, w = (torch.from_numpy(x).to(hip.device) for x in (a_np.astype(np.int32), r_np, d_np.astype(np.float32), w_np))
+        for t in taus:
+            rng.uniform(rng.STREAM_TAUS, t, t.numel())                     # BaseLearner.train_batch
+        loss_e = dev.update(ring, slot, 2 * 28224, a, r, d, w, rand=taus).clone()
+        nat.update(ring, slot, 2 * 28224, a, r, d, w, loss_out=loss_n)
+        torch.cuda.synchronize()
+        on, tg, m, v, st = nat.get()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_n, loss_e[:B]), f"update {s}: per-sample losses (max diff {float((loss_n - loss_e[:B]).abs().max())})"
+        assert torch.equal(on, dev.online.flat) and torch.equal(tg, dev.target.flat), f"update {s}: parameters / target"
+        assert torch.equal(m, dev.adam_m) and torch.equal(v, dev.adam_v), f"update {s}: Adam moments"
+        assert torch.equal(st, dev.state), f"update {s}: status words {st.tolist()} vs {dev.state.tolist()}"
+    assert int(st[1]) == 4 and not torch.equal(on, tg) and float(loss_n.min()) >= 0.0
+    cb = L.blocks["cos"]
+    assert float(m[cb.all].abs().max()) > 0.0, "the cosine embedding is trained"
+    nat.close()
+
+
 def test_plain_c_host_drives_a_learner_through_the_c_abi(tmp_path):
     """The drop-in boundary is a C-ABI: tests/c_host_demo.c — plain C, include/agent0_hip.h and the HIP runtime, no Python, no torch — creates an a0_learner, loads
     parameters, runs three dueling double-Q n-step updates (one a0_learner_update call each) and reads the state back.  Compiled here with gcc (the HIP runtime's C API) against the in-tree
