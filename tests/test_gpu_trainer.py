@@ -622,8 +622,10 @@ RAINBOW = {"learner.double_q": "true", "learner.dueling_head": "true", "learner.
 
 @pytest.mark.parametrize("algo,extra", [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3}),
                                         ("dqn", {"replay.policy": "prioritize", "learner.n_step_q": 3, "env_task": "block"}), ("c51", {}), ("c51", RAINBOW),
-                                        ("c51", {**RAINBOW, "env_task": "block", "actor.sample_steps": 10, "learner.reset_noise_freq": 3})],
-                         ids=["dqn-uniform", "duel-double-n3", "prioritized-n3-block", "c51", "rainbow-lite", "rainbow-lite-block-noise3"])
+                                        ("c51", {**RAINBOW, "env_task": "block", "actor.sample_steps": 10, "learner.reset_noise_freq": 3}),
+                                        ("iqn", {"env_id": "Asterix"}), ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3,
+                                                                               "replay.policy": "prioritize", "env_task": "block"})],
+                         ids=["dqn-uniform", "duel-double-n3", "prioritized-n3-block", "c51", "rainbow-lite", "rainbow-lite-block-noise3", "iqn", "iqn-duel-double-n3-per-block"])
 def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     """Round 4 (opaque handles, library-owned HBM): ``a0_actor`` / ``a0_rbuf`` / ``a0_learner`` (csrc/runtime.hip, learner.hip) restate the host-side
     bookkeeping of the Python classes — cursors, shuffled epochs, Philox offsets, beta, epsilon — in C++, so that a host needs a handful of C calls per iteration.
@@ -654,13 +656,15 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     st = torch.cuda.current_stream().cuda_stream
     prio, duel, dq, n = cfg.replay.policy.name == "prioritize", bool(cfg.learner.dueling_head), bool(cfg.learner.double_q), int(cfg.learner.n_step_q)
     noisy = bool(cfg.learner.noisy_net)
-    nat = tr.ops.native_learner(A=4, dueling=duel, double_q=dq, B=B, n_step=n, discount=cfg.learner.discount, lr=cfg.learner.learning_rate, target_update_freq=TF, algo=algo,
-                                num_atoms=cfg.learner.c51.num_atoms, vmin=cfg.learner.c51.vmin, vmax=cfg.learner.c51.vmax, noisy=noisy, seed=cfg.seed + 15485863)
+    A = int(cfg.action_dim)
+    nat = tr.ops.native_learner(A=A, dueling=duel, double_q=dq, B=B, n_step=n, discount=cfg.learner.discount, lr=cfg.learner.learning_rate, target_update_freq=TF, algo=algo,
+                                num_atoms=cfg.learner.c51.num_atoms, vmin=cfg.learner.c51.vmin, vmax=cfg.learner.c51.vmax, noisy=noisy, seed=cfg.seed + 15485863,
+                                K=cfg.learner.iqn.K, N=cfg.learner.iqn.N, N_dash=cfg.learner.iqn.N_dash)
     nat.set_params(eng.online.flat, eng.target.flat)
     rd = RbufDesc(SIZE, 4 * 84 * 84, B, int(prio), cfg.replay.alpha, cfg.replay.eps, cfg.replay.beta0, cfg.trainer.total_steps, cfg.seed + 104729)
     rb = C.c_void_p()
     ok(lib.a0_rbuf_create(C.addressof(rd), C.addressof(rb)), "a0_rbuf_create")
-    ad = ActorDesc(E, T, 4, int(duel), n, cfg.learner.discount, cfg.seed, 0, {"stream": 0, "block": 1}[cfg.env_task], int(cfg.learner.reset_noise_freq))
+    ad = ActorDesc(E, T, A, int(duel), n, cfg.learner.discount, cfg.seed, 0, {"stream": 0, "block": 1}[cfg.env_task], int(cfg.learner.reset_noise_freq))
     ac = C.c_void_p()
     ok(lib.a0_actor_create(C.addressof(ad), C.addressof(ac)), "a0_actor_create")
     eps_fn = epsilon_schedule(cfg)
@@ -709,8 +713,10 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
 
 
 @pytest.mark.parametrize("algo,extra", [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
-                                        ("c51", {"env_task": "block"}), ("c51", RAINBOW), ("c51", {**RAINBOW, "learner.reset_noise_freq": 3, "env_task": "block"})],
-                         ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block"])
+                                        ("c51", {"env_task": "block"}), ("c51", RAINBOW), ("c51", {**RAINBOW, "learner.reset_noise_freq": 3, "env_task": "block"}),
+                                        ("iqn", {"env_id": "Asterix", "env_task": "block"}),
+                                        ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"})],
+                         ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block", "iqn-block", "iqn-duel-double-n3-per"])
 def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
     """agent0_amd/deepq/native_loop.py: for the configurations the handles cover, ``Trainer.run_iteration`` hands the loop to a0_actor / a0_rbuf / a0_learner created
     OVER the Python classes' own buffers (a0_learner_create_on / a0_rbuf_create_on) — one C call per rollout, batch and update, eager launches from native code.
@@ -787,10 +793,10 @@ def _rbuf_frames(lib, rb):
     return p
 
 
-@pytest.mark.parametrize("config", [1, 2])
+@pytest.mark.parametrize("config", [1, 2, 3])
 def test_plain_c_host_runs_baseline_config1(tmp_path, config):
     """tests/c_host_loop.c: BASELINE configs[1]'s workload (256 envs x 80 steps + 20 updates of batch 512 per iteration; a 40 000-slot ring here) — and configs[2]'s
-    (c51 rainbow-lite on prioritized replay) — driven from plain C through the a0_actor / a0_rbuf / a0_learner handles — no Python, no torch in the process.
+    (c51 rainbow-lite on prioritized replay) and configs[3]'s (Asterix-shaped iqn) — driven from plain C through the a0_actor / a0_rbuf / a0_learner handles — no Python, no torch in the process.
     Compiled with gcc against the in-tree library, run as a child."""
     import json, os, shutil, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -801,9 +807,10 @@ def test_plain_c_host_runs_baseline_config1(tmp_path, config):
     r = subprocess.run([gcc, "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "c_host_loop.c"), "-I/opt/rocm/include", "-I", os.path.join(root, "include"), "-L", lib,
                         "-lagent0_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([exe, "12", "40000", "1", str(config)], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    r = subprocess.run([exe, "12" if config < 3 else "4", "40000", "1", str(config)], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     print(out)
-    assert out["iterations_timed"] == 12 and out["updates"] == 12 * 20 and out["finite"] == 1 and out["episodes"] > 100
-    assert out["env_frames_per_sec"] > (5e5 if config == 1 else 3e5), "a C host has no reason to be slower than the Python one"
+    it = 12 if config < 3 else 4
+    assert out["iterations_timed"] == it and out["updates"] == it * 20 and out["finite"] == 1 and out["episodes"] > 100
+    assert out["env_frames_per_sec"] > {1: 5e5, 2: 3e5, 3: 1e5}[config], "a C host has no reason to be slower than the Python one"
