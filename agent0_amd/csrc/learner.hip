@@ -27,8 +27,10 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
     const a0_learner_buffers& U = bufs ? *bufs : none;
     if (U.loss_ring && U.loss_ring_cap < 1) return a0_fail(A0_EINVAL, "a0_learner_create_on: loss_ring_cap");
     if (d->A < 1 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1 ||
-        (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51 && d->algo != A0_ALGO_IQN))
+        (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51 && d->algo != A0_ALGO_IQN && d->algo != A0_ALGO_FQF))
         return a0_fail(A0_EINVAL, "a0_learner_create: bad description");
+    if (d->algo == A0_ALGO_FQF && (d->noisy || d->fqf_F < 2 || d->fqf_F > 32 || d->A + (d->dueling ? 1 : 0) > 32))
+        return a0_fail(A0_EINVAL, "a0_learner_create: fqf needs 2 <= F <= 32, no NoisyNet, A + dueling <= 32");
     if (d->algo == A0_ALGO_IQN && (d->noisy || d->iqn_K < 1 || d->iqn_N < 1 || d->iqn_N_dash < 1 || d->A + (d->dueling ? 1 : 0) > 32))
         return a0_fail(A0_EINVAL, "a0_learner_create: iqn needs K, N, N' >= 1, no NoisyNet, A + dueling <= 32");
     if (d->algo == A0_ALGO_DQN && (d->A + (d->dueling ? 1 : 0) > 24 || d->noisy))
@@ -51,9 +53,11 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         add(L->conv1, 32, L->C * 64); add(L->conv2, 64, 512); add(L->conv3, 64, 576);                                                              // deepq/layout.py
         if (d->noisy) { add(L->fc1, 512, L->feat); add(L->fc1_sigma, 512, L->feat); add(L->head, L->Npad, 512); add(L->head_sigma, L->Npad, 512); }
         else { add(L->fc1, 512, L->feat); add(L->head, L->Npad, 512); }
-        const bool iqn = d->algo == A0_ALGO_IQN;
+        const bool fqf = d->algo == A0_ALGO_FQF;
+        const bool iqn = d->algo == A0_ALGO_IQN || fqf;           // the quantile family: cosine-embedding heads over B * n_tau rows
         if (iqn) add(L->cos, L->feat, 64);
         L->n_adam = off;
+        if (fqf) { add(L->frac, 32, L->feat); L->F = d->fqf_F; }  // behind the Adam range: its own RMSprop step (agent.py:139-148)
         if (d->noisy) {
             // composed weights [fc1 | head] per network; noise vectors per NoisyLinear module in the reference's module order (first_dense, q_head, value_head), each
             // (noise_in, noise_out_weight, noise_out_bias) padded to four floats — the layout one Philox fill of the whole buffer reproduces (engine.py DeviceNet)
@@ -94,7 +98,7 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             L->h = L->alloc<float>((long long)B * 512);
         }
         L->q_o = L->alloc<float>((long long)B * d->A * L->T); L->q_t = L->alloc<float>((long long)B * d->A * L->T);
-        const long long Rg = iqn ? (long long)B * d->iqn_N : (long long)B;           // rows of the differentiated pass
+        const long long Rg = fqf ? (long long)B * d->fqf_F : (iqn ? (long long)B * d->iqn_N : (long long)B);           // rows of the differentiated pass
         L->draw = L->alloc<float>(Rg * L->Npad); L->dh = L->alloc<float>(Rg * 512); L->d3 = L->alloc<float>((long long)B * L->feat);
         L->d2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64); L->d1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->loss = L->alloc<float>(B);
         // one slab scratch for the dense weight gradients (disjoint regions, one reduction launch) and, after them, the encoder's
@@ -104,7 +108,8 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         L->slab_off3[0] = 0; L->slab_off3[1] = s_head; L->slab_off3[2] = s_head + s_fc1;
         // (the dense layers' slab reductions ride in the encoder's reduction launch, a0_pending_reduce: the encoder's slabs start behind theirs)
         L->enc_slab_off = s_head + s_fc1 + s_cos;
-        const long long n_slab = L->enc_slab_off + a0_net_encoder_bwd_scratch(L->net, B);
+        long long n_slab = L->enc_slab_off + a0_net_encoder_bwd_scratch(L->net, B);
+        if (fqf && a0_dense_wgrad_scratch(B, 32, L->feat) > n_slab) n_slab = a0_dense_wgrad_scratch(B, 32, L->feat);
         L->slabs = L->alloc<float>(n_slab > 4 ? n_slab : 4);
         if (d->noisy) {
             L->eff_on = U.eff_online ? U.eff_online : L->alloc<float>(L->n_eff, true); L->eff_tg = U.eff_target ? U.eff_target : L->alloc<float>(L->n_eff, true);
@@ -142,7 +147,7 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             A0_HIP_THROW(hipMemcpy(L->atoms, at.data(), (size_t)L->T * 4, hipMemcpyHostToDevice));
         }
         if (iqn) {
-            const int K = d->iqn_K, N = d->iqn_N, Nd = d->iqn_N_dash;
+            const int K = fqf ? d->fqf_F : d->iqn_K, N = fqf ? d->fqf_F : d->iqn_N, Nd = fqf ? d->fqf_F : d->iqn_N_dash;
             L->rng.init(d->seed, 0);
             L->a_star = L->alloc<int>(B, true);
             long long sc = 4;
@@ -151,8 +156,8 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
                 w.h = L->alloc<float>(w.R * 512); w.raw = L->alloc<float>(w.R * L->Npad); w.q = L->alloc<float>(w.R * d->A);
                 w.cosx = L->alloc<float>(w.R * 64); w.emb = L->alloc<float>(w.R * L->feat); w.x = L->alloc<float>(w.R * L->feat);
                 if (grads) { w.dq = L->alloc<float>(w.R * d->A, true); w.dx = L->alloc<float>(w.R * L->feat); w.demb = L->alloc<float>(w.R * L->feat); }
-                for (int r : {B * K, B * Nd, B * N}) {
-                    if (r > w.R) continue;
+                for (int r : {B * K, B * Nd, B * N, B * (N - 1)}) {
+                    if (r > w.R || r < 1) continue;
                     const long long a = a0_dense_fwd_scratch(r, L->feat, 64), b2 = a0_dense_fwd_scratch(r, 512, L->feat), c = a0_dense_fwd_scratch(r, L->Npad, 512);
                     sc = std::max(sc, std::max(a, std::max(b2, c)));
                 }
@@ -160,9 +165,20 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             ws(L->qo, N, L->act3_o, true);
             ws(L->qt, Nd > K ? Nd : K, L->act3_t, false);
             if (d->double_q) ws(L->qs, K, L->act3_s, false);
+            if (fqf) sc = std::max(sc, (long long)a0_dense_fwd_scratch(B, 32, L->feat));
             L->fwd_scratch = L->alloc<float>(sc);
             L->t_sel = L->alloc<float>(ceil_to((long long)B * K, 4)); L->t_tgt = L->alloc<float>(ceil_to((long long)B * Nd, 4)); L->t_on = L->alloc<float>(ceil_to((long long)B * N, 4));
             L->y = L->alloc<float>((long long)B * Nd);
+            if (fqf) {
+                const int F = d->fqf_F;
+                auto fw = [&](a0_learner::FWs& w) { w.logits = L->alloc<float>((long long)B * 32, true); w.tau_all = L->alloc<float>((long long)B * (F + 1)); w.tau_hat = L->alloc<float>((long long)B * F); };
+                fw(L->fo); fw(L->ft);
+                if (d->double_q) fw(L->fs);
+                ws(L->qf, F, L->act3_o, false);
+                L->inner_taus = L->alloc<float>((long long)B * F);
+                L->rms_sq = U.rms_sq ? U.rms_sq : L->alloc<float>(L->frac.size(), true);
+                L->frac_loss = L->alloc<float>(B, true); L->dfrac = L->alloc<float>((long long)B * 32, true); L->clip = L->alloc<float>(4, true);
+            }
         }
     } catch (...) { delete L; throw; }
     *out = L;
@@ -209,6 +225,14 @@ extern "C" int a0_learner_loss_buffer(const a0_learner* L, float** loss_dev) {
     if (!L || !loss_dev) return a0_fail(A0_EINVAL, "a0_learner_loss_buffer: null argument");
     *loss_dev = L->loss;
     return A0_OK;
+}
+
+extern "C" int a0_learner_get_frac_loss(const a0_learner* L, float* out_dev, void* stream) {
+    A0_TRY
+    if (!L || !out_dev || !L->frac_loss) return a0_fail(A0_EINVAL, "a0_learner_get_frac_loss: an fqf handle and an output buffer");
+    A0_HIP_THROW(hipMemcpyAsync(out_dev, L->frac_loss, (size_t)L->d.B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return A0_OK;
+    A0_CATCH
 }
 
 extern "C" int a0_learner_set_support(a0_learner* L, const float* atoms_host) {
@@ -267,7 +291,41 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     a0_pending_reduce pend;
     pend.n = 0;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
-    if (L->d.algo == A0_ALGO_IQN) {
+    if (L->d.algo == A0_ALGO_FQF) {
+        // ---- FQFLearner.train_step (agent.py:334-388) in the order of agent0_amd/deepq/engine.py's fqf path
+        const int F = L->F;
+        a0_encoder_pass passes[3];
+        int np = 0;
+        passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
+        passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->act3_t};
+        if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
+        A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
+        // FQFHead.prop_taus (model.py:268-278): the fraction net on the (detached) features -> taus, tau_hats
+        auto taus = [&](const float* flat, const float* act3, a0_learner::FWs& w) -> int {
+            A0_CHECK(a0_dense_fwd(act3, L->feat, flat + L->frac.w(), flat + L->frac.b(), w.logits, B, 32, L->feat, 0, L->fwd_scratch, stream));
+            return a0_fqf_taus(w.logits, 32, w.tau_all, w.tau_hat, B, F, stream);
+        };
+        A0_CHECK(taus(on, L->act3_o, L->fo));
+        A0_CHECK(a0_iqn_head(L, on, L->qo, L->fo.tau_hat, F, true, stream));
+        if (dq) {
+            A0_CHECK(taus(on, L->act3_s, L->fs));
+            A0_CHECK(a0_iqn_head(L, on, L->qs, L->fs.tau_hat, F, false, stream));
+            A0_CHECK(a0_select_action(L->qs.q, (long long)F * A, 1, A, B, A, F, 3, L->fs.tau_all, L->a_star, nullptr, nullptr, stream));
+        } else {
+            A0_CHECK(taus(tg, L->act3_t, L->ft));
+            A0_CHECK(a0_iqn_head(L, tg, L->qt, L->ft.tau_hat, F, false, stream));
+            A0_CHECK(a0_select_action(L->qt.q, (long long)F * A, 1, A, B, A, F, 3, L->ft.tau_all, L->a_star, nullptr, nullptr, stream));
+        }
+        A0_CHECK(a0_iqn_head(L, tg, L->qt, L->fo.tau_hat, F, false, stream));                      // quirk Q16: the target evaluated at the ONLINE tau-hats
+        A0_CHECK(a0_quantile_target(L->qt.q, (long long)F * A, A, 1, L->a_star, rew, done, L->gamma_n, B, F, L->y, stream));
+        A0_HIP_THROW(hipMemsetAsync(L->qo.dq, 0, (size_t)L->qo.R * A * 4, (hipStream_t)stream));
+        A0_CHECK(a0_loss_quantile_huber(L->qo.q, (long long)F * A, A, 1, L->y, L->fo.tau_hat, F, act, wgt, B, F, F, L->loss, L->qo.dq, L->state, stream));
+        // fraction loss: q at the interior taus (no grad), its gradient w.r.t. the fraction logits; the fraction net's RMSprop step follows the backward pass
+        A0_CHECK(a0_fqf_inner_taus(L->fo.tau_all, L->inner_taus, B, F, stream));
+        A0_CHECK(a0_iqn_head(L, on, L->qf, L->inner_taus, F - 1, false, stream));
+        A0_CHECK(a0_fqf_fraction_loss(L->qf.q, L->qo.q, L->fo.tau_all, act, wgt, B, F, A, 32, L->frac_loss, L->dfrac, L->fo.logits, stream));
+        A0_CHECK(a0_dense_wgrad(L->dfrac, L->act3_o, L->feat, L->grads + L->frac.off, B, 32, L->feat, L->slabs, stream));
+    } else if (L->d.algo == A0_ALGO_IQN) {
         // ---- IQNLearner.train_step (agent.py:296-331) in the order of agent0_amd/deepq/engine.py's iqn path.  The update's three tau draws first (BaseLearner.train_batch:
         // K, N', N fractions per sample, Philox stream 3)
         const int K = L->d.iqn_K, N = L->d.iqn_N, Nd = L->d.iqn_N_dash;
@@ -292,19 +350,6 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         A0_CHECK(a0_iqn_head(L, on, L->qo, L->t_on, N, true, stream));
         A0_HIP_THROW(hipMemsetAsync(L->qo.dq, 0, (size_t)L->qo.R * A * 4, (hipStream_t)stream));
         A0_CHECK(a0_loss_quantile_huber(L->qo.q, (long long)N * A, A, 1, L->y, L->t_on, N, act, wgt, B, N, Nd, L->loss, L->qo.dq, L->state, stream));
-        // ---- dense backward over the B * N rows of the differentiated pass (DeviceLearner._backward_dense, quantile branch)
-        const int R = (int)L->qo.R;
-        A0_CHECK(a0_dueling_bwd(L->qo.dq, L->draw, L->Npad, R, A, 1, L->d.dueling ? 1 : 0, stream));
-        A0_CHECK(a0_dense_dgrad(L->draw, on + L->head.w(), L->qo.h, L->dh, R, L->Npad, 512, stream));
-        A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), nullptr, L->qo.dx, R, 512, L->feat, stream));
-        A0_CHECK(a0_hadamard_bwd(L->qo.dx, L->qo.emb, L->act3_o, L->qo.demb, L->d3, B, N, L->feat, stream));
-        {
-            const float* dY[3] = {L->draw, L->dh, L->qo.demb};
-            const float* X[3] = {L->qo.h, L->qo.x, L->qo.cosx};
-            const int ldx[3] = {512, L->feat, 64}, Rr[3] = {R, R, R}, Nn[3] = {L->Npad, 512, L->feat}, Kk[3] = {512, L->feat, 64};
-            float* G[3] = {L->grads + L->head.off, L->grads + L->fc1.off, L->grads + L->cos.off};
-            A0_CHECK(a0_dense_wgrad_multi(3, dY, X, ldx, G, Rr, Nn, Kk, L->slabs, L->slab_off3, &pend, stream));
-        }
     } else if (L->d.algo == A0_ALGO_C51) {
         // ---- C51Learner.train_step (agent.py:218-268), in the order of agent0_amd/deepq/engine.py's c51 path: the three encoder passes in one launch; the online
         // fc1 over [s ; s'] rows as ONE GEMM and the target's, their slabs finished by one reduction launch; the two head GEMMs; and one launch for everything behind
@@ -380,8 +425,25 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
                                     on + L->head.w(), on + L->head.b(), tg + L->head.w(), tg + L->head.b(), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, B,
                                     L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
     }
+    const bool quantile = L->d.algo == A0_ALGO_IQN || L->d.algo == A0_ALGO_FQF;
+    if (quantile) {
+        const int N = L->qo.n_tau;
+        // ---- dense backward over the B * n_tau rows of the differentiated pass (DeviceLearner._backward_dense, quantile branch)
+        const int R = (int)L->qo.R;
+        A0_CHECK(a0_dueling_bwd(L->qo.dq, L->draw, L->Npad, R, A, 1, L->d.dueling ? 1 : 0, stream));
+        A0_CHECK(a0_dense_dgrad(L->draw, on + L->head.w(), L->qo.h, L->dh, R, L->Npad, 512, stream));
+        A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), nullptr, L->qo.dx, R, 512, L->feat, stream));
+        A0_CHECK(a0_hadamard_bwd(L->qo.dx, L->qo.emb, L->act3_o, L->qo.demb, L->d3, B, N, L->feat, stream));
+        {
+            const float* dY[3] = {L->draw, L->dh, L->qo.demb};
+            const float* X[3] = {L->qo.h, L->qo.x, L->qo.cosx};
+            const int ldx[3] = {512, L->feat, 64}, Rr[3] = {R, R, R}, Nn[3] = {L->Npad, 512, L->feat}, Kk[3] = {512, L->feat, 64};
+            float* G[3] = {L->grads + L->head.off, L->grads + L->fc1.off, L->grads + L->cos.off};
+            A0_CHECK(a0_dense_wgrad_multi(3, dY, X, ldx, G, Rr, Nn, Kk, L->slabs, L->slab_off3, &pend, stream));
+        }
+    }
     // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
-    if (L->d.algo != A0_ALGO_IQN) {
+    if (!quantile) {
     A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
         const float* dY[2] = {L->draw, L->dh};
         const float* X[2] = {L->h, L->act3_o};
@@ -405,6 +467,8 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         A0_CHECK(a0_noisy_multi(1, L->n_mods, gmu, nullptr, gs, N, K, r0, r1, nin, nw, nb, stream));
     }
     if (loss_out) A0_HIP_THROW(hipMemcpyAsync(loss_out, L->loss, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (L->d.algo == A0_ALGO_FQF)      // unconditional, like the reference's fqf_optimizer.step() in front of the NaN guard (agent.py:139-148); lr / 2e4, alpha 0.95, eps 1e-5
+        A0_CHECK(a0_rmsprop_step(on + L->frac.off, L->grads + L->frac.off, L->rms_sq, L->frac.size(), L->d.lr / 2e4, 0.95, 1e-5, -1.0, L->clip, stream));
     // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
     const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;
     A0_CHECK(a0_adam_step_sync_wt(on, L->grads, L->m, L->v, L->n_adam, L->state, L->scalars, L->d.lr, 0.9, 0.999, eps, L->d.target_update_freq, tg, L->n_pad, nullptr, &w_on, L->C,

@@ -43,6 +43,12 @@ struct a0_learner {
     struct QWs { int n_tau = 0; long long R = 0; float *h = nullptr, *raw = nullptr, *q = nullptr, *cosx = nullptr, *emb = nullptr, *x = nullptr, *act3 = nullptr;
                  float *dq = nullptr, *dx = nullptr, *demb = nullptr; } qo, qt, qs;      // online on s (differentiated), target on s', online on s' (double-Q)
     float *t_sel = nullptr, *t_tgt = nullptr, *t_on = nullptr, *y = nullptr, *fwd_scratch = nullptr;
+    // ---- fully parameterised quantile function (A0_ALGO_FQF): fraction net block behind the Adam range, its RMSprop state, per-pass fraction buffers
+    Blk frac;
+    int F = 0;
+    struct FWs { float *logits = nullptr, *tau_all = nullptr, *tau_hat = nullptr; } fo, ft, fs;
+    QWs qf;                                                   // q at the interior fractions taus[1:-1] (F - 1 per sample) on the online features
+    float *inner_taus = nullptr, *rms_sq = nullptr, *frac_loss = nullptr, *dfrac = nullptr, *clip = nullptr;
     long long slab_off3[3] = {0, 0, 0};
     // effective (W, b) of a dense layer of the online / target network
     const float* Wf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.w() : (tg ? target : online) + fc1.w(); }

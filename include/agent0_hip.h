@@ -286,6 +286,8 @@ int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, floa
  * entry points (agent0_amd/deepq/engine.py shows the order). */
 #define A0_ALGO_DQN 0
 #define A0_ALGO_C51 1
+#define A0_ALGO_FQF 3   /* FQFLearner.train_step (agent.py:334-388) with the fraction proposal network (model.py:260-284; its own RMSprop step, agent.py:139-148): packed layout
+                         * conv1 | conv2 | conv3 | fc1 | head | cos | frac, Adam over everything before frac; BASELINE configs[4] */
 #define A0_ALGO_IQN 2   /* IQNLearner.train_step (agent.py:296-331) with the cosine-embedding head (model.py:203-257): packed layout conv1 | conv2 | conv3 | fc1 | head | cos;
                          * the three tau draws of an update (K, N', N per sample, in that order) come from Philox stream 3 of `seed` as BaseLearner's do */
 typedef struct a0_learner a0_learner;
@@ -299,6 +301,7 @@ typedef struct a0_learner_desc {
     int noisy;                        /* learner.noisy_net */
     unsigned long long seed;          /* the learner's Philox seed (the Python classes use cfg.seed + 15485863): noise and tau draws */
     int iqn_K, iqn_N, iqn_N_dash;     /* iqn: learner.iqn.K / N / N_dash (config.py:103-109); 64 cosines */
+    int fqf_F;                        /* fqf: learner.iqn.F fractions (<= 32) */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
 /* The same handle over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the
@@ -314,6 +317,7 @@ typedef struct a0_learner_buffers {
     float* loss_ring; int loss_ring_cap;
     float *wt_online, *wt_target;
     float *eff_online, *eff_target, *noise;
+    float* rms_sq;                    /* fqf: the fraction net's RMSprop state, 32 * feat + 32 floats */
 } a0_learner_buffers;
 int a0_learner_create_on(const a0_learner_desc* desc, const a0_learner_buffers* buffers, a0_learner** out);
 /* the next draw offset of one of the learner's Philox streams (4 = NoisyNet noise) */
@@ -327,6 +331,8 @@ int a0_learner_get(const a0_learner* learner, float* online_out, float* target_o
 /* the handle's own buffer of per-sample losses [B] of the last update (device pointer, valid for the handle's lifetime): what a0_rbuf_update_priority takes without
  * the copy a non-NULL loss_out of a0_learner_update costs */
 int a0_learner_loss_buffer(const a0_learner* learner, float** loss_dev);
+/* fqf: a copy of the per-sample fraction losses [B] of the last update (the `fraction_loss` statistic, trainer.py:99-101) into out_dev */
+int a0_learner_get_frac_loss(const a0_learner* learner, float* out_dev, void* stream);
 /* c51: the support atoms [num_atoms] from HOST memory, for a caller that holds the exact values its reference run used (default: linspace in fp32, torch's formula) */
 int a0_learner_set_support(a0_learner* learner, const float* atoms_host);
 /* frames: u8 replay rows st || st_next of row_bytes bytes, read through slot [B] (ring slots of the sampled batch; NULL = rows 0 .. B-1); act int32, rew / done /

@@ -866,6 +866,48 @@ def test_native_iqn_learner_handle_equals_the_per_kernel_composition(hip, A, due
     nat.close()
 
 
+@pytest.mark.parametrize("A,dueling,double_q,n_step,B", [(9, False, False, 1, 32), (18, True, True, 3, 16), (9, False, False, 1, 512)], ids=["fqf", "fqf-a18-duel-double-n3", "fqf-b512"])
+def test_native_fqf_learner_handle_equals_the_per_kernel_composition(hip, A, dueling, double_q, n_step, B):
+    """The a0_learner handle with algo = A0_ALGO_FQF (BASELINE configs[4]): fractions proposed by the fraction net on the detached features, quantile values at the
+    tau-hats (the target at the ONLINE tau-hats, quirk Q16), quantile Huber loss, the fraction loss from the values at the interior fractions, backward over B * F rows,
+    the fraction net's own RMSprop step in front of Adam — one a0_learner_update call, torch.equal to DeviceLearner.update on the losses, the fraction losses, parameters
+    (fraction net included), target, Adam moments and status words after each of four updates across a target sync."""
+    from agent0_amd.deepq.engine import DeviceLearner
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec("fqf", A, dueling=dueling)
+    L = NetLayout.from_spec(spec)
+    cap = max(200, B + 40)
+    dev = DeviceLearner(hip, L, B, n_step=n_step, double_q=double_q, target_update_freq=3)
+    dev.online.load_state_dict(recipe.make_state_dict(spec, 11))
+    dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
+    nat = hip.native_learner(A=A, dueling=dueling, double_q=double_q, B=B, n_step=n_step, discount=0.99, lr=5e-4, target_update_freq=3, algo="fqf", seed=1, F=L.F)
+    assert nat.n == L.n_params_padded
+    nat.set_params(dev.online.flat, dev.target.flat)
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(-1).contiguous()
+    loss_n, fl_n = hip.empty(B), hip.empty(B)
+    fb = L.blocks["frac"]
+    frac0 = dev.online.flat[fb.all].clone()
+    for s in range(4):
+        slot = torch.from_numpy(recipe.gen(40 + s).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+        a_np, r_np, d_np, w_np = recipe.make_transitions(B, A, 70 + s)
+        a, r, d, w = (torch.from_numpy(x).to(hip.device) for x in (a_np.astype(np.int32), r_np, d_np.astype(np.float32), w_np))
+        loss_e, fl_e = dev.update(ring, slot, 2 * 28224, a, r, d, w)
+        loss_e, fl_e = loss_e.clone(), fl_e.clone()
+        nat.update(ring, slot, 2 * 28224, a, r, d, w, loss_out=loss_n)
+        nat.frac_loss(fl_n)
+        torch.cuda.synchronize()
+        on, tg, m, v, st = nat.get()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_n, loss_e[:B]), f"update {s}: per-sample losses (max diff {float((loss_n - loss_e[:B]).abs().max())})"
+        assert torch.equal(fl_n, fl_e[:B]), f"update {s}: fraction losses"
+        assert torch.equal(on, dev.online.flat) and torch.equal(tg, dev.target.flat), f"update {s}: parameters / target"
+        assert torch.equal(m, dev.adam_m) and torch.equal(v, dev.adam_v), f"update {s}: Adam moments"
+        assert torch.equal(st, dev.state), f"update {s}: status words {st.tolist()} vs {dev.state.tolist()}"
+    assert int(st[1]) == 4 and not torch.equal(on, tg)
+    assert not torch.equal(on[fb.all], frac0), "the fraction net moved (its RMSprop step)"
+    nat.close()
+
+
 def test_plain_c_host_drives_a_learner_through_the_c_abi(tmp_path):
     """The drop-in boundary is a C-ABI: tests/c_host_demo.c — plain C, include/agent0_hip.h and the HIP runtime, no Python, no torch — creates an a0_learner, loads
     parameters, runs three dueling double-Q n-step updates (one a0_learner_update call each) and reads the state back.  Compiled here with gcc (the HIP runtime's C API) against the in-tree
