@@ -218,6 +218,7 @@ struct a0_actor {
     int dist_Npad = 0;
     // quantile heads (iqn): E * K rows — tau draws, cosine features, embedding x features, fc1 output
     float *q_taus = nullptr, *q_cosx = nullptr, *q_x = nullptr;
+    float *f_logits = nullptr, *f_tau_all = nullptr;        // fqf: fraction logits [E][32], taus [E][F + 1] (q_taus holds the tau-hats)
 };
 
 extern "C" int a0_actor_create(const a0_actor_desc* d, a0_actor** out) {
@@ -276,17 +277,19 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     if (L->d.A != a->d.A || (L->d.dueling != 0) != (a->d.dueling != 0) || R->obs_bytes != a->obs_bytes || R->size < a->E)
         return a0_fail(A0_EINVAL, "a0_actor_rollout: actor, learner and replay were created for different shapes");
     const int E = a->E, A = a->d.A;
-    const bool dist = L->d.algo == A0_ALGO_C51, quant = L->d.algo == A0_ALGO_IQN;
+    const bool dist = L->d.algo == A0_ALGO_C51, fqf = L->d.algo == A0_ALGO_FQF, quant = L->d.algo == A0_ALGO_IQN || fqf;
     const int freq = a->d.reset_noise_freq > 0 ? a->d.reset_noise_freq : 4;
-    const int nt = quant ? L->d.iqn_K : 1;                 // fractions per env and step (agent.py:25-39 with IQNHead.qval, model.py:253-257)
+    const int nt = fqf ? L->F : (quant ? L->d.iqn_K : 1);  // fractions per env and step (agent.py:25-39 with IQNHead.qval / FQFHead.qval, model.py:253-257,280-284)
     if (quant && a->h == nullptr) {
         const long long R = (long long)E * nt;
         if (a0_dense_fwd_scratch((int)R, L->feat, 64) != 0) return a0_fail(A0_EINVAL, "a0_actor_rollout: E * K rows too few for the embedding kernel this path takes");
         a->h = a->mem.alloc<float>(R * 512);
         a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs((int)R, L->Npad, 512) * R * L->Npad);
-        const long long sc = a0_dense_fwd_scratch((int)R, 512, L->feat);
+        long long sc = a0_dense_fwd_scratch((int)R, 512, L->feat);
+        if (fqf && a0_dense_fwd_scratch(E, 32, L->feat) > sc) sc = a0_dense_fwd_scratch(E, 32, L->feat);
         a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
         a->q_taus = a->mem.alloc<float>(ceil_to(R, 4)); a->q_cosx = a->mem.alloc<float>(R * 64); a->q_x = a->mem.alloc<float>(R * L->feat);
+        if (fqf) { a->f_logits = a->mem.alloc<float>((long long)E * 32); a->f_tau_all = a->mem.alloc<float>((long long)E * (nt + 1)); }
         a->dist_Npad = L->Npad;
     }
     if (dist && (a->h == nullptr || a->dist_Npad != L->Npad)) {
@@ -318,7 +321,12 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             // first-max argmax, epsilon-greedy, env step, n-step bookkeeping and the replay row
             const int rows = E * nt;
             const float* on = L->online;
-            A0_CHECK(a0_rng_uniform(a->rng.seed, 3 /* STREAM_TAUS */, a->rng.reserve(3, rows), a->q_taus, rows, stream));
+            if (fqf) {      // FQFHead.prop_taus (model.py:268-278): the fraction net on the step's features; no draws
+                A0_CHECK(a0_dense_fwd(a->act3, L->feat, on + L->frac.w(), on + L->frac.b(), a->f_logits, E, 32, L->feat, 0, a->fwd_scratch, stream));
+                A0_CHECK(a0_fqf_taus(a->f_logits, 32, a->f_tau_all, a->q_taus, E, nt, stream));
+            } else {
+                A0_CHECK(a0_rng_uniform(a->rng.seed, 3 /* STREAM_TAUS */, a->rng.reserve(3, rows), a->q_taus, rows, stream));
+            }
             A0_CHECK(a0_cos_features(a->q_taus, a->q_cosx, rows, 64, stream));
             A0_CHECK(a0_dense_fwd_mul(a->q_cosx, 64, on + L->cos.w(), on + L->cos.b(), a->act3, nt, a->q_x, rows, L->feat, 64, 1, stream));
             A0_CHECK(a0_dense_fwd(a->q_x, L->feat, on + L->fc1.w(), on + L->fc1.b(), a->h, rows, 512, L->feat, 1, a->fwd_scratch, stream));
@@ -327,7 +335,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);
             const int nx = (a->cur + 1) % a->K;
             a->g += 1;
-            A0_CHECK(a0_actor_quantile_tail_env_step(a->head_slabs, (long long)rows * L->Npad, ns, on + L->head.b(), L->Npad, A, nt, a->d.dueling ? 1 : 0, 1, nullptr, E, a->rng.seed,
+            A0_CHECK(a0_actor_quantile_tail_env_step(a->head_slabs, (long long)rows * L->Npad, ns, on + L->head.b(), L->Npad, A, nt, a->d.dueling ? 1 : 0, fqf ? 3 : 1, fqf ? a->f_tau_all : nullptr, E, a->rng.seed,
                                                      STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed,
                                                      a->d.rank, a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
                                                      a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act,

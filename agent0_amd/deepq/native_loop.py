@@ -8,7 +8,7 @@ target, Adam moments, status words, loss ring, weight copies, NoisyNet buffers, 
 reader of ``trainer.replay`` keep seeing the live data, with no copies in either direction.  What the handles own themselves: the actor's env state and Philox
 offsets, the sampler's state (epochs / beta), the workspaces.
 
-Scope = what the handles cover (include/agent0_hip.h): dqn (A + dueling <= 24, no NoisyNet), c51 (any) and iqn (no NoisyNet) on 4 x 84 x 84 observations, the device-resident env,
+Scope = what the handles cover (include/agent0_hip.h): dqn (A + dueling <= 24, no NoisyNet), c51 (any), iqn and fqf (no NoisyNet) on 4 x 84 x 84 observations, the device-resident env,
 uniform or sum-tree replay, one GPU, the ``main`` schedule.  Everything else — and any Trainer whose hot-loop methods a test harness has wrapped — stays on the Python
 classes.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
 """
@@ -39,7 +39,7 @@ class _ActorDesc(C.Structure):
 class _LearnerBuffers(C.Structure):
     _fields_ = [("online", C.c_void_p), ("target", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("state", C.c_void_p), ("scalars", C.c_void_p),
                 ("loss_ring", C.c_void_p), ("loss_ring_cap", C.c_int), ("wt_online", C.c_void_p), ("wt_target", C.c_void_p), ("eff_online", C.c_void_p), ("eff_target", C.c_void_p),
-                ("noise", C.c_void_p)]
+                ("noise", C.c_void_p), ("rms_sq", C.c_void_p)]
 
 
 class _Batch(C.Structure):
@@ -64,9 +64,9 @@ def eligible(tr) -> Optional[str]:
     if algo == "dqn":
         if lc.noisy_net or cfg.action_dim + (1 if lc.dueling_head else 0) > 24:
             return "dqn handle: no NoisyNet, A + dueling <= 24"
-    elif algo == "iqn":
+    elif algo in ("iqn", "fqf"):
         if lc.noisy_net or cfg.action_dim + (1 if lc.dueling_head else 0) > 32 or not getattr(tr.actors[1], "quant_tail", False):
-            return "iqn handle: no NoisyNet, A + dueling <= 32, the merged quantile tail"
+            return "quantile handles: no NoisyNet, A + dueling <= 32, the merged quantile tail"
     elif algo != "c51":
         return f"no handle for {algo}"
     if tuple(cfg.obs_shape) != (4, 84, 84):
@@ -102,11 +102,11 @@ class NativeLoop:
         self.prio = rp.prioritize
         # ---- learner over the engine's buffers
         desc = _abi.LearnerDesc(int(cfg.action_dim), int(bool(lc.dueling_head)), int(bool(lc.double_q)), self.B, int(lc.n_step_q), float(lc.discount), float(lc.learning_rate),
-                                float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1, "iqn": 2}[lc.algo.name], int(lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
+                                float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1, "iqn": 2, "fqf": 3}[lc.algo.name], int(lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
                                 int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF, int(lc.iqn.K), int(lc.iqn.N), int(lc.iqn.N_dash), int(lc.iqn.F))
         p = lambda t: None if t is None else t.data_ptr()
         bufs = _LearnerBuffers(p(eng.online.flat), p(eng.target.flat), p(eng.grads), p(eng.adam_m), p(eng.adam_v), p(eng.state), p(eng.scalars), p(eng.loss_ring),
-                               int(eng.loss_ring.numel()), p(eng.online.wt), p(eng.target.wt), p(eng.online.eff), p(eng.target.eff), p(eng.noise_joint))
+                               int(eng.loss_ring.numel()), p(eng.online.wt), p(eng.target.wt), p(eng.online.eff), p(eng.target.eff), p(eng.noise_joint), p(getattr(eng, "rms_sq", None)))
         self.learner = C.c_void_p()
         ok(lib.a0_learner_create_on(C.addressof(desc), C.addressof(bufs), C.addressof(self.learner)), "a0_learner_create_on")
         assert int(lib.a0_learner_param_floats(self.learner)) == L.n_params_padded
@@ -131,6 +131,8 @@ class NativeLoop:
         self.loss_ptr = lp                                # the learner's own per-sample losses: update_priority reads them in place
         self._qs, self._rs, self._nret = (C.c_float * self.T)(), (C.c_float * (self.T * self.E))(), C.c_int()
         self._pending_rollout = False
+        self.fqf = lc.algo.name == "fqf"
+        self._floss = ops.empty(self.B) if self.fqf else None
         self.frames_ptr = p(rp.frames)
         self.row_bytes = int(rp.row_bytes)
 
@@ -159,11 +161,16 @@ class NativeLoop:
         eng, ln = tr.learner.engine, tr.learner
         b = _Batch()
         n = int(cfg.learner.learner_steps)
-        for _ in range(n):
+        if self.fqf and tr._floss_means.numel() < n:
+            tr._loss_means, tr._floss_means = tr.ops.zeros(n), tr.ops.zeros(n)
+        for i in range(n):
             ok(lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
             ok(lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, None, st), "a0_learner_update")
             if self.prio:
                 ok(lib.a0_rbuf_update_priority(self.rbuf, self.loss_ptr, eng.state.data_ptr(), st), "a0_rbuf_update_priority")
+            if self.fqf:                                  # the `fraction_loss` statistic (trainer.py:99-101): batch mean of the update's fraction losses
+                ok(lib.a0_learner_get_frac_loss(self.learner, self._floss.data_ptr(), st), "a0_learner_get_frac_loss")
+                tr.ops.mean_rows(self._floss, 1, self.B, tr._floss_means[i:i + 1])
         tr._ring0 = ln.updates_issued                     # the Adam launch wrote the block's batch-mean losses to ring slots ring0 .. ring0 + n - 1
         ln.updates_issued += n
         if self.prio:
@@ -180,7 +187,7 @@ class NativeLoop:
         self._pending_rollout = False
         self._commit(st)
         n_upd = self._block(st)
-        blk = tr._block_stats_async(n_upd, False)         # loss ring -> page-locked buffer, stream-ordered behind the block
+        blk = tr._block_stats_async(n_upd, self.fqf and n_upd > 0)      # loss ring (+ fraction-loss means) -> page-locked buffers, stream-ordered behind the block
         ok(lib.a0_actor_collect_begin(self.actor, st), "a0_actor_collect_begin")
         if prefetch:
             self._rollout(st)                             # the next iteration's rollout before the host waits for this one's statistics

@@ -282,7 +282,7 @@ int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, floa
  * enqueues the same launches, in the same order, as the per-kernel entry points above (bit-identical results), never allocates and never synchronises.
  * algo = A0_ALGO_C51 (round 4): C51Learner.train_step (agent.py:218-268) — BASELINE configs[2], with NoisyLinear layers (model.py:28-87; packed as fc1.mu | fc1.sigma |
  * head.mu | head.sigma, composed weights and the noise vectors in HBM of the handle, both networks' noise redrawn per update from Philox stream 4 of `seed` exactly
- * as BaseLearner.train does, agent.py:125-127), dueling, double-Q and n-step.  algo = A0_ALGO_IQN: BASELINE configs[3].  qr, fqf and mdqn are composed from the per-kernel
+ * as BaseLearner.train does, agent.py:125-127), dueling, double-Q and n-step.  algo = A0_ALGO_IQN / A0_ALGO_FQF: BASELINE configs[3] / [4].  qr and mdqn are composed from the per-kernel
  * entry points (agent0_amd/deepq/engine.py shows the order). */
 #define A0_ALGO_DQN 0
 #define A0_ALGO_C51 1
@@ -371,7 +371,7 @@ int a0_rbuf_sample(a0_rbuf* replay, a0_batch* out, void* stream);
 /* ReplayDataset.update_priority with the last batch's indices and the learner's per-sample losses; learner_state: a0_learner_get's status words or NULL */
 int a0_rbuf_update_priority(a0_rbuf* replay, const float* loss, const int* learner_state, void* stream);
 
-/* a0_actor = Actor (agent.py:19-90) on the device-resident synthetic env for the heads a0_learner covers (scalar; categorical with or without NoisyNet; implicit quantile): observations, epsilon-greedy Philox streams (seed, rank), n-step ring,
+/* a0_actor = Actor (agent.py:19-90) on the device-resident synthetic env for the heads a0_learner covers (scalar; categorical with or without NoisyNet; implicit quantile; fully parameterised quantile): observations, epsilon-greedy Philox streams (seed, rank), n-step ring,
  * episode statistics.  a0_actor_rollout = Actor.sample: T steps acting with the learner's online network, transitions written into the replay ring at its write
  * cursor (then a0_rbuf_commit(replay, T * E)); a0_actor_collect waits for the stream and returns qs [T] and the finished episodes' returns (host memory). */
 typedef struct a0_actor a0_actor;

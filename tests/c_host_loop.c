@@ -1,7 +1,7 @@
 /* BASELINE configs[1] — Breakout-shaped dqn, 256 vectorized envs x 80 steps + 20 updates of batch 512 per iteration — configs[2] — c51 rainbow-lite: NoisyNet,
- * dueling, double-Q, 3-step returns, prioritized replay — or configs[3] — Asterix-shaped (9 actions) implicit quantile network — run by a host that is NOT Python: plain C against include/agent0_hip.h, the three handles
+ * dueling, double-Q, 3-step returns, prioritized replay — configs[3] — Asterix-shaped (9 actions) implicit quantile network — or configs[4]'s per-GPU workload — fqf on 9 actions — run by a host that is NOT Python: plain C against include/agent0_hip.h, the three handles
  * a0_actor / a0_rbuf / a0_learner (library-owned HBM) and the loop of trainer.py:74-119,171-184 written out.
- * usage: c_host_loop [iterations] [replay_size] [env_task 0|1] [config 1|2|3]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
+ * usage: c_host_loop [iterations] [replay_size] [env_task 0|1] [config 1|2|3|4]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
 #include <hip/hip_runtime_api.h>      /* gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include */
 #include <math.h>
 #include <stdio.h>
@@ -21,12 +21,12 @@ int main(int argc, char** argv) {
     const long long size = argc > 2 ? atoll(argv[2]) : 100000;
     const int task = argc > 3 ? atoi(argv[3]) : A0_ENV_TASK_STREAM;
     const int config = argc > 4 ? atoi(argv[4]) : 1;
-    const int E = 256, T = 80, B = 512, LSTEPS = 20, A = config == 3 ? 9 : 4, OBS = 4 * 84 * 84;
+    const int E = 256, T = 80, B = 512, LSTEPS = 20, A = config >= 3 ? 9 : 4, OBS = 4 * 84 * 84;
     const long long start_steps = size < 100000 ? size / 2 : 100000, exploration = 1000000;
     const double min_eps = 0.01;
     const int rainbow = config == 2;
-    a0_learner_desc ld = {A, rainbow, rainbow, B, rainbow ? 3 : 1, 0.99, 5e-4, 0.0, 500, rainbow ? A0_ALGO_C51 : (config == 3 ? A0_ALGO_IQN : A0_ALGO_DQN), 51, -10.0, 10.0, rainbow,
-                          42 + 15485863, /* iqn K, N, N' */ 32, 64, 64};
+    a0_learner_desc ld = {A, rainbow, rainbow, B, rainbow ? 3 : 1, 0.99, 5e-4, 0.0, 500, rainbow ? A0_ALGO_C51 : (config == 3 ? A0_ALGO_IQN : (config == 4 ? A0_ALGO_FQF : A0_ALGO_DQN)), 51, -10.0, 10.0,
+                          rainbow, 42 + 15485863, /* iqn K, N, N' */ 32, 64, 64, /* fqf F */ 32};
     a0_rbuf_desc rd = {size, OBS, B, rainbow, 0.5, 0.01, 0.4, 10000000, 42 + 104729};
     a0_actor_desc ad = {E, T, A, rainbow, rainbow ? 3 : 1, 0.99, 42, 0, task, 4};
     a0_learner* L = NULL; a0_rbuf* R = NULL; a0_actor* ac = NULL;
@@ -80,7 +80,8 @@ int main(int argc, char** argv) {
            "\"config\": \"%s\"}\n",
            timed, 1e3 * dt / timed, (double)timed * T * E / dt, frames, updates, episodes, episodes ? ret_sum / (double)episodes : 0.0, mean, qmax, finite, size, task,
            rainbow ? "BASELINE configs[2]: c51 + NoisyNet + dueling + double-Q + 3-step + prioritized replay"
-                   : (config == 3 ? "BASELINE configs[3]: iqn, 9 actions, K = 32, N = N' = 64, uniform replay" : "BASELINE configs[1]: dqn, uniform replay"));
+                   : (config == 3 ? "BASELINE configs[3]: iqn, 9 actions, K = 32, N = N' = 64, uniform replay"
+                                  : (config == 4 ? "BASELINE configs[4] (one GPU's share): fqf, 9 actions, F = 32, uniform replay" : "BASELINE configs[1]: dqn, uniform replay")));
     CHECK(a0_actor_destroy(ac)); CHECK(a0_rbuf_destroy(R)); CHECK(a0_learner_destroy(L));
     return 0;
 }

@@ -624,8 +624,11 @@ RAINBOW = {"learner.double_q": "true", "learner.dueling_head": "true", "learner.
                                         ("dqn", {"replay.policy": "prioritize", "learner.n_step_q": 3, "env_task": "block"}), ("c51", {}), ("c51", RAINBOW),
                                         ("c51", {**RAINBOW, "env_task": "block", "actor.sample_steps": 10, "learner.reset_noise_freq": 3}),
                                         ("iqn", {"env_id": "Asterix"}), ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3,
+                                                                               "replay.policy": "prioritize", "env_task": "block"}),
+                                        ("fqf", {"env_id": "Asterix"}), ("fqf", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3,
                                                                                "replay.policy": "prioritize", "env_task": "block"})],
-                         ids=["dqn-uniform", "duel-double-n3", "prioritized-n3-block", "c51", "rainbow-lite", "rainbow-lite-block-noise3", "iqn", "iqn-duel-double-n3-per-block"])
+                         ids=["dqn-uniform", "duel-double-n3", "prioritized-n3-block", "c51", "rainbow-lite", "rainbow-lite-block-noise3", "iqn", "iqn-duel-double-n3-per-block", "fqf",
+                              "fqf-duel-double-n3-per-block"])
 def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     """Round 4 (opaque handles, library-owned HBM): ``a0_actor`` / ``a0_rbuf`` / ``a0_learner`` (csrc/runtime.hip, learner.hip) restate the host-side
     bookkeeping of the Python classes — cursors, shuffled epochs, Philox offsets, beta, epsilon — in C++, so that a host needs a handful of C calls per iteration.
@@ -659,7 +662,7 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     A = int(cfg.action_dim)
     nat = tr.ops.native_learner(A=A, dueling=duel, double_q=dq, B=B, n_step=n, discount=cfg.learner.discount, lr=cfg.learner.learning_rate, target_update_freq=TF, algo=algo,
                                 num_atoms=cfg.learner.c51.num_atoms, vmin=cfg.learner.c51.vmin, vmax=cfg.learner.c51.vmax, noisy=noisy, seed=cfg.seed + 15485863,
-                                K=cfg.learner.iqn.K, N=cfg.learner.iqn.N, N_dash=cfg.learner.iqn.N_dash)
+                                K=cfg.learner.iqn.K, N=cfg.learner.iqn.N, N_dash=cfg.learner.iqn.N_dash, F=cfg.learner.iqn.F)
     nat.set_params(eng.online.flat, eng.target.flat)
     rd = RbufDesc(SIZE, 4 * 84 * 84, B, int(prio), cfg.replay.alpha, cfg.replay.eps, cfg.replay.beta0, cfg.trainer.total_steps, cfg.seed + 104729)
     rb = C.c_void_p()
@@ -715,8 +718,11 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
 @pytest.mark.parametrize("algo,extra", [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
                                         ("c51", {"env_task": "block"}), ("c51", RAINBOW), ("c51", {**RAINBOW, "learner.reset_noise_freq": 3, "env_task": "block"}),
                                         ("iqn", {"env_id": "Asterix", "env_task": "block"}),
-                                        ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"})],
-                         ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block", "iqn-block", "iqn-duel-double-n3-per"])
+                                        ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
+                                        ("fqf", {"env_id": "Asterix", "env_task": "block"}),
+                                        ("fqf", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"})],
+                         ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block", "iqn-block", "iqn-duel-double-n3-per", "fqf-block",
+                              "fqf-duel-double-n3-per"])
 def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
     """agent0_amd/deepq/native_loop.py: for the configurations the handles cover, ``Trainer.run_iteration`` hands the loop to a0_actor / a0_rbuf / a0_learner created
     OVER the Python classes' own buffers (a0_learner_create_on / a0_rbuf_create_on) — one C call per rollout, batch and update, eager launches from native code.
@@ -739,7 +745,7 @@ def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
         eng, rp = tr.learner.engine, tr.replay
         n_len = len(rp)
         tree = rp.tree.clone() if rp.prioritize else torch.zeros(1)
-        out = (res, list(tr.Ls), list(tr.Qs), list(tr.Rs), tr.frame_count, n_len, rp.written, float(rp.beta) if rp.prioritize else 0.0, rp.max_p if rp.prioritize else 1.0,
+        out = (res, list(tr.Ls) + list(tr.FLs), list(tr.Qs), list(tr.Rs), tr.frame_count, n_len, rp.written, float(rp.beta) if rp.prioritize else 0.0, rp.max_p if rp.prioritize else 1.0,
                eng.online.flat.clone(), eng.target.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.state.clone(), rp.frames.clone(), rp.act.clone(), rp.rew.clone(),
                rp.done.clone(), tree, sd)
         tr.test = lambda: None
@@ -748,7 +754,7 @@ def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
 
     a = run(False)
     b = run(True)
-    assert len(a[1]) == 9 * 5 and a[4] == 10 * 96
+    assert len(a[1]) == 9 * 5 * (2 if algo == "fqf" else 1) and a[4] == 10 * 96
     for i, (x, y) in enumerate(zip(a, b)):
         if isinstance(x, torch.Tensor):
             assert torch.equal(x, y), f"item {i}"
@@ -793,10 +799,10 @@ def _rbuf_frames(lib, rb):
     return p
 
 
-@pytest.mark.parametrize("config", [1, 2, 3])
+@pytest.mark.parametrize("config", [1, 2, 3, 4])
 def test_plain_c_host_runs_baseline_config1(tmp_path, config):
     """tests/c_host_loop.c: BASELINE configs[1]'s workload (256 envs x 80 steps + 20 updates of batch 512 per iteration; a 40 000-slot ring here) — and configs[2]'s
-    (c51 rainbow-lite on prioritized replay) and configs[3]'s (Asterix-shaped iqn) — driven from plain C through the a0_actor / a0_rbuf / a0_learner handles — no Python, no torch in the process.
+    (c51 rainbow-lite on prioritized replay) configs[3]'s (Asterix-shaped iqn) and configs[4]'s per-GPU share (fqf) — driven from plain C through the a0_actor / a0_rbuf / a0_learner handles — no Python, no torch in the process.
     Compiled with gcc against the in-tree library, run as a child."""
     import json, os, shutil, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -813,4 +819,4 @@ def test_plain_c_host_runs_baseline_config1(tmp_path, config):
     print(out)
     it = 12 if config < 3 else 4
     assert out["iterations_timed"] == it and out["updates"] == it * 20 and out["finite"] == 1 and out["episodes"] > 100
-    assert out["env_frames_per_sec"] > {1: 5e5, 2: 3e5, 3: 1e5}[config], "a C host has no reason to be slower than the Python one"
+    assert out["env_frames_per_sec"] > {1: 5e5, 2: 3e5, 3: 1e5, 4: 1e5}[config], "a C host has no reason to be slower than the Python one"
