@@ -34,11 +34,11 @@ def test_every_family_learns_the_block_task(name, algo, extra, frames, env_id, l
     check_learned(r)
 
 
-@pytest.mark.parametrize("name,algo,extra", [("dqn", "dqn", {}), ("c51_rainbow_lite", "c51", LR.RAINBOW)])
-def test_the_native_loop_learns_the_block_task(name, algo, extra, monkeypatch):
+@pytest.mark.parametrize("name,algo,extra,env_id", [("dqn", "dqn", {}, "Breakout"), ("c51_rainbow_lite", "c51", LR.RAINBOW, "Breakout"), ("fqf", "fqf", {}, "Asterix")])
+def test_the_native_loop_learns_the_block_task(name, algo, extra, env_id, monkeypatch):
     """The same criterion with the loop issued by the library's own handles (agent0_amd/deepq/native_loop.py: the production default for these configurations)."""
     monkeypatch.setenv("A0_NATIVE_LOOP", "1")
-    r = LR.run(algo, extra, 2_600_000)
+    r = LR.run(algo, extra, 2_600_000, env_id=env_id)
     r["name"] = name
     assert r["host_loop"] == "native handles"
     check_learned(r)

@@ -14,6 +14,8 @@ for rep in 0 1 2; do
   python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry --steps 10 --warmup 3 $C51 2> /dev/null > gpurun_out/$R/c_host_py2_$rep.json || exit 1
   A0_NATIVE_LOOP=0 python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry --steps 10 --warmup 3 $C51 2> /dev/null > gpurun_out/$R/c_host_pg2_$rep.json || exit 1
 done
+/tmp/c_host_loop 6 1000000 0 3 > gpurun_out/$R/c_host_3.json || exit 1
+/tmp/c_host_loop 6 1000000 0 4 > gpurun_out/$R/c_host_4.json || exit 1
 python3 - <<PY
 import json
 R = "$R"
@@ -24,7 +26,9 @@ for c, key in ((1, "configs[1]"), (2, "configs[2]")):
     cs = [rd(f"c_host_{c}_{r}.json") for r in range(3)]
     out[key] = {"c_host_ms": [x["ms_per_iteration"] for x in cs], "python_native_loop_ms": [rd(f"c_host_py{c}_{r}.json")["ms_per_step"] for r in range(3)],
                 "python_classes_hipgraph_ms": [rd(f"c_host_pg{c}_{r}.json")["ms_per_step"] for r in range(3)], "c_host_last": cs[-1]}
+out["configs[3]"] = {"c_host_last": rd("c_host_3.json")}
+out["configs[4] (one GPU's share)"] = {"c_host_last": rd("c_host_4.json")}
 json.dump(out, open(f"gpurun_out/{R}/c_host_loop.json", "w"), indent=1)
-print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "c_host_last"} for k, v in out.items() if k != "note"}))
+print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk != "c_host_last"} or v["c_host_last"]["ms_per_iteration"]) for k, v in out.items() if k != "note"}))
 PY
-rm -f gpurun_out/$R/c_host_1_*.json gpurun_out/$R/c_host_2_*.json gpurun_out/$R/c_host_py*.json gpurun_out/$R/c_host_pg*.json
+rm -f gpurun_out/$R/c_host_1_*.json gpurun_out/$R/c_host_2_*.json gpurun_out/$R/c_host_py*.json gpurun_out/$R/c_host_pg*.json gpurun_out/$R/c_host_3.json gpurun_out/$R/c_host_4.json
