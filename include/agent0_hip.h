@@ -53,7 +53,7 @@ typedef struct a0_frames_arg {
     int chan_off;               /* 0 = st, 4*H*W = st_next half of a replay row (agent0/deepq/agent.py:132-135) */
 } a0_frames_arg;
 
-/* one pending slab reduction: out[i] = sum_z slabs[z * slab_stride + i], i < count (z ascending: deterministic) */
+/* one pending slab reduction of a weight gradient (loss.backward(), agent.py:153-155): out[i] = sum_z slabs[z * slab_stride + i], i < count (z ascending: deterministic) */
 typedef struct a0_reduce_seg { const float* slabs; long long slab_stride; int nslab; float* out; long long count; } a0_reduce_seg;
 typedef struct a0_pending_reduce { a0_reduce_seg seg[4]; int n; } a0_pending_reduce;
 
@@ -304,7 +304,7 @@ typedef struct a0_learner_desc {
     int fqf_F;                        /* fqf: learner.iqn.F fractions (<= 32) */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
-/* The same handle over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the
+/* BaseLearner.__init__ (agent.py:97-110) over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the
  * parameters — the Python classes' flat tensors, a checkpointing layer — hand the update loop to the library without copies (agent0_amd/deepq/native_loop.py).  Sizes:
  * online / target / adam_m / adam_v a0_learner_param_floats floats (known from a throw-away handle or deepq/layout.py), grads 4 more, state 8 ints, scalars 4,
  * loss_ring loss_ring_cap floats (the per-update batch-mean loss lands in slot state[6] % cap), wt_* a0_net_conv_wt_floats(4), eff_* the composed NoisyNet weights
@@ -320,7 +320,7 @@ typedef struct a0_learner_buffers {
     float* rms_sq;                    /* fqf: the fraction net's RMSprop state, 32 * feat + 32 floats */
 } a0_learner_buffers;
 int a0_learner_create_on(const a0_learner_desc* desc, const a0_learner_buffers* buffers, a0_learner** out);
-/* the next draw offset of one of the learner's Philox streams (4 = NoisyNet noise) */
+/* the next draw offset of one of the learner's Philox streams (3 = the quantile fractions of agent.py:300-310, 4 = NoisyNet's reset_noise of agent.py:125-127) */
 int a0_learner_set_rng(a0_learner* learner, int stream_id, unsigned long long offset);
 int a0_learner_destroy(a0_learner* learner);
 long long a0_learner_param_floats(const a0_learner* learner);
@@ -328,8 +328,8 @@ long long a0_learner_param_floats(const a0_learner* learner);
 int a0_learner_set_params(a0_learner* learner, const float* online_packed, const float* target_packed, void* stream);
 /* copies of what the handle holds (any pointer may be NULL): parameters, target parameters, Adam moments (param_floats each), the eight status words */
 int a0_learner_get(const a0_learner* learner, float* online_out, float* target_out, float* adam_m_out, float* adam_v_out, int* state_out8, void* stream);
-/* the handle's own buffer of per-sample losses [B] of the last update (device pointer, valid for the handle's lifetime): what a0_rbuf_update_priority takes without
- * the copy a non-NULL loss_out of a0_learner_update costs */
+/* the handle's own buffer of per-sample losses [B] of the last update — BaseLearner.train's return value (agent.py:163-169) — as a device pointer valid for the
+ * handle's lifetime: what a0_rbuf_update_priority (trainer.py:103-104) takes without the copy a non-NULL loss_out of a0_learner_update costs */
 int a0_learner_loss_buffer(const a0_learner* learner, float** loss_dev);
 /* fqf: a copy of the per-sample fraction losses [B] of the last update (the `fraction_loss` statistic, trainer.py:99-101) into out_dev */
 int a0_learner_get_frac_loss(const a0_learner* learner, float* out_dev, void* stream);
@@ -353,7 +353,7 @@ typedef struct a0_rbuf_desc {
 } a0_rbuf_desc;
 typedef struct a0_batch { const long long* idx; const int* slot; const int* act; const float* rew; const float* done; const float* prio; const float* weights; } a0_batch;
 int a0_rbuf_create(const a0_rbuf_desc* desc, a0_rbuf** out);
-/* over ring buffers the caller already holds (each may be NULL: library-owned): frames [size * 2 * obs_bytes] u8, act i32 / rew / done f32 [size], tree f32
+/* ReplayDataset.__init__ (replay.py:14-30) over ring buffers the caller already holds (each may be NULL: library-owned): frames [size * 2 * obs_bytes] u8, act i32 / rew / done f32 [size], tree f32
  * [2 * 2^ceil(log2 size)] (prioritized), max_p f32 [1] (must hold the caller's current max priority: 1 for an empty ring) */
 int a0_rbuf_create_on(const a0_rbuf_desc* desc, uint8_t* frames, int* act, float* rew, float* done, float* tree, float* max_p, a0_rbuf** out);
 int a0_rbuf_destroy(a0_rbuf* replay);
@@ -388,7 +388,7 @@ int a0_actor_destroy(a0_actor* actor);
  * network's noise every reset_noise_freq steps from ITS Philox stream 4 and recomposes the effective weights, agent.py:52-53) */
 int a0_actor_rollout(a0_actor* actor, a0_learner* learner, a0_rbuf* replay, float epsilon, void* stream);
 int a0_actor_collect(a0_actor* actor, float* qs_host, float* returns_host, int max_returns, int* n_returns, void* stream);
-/* a0_actor_collect in two halves, so that the next rollout can be enqueued before the host waits: _begin enqueues the copies of the statistics into page-locked
+/* a0_actor_collect (the rs / qs of Actor.sample, agent.py:85-90) in two halves, so that the next rollout can be enqueued before the host waits: _begin enqueues the copies of the statistics into page-locked
  * buffers of the handle and records an event (call it BEFORE the next a0_actor_rollout, which reuses the device buffers); _end waits for that event only */
 int a0_actor_collect_begin(a0_actor* actor, void* stream);
 int a0_actor_collect_end(a0_actor* actor, float* qs_host, float* returns_host, int max_returns, int* n_returns);
@@ -458,7 +458,7 @@ int a0_priority_from_loss(const float* loss, int n, float eps, float alpha, floa
 int a0_sumtree_set_from_loss_ok(long long cap2);
 int a0_sumtree_set_from_loss(float* tree, long long cap2, const long long* idx, const float* loss, int n, float eps, float alpha, float* pstate, const int* state,
                              int defer_top, void* stream);
-/* defer_top = 1: leaves and subtrees only (one launch); tree[1 .. 2047] are stale until a0_sumtree_sample_batch(rebuild_top = 1), a0_sumtree_set_range (which
+/* defer_top = 1 (replay.py:55-59 followed by the next batch of trainer.py:63-72 in two launches): leaves and subtrees only (one launch); tree[1 .. 2047] are stale until a0_sumtree_sample_batch(rebuild_top = 1), a0_sumtree_set_range (which
  * recomputes the top from level 2048 anyway) or a0_sumtree_top_rebuild has run — every other reader of the top levels must be preceded by one of them */
 int a0_sumtree_top_rebuild(float* tree, long long cap2, void* stream);
 
