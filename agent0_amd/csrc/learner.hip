@@ -27,8 +27,10 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
     const a0_learner_buffers& U = bufs ? *bufs : none;
     if (U.loss_ring && U.loss_ring_cap < 1) return a0_fail(A0_EINVAL, "a0_learner_create_on: loss_ring_cap");
     if (d->A < 1 || d->B < 1 || d->n_step < 1 || !(d->discount > 0.0) || !(d->lr >= 0.0) || d->target_update_freq < 1 ||
-        (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51 && d->algo != A0_ALGO_IQN && d->algo != A0_ALGO_FQF))
+        (d->algo != A0_ALGO_DQN && d->algo != A0_ALGO_C51 && d->algo != A0_ALGO_IQN && d->algo != A0_ALGO_FQF && d->algo != A0_ALGO_QR && d->algo != A0_ALGO_MDQN))
         return a0_fail(A0_EINVAL, "a0_learner_create: bad description");
+    if (d->algo == A0_ALGO_QR && (d->num_atoms < 1 || d->num_atoms > 1024)) return a0_fail(A0_EINVAL, "a0_learner_create: qr needs 1 <= num_atoms <= 1024");
+    if (d->algo == A0_ALGO_MDQN && !(d->mdqn_tau > 0.0)) return a0_fail(A0_EINVAL, "a0_learner_create: mdqn needs tau > 0");
     if (d->algo == A0_ALGO_FQF && (d->noisy || d->fqf_F < 2 || d->fqf_F > 32 || d->A + (d->dueling ? 1 : 0) > 32))
         return a0_fail(A0_EINVAL, "a0_learner_create: fqf needs 2 <= F <= 32, no NoisyNet, A + dueling <= 32");
     if (d->algo == A0_ALGO_IQN && (d->noisy || d->iqn_K < 1 || d->iqn_N < 1 || d->iqn_N_dash < 1 || d->A + (d->dueling ? 1 : 0) > 32))
@@ -43,7 +45,8 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         a0_net_desc nd{4, 84, 84};
         if (a0_net_create(&nd, &L->net) != A0_OK) { delete L; return A0_EINVAL; }
         const bool c51 = d->algo == A0_ALGO_C51;
-        L->T = c51 ? d->num_atoms : 1;
+        const bool generic = d->algo == A0_ALGO_QR || d->algo == A0_ALGO_MDQN;          // dense heads evaluated layer by layer (engine.py's unfused path)
+        L->T = (c51 || d->algo == A0_ALGO_QR) ? d->num_atoms : 1;
         L->Nq = d->A * L->T;
         L->V = d->dueling ? L->T : 0;
         L->NQ = d->A + (d->dueling ? 1 : 0);
@@ -146,6 +149,25 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             for (int i = 0; i < L->T; ++i) at[(size_t)i] = i < L->T / 2 ? std::fmaf(step, (float)i, lo) : std::fmaf(-step, (float)(L->T - 1 - i), hi);
             A0_HIP_THROW(hipMemcpy(L->atoms, at.data(), (size_t)L->T * 4, hipMemcpyHostToDevice));
         }
+        if (generic) {
+            const long long nq = (long long)B * d->A * L->T;
+            auto gw = [&](a0_learner::DWs& w, float* act3, float* h, float* q) { w.act3 = act3; w.h = h ? h : L->alloc<float>((long long)B * 512); w.raw = L->alloc<float>((long long)B * L->Npad); w.q = q ? q : L->alloc<float>(nq); };
+            gw(L->go, L->act3_o, L->h, L->q_o);
+            gw(L->gt, L->act3_t, nullptr, L->q_t);
+            if (d->double_q && d->algo == A0_ALGO_QR) gw(L->gs, L->act3_s ? L->act3_s : (L->act3_s = L->alloc<float>((long long)B * L->feat)), nullptr, nullptr);
+            if (d->algo == A0_ALGO_MDQN) gw(L->gm, L->alloc<float>((long long)B * L->feat), nullptr, nullptr);
+            L->g_dq = L->alloc<float>(nq, true);
+            L->a_star = L->alloc<int>(B, true);
+            const long long s1 = a0_dense_fwd_scratch(B, 512, L->feat), s2 = a0_dense_fwd_scratch(B, L->Npad, 512);
+            L->fwd_scratch = L->alloc<float>(std::max(4LL, std::max(s1, s2)));
+            if (d->algo == A0_ALGO_QR) {
+                L->y = L->alloc<float>((long long)B * L->T);
+                L->qr_taus = L->alloc<float>(L->T);
+                std::vector<float> t((size_t)L->T);
+                for (int i = 0; i < L->T; ++i) t[(size_t)i] = (2.0f * (float)i + 1.0f) / (2.0f * (float)L->T);          // agent.py:274: the quantile midpoints
+                A0_HIP_THROW(hipMemcpy(L->qr_taus, t.data(), (size_t)L->T * 4, hipMemcpyHostToDevice));
+            }
+        }
         if (iqn) {
             const int K = fqf ? d->fqf_F : d->iqn_K, N = fqf ? d->fqf_F : d->iqn_N, Nd = fqf ? d->fqf_F : d->iqn_N_dash;
             L->rng.init(d->seed, 0);
@@ -184,6 +206,14 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
     *out = L;
     return A0_OK;
     A0_CATCH
+}
+
+// DeepQHead.forward (model.py:108-131; the distributional variants 137-177): relu(first_dense(x)), the q / value heads, the dueling combine — DeviceNet.head, dense branch
+static int a0_dense_head(a0_learner* L, bool target, a0_learner::DWs& w, void* stream) {
+    const int B = L->d.B;
+    A0_CHECK(a0_dense_fwd(w.act3, L->feat, L->Wf(target), L->bf(target), w.h, B, 512, L->feat, 1, L->fwd_scratch, stream));
+    A0_CHECK(a0_dense_fwd(w.h, 512, L->Wh(target), L->bh(target), w.raw, B, L->Npad, 512, 0, L->fwd_scratch, stream));
+    return a0_dueling_fwd(w.raw, L->Npad, w.q, B, L->d.A, L->T, L->d.dueling ? 1 : 0, stream);
 }
 
 // IQNHead.forward (model.py:235-251) for `n_tau` fractions per sample: cosine features, the embedding times the state features (in the embedding GEMM's epilogue where the
@@ -291,7 +321,38 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     a0_pending_reduce pend;
     pend.n = 0;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
-    if (L->d.algo == A0_ALGO_FQF) {
+    if (L->d.algo == A0_ALGO_QR || L->d.algo == A0_ALGO_MDQN) {
+        // ---- engine.py's layer-by-layer path: the passes' encoders in one launch, then per pass fc1, head, dueling combine
+        const bool mdqn = L->d.algo == A0_ALGO_MDQN;
+        const int T = L->T;
+        a0_encoder_pass passes[3];
+        int np = 0;
+        passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->gt.act3};
+        if (mdqn) passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_obs, B, nullptr, nullptr, L->gm.act3};            // the target network on the CURRENT observation (agent.py:202-204)
+        else if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->gs.act3};
+        passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->go.act3};
+        A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
+        A0_CHECK(a0_dense_head(L, true, L->gt, stream));
+        if (mdqn) {
+            A0_CHECK(a0_dense_head(L, true, L->gm, stream));
+            A0_CHECK(a0_dense_head(L, false, L->go, stream));
+            A0_CHECK(a0_loss_mdqn(L->go.q, L->gt.q, L->gm.q, A, act, rew, done, wgt, L->gamma_n, (float)L->d.mdqn_tau, (float)L->d.mdqn_lo, B, L->loss, L->g_dq, L->state, stream));
+        } else {
+            if (dq) {
+                A0_CHECK(a0_dense_head(L, false, L->gs, stream));
+                A0_CHECK(a0_select_action(L->gs.q, (long long)A * T, T, 1, B, A, T, 1, nullptr, L->a_star, nullptr, nullptr, stream));
+            } else {
+                A0_CHECK(a0_select_action(L->gt.q, (long long)A * T, T, 1, B, A, T, 1, nullptr, L->a_star, nullptr, nullptr, stream));
+            }
+            A0_CHECK(a0_dense_head(L, false, L->go, stream));
+            A0_CHECK(a0_quantile_target(L->gt.q, (long long)A * T, 1, T, L->a_star, rew, done, L->gamma_n, B, T, L->y, stream));
+            A0_HIP_THROW(hipMemsetAsync(L->g_dq, 0, (size_t)B * A * T * 4, (hipStream_t)stream));
+            A0_CHECK(a0_loss_quantile_huber(L->go.q, (long long)A * T, 1, T, L->y, L->qr_taus, 0, act, wgt, B, T, T, L->loss, L->g_dq, L->state, stream));
+        }
+        // DeviceLearner._backward_dense: the dueling combine's and the head's backward-data passes; fc1's and the weight gradients follow in the common block
+        A0_CHECK(a0_dueling_bwd(L->g_dq, L->draw, L->Npad, B, A, T, L->d.dueling ? 1 : 0, stream));
+        A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->h, L->dh, B, L->Npad, 512, stream));
+    } else if (L->d.algo == A0_ALGO_FQF) {
         // ---- FQFLearner.train_step (agent.py:334-388) in the order of agent0_amd/deepq/engine.py's fqf path
         const int F = L->F;
         a0_encoder_pass passes[3];

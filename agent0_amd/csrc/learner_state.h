@@ -49,6 +49,9 @@ struct a0_learner {
     struct FWs { float *logits = nullptr, *tau_all = nullptr, *tau_hat = nullptr; } fo, ft, fs;
     QWs qf;                                                   // q at the interior fractions taus[1:-1] (F - 1 per sample) on the online features
     float *inner_taus = nullptr, *rms_sq = nullptr, *frac_loss = nullptr, *dfrac = nullptr, *clip = nullptr;
+    // ---- dense heads evaluated layer by layer (A0_ALGO_QR, A0_ALGO_MDQN): fc1 output, raw head output, combined head output per pass; dq of the differentiated pass
+    struct DWs { float *act3 = nullptr, *h = nullptr, *raw = nullptr, *q = nullptr; } go, gt, gs, gm;      // online on s, target on s', online on s' (double-Q), target on s (mdqn)
+    float *g_dq = nullptr, *qr_taus = nullptr;
     long long slab_off3[3] = {0, 0, 0};
     // effective (W, b) of a dense layer of the online / target network
     const float* Wf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.w() : (tg ? target : online) + fc1.w(); }

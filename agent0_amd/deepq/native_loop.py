@@ -103,7 +103,7 @@ class NativeLoop:
         # ---- learner over the engine's buffers
         desc = _abi.LearnerDesc(int(cfg.action_dim), int(bool(lc.dueling_head)), int(bool(lc.double_q)), self.B, int(lc.n_step_q), float(lc.discount), float(lc.learning_rate),
                                 float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1, "iqn": 2, "fqf": 3}[lc.algo.name], int(lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
-                                int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF, int(lc.iqn.K), int(lc.iqn.N), int(lc.iqn.N_dash), int(lc.iqn.F))
+                                int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF, int(lc.iqn.K), int(lc.iqn.N), int(lc.iqn.N_dash), int(lc.iqn.F), float(lc.mdqn.tau), float(lc.mdqn.lo))
         p = lambda t: None if t is None else t.data_ptr()
         bufs = _LearnerBuffers(p(eng.online.flat), p(eng.target.flat), p(eng.grads), p(eng.adam_m), p(eng.adam_v), p(eng.state), p(eng.scalars), p(eng.loss_ring),
                                int(eng.loss_ring.numel()), p(eng.online.wt), p(eng.target.wt), p(eng.online.eff), p(eng.target.eff), p(eng.noise_joint), p(getattr(eng, "rms_sq", None)))

@@ -282,10 +282,12 @@ int a0_adam_step_sync_wt(float* params, const float* grads, float* exp_avg, floa
  * enqueues the same launches, in the same order, as the per-kernel entry points above (bit-identical results), never allocates and never synchronises.
  * algo = A0_ALGO_C51 (round 4): C51Learner.train_step (agent.py:218-268) — BASELINE configs[2], with NoisyLinear layers (model.py:28-87; packed as fc1.mu | fc1.sigma |
  * head.mu | head.sigma, composed weights and the noise vectors in HBM of the handle, both networks' noise redrawn per update from Philox stream 4 of `seed` exactly
- * as BaseLearner.train does, agent.py:125-127), dueling, double-Q and n-step.  algo = A0_ALGO_IQN / A0_ALGO_FQF: BASELINE configs[3] / [4].  qr and mdqn are composed from the per-kernel
- * entry points (agent0_amd/deepq/engine.py shows the order). */
+ * as BaseLearner.train does, agent.py:125-127), dueling, double-Q and n-step.  algo = A0_ALGO_IQN / A0_ALGO_FQF: BASELINE configs[3] / [4]; A0_ALGO_QR / A0_ALGO_MDQN: the reference's remaining learners
+ * (num_atoms quantiles per action for qr; NoisyNet allowed for both). */
 #define A0_ALGO_DQN 0
 #define A0_ALGO_C51 1
+#define A0_ALGO_QR 4    /* QRLearner.train_step (agent.py:272-293): num_atoms fixed quantiles per action, quantile Huber loss at the midpoints (2 i + 1) / (2 T) */
+#define A0_ALGO_MDQN 5  /* MDQNLearner.train_step (agent.py:194-215): Munchausen DQN, the target network also evaluated on the current observation */
 #define A0_ALGO_FQF 3   /* FQFLearner.train_step (agent.py:334-388) with the fraction proposal network (model.py:260-284; its own RMSprop step, agent.py:139-148): packed layout
                          * conv1 | conv2 | conv3 | fc1 | head | cos | frac, Adam over everything before frac; BASELINE configs[4] */
 #define A0_ALGO_IQN 2   /* IQNLearner.train_step (agent.py:296-331) with the cosine-embedding head (model.py:203-257): packed layout conv1 | conv2 | conv3 | fc1 | head | cos;
@@ -302,6 +304,7 @@ typedef struct a0_learner_desc {
     unsigned long long seed;          /* the learner's Philox seed (the Python classes use cfg.seed + 15485863): noise and tau draws */
     int iqn_K, iqn_N, iqn_N_dash;     /* iqn: learner.iqn.K / N / N_dash (config.py:103-109); 64 cosines */
     int fqf_F;                        /* fqf: learner.iqn.F fractions (<= 32) */
+    double mdqn_tau, mdqn_lo;         /* mdqn: learner.mdqn.tau / lo (config.py:88-92) */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
 /* BaseLearner.__init__ (agent.py:97-110) over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the

@@ -908,6 +908,51 @@ def test_native_fqf_learner_handle_equals_the_per_kernel_composition(hip, A, due
     nat.close()
 
 
+@pytest.mark.parametrize("algo,A,dueling,double_q,n_step,noisy,B", [("qr", 4, False, False, 1, False, 32), ("qr", 6, True, True, 3, True, 32), ("qr", 4, False, True, 1, False, 512),
+                                                                   ("mdqn", 4, False, False, 1, False, 64), ("mdqn", 18, True, False, 3, True, 32)],
+                         ids=["qr", "qr-duel-double-n3-noisy", "qr-b512", "mdqn", "mdqn-a18-duel-n3-noisy"])
+def test_native_qr_and_mdqn_learner_handles_equal_the_per_kernel_composition(hip, algo, A, dueling, double_q, n_step, noisy, B):
+    """The reference's remaining learners behind the handle: A0_ALGO_QR (200 fixed quantiles per action, quantile Huber at the midpoints, agent.py:272-293) and
+    A0_ALGO_MDQN (Munchausen DQN, agent.py:194-215: the target network also on the current observation), with NoisyNet, dueling, double-Q (qr) and n-step —
+    torch.equal to DeviceRng + DeviceLearner.update on losses, parameters, target, Adam moments and status words after each of four updates across a target sync."""
+    from agent0_amd.common.utils import DeviceRng
+    from agent0_amd.deepq.engine import DeviceLearner
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec(algo, A, dueling=dueling, noisy=noisy, **({"num_atoms": 200} if algo == "qr" else {}))
+    L = NetLayout.from_spec(spec)
+    cap = max(200, B + 40)
+    dev = DeviceLearner(hip, L, B, n_step=n_step, double_q=double_q, target_update_freq=3)
+    dev.online.load_state_dict(recipe.make_state_dict(spec, 11))
+    dev.target.load_state_dict(recipe.make_state_dict(spec, 12))
+    seed = 42 + 15485863
+    rng = DeviceRng(hip, seed)
+    if noisy:
+        rng.reserve(rng.STREAM_NOISE, dev.online.noise_len); rng.reserve(rng.STREAM_NOISE, dev.target.noise_len)      # BaseLearner.__init__: both networks' first noise
+    nat = hip.native_learner(A=A, dueling=dueling, double_q=double_q, B=B, n_step=n_step, discount=0.99, lr=5e-4, target_update_freq=3, algo=algo, num_atoms=L.T, noisy=noisy,
+                             seed=seed, mdqn_tau=dev.mdqn_tau, mdqn_lo=dev.mdqn_lo)
+    assert nat.n == L.n_params_padded
+    nat.set_params(dev.online.flat, dev.target.flat)
+    ring = torch.from_numpy(recipe.make_frames(cap, 5, spec.obs_shape)).to(hip.device).reshape(-1).contiguous()
+    loss_n = hip.empty(B)
+    for s in range(4):
+        slot = torch.from_numpy(recipe.gen(40 + s).permutation(cap)[:B].astype(np.int32)).to(hip.device)
+        a_np, r_np, d_np, w_np = recipe.make_transitions(B, A, 70 + s)
+        a, r, d, w = (torch.from_numpy(x).to(hip.device) for x in (a_np.astype(np.int32), r_np, d_np.astype(np.float32), w_np))
+        if noisy:
+            rng.normal(rng.STREAM_NOISE, 0.1, dev.noise_joint, dev.noise_joint.numel())
+        loss_e = dev.update(ring, slot, 2 * 28224, a, r, d, w).clone()
+        nat.update(ring, slot, 2 * 28224, a, r, d, w, loss_out=loss_n)
+        torch.cuda.synchronize()
+        on, tg, m, v, st = nat.get()
+        torch.cuda.synchronize()
+        assert torch.equal(loss_n, loss_e[:B]), f"update {s}: per-sample losses (max diff {float((loss_n - loss_e[:B]).abs().max())})"
+        assert torch.equal(on, dev.online.flat) and torch.equal(tg, dev.target.flat), f"update {s}: parameters / target"
+        assert torch.equal(m, dev.adam_m) and torch.equal(v, dev.adam_v), f"update {s}: Adam moments"
+        assert torch.equal(st, dev.state), f"update {s}: status words {st.tolist()} vs {dev.state.tolist()}"
+    assert int(st[1]) == 4 and not torch.equal(on, tg)
+    nat.close()
+
+
 def test_plain_c_host_drives_a_learner_through_the_c_abi(tmp_path):
     """The drop-in boundary is a C-ABI: tests/c_host_demo.c — plain C, include/agent0_hip.h and the HIP runtime, no Python, no torch — creates an a0_learner, loads
     parameters, runs three dueling double-Q n-step updates (one a0_learner_update call each) and reads the state back.  Compiled here with gcc (the HIP runtime's C API) against the in-tree
