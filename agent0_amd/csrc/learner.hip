@@ -9,7 +9,7 @@
 //
 // Scope: on 4 x 84 x 84 observations, the scalar-head learners (dqn; dueling; double-Q; n-step through discount^n) — BASELINE configs[1], the bench line — and
 // the categorical one (c51, also with NoisyLinear layers: BASELINE configs[2], rainbow-lite), the implicit quantile network (configs[3]) and the fully
-// parameterised quantile function (configs[4]).  qr and mdqn stay with the per-kernel entry points (INTEGRATION.md options A / B).
+// parameterised quantile function (configs[4]), plus qr and mdqn: the reference's six learners.
 #include "learner_state.h"
 
 extern "C" int a0_learner_create(const a0_learner_desc* d, a0_learner** out) { return a0_learner_create_on(d, nullptr, out); }

@@ -277,7 +277,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     if (L->d.A != a->d.A || (L->d.dueling != 0) != (a->d.dueling != 0) || R->obs_bytes != a->obs_bytes || R->size < a->E)
         return a0_fail(A0_EINVAL, "a0_actor_rollout: actor, learner and replay were created for different shapes");
     const int E = a->E, A = a->d.A;
-    const bool dist = L->d.algo == A0_ALGO_C51, fqf = L->d.algo == A0_ALGO_FQF, quant = L->d.algo == A0_ALGO_IQN || fqf;
+    const bool dist = L->d.algo == A0_ALGO_C51 || L->d.algo == A0_ALGO_QR, fqf = L->d.algo == A0_ALGO_FQF, quant = L->d.algo == A0_ALGO_IQN || fqf;
     const int freq = a->d.reset_noise_freq > 0 ? a->d.reset_noise_freq : 4;
     const int nt = fqf ? L->F : (quant ? L->d.iqn_K : 1);  // fractions per env and step (agent.py:25-39 with IQNHead.qval / FQFHead.qval, model.py:253-257,280-284)
     if (quant && a->h == nullptr) {
@@ -353,7 +353,9 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);
             const int nx = (a->cur + 1) % a->K;
             a->g += 1;
-            A0_CHECK(a0_actor_dist_tail_env_step(a->head_slabs, (long long)E * L->Npad, ns, L->bh(false), L->Npad, A, L->T, a->d.dueling ? 1 : 0, 2, L->atoms, E, a->rng.seed,
+            if (4LL * ((long long)A * L->T + L->T) * 4 > 160 * 1024) return a0_fail(A0_EINVAL, "a0_actor_rollout: head too wide for the distributional tail kernel");
+            A0_CHECK(a0_actor_dist_tail_env_step(a->head_slabs, (long long)E * L->Npad, ns, L->bh(false), L->Npad, A, L->T, a->d.dueling ? 1 : 0, L->d.algo == A0_ALGO_C51 ? 2 : 1,
+                                                 L->d.algo == A0_ALGO_C51 ? L->atoms : nullptr, E, a->rng.seed,
                                                  STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed, a->d.rank,
                                                  a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps, a->d.discount,
                                                  a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,
@@ -366,7 +368,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
         const unsigned long long off_a = a->rng.reserve(STREAM_EGREEDY_A, E), off_u = a->rng.reserve(STREAM_EGREEDY_U, E);
         const int nxt = (a->cur + 1) % a->K;
         a->g += 1;
-        A0_CHECK(a0_actor_qhead_env_step(a->act3, E, a->feat, L->online + L->fc1.w(), L->online + L->fc1.b(), L->online + L->head.w(), L->online + L->head.b(), A, a->d.dueling ? 1 : 0,
+        A0_CHECK(a0_actor_qhead_env_step(a->act3, E, a->feat, L->Wf(false), L->bf(false), L->Wh(false), L->bh(false), A, a->d.dueling ? 1 : 0,
                                          a->scratch, a->rng.seed, STREAM_EGREEDY_A, STREAM_EGREEDY_U, off_a, off_u, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E,
                                          a->d.seed, a->d.rank, a->g, cur_obs, a->obs[nxt], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
                                          a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,

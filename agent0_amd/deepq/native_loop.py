@@ -8,7 +8,7 @@ target, Adam moments, status words, loss ring, weight copies, NoisyNet buffers, 
 reader of ``trainer.replay`` keep seeing the live data, with no copies in either direction.  What the handles own themselves: the actor's env state and Philox
 offsets, the sampler's state (epochs / beta), the workspaces.
 
-Scope = what the handles cover (include/agent0_hip.h): dqn (A + dueling <= 24, no NoisyNet), c51 (any), iqn and fqf (no NoisyNet) on 4 x 84 x 84 observations, the device-resident env,
+Scope = what the handles cover (include/agent0_hip.h): all six learners (dqn without NoisyNet and with A + dueling <= 24; iqn / fqf without NoisyNet) on 4 x 84 x 84 observations, the device-resident env,
 uniform or sum-tree replay, one GPU, the ``main`` schedule.  Everything else — and any Trainer whose hot-loop methods a test harness has wrapped — stays on the Python
 classes.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
 """
@@ -67,6 +67,12 @@ def eligible(tr) -> Optional[str]:
     elif algo in ("iqn", "fqf"):
         if lc.noisy_net or cfg.action_dim + (1 if lc.dueling_head else 0) > 32 or not getattr(tr.actors[1], "quant_tail", False):
             return "quantile handles: no NoisyNet, A + dueling <= 32, the merged quantile tail"
+    elif algo == "qr":
+        if not getattr(tr.actors[1], "dist_tail", False):
+            return "qr handle: the distributional tail kernel"
+    elif algo == "mdqn":
+        if not getattr(tr.actors[1], "fused_tail", False):
+            return "mdqn handle: A + dueling <= 24"
     elif algo != "c51":
         return f"no handle for {algo}"
     if tuple(cfg.obs_shape) != (4, 84, 84):
@@ -102,7 +108,7 @@ class NativeLoop:
         self.prio = rp.prioritize
         # ---- learner over the engine's buffers
         desc = _abi.LearnerDesc(int(cfg.action_dim), int(bool(lc.dueling_head)), int(bool(lc.double_q)), self.B, int(lc.n_step_q), float(lc.discount), float(lc.learning_rate),
-                                float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1, "iqn": 2, "fqf": 3}[lc.algo.name], int(lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
+                                float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1, "iqn": 2, "fqf": 3, "qr": 4, "mdqn": 5}[lc.algo.name], int(lc.qr.num_atoms if lc.algo.name == "qr" else lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
                                 int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF, int(lc.iqn.K), int(lc.iqn.N), int(lc.iqn.N_dash), int(lc.iqn.F), float(lc.mdqn.tau), float(lc.mdqn.lo))
         p = lambda t: None if t is None else t.data_ptr()
         bufs = _LearnerBuffers(p(eng.online.flat), p(eng.target.flat), p(eng.grads), p(eng.adam_m), p(eng.adam_v), p(eng.state), p(eng.scalars), p(eng.loss_ring),

@@ -626,9 +626,10 @@ RAINBOW = {"learner.double_q": "true", "learner.dueling_head": "true", "learner.
                                         ("iqn", {"env_id": "Asterix"}), ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3,
                                                                                "replay.policy": "prioritize", "env_task": "block"}),
                                         ("fqf", {"env_id": "Asterix"}), ("fqf", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3,
-                                                                               "replay.policy": "prioritize", "env_task": "block"})],
+                                                                               "replay.policy": "prioritize", "env_task": "block"}),
+                                        ("qr", RAINBOW), ("mdqn", {"learner.noisy_net": "true", "learner.dueling_head": "true", "env_task": "block"})],
                          ids=["dqn-uniform", "duel-double-n3", "prioritized-n3-block", "c51", "rainbow-lite", "rainbow-lite-block-noise3", "iqn", "iqn-duel-double-n3-per-block", "fqf",
-                              "fqf-duel-double-n3-per-block"])
+                              "fqf-duel-double-n3-per-block", "qr-rainbow", "mdqn-noisy-duel-block"])
 def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     """Round 4 (opaque handles, library-owned HBM): ``a0_actor`` / ``a0_rbuf`` / ``a0_learner`` (csrc/runtime.hip, learner.hip) restate the host-side
     bookkeeping of the Python classes — cursors, shuffled epochs, Philox offsets, beta, epsilon — in C++, so that a host needs a handful of C calls per iteration.
@@ -661,8 +662,9 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
     noisy = bool(cfg.learner.noisy_net)
     A = int(cfg.action_dim)
     nat = tr.ops.native_learner(A=A, dueling=duel, double_q=dq, B=B, n_step=n, discount=cfg.learner.discount, lr=cfg.learner.learning_rate, target_update_freq=TF, algo=algo,
-                                num_atoms=cfg.learner.c51.num_atoms, vmin=cfg.learner.c51.vmin, vmax=cfg.learner.c51.vmax, noisy=noisy, seed=cfg.seed + 15485863,
-                                K=cfg.learner.iqn.K, N=cfg.learner.iqn.N, N_dash=cfg.learner.iqn.N_dash, F=cfg.learner.iqn.F)
+                                num_atoms=cfg.learner.qr.num_atoms if algo == "qr" else cfg.learner.c51.num_atoms, vmin=cfg.learner.c51.vmin, vmax=cfg.learner.c51.vmax, noisy=noisy,
+                                seed=cfg.seed + 15485863, K=cfg.learner.iqn.K, N=cfg.learner.iqn.N, N_dash=cfg.learner.iqn.N_dash, F=cfg.learner.iqn.F,
+                                mdqn_tau=cfg.learner.mdqn.tau, mdqn_lo=cfg.learner.mdqn.lo)
     nat.set_params(eng.online.flat, eng.target.flat)
     rd = RbufDesc(SIZE, 4 * 84 * 84, B, int(prio), cfg.replay.alpha, cfg.replay.eps, cfg.replay.beta0, cfg.trainer.total_steps, cfg.seed + 104729)
     rb = C.c_void_p()
@@ -720,9 +722,10 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
                                         ("iqn", {"env_id": "Asterix", "env_task": "block"}),
                                         ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
                                         ("fqf", {"env_id": "Asterix", "env_task": "block"}),
-                                        ("fqf", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"})],
+                                        ("fqf", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
+                                        ("qr", {"learner.double_q": "true", "env_task": "block"}), ("mdqn", {"learner.n_step_q": 3, "replay.policy": "prioritize"})],
                          ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block", "iqn-block", "iqn-duel-double-n3-per", "fqf-block",
-                              "fqf-duel-double-n3-per"])
+                              "fqf-duel-double-n3-per", "qr-double-block", "mdqn-n3-per"])
 def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
     """agent0_amd/deepq/native_loop.py: for the configurations the handles cover, ``Trainer.run_iteration`` hands the loop to a0_actor / a0_rbuf / a0_learner created
     OVER the Python classes' own buffers (a0_learner_create_on / a0_rbuf_create_on) — one C call per rollout, batch and update, eager launches from native code.
