@@ -695,6 +695,54 @@ __global__ void a0_sample_slots_kernel(unsigned long long start, unsigned long l
     if (prio) prio[b] = priority ? priority[li] : 1.f;
 }
 
+// n batches of the same epoch structure in ONE launch: batch g = blockIdx.y takes permutation elements start[g] .. start[g] + B - 1 of the epoch (n_perm[g], seed[g]) and
+// writes row g of the [n][B] outputs.  Uniform replay's batches do not depend on the updates between them (the DataLoader's shuffled epochs, trainer.py:63-72), so a
+// whole update block's sampling is one 5 us launch instead of twenty.  Per batch == a0_sample_slots_kernel.
+struct a0_slots_multi_args { unsigned long long start[32], n_perm[32]; uint32_t seed[32]; };
+__global__ void a0_sample_slots_multi_kernel(a0_slots_multi_args S, long long top, long long head, long long cap, const int* __restrict__ r_act, const float* __restrict__ r_rew,
+                                             const float* __restrict__ r_done, int B, long long* __restrict__ idx_out, int* __restrict__ slot_out, int* __restrict__ act,
+                                             float* __restrict__ rew, float* __restrict__ done, float* __restrict__ prio) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (b >= B) return;
+    const unsigned long long n_perm = S.n_perm[g];
+    const uint32_t seed = S.seed[g];
+    uint32_t h = 1;
+    while ((1ull << (2 * h)) < n_perm) ++h;
+    const uint32_t mask = (uint32_t)((1ull << h) - 1);
+    unsigned long long x = S.start[g] + (unsigned long long)b;
+    do {
+        uint32_t l = (uint32_t)(x >> h) & mask, r = (uint32_t)x & mask;
+        for (uint32_t round = 0; round < 4; ++round) {
+            const uint32_t f = a0_mix32(r ^ (seed + 0x9E3779B9u * (round + 1))) & mask;
+            const uint32_t nl = r, nr = l ^ f;
+            l = nl; r = nr;
+        }
+        x = ((unsigned long long)l << h) | r;
+    } while (x >= n_perm);
+    const long long li = (long long)(x % (unsigned long long)top);
+    const long long s = (head + li) % cap;
+    const long long o = (long long)g * B + b;
+    idx_out[o] = li; slot_out[o] = (int)s; act[o] = r_act[s]; rew[o] = r_rew[s]; done[o] = r_done[s];
+    if (prio) prio[o] = 1.f;
+}
+
+extern "C" int a0_replay_sample_slots_multi(int n, const unsigned long long* start, const unsigned long long* n_perm, const unsigned int* seed, long long top, long long head,
+                                            long long cap, const int* r_act, const float* r_rew, const float* r_done, int B, long long* idx_out, int* slot_out, int* act, float* rew,
+                                            float* done, float* prio, void* stream) {
+    if (n < 1 || n > 32 || !start || !n_perm || !seed || !r_act || !r_rew || !r_done || !idx_out || !slot_out || !act || !rew || !done || B < 1 || top < 1 || cap < top ||
+        cap > 2147483647LL)
+        return a0_fail(A0_EINVAL, "a0_replay_sample_slots_multi: bad argument (1..32 batches)");
+    a0_slots_multi_args S;
+    for (int g = 0; g < 32; ++g) {
+        const int j = g < n ? g : 0;
+        if (n_perm[j] < 1 || start[j] + (unsigned long long)B > n_perm[j]) return a0_fail(A0_EINVAL, "a0_replay_sample_slots_multi: batch outside its epoch");
+        S.start[g] = start[j]; S.n_perm[g] = n_perm[j]; S.seed[g] = seed[j];
+    }
+    hipLaunchKernelGGL(a0_sample_slots_multi_kernel, dim3((B + 127) / 128, n), dim3(128), 0, (hipStream_t)stream, S, top, head, cap, r_act, r_rew, r_done, B, idx_out, slot_out, act,
+                       rew, done, prio);
+    return a0_fail_hip((int)hipGetLastError(), "a0_replay_sample_slots_multi");
+}
+
 extern "C" int a0_replay_sample_slots(unsigned long long start, unsigned long long n_perm, unsigned int seed, long long top, long long head, long long cap,
                                       const int* r_act, const float* r_rew, const float* r_done, const float* priority, int B, long long* idx_out, int* slot_out,
                                       int* act, float* rew, float* done, float* prio, void* stream) {

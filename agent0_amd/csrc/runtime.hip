@@ -57,6 +57,8 @@ struct a0_rbuf {
     float *tree = nullptr, *pstate = nullptr, *val = nullptr, *ones = nullptr;
     bool top_stale = false;        // update_priority left tree[1 .. 2047] to the next sample's launch (a0_sumtree_set_from_loss(defer_top)); a0_rbuf_read brings them up to date
     long long* b_idx = nullptr; int *b_slot = nullptr, *b_act = nullptr; float *b_rew = nullptr, *b_done = nullptr, *b_prio = nullptr, *b_w = nullptr;
+    // a0_rbuf_sample_block: up to 32 batches' buffers [32][B], allocated on first use
+    long long* m_idx = nullptr; int *m_slot = nullptr, *m_act = nullptr; float *m_rew = nullptr, *m_done = nullptr, *m_prio = nullptr;
     long long head() const { return written > size ? written % size : 0; }
 };
 
@@ -174,6 +176,35 @@ extern "C" int a0_rbuf_sample(a0_rbuf* R, a0_batch* out, void* stream) {
     A0_CHECK(a0_replay_sample_slots((unsigned long long)start, (unsigned long long)R->ep.top, R->ep.seed, R->top, R->head(), R->size, R->act, R->rew, R->done, nullptr, B,
                                     R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, stream));
     *out = a0_batch{R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, R->ones};
+    return A0_OK;
+    A0_CATCH
+}
+
+extern "C" int a0_rbuf_sample_block(a0_rbuf* R, int n, a0_batch* out, void* stream) {
+    A0_TRY
+    if (!R || !out || n < 1 || n > 32) return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: 1..32 batches");
+    if (R->prio) return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: prioritized batches depend on the update before them (a0_rbuf_sample)");
+    const int B = R->B;
+    if (!R->m_idx) {
+        R->m_idx = R->mem.alloc<long long>(32LL * B); R->m_slot = R->mem.alloc<int>(32LL * B); R->m_act = R->mem.alloc<int>(32LL * B); R->m_rew = R->mem.alloc<float>(32LL * B);
+        R->m_done = R->mem.alloc<float>(32LL * B); R->m_prio = R->mem.alloc<float>(32LL * B);
+    }
+    unsigned long long start[32], n_perm[32];
+    unsigned int seed[32];
+    for (int g = 0; g < n; ++g) {        // the epoch bookkeeping of n consecutive a0_rbuf_sample calls (the ring does not change inside an update block)
+        if (!R->ep.open || R->ep.pos + 1 >= R->ep.nb) {
+            R->ep.top = R->top; R->ep.nb = (R->top + B - 1) / B; R->ep.pos = 0; R->ep.seed = R->rng.next_seed32(STREAM_PERM); R->ep.open = true;
+            if (R->ep.nb < 2) { R->ep.open = false; return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: the ring holds fewer than two batches"); }
+        }
+        start[g] = (unsigned long long)(R->ep.pos * B); n_perm[g] = (unsigned long long)R->ep.top; seed[g] = R->ep.seed;
+        R->ep.pos += 1;
+    }
+    A0_CHECK(a0_replay_sample_slots_multi(n, start, n_perm, seed, R->top, R->head(), R->size, R->act, R->rew, R->done, B, R->m_idx, R->m_slot, R->m_act, R->m_rew, R->m_done,
+                                          R->m_prio, stream));
+    for (int g = 0; g < n; ++g) {
+        const long long o = (long long)g * B;
+        out[g] = a0_batch{R->m_idx + o, R->m_slot + o, R->m_act + o, R->m_rew + o, R->m_done + o, R->m_prio + o, R->ones};
+    }
     return A0_OK;
     A0_CATCH
 }

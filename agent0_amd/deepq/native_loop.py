@@ -169,8 +169,14 @@ class NativeLoop:
         n = int(cfg.learner.learner_steps)
         if self.fqf and tr._floss_means.numel() < n:
             tr._loss_means, tr._floss_means = tr.ops.zeros(n), tr.ops.zeros(n)
+        blk = (_Batch * 32)()
         for i in range(n):
-            ok(lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
+            if self.prio:
+                ok(lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
+            else:                                         # uniform replay: the block's batches do not depend on its updates — 32 of them per sampling launch
+                if i % 32 == 0:
+                    ok(lib.a0_rbuf_sample_block(self.rbuf, min(32, n - i), blk, st), "a0_rbuf_sample_block")
+                b = blk[i % 32]
             ok(lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, None, st), "a0_learner_update")
             if self.prio:
                 ok(lib.a0_rbuf_update_priority(self.rbuf, self.loss_ptr, eng.state.data_ptr(), st), "a0_rbuf_update_priority")

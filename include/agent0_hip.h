@@ -371,6 +371,9 @@ int a0_rbuf_read(const a0_rbuf* replay, long long rows, uint8_t* frames_out, int
 int a0_rbuf_commit(a0_rbuf* replay, long long n, void* stream);
 /* one batch into the handle's persistent batch buffers (device pointers in *out, valid until the next sample) */
 int a0_rbuf_sample(a0_rbuf* replay, a0_batch* out, void* stream);
+/* uniform replay: the next n <= 32 batches — exactly the batches n consecutive a0_rbuf_sample calls would return (trainer.py:63-72: they do not depend on the updates
+ * between them) — drawn by ONE launch into n persistent batch buffers (valid until the next sample call of either kind).  Prioritized replay: A0_EINVAL. */
+int a0_rbuf_sample_block(a0_rbuf* replay, int n, a0_batch* out, void* stream);
 /* ReplayDataset.update_priority with the last batch's indices and the learner's per-sample losses; learner_state: a0_learner_get's status words or NULL */
 int a0_rbuf_update_priority(a0_rbuf* replay, const float* loss, const int* learner_state, void* stream);
 
@@ -430,6 +433,11 @@ int a0_replay_sample_gather(int mode, unsigned long long start, unsigned long lo
 int a0_replay_sample_slots(unsigned long long start, unsigned long long n_perm, unsigned int seed, long long top, long long head, long long cap,
                            const int* r_act, const float* r_rew, const float* r_done, const float* priority, int B, long long* idx_out, int* slot_out,
                            int* act, float* rew, float* done, float* prio, void* stream);
+/* n <= 32 such batches in ONE launch (host arrays start / n_perm / seed [n]; outputs [n][B]): uniform replay's batches do not depend on the updates between them
+ * (the DataLoader's shuffled epochs, trainer.py:63-72), so a whole update block's sampling is one launch */
+int a0_replay_sample_slots_multi(int n, const unsigned long long* start, const unsigned long long* n_perm, const unsigned int* seed, long long top, long long head, long long cap,
+                                 const int* r_act, const float* r_rew, const float* r_done, int B, long long* idx_out, int* slot_out, int* act, float* rew, float* done,
+                                 float* prio, void* stream);
 int a0_fill_f32(float* p, long long n, float v, void* stream);
 int a0_priority_update(float* priority, const long long* ids, const float* loss, int B, float eps, float alpha,
                        float* pstate, const int* state, void* stream);

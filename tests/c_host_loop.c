@@ -55,9 +55,11 @@ int main(int argc, char** argv) {
         const int training = a0_rbuf_len(R) > start_steps;
         if (training) {
             if (timed == 0 && t0 == 0.0) { HIP(hipDeviceSynchronize()); t0 = now(); }
+            a0_batch blk[32];
+            if (!rainbow) CHECK(a0_rbuf_sample_block(R, LSTEPS, blk, NULL));      /* uniform replay: the block's 20 batches in one launch */
             for (int u = 0; u < LSTEPS; ++u) {
                 a0_batch b;
-                CHECK(a0_rbuf_sample(R, &b, NULL));
+                if (rainbow) CHECK(a0_rbuf_sample(R, &b, NULL)); else b = blk[u];
                 CHECK(a0_learner_update(L, ring, b.slot, 2LL * OBS, b.act, b.rew, b.done, b.weights, NULL, NULL));
                 CHECK(a0_rbuf_update_priority(R, dloss, NULL, NULL));      /* the learner's own loss buffer: no copy */
                 ++updates;
