@@ -7,8 +7,9 @@ for spec in "dqn 10000000 learner.double_q=true" \
             "iqn 1500000" "fqf 1500000" "qr 6000000 learner.n_step_q=3"; do
   set -- $spec; a=$1; n=$2; shift 2
   timeout -k 10 400 python -m agent0.deepq.main env_id=Asterix learner.algo=$a actor.num_envs=256 replay.size=300000 trainer.total_steps=$n \
-      trainer.training_start_steps=50000 wandb=false tb=false logdir=/tmp/soak/$a "$@" > /tmp/soak_$a.log 2>&1
+      trainer.training_start_steps=50000 env_task=${TASK:-stream} wandb=false tb=false logdir=/tmp/soak/$a "$@" > /tmp/soak_$a.log 2>&1
   echo "== $a rc=$? lines=$(wc -l < /tmp/soak_$a.log)"
+  grep -c "host loop: library handles" /tmp/soak_$a.log | sed 's/^/native-loop lines: /'
   grep "frames:" /tmp/soak_$a.log | tail -1 | cut -c40-230
   echo "nan/error lines: $(grep -ci 'nan\|error\|Traceback' /tmp/soak_$a.log)"
 done
