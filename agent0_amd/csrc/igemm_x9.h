@@ -360,6 +360,38 @@ static inline hipError_t a0_igemm_x9_group_launch(hipStream_t st, int n, const a
     return hipGetLastError();
 }
 
+// Two DIFFERENT GEMMs with the same tile shape and the same number of workgroups in one launch (blockIdx.y picks the body): fc1's data gradient and fc1's weight gradient of
+// a 512-row batch are 392 tiles each on a chip with 512 workgroup slots — alone each leaves a quarter of the slots empty and ends on the CUs that hold two workgroups; together
+// their 784 workgroups keep the slots filled (1.5 rounds instead of 2 x 1).  Same bodies, same tiles: bit-identical results.
+template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
+__global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_pair_kernel(typename OA1::Params pa1, typename OB1::Params pb1, typename EP1::Params pe1, int X1, int Y1, int K1, int kc1,
+                                                                int gx1, int gy1, typename OA2::Params pa2, typename OB2::Params pb2, typename EP2::Params pe2, int X2, int Y2,
+                                                                int K2, int kc2, int gx2, int gy2) {
+    if (blockIdx.y == 0) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1);
+    else a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+}
+
+template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
+static inline hipError_t a0_igemm_x9_pair_launch(hipStream_t st, const typename OA1::Params& pa1, const typename OB1::Params& pb1, const typename EP1::Params& pe1, int X1, int Y1, int K1,
+                                                 const typename OA2::Params& pa2, const typename OB2::Params& pb2, const typename EP2::Params& pe2, int X2, int Y2, int K2) {
+    typedef a0_x9_geom<OA1, OB1, WM, WN, MT, NT, KS> G1;
+    typedef a0_x9_geom<OA2, OB2, WM, WN, MT, NT, KS> G2;
+    constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
+    auto kern = a0_igemm_x9_pair_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    constexpr int BK = 16 * KS;
+    const int kc1 = ((K1 + BK - 1) / BK) * BK, kc2 = ((K2 + BK - 1) / BK) * BK;          // no reduction split
+    const int gx1 = (X1 + G1::BX - 1) / G1::BX, gy1 = (Y1 + G1::BY - 1) / G1::BY, gx2 = (X2 + G2::BX - 1) / G2::BX, gy2 = (Y2 + G2::BY - 1) / G2::BY;
+    if (gx1 * gy1 != gx2 * gy2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx1 * gy1), 2), dim3(WM * WN * 64), LDS, st, pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1, pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    return hipGetLastError();
+}
+
 template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
 static inline hipError_t a0_igemm_x9_launch(hipStream_t st, const typename OA::Params& pa, const typename OB::Params& pb,
                                             const typename EP::Params& pe, int X, int Y, int K, int splits) {

@@ -505,12 +505,17 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     }
     // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
     if (!quantile) {
-    A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
         const float* dY[2] = {L->draw, L->dh};
         const float* X[2] = {L->h, L->act3_o};
         const int ldx[2] = {512, L->feat}, R[2] = {B, B}, N[2] = {L->Npad, 512}, K[2] = {512, L->feat};
         float* G[2] = {L->grads + L->head.off, L->grads + L->fc1.off};
-        A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, &pend, stream));
+        if (a0_dense_dgrad_wgrad_ok(B, 512, L->feat)) {      // fc1's data gradient and weight gradient as one launch; the head's weight gradient alone
+            A0_CHECK(a0_dense_dgrad_wgrad(L->dh, L->Wf(false), L->act3_o, L->feat, L->d3, G[1], B, 512, L->feat, stream));
+            A0_CHECK(a0_dense_wgrad_multi(1, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, &pend, stream));
+        } else {
+            A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
+            A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, &pend, stream));
+        }
     }
     A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
     A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,

@@ -785,6 +785,27 @@ extern "C" int a0_dense_dgrad(const float* dY, const float* W, const float* act_
     A0_CATCH
 }
 
+// a0_dense_dgrad (with the ReLU mask) and the unsplit a0_dense_wgrad of ONE layer — same dY, R x N x K with as many 64 x 64 tiles in the data gradient (R x K) as in the
+// weight gradient (N x K): N == R — as one launch (a0_igemm_x9_pair_kernel).  fc1 of a 512-row batch: dX = (dY W) * (X > 0) into dX, dW = dY^T X (+ bias row sums) into grad.
+// Bit-identical to the two calls.  Shapes: a0_dense_dgrad_wgrad_ok.
+extern "C" int a0_dense_dgrad_wgrad_ok(int R, int N, int K) {
+    static const bool off = getenv("A0_NO_DGRAD_WGRAD_PAIR") != nullptr || getenv("A0_DGRAD_VARIANT") != nullptr || getenv("A0_WGRAD_VARIANT") != nullptr;      // tuning aids
+    const long long b128 = (long long)((R + 127) / 128) * ((K + 63) / 64), b64 = (long long)((N + 63) / 64) * ((K + 63) / 64);
+    return (!off && g_gemm_x9 != 0 && g_probe.tag == 0 && R == N && R >= 1 && R <= 1024 && !(N & 3) && !(K & 3) && b128 < 256 && b64 >= 256 && N >= 512 &&
+            (long long)((R + 127) / 128) * ((K + 127) / 128) < g_x9_big_min) ? 1 : 0;
+}
+extern "C" int a0_dense_dgrad_wgrad(const float* dY, const float* W, const float* X, int ldx, float* dX, float* grad, int R, int N, int K, void* stream) {
+    A0_TRY
+    if (!dY || !W || !X || !dX || !grad || ldx < K || (ldx & 3) || !a0_dense_dgrad_wgrad_ok(R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_dgrad_wgrad: shapes a0_dense_dgrad_wgrad_ok accepts");
+    a0_mat_src a1{dY, N}, b1{W, K};                          // data gradient: rows r, reduction over n
+    EpiMaskMat::Params e1{dX, X, K};
+    a0_mat_src a2{dY, N}, b2{X, ldx};                        // weight gradient: rows n, reduction over r
+    EpiWgradSlab::Params e2{grad, 0, K, (long long)N * K};
+    A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
+    return A0_OK;
+    A0_CATCH
+}
+
 extern "C" long long a0_dense_wgrad_scratch(int R, int N, int K) { return a0_dense_wgrad_scratch_impl(R, N, K); }
 
 extern "C" int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad, int R, int N, int K, float* slabs, void* stream) {

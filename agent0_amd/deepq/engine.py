@@ -364,8 +364,12 @@ class DeviceLearner:
         if not have_dh:
             ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
         if not L.quantile:
-            wg.append((ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat))
-            ops.dense_dgrad(ws.dh, Wf, ws.act3, ws.d3, R, 512, L.feat)
+            if hasattr(ops, "dense_dgrad_wgrad") and ops.dense_dgrad_wgrad_ok(R, 512, L.feat):
+                # fc1's data gradient and weight gradient — 392 tiles each at R = 512 — as ONE launch that keeps the chip's workgroup slots filled (bit-identical)
+                ops.dense_dgrad_wgrad(ws.dh, Wf, ws.act3, L.feat, ws.d3, self._grad("fc1"), R, 512, L.feat)
+            else:
+                wg.append((ws.dh, ws.act3, L.feat, self._grad("fc1"), R, 512, L.feat))
+                ops.dense_dgrad(ws.dh, Wf, ws.act3, ws.d3, R, 512, L.feat)
         else:
             n = ws.n_tau
             wg.append((ws.dh, ws.x, L.feat, self._grad("fc1"), R, 512, L.feat))

@@ -726,6 +726,14 @@ class HipOps:
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
                   "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}
 
+    def dense_dgrad_wgrad_ok(self, R, N, K) -> bool:
+        return bool(self.lib.a0_dense_dgrad_wgrad_ok(R, N, K))
+
+    def dense_dgrad_wgrad(self, dY, W, X, ldx, dX, grad, R, N, K):
+        """One layer's masked data gradient and unsplit weight gradient in one launch (a0_dense_dgrad_wgrad)."""
+        check(self.lib.a0_dense_dgrad_wgrad(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"), _req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx,
+                                            _req(dX, torch.float32, R * K, "dX"), _req(grad, torch.float32, N * K + N, "grad"), R, N, K, _stream()), "a0_dense_dgrad_wgrad")
+
     def dense_wgrad_multi(self, layers, slabs, pend=None):
         """layers: [(dY, X, ldx, grad, R, N, K)] (at most four); their slab reductions run as one launch — or, with ``pend``, in the next encoder_wgrad(pend=...)'s."""
         n = len(layers)

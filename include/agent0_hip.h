@@ -117,6 +117,10 @@ long long a0_dense_fwd_scratch(int R, int N, int K);
 int a0_dense_fwd(const float* X, int ldx, const float* W, const float* b, float* Y, int R, int N, int K, int relu,
                  float* scratch, void* stream);
 int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float* dX, int R, int N, int K, void* stream);
+/* (round 4) a0_dense_dgrad with the ReLU mask X and the unsplit a0_dense_wgrad of ONE layer (loss.backward() through first_dense, agent.py:153-155) as one launch: the two
+ * GEMMs have the same number of 64 x 64 tiles (R == N) and together keep the chip's workgroup slots filled; bit-identical to the two calls.  Shapes: _ok (fc1 of a 512-row batch) */
+int a0_dense_dgrad_wgrad_ok(int R, int N, int K);
+int a0_dense_dgrad_wgrad(const float* dY, const float* W, const float* X, int ldx, float* dX, float* grad_w_b, int R, int N, int K, void* stream);
 long long a0_dense_wgrad_scratch(int R, int N, int K);
 int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
 /* n <= 4 dense weight gradients (the head's and fc1's, + the cosine embedding's) whose slab reductions share one launch; layer i reduces in

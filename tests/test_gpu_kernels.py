@@ -377,6 +377,25 @@ def test_grouped_fc1_passes_equal_the_separate_gemms(hip, n, R):
         assert torch.isfinite(slabs[i][: ns * R * N]).all() and (ns == ns1 or torch.isnan(slabs[i][ns * R * N:]).all())
 
 
+def test_fc1_data_and_weight_gradient_in_one_launch_equal_the_two_calls(hip):
+    """a0_dense_dgrad_wgrad (round 4): fc1's masked data gradient and its unsplit weight gradient of a 512-row batch — two GEMMs of 392 tiles each — as one launch
+    (a0_igemm_x9_pair_kernel: blockIdx.y picks the body).  Same bodies on the same tiles: dX and the [W | b] gradient block must be bit-identical to
+    a0_dense_dgrad + a0_dense_wgrad."""
+    R, N, K = 512, 512, 3136
+    assert hip.dense_dgrad_wgrad_ok(R, N, K) and not hip.dense_dgrad_wgrad_ok(256, 512, K) and not hip.dense_dgrad_wgrad_ok(512, 256, K)
+    g = recipe.gen(5)
+    dY = D(hip, g.standard_normal((R, N)).astype(np.float32))
+    W = D(hip, (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    X = D(hip, np.maximum(g.standard_normal((R, K)), 0).astype(np.float32))
+    dX0, dX1 = hip.empty(R * K), hip.empty(R * K).fill_(float("nan"))
+    g0, g1 = hip.empty(N * K + N), hip.empty(N * K + N).fill_(float("nan"))
+    hip.dense_dgrad(dY, W, X, dX0, R, N, K)
+    hip.dense_wgrad(dY, X, K, g0, R, N, K, hip.empty(max(hip.dense_wgrad_scratch(R, N, K), 4)))
+    hip.dense_dgrad_wgrad(dY, W, X, K, dX1, g1, R, N, K)
+    assert torch.equal(dX0, dX1) and torch.equal(g0, g1)
+    assert float((dX1.view(R, K)[X.view(R, K) <= 0]).abs().max()) == 0.0, "the ReLU mask"
+
+
 def test_sumtree_sample_batch_equals_separate_kernels(hip):
     """a0_sumtree_sample_batch (draws + descent + lookup + importance weights, one launch) against a0_rng_uniform + a0_sumtree_sample +
     a0_replay_lookup + a0_is_weights: identical indices, slots, metadata, priorities and weights."""
