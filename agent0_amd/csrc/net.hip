@@ -801,7 +801,11 @@ extern "C" int a0_dense_dgrad_wgrad(const float* dY, const float* W, const float
     EpiMaskMat::Params e1{dX, X, K};
     a0_mat_src a2{dY, N}, b2{X, ldx};                        // weight gradient: rows n, reduction over r
     EpiWgradSlab::Params e2{grad, 0, K, (long long)N * K};
-    A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
+    // 128 x 64 tiles on eight waves (196 + 196 workgroups, one per CU at a time): the same sums as the 64 x 64 tiles of the separate calls (every output element's k loop is the
+    // same sequence of MFMAs), equal on the `main` schedule and ~2 % faster under `launch`, where the rollout's kernels share the chip (A0_PAIR_TILE=0: 64 x 64, tuning aid)
+    static const int pv = getenv("A0_PAIR_TILE") ? atoi(getenv("A0_PAIR_TILE")) : 1;
+    if (pv == 1) A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 4, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
+    else A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
     return A0_OK;
     A0_CATCH
 }
