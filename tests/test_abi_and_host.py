@@ -210,3 +210,17 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
     assert len(rows) > 100 and any("a0_encoder_fused_kernel" in r["name"] for r in rows)
     bad = [r for r in rows if int(r["scratch"]) or int(r["vgpr_spill"]) or int(r["sgpr_spill"])]
     assert not bad, f"kernels with scratch / spills: {[(r['name'], r['scratch'], r['vgpr_spill'], r['sgpr_spill']) for r in bad]}"
+
+
+def test_plain_c_hosts_compile_against_the_header():
+    """include/agent0_hip.h is a C header: tests/c_host_demo.c and tests/c_host_loop.c (the non-Python hosts of the handle API; run on the GPU box by
+    tests/test_gpu_engine.py / test_gpu_trainer.py) must compile as C — syntax and types only, no GPU needed."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no C compiler / ROCm headers here")
+    for src in ("c_host_demo.c", "c_host_loop.c"):
+        r = subprocess.run([gcc, "-std=gnu99", "-Wall", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", src)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, src + ":\n" + r.stderr[-3000:]
