@@ -29,12 +29,16 @@ the autoreset, episode statistics and reward clipping the reference gets from gy
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 import time
 from multiprocessing import shared_memory
 from typing import Callable, Optional
 
 import numpy as np
 import torch
+
+from agent0_amd._abi import check
 
 from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_ARG, CTL_DONE0, CTL_WORD, N_SCAL, HostSynthSlice, OffsetSlices, VectorizedSingles, block_layout,  # noqa: F401
                         block_views, ctl_word, record, worker_main)
@@ -51,7 +55,7 @@ class _Space:
 class HostEnvPool:
     def __init__(self, make_slice: Callable[[int, int], object], num_envs: int, obs_shape=(4, 84, 84), action_dim: int = 4, num_workers: int = 4, ops=None,
                  start_method: str = "spawn", spin_us: float = 20.0, has_life_loss: bool = True, newest_frame: Optional[bool] = None,
-                 busy_us: float = 500.0):
+                 busy_us: float = 500.0, inline_upload: bool = True):
         """``make_slice(e0, k)`` -> vector env over envs [e0, e0 + k) (must be picklable for worker processes).  ``num_workers = 0`` steps
         the whole vector env in this process (same buffers and copy stream; the action then has to be waited for here)."""
         if ops is None:
@@ -99,6 +103,21 @@ class HostEnvPool:
         self._seq_d = torch.zeros(1, dtype=torch.int64, device=ops.device)          # (CMD_STEP << 56) | seq: ONE word, DMA-copied over ctl[0] behind the actions
         self.copy_stream = torch.cuda.Stream()
         self._uploaded = torch.cuda.Event()
+        # the step path's two PCIe legs as one library call each (a0_env_pool_upload / a0_env_pool_send): raw addresses, resolved once.  ``inline_upload``:
+        # the upload is enqueued on the caller's stream (a solo pool: the encoder waits for it anyway); a pool of a group keeps its copy stream, whose
+        # DMA runs beside the other group's inference.  A0_ENV_POOL_CALLS=0: the per-copy torch calls (same bytes; a tuning aid)
+        self.library_calls = self.newest_frame and os.environ.get("A0_ENV_POOL_CALLS", "1") != "0"
+        self.inline_upload = bool(inline_upload)
+        self.wait_s = 0.0                     # host time spent waiting for the workers (the env's own cost as the step path sees it)
+        if self.library_calls:
+            dp = C.c_void_p()
+            check(ops.lib.a0_host_device_pointer(whole.data_ptr(), C.byref(dp)), "a0_host_device_pointer")
+            base = dp.value - whole.data_ptr()                                        # device address of a host byte = host address + base (0 on this platform)
+            self._p = dict(act_dev=self._act_h.data_ptr() + base, ctl_dev=self._ctl_h[CTL_WORD:].data_ptr() + base,
+                           new_h=[self._new_h[h].data_ptr() for h in (0, 1)], scal_h=[self._scal_h[h].data_ptr() for h in (0, 1)],
+                           obs_h=[self._obs_h[h].data_ptr() for h in (0, 1)], obs_d=[o.data_ptr() for o in self._obs],
+                           scal_d=[t.data_ptr() for t in self._scal_d], new_d=self._new_d.data_ptr())
+            self._n_whole = C.c_int(0)
         self.seq = 0
         self.g = 0
         self.pcie_bytes_per_step = E * ((self.frame_bytes or self.obs_bytes) + N_SCAL * 4 + 4) + 16      # + obs_bytes per whole-stack upload (full_uploads)
@@ -130,6 +149,7 @@ class HostEnvPool:
         while True:
             done = ctl[CTL_DONE0:CTL_DONE0 + self.W]
             if (done == self.seq).all():
+                self.wait_s += time.perf_counter() - t0
                 return
             if (done < 0).any():
                 raise RuntimeError("an env worker process died")
@@ -142,6 +162,19 @@ class HostEnvPool:
     def _upload(self, half: int, scalars: bool):
         """Page-locked half -> device buffers on the copy stream; the compute stream picks the result up through an event.  ``scalars`` is
         False for a reset (whole stacks, nothing else)."""
+        if scalars and self.library_calls:
+            p, cur = self._p, torch.cuda.current_stream()
+            if not self.inline_upload:
+                self.copy_stream.wait_stream(cur)
+            stream = cur if self.inline_upload else self.copy_stream
+            check(self.ops.lib.a0_env_pool_upload(p["new_h"][half], p["new_d"], p["scal_h"][half], p["scal_d"][half], N_SCAL, 6, p["obs_h"][half],
+                                                           p["obs_d"][half ^ 1], p["obs_d"][half], self.E, self.nstack, self.frame_bytes, C.byref(self._n_whole),
+                                                           stream.cuda_stream), "a0_env_pool_upload")
+            self.full_uploads += self._n_whole.value
+            if not self.inline_upload:
+                self._uploaded.record(self.copy_stream)
+                cur.wait_event(self._uploaded)
+            return
         self.copy_stream.wait_stream(torch.cuda.current_stream())      # kernels still reading this half of the DEVICE ring (n-step / replay insert of two steps ago)
         with torch.cuda.stream(self.copy_stream):
             if scalars and self.newest_frame:
@@ -204,9 +237,13 @@ class HostEnvPool:
         cur = torch.cuda.current_stream()
         # actions, then the command word (CMD_STEP and the sequence number in ONE 8-byte word): two DMA copies in stream order — workers
         # that see the new number see the actions, and can never pair it with the previous command
-        self._act_h.copy_(action, non_blocking=True)
-        self._seq_d.add_(1)
-        self._ctl_h[CTL_WORD:CTL_WORD + 1].copy_(self._seq_d, non_blocking=True)
+        if self.library_calls and action.dtype == torch.int32 and action.is_contiguous() and action.numel() == self.E:
+            check(self.ops.lib.a0_env_pool_send(action.data_ptr(), self._p["act_dev"], self.E, self._p["ctl_dev"], ctl_word(CMD_STEP, self.seq), cur.cuda_stream),
+                           "a0_env_pool_send")
+        else:
+            self._seq_d.fill_(ctl_word(CMD_STEP, self.seq))
+            self._act_h.copy_(action, non_blocking=True)
+            self._ctl_h[CTL_WORD:CTL_WORD + 1].copy_(self._seq_d, non_blocking=True)
         if self.W == 0:
             ev = torch.cuda.Event()
             ev.record(cur)
@@ -279,7 +316,7 @@ class HostEnvGroups:
         bounds = [round(i * self.E / groups) for i in range(groups + 1)]
         per = 0 if num_workers == 0 else max(1, int(num_workers) // groups)
         self.offsets = bounds[:-1]
-        self.pools = [HostEnvPool(OffsetSlices(make_slice, bounds[i]), bounds[i + 1] - bounds[i], num_workers=per, ops=ops, **kw) for i in range(groups)]
+        self.pools = [HostEnvPool(OffsetSlices(make_slice, bounds[i]), bounds[i + 1] - bounds[i], num_workers=per, ops=ops, inline_upload=False, **kw) for i in range(groups)]
         p0 = self.pools[0]
         self.obs_shape, self.obs_bytes, self.action_dim = p0.obs_shape, p0.obs_bytes, p0.action_dim
         self.observation_space = _Space(shape=(self.E,) + self.obs_shape)

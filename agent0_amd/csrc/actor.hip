@@ -130,3 +130,56 @@ extern "C" int a0_env_frame_stack(const uint8_t* prev, const uint8_t* newest, co
     hipLaunchKernelGGL(a0_frame_stack_kernel, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, (const uint4*)prev, (const uint4*)newest, advance, (uint4*)out, nstack, fv);
     return a0_fail_hip((int)hipGetLastError(), "a0_env_frame_stack");
 }
+
+// The host-environment front-end's two PCIe legs as ONE library call each (round 4): the Python thread's eager copies and launches were on the
+// critical path between "workers finished" and "workers see the next actions" (~130 us of a ~310 us step, profiles/r04_experiments.md).
+//   upload: newest frames + scalars (+ the few whole stacks) host -> device, then the device frame stack — agent.py:27's torch.from_numpy(obs).to(device);
+//   send:   actions and the step word device -> host, the direction gymnasium's AsyncVectorEnv.step_async pickles through pipes (atari_wrappers.py:59-69).
+// The send stores straight into the page-locked shared block from two tiny kernels (system-scope relaxed stores, no fence inside a kernel: the kernel
+// boundary orders the actions before the word, and a worker that sees the new word therefore sees its actions) instead of two DMA copies.
+__global__ void a0_pool_send_actions_kernel(const int* __restrict__ action, int* act_host, int E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) __hip_atomic_store(act_host + i, action[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void a0_pool_send_word_kernel(long long* ctl_host, long long word) {
+    __hip_atomic_store(ctl_host, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int a0_host_device_pointer(void* host, void** dev) {
+    if (!host || !dev) return a0_fail(A0_EINVAL, "a0_host_device_pointer: null argument");
+    return a0_fail_hip((int)hipHostGetDevicePointer(dev, host, 0), "a0_host_device_pointer (is the block page-locked with hipHostRegister?)");
+}
+
+extern "C" int a0_env_pool_send(const int* action, int* act_host_dev, int E, long long* ctl_host_dev, long long word, void* stream) {
+    if (!action || !act_host_dev || !ctl_host_dev || E < 1 || (((uintptr_t)ctl_host_dev) % 8))
+        return a0_fail(A0_EINVAL, "a0_env_pool_send: bad argument");
+    hipLaunchKernelGGL(a0_pool_send_actions_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, action, act_host_dev, E);
+    hipLaunchKernelGGL(a0_pool_send_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctl_host_dev, word);
+    return a0_fail_hip((int)hipGetLastError(), "a0_env_pool_send");
+}
+
+extern "C" int a0_env_pool_upload(const uint8_t* new_host, uint8_t* new_dev, const float* scal_host, float* scal_dev, int n_scal, int advance_row,
+                                  const uint8_t* obs_host, const uint8_t* prev, uint8_t* out, int E, int nstack, long long frame_bytes, int* n_whole,
+                                  void* stream) {
+    if (!new_host || !new_dev || !scal_host || !scal_dev || !obs_host || !prev || !out || prev == out || E < 1 || nstack < 2 || n_scal < 1 || advance_row < 0 ||
+        advance_row >= n_scal || frame_bytes < 16 || (frame_bytes % 16) || ((((uintptr_t)prev) | ((uintptr_t)new_dev) | ((uintptr_t)out)) % 16))
+        return a0_fail(A0_EINVAL, "a0_env_pool_upload: bad argument (frames of a multiple of 16 bytes, 16-byte aligned, out != prev)");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemcpyAsync(new_dev, new_host, (size_t)E * frame_bytes, hipMemcpyHostToDevice, s);
+    if (err == hipSuccess) err = hipMemcpyAsync(scal_dev, scal_host, (size_t)n_scal * E * sizeof(float), hipMemcpyHostToDevice, s);
+    // whole stacks for the envs that did not merely advance (the workers have finished: the host rows are final); adjacent envs in one copy
+    const float* adv = scal_host + (size_t)advance_row * E;
+    const long long ob = (long long)nstack * frame_bytes;
+    int whole = 0;
+    for (int e = 0; e < E && err == hipSuccess;) {
+        if (adv[e] != 0.f) { ++e; continue; }
+        int j = e;
+        while (j + 1 < E && adv[j + 1] == 0.f) ++j;
+        err = hipMemcpyAsync(out + e * ob, obs_host + e * ob, (size_t)(j + 1 - e) * ob, hipMemcpyHostToDevice, s);
+        whole += j + 1 - e;
+        e = j + 1;
+    }
+    if (n_whole) *n_whole = whole;
+    if (err != hipSuccess) return a0_fail_hip((int)err, "a0_env_pool_upload: hipMemcpyAsync");
+    return a0_env_frame_stack(prev, new_dev, scal_dev + (size_t)advance_row * E, out, E, nstack, frame_bytes, stream);
+}

@@ -241,6 +241,53 @@ class Actor:
         if self.fused_tail or self.dist_tail or (self.quant_tail and bound and not test and self.fused_commit):
             ops.mean_rows(self.qmax_all, T, E, self.qs)          # per-step mean max-Q (agent.py:38,88), all steps at once
 
+    # ------------------------------------------------------------------ host envs (env_pool.HostEnvPool): nothing but inference between two env steps
+    def _rollout_host(self, epsilon, T, start):
+        """Actor.sample's loop (agent.py:48-88) over a host env that takes its actions without waiting (``step_send`` / ``step_recv``).  What lies between "the
+        workers have finished step t" and "the workers see the actions of step t + 1" is the upload and Actor.act alone: the bookkeeping of step t (n-step window,
+        replay row, episode statistics: agent.py:63-88) is enqueued AFTER the actions of step t + 1 have been sent and runs while the workers step.  Same kernels on
+        the same inputs in an order that respects every dependency — the bytes of ``_rollout`` (tests/test_gpu_trainer.py::test_host_env_pool_matches_device_env);
+        the action buffer alternates between two tensors because step t's n-step update reads its actions after step t + 1's have been chosen."""
+        cfg, ops, E, rp = self.cfg, self.ops, self.E, self.replay
+        R, ob, gamma = self.ring_len, self.obs_bytes, float(cfg.learner.discount)
+        if getattr(self, "_host_actions", None) is None:
+            self._host_actions = (self.action, ops.zeros(E, dtype=torch.int32))
+
+        def bookkeeping(t, steps, action, cur_obs, obs_next, reward, terminal, truncated, info):
+            sl = slice(t * E, (t + 1) * E)
+            self.stat_mask[sl].copy_(info["final_mask"], non_blocking=True)
+            self.stat_ret[sl].copy_(info["final_ret"], non_blocking=True)
+            if self.n > 1:
+                slot = steps % R
+                self.ring_obs[slot * E * ob:(slot + 1) * E * ob].copy_(cur_obs)
+                oldest = (steps - (min(steps + 1, self.n) - 1)) % R
+                obs0 = self.ring_obs[oldest * E * ob:(oldest + 1) * E * ob]
+            else:
+                obs0 = cur_obs
+            ops.actor_nstep(E, self.n, steps, gamma, action, reward, terminal, truncated, info.get("life_loss"), self.ring_act, self.ring_rew, self.ring_done,
+                            self.out_act, self.out_rew, self.out_done, None)
+            ops.replay_insert(rp.frames, rp.size, ob, (start + t * E) % rp.size, E, obs0, obs_next, self.out_act, self.out_rew, self.out_done, rp.act, rp.rew, rp.done, None)
+
+        if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq != 0:
+            self.model._dev.compose_noise()                     # as in _rollout
+        pending = None
+        for t in range(T):
+            if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
+                self.model.reset_noise(rng=self.rng)
+            self.action = self._host_actions[t & 1]
+            self._act_device(epsilon, self.qs[t:t + 1], None, None, t)
+            self.envs.step_send(self.action)
+            if pending is not None:
+                bookkeeping(*pending)
+            obs_next, reward, terminal, truncated, info = self.envs.step_recv()
+            pending = (t, self.steps, self.action, self.obs, obs_next, reward, terminal, truncated, info)
+            self.steps += 1
+            self.obs = obs_next
+        bookkeeping(*pending)
+        self.action = self._host_actions[0]
+        if self.fused_tail or self.dist_tail:
+            ops.mean_rows(self.qmax_all, T, E, self.qs)
+
     # ------------------------------------------------------------------ grouped host envs: CPU stepping of one group beside the GPU's inference of the other
     def _group_infer_send(self, g, obs, epsilon, t, offs):
         """Actor.act for group ``g`` on its observations (agent.py:25-39), then the actions go to the group's workers without waiting for them."""
@@ -373,6 +420,8 @@ class Actor:
             self._rollout_groups(epsilon, T, start)
         elif self._graph_eligible(T, bound, test, state_dict):
             self._rollout_graphed(epsilon, T, start)
+        elif bound and hasattr(self.envs, "step_send") and os.environ.get("A0_HOST_ROLLOUT", "1") != "0":      # 0: the step-by-step order of _rollout (same bytes; a tuning aid)
+            self._rollout_host(epsilon, T, start)
         else:
             self._rollout(epsilon, T, start, bound, test, st, frames_out)
         done_ev = torch.cuda.Event()

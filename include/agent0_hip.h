@@ -514,6 +514,20 @@ int a0_actor_nstep(int E, int n, long long steps, double gamma, const int* actio
 int a0_env_frame_stack(const uint8_t* prev, const uint8_t* newest, const float* advance, uint8_t* out, int E, int nstack, long long frame_bytes,
                        void* stream);
 
+/* The two PCIe legs of a host-environment step as one call each (the host thread's enqueue time is on the critical path between "the
+ * workers have finished" and "the workers see the next actions").
+ * a0_env_pool_upload: agent.py:27 `torch.from_numpy(obs).to(device)` — newest frames [E][frame_bytes] and scalars [n_scal][E] host -> device,
+ *   whole stacks (obs_host rows [E][nstack][frame_bytes]) for the envs whose row `advance_row` of the HOST scalars is 0, then a0_env_frame_stack
+ *   into `out` from `prev`.  Host pointers must be page-locked; *n_whole (optional) receives the number of whole stacks uploaded.
+ * a0_env_pool_send: the direction AsyncVectorEnv.step_async pickles through pipes (atari_wrappers.py:59-69) — E actions, then the 8-byte step
+ *   word, stored into page-locked host memory through its DEVICE address (a0_host_device_pointer) by two kernels in stream order: a worker that
+ *   reads the new word reads the new actions.  No host-side wait in either call. */
+int a0_host_device_pointer(void* host, void** dev);
+int a0_env_pool_upload(const uint8_t* new_host, uint8_t* new_dev, const float* scal_host, float* scal_dev, int n_scal, int advance_row,
+                       const uint8_t* obs_host, const uint8_t* prev, uint8_t* out, int E, int nstack, long long frame_bytes, int* n_whole,
+                       void* stream);
+int a0_env_pool_send(const int* action, int* act_host_dev, int E, long long* ctl_host_dev, long long word, void* stream);
+
 /* ---------------------------------------------------------------- device RNG + synthetic env (no reference counterpart) */
 int a0_rng_u32(unsigned long long seed, unsigned int stream_id, unsigned long long offset, unsigned int* out, long long n, void* stream);
 int a0_rng_uniform(unsigned long long seed, unsigned int stream_id, unsigned long long offset, float* out, long long n, void* stream);

@@ -262,13 +262,19 @@ def test_host_env_pool_device_frame_stack_is_exact(workers):
         pool.close()
 
 
-@pytest.mark.parametrize("workers,newest", [(0, True), (3, True), (3, False)])
-def test_host_env_pool_matches_device_env(workers, newest):
+@pytest.mark.parametrize("workers,newest,algo,knobs", [(0, True, "dqn", {}), (3, True, "dqn", {}), (3, False, "dqn", {}), (3, True, "c51", {}), (2, True, "iqn", {}),
+                                                       (3, True, "dqn", {"A0_ENV_POOL_CALLS": "0"}), (3, True, "dqn", {"A0_HOST_ROLLOUT": "0"})])
+def test_host_env_pool_matches_device_env(workers, newest, algo, knobs, monkeypatch):
     """N1: HOST environments behind env_pool.HostEnvPool feed the same device pipeline — worker processes (3 workers over 8 envs: slices
     of 3 / 2 / 3) or in-process stepping (0) write into the page-locked double-buffered ring, observations arrive over the copy stream,
     actions reach the workers by DMA.  With the oracle's CPU twin of the synthetic env inside the workers, the replay contents, episode
-    returns and per-step max-Q must equal those produced with the device-resident env, byte for byte, for n-step 3 over 5 rollouts."""
+    returns and per-step max-Q must equal those produced with the device-resident env, byte for byte, for n-step 3 over 5 rollouts.
+    Round 4: the step path's two PCIe legs are one library call each (a0_env_pool_upload; a0_env_pool_send, whose kernels store the actions and the
+    step word straight into the page-locked block) and the actor enqueues a step's bookkeeping behind the NEXT step's actions (Actor._rollout_host);
+    the knobs select the per-copy torch calls / the step-by-step order, which must give the same bytes."""
     import host_slices
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     from agent0_amd.common.env_pool import HostEnvPool
     from agent0_amd.deepq.agent import Actor
     from agent0_amd.deepq.model import DeepQNet
@@ -276,13 +282,15 @@ def test_host_env_pool_matches_device_env(workers, newest):
     E = 8
     outs = []
     for host in (False, True):
-        cfg = make_cfg("dqn", E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 300, "learner.batch_size": 8})
+        cfg = make_cfg(algo, E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 300, "learner.batch_size": 8})
         model = DeepQNet(cfg)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec("dqn", 4), 11).items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec(algo, 4), 11).items()})
         replay = ReplayDataset(cfg, ops=model.ops)
         envs = HostEnvPool(host_slices.synth_slice(cfg.seed, 0), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops,
                            newest_frame=newest) if host else None
         actor = Actor(cfg, model, replay=replay, rank=0, envs=envs)
+        if host:
+            assert envs.library_calls == (newest and knobs.get("A0_ENV_POOL_CALLS") != "0")
         rs_all, qs_all = [], []
         for _ in range(5):
             data, rs, qs = actor.sample(0.3)

@@ -33,11 +33,13 @@ def main():
     cfg.trainer.training_start_steps = 1 << 62
     tr.run_iteration()
     torch.cuda.synchronize()
-    t0, whole0 = time.time(), pool.full_uploads
+    waited = lambda: sum(p.wait_s for p in getattr(pool, "pools", [pool]))
+    t0, whole0, w0 = time.time(), pool.full_uploads, waited()
     for _ in range(iters):
         tr.run_iteration()
     torch.cuda.synchronize()
     t_act = (time.time() - t0) / iters
+    wait_us = 1e6 * (waited() - w0) / (iters * cfg.actor.sample_steps)      # host time per step spent waiting for the workers: the env's own cost as the step path sees it
     whole = (pool.full_uploads - whole0) / (iters * cfg.actor.sample_steps)
     per_step = pool.pcie_bytes_per_step + whole * (pool.obs_bytes if groups == 1 else pool.pools[0].obs_bytes)
     cfg.trainer.training_start_steps = 1000
@@ -53,6 +55,8 @@ def main():
     print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "groups": groups, "host_cores": os.cpu_count(),
                       "device_frame_stack": pool.newest_frame, "whole_stack_uploads_per_step": round(whole, 3),
                       "actor_only_env_frames_per_sec": round(n / t_act, 1), "actor_only_ms_per_rollout": round(1e3 * t_act, 2),
+                      "actor_only_us_per_step": round(1e6 * t_act / cfg.actor.sample_steps, 1), "of_which_waiting_for_the_workers_us": round(wait_us, 1),
+                      "library_calls": bool(getattr(pool, "pools", [pool])[0].library_calls), "rollout": "host order" if os.environ.get("A0_HOST_ROLLOUT", "1") != "0" and groups == 1 else "step by step",
                       "iteration_env_frames_per_sec": round(n / t_full, 1), "iteration_ms": round(1e3 * t_full, 2),
                       "pcie_bytes_per_step": round(per_step), "pcie_GBps_at_actor_rate": round(per_step * cfg.actor.sample_steps / t_act / 1e9, 2)}))
     pool.close()
