@@ -8,11 +8,13 @@ What it replaces: the reference's ``make_atari`` returns a gymnasium AsyncVector
   * every worker owns envs [e0, e0 + k) and writes observations, rewards, done flags and finished-episode records into shared memory
     that is registered with the HIP runtime as page-locked (``hipHostRegister``), one half of a two-deep ring per step — there is no
     pickling and no staging copy, and the half the GPU may still be reading is never the one being written;
-  * actions travel the other way without a host-side wait: the actor's action tensor and a step sequence number are DMA-copied into the
-    same shared block in stream order, and the workers poll the sequence number — the Python thread never calls ``.cpu()`` or
-    ``stream.synchronize()`` on the step path; it only waits for its own workers (CPU work) before enqueueing the next upload;
-  * uploads run on a dedicated copy stream; the compute stream waits for them through an event, so the n-step / replay-insert kernels
-    of step t and anything else already enqueued overlap the DMA of step t+1's observations;
+  * actions travel the other way without a host-side wait: the actor's action tensor and then a step sequence number are written into the
+    same shared block in stream order (``a0_env_pool_send``: two tiny kernels storing through the block's device address), and the workers
+    poll the sequence number — the Python thread never calls ``.cpu()`` or ``stream.synchronize()`` on the step path; it only waits for
+    its own workers (CPU work) before enqueueing the next upload;
+  * an upload is ONE library call (``a0_env_pool_upload``: the copies and the frame-stack kernel) on the caller's stream — the encoder waits
+    for it anyway, and the bookkeeping of the previous step is enqueued behind the actions (``Actor._rollout_host``), so it runs while the
+    workers step.  (The per-copy torch path — whole-stack mode, resets, ``A0_ENV_POOL_CALLS=0`` — uploads on a copy stream.)
   * the frame stack lives on the DEVICE (``newest_frame=True``, the default for stacked observations): a worker marks every env whose
     stack merely advanced — its older frames are byte-for-byte the previous observation's newer ones — and for those only the newest
     frame crosses PCIe (7 KB instead of 28 KB per env and step); ``a0_env_frame_stack`` rebuilds the stack from the previous observation
@@ -39,6 +41,7 @@ import numpy as np
 import torch
 
 from agent0_amd._abi import check
+from agent0_amd.ops import _stream
 
 from .host_envs import (CMD_CLOSE, CMD_RESET, CMD_STEP, CTL_ARG, CTL_DONE0, CTL_WORD, N_SCAL, HostSynthSlice, OffsetSlices, VectorizedSingles, block_layout,  # noqa: F401
                         block_views, ctl_word, record, worker_main)
@@ -104,8 +107,8 @@ class HostEnvPool:
         self.copy_stream = torch.cuda.Stream()
         self._uploaded = torch.cuda.Event()
         # the step path's two PCIe legs as one library call each (a0_env_pool_upload / a0_env_pool_send): raw addresses, resolved once.  ``inline_upload``:
-        # the upload is enqueued on the caller's stream (a solo pool: the encoder waits for it anyway); a pool of a group keeps its copy stream, whose
-        # DMA runs beside the other group's inference.  A0_ENV_POOL_CALLS=0: the per-copy torch calls (same bytes; a tuning aid)
+        # the upload is enqueued on the caller's stream (the encoder waits for it anyway), False: on the pool's copy stream, whose DMA can run beside another
+        # group's inference (HostEnvGroups, A0_ENV_GROUP_COPY_STREAMS=1).  A0_ENV_POOL_CALLS=0: the per-copy torch calls (same bytes; a tuning aid)
         self.library_calls = self.newest_frame and os.environ.get("A0_ENV_POOL_CALLS", "1") != "0"
         self.inline_upload = bool(inline_upload)
         self.wait_s = 0.0                     # host time spent waiting for the workers (the env's own cost as the step path sees it)
@@ -163,13 +166,16 @@ class HostEnvPool:
         """Page-locked half -> device buffers on the copy stream; the compute stream picks the result up through an event.  ``scalars`` is
         False for a reset (whole stacks, nothing else)."""
         if scalars and self.library_calls:
-            p, cur = self._p, torch.cuda.current_stream()
-            if not self.inline_upload:
+            p = self._p
+            if self.inline_upload:
+                stream = _stream()
+            else:
+                cur = torch.cuda.current_stream()
                 self.copy_stream.wait_stream(cur)
-            stream = cur if self.inline_upload else self.copy_stream
+                stream = self.copy_stream.cuda_stream
             check(self.ops.lib.a0_env_pool_upload(p["new_h"][half], p["new_d"], p["scal_h"][half], p["scal_d"][half], N_SCAL, 6, p["obs_h"][half],
-                                                           p["obs_d"][half ^ 1], p["obs_d"][half], self.E, self.nstack, self.frame_bytes, C.byref(self._n_whole),
-                                                           stream.cuda_stream), "a0_env_pool_upload")
+                                                  p["obs_d"][half ^ 1], p["obs_d"][half], self.E, self.nstack, self.frame_bytes, C.byref(self._n_whole), stream),
+                  "a0_env_pool_upload")
             self.full_uploads += self._n_whole.value
             if not self.inline_upload:
                 self._uploaded.record(self.copy_stream)
@@ -234,19 +240,17 @@ class HostEnvPool:
         self.seq += 1
         self.g += 1
         half = self.seq & 1
-        cur = torch.cuda.current_stream()
         # actions, then the command word (CMD_STEP and the sequence number in ONE 8-byte word): two DMA copies in stream order — workers
         # that see the new number see the actions, and can never pair it with the previous command
         if self.library_calls and action.dtype == torch.int32 and action.is_contiguous() and action.numel() == self.E:
-            check(self.ops.lib.a0_env_pool_send(action.data_ptr(), self._p["act_dev"], self.E, self._p["ctl_dev"], ctl_word(CMD_STEP, self.seq), cur.cuda_stream),
-                           "a0_env_pool_send")
+            check(self.ops.lib.a0_env_pool_send(action.data_ptr(), self._p["act_dev"], self.E, self._p["ctl_dev"], ctl_word(CMD_STEP, self.seq), _stream()), "a0_env_pool_send")
         else:
             self._seq_d.fill_(ctl_word(CMD_STEP, self.seq))
             self._act_h.copy_(action, non_blocking=True)
             self._ctl_h[CTL_WORD:CTL_WORD + 1].copy_(self._seq_d, non_blocking=True)
         if self.W == 0:
             ev = torch.cuda.Event()
-            ev.record(cur)
+            ev.record(torch.cuda.current_stream())
             ev.synchronize()                     # in-process stepping has to wait for the action here (worker mode: the workers poll instead)
             record(self._np, half, 0, self.E, *self._local.step(self._np["act"].copy()))
 
@@ -299,7 +303,7 @@ class HostEnvPool:
 
 
 class HostEnvGroups:
-    """The vector env as ``groups`` consecutive ranges of envs, each a ``HostEnvPool`` of its own (own workers, own page-locked ring, own copy stream), so that
+    """The vector env as ``groups`` consecutive ranges of envs, each a ``HostEnvPool`` of its own (own workers, own page-locked ring), so that
     the actor can step one group on the CPU while the GPU infers the other — what the reference gets from running ``num_actors`` actor processes beside each
     other (agent0/deepq/launch.py:30-61, 166-172), without giving up the single replay ring and its transition order: the actor writes group g's transitions of
     step t to the slots a one-group rollout would have used (``Actor._rollout_groups``), so the ring holds the same bytes in the same order.
@@ -316,7 +320,10 @@ class HostEnvGroups:
         bounds = [round(i * self.E / groups) for i in range(groups + 1)]
         per = 0 if num_workers == 0 else max(1, int(num_workers) // groups)
         self.offsets = bounds[:-1]
-        self.pools = [HostEnvPool(OffsetSlices(make_slice, bounds[i]), bounds[i + 1] - bounds[i], num_workers=per, ops=ops, inline_upload=False, **kw) for i in range(groups)]
+        # every group's upload goes on the caller's stream: the Python thread bounds a grouped rollout, and a copy stream per group costs it three stream calls per
+        # group-step for a DMA overlap the GPU does not need (1.16 - 1.22 M env-frames/s against 0.94 - 1.00 M, profiles/r04_experiments.md).  A0_ENV_GROUP_COPY_STREAMS=1: copy streams
+        inline = os.environ.get("A0_ENV_GROUP_COPY_STREAMS", "0") != "1"
+        self.pools = [HostEnvPool(OffsetSlices(make_slice, bounds[i]), bounds[i + 1] - bounds[i], num_workers=per, ops=ops, inline_upload=inline, **kw) for i in range(groups)]
         p0 = self.pools[0]
         self.obs_shape, self.obs_bytes, self.action_dim = p0.obs_shape, p0.obs_bytes, p0.action_dim
         self.observation_space = _Space(shape=(self.E,) + self.obs_shape)

@@ -16,7 +16,10 @@ from ._abi import A0Error, EncoderPass, EncoderWeights, FramesArg, LearnerDesc, 
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device.  ``torch.cuda.current_stream().cuda_stream`` returns the same handle but spends ~8 us per call
+    in torch's device-index bookkeeping on this image (a device-count query every time: cProfile of the host-env step path, profiles/r04_experiments.md) — per
+    LAUNCH of every eager path."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _req(t: Optional[torch.Tensor], dtype, min_numel: int, name: str, optional: bool = False):
