@@ -571,3 +571,57 @@ def test_replay_extend_accepts_the_reference_transition_list(hip, size, prioriti
         rp.extend([(b"\x00" * 100, 0, 0.0, False)])
     with pytest.raises(TypeError):
         rp.extend([(1, 2, 3)])
+
+
+@pytest.mark.parametrize("E,nstack,fb", [(5, 4, 64), (256, 4, 7056), (37, 2, 16)])
+def test_host_env_pcie_legs_as_library_calls(hip, E, nstack, fb):
+    """Round 4 (N1): a0_env_pool_upload — newest frames + scalars + the whole stacks of the envs whose `advance` scalar is 0, then the device frame stack — must leave
+    exactly what the per-copy sequence leaves (the stack a host-side FrameStack would hold, atari_wrappers.py:63 / agent.py:27), report the number of whole stacks, and
+    work on the caller's stream; a0_env_pool_send must put the actions and then the 8-byte step word into page-locked host memory through its device address."""
+    import ctypes as C
+    from agent0_amd._abi import check
+    from agent0_amd.ops import _stream
+    g = np.random.default_rng(E * 131 + fb)
+    n_scal, adv_row = 7, 6
+    prev = g.integers(0, 256, (E, nstack, fb), dtype=np.uint8)
+    host_obs = g.integers(0, 256, (E, nstack, fb), dtype=np.uint8)           # what the workers hold: used for the envs uploaded whole
+    newest = g.integers(0, 256, (E, fb), dtype=np.uint8)
+    scal = g.standard_normal((n_scal, E)).astype(np.float32)
+    adv = (g.random(E) < 0.7).astype(np.float32)
+    adv[0], adv[E - 1] = 0.0, 0.0                                            # runs at both ends (E - 2 .. E - 1 adjacent when the draw says so)
+    if E > 3:
+        adv[1], adv[2] = 0.0, 1.0
+    scal[adv_row] = adv
+    want = np.where(adv[:, None, None] != 0, np.concatenate([prev[:, 1:], newest[:, None]], axis=1), host_obs)
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    new_h, scal_h, obs_h = pin(newest), pin(scal), pin(host_obs)
+    prev_d, out_d = D(hip, prev), torch.full((E, nstack, fb), 7, dtype=torch.uint8, device=hip.device)
+    new_d, scal_d = torch.zeros(E * fb, dtype=torch.uint8, device=hip.device), torch.zeros(n_scal, E, device=hip.device)
+    n_whole = C.c_int(-1)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        check(hip.lib.a0_env_pool_upload(new_h.data_ptr(), new_d.data_ptr(), scal_h.data_ptr(), scal_d.data_ptr(), n_scal, adv_row, obs_h.data_ptr(), prev_d.data_ptr(),
+                                         out_d.data_ptr(), E, nstack, fb, C.byref(n_whole), _stream()), "a0_env_pool_upload")
+    side.synchronize()
+    assert n_whole.value == int((adv == 0).sum())
+    assert np.array_equal(out_d.cpu().numpy(), want) and np.array_equal(scal_d.cpu().numpy(), scal) and np.array_equal(new_d.cpu().numpy().reshape(E, fb), newest)
+    # the per-copy sequence of round 3 gives the same device stack
+    out2 = torch.full((E, nstack, fb), 9, dtype=torch.uint8, device=hip.device)
+    for e in np.flatnonzero(adv == 0):
+        out2[e].copy_(obs_h[e])
+    hip.env_frame_stack(prev_d.view(-1), new_d, scal_d[adv_row], out2.view(-1), E, nstack, fb)
+    assert torch.equal(out2, out_d)
+    # send: actions, then the word
+    act = D(hip, g.integers(0, 18, E, dtype=np.int32))
+    act_h, ctl_h = torch.full((E,), -1, dtype=torch.int32).pin_memory(), torch.zeros(2, dtype=torch.int64).pin_memory()
+    dp = [C.c_void_p(), C.c_void_p()]
+    check(hip.lib.a0_host_device_pointer(act_h.data_ptr(), C.byref(dp[0])), "a0_host_device_pointer")
+    check(hip.lib.a0_host_device_pointer(ctl_h.data_ptr(), C.byref(dp[1])), "a0_host_device_pointer")
+    word = (2 << 56) | 123456789
+    check(hip.lib.a0_env_pool_send(act.data_ptr(), dp[0].value, E, dp[1].value + 8, word, _stream()), "a0_env_pool_send")
+    torch.cuda.synchronize()
+    assert torch.equal(act_h, act.cpu()) and int(ctl_h[1]) == word and int(ctl_h[0]) == 0
+    from agent0_amd.ops import A0Error
+    with pytest.raises(A0Error):
+        check(hip.lib.a0_env_pool_upload(new_h.data_ptr(), new_d.data_ptr(), scal_h.data_ptr(), scal_d.data_ptr(), n_scal, n_scal, obs_h.data_ptr(), prev_d.data_ptr(),
+                                         out_d.data_ptr(), E, nstack, fb, None, _stream()), "a0_env_pool_upload")
