@@ -75,7 +75,9 @@ class Trainer:
             # current stream.  ``overlap=False`` issues the same work on one stream (used by the tests to show the overlap is race-free).
             self.stage = StageRing(ops, 2 * cfg.actor.sample_steps * cfg.actor.num_envs, self.replay.obs_bytes)
             self.actors = [None, agents.Actor(cfg, None, replay=self.stage, ops=ops, rank=rank)]
-            self.actor_stream = torch.cuda.Stream()
+            # high priority: a rollout kernel that becomes ready goes ahead of the update block's queued kernels.  No difference with the device env (9.43 - 9.49 ms
+            # either way); with a host env, whose workers wait for every step's actions, 23.5 -> 21.7 ms per iteration (profiles/r04_experiments.md).  A0_ACTOR_STREAM_PRIO=0: default priority
+            self.actor_stream = torch.cuda.Stream(priority=int(os.environ.get("A0_ACTOR_STREAM_PRIO", "-1")))
             self.overlap = True
             self._pending = None
         self.epsilon_fn = epsilon_schedule(cfg)
@@ -405,6 +407,29 @@ class Trainer:
         if self._pending is None:
             self._pending = self._issue_rollout()   # launch.py:32-37 primes the pipeline before the loop
         transitions, returns, qmax = self.actors[1].sample_finish(self._pending)
+        actor = self.actors[1]
+        if self.overlap and (hasattr(actor.envs, "step_send") or hasattr(actor.envs, "pools")):
+            # a HOST env's rollout occupies this thread until its last step (it waits for the worker processes), so the update block — which needs nothing from the
+            # thread once enqueued — goes first and the rollout then runs on the actor stream beside it: launch.py's actor processes stepping their emulators while
+            # the learner trains (launch.py:44-63).  Same dependencies as the order below (weights snapshot before the block's first Adam, epsilon from the frame
+            # count before the commit, the rollout into the other half of the stage), hence the same numbers (tests/test_gpu_trainer.py).
+            eps = self.epsilon_fn(self.frame_count)
+            cur = torch.cuda.current_stream()
+            actor.model._dev.copy_from(self.learner.model._dev)
+            snap = torch.cuda.Event()
+            snap.record(cur)
+            self.Qs.extend(qmax)
+            self.Rs.extend(returns)
+            stats = self._step_device(transitions, defer=True)
+            self.actor_stream.wait_event(snap)
+            with torch.cuda.stream(self.actor_stream):
+                self._pending = actor.sample_async(eps)
+            self.stage.written += self.num_transitions
+            torch.cuda.synchronize()
+            self._block_stats_finish(stats)
+            result = self._result()
+            result.update(fps=self.num_transitions / (time.time() - tic))
+            return result
         self._pending = self._issue_rollout()
         result = self.step(transitions, returns, qmax)
         torch.cuda.synchronize()

@@ -366,6 +366,39 @@ def test_launch_mode_overlap_is_race_free(algo, extra):
     assert a[4][-1] is not None and not torch.equal(a[0], a[7])      # training happened; the actor's copy is one update block behind
 
 
+@pytest.mark.parametrize("algo,extra,workers", [("dqn", [], 3), ("c51", ["learner.noisy_net=true", "learner.n_step_q=3", "replay.policy=prioritize"], 2)])
+def test_launch_mode_with_host_envs_trains_beside_the_rollout(algo, extra, workers):
+    """Round 4 (N1 x N2): with a HOST env the rollout occupies the Python thread (it waits for the worker processes), so ``run_iteration_lp`` enqueues the update block
+    first and runs the rollout on the actor stream beside it — launch.py's actor processes stepping emulators while the learner trains (launch.py:44-63).  Parameters,
+    replay contents and statistics must equal, bit for bit, the one-stream order (rollout, then block) on the host env AND the same schedule on the device-resident env."""
+    import host_slices
+    from agent0_amd.common.env_pool import HostEnvPool
+    from agent0_amd.deepq import agent as agents
+    from agent0_amd.deepq.config import parse_overrides
+    from agent0_amd.deepq.trainer import Trainer
+    res = []
+    for host, overlap in ((False, False), (True, True), (True, False)):
+        cfg = parse_overrides([f"learner.algo={algo}", "actor.num_envs=16", "actor.sample_steps=12", "learner.batch_size=32", "learner.learner_steps=3", "replay.size=500",
+                               "trainer.training_start_steps=100", "learner.target_update_freq=4", "wandb=false", "tb=false", "logdir=/tmp/a0_lp"] + extra)
+        tr = Trainer(cfg, use_lp=True)
+        if host:
+            tr.actors[1].close()
+            pool = HostEnvPool(host_slices.synth_slice(cfg.seed, 0), 16, obs_shape=(4, 84, 84), action_dim=tr.act_dim, num_workers=workers, ops=tr.ops)
+            tr.actors[1] = agents.Actor(cfg, None, replay=tr.stage, ops=tr.ops, rank=0, envs=pool)
+        tr.overlap = overlap
+        out = [tr.run_iteration() for _ in range(7)]
+        torch.cuda.synchronize()
+        res.append((tr.learner.engine.online.flat.clone(), tr.replay.frames.clone(), tr.replay.act.clone(), tr.replay.rew.clone(), [o["loss"] for o in out],
+                    [o["qmax"] for o in out], tr.frame_count, tr.actors[1].model._dev.flat.clone(), [o["return_train"] for o in out]))
+        tr.actors[1].close()
+    for b in res[1:]:
+        a = res[0]
+        assert a[6] == b[6] == 7 * 16 * 12
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[7], b[7])
+        assert a[4] == b[4] and a[5] == b[5] and a[8] == b[8]
+    assert res[0][4][-1] is not None
+
+
 def test_launch_mode_uses_stale_weights_like_the_reference():
     """launch.py:58-63 issues the next rollout BEFORE the update block: rollout k+1 acts with the weights after block k-1.  Check that the
     actor's snapshot equals the learner's parameters as they were when the rollout was issued."""

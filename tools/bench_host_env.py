@@ -1,7 +1,7 @@
 """PCIe-inclusive throughput of the host-environment front-end (env_pool.HostEnvPool) on BASELINE configs[1]'s shapes: 256 envs x 80 steps
 per rollout, Breakout dqn, observations stepped on the host by worker processes, uploaded through the page-locked ring.  Prints one JSON
 line: actor-only env-frames/s, the full iteration (rollout + 20 updates of batch 512) and the bytes that cross PCIe per step.
-usage: python tools/bench_host_env.py [workers] [iterations] [device_frame_stack 1|0] [groups]      (groups >= 2: env_pool.HostEnvGroups — the CPU steps one group
+usage: python tools/bench_host_env.py [workers] [iterations] [device_frame_stack 1|0] [groups] [main|launch]      (groups >= 2: env_pool.HostEnvGroups — the CPU steps one group
 while the GPU infers the other)"""
 import json
 import os
@@ -25,10 +25,12 @@ def main():
     cfg = parse_overrides(["env_id=Breakout", "actor.num_envs=256", "replay.size=100000", "learner.batch_size=512", "wandb=false", "tb=false",
                            f"logdir={os.path.join(ROOT, 'gpurun_out', 'bench_logs')}"])
     cfg.obs_shape, cfg.action_dim = (4, 84, 84), 4
-    tr = Trainer(cfg)
+    launch = len(sys.argv) > 5 and sys.argv[5] == "launch"          # the launch.py schedule: the update block of rollout k beside rollout k + 1 (Trainer(use_lp=True))
+    tr = Trainer(cfg, use_lp=launch)
     pool = (HostEnvGroups(HostSynthSlice(cfg.seed), 256, groups=groups, num_workers=workers, ops=tr.ops, newest_frame=newest) if groups > 1 else
             HostEnvPool(HostSynthSlice(cfg.seed), 256, num_workers=workers, ops=tr.ops, newest_frame=newest))
-    tr.actors[1] = agents.Actor(cfg, tr.learner.model, replay=tr.replay, ops=tr.ops, rank=0, envs=pool)
+    tr.actors[1].close()
+    tr.actors[1] = agents.Actor(cfg, None if launch else tr.learner.model, replay=tr.stage if launch else tr.replay, ops=tr.ops, rank=0, envs=pool)
     start = cfg.trainer.training_start_steps
     cfg.trainer.training_start_steps = 1 << 62
     tr.run_iteration()
@@ -52,7 +54,7 @@ def main():
     torch.cuda.synchronize()
     t_full = (time.time() - t0) / iters
     n = cfg.actor.sample_steps * cfg.actor.num_envs
-    print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "groups": groups, "host_cores": os.cpu_count(),
+    print(json.dumps({"front_end": "HostEnvPool + HostSynthSlice (host synthetic env, numpy)", "workers": workers, "groups": groups, "schedule": "launch" if launch else "main", "host_cores": os.cpu_count(),
                       "device_frame_stack": pool.newest_frame, "whole_stack_uploads_per_step": round(whole, 3),
                       "actor_only_env_frames_per_sec": round(n / t_act, 1), "actor_only_ms_per_rollout": round(1e3 * t_act, 2),
                       "actor_only_us_per_step": round(1e6 * t_act / cfg.actor.sample_steps, 1), "of_which_waiting_for_the_workers_us": round(wait_us, 1),
