@@ -238,6 +238,21 @@ extern "C" int a0_learner_destroy(a0_learner* L) { delete L; return A0_OK; }
 
 extern "C" long long a0_learner_param_floats(const a0_learner* L) { return L ? L->n_pad : 0; }
 
+// Data parallelism through the handle (the reference has no multi-GPU learner: launch.py's actors are its only parallelism): `comm` from
+// a0_dp_init makes every a0_learner_update SUM its gradients over the ranks between backward and Adam — the two buckets, the side stream and the order of
+// agent0_amd/deepq/dist.py::RcclGradAllReduce, issued eagerly.  comm = 0 switches the exchange off again.  The caller owns the communicator.
+extern "C" int a0_learner_set_exchange(a0_learner* L, long long comm) {
+    A0_TRY
+    if (!L) return a0_fail(A0_EINVAL, "a0_learner_set_exchange: null handle");
+    if (comm && !L->dp_side) {
+        A0_HIP_THROW(hipStreamCreateWithFlags(&L->dp_side, hipStreamNonBlocking));
+        for (hipEvent_t& e : L->dp_ev) A0_HIP_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    L->dp_comm = comm;
+    return A0_OK;
+    A0_CATCH
+}
+
 extern "C" int a0_learner_set_params(a0_learner* L, const float* online_packed, const float* target_packed, void* stream) {
     A0_TRY
     if (!L || !online_packed) return a0_fail(A0_EINVAL, "a0_learner_set_params: null argument");
@@ -320,6 +335,9 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     }
     a0_pending_reduce pend;
     pend.n = 0;
+    // data parallelism: the dense range is exchanged right after the dense backward, so its slab reductions cannot wait for the encoder's launch (engine.py::_backward_dense)
+    const bool dp = L->dp_comm != 0;
+    a0_pending_reduce* const pp = dp ? nullptr : &pend;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
     if (L->d.algo == A0_ALGO_QR || L->d.algo == A0_ALGO_MDQN) {
         // ---- engine.py's layer-by-layer path: the passes' encoders in one launch, then per pass fc1, head, dueling combine
@@ -500,7 +518,7 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
             const float* X[3] = {L->qo.h, L->qo.x, L->qo.cosx};
             const int ldx[3] = {512, L->feat, 64}, Rr[3] = {R, R, R}, Nn[3] = {L->Npad, 512, L->feat}, Kk[3] = {512, L->feat, 64};
             float* G[3] = {L->grads + L->head.off, L->grads + L->fc1.off, L->grads + L->cos.off};
-            A0_CHECK(a0_dense_wgrad_multi(3, dY, X, ldx, G, Rr, Nn, Kk, L->slabs, L->slab_off3, &pend, stream));
+            A0_CHECK(a0_dense_wgrad_multi(3, dY, X, ldx, G, Rr, Nn, Kk, L->slabs, L->slab_off3, pp, stream));
         }
     }
     // ---- backward (agent.py:153-155): fc1's data gradient, the dense weight gradients with one slab reduction, the encoder
@@ -511,16 +529,13 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         float* G[2] = {L->grads + L->head.off, L->grads + L->fc1.off};
         if (a0_dense_dgrad_wgrad_ok(B, 512, L->feat)) {      // fc1's data gradient and weight gradient as one launch; the head's weight gradient alone
             A0_CHECK(a0_dense_dgrad_wgrad(L->dh, L->Wf(false), L->act3_o, L->feat, L->d3, G[1], B, 512, L->feat, stream));
-            A0_CHECK(a0_dense_wgrad_multi(1, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, &pend, stream));
+            A0_CHECK(a0_dense_wgrad_multi(1, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, pp, stream));
         } else {
             A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
-            A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, &pend, stream));
+            A0_CHECK(a0_dense_wgrad_multi(2, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, pp, stream));
         }
     }
-    A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
-    A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,
-                                  L->slabs + L->enc_slab_off, &pend, stream));
-    if (L->d.noisy) {      // d sigma = d eff * eps, from the reduced gradients in the mu blocks (model.py:78-87 differentiated)
+    auto sigma_grads = [&]() -> int {      // d sigma = d eff * eps, from the reduced gradients in the mu blocks (model.py:78-87 differentiated)
         const float *gmu[3], *nin[3], *nw[3], *nb[3];
         float* gs[3];
         int N[3], K[3], r0[3], r1[3];
@@ -530,14 +545,37 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
             gmu[k] = L->grads + bm.off; gs[k] = L->grads + bs.off; N[k] = bm.N; K[k] = bm.K; r0[k] = m.r0; r1[k] = m.r1;
             nin[k] = L->noise + m.off_in; nw[k] = L->noise + m.off_w; nb[k] = L->noise + m.off_b;
         }
-        A0_CHECK(a0_noisy_multi(1, L->n_mods, gmu, nullptr, gs, N, K, r0, r1, nin, nw, nb, stream));
+        return a0_noisy_multi(1, L->n_mods, gmu, nullptr, gs, N, K, r0, r1, nin, nw, nb, stream);
+    };
+    const long long conv_end = L->fc1.off;      // [0, conv_end): convolution blocks; [conv_end, n_pad]: dense blocks + the NaN flag (layout.py; the two buckets of dist.RcclGradAllReduce)
+    if (dp) {
+        // DeviceLearner.exchange_begin: every dense gradient (and the NaN flag riding behind them) is final here; their SUM over the ranks runs on the side stream
+        // while the encoder backward computes the convolution gradients on this one
+        if (L->d.noisy) A0_CHECK(sigma_grads());
+        A0_CHECK(a0_nan_flag_export(L->state, L->grads + L->n_pad, stream));
+        A0_HIP_THROW(hipEventRecord(L->dp_ev[0], (hipStream_t)stream));
+        A0_HIP_THROW(hipStreamWaitEvent(L->dp_side, L->dp_ev[0], 0));
+        A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads + conv_end, L->n_pad + 1 - conv_end, L->dp_side));
+    }
+    A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
+    A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,
+                                  L->slabs + L->enc_slab_off, &pend, stream));
+    if (dp) {
+        // DeviceLearner.exchange_end: the convolution bucket behind the dense one on the same communicator and stream (one total order on every rank), then the join
+        A0_HIP_THROW(hipEventRecord(L->dp_ev[1], (hipStream_t)stream));
+        A0_HIP_THROW(hipStreamWaitEvent(L->dp_side, L->dp_ev[1], 0));
+        A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads, conv_end, L->dp_side));
+        A0_HIP_THROW(hipEventRecord(L->dp_ev[2], L->dp_side));
+        A0_HIP_THROW(hipStreamWaitEvent((hipStream_t)stream, L->dp_ev[2], 0));
+    } else if (L->d.noisy) {
+        A0_CHECK(sigma_grads());
     }
     if (loss_out) A0_HIP_THROW(hipMemcpyAsync(loss_out, L->loss, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (L->d.algo == A0_ALGO_FQF)      // unconditional, like the reference's fqf_optimizer.step() in front of the NaN guard (agent.py:139-148); lr / 2e4, alpha 0.95, eps 1e-5
         A0_CHECK(a0_rmsprop_step(on + L->frac.off, L->grads + L->frac.off, L->rms_sq, L->frac.size(), L->d.lr / 2e4, 0.95, 1e-5, -1.0, L->clip, stream));
     // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
     const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;
-    A0_CHECK(a0_adam_step_sync_wt(on, L->grads, L->m, L->v, L->n_adam, L->state, L->scalars, L->d.lr, 0.9, 0.999, eps, L->d.target_update_freq, tg, L->n_pad, nullptr, &w_on, L->C,
+    A0_CHECK(a0_adam_step_sync_wt(on, L->grads, L->m, L->v, L->n_adam, L->state, L->scalars, L->d.lr, 0.9, 0.999, eps, L->d.target_update_freq, tg, L->n_pad, dp ? L->grads + L->n_pad : nullptr, &w_on, L->C,
                                   L->wt_on, L->wt_tg, L->loss, B, L->loss_ring, L->loss_ring_cap, stream));
     return A0_OK;
     A0_CATCH

@@ -71,6 +71,10 @@ struct a0_learner {
     float *fc1_slabs[3] = {nullptr, nullptr, nullptr};
     float *h = nullptr, *q_o = nullptr, *q_t = nullptr, *draw = nullptr, *dh = nullptr, *d3 = nullptr, *d2 = nullptr, *d1 = nullptr, *loss = nullptr, *slabs = nullptr;
     std::vector<void*> owned;
+    // ---- data parallelism: a communicator of a0_dp_init; the dense bucket's all-reduce runs on `dp_side` beside the encoder backward
+    long long dp_comm = 0;
+    hipStream_t dp_side = nullptr;
+    hipEvent_t dp_ev[3] = {nullptr, nullptr, nullptr};
 
     template <class T> T* alloc(long long n, bool zero = false) {
         void* p = nullptr;
@@ -82,6 +86,8 @@ struct a0_learner {
     ~a0_learner() {
         for (void* p : owned) (void)hipFree(p);
         if (net) a0_net_destroy(net);
+        for (hipEvent_t e : dp_ev) if (e) (void)hipEventDestroy(e);
+        if (dp_side) (void)hipStreamDestroy(dp_side);
     }
     a0_encoder_weights enc(const float* flat) const { return a0_encoder_weights{flat + conv1.w(), flat + conv1.b(), flat + conv2.w(), flat + conv2.b(), flat + conv3.w(), flat + conv3.b()}; }
 };

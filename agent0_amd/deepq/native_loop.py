@@ -51,6 +51,16 @@ def _wrapped(obj) -> bool:
     return any(type(v).__name__ in ("function", "method") for k, v in vars(obj).items() if k != "epsilon_fn")
 
 
+def hook_ok(hook) -> bool:
+    """No gradient hook, or — opt-in, A0_NATIVE_LOOP_DP=1 (the same on every rank) — the RCCL exchange of dist.RcclGradAllReduce, which the learner handle issues itself
+    (``a0_learner_set_exchange``: same communicator, buckets, side stream and order, eager instead of captured).  Off by default: the multi-rank form has only been rehearsed
+    with a one-rank group (one-GPU boxes), so N > 1 jobs stay on the path whose collective start-up and failure handling the gloo tests cover."""
+    if hook is None:
+        return True
+    from .dist import RcclGradAllReduce
+    return os.environ.get("A0_NATIVE_LOOP_DP", "0") == "1" and isinstance(hook, RcclGradAllReduce)
+
+
 def eligible(tr) -> Optional[str]:
     """None when the Trainer's configuration is one the handles cover, else the reason it is not."""
     from agent0_amd.common.atari_wrappers import DeviceSynthVecEnv
@@ -119,6 +129,9 @@ class NativeLoop:
         if lc.algo.name == "c51":
             atoms = (C.c_float * L.T)(*[float(x) for x in eng.atoms.cpu().tolist()])
             ok(lib.a0_learner_set_support(self.learner, atoms), "a0_learner_set_support")
+        hook = eng.grad_hook
+        if hook is not None:      # hook_ok: dist.RcclGradAllReduce — its communicator moves into the handle (an inactive hook, A0_DP_DRYRUN=1, exchanges nothing there either)
+            ok(lib.a0_learner_set_exchange(self.learner, C.c_longlong(int(hook.comm) if hook.active else 0)), "a0_learner_set_exchange")
         if lc.noisy_net:
             rng = tr.learner.rng
             ok(lib.a0_learner_set_rng(self.learner, rng.STREAM_NOISE, C.c_ulonglong(rng.offsets.get(rng.STREAM_NOISE, 0))), "a0_learner_set_rng")
@@ -213,6 +226,11 @@ class NativeLoop:
             torch.cuda.synchronize()
         result.update(fps=tr.num_transitions / (time.time() - tic))
         return result
+
+    def detach_exchange(self):
+        """The handle stops exchanging gradients (before the communicator's owner destroys it)."""
+        if self.learner:
+            self.ok(self.lib.a0_learner_set_exchange(self.learner, C.c_longlong(0)), "a0_learner_set_exchange")
 
     def drain(self):
         """A rollout issued ahead and never consumed: book it (Trainer.final)."""

@@ -443,7 +443,7 @@ class Trainer:
         if nl is False:
             return None
         from . import native_loop
-        ok_now = self.learner.engine.grad_hook is None and not any(native_loop._wrapped(o) for o in (self, self.replay, self.learner, self.actors[1]))
+        ok_now = native_loop.hook_ok(self.learner.engine.grad_hook) and not any(native_loop._wrapped(o) for o in (self, self.replay, self.learner, self.actors[1]))
         if nl is None:
             why = native_loop.eligible(self)
             if why is not None or not ok_now or getattr(self, "_prefetched", None) is not None or self.replay.written != 0 or self.actors[1].steps != 0:

@@ -365,6 +365,9 @@ def main():
     exchange = None
     if eng.grad_hook is not None:
         exchange = type(eng.grad_hook).__name__ + (" (captured in the update's hipGraph)" if getattr(eng.grad_hook, "in_graph", False) else " (eager, between three graphs)")
+        if getattr(tr, "_nl", None):      # A0_NATIVE_LOOP_DP=1: the learner handle issues the same two all-reduces itself
+            exchange = type(eng.grad_hook).__name__ + "'s communicator in the learner handle (a0_learner_set_exchange: eager launches from native code)"
+            tr._nl.detach_exchange()
         if hasattr(eng.grad_hook, "close"):
             eng.grad_hook.close()
     if rank != 0:

@@ -331,6 +331,12 @@ int a0_learner_create_on(const a0_learner_desc* desc, const a0_learner_buffers* 
 int a0_learner_set_rng(a0_learner* learner, int stream_id, unsigned long long offset);
 int a0_learner_destroy(a0_learner* learner);
 long long a0_learner_param_floats(const a0_learner* learner);
+/* Data parallelism through the handle (one process per GPU, the reference itself has no multi-GPU learner — launch.py:30-61's actor processes
+ * are its only parallelism): with `comm` from a0_dp_init every a0_learner_update SUMs its gradients over the ranks between backward and Adam — the dense blocks
+ * (plus the NaN flag behind them) on a side stream while the encoder backward runs, then the convolution blocks, then the join; Adam skips the step on every rank
+ * if any rank saw a NaN.  Same buckets and order as agent0_amd/deepq/dist.py::RcclGradAllReduce, issued eagerly.  Collective: every rank sets it before its first
+ * update and calls a0_learner_update the same number of times.  comm = 0 switches the exchange off; the caller keeps ownership of the communicator. */
+int a0_learner_set_exchange(a0_learner* learner, long long comm);
 /* parameters in the packed layout (device pointers, a0_learner_param_floats floats each); target_packed = NULL: target = copy of online (agent.py:100) */
 int a0_learner_set_params(a0_learner* learner, const float* online_packed, const float* target_packed, void* stream);
 /* copies of what the handle holds (any pointer may be NULL): parameters, target parameters, Adam moments (param_floats each), the eight status words */

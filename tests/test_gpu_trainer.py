@@ -502,6 +502,40 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
                                            f"again {line2['value']:.0f} vs {plain2['value']:.0f}")
 
 
+@pytest.mark.parametrize("extra", [[], ["--algo", "c51", "learner.noisy_net=true", "learner.dueling_head=true", "learner.double_q=true", "learner.n_step_q=3", "replay.policy=prioritize"]],
+                         ids=["dqn", "c51-rainbow-lite"])
+def test_learner_handle_exchanges_gradients_itself_one_rank_group(extra):
+    """Round 4, (e) through the boundary: ``a0_learner_set_exchange`` puts the RCCL gradient exchange (dense bucket + NaN flag on a side stream beside the encoder backward,
+    convolution bucket behind it, join before Adam — dist.RcclGradAllReduce's buckets and order) into ``a0_learner_update``, so the native host loop (opt-in,
+    A0_NATIVE_LOOP_DP=1) and a plain C host can run data-parallel.  Rehearsed with a one-rank RCCL group (the identity): the losses must equal, bit for bit, the plain
+    native run, the Python classes' plain run and the Python classes' data-parallel run; the line must say who issued the exchange."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--replay-size", "40960", "--no-cpu-baseline", "--no-ratio320", "--no-other-entry"] + extra
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    base = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    lines = {}
+    for name, env in (("python plain", dict(A0_NATIVE_LOOP="0", A0_DP_FORCE="0")), ("native plain", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="0")),
+                      ("python dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1")), ("native dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1", A0_NATIVE_LOOP_DP="1"))):
+        r = subprocess.run(cmd, env=dict(base, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        lines[name] = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    handles = "library handles"
+    assert handles in lines["native plain"]["config"]["host_loop"] and handles in lines["native dp"]["config"]["host_loop"]
+    assert handles not in lines["python plain"]["config"]["host_loop"] and handles not in lines["python dp"]["config"]["host_loop"]      # without the opt-in a hook keeps the Python classes
+    assert "captured" in lines["python dp"]["gradient_exchange"] and "a0_learner_set_exchange" in lines["native dp"]["gradient_exchange"]
+    losses = {k: v["last_loss"] for k, v in lines.items()}
+    assert len(set(losses.values())) == 1 and losses["native dp"] is not None, losses
+    # the two all-reduce launches per update (one-rank: copies in place) and the dense reductions that can no longer wait for the encoder's launch cost a few per cent, not more
+    assert lines["native dp"]["value"] > 0.9 * lines["native plain"]["value"], (lines["native dp"]["value"], lines["native plain"]["value"])
+
+
 @pytest.mark.parametrize("native", ["0", "1"], ids=["python-classes", "native-loop"])
 def test_main_entry_point_at_baseline_config0_sizes(tmp_path, native):
     """BASELINE configs[0] — "Breakout dqn, agent0.deepq.main, 16 envs, 100k replay" — as a child process through the reference's entry point
