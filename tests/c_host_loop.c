@@ -1,7 +1,7 @@
 /* BASELINE configs[1] — Breakout-shaped dqn, 256 vectorized envs x 80 steps + 20 updates of batch 512 per iteration — configs[2] — c51 rainbow-lite: NoisyNet,
  * dueling, double-Q, 3-step returns, prioritized replay — configs[3] — Asterix-shaped (9 actions) implicit quantile network — or configs[4]'s per-GPU workload — fqf on 9 actions — run by a host that is NOT Python: plain C against include/agent0_hip.h, the three handles
  * a0_actor / a0_rbuf / a0_learner (library-owned HBM) and the loop of trainer.py:74-119,171-184 written out.
- * usage: c_host_loop [iterations] [replay_size] [env_task 0|1] [config 1|2|3|4]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
+ * usage: c_host_loop [iterations] [replay_size] [env_task 0|1] [config 1|2|3|4] [gradient exchange 0|1]     prints one JSON line (tests/test_gpu_trainer.py compiles and runs it on the GPU box). */
 #include <hip/hip_runtime_api.h>      /* gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include */
 #include <math.h>
 #include <stdio.h>
@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
     const long long size = argc > 2 ? atoll(argv[2]) : 100000;
     const int task = argc > 3 ? atoi(argv[3]) : A0_ENV_TASK_STREAM;
     const int config = argc > 4 ? atoi(argv[4]) : 1;
+    const int exchange = argc > 5 ? atoi(argv[5]) : 0;      /* 1: data-parallel form with a ONE-rank RCCL communicator (a rehearsal: the sums are the identity) */
     const int E = 256, T = 80, B = 512, LSTEPS = 20, A = config >= 3 ? 9 : 4, OBS = 4 * 84 * 84;
     const long long start_steps = size < 100000 ? size / 2 : 100000, exploration = 1000000;
     const double min_eps = 0.01;
@@ -31,6 +32,16 @@ int main(int argc, char** argv) {
     a0_actor_desc ad = {E, T, A, rainbow, rainbow ? 3 : 1, 0.99, 42, 0, task, 4};
     a0_learner* L = NULL; a0_rbuf* R = NULL; a0_actor* ac = NULL;
     CHECK(a0_learner_create(&ld, &L)); CHECK(a0_rbuf_create(&rd, &R)); CHECK(a0_actor_create(&ad, &ac));
+    long long comm = 0;
+    if (exchange) {
+        /* one process per GPU; rank 0 creates the 128-byte id and hands it to the other ranks over whatever transport the job has (MPI, a file, a socket), every rank
+         * then joins with its rank and the world size.  From here on a0_learner_update sums the gradients over the ranks between backward and Adam. */
+        char id[128];
+        CHECK(a0_dp_unique_id(id));
+        comm = a0_dp_init(id, 0, 1);
+        if (!comm) { fprintf(stderr, "a0_dp_init failed: %s\n", a0_last_error()); return 1; }
+        CHECK(a0_learner_set_exchange(L, comm));
+    }
     /* small random initial weights (a real host would load a packed checkpoint: agent0_amd/deepq/layout.py) */
     const long long n = a0_learner_param_floats(L);
     float* hp = (float*)malloc((size_t)n * sizeof(float));
@@ -79,11 +90,13 @@ int main(int argc, char** argv) {
     for (int b = 0; b < B; ++b) { mean += hl[b] / B; if (!isfinite(hl[b])) finite = 0; }
     printf("{\"host\": \"plain C (tests/c_host_loop.c)\", \"iterations_timed\": %d, \"ms_per_iteration\": %.3f, \"env_frames_per_sec\": %.1f, \"frames\": %lld, \"updates\": %lld, "
            "\"episodes\": %lld, \"mean_return\": %.4f, \"last_mean_loss\": %.6g, \"last_qmax\": %.5g, \"finite\": %d, \"replay_size\": %lld, \"env_task\": %d, "
-           "\"config\": \"%s\"}\n",
+           "\"gradient_exchange\": \"%s\", \"config\": \"%s\"}\n",
            timed, 1e3 * dt / timed, (double)timed * T * E / dt, frames, updates, episodes, episodes ? ret_sum / (double)episodes : 0.0, mean, qmax, finite, size, task,
+           exchange ? "a0_learner_set_exchange, one-rank RCCL communicator" : "none",
            rainbow ? "BASELINE configs[2]: c51 + NoisyNet + dueling + double-Q + 3-step + prioritized replay"
                    : (config == 3 ? "BASELINE configs[3]: iqn, 9 actions, K = 32, N = N' = 64, uniform replay"
                                   : (config == 4 ? "BASELINE configs[4] (one GPU's share): fqf, 9 actions, F = 32, uniform replay" : "BASELINE configs[1]: dqn, uniform replay")));
+    if (comm) { CHECK(a0_learner_set_exchange(L, 0)); CHECK(a0_dp_destroy(comm)); }
     CHECK(a0_actor_destroy(ac)); CHECK(a0_rbuf_destroy(R)); CHECK(a0_learner_destroy(L));
     return 0;
 }

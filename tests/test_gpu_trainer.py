@@ -898,3 +898,13 @@ def test_plain_c_host_runs_baseline_config1(tmp_path, config):
     it = 12 if config < 3 else 4
     assert out["iterations_timed"] == it and out["updates"] == it * 20 and out["finite"] == 1 and out["episodes"] > 100
     assert out["env_frames_per_sec"] > {1: 5e5, 2: 3e5, 3: 1e5, 4: 1e5}[config], "a C host has no reason to be slower than the Python one"
+    if config in (1, 2):
+        # (e) without Python: the same host with a ONE-rank RCCL communicator in the learner handle (a0_dp_unique_id / a0_dp_init / a0_learner_set_exchange) — every update
+        # all-reduces its two gradient buckets; a one-rank sum is the identity, so the run must end on the same numbers
+        r = subprocess.run([exe, "12", "40000", "1", str(config), "1"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        dp = json.loads(r.stdout.strip().splitlines()[-1])
+        print(dp)
+        assert "a0_learner_set_exchange" in dp["gradient_exchange"] and out["gradient_exchange"] == "none"
+        for k in ("updates", "episodes", "mean_return", "last_mean_loss", "last_qmax", "finite", "frames"):
+            assert dp[k] == out[k], (k, dp[k], out[k])
