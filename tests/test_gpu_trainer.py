@@ -262,7 +262,7 @@ def test_host_env_pool_device_frame_stack_is_exact(workers):
         pool.close()
 
 
-@pytest.mark.parametrize("workers,newest,algo,knobs", [(0, True, "dqn", {}), (3, True, "dqn", {}), (3, False, "dqn", {}), (3, True, "c51", {}), (2, True, "iqn", {}),
+@pytest.mark.parametrize("workers,newest,algo,knobs", [(0, True, "dqn", {}), (3, True, "dqn", {}), (3, False, "dqn", {}), (3, True, "c51", {}), (2, True, "iqn", {}), (3, True, "c51-noisy", {}),
                                                        (3, True, "dqn", {"A0_ENV_POOL_CALLS": "0"}), (3, True, "dqn", {"A0_HOST_ROLLOUT": "0"})])
 def test_host_env_pool_matches_device_env(workers, newest, algo, knobs, monkeypatch):
     """N1: HOST environments behind env_pool.HostEnvPool feed the same device pipeline — worker processes (3 workers over 8 envs: slices
@@ -282,9 +282,11 @@ def test_host_env_pool_matches_device_env(workers, newest, algo, knobs, monkeypa
     E = 8
     outs = []
     for host in (False, True):
-        cfg = make_cfg(algo, E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 300, "learner.batch_size": 8})
+        noisy = algo.endswith("-noisy")      # NoisyNet: the noise of every layer is redrawn every reset_noise_freq = 4 steps, in the middle of the 6-step rollouts
+        name = algo.split("-")[0]
+        cfg = make_cfg(name, E, **{"learner.n_step_q": 3, "actor.sample_steps": 6, "replay.size": 300, "learner.batch_size": 8, "learner.noisy_net": str(noisy).lower()})
         model = DeepQNet(cfg)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec(algo, 4), 11).items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec(name, 4, noisy=noisy), 11).items()})
         replay = ReplayDataset(cfg, ops=model.ops)
         envs = HostEnvPool(host_slices.synth_slice(cfg.seed, 0), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops,
                            newest_frame=newest) if host else None
