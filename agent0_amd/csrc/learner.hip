@@ -337,6 +337,9 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     pend.n = 0;
     // data parallelism: the dense range is exchanged right after the dense backward, so its slab reductions cannot wait for the encoder's launch (engine.py::_backward_dense)
     const bool dp = L->dp_comm != 0;
+    // A0_DP_ONE_STREAM=1 (the same on every rank; a tuning aid): both all-reduces on the caller's stream — no overlap with the encoder backward, but none of the three
+    // cross-stream hand-offs either, which cost an eager host ~10 us each (profiles/r04_experiments.md)
+    static const bool dp_inline = getenv("A0_DP_ONE_STREAM") != nullptr && atoi(getenv("A0_DP_ONE_STREAM")) != 0;
     a0_pending_reduce* const pp = dp ? nullptr : &pend;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
     if (L->d.algo == A0_ALGO_QR || L->d.algo == A0_ALGO_MDQN) {
@@ -553,20 +556,28 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         // while the encoder backward computes the convolution gradients on this one
         if (L->d.noisy) A0_CHECK(sigma_grads());
         A0_CHECK(a0_nan_flag_export(L->state, L->grads + L->n_pad, stream));
-        A0_HIP_THROW(hipEventRecord(L->dp_ev[0], (hipStream_t)stream));
-        A0_HIP_THROW(hipStreamWaitEvent(L->dp_side, L->dp_ev[0], 0));
-        A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads + conv_end, L->n_pad + 1 - conv_end, L->dp_side));
+        if (dp_inline) {
+            A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads + conv_end, L->n_pad + 1 - conv_end, stream));
+        } else {
+            A0_HIP_THROW(hipEventRecord(L->dp_ev[0], (hipStream_t)stream));
+            A0_HIP_THROW(hipStreamWaitEvent(L->dp_side, L->dp_ev[0], 0));
+            A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads + conv_end, L->n_pad + 1 - conv_end, L->dp_side));
+        }
     }
     A0_CHECK(a0_net_encoder_dgrad_fused(L->C, L->H, L->W, L->wt_on, L->d3, L->act1, L->act2, B, L->d2, L->d1, stream));
     A0_CHECK(a0_net_encoder_wgrad(L->net, &w_on, &f_obs, B, L->act1, L->act2, L->d3, L->d2, L->d1, L->grads + L->conv1.off, L->grads + L->conv2.off, L->grads + L->conv3.off,
                                   L->slabs + L->enc_slab_off, &pend, stream));
     if (dp) {
         // DeviceLearner.exchange_end: the convolution bucket behind the dense one on the same communicator and stream (one total order on every rank), then the join
-        A0_HIP_THROW(hipEventRecord(L->dp_ev[1], (hipStream_t)stream));
-        A0_HIP_THROW(hipStreamWaitEvent(L->dp_side, L->dp_ev[1], 0));
-        A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads, conv_end, L->dp_side));
-        A0_HIP_THROW(hipEventRecord(L->dp_ev[2], L->dp_side));
-        A0_HIP_THROW(hipStreamWaitEvent((hipStream_t)stream, L->dp_ev[2], 0));
+        if (dp_inline) {
+            A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads, conv_end, stream));
+        } else {
+            A0_HIP_THROW(hipEventRecord(L->dp_ev[1], (hipStream_t)stream));
+            A0_HIP_THROW(hipStreamWaitEvent(L->dp_side, L->dp_ev[1], 0));
+            A0_CHECK(a0_dp_allreduce(L->dp_comm, L->grads, conv_end, L->dp_side));
+            A0_HIP_THROW(hipEventRecord(L->dp_ev[2], L->dp_side));
+            A0_HIP_THROW(hipStreamWaitEvent((hipStream_t)stream, L->dp_ev[2], 0));
+        }
     } else if (L->d.noisy) {
         A0_CHECK(sigma_grads());
     }
