@@ -163,8 +163,9 @@ class HostEnvPool:
                 time.sleep(2e-5)
 
     def _upload(self, half: int, scalars: bool):
-        """Page-locked half -> device buffers on the copy stream; the compute stream picks the result up through an event.  ``scalars`` is
-        False for a reset (whole stacks, nothing else)."""
+        """Page-locked half -> device buffers: one ``a0_env_pool_upload`` call on the caller's stream (or the pool's copy stream, ``inline_upload=False``) on the step
+        path; the per-copy form below for resets (``scalars`` False: whole stacks, nothing else), whole-stack mode and ``A0_ENV_POOL_CALLS=0`` runs on the copy
+        stream, and the compute stream picks the result up through an event."""
         if scalars and self.library_calls:
             p = self._p
             if self.inline_upload:
@@ -235,12 +236,12 @@ class HostEnvPool:
         return self.step_recv(final_mask, final_ret)
 
     def step_send(self, action: torch.Tensor):
-        """First half of ``step``: hand the actions to the workers (two DMA copies in stream order) and return at once — the workers step while the caller
+        """First half of ``step``: hand the actions to the workers (``a0_env_pool_send``: actions, then the step word, in stream order) and return at once — the workers step while the caller
         does something else (``HostEnvGroups``: the other group's inference).  In-process stepping (no workers) does the env step here."""
         self.seq += 1
         self.g += 1
         half = self.seq & 1
-        # actions, then the command word (CMD_STEP and the sequence number in ONE 8-byte word): two DMA copies in stream order — workers
+        # actions, then the command word (CMD_STEP and the sequence number in ONE 8-byte word): two kernels (or two DMA copies) in stream order — workers
         # that see the new number see the actions, and can never pair it with the previous command
         if self.library_calls and action.dtype == torch.int32 and action.is_contiguous() and action.numel() == self.E:
             check(self.ops.lib.a0_env_pool_send(action.data_ptr(), self._p["act_dev"], self.E, self._p["ctl_dev"], ctl_word(CMD_STEP, self.seq), _stream()), "a0_env_pool_send")
