@@ -45,12 +45,21 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         a0_net_desc nd{4, 84, 84};
         if (a0_net_create(&nd, &L->net) != A0_OK) { delete L; return A0_EINVAL; }
         const bool c51 = d->algo == A0_ALGO_C51;
-        const bool generic = d->algo == A0_ALGO_QR || d->algo == A0_ALGO_MDQN;          // dense heads evaluated layer by layer (engine.py's unfused path)
         L->T = (c51 || d->algo == A0_ALGO_QR) ? d->num_atoms : 1;
         L->Nq = d->A * L->T;
         L->V = d->dueling ? L->T : 0;
         L->NQ = d->A + (d->dueling ? 1 : 0);
         L->Npad = (int)ceil_to(L->Nq + L->V, 32);
+        // round 5: qr runs c51's layer structure with a0_qr_head_loss_slabs behind it when a sample's staged head outputs fit in LDS (engine.py::_qr_fused_ok), mdqn
+        // runs dqn's with the Munchausen target (a0_mdqn_head_loss_slabs) when the scalar-head kernel covers the action set
+        {
+            const int Ron = d->double_q ? 2 * d->B : d->B;
+            L->qr_fused = d->algo == A0_ALGO_QR && d->A <= 32 && (3LL * L->Npad + ceil_to(L->T, 4)) * 4 <= 150 * 1024 &&
+                          std::max(a0_dense_fwd_partial_slabs(Ron, L->Npad, 512), a0_dense_fwd_partial_slabs(d->B, L->Npad, 512)) <= 8;
+            L->mdqn_fused = d->algo == A0_ALGO_MDQN && L->NQ <= 24;
+        }
+        const bool dist = c51 || L->qr_fused;                                            // distributional heads from the head GEMMs' slabs (engine.py::_dist_heads_to_slabs)
+        const bool generic = (d->algo == A0_ALGO_QR && !L->qr_fused) || (d->algo == A0_ALGO_MDQN && !L->mdqn_fused);          // dense heads evaluated layer by layer (engine.py's unfused path)
         long long off = 0;
         auto add = [&](Blk& b, int N, int K) { b = Blk{off, N, K}; off += b.size(); };
         add(L->conv1, 32, L->C * 64); add(L->conv2, 64, 512); add(L->conv3, 64, 576);                                                              // deepq/layout.py
@@ -94,11 +103,12 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         L->act1 = L->alloc<float>((long long)B * L->H1 * L->W1 * 32); L->act2 = L->alloc<float>((long long)B * L->H2 * L->W2 * 64);
         L->act3_t = L->alloc<float>((long long)B * L->feat);
         L->ns_fc1 = a0_dense_fwd_partial_slabs(B, 512, L->feat);
-        if (!c51) {
+        if (!dist) {
             L->act3_o = L->alloc<float>((long long)B * L->feat);
-            if (d->double_q) L->act3_s = L->alloc<float>((long long)B * L->feat);
-            for (int i = 0; i < (d->double_q ? 3 : 2); ++i) L->fc1_slabs[i] = L->alloc<float>((long long)L->ns_fc1 * B * 512);
+            if (d->double_q || L->mdqn_fused) L->act3_s = L->alloc<float>((long long)B * L->feat);      // mdqn: the target network's features of the CURRENT observation
+            for (int i = 0; i < ((d->double_q || L->mdqn_fused) ? 3 : 2); ++i) L->fc1_slabs[i] = L->alloc<float>((long long)L->ns_fc1 * B * 512);
             L->h = L->alloc<float>((long long)B * 512);
+            if (L->mdqn_fused) L->q_cur = L->alloc<float>((long long)B * d->A);
         }
         L->q_o = L->alloc<float>((long long)B * d->A * L->T); L->q_t = L->alloc<float>((long long)B * d->A * L->T);
         const long long Rg = fqf ? (long long)B * d->fqf_F : (iqn ? (long long)B * d->iqn_N : (long long)B);           // rows of the differentiated pass
@@ -127,7 +137,7 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             A0_HIP_THROW(hipDeviceSynchronize());
             }
         }
-        if (c51) {
+        if (dist) {
             const int dq = d->double_q ? 1 : 0;
             L->R_on = dq ? 2 * B : B;
             L->ns_on = a0_dense_fwd_partial_slabs(L->R_on, 512, L->feat);
@@ -141,7 +151,16 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
             L->h_on = L->alloc<float>((long long)L->R_on * 512); L->h_tg = L->alloc<float>((long long)B * 512);
             L->h = L->h_on;                                  // h(s) of the online network: what the backward pass reads
             L->hs_on = L->alloc<float>((long long)L->nh_on * L->R_on * L->Npad); L->hs_tg = L->alloc<float>((long long)L->nh_tg * B * L->Npad);
-            L->atoms = L->alloc<float>(L->T); L->m_proj = L->alloc<float>((long long)B * L->T); L->a_star = L->alloc<int>(B, true);
+            L->a_star = L->alloc<int>(B, true);
+        }
+        if (L->qr_fused) {
+            L->qr_taus = L->alloc<float>(L->T);
+            std::vector<float> t((size_t)L->T);
+            for (int i = 0; i < L->T; ++i) t[(size_t)i] = (2.0f * (float)i + 1.0f) / (2.0f * (float)L->T);          // agent.py:274: the quantile midpoints
+            A0_HIP_THROW(hipMemcpy(L->qr_taus, t.data(), (size_t)L->T * 4, hipMemcpyHostToDevice));
+        }
+        if (c51) {
+            L->atoms = L->alloc<float>(L->T); L->m_proj = L->alloc<float>((long long)B * L->T);
             // torch.linspace(vmin, vmax, T) in fp32 as ATen's vectorised CPU kernel computes it (RangeFactories: step = (end - start) / (steps - 1); fma(step, i, start)
             // below the middle, fma(-step, steps - 1 - i, end) above).  A host whose torch build rounds differently hands its own values to a0_learner_set_support.
             std::vector<float> at((size_t)L->T);
@@ -342,7 +361,7 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     static const bool dp_inline = getenv("A0_DP_ONE_STREAM") != nullptr && atoi(getenv("A0_DP_ONE_STREAM")) != 0;
     a0_pending_reduce* const pp = dp ? nullptr : &pend;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
-    if (L->d.algo == A0_ALGO_QR || L->d.algo == A0_ALGO_MDQN) {
+    if ((L->d.algo == A0_ALGO_QR && !L->qr_fused) || (L->d.algo == A0_ALGO_MDQN && !L->mdqn_fused)) {
         // ---- engine.py's layer-by-layer path: the passes' encoders in one launch, then per pass fc1, head, dueling combine
         const bool mdqn = L->d.algo == A0_ALGO_MDQN;
         const int T = L->T;
@@ -432,8 +451,8 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         A0_CHECK(a0_iqn_head(L, on, L->qo, L->t_on, N, true, stream));
         A0_HIP_THROW(hipMemsetAsync(L->qo.dq, 0, (size_t)L->qo.R * A * 4, (hipStream_t)stream));
         A0_CHECK(a0_loss_quantile_huber(L->qo.q, (long long)N * A, A, 1, L->y, L->t_on, N, act, wgt, B, N, Nd, L->loss, L->qo.dq, L->state, stream));
-    } else if (L->d.algo == A0_ALGO_C51) {
-        // ---- C51Learner.train_step (agent.py:218-268), in the order of agent0_amd/deepq/engine.py's c51 path: the three encoder passes in one launch; the online
+    } else if (L->d.algo == A0_ALGO_C51 || L->d.algo == A0_ALGO_QR) {
+        // ---- C51Learner.train_step (agent.py:218-268) / QRLearner.train_step (agent.py:272-293), in the order of agent0_amd/deepq/engine.py's c51 / qr path: the three encoder passes in one launch; the online
         // fc1 over [s ; s'] rows as ONE GEMM and the target's, their slabs finished by one reduction launch; the two head GEMMs; and one launch for everything behind
         // them (slab sums, dueling, greedy next action, projection, cross entropy, head gradient)
         a0_encoder_pass passes[3];
@@ -477,6 +496,11 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
             A0_CHECK(a0_dense_fwd_partial(L->h_on, 512, L->Wh(false), L->R_on, L->Npad, 512, L->hs_on, stream));
             A0_CHECK(a0_dense_fwd_partial(L->h_tg, 512, L->Wh(true), B, L->Npad, 512, L->hs_tg, stream));
         }
+        if (L->d.algo == A0_ALGO_QR)
+            A0_CHECK(a0_qr_head_loss_slabs(L->hs_on, (long long)L->R_on * L->Npad, nh_on, L->R_on, L->hs_tg, (long long)B * L->Npad, nh_tg, dq ? B : -1, L->bh(false), L->bh(true),
+                                           L->Npad, A, L->T, L->d.dueling ? 1 : 0, act, rew, done, wgt, L->qr_taus, L->gamma_n, B, L->loss, L->draw, L->q_o, L->q_t, L->a_star,
+                                           L->state, stream));
+        else
         A0_CHECK(a0_c51_head_loss_slabs(L->hs_on, (long long)L->R_on * L->Npad, nh_on, L->R_on, L->hs_tg, (long long)B * L->Npad, nh_tg, dq ? B : -1, L->bh(false), L->bh(true),
                                         L->Npad, A, L->T, L->d.dueling ? 1 : 0, act, rew, done, wgt, L->atoms, L->gamma_n, (float)L->d.vmin, (float)L->d.vmax, B, L->loss, L->draw,
                                         L->q_o, L->q_t, L->m_proj, L->a_star, L->state, stream));
@@ -484,27 +508,37 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->h, L->dh, B, L->Npad, 512, stream));
     } else {
     // ---- forward: the target pass on s', the online pass on s' (double-Q) and the online pass on s as ONE encoder launch, then their fc1 GEMMs (split-K slabs)
+    // (mdqn, round 5: the third pass is the TARGET network on the CURRENT observation, agent.py:202-204, in the order engine.py's mdqn path issues the passes)
+    const bool mdqn = L->d.algo == A0_ALGO_MDQN;
     a0_encoder_pass passes[3];
     int np = 0;
     passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_next, B, nullptr, nullptr, L->act3_t};
-    if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
+    if (mdqn) passes[np++] = a0_encoder_pass{L->wt_tg, &w_tg, &f_obs, B, nullptr, nullptr, L->act3_s};
+    else if (dq) passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_next, B, nullptr, nullptr, L->act3_s};
     passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
     A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
     int ns = L->ns_fc1;
-    const int n_fc1 = dq ? 3 : 2;
+    const bool third = mdqn || dq;
+    const int n_fc1 = third ? 3 : 2;
+    const float* W3 = mdqn ? L->Wf(true) : L->Wf(false);
     if (a0_dense_fwd_partial_multi_ok(n_fc1, B, 512, L->feat)) {      // the passes' fc1 GEMMs as one launch (fewer, deeper splits each)
         const float* Xs[3] = {L->act3_o, L->act3_t, L->act3_s};
-        const float* Ws[3] = {on + L->fc1.w(), tg + L->fc1.w(), on + L->fc1.w()};
+        const float* Ws[3] = {L->Wf(false), L->Wf(true), W3};
         A0_CHECK(a0_dense_fwd_partial_multi(n_fc1, Xs, L->feat, Ws, B, 512, L->feat, L->fc1_slabs, nullptr, stream));
         ns = a0_dense_fwd_partial_multi_slabs(n_fc1, B, 512, L->feat);
     } else {
-        A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, tg + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[1], stream));
-        if (dq) A0_CHECK(a0_dense_fwd_partial(L->act3_s, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[2], stream));
-        A0_CHECK(a0_dense_fwd_partial(L->act3_o, L->feat, on + L->fc1.w(), B, 512, L->feat, L->fc1_slabs[0], stream));
+        A0_CHECK(a0_dense_fwd_partial(L->act3_t, L->feat, L->Wf(true), B, 512, L->feat, L->fc1_slabs[1], stream));
+        if (third) A0_CHECK(a0_dense_fwd_partial(L->act3_s, L->feat, W3, B, 512, L->feat, L->fc1_slabs[2], stream));
+        A0_CHECK(a0_dense_fwd_partial(L->act3_o, L->feat, L->Wf(false), B, 512, L->feat, L->fc1_slabs[0], stream));
     }
-    // ---- heads of both networks, dueling, argmax, Huber loss, head gradient and the head's backward-data pass in one launch (agent.py:173-190)
-    A0_CHECK(a0_dqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], dq ? L->fc1_slabs[2] : nullptr, (long long)B * 512, ns, on + L->fc1.b(), tg + L->fc1.b(), L->h,
-                                    on + L->head.w(), on + L->head.b(), tg + L->head.w(), tg + L->head.b(), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, B,
+    // ---- heads of both networks, dueling, argmax, Huber loss, head gradient and the head's backward-data pass in one launch (agent.py:173-190; mdqn 193-215)
+    if (mdqn)
+        A0_CHECK(a0_mdqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], L->fc1_slabs[2], (long long)B * 512, ns, L->bf(false), L->bf(true), L->h, L->Wh(false), L->bh(false),
+                                         L->Wh(true), L->bh(true), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, (float)L->d.mdqn_tau, (float)L->d.mdqn_lo, B,
+                                         L->loss, L->q_o, L->q_t, L->q_cur, L->draw, L->state, L->dh, stream));
+    else
+    A0_CHECK(a0_dqn_head_loss_slabs(L->fc1_slabs[0], L->fc1_slabs[1], dq ? L->fc1_slabs[2] : nullptr, (long long)B * 512, ns, L->bf(false), L->bf(true), L->h,
+                                    L->Wh(false), L->bh(false), L->Wh(true), L->bh(true), A, L->d.dueling ? 1 : 0, L->Npad, act, rew, done, wgt, L->gamma_n, B,
                                     L->loss, L->q_o, L->q_t, L->draw, L->state, L->dh, stream));
     }
     const bool quantile = L->d.algo == A0_ALGO_IQN || L->d.algo == A0_ALGO_FQF;

@@ -52,6 +52,8 @@ struct a0_learner {
     // ---- dense heads evaluated layer by layer (A0_ALGO_QR, A0_ALGO_MDQN): fc1 output, raw head output, combined head output per pass; dq of the differentiated pass
     struct DWs { float *act3 = nullptr, *h = nullptr, *raw = nullptr, *q = nullptr; } go, gt, gs, gm;      // online on s, target on s', online on s' (double-Q), target on s (mdqn)
     float *g_dq = nullptr, *qr_taus = nullptr;
+    bool qr_fused = false, mdqn_fused = false;      // round 5: qr from the head GEMMs' slabs (a0_qr_head_loss_slabs), mdqn from the fc1 slabs (a0_mdqn_head_loss_slabs)
+    float* q_cur = nullptr;                         // mdqn: target(obs) [B][A]
     long long slab_off3[3] = {0, 0, 0};
     // effective (W, b) of a dense layer of the online / target network
     const float* Wf(bool tg) const { return d.noisy ? (tg ? eff_tg : eff_on) + eff_fc1.w() : (tg ? target : online) + fc1.w(); }

@@ -600,6 +600,12 @@ extern "C" int a0_dqn_head_loss(const float* h_on, const float* h_tg, const floa
 // behind (a0_dense_fwd_partial) and this kernel sums them in slab order, adds the bias and applies the ReLU exactly like
 // a0_reduce_bias_act_kernel would (bit-identical), writing only the online activations h(s) that the backward pass needs.  Two or three
 // reduction launches per update disappear.
+// Round 5, MDQN = true: MDQNLearner.train_step (agent.py:193-215) through the same kernel — the third pass is the TARGET network on the current observation
+// (its fc1 bias and head rows are the target's), and the loss is the Munchausen one (a0_mdqn_target below, shared with a0_mdqn_loss_kernel); q_sel_out receives it.
+struct a0_mdqn_par { float tau, lo; float* q_sel_out; };
+template <class QN, class QC>
+A0_D float a0_mdqn_target(QN qn, QC qc, int A, int a, float rew, float done, float gamma_n, float tau, float lo);
+template <bool MDQN>
 __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float* __restrict__ s_on, const float* __restrict__ s_tg, const float* __restrict__ s_sel,
                                                                      long long slab_stride, int nslab, const float* __restrict__ b1_on,
                                                                      const float* __restrict__ b1_tg, float* __restrict__ h_on_out,
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
                                                                      const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ wgt,
                                                                      float gamma_n, int B, float* __restrict__ loss, float* __restrict__ q_on_out,
                                                                      float* __restrict__ q_tg_out, float* __restrict__ draw, int* __restrict__ nan_flag,
-                                                                     float* __restrict__ dh_out) {
+                                                                     float* __restrict__ dh_out, a0_mdqn_par M) {
     extern __shared__ float wsm[];                 // [online rows | target rows], NQ x 512 each
     __shared__ float raw[4][3][32];
     __shared__ float dsh[4][32];                   // this row's head gradient (draw), for the fused head data gradient
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
         const float bo = b1_on[lane + 64 * i], bt = b1_tg[lane + 64 * i];
         float v = ho[i] + bo; ho[i] = v < 0.f ? 0.f : v;
         v = ht[i] + bt; ht[i] = v < 0.f ? 0.f : v;
-        v = hs[i] + bo; hs[i] = v < 0.f ? 0.f : v;
+        v = hs[i] + (MDQN ? bt : bo); hs[i] = v < 0.f ? 0.f : v;
     }
     __syncthreads();
     if (b >= B) return;
@@ -664,16 +670,16 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
         float so = 0.f, st = 0.f, ss = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float w1 = wo[lane + 64 * i];
+            const float w1 = wo[lane + 64 * i], w2 = wt[lane + 64 * i];
             so = fmaf(ho[i], w1, so);
-            ss = fmaf(hs[i], w1, ss);
-            st = fmaf(ht[i], wt[lane + 64 * i], st);
+            ss = fmaf(hs[i], MDQN ? w2 : w1, ss);
+            st = fmaf(ht[i], w2, st);
         }
         so = a0_wave_sum(so); st = a0_wave_sum(st); ss = a0_wave_sum(ss);
-        if (lane == 0) { raw[wave][0][a] = so + b_on[a]; raw[wave][1][a] = st + b_tg[a]; raw[wave][2][a] = ss + b_on[a]; }
+        if (lane == 0) { raw[wave][0][a] = so + b_on[a]; raw[wave][1][a] = st + b_tg[a]; raw[wave][2][a] = ss + (MDQN ? b_tg[a] : b_on[a]); }
     }
     if (lane == 0) {
-    const int nsel = s_sel ? 2 : 1;
+    const int nsel = (s_sel && !MDQN) ? 2 : 1;
     float mean[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
     if (dueling)
         for (int s3 = 0; s3 < 3; ++s3) {
@@ -690,10 +696,16 @@ __global__ __launch_bounds__(256) void a0_dqn_head_loss_slabs_kernel(const float
         if (a == 0 || x > best) { best = x; a_star = a; }       // first maximum wins, like torch.argmax on CPU
         q_on_out[(long long)b * A + a] = q(0, a);
         if (q_tg_out) q_tg_out[(long long)b * A + a] = q(1, a);
+        if (MDQN && M.q_sel_out) M.q_sel_out[(long long)b * A + a] = q(2, a);
     }
-    const float qn = q(1, a_star);
-    const float y = rew[b] + (gamma_n * (1.f - done[b])) * qn;
     const int ab = act[b];
+    float y;
+    if (MDQN) {
+        y = a0_mdqn_target([&](int k) { return q(1, k); }, [&](int k) { return q(2, k); }, A, ab, rew[b], done[b], gamma_n, M.tau, M.lo);
+    } else {
+        const float qn = q(1, a_star);
+        y = rew[b] + (gamma_n * (1.f - done[b])) * qn;
+    }
     const float d = q(0, ab) - y;
     const float ad = fabsf(d);
     const float l = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
@@ -744,13 +756,33 @@ extern "C" int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_
     const size_t lds = (size_t)2 * NQ * 512 * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)a0_dqn_head_loss_slabs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)a0_dqn_head_loss_slabs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return a0_fail(A0_EINVAL, "a0_dqn_head_loss_slabs: LDS");
         configured = lds;
     }
-    hipLaunchKernelGGL(a0_dqn_head_loss_slabs_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, slabs_on, slabs_tg, slabs_sel, slab_stride, nslab, b1_on, b1_tg,
-                       h_on_out, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag, dh_out);
+    hipLaunchKernelGGL(a0_dqn_head_loss_slabs_kernel<false>, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, slabs_on, slabs_tg, slabs_sel, slab_stride, nslab, b1_on, b1_tg,
+                       h_on_out, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag, dh_out, a0_mdqn_par{0.f, 0.f, nullptr});
     return a0_fail_hip((int)hipGetLastError(), "a0_dqn_head_loss_slabs");
+}
+
+extern "C" int a0_mdqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const float* slabs_cur, long long slab_stride, int nslab, const float* b1_on,
+                                       const float* b1_tg, float* h_on_out, const float* W_on, const float* b_on, const float* W_tg, const float* b_tg, int A,
+                                       int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt, float gamma_n, float tau, float lo,
+                                       int B, float* loss, float* q_on_out, float* q_tg_out, float* q_cur_out, float* draw, int* nan_flag, float* dh_out, void* stream) {
+    const int NQ = A + (dueling ? 1 : 0);
+    if (!slabs_on || !slabs_tg || !slabs_cur || !b1_on || !b1_tg || !h_on_out || !W_on || !b_on || !W_tg || !b_tg || !act || !rew || !done || !wgt || !loss || !q_on_out ||
+        !draw || !nan_flag || B < 1 || A < 1 || NQ > 24 || ld < NQ || nslab < 1 || slab_stride < (long long)B * 512 || !(tau > 0.f))
+        return a0_fail(A0_EINVAL, "a0_mdqn_head_loss_slabs: bad argument (A + dueling <= 24, tau > 0)");
+    const size_t lds = (size_t)2 * NQ * 512 * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_dqn_head_loss_slabs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_mdqn_head_loss_slabs: LDS");
+        configured = lds;
+    }
+    hipLaunchKernelGGL(a0_dqn_head_loss_slabs_kernel<true>, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, slabs_on, slabs_tg, slabs_cur, slab_stride, nslab, b1_on, b1_tg,
+                       h_on_out, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on_out, q_tg_out, draw, nan_flag, dh_out, a0_mdqn_par{tau, lo, q_cur_out});
+    return a0_fail_hip((int)hipGetLastError(), "a0_mdqn_head_loss_slabs");
 }
 
 // ------------------------------------------------------------------------------------------------ Munchausen DQN
@@ -758,6 +790,23 @@ extern "C" int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_
 //   lp(x)  = z - tau * logsumexp(z / tau),  z = x - max(x)
 //   v_next = sum_a softmax(q')_a * (q'_a - lp(q')_a)            (softmax at temperature 1, as the reference has it)
 //   y      = r + tau * clamp(lp(q_tgt(obs))[a], lo, 0) + gamma_n * (1 - d) * v_next        (alpha is unused in the reference, Q17)
+template <class QN, class QC>
+A0_D float a0_mdqn_target(QN qn, QC qc, int A, int a, float rew, float done, float gamma_n, float tau, float lo) {
+    float mx = qn(0), mc = qc(0);
+    for (int k = 1; k < A; ++k) { mx = fmaxf(mx, qn(k)); mc = fmaxf(mc, qc(k)); }
+    float se_t = 0.f, se_1 = 0.f, sc_t = 0.f;
+    for (int k = 0; k < A; ++k) { se_t += expf((qn(k) - mx) / tau); se_1 += expf(qn(k) - mx); sc_t += expf((qc(k) - mc) / tau); }
+    const float lse_t = logf(se_t), lsc_t = logf(sc_t);
+    float v_next = 0.f;
+    for (int k = 0; k < A; ++k) {
+        const float lp = (qn(k) - mx) - tau * lse_t;
+        v_next += (expf(qn(k) - mx) / se_1) * (qn(k) - lp);
+    }
+    float add_on = (qc(a) - mc) - tau * lsc_t;
+    add_on = fminf(fmaxf(add_on, lo), 0.f);
+    return rew + tau * add_on + (gamma_n * (1.f - done)) * v_next;
+}
+
 __global__ void a0_mdqn_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next, const float* __restrict__ q_cur_tgt, int A,
                                     const int* __restrict__ act, const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ wgt,
                                     float gamma_n, float tau, float lo, int B, float* __restrict__ loss, float* __restrict__ dq, int* __restrict__ nan_flag) {
@@ -765,20 +814,8 @@ __global__ void a0_mdqn_loss_kernel(const float* __restrict__ q, const float* __
     if (b >= B) return;
     const float* qn = q_next + (long long)b * A;
     const float* qc = q_cur_tgt + (long long)b * A;
-    float mx = qn[0], mc = qc[0];
-    for (int k = 1; k < A; ++k) { mx = fmaxf(mx, qn[k]); mc = fmaxf(mc, qc[k]); }
-    float se_t = 0.f, se_1 = 0.f, sc_t = 0.f;
-    for (int k = 0; k < A; ++k) { se_t += expf((qn[k] - mx) / tau); se_1 += expf(qn[k] - mx); sc_t += expf((qc[k] - mc) / tau); }
-    const float lse_t = logf(se_t), lsc_t = logf(sc_t);
-    float v_next = 0.f;
-    for (int k = 0; k < A; ++k) {
-        const float lp = (qn[k] - mx) - tau * lse_t;
-        v_next += (expf(qn[k] - mx) / se_1) * (qn[k] - lp);
-    }
     const int a = act[b];
-    float add_on = (qc[a] - mc) - tau * lsc_t;
-    add_on = fminf(fmaxf(add_on, lo), 0.f);
-    const float y = rew[b] + tau * add_on + (gamma_n * (1.f - done[b])) * v_next;
+    const float y = a0_mdqn_target([&](int k) { return qn[k]; }, [&](int k) { return qc[k]; }, A, a, rew[b], done[b], gamma_n, tau, lo);
     const float d = q[(long long)b * A + a] - y;
     const float ad = fabsf(d);
     const float l = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
@@ -1098,6 +1135,30 @@ __global__ void a0_quantile_target_kernel(const float* __restrict__ q_next, long
     y[i] = rew[b] + (gamma_n * (1.f - done[b])) * q_next[(long long)b * sb + (long long)j * sj + (long long)a_star[b] * sa];
 }
 
+// One online quantile q_i against the N' targets held in LDS (16-byte aligned), in target order: al = sum_j huber(q_i - T_j) |tau_i - 1{T_j < q_i}| and
+// ag = sum_j clamp(q_i - T_j, -1, 1) |tau_i - 1{T_j < q_i}| (reference agent.py:110-114 and its derivative w.r.t. q_i).  Shared by the stand-alone loss kernel and
+// by the kernel that runs QRLearner.train_step from the head GEMMs' slabs, so the two cannot differ.  Four targets per LDS read (every lane reads the same address: a
+// broadcast); the two values |tau - 1| and |tau - 0| the weight can take are formed once per quantile.
+A0_D void a0_qh_sweep(float qi, float tau, const float* __restrict__ s_t, int Nd, float& al, float& ag) {
+    const float w_lt = fabsf(tau - 1.f), w_ge = fabsf(tau - 0.f);
+    float l = 0.f, g = 0.f;
+    auto pair = [&](float tj) {
+        const float d = qi - tj;
+        const float ad = fabsf(d);
+        const float h = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+        const float wq = (tj < qi) ? w_lt : w_ge;
+        l += h * wq;
+        g += fminf(fmaxf(d, -1.f), 1.f) * wq;
+    };
+    int j = 0;
+    for (; j + 4 <= Nd; j += 4) {
+        const a0_f4 t = *(const a0_f4*)(s_t + j);
+        pair(t.x); pair(t.y); pair(t.z); pair(t.w);
+    }
+    for (; j < Nd; ++j) pair(s_t[j]);
+    al = l; ag = g;
+}
+
 // One workgroup per sample; thread i owns online quantile i and sweeps the N' targets held in LDS, so the
 // B x N' x N pairwise tensor of the reference (agent.py:110-114) is never materialised.
 // q(b,i,a) = q[b*sb + i*si + a*sa]; taus[b*tb + i] (tb = 0: shared fixed midpoints).
@@ -1107,7 +1168,7 @@ __global__ __launch_bounds__(256) void a0_quantile_huber_kernel(const float* __r
                                                                  const int* __restrict__ act, const float* __restrict__ wgt,
                                                                  int B, int N, int Nd, float* __restrict__ loss, float* __restrict__ dq,
                                                                  int* __restrict__ nan_flag) {
-    extern __shared__ float s_t[];       // Nd targets, then 4 partial sums
+    extern __shared__ __attribute__((aligned(16))) float s_t[];       // Nd targets
     __shared__ float s_part[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int j = tid; j < Nd; j += blockDim.x) s_t[j] = y[(long long)b * Nd + j];
@@ -1116,18 +1177,8 @@ __global__ __launch_bounds__(256) void a0_quantile_huber_kernel(const float* __r
     float total = 0.f;
     for (int i = tid; i < N; i += blockDim.x) {
         const long long qi_off = (long long)b * sb + (long long)i * si + (long long)a * sa;
-        const float qi = q[qi_off];
-        const float tau = taus[(long long)b * tb + i];
-        float al = 0.f, ag = 0.f;
-        for (int j = 0; j < Nd; ++j) {
-            const float tj = s_t[j];
-            const float d = qi - tj;
-            const float ad = fabsf(d);
-            const float h = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
-            const float wq = fabsf(tau - ((tj < qi) ? 1.f : 0.f));
-            al += h * wq;
-            ag += fminf(fmaxf(d, -1.f), 1.f) * wq;
-        }
+        float al, ag;
+        a0_qh_sweep(q[qi_off], taus[(long long)b * tb + i], s_t, Nd, al, ag);
         total += al;
         dq[qi_off] = wgt[b] * ag / (float)Nd;
     }
@@ -1141,6 +1192,157 @@ __global__ __launch_bounds__(256) void a0_quantile_huber_kernel(const float* __r
         loss[b] = l;
         if (l != l) atomicOr(nan_flag, 1);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ QR: head tail + loss from the head GEMMs' slabs
+// Round 5.  QRLearner.train_step (reference agent.py:272-293) from the head GEMMs on, in ONE launch — the quantile-regression counterpart of
+// a0_c51_head_loss_slabs_kernel, same slab layout: the online head GEMM over [s ; s'] rows (s' only under double-Q) and the target head GEMM over s' leave their
+// split-K slabs; per sample one workgroup of four waves
+//   sums them in slab order and adds the bias                                    (== a0_reduce_bias_act_kernel, three times)
+//   applies the dueling combine per quantile                                     (== a0_dueling_fwd_kernel, three times; model.py:163-177 through QRHead 180-192)
+//   takes the mean over the quantiles and its first maximum                      (== a0_select_action_kernel mode 1; agent.py:277-280)
+//   forms the target quantiles r + gamma^n (1 - d) q'(a*)                        (== a0_quantile_target_kernel; agent.py:281-286)
+//   sweeps the N x N pairs of the quantile Huber loss                            (== a0_quantile_huber_kernel; agent.py:110-114,288-292)
+//   and carries d loss / d q back through the dueling combine                    (== the dq memset + a0_dueling_bwd_kernel)
+// — eleven launches of ~5 us of latency each around a 10 us loss kernel — statement for statement the same arithmetic, so the update's numbers do not change.
+// The staged head outputs (3 passes x ld floats) and the N targets live in LDS; thread i owns online quantile i (strided when N > 256).
+struct a0_qrhl_args {
+    const float* s_on; long long stride_on; int nslab_on;      // online head slabs [nslab_on][R_on][ld]: rows [0, B) = s, rows [sel_off, sel_off + B) = s'
+    const float* s_tg; long long stride_tg; int nslab_tg;      // target head slabs [nslab_tg][B][ld] on s'
+    int sel_off;                                               // < 0: no double-Q (the greedy next action comes from the target's own quantile mean)
+    const float *bias_on, *bias_tg; int ld, A, T, dueling;
+    const int* act; const float *rew, *done, *wgt, *taus; float gamma_n; int B;
+    float *loss, *draw, *q_on_out, *q_tg_out; int* a_star_out; int* nan_flag;
+};
+__global__ __launch_bounds__(256) void a0_qr_head_loss_slabs_kernel(a0_qrhl_args P) {
+    extern __shared__ __attribute__((aligned(16))) float xq[];     // [3 passes: online(s), target(s'), online(s')][ld], then the T targets (padded to 4)
+    __shared__ float s_val[32];
+    __shared__ float s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = P.A, T = P.T, NQ = A + (P.dueling ? 1 : 0), NC = NQ * T, ld = P.ld;
+    const int b = blockIdx.x;
+    // the sample's scalars are requested before the staging loads
+    const int act_b = P.act[b];
+    const float rew_b = P.rew[b], done_b = P.done[b], wgt_b = P.wgt[b];
+    float* s_y = xq + 3 * ld;
+    // staging: 16 bytes per lane and slab over the padded row (the pad columns are summed too and never read); a pass at a time, so that the slab addresses are
+    // wave-uniform offsets from one base; all slabs of a piece (at most eight) requested before any is added, additions in slab order
+    const int npass = P.sel_off < 0 ? 2 : 3;
+    const int ld4 = ld >> 2;
+    for (int p = 0; p < npass; ++p) {
+        const float* base = (p == 1) ? P.s_tg : P.s_on;
+        const long long st4 = ((p == 1) ? P.stride_tg : P.stride_on) >> 2;
+        const int ns = (p == 1) ? P.nslab_tg : P.nslab_on;
+        const a0_f4* row = (const a0_f4*)(base + (long long)(((p == 2) ? P.sel_off : 0) + b) * ld);
+        const a0_f4* bias4 = (const a0_f4*)((p == 1) ? P.bias_tg : P.bias_on);
+        for (int c4 = tid; c4 < ld4; c4 += 256) {
+            a0_f4 t[8];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) t[zz] = (zz < ns) ? row[(long long)zz * st4 + c4] : a0_zero4();
+            a0_f4 acc = a0_zero4();
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz)
+                if (zz < ns) { acc.x += t[zz].x; acc.y += t[zz].y; acc.z += t[zz].z; acc.w += t[zz].w; }
+            const a0_f4 bv = bias4[c4];
+            acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+            *(a0_f4*)(xq + p * ld + 4 * c4) = acc;
+        }
+    }
+    __syncthreads();
+    // dueling combine: thread t owns column t of every action in every pass (it reads back only what it wrote itself)
+    for (int t = tid; t < T; t += 256) {
+        if (P.dueling)
+            for (int p = 0; p < npass; ++p) {
+                float* x = xq + p * ld;
+                float s = 0.f;
+#pragma unroll 4
+                for (int a = 0; a < A; ++a) s += x[a * T + t];
+                const float mean = s / (float)A;
+                const float v = x[A * T + t];
+#pragma unroll 4
+                for (int a = 0; a < A; ++a) x[a * T + t] = v + (x[a * T + t] - mean);
+            }
+        if (P.q_on_out) for (int a = 0; a < A; ++a) P.q_on_out[((long long)b * A + a) * T + t] = xq[a * T + t];
+        if (P.q_tg_out) for (int a = 0; a < A; ++a) P.q_tg_out[((long long)b * A + a) * T + t] = xq[ld + a * T + t];
+    }
+    __syncthreads();
+    // greedy next action: mean over the quantiles of the selecting network's values, first maximum (a0_select_action_kernel, mode 1: lane-strided partial sums,
+    // then the wave's butterfly) — wave w takes actions w, w + 4, ...
+    const float* xsel = xq + (P.sel_off < 0 ? 1 : 2) * ld;
+    for (int a = wave; a < A; a += 4) {
+        const float* p = xsel + a * T;
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += p[t];
+        const float v = a0_wave_sum(s) / (float)T;
+        if (lane == 0) s_val[a] = v;
+    }
+    __syncthreads();
+    float best = 0.f;
+    int a_star = 0;
+    for (int a = 0; a < A; ++a) {
+        const float v = s_val[a];
+        if (a == 0 || v > best) { best = v; a_star = a; }
+    }
+    if (P.a_star_out && tid == 0) P.a_star_out[b] = a_star;
+    // target quantiles (a0_quantile_target_kernel)
+    for (int j = tid; j < T; j += 256) s_y[j] = rew_b + (P.gamma_n * (1.f - done_b)) * xq[ld + a_star * T + j];
+    __syncthreads();
+    // the pairwise sweep (a0_quantile_huber_kernel) and, with each quantile's gradient at hand, its way back through the dueling combine (a0_dueling_bwd_kernel on a dq
+    // that is zero outside the taken action) straight into the head GEMM's output gradient
+    float* o = P.draw + (long long)b * ld;
+    float tot = 0.f;
+    for (int i = tid; i < T; i += 256) {
+        float al, ag;
+        a0_qh_sweep(xq[act_b * T + i], P.taus[i], s_y, T, al, ag);
+        tot += al;
+        const float g = wgt_b * ag / (float)T;
+        float sdl = 0.f;
+        for (int k = 0; k < A; ++k) sdl += (k == act_b) ? g : 0.f;
+        for (int k = 0; k < A; ++k) {
+            float out = (k == act_b) ? g : 0.f;
+            if (P.dueling) out -= sdl / (float)A;
+            o[k * T + i] = out;
+        }
+        if (P.dueling) o[A * T + i] = sdl;
+    }
+    for (int c = NC + tid; c < ld; c += 256) o[c] = 0.f;
+    tot = a0_wave_sum(tot);
+    if (lane == 0) s_part[wave] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += s_part[w];
+        const float l = s / (float)T;
+        P.loss[b] = l;
+        if (l != l) atomicOr(P.nan_flag, 1);
+    }
+}
+
+extern "C" int a0_qr_head_loss_slabs(const float* slabs_on, long long stride_on, int nslab_on, int rows_on, const float* slabs_tg, long long stride_tg, int nslab_tg,
+                                     int sel_off, const float* bias_on, const float* bias_tg, int ld, int A, int T, int dueling, const int* act, const float* rew,
+                                     const float* done, const float* wgt, const float* taus, float gamma_n, int B, float* loss, float* draw, float* q_on_out,
+                                     float* q_tg_out, int* a_star_out, int* nan_flag, void* stream) {
+    const int NQ = A + (dueling ? 1 : 0);
+    if (!slabs_on || !slabs_tg || !bias_on || !bias_tg || !act || !rew || !done || !wgt || !taus || !loss || !draw || !nan_flag || B < 1 || A < 1 || A > 32 || T < 1 ||
+        ld < NQ * T || nslab_on < 1 || nslab_tg < 1 || nslab_on > 8 || nslab_tg > 8 || rows_on < B || stride_on < (long long)rows_on * ld || stride_tg < (long long)B * ld ||
+        (sel_off >= 0 && (sel_off < B || sel_off + B > rows_on)))
+        return a0_fail(A0_EINVAL, "a0_qr_head_loss_slabs: bad argument (A <= 32; at most 8 slabs per head; the s' rows of the online slabs must lie behind the s rows)");
+    const size_t lds = ((size_t)3 * ld + (size_t)((T + 3) / 4 * 4)) * sizeof(float);
+    if (lds > 150 * 1024) return a0_fail(A0_EINVAL, "a0_qr_head_loss_slabs: head too wide for LDS");
+    if ((ld & 3) || (stride_on & 3) || (stride_tg & 3) || ((((uintptr_t)slabs_on) | ((uintptr_t)slabs_tg) | ((uintptr_t)bias_on) | ((uintptr_t)bias_tg)) & 15))
+        return a0_fail(A0_EINVAL, "a0_qr_head_loss_slabs: slabs and biases must be 16-byte aligned, ld and the slab strides multiples of 4 floats");
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_qr_head_loss_slabs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_qr_head_loss_slabs: LDS");
+        configured = lds;
+    }
+    a0_qrhl_args P;
+    P.s_on = slabs_on; P.stride_on = stride_on; P.nslab_on = nslab_on; P.s_tg = slabs_tg; P.stride_tg = stride_tg; P.nslab_tg = nslab_tg; P.sel_off = sel_off;
+    P.bias_on = bias_on; P.bias_tg = bias_tg; P.ld = ld; P.A = A; P.T = T; P.dueling = dueling; P.act = act; P.rew = rew; P.done = done; P.wgt = wgt; P.taus = taus;
+    P.gamma_n = gamma_n; P.B = B; P.loss = loss; P.draw = draw; P.q_on_out = q_on_out; P.q_tg_out = q_tg_out; P.a_star_out = a_star_out; P.nan_flag = nan_flag;
+    hipLaunchKernelGGL(a0_qr_head_loss_slabs_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, P);
+    return a0_fail_hip((int)hipGetLastError(), "a0_qr_head_loss_slabs");
 }
 
 extern "C" int a0_quantile_target(const float* q_next, long long sb, long long sj, long long sa, const int* a_star, const float* rew,

@@ -508,6 +508,72 @@ class DeviceLearner:
         ops.encoder_fwd_fused(tg.net, tg.wt, tg.encoder_weights(), frames, slot, sample_stride, self.obs_bytes, B, None, None, act3)
         ops.dense_fwd_partial(act3, L.feat, Wf_t, B, 512, L.feat, slabs)
 
+    def _qr_fused_ok(self) -> bool:
+        """QR's head path from the GEMM slabs to the loss in one launch (a0_qr_head_loss_slabs): the staged head outputs of a sample must fit in LDS."""
+        L, ops = self.L, self.ops
+        if not hasattr(ops, "qr_head_loss_slabs") or os.environ.get("A0_QR_SEPARATE", "0") == "1":       # 1: tuning aid (same numbers, the eleven separate launches)
+            return False
+        R_on = 2 * self.B if self.double_q else self.B
+        return (L.A <= 32 and (3 * L.Npad + (L.T + 3) // 4 * 4) * 4 <= 150 * 1024 and L.Npad % 4 == 0
+                and max(ops.dense_fwd_partial_slabs(R_on, L.Npad, 512), ops.dense_fwd_partial_slabs(self.B, L.Npad, 512)) <= 8)
+
+    def _dist_heads_to_slabs(self, frames, slot, sample_stride, tstage):
+        """The distributional learners' passes (online on s, online on s' under double-Q, target on s': agent.py:219-231 / 272-280) up to the head GEMMs' split-K slabs:
+        the encoders as one launch, the fc1 GEMMs as one grouped launch (the online passes' rows interleaved into one [splits][R_on][512] buffer), ONE reduction launch
+        (bias + ReLU), the head GEMMs as one grouped launch.  Returns (buffers, online head slab count, target head slab count, R_on); buffers["hs_on"] holds rows
+        [0, B) = s and, under double-Q, rows [B, 2B) = s'."""
+        L, ops, B = self.L, self.ops, self.B
+        on, tg = self.online, self.target
+        wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
+        nxt = self.obs_bytes
+        dq_ = self.double_q
+        ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
+        R_on = 2 * B if dq_ else B
+        ns_on = ops.dense_fwd_partial_slabs(R_on, 512, L.feat)
+        if getattr(self, "_c51_buf", None) is None:
+            nh_on, nh_tg = ops.dense_fwd_partial_slabs(R_on, L.Npad, 512), ops.dense_fwd_partial_slabs(B, L.Npad, 512)
+            self._c51_buf = dict(fc1_on=ops.empty(ns_on * R_on * 512), fc1_tg=ops.empty(ns * B * 512), h_on=ops.empty(R_on * 512), act3_on=ops.empty(R_on * L.feat),
+                                 hs_on=ops.empty(nh_on * R_on * L.Npad), hs_tg=ops.empty(nh_tg * B * L.Npad), R_on=R_on)
+            wo.h = self._c51_buf["h_on"][: B * 512]                  # h(s) of the online network: what the backward pass reads
+            # the online network's features of s and (double-Q) of s' back to back: fc1 and the head run over both as ONE GEMM each (same weights)
+            wo.act3 = self._c51_buf["act3_on"][: B * L.feat]
+            if dq_:
+                wsel.act3 = self._c51_buf["act3_on"][B * L.feat:]
+        buf = self._c51_buf
+        (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
+        (Wh_o, _), (Wh_t, _) = on.wb("head"), tg.wb("head")
+        s_tg = buf["fc1_tg"]
+        self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if dq_ else []) + [(on, wo, 0, True)])
+        npass = 3 if dq_ else 2
+        grouped = (tstage is None and hasattr(ops, "dense_fwd_partial_multi") and ops.dense_fwd_partial_multi_ok(npass, B, 512, L.feat)
+                   and ops.dense_fwd_partial_multi_ok(npass, B, L.Npad, 512))
+        if grouped:
+            # the passes (online on s, online on s' under double-Q, target on s') are GEMMs of one shape each for fc1 and for the head: ONE grouped launch per layer,
+            # the online passes' rows interleaved into the [splits][R_on][N] buffers the reduction and the loss kernel read
+            a3, f1 = buf["act3_on"], buf["fc1_on"]
+            Xs = [a3[: B * L.feat]] + ([a3[B * L.feat:]] if dq_ else []) + [wt.act3]
+            sl = [f1] + ([f1[B * 512:]] if dq_ else []) + [s_tg]
+            st = [R_on * 512] * (npass - 1) + [B * 512]
+            ns_on = ns = ops.dense_fwd_partial_multi(Xs, L.feat, [Wf_o] * (npass - 1) + [Wf_t], B, 512, L.feat, sl, st)
+        else:
+            if tstage is None:
+                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
+            else:
+                s_tg = self._tstage_buf(tstage)[1]
+            ops.dense_fwd_partial(buf["act3_on"], L.feat, Wf_o, R_on, 512, L.feat, buf["fc1_on"])
+        layers = [(buf["fc1_on"], ns_on, bf_o, buf["h_on"], R_on), (s_tg, ns, bf_t, wt.h, B)]
+        ops.reduce_bias_act_multi(layers, 512, True)
+        if grouped:
+            h, hs = buf["h_on"], buf["hs_on"]
+            Xs = [h[: B * 512]] + ([h[B * 512:]] if dq_ else []) + [wt.h]
+            sl = [hs] + ([hs[B * L.Npad:]] if dq_ else []) + [buf["hs_tg"]]
+            st = [R_on * L.Npad] * (npass - 1) + [B * L.Npad]
+            nh_on = nh_tg = ops.dense_fwd_partial_multi(Xs, 512, [Wh_o] * (npass - 1) + [Wh_t], B, L.Npad, 512, sl, st)
+        else:
+            nh_on = ops.dense_fwd_partial(buf["h_on"], 512, Wh_o, R_on, L.Npad, 512, buf["hs_on"])
+            nh_tg = ops.dense_fwd_partial(wt.h, 512, Wh_t, B, L.Npad, 512, buf["hs_tg"])
+        return buf, nh_on, nh_tg, R_on
+
     def forward_dense(self, frames, slot, sample_stride, act, rew, done, wgt, rand: Optional[List[torch.Tensor]] = None, tstage: Optional[int] = None):
         """Forward passes, losses and the dense half of the backward pass (every gradient but the convolution blocks', which
         backward_encoder adds); no parameter is modified (FQF's fraction net aside, which the reference also steps separately,
@@ -536,7 +602,28 @@ class DeviceLearner:
         wo, wt, wsel = self.ws_o, self.ws_t, self.ws_s
         frac = None
         have_draw = have_dh = False
-        if algo == "mdqn":
+        if algo == "mdqn" and L.A + (1 if L.dueling else 0) <= 24 and hasattr(ops, "mdqn_head_loss_slabs") and os.environ.get("A0_MDQN_SEPARATE", "0") != "1":
+            # round 5: dqn's path with the Munchausen target (a0_mdqn_head_loss_slabs) — the three passes' encoders in one launch, their fc1 GEMMs in one grouped launch,
+            # and one kernel from the fc1 slabs to loss, head gradient and dh.  The third pass is the TARGET network on the current observation (agent.py:202-204).
+            wm = self.ws_m
+            (Wo, bo), (Wt, bt) = on.wb("head"), tg.wb("head")
+            ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
+            if getattr(self, "_fc1_slabs", None) is None or self._fc1_slabs[0].numel() < ns * B * 512:
+                self._fc1_slabs = [ops.empty(ns * B * 512) for _ in range(3)]
+                self._q_cur = ops.empty(B * L.A)
+            (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
+            self._encode_passes(frames, slot, sample_stride, [(tg, wt, nxt, False), (tg, wm, 0, False), (on, wo, 0, True)])
+            if hasattr(ops, "dense_fwd_partial_multi") and ops.dense_fwd_partial_multi_ok(3, B, 512, L.feat):
+                ns = ops.dense_fwd_partial_multi([wo.act3, wt.act3, wm.act3], L.feat, [Wf_o, Wf_t, Wf_t], B, 512, L.feat, self._fc1_slabs[:3])
+            else:
+                ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, self._fc1_slabs[1])
+                ops.dense_fwd_partial(wm.act3, L.feat, Wf_t, B, 512, L.feat, self._fc1_slabs[2])
+                ops.dense_fwd_partial(wo.act3, L.feat, Wf_o, B, 512, L.feat, self._fc1_slabs[0])
+            ops.mdqn_head_loss_slabs(self._fc1_slabs[0], self._fc1_slabs[1], self._fc1_slabs[2], ns, bf_o, bf_t, wo.h, Wo, bo, Wt, bt, L.A, L.dueling, L.Npad, act, rew, done, wgt,
+                                     self.gamma_n, self.mdqn_tau, self.mdqn_lo, B, self.loss, wo.q, wt.q, self._q_cur, wo.draw, self.state, wo.dh)
+            have_dh = True
+            have_draw = True
+        elif algo == "mdqn":
             wm = self.ws_m
             # target net on the next AND on the current observation (agent.py:202-204), online net on the current one: one launch
             self._encode_passes(frames, slot, sample_stride, [(tg, wt, nxt, False), (tg, wm, 0, False), (on, wo, 0, True)])
@@ -574,55 +661,21 @@ class DeviceLearner:
         elif algo == "c51" and hasattr(ops, "c51_head_loss_slabs") and os.environ.get("A0_C51_SEPARATE", "0") != "1":      # 1: tuning aid (same numbers, the nine separate launches)
             # three fc1 GEMMs (their split-K slabs finished by ONE reduction launch), the online head as ONE GEMM over [s ; s'] rows, the target head, and
             # one launch for everything behind them (a0_c51_head_loss_slabs: slab sums, dueling, greedy next action, projection + cross entropy, head gradient)
-            dq_ = self.double_q
-            ns = ops.dense_fwd_partial_slabs(B, 512, L.feat)
-            R_on = 2 * B if dq_ else B
-            ns_on = ops.dense_fwd_partial_slabs(R_on, 512, L.feat)
-            if getattr(self, "_c51_buf", None) is None:
-                nh_on, nh_tg = ops.dense_fwd_partial_slabs(R_on, L.Npad, 512), ops.dense_fwd_partial_slabs(B, L.Npad, 512)
-                self._c51_buf = dict(fc1_on=ops.empty(ns_on * R_on * 512), fc1_tg=ops.empty(ns * B * 512), h_on=ops.empty(R_on * 512), act3_on=ops.empty(R_on * L.feat),
-                                     hs_on=ops.empty(nh_on * R_on * L.Npad), hs_tg=ops.empty(nh_tg * B * L.Npad), R_on=R_on)
-                wo.h = self._c51_buf["h_on"][: B * 512]                  # h(s) of the online network: what the backward pass reads
-                # the online network's features of s and (double-Q) of s' back to back: fc1 and the head run over both as ONE GEMM each (same weights)
-                wo.act3 = self._c51_buf["act3_on"][: B * L.feat]
-                if dq_:
-                    wsel.act3 = self._c51_buf["act3_on"][B * L.feat:]
-            buf = self._c51_buf
-            (Wf_o, bf_o), (Wf_t, bf_t) = on.wb("fc1"), tg.wb("fc1")
-            (Wh_o, bh_o), (Wh_t, bh_t) = on.wb("head"), tg.wb("head")
-            s_tg = buf["fc1_tg"]
-            self._encode_passes(frames, slot, sample_stride, ([(tg, wt, nxt, False)] if tstage is None else []) + ([(on, wsel, nxt, False)] if dq_ else []) + [(on, wo, 0, True)])
-            npass = 3 if dq_ else 2
-            grouped = (tstage is None and hasattr(ops, "dense_fwd_partial_multi") and ops.dense_fwd_partial_multi_ok(npass, B, 512, L.feat)
-                       and ops.dense_fwd_partial_multi_ok(npass, B, L.Npad, 512))
-            if grouped:
-                # the passes (online on s, online on s' under double-Q, target on s') are GEMMs of one shape each for fc1 and for the head: ONE grouped launch per layer,
-                # the online passes' rows interleaved into the [splits][R_on][N] buffers the reduction and the loss kernel read
-                a3, f1 = buf["act3_on"], buf["fc1_on"]
-                Xs = [a3[: B * L.feat]] + ([a3[B * L.feat:]] if dq_ else []) + [wt.act3]
-                sl = [f1] + ([f1[B * 512:]] if dq_ else []) + [s_tg]
-                st = [R_on * 512] * (npass - 1) + [B * 512]
-                ns_on = ns = ops.dense_fwd_partial_multi(Xs, L.feat, [Wf_o] * (npass - 1) + [Wf_t], B, 512, L.feat, sl, st)
-            else:
-                if tstage is None:
-                    ops.dense_fwd_partial(wt.act3, L.feat, Wf_t, B, 512, L.feat, s_tg)
-                else:
-                    s_tg = self._tstage_buf(tstage)[1]
-                ops.dense_fwd_partial(buf["act3_on"], L.feat, Wf_o, R_on, 512, L.feat, buf["fc1_on"])
-            layers = [(buf["fc1_on"], ns_on, bf_o, buf["h_on"], R_on), (s_tg, ns, bf_t, wt.h, B)]
-            ops.reduce_bias_act_multi(layers, 512, True)
-            if grouped:
-                h, hs = buf["h_on"], buf["hs_on"]
-                Xs = [h[: B * 512]] + ([h[B * 512:]] if dq_ else []) + [wt.h]
-                sl = [hs] + ([hs[B * L.Npad:]] if dq_ else []) + [buf["hs_tg"]]
-                st = [R_on * L.Npad] * (npass - 1) + [B * L.Npad]
-                nh_on = nh_tg = ops.dense_fwd_partial_multi(Xs, 512, [Wh_o] * (npass - 1) + [Wh_t], B, L.Npad, 512, sl, st)
-            else:
-                nh_on = ops.dense_fwd_partial(buf["h_on"], 512, Wh_o, R_on, L.Npad, 512, buf["hs_on"])
-                nh_tg = ops.dense_fwd_partial(wt.h, 512, Wh_t, B, L.Npad, 512, buf["hs_tg"])
-            ops.c51_head_loss_slabs(buf["hs_on"], nh_on, R_on, buf["hs_tg"], nh_tg, B if dq_ else -1, bh_o, bh_t, L.Npad, L.A, L.T, L.dueling, act, rew, done, wgt,
+            buf, nh_on, nh_tg, R_on = self._dist_heads_to_slabs(frames, slot, sample_stride, tstage)
+            _, bh_o = on.wb("head")
+            _, bh_t = tg.wb("head")
+            ops.c51_head_loss_slabs(buf["hs_on"], nh_on, R_on, buf["hs_tg"], nh_tg, B if self.double_q else -1, bh_o, bh_t, L.Npad, L.A, L.T, L.dueling, act, rew, done, wgt,
                                     self.atoms, self.gamma_n, self.vmin, self.vmax, B, self.loss, wo.draw, self.state, q_on=wo.q, q_tg=wt.q, m_out=self.m_proj,
                                     a_star=self.a_star)
+            have_draw = True
+        elif algo == "qr" and self._qr_fused_ok():
+            # round 5: the same layer structure as c51 (grouped fc1 GEMMs, one reduction launch, grouped head GEMMs) and ONE launch from the head slabs to the
+            # quantile Huber loss and the head gradient (a0_qr_head_loss_slabs; agent.py:272-293)
+            buf, nh_on, nh_tg, R_on = self._dist_heads_to_slabs(frames, slot, sample_stride, tstage)
+            _, bh_o = on.wb("head")
+            _, bh_t = tg.wb("head")
+            ops.qr_head_loss_slabs(buf["hs_on"], nh_on, R_on, buf["hs_tg"], nh_tg, B if self.double_q else -1, bh_o, bh_t, L.Npad, L.A, L.T, L.dueling, act, rew, done, wgt,
+                                   self.qr_taus, self.gamma_n, B, self.loss, wo.draw, self.state, q_on=wo.q, q_tg=wt.q, a_star=self.a_star)
             have_draw = True
         elif algo in ("dqn", "c51", "qr"):
             self._encode_passes(frames, slot, sample_stride, [(tg, wt, nxt, False)] + ([(on, wsel, nxt, False)] if self.double_q else []) + [(on, wo, 0, True)])

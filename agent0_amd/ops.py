@@ -488,6 +488,33 @@ class HipOps:
                                               _req(draw, torch.float32, B * ld, "draw"), _req(state, torch.int32, 4, "state"),
                                               _req(dh, torch.float32, B * 512, "dh", optional=True), _stream()), "a0_dqn_head_loss_slabs")
 
+    def mdqn_head_loss_slabs(self, s_on, s_tg, s_cur, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, tau, lo, B, loss,
+                             q_on, q_tg, q_cur, draw, state, dh=None):
+        """MDQNLearner.train_step from the fc1 GEMMs' slabs on (a0_mdqn_head_loss_slabs): s_cur = the TARGET network's fc1 slabs on the current observation."""
+        nq = A + (1 if dueling else 0)
+        n = nslab * B * 512
+        check(self.lib.a0_mdqn_head_loss_slabs(_req(s_on, torch.float32, n, "slabs_on"), _req(s_tg, torch.float32, n, "slabs_tg"), _req(s_cur, torch.float32, n, "slabs_cur"),
+                                               B * 512, nslab, _req(b1_on, torch.float32, 512, "b1_on"), _req(b1_tg, torch.float32, 512, "b1_tg"),
+                                               _req(h_on, torch.float32, B * 512, "h_on"), _req(W_on, torch.float32, nq * 512, "W_on"), _req(b_on, torch.float32, nq, "b_on"),
+                                               _req(W_tg, torch.float32, nq * 512, "W_tg"), _req(b_tg, torch.float32, nq, "b_tg"), A, int(dueling), ld,
+                                               _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                               _req(wgt, torch.float32, B, "wgt"), float(gamma_n), float(tau), float(lo), B, _req(loss, torch.float32, B, "loss"),
+                                               _req(q_on, torch.float32, B * A, "q_on"), _req(q_tg, torch.float32, B * A, "q_tg", optional=True),
+                                               _req(q_cur, torch.float32, B * A, "q_cur", optional=True), _req(draw, torch.float32, B * ld, "draw"),
+                                               _req(state, torch.int32, 4, "state"), _req(dh, torch.float32, B * 512, "dh", optional=True), _stream()), "a0_mdqn_head_loss_slabs")
+
+    def qr_head_loss_slabs(self, s_on, nslab_on, rows_on, s_tg, nslab_tg, sel_off, bias_on, bias_tg, ld, A, T, dueling, act, rew, done, wgt, taus, gamma_n, B, loss, draw, state,
+                           q_on=None, q_tg=None, a_star=None):
+        """QRLearner.train_step from the head GEMMs' slabs on (a0_qr_head_loss_slabs): the slab layout of ``c51_head_loss_slabs``; taus [T] = the quantile midpoints."""
+        check(self.lib.a0_qr_head_loss_slabs(_req(s_on, torch.float32, nslab_on * rows_on * ld, "slabs_on"), rows_on * ld, nslab_on, rows_on,
+                                             _req(s_tg, torch.float32, nslab_tg * B * ld, "slabs_tg"), B * ld, nslab_tg, int(sel_off),
+                                             _req(bias_on, torch.float32, ld, "bias_on"), _req(bias_tg, torch.float32, ld, "bias_tg"), ld, A, T, int(dueling),
+                                             _req(act, torch.int32, B, "act"), _req(rew, torch.float32, B, "rew"), _req(done, torch.float32, B, "done"),
+                                             _req(wgt, torch.float32, B, "wgt"), _req(taus, torch.float32, T, "taus"), float(gamma_n), B,
+                                             _req(loss, torch.float32, B, "loss"), _req(draw, torch.float32, B * ld, "draw"),
+                                             _req(q_on, torch.float32, B * A * T, "q_on", optional=True), _req(q_tg, torch.float32, B * A * T, "q_tg", optional=True),
+                                             _req(a_star, torch.int32, B, "a_star", optional=True), _req(state, torch.int32, 4, "state"), _stream()), "a0_qr_head_loss_slabs")
+
     def reduce_bias_act_multi(self, layers, N, relu=True):
         """layers: [(slabs, nslab, bias, out, rows)] (at most four, all of width N): out = act(sum of the layer's split-K slabs + bias), one launch."""
         n = len(layers)

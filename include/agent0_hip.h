@@ -227,6 +227,13 @@ int a0_dqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const f
 /* MDQNLearner.train_step (agent.py:194-215): q_next = target(next_obs), q_cur_tgt = target(obs), both [B][A] */
 int a0_loss_mdqn(const float* q, const float* q_next, const float* q_cur_tgt, int A, const int* act, const float* rew, const float* done,
                  const float* wgt, float gamma_n, float tau, float lo, int B, float* loss, float* dq, int* nan_flag, void* stream);
+/* (round 5) MDQNLearner.train_step (agent.py:193-215) from the fc1 GEMMs' split-K slabs on, one launch — a0_dqn_head_loss_slabs with the Munchausen target: slabs_cur are
+ * the TARGET network's fc1 slabs on the CURRENT observation (agent.py:202-204; finished with the target's fc1 bias, evaluated with the target's head), tau / lo as in
+ * a0_loss_mdqn.  q_cur_out (optional, [B][A]) receives target(obs).  Given the q values it writes, loss and draw equal a0_loss_mdqn + a0_dueling_bwd bit for bit. */
+int a0_mdqn_head_loss_slabs(const float* slabs_on, const float* slabs_tg, const float* slabs_cur, long long slab_stride, int nslab, const float* b1_on,
+                            const float* b1_tg, float* h_on_out, const float* W_on, const float* b_on, const float* W_tg, const float* b_tg, int A,
+                            int dueling, int ld, const int* act, const float* rew, const float* done, const float* wgt, float gamma_n, float tau, float lo,
+                            int B, float* loss, float* q_on_out, float* q_tg_out, float* q_cur_out, float* draw, int* nan_flag, float* dh_out, void* stream);
 /* C51Learner.train_step (agent.py:219-269) from the head GEMMs' split-K slabs on, one launch: slab sums + bias (a0_dense_fwd's reduction), dueling combine per
  * atom (model.py:163-177), greedy next action from the expectation under softmax (agent.py:225-231), projection of the target distribution and cross entropy
  * (a0_loss_c51), d loss / d logits carried back through the dueling combine into `draw` [B][ld] — the gradient w.r.t. the online head GEMM's output on s.
@@ -238,6 +245,17 @@ int a0_c51_head_loss_slabs(const float* slabs_on, long long stride_on, int nslab
                            int sel_off, const float* bias_on, const float* bias_tg, int ld, int A, int T, int dueling, const int* act, const float* rew,
                            const float* done, const float* wgt, const float* atoms, float gamma_n, float vmin, float vmax, int B, float* loss, float* draw,
                            float* q_on_out, float* q_tg_out, float* m_out, int* a_star_out, int* nan_flag, void* stream);
+/* (round 5) QRLearner.train_step (agent.py:272-293 with huber_qr_loss 110-114) from the head GEMMs' split-K slabs on, one launch — the quantile-regression counterpart
+ * of a0_c51_head_loss_slabs, same slab layout and the same meaning of rows_on / sel_off: slab sums + bias, dueling combine per quantile (model.py:163-177 through QRHead
+ * 180-192), greedy next action from the mean over the T quantiles (agent.py:277-280), target quantiles r + gamma^n (1 - d) q'(a*), the T x T pairwise quantile Huber loss
+ * with fractions taus [T] (the fixed midpoints, agent.py:274), d loss / d q carried back through the dueling combine into `draw` [B][ld].  One workgroup per sample, the
+ * staged head outputs and the targets in LDS, the B x T x T pair tensor never materialised.  Optional outputs: q_on_out / q_tg_out [B][A][T], a_star_out [B].  Same
+ * arithmetic, statement for statement, as a0_dense_fwd's reduction + a0_dueling_fwd + a0_select_action(mode 1) + a0_quantile_target + a0_loss_quantile_huber +
+ * a0_dueling_bwd. */
+int a0_qr_head_loss_slabs(const float* slabs_on, long long stride_on, int nslab_on, int rows_on, const float* slabs_tg, long long stride_tg, int nslab_tg,
+                          int sel_off, const float* bias_on, const float* bias_tg, int ld, int A, int T, int dueling, const int* act, const float* rew,
+                          const float* done, const float* wgt, const float* taus, float gamma_n, int B, float* loss, float* draw, float* q_on_out,
+                          float* q_tg_out, int* a_star_out, int* nan_flag, void* stream);
 /* C51Learner.train_step (agent.py:219-269): logits / tgt_logits [B][A][T]; m_out (optional) = projected target [B][T] */
 int a0_loss_c51(const float* logits, const float* tgt_logits, int A, int T, const int* act, const int* a_star,
                 const float* rew, const float* done, const float* wgt, const float* atoms, float gamma_n,

@@ -405,6 +405,50 @@ class CpuOps:
         self.loss_c51(q_o, q_t, A, T, act, a_s, rew, done, wgt, atoms, gamma_n, vmin, vmax, B, loss, dq, m_out, state)
         self.dueling_bwd(dq, draw, ld, B, A, T, dueling)
 
+    def qr_head_loss_slabs(self, s_on, nslab_on, rows_on, s_tg, nslab_tg, sel_off, bias_on, bias_tg, ld, A, T, dueling, act, rew, done, wgt, taus, gamma_n, B, loss, draw, state,
+                           q_on=None, q_tg=None, a_star=None):
+        """The composition the HIP kernel replaces: slab sums + bias, dueling, greedy next action (mean over quantiles), target quantiles, quantile Huber, dueling backward."""
+        raw_on = s_on[: nslab_on * rows_on * ld].view(nslab_on, rows_on, ld).sum(0) + bias_on[:ld]
+        raw_tg = s_tg[: nslab_tg * B * ld].view(nslab_tg, B, ld).sum(0) + bias_tg[:ld]
+        q_o = q_on if q_on is not None else torch.empty(B * A * T)
+        q_t = q_tg if q_tg is not None else torch.empty(B * A * T)
+        self.dueling_fwd(raw_on[:B].reshape(-1).contiguous(), ld, q_o, B, A, T, dueling)
+        self.dueling_fwd(raw_tg.reshape(-1).contiguous(), ld, q_t, B, A, T, dueling)
+        a_s = a_star if a_star is not None else torch.zeros(B, dtype=torch.int32)
+        if sel_off >= 0:
+            q_s = torch.empty(B * A * T)
+            self.dueling_fwd(raw_on[sel_off: sel_off + B].reshape(-1).contiguous(), ld, q_s, B, A, T, dueling)
+            self.select_action(q_s, A * T, T, 1, B, A, T, 1, None, a_s, None, None)
+        else:
+            self.select_action(q_t, A * T, T, 1, B, A, T, 1, None, a_s, None, None)
+        y = torch.empty(B * T)
+        self.quantile_target(q_t, A * T, 1, T, a_s, rew, done, gamma_n, B, T, y)
+        dq = torch.zeros(B * A * T)
+        self.loss_quantile_huber(q_o, A * T, 1, T, y, taus, 0, act, wgt, B, T, T, loss, dq, state)
+        self.dueling_bwd(dq, draw, ld, B, A, T, dueling)
+
+    def mdqn_head_loss_slabs(self, s_on, s_tg, s_cur, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, tau, lo, B, loss,
+                             q_on, q_tg, q_cur, draw, state, dh=None):
+        def fc1(slabs, bias):
+            return torch.relu(slabs[: nslab * B * 512].view(nslab, B, 512).sum(0) + bias[:512]).reshape(-1).contiguous()
+
+        def head(h, W, b, q):
+            raw = torch.empty(B * ld)
+            self.dense_fwd(h, 512, W, b, raw, B, ld, 512, False, self.empty(max(self.dense_fwd_scratch(B, ld, 512), 1)))
+            self.dueling_fwd(raw, ld, q, B, A, 1, dueling)
+
+        h_on[: B * 512] = fc1(s_on, b1_on)
+        q_t = q_tg if q_tg is not None else torch.empty(B * A)
+        q_c = q_cur if q_cur is not None else torch.empty(B * A)
+        head(h_on, W_on, b_on, q_on)
+        head(fc1(s_tg, b1_tg), W_tg, b_tg, q_t)
+        head(fc1(s_cur, b1_tg), W_tg, b_tg, q_c)
+        dq = torch.zeros(B * A)
+        self.loss_mdqn(q_on, q_t, q_c, A, act, rew, done, wgt, gamma_n, tau, lo, B, loss, dq, state)
+        self.dueling_bwd(dq, draw, ld, B, A, 1, dueling)
+        if dh is not None:
+            self.dense_dgrad(draw, W_on, h_on, dh, B, ld, 512)
+
     def dqn_head_loss_slabs(self, s_on, s_tg, s_sel, nslab, b1_on, b1_tg, h_on, W_on, b_on, W_tg, b_tg, A, dueling, ld, act, rew, done, wgt, gamma_n, B, loss, q_on, q_tg,
                             draw, state, dh=None):
         def fc1(slabs, bias):

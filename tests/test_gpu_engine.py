@@ -622,6 +622,118 @@ def test_c51_head_loss_from_slabs_equals_the_separate_kernels(hip, A, T, dueling
         assert torch.equal(out, wv)
 
 
+@pytest.mark.parametrize("A,T,dueling,double_q,B", [(4, 200, True, True, 512), (4, 200, False, False, 37), (18, 200, True, True, 33), (6, 11, True, False, 9), (3, 64, False, True, 130),
+                                                    (2, 300, True, False, 5)])
+def test_qr_head_loss_from_slabs_equals_the_separate_kernels(hip, A, T, dueling, double_q, B):
+    """a0_qr_head_loss_slabs (round 5: one launch from the head GEMMs' split-K slabs to the quantile Huber loss + head gradient; reference agent.py:272-293) against the
+    launches it replaces — slab reduction, a0_dueling_fwd x3, a0_select_action (mean over quantiles), a0_quantile_target, dq memset + a0_loss_quantile_huber,
+    a0_dueling_bwd — on the same slabs: the same arithmetic statement for statement, so every output must be BIT-identical (torch.equal); T > 256 (strided
+    quantile ownership), T not a multiple of four (scalar tail of the target sweep) and padded head columns included."""
+    g = recipe.gen(A * 1000 + T + B)
+    NQ = A + (1 if dueling else 0)
+    ld = (NQ * T + 31) // 32 * 32
+    R_on = 2 * B if double_q else B
+    ns_on, ns_tg = 5, 3
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
+    s_on = D((g.standard_normal((ns_on, R_on, ld)) * 0.7).astype(np.float32))
+    s_tg = D((g.standard_normal((ns_tg, B, ld)) * 0.7).astype(np.float32))
+    b_on, b_tg = D(g.standard_normal(ld).astype(np.float32)), D(g.standard_normal(ld).astype(np.float32))
+    a, r, d, w = recipe.make_transitions(B, A, 5)
+    act, rew, done, wgt = D(a.astype(np.int32)), D(r), D(d.astype(np.float32)), D(w)
+    taus = ((2 * torch.arange(T, dtype=torch.float32) + 1) / (2.0 * T)).to(hip.device)
+    state = hip.zeros(8, dtype=torch.int32)
+    loss, draw = hip.empty(B), hip.empty(B * ld).fill_(7.0)
+    q_on, q_tg, a_star = hip.empty(B * A * T), hip.empty(B * A * T), hip.zeros(B, dtype=torch.int32)
+    hip.qr_head_loss_slabs(s_on.reshape(-1), ns_on, R_on, s_tg.reshape(-1), ns_tg, B if double_q else -1, b_on, b_tg, ld, A, T, dueling, act, rew, done, wgt, taus,
+                           0.97, B, loss, draw, state, q_on=q_on, q_tg=q_tg, a_star=a_star)
+    def reduce(slabs, bias):
+        acc = torch.zeros_like(slabs[0])
+        for z in range(slabs.shape[0]):
+            acc = acc + slabs[z]                # slab order
+        return (acc + bias).contiguous()
+    raw_on, raw_tg = reduce(s_on, b_on), reduce(s_tg, b_tg)
+    q1, q2, q3 = hip.empty(B * A * T), hip.empty(B * A * T), hip.empty(B * A * T)
+    hip.dueling_fwd(raw_on[:B].reshape(-1), ld, q1, B, A, T, dueling)
+    hip.dueling_fwd(raw_tg.reshape(-1), ld, q2, B, A, T, dueling)
+    a2 = hip.zeros(B, dtype=torch.int32)
+    if double_q:
+        hip.dueling_fwd(raw_on[B:].reshape(-1).contiguous(), ld, q3, B, A, T, dueling)
+        hip.select_action(q3, A * T, T, 1, B, A, T, 1, None, a2, None, None)
+    else:
+        hip.select_action(q2, A * T, T, 1, B, A, T, 1, None, a2, None, None)
+    y = hip.empty(B * T)
+    hip.quantile_target(q2, A * T, 1, T, a2, rew, done, 0.97, B, T, y)
+    loss2, dq2, draw2 = hip.empty(B), hip.zeros(B * A * T), hip.empty(B * ld)
+    hip.loss_quantile_huber(q1, A * T, 1, T, y, taus, 0, act, wgt, B, T, T, loss2, dq2, state)
+    hip.dueling_bwd(dq2, draw2, ld, B, A, T, dueling)
+    torch.cuda.synchronize()
+    assert torch.equal(q_on, q1) and torch.equal(q_tg, q2), "combined quantile values"
+    assert torch.equal(a_star, a2), "greedy next action"
+    assert torch.equal(loss, loss2), "per-sample loss"
+    assert torch.equal(draw, draw2), "gradient w.r.t. the raw head output"
+    assert int(state[0]) == 0
+    # and against a float64 evaluation of agent.py:110-114 on the device's own q values (the pair tensor materialised)
+    qv = q1.view(B, A, T).double().cpu()
+    qsel = qv[torch.arange(B), torch.from_numpy(a.astype(np.int64))]                                            # [B][T] online quantiles at the taken action
+    tgt = y.view(B, T).double().cpu()
+    dlt = qsel[:, None, :] - tgt[:, :, None]                                                                    # [B][N' = j][N = i]
+    hub = torch.where(dlt.abs() < 1, 0.5 * dlt * dlt, dlt.abs() - 0.5)
+    wq = (taus.double().cpu()[None, None, :] - (tgt[:, :, None] < qsel[:, None, :]).double()).abs()
+    want = (hub * wq).sum(-1).mean(-1)
+    assert float((loss.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("A,dueling,B", [(4, False, 512), (4, True, 37), (18, True, 65), (23, True, 9), (6, False, 130)])
+def test_mdqn_head_loss_from_slabs_equals_the_separate_kernels(hip, A, dueling, B):
+    """a0_mdqn_head_loss_slabs (round 5: MDQNLearner.train_step, agent.py:193-215, from the three fc1 GEMMs' split-K slabs in one launch) against the separate
+    kernels: fc1 = slab sums + bias + ReLU, the heads as a0_dense_fwd GEMMs + a0_dueling_fwd (another association of the 512-term dot products: compared at
+    2e-6 of the scale), and — on the q values the fused kernel itself reports — a0_loss_mdqn + a0_dueling_bwd + a0_dense_dgrad bit for bit (loss, draw) / to
+    rounding (dh).  The third pass must use the TARGET network's fc1 bias and head rows."""
+    g = recipe.gen(A * 977 + B)
+    NQ = A + (1 if dueling else 0)
+    ld = (NQ + 31) // 32 * 32
+    ns = 4
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(hip.device)
+    s_on, s_tg, s_cur = (D((g.standard_normal((ns, B, 512)) * 0.5).astype(np.float32)) for _ in range(3))
+    b1_on, b1_tg = D((g.standard_normal(512) * 0.3).astype(np.float32)), D((g.standard_normal(512) * 0.3).astype(np.float32))
+    W_on, W_tg = D((g.standard_normal((ld, 512)) * 0.05).astype(np.float32)), D((g.standard_normal((ld, 512)) * 0.05).astype(np.float32))
+    b_on, b_tg = D((g.standard_normal(ld) * 0.1).astype(np.float32)), D((g.standard_normal(ld) * 0.1).astype(np.float32))
+    a, r, d, w = recipe.make_transitions(B, A, 5)
+    act, rew, done, wgt = D(a.astype(np.int32)), D(r), D(d.astype(np.float32)), D(w)
+    state = hip.zeros(8, dtype=torch.int32)
+    loss, draw, dh, h_on = hip.empty(B), hip.empty(B * ld).fill_(7.0), hip.empty(B * 512), hip.empty(B * 512)
+    q_on, q_tg, q_cur = hip.empty(B * A), hip.empty(B * A), hip.empty(B * A)
+    tau, lo, gam = 0.03, -1.0, 0.97
+    hip.mdqn_head_loss_slabs(s_on.reshape(-1), s_tg.reshape(-1), s_cur.reshape(-1), ns, b1_on, b1_tg, h_on, W_on.reshape(-1), b_on, W_tg.reshape(-1), b_tg, A, dueling, ld,
+                             act, rew, done, wgt, gam, tau, lo, B, loss, q_on, q_tg, q_cur, draw, state, dh)
+    def fc1(slabs, bias):
+        acc = torch.zeros_like(slabs[0])
+        for z in range(ns):
+            acc = acc + slabs[z]
+        return torch.relu(acc + bias).reshape(-1).contiguous()
+    def head(h, W, b):
+        raw, q = hip.empty(B * ld), hip.empty(B * A)
+        hip.dense_fwd(h, 512, W.reshape(-1), b, raw, B, ld, 512, False, hip.empty(max(hip.dense_fwd_scratch(B, ld, 512), 4)))
+        hip.dueling_fwd(raw, ld, q, B, A, 1, dueling)
+        return q
+    h1 = fc1(s_on, b1_on)
+    q1, q2, q3 = head(h1, W_on, b_on), head(fc1(s_tg, b1_tg), W_tg, b_tg), head(fc1(s_cur, b1_tg), W_tg, b_tg)
+    torch.cuda.synchronize()
+    assert torch.equal(h_on, h1), "online fc1 activations"
+    scale = float(q1.abs().max())
+    for got, want, what in ((q_on, q1, "online(s)"), (q_tg, q2, "target(s')"), (q_cur, q3, "target(s)")):
+        assert float((got - want).abs().max()) <= 2e-6 * max(scale, 1.0), what
+    loss2, dq2, draw2, dh2 = hip.empty(B), hip.zeros(B * A), hip.empty(B * ld), hip.empty(B * 512)
+    hip.loss_mdqn(q_on, q_tg, q_cur, A, act, rew, done, wgt, gam, tau, lo, B, loss2, dq2, state)
+    hip.dueling_bwd(dq2, draw2, ld, B, A, 1, dueling)
+    hip.dense_dgrad(draw2, W_on.reshape(-1), h1, dh2, B, ld, 512)
+    torch.cuda.synchronize()
+    assert torch.equal(loss, loss2), "per-sample Munchausen loss"
+    assert torch.equal(draw, draw2), "gradient w.r.t. the raw head output"
+    assert float((dh - dh2).abs().max()) <= 2e-6 * max(float(dh2.abs().max()), 1e-6)
+    assert int(state[0]) == 0
+
+
 G6P_GPU = ["fqf_b16_dq0_n1", "fqf_duel_b16_dq1_n3", "fqf_duel_a18_b16_dq1_n3"]
 
 
