@@ -32,6 +32,9 @@ struct rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -57,6 +60,9 @@ rccl_api& api() {
         a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
         a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
         a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
+        a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
+        a.CommCuDevice = (decltype(a.CommCuDevice))sym("ncclCommCuDevice");
     });
     return a;
 }
@@ -94,6 +100,19 @@ extern "C" int a0_dp_allreduce(long long comm, float* buf, long long n, void* st
     if (!comm || !buf || n < 1) return a0_fail(A0_EINVAL, "a0_dp_allreduce: bad argument");
     ncclResult_t r = a.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)(intptr_t)comm, (hipStream_t)stream);
     return r == ncclSuccess ? A0_OK : fail_rccl(r, "ncclAllReduce");
+}
+
+// What RCCL itself says about a communicator — ncclCommCount, ncclCommUserRank, ncclCommCuDevice — so that a multi-rank record (bench.py's "rccl" object) carries the
+// library's own statement of the rank count instead of the launcher's environment.  host_out3 = {nranks, rank, device}.
+extern "C" int a0_dp_info(long long comm, int* host_out3) {
+    rccl_api& a = api();
+    if (!a.error.empty()) return a0_fail(A0_EINVAL, a.error.c_str());
+    if (!comm || !host_out3) return a0_fail(A0_EINVAL, "a0_dp_info: bad argument");
+    ncclComm_t c = (ncclComm_t)(intptr_t)comm;
+    ncclResult_t r = a.CommCount(c, &host_out3[0]);
+    if (r == ncclSuccess) r = a.CommUserRank(c, &host_out3[1]);
+    if (r == ncclSuccess) r = a.CommCuDevice(c, &host_out3[2]);
+    return r == ncclSuccess ? A0_OK : fail_rccl(r, "ncclCommCount / ncclCommUserRank / ncclCommCuDevice");
 }
 
 extern "C" int a0_dp_destroy(long long comm) {

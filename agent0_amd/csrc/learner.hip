@@ -291,6 +291,24 @@ extern "C" int a0_learner_loss_buffer(const a0_learner* L, float** loss_dev) {
     return A0_OK;
 }
 
+// Borrowed views of the handle's own HBM for inspection (parity harnesses walking the handle path link by link against the CPU oracle need the gradients and the
+// differentiated pass's activations — the ReLU decisions — that a0_learner_get does not copy out).  Valid until the next call on the handle / a0_learner_destroy.
+extern "C" int a0_learner_peek(const a0_learner* L, int what, float** dev_ptr, long long* count) {
+    if (!L || !dev_ptr || !count) return a0_fail(A0_EINVAL, "a0_learner_peek: null argument");
+    const long long B = L->d.B;
+    switch (what) {
+        case A0_PEEK_GRADS: *dev_ptr = L->grads; *count = L->n_pad; break;
+        case A0_PEEK_ACT1: *dev_ptr = L->act1; *count = B * L->H1 * L->W1 * 32; break;
+        case A0_PEEK_ACT2: *dev_ptr = L->act2; *count = B * L->H2 * L->W2 * 64; break;
+        case A0_PEEK_ACT3: *dev_ptr = L->act3_o; *count = B * L->feat; break;
+        case A0_PEEK_FC1: *dev_ptr = (L->d.algo == A0_ALGO_IQN || L->d.algo == A0_ALGO_FQF) ? L->qo.h : L->h; *count = ((L->d.algo == A0_ALGO_IQN || L->d.algo == A0_ALGO_FQF) ? L->qo.R : B) * 512; break;
+        case A0_PEEK_LOSS: *dev_ptr = L->loss; *count = B; break;
+        default: return a0_fail(A0_EINVAL, "a0_learner_peek: unknown buffer");
+    }
+    if (!*dev_ptr) return a0_fail(A0_ESTATE, "a0_learner_peek: this learner does not keep that buffer");
+    return A0_OK;
+}
+
 extern "C" int a0_learner_get_frac_loss(const a0_learner* L, float* out_dev, void* stream) {
     A0_TRY
     if (!L || !out_dev || !L->frac_loss) return a0_fail(A0_EINVAL, "a0_learner_get_frac_loss: an fqf handle and an output buffer");

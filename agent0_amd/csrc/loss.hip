@@ -1138,14 +1138,21 @@ __global__ void a0_quantile_target_kernel(const float* __restrict__ q_next, long
 // One online quantile q_i against the N' targets held in LDS (16-byte aligned), in target order: al = sum_j huber(q_i - T_j) |tau_i - 1{T_j < q_i}| and
 // ag = sum_j clamp(q_i - T_j, -1, 1) |tau_i - 1{T_j < q_i}| (reference agent.py:110-114 and its derivative w.r.t. q_i).  Shared by the stand-alone loss kernel and
 // by the kernel that runs QRLearner.train_step from the head GEMMs' slabs, so the two cannot differ.  Four targets per LDS read (every lane reads the same address: a
-// broadcast); the two values |tau - 1| and |tau - 0| the weight can take are formed once per quantile.
+// broadcast).  Eight vector instructions per pair (round 4: eleven), none of them changing a rounding:
+//   * the two values |tau - 1| and |tau - 0| the weight can take are formed once per quantile (kept out of the loop by an empty asm: the compiler would otherwise
+//     sink the abs behind the select and pay it per pair);
+//   * with c = min(|d|, 1) the Huber value (|d| < 1 ? 0.5 d d : |d| - 0.5) is c * (|d| - 0.5 c): for |d| < 1 the bracket is |d| - 0.5 |d| = 0.5 |d| exactly (an
+//     exponent step) and the product |d| * (0.5 |d|) is the same correctly rounded product as (0.5 d) * d; for |d| >= 1 it is 1 * (|d| - 0.5);
+//   * both sums advance in one packed fma.
 A0_D void a0_qh_sweep(float qi, float tau, const float* __restrict__ s_t, int Nd, float& al, float& ag) {
-    const float w_lt = fabsf(tau - 1.f), w_ge = fabsf(tau - 0.f);
+    float w_lt = fabsf(tau - 1.f), w_ge = fabsf(tau - 0.f);
+    asm volatile("" : "+v"(w_lt), "+v"(w_ge));
     float l = 0.f, g = 0.f;
     auto pair = [&](float tj) {
         const float d = qi - tj;
         const float ad = fabsf(d);
-        const float h = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+        const float c = fminf(ad, 1.f);
+        const float h = c * __builtin_fmaf(-0.5f, c, ad);
         const float wq = (tj < qi) ? w_lt : w_ge;
         l += h * wq;
         g += fminf(fmaxf(d, -1.f), 1.f) * wq;

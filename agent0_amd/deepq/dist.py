@@ -93,6 +93,14 @@ class GradAllReduce:
             self._dense.wait()          # the current stream waits for the dense bucket (no host block on RCCL)
             self._dense = None
 
+    def report(self) -> dict:
+        """The torch.distributed counterpart of RcclGradAllReduce.report (collective)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        x = torch.ones(1024, device=dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
+        return {"backend": f"torch.distributed ({self.dist.get_backend(self.group)})", "nranks": self.dist.get_world_size(self.group), "rank": self.dist.get_rank(self.group),
+                "device": (torch.cuda.current_device() if dev.type == "cuda" else None), "allreduce_of_ones": float(x[0]), "allreduce_of_ones_last": float(x[-1]), "in_graph": False}
+
     def __call__(self, grads: torch.Tensor, state: torch.Tensor):
         """One-shot form (no overlap): the whole buffer, then the flag."""
         if not self.active:
@@ -262,6 +270,17 @@ class RcclGradAllReduce:
         self.side.wait_stream(cur)                                   # the convolution blocks' gradients are final
         self.ops.dp_allreduce(self.comm, grads[:conv_end], conv_end, stream=self.side)
         cur.wait_stream(self.side)                                   # Adam sees both buckets reduced
+
+    def report(self) -> dict:
+        """What the exchange itself says about the job (collective: every rank calls it at the same point): RCCL's own rank count / rank / device for the communicator
+        the gradients travel on (a0_dp_info) and the result of an all-reduce of ones through it — a record that reads nranks = 8 and allreduce_of_ones = 8.0 was
+        produced by eight ranks that really exchanged data."""
+        nranks, rank, device = self.ops.dp_info(self.comm)
+        x = torch.ones(1024, device="cuda")
+        self.ops.dp_allreduce(self.comm, x, x.numel())
+        torch.cuda.synchronize()
+        return {"backend": "rccl (a0_dp_allreduce: ncclAllReduce through the C-ABI)", "nranks": nranks, "rank": rank, "device": device,
+                "allreduce_of_ones": float(x[0]), "allreduce_of_ones_last": float(x[-1]), "in_graph": bool(self.in_graph)}
 
     def close(self):
         if self.comm:

@@ -108,9 +108,17 @@ def eligible(tr) -> Optional[str]:
 class NativeLoop:
     def __init__(self, tr):
         self.tr = tr
+        self.learner = self.rbuf = self.actor = None        # close() destroys whatever exists, also when a later create call fails
+        self.lib, self.ok = _abi.load(), _abi.check
+        try:
+            self._create(tr)
+        except Exception:
+            self.close()
+            raise
+
+    def _create(self, tr):
         cfg, ops = tr.cfg, tr.ops
         lc, rc = cfg.learner, cfg.replay
-        self.lib, self.ok = _abi.load(), _abi.check
         lib, ok = self.lib, self.ok
         eng, rp, actor = tr.learner.engine, tr.replay, tr.actors[1]
         L = eng.L
@@ -172,27 +180,39 @@ class NativeLoop:
             self.ok(self.lib.a0_rbuf_info(self.rbuf, None, None, C.addressof(beta)), "a0_rbuf_info")
             rp.beta = beta.value
 
+    # the three links of one update (trainer.py:81-104) — kept apart so that a parity harness can stand between them (tests/test_gpu_trace.py walks this very path
+    # against the CPU oracle link by link)
+    def _sample(self, i: int, n: int, st):
+        """The i-th batch of a block of n: sampled indices, ring slots, metadata and importance weights in the handle's device buffers (a0_batch)."""
+        if self.prio:
+            b = _Batch()
+            self.ok(self.lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
+            return b
+        if i % 32 == 0:                                   # uniform replay: the block's batches do not depend on its updates — 32 of them per sampling launch
+            self._blk = (_Batch * 32)()
+            self.ok(self.lib.a0_rbuf_sample_block(self.rbuf, min(32, n - i), self._blk, st), "a0_rbuf_sample_block")
+        return self._blk[i % 32]
+
+    def _update(self, b, st):
+        self.ok(self.lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, None, st), "a0_learner_update")
+
+    def _priority(self, st):
+        self.ok(self.lib.a0_rbuf_update_priority(self.rbuf, self.loss_ptr, self.tr.learner.engine.state.data_ptr(), st), "a0_rbuf_update_priority")
+
     def _block(self, st) -> int:
         tr, lib, ok = self.tr, self.lib, self.ok
         cfg = tr.cfg
         if int(lib.a0_rbuf_len(self.rbuf)) <= cfg.trainer.training_start_steps:
             return 0
-        eng, ln = tr.learner.engine, tr.learner
-        b = _Batch()
+        ln = tr.learner
         n = int(cfg.learner.learner_steps)
         if self.fqf and tr._floss_means.numel() < n:
             tr._loss_means, tr._floss_means = tr.ops.zeros(n), tr.ops.zeros(n)
-        blk = (_Batch * 32)()
         for i in range(n):
+            b = self._sample(i, n, st)
+            self._update(b, st)
             if self.prio:
-                ok(lib.a0_rbuf_sample(self.rbuf, C.addressof(b), st), "a0_rbuf_sample")
-            else:                                         # uniform replay: the block's batches do not depend on its updates — 32 of them per sampling launch
-                if i % 32 == 0:
-                    ok(lib.a0_rbuf_sample_block(self.rbuf, min(32, n - i), blk, st), "a0_rbuf_sample_block")
-                b = blk[i % 32]
-            ok(lib.a0_learner_update(self.learner, self.frames_ptr, b.slot, C.c_longlong(self.row_bytes), b.act, b.rew, b.done, b.weights, None, st), "a0_learner_update")
-            if self.prio:
-                ok(lib.a0_rbuf_update_priority(self.rbuf, self.loss_ptr, eng.state.data_ptr(), st), "a0_rbuf_update_priority")
+                self._priority(st)
             if self.fqf:                                  # the `fraction_loss` statistic (trainer.py:99-101): batch mean of the update's fraction losses
                 ok(lib.a0_learner_get_frac_loss(self.learner, self._floss.data_ptr(), st), "a0_learner_get_frac_loss")
                 tr.ops.mean_rows(self._floss, 1, self.B, tr._floss_means[i:i + 1])
@@ -249,7 +269,7 @@ class NativeLoop:
             pass
 
     def close(self):
-        if self.actor is None and self.rbuf is None and self.learner is None:
+        if getattr(self, "actor", None) is None and getattr(self, "rbuf", None) is None and getattr(self, "learner", None) is None:
             return
         torch.cuda.synchronize()
         for h, fn in ((self.actor, self.lib.a0_actor_destroy), (self.rbuf, self.lib.a0_rbuf_destroy), (self.learner, self.lib.a0_learner_destroy)):

@@ -450,7 +450,14 @@ class Trainer:
                 self._nl = False
                 self.native_loop_reason = why or "hot-loop methods wrapped, a gradient hook, or a run already under way"
                 return None
-            nl = self._nl = native_loop.NativeLoop(self)
+            try:
+                nl = self._nl = native_loop.NativeLoop(self)
+            except RuntimeError as e:            # a create call refused the configuration: NativeLoop has destroyed what it had created; the Python classes run the loop
+                self._nl = False
+                self.native_loop_reason = f"handle creation failed: {e}"
+                if self.primary:
+                    self.logger.info("host loop: Python classes (%s)", self.native_loop_reason)
+                return None
             if self.primary:
                 self.logger.info("host loop: library handles over this Trainer's buffers (agent0_amd/deepq/native_loop.py); A0_NATIVE_LOOP=0 keeps the Python classes in charge")
         elif not ok_now:

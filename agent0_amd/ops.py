@@ -749,6 +749,12 @@ class HipOps:
         """In-place fp32 SUM over the communicator's ranks, enqueued on ``stream`` (a torch.cuda.Stream; default: the current one)."""
         check(self.lib.a0_dp_allreduce(comm, _req(buf, torch.float32, n, "buf"), n, _stream() if stream is None else stream.cuda_stream), "a0_dp_allreduce")
 
+    def dp_info(self, comm: int):
+        """(ncclCommCount, ncclCommUserRank, ncclCommCuDevice) of a communicator, as RCCL reports them."""
+        out = (C.c_int * 3)()
+        check(self.lib.a0_dp_info(comm, out), "a0_dp_info")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def dp_destroy(self, comm: int):
         check(self.lib.a0_dp_destroy(comm), "a0_dp_destroy")
 

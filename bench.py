@@ -206,6 +206,40 @@ def cpu_baseline(args, cfg):
             "items": items}
 
 
+def rank_clock(dist, dt: float, dt_local: float, rank: int, world: int, steps: int, device):
+    """The contract's clock under data parallelism: MAX over the ranks of the barrier-to-barrier time, plus every rank's own time for its K steps up to its local
+    synchronize (a straggler shows in the one JSON line).  Two collectives on ``device`` ("cuda" under RCCL; "cpu" in the gloo test of this function)."""
+    import torch
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    loc = torch.zeros(world, device=device, dtype=torch.float64)
+    loc[rank] = dt_local
+    dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+    ms = [round(1e3 * float(x) / steps, 3) for x in loc.tolist()]
+    per_rank = {"min": min(ms), "max": max(ms), "ranks": ms,
+                "note": "each rank's own time for the K steps up to its local synchronize, before the closing barrier; ms_per_step is the max over ranks of the barrier-to-barrier time"}
+    return float(t[0]), per_rank
+
+
+def exchange_report(hook, world: int):
+    """The "rccl" object of a data-parallel line: what the gradient exchange itself reports (hook.report(): RCCL's ncclCommCount / ncclCommUserRank for the communicator
+    the gradients travel on and an all-reduce of ones through it), checked against the launcher's WORLD_SIZE.  Collective."""
+    if hook is None or not hasattr(hook, "report"):
+        return None
+    r = hook.report()
+    r["matches_world_size"] = bool(r["nranks"] == world and abs(r["allreduce_of_ones"] - world) < 1e-3 and abs(r["allreduce_of_ones_last"] - world) < 1e-3)
+    return r
+
+
+def throughput_fields(world: int, per_iter: int, learner_steps: int, steps: int, warmup: int, dt: float):
+    """value = units ALL ranks processed / the max-over-ranks time (weak scaling: per-rank work is fixed)."""
+    value = world * per_iter * steps / dt
+    return {"value": round(value, 1), "unit": "env-frames/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "emulator_frames_per_sec_x4": round(4 * value, 1),
+            "updates_per_sec": round(world * learner_steps * steps / dt, 2)}
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
@@ -278,15 +312,7 @@ def main():
     per_rank = None
     if dp:
         import torch.distributed as dist
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-        loc = torch.zeros(world, device="cuda", dtype=torch.float64)
-        loc[rank] = dt_local
-        dist.all_reduce(loc, op=dist.ReduceOp.SUM)
-        ms = [round(1e3 * float(x) / args.steps, 3) for x in loc.tolist()]
-        per_rank = {"min": min(ms), "max": max(ms), "ranks": ms,
-                    "note": "each rank's own time for the K steps up to its local synchronize, before the closing barrier; ms_per_step is the max over ranks of the barrier-to-barrier time"}
+        dt, per_rank = rank_clock(dist, dt, dt_local, rank, world, args.steps, "cuda")
     # ---- roofline of the dominant kernel: the same iterations once more with the hipGraphs switched off, so that HIP events can
     # bracket every launch of that kernel on its stream (events cannot be read out of a replayed graph).  Not part of `value`.
     # the quantile networks (iqn / fqf) spend their time in the fc1-family GEMMs over B * N rows ("IQN/FQF fc1 + cosine-embed GEMMs:
@@ -363,6 +389,7 @@ def main():
     if dp:
         barrier()
     exchange = None
+    rccl = exchange_report(eng.grad_hook, world) if dp and not args.replicas else None          # collective: before the communicator is closed
     if eng.grad_hook is not None:
         exchange = type(eng.grad_hook).__name__ + (" (captured in the update's hipGraph)" if getattr(eng.grad_hook, "in_graph", False) else " (eager, between three graphs)")
         if getattr(tr, "_nl", None):      # A0_NATIVE_LOOP_DP=1: the learner handle issues the same two all-reduces itself
@@ -375,13 +402,10 @@ def main():
             import torch.distributed as dist
             dist.destroy_process_group()
         return
-    value = world * per_iter * args.steps / dt
-    upd_per_s = world * cfg.learner.learner_steps * args.steps / dt
     cu, hbm, arch = tr.ops.device_info()
     out = {
         "metric": "env-frames/sec (learner FPS: transitions collected and saved to replay per second with the learner running, pre-frameskip)",
-        "value": round(value, 1), "unit": "env-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        **throughput_fields(world, per_iter, cfg.learner.learner_steps, args.steps, args.warmup, dt),
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg.env_id} {cfg.learner.algo.name}, {cfg.actor.num_envs} vectorized envs x {cfg.actor.sample_steps} steps + "
                                f"{cfg.learner.learner_steps} updates of batch {cfg.learner.batch_size} per iteration, {cfg.replay.size}-transition HBM replay "
@@ -392,8 +416,7 @@ def main():
                    "host_loop": ("library handles over the Python classes' buffers (deepq/native_loop.py: eager launches from native code)" if getattr(tr, "_nl", None)
                                  else "Python classes + hipGraphs"),
                    "gradient_exchange": exchange},
-        "per_rank_ms_per_step": per_rank, "gradient_exchange": exchange,
-        "emulator_frames_per_sec_x4": round(4 * value, 1), "updates_per_sec": round(upd_per_s, 2),
+        "per_rank_ms_per_step": per_rank, "gradient_exchange": exchange, "rccl": rccl,
         "device": arch, "replay_fill_s": round(t_fill, 2),
         "at_reference_update_ratio": ratio320, "other_entry": other,
         "replay_sample_GBps": None if replay_gbps is None else round(replay_gbps, 1), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),
@@ -448,7 +471,11 @@ def main():
                 "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off",
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
     out["roofline"] = roof
-    out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args, cfg)     # rank 0 at N=1 only
+    # the CPU baseline is a property of the box, not of the rank count: rank 0 times it at every N (the other ranks have left their last collective by now and
+    # only wait in destroy_process_group)
+    out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args, cfg)
+    if out["cpu_baseline"] is not None and world > 1:
+        out["cpu_baseline"]["note"] = f"timed on rank 0's share of the host cores while the other {world - 1} ranks idle; compare with the N = 1 line's"
     print(json.dumps(out))
     if dp:
         import torch.distributed as dist

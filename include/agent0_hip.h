@@ -362,6 +362,11 @@ int a0_learner_get(const a0_learner* learner, float* online_out, float* target_o
 /* the handle's own buffer of per-sample losses [B] of the last update — BaseLearner.train's return value (agent.py:163-169) — as a device pointer valid for the
  * handle's lifetime: what a0_rbuf_update_priority (trainer.py:103-104) takes without the copy a non-NULL loss_out of a0_learner_update costs */
 int a0_learner_loss_buffer(const a0_learner* learner, float** loss_dev);
+/* (round 5) borrowed views of the handle's HBM for inspection — the flat gradient buffer (layout of the parameters) and the differentiated pass's activations
+ * (NHWC; their signs are the ReLU decisions of the last update), which a0_learner_get does not copy out: *dev_ptr / *count (floats).  Valid until the next call on
+ * the handle.  tests/test_gpu_trace.py walks the handle path against the CPU oracle with them. */
+enum { A0_PEEK_GRADS = 0, A0_PEEK_ACT1 = 1, A0_PEEK_ACT2 = 2, A0_PEEK_ACT3 = 3, A0_PEEK_FC1 = 4, A0_PEEK_LOSS = 5 };
+int a0_learner_peek(const a0_learner* learner, int what, float** dev_ptr, long long* count);
 /* fqf: a copy of the per-sample fraction losses [B] of the last update (the `fraction_loss` statistic, trainer.py:99-101) into out_dev */
 int a0_learner_get_frac_loss(const a0_learner* learner, float* out_dev, void* stream);
 /* c51: the support atoms [num_atoms] from HOST memory, for a caller that holds the exact values its reference run used (default: linspace in fp32, torch's formula) */
@@ -588,6 +593,8 @@ int a0_dp_unique_id(void* host_id128);
 long long a0_dp_init(const void* host_id128, int rank, int world);
 int a0_dp_allreduce(long long comm, float* buf, long long n, void* stream);
 int a0_dp_destroy(long long comm);
+/* (round 5) what RCCL reports for the communicator: host_out3 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice}; bench.py prints it beside an all-reduce of ones */
+int a0_dp_info(long long comm, int* host_out3);
 
 #ifdef __cplusplus
 }

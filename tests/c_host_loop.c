@@ -16,6 +16,15 @@
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static unsigned lcg(unsigned* s) { *s = *s * 1664525u + 1013904223u; return *s >> 8; }
 
+/* position-weighted word sums (mod 2^64) of a device buffer: the fingerprint tests/test_gpu_trainer.py recomputes with numpy from the Python run of the same seed */
+static int fingerprint(const void* dev, size_t bytes, unsigned long long* s1, unsigned long long* s2, unsigned long long* pos) {
+    unsigned* h = (unsigned*)malloc(bytes);
+    if (!h || hipMemcpy(h, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return 1; }
+    for (size_t i = 0; i < bytes / 4; ++i) { *s1 += h[i]; *s2 += (unsigned long long)(++*pos) * h[i]; }
+    free(h);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
     const long long size = argc > 2 ? atoll(argv[2]) : 100000;
@@ -96,6 +105,23 @@ int main(int argc, char** argv) {
            rainbow ? "BASELINE configs[2]: c51 + NoisyNet + dueling + double-Q + 3-step + prioritized replay"
                    : (config == 3 ? "BASELINE configs[3]: iqn, 9 actions, K = 32, N = N' = 64, uniform replay"
                                   : (config == 4 ? "BASELINE configs[4] (one GPU's share): fqf, 9 actions, F = 32, uniform replay" : "BASELINE configs[1]: dqn, uniform replay")));
+    {   /* what the run left behind: parameters, target, Adam moments; the ring's actions / n-step rewards / dones and every 997th row's st||st_next bytes */
+        unsigned long long p1 = 0, p2 = 0, pp = 0, r1 = 0, r2 = 0, rp = 0;
+        float* tmp = NULL;
+        HIP(hipMalloc((void**)&tmp, (size_t)n * 4));
+        for (int k = 0; k < 4; ++k) {
+            CHECK(a0_learner_get(L, k == 0 ? tmp : NULL, k == 1 ? tmp : NULL, k == 2 ? tmp : NULL, k == 3 ? tmp : NULL, NULL, NULL));
+            HIP(hipDeviceSynchronize());
+            if (fingerprint(tmp, (size_t)n * 4, &p1, &p2, &pp)) return 1;
+        }
+        HIP(hipFree(tmp));
+        int* r_act = NULL; float *r_rew = NULL, *r_done = NULL;
+        CHECK(a0_rbuf_buffers(R, NULL, &r_act, &r_rew, &r_done, NULL, NULL));
+        if (fingerprint(r_act, (size_t)size * 4, &r1, &r2, &rp) || fingerprint(r_rew, (size_t)size * 4, &r1, &r2, &rp) || fingerprint(r_done, (size_t)size * 4, &r1, &r2, &rp)) return 1;
+        for (long long row = 0; row < size; row += 997)
+            if (fingerprint(ring + row * 2LL * OBS, (size_t)2 * OBS, &r1, &r2, &rp)) return 1;
+        printf("{\"fingerprint\": {\"learner\": [%llu, %llu], \"ring\": [%llu, %llu]}}\n", p1, p2, r1, r2);
+    }
     if (comm) { CHECK(a0_learner_set_exchange(L, 0)); CHECK(a0_dp_destroy(comm)); }
     CHECK(a0_actor_destroy(ac)); CHECK(a0_rbuf_destroy(R)); CHECK(a0_learner_destroy(L));
     return 0;

@@ -200,3 +200,42 @@ def test_dp_init_timeout_raises_instead_of_hanging():
     assert adist._call_with_timeout(lambda: 41 + 1, 5, "x") == 42
     with pytest.raises(ValueError):
         adist._call_with_timeout(lambda: (_ for _ in ()).throw(ValueError("boom")), 5, "x")
+
+
+def _bench_line_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import bench
+    from agent0_amd.deepq.dist import GradAllReduce, init_process_group
+
+    init_process_group(backend="gloo")
+    hook = GradAllReduce(1000)
+    # each rank's clock: rank 1 is the straggler of the K = 4 steps, and its barrier-to-barrier time is the larger one
+    dt_local, dt = (0.040, 0.0505) if rank == 0 else (0.050, 0.051)
+    dt_max, per_rank = bench.rank_clock(dist, dt, dt_local, rank, world, 4, "cpu")
+    rep = bench.exchange_report(hook, world)
+    out[rank] = (dt_max, per_rank, rep, bench.throughput_fields(world, 80 * 256, 20, 4, 2, dt_max))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_line_assembly_over_two_ranks():
+    """bench.py's multi-rank bookkeeping with the GPU parts left out (gloo, world_size 2): the clock is the MAX over ranks of the
+    barrier-to-barrier time, per_rank_ms_per_step carries every rank's own time, `value` counts the units of ALL ranks, and the "rccl" object is what the
+    exchange itself reports (rank count, an all-reduce of ones) checked against WORLD_SIZE."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bench_line_worker, args=(2, port, out), nprocs=2, join=True)
+    res = dict(out)
+    for rank in (0, 1):
+        dt_max, per_rank, rep, tp = res[rank]
+        assert dt_max == pytest.approx(0.051)
+        assert per_rank["ranks"] == [10.0, 12.5] and per_rank["min"] == 10.0 and per_rank["max"] == 12.5
+        assert rep["nranks"] == 2 and rep["rank"] == rank and rep["allreduce_of_ones"] == 2.0 and rep["matches_world_size"] is True
+        assert tp["n_gpus"] == 2 and tp["scaling"] == "weak" and tp["ms_per_step"] == pytest.approx(12.75)
+        assert tp["value"] == pytest.approx(2 * 80 * 256 * 4 / 0.051, rel=1e-6)
+        assert tp["updates_per_sec"] == pytest.approx(2 * 20 * 4 / 0.051, rel=1e-4)
+    import bench
+    assert bench.exchange_report(None, 2) is None

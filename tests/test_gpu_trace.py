@@ -150,6 +150,12 @@ class LockStep:
         L.pack({**ol.adam.m, **zeros}, eng.adam_m)
         L.pack({**ol.adam.v, **zeros}, eng.adam_v)
 
+    def relu_masks(self, B):
+        return E.device_relu_masks(self.eng, self.L, B)
+
+    def _frames_after_extend(self):
+        return self.tr.frame_count + self.tr.num_transitions        # Trainer.step counts the rollout's frames after replay.extend (trainer.py:77-78)
+
     # ---- the wrapped calls, in the order Trainer.step makes them
     def extend(self, transitions):
         rp, ora = self.rp, self.ora
@@ -158,7 +164,7 @@ class LockStep:
         self.rollout_stats = (rs, qs)
         ora.begin_step(data, rs, qs)
         self.n_ext += 1
-        assert rp.top == len(ora.replay) and self.tr.frame_count + self.tr.num_transitions == ora.frame_count
+        assert rp.top == len(ora.replay) and self._frames_after_extend() == ora.frame_count
         frames = rp.frames.view(rp.size, -1).cpu().numpy()
         act, rew, done = rp.act.cpu().numpy(), rp.rew.cpu().numpy(), rp.done.cpu().numpy()
         n_live = 0
@@ -232,7 +238,7 @@ class LockStep:
         tag = f"update {self.n_upd}"
         if self.spec.noisy:
             self.ora._learner_box.append((device_noise(self.eng.online), device_noise(self.eng.target)))
-        nets.RELU_MASKS, nets.RELU_STATS = E.device_relu_masks(self.eng, self.L, len(self.rec.idx)), {}
+        nets.RELU_MASKS, nets.RELU_STATS = self.relu_masks(len(self.rec.idx)), {}
         try:
             rec = self.ora.train_batch(self.rec)
         finally:
@@ -391,3 +397,150 @@ def test_launch_schedule_rollout_uses_the_weights_of_its_issue_time():
         for it in range(7):
             tr.run_iteration()
             assert_close(tr.Qs, ora.Qs, 5e-5, 5e-6, "mean max-Q per step")
+
+
+# ------------------------------------------------------------------------------------------------ the library-handle loop against the oracle, link by link
+class _DevView:
+    """A device pointer as a torch tensor (no copy): the buffers an ``a0_batch`` points to and the handle's workspaces (a0_learner_peek)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+
+
+def dev_view(ptr, n, dtype):
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+    return torch.as_tensor(_DevView(ptr, n, typestr), device="cuda")
+
+
+class HandleLockStep(LockStep):
+    """LockStep over the PRODUCTION-DEFAULT host loop (agent0_amd/deepq/native_loop.py): the iteration is driven through the library's handles —
+    a0_actor_rollout + a0_rbuf_commit, a0_rbuf_sample / _sample_block, a0_learner_update, a0_rbuf_update_priority — and after every C call the oracle performs its
+    corresponding step and the state is compared right there, exactly as in LockStep: no Python class computes or issues anything on the device side of this walk.
+    The handles work over the Trainer's buffers (a0_learner_create_on / a0_rbuf_create_on), which is where the comparisons read ring, tree, parameters, gradients and
+    moments; the batch comes through the a0_batch pointers, the per-sample losses and the ReLU decisions of the differentiated pass through a0_learner_peek."""
+
+    def __init__(self, tr, ora, spec, tfreq=SMALL.tfreq, actor_q=None):
+        import ctypes as C
+        from agent0_amd.common.utils import DeviceRng
+        from agent0_amd.deepq.native_loop import NativeLoop, eligible
+        self.tr, self.ora, self.spec, self.tfreq, self.free = tr, ora, spec, tfreq, False
+        self.drift, self.rec, self.rollout_stats, self._tau_bufs = [], None, None, None
+        self.n_ext = self.n_upd = self.relu_flips = 0
+        self.rp, self.eng, self.L = tr.replay, tr.learner.engine, tr.learner.engine.L
+        assert eligible(tr) is None, eligible(tr)
+        self.nl = tr._nl = NativeLoop(tr)
+        self.C, self.st = C, torch.cuda.current_stream().cuda_stream
+        nl, B = self.nl, int(tr.cfg.learner.batch_size)
+        # NoisyNet: the actor handle draws its resets inside a0_actor_rollout (Philox stream 4 of the actor's seed, noise_len values per reset, offsets advancing by the
+        # padded length: csrc/runtime.hip) — the same values are regenerated here from a twin of that stream and handed to the oracle, like every other draw
+        self._actor_q, self._twin = actor_q, (DeviceRng(tr.ops, tr.cfg.seed, tr.rank) if spec.noisy else None)
+
+        def peek(what, dtype=torch.float32):
+            p, n = C.c_void_p(), C.c_longlong()
+            nl.ok(nl.lib.a0_learner_peek(nl.learner, what, C.addressof(p), C.addressof(n)), "a0_learner_peek")
+            return dev_view(p.value, n.value, dtype)
+        self._peek = peek
+
+        def _extend(_):
+            if self._twin is not None:
+                steps = self.n_ext * nl.T
+                freq = int(tr.cfg.learner.reset_noise_freq)
+                on = self.eng.online
+                scratch = tr.ops.zeros(on.noise_len)
+                for t in range(nl.T):
+                    if (steps + t) % freq == 0:
+                        self._twin.normal(self._twin.STREAM_NOISE, 0.1, scratch, on.noise_len)
+                        self._actor_q.append(_noise_list(self.L, scratch))
+            nl._rollout(self.st)
+            nl._commit(self.st)
+        self._extend = _extend
+
+        def _sample():
+            b = nl._sample(self._i, self._n, self.st)
+            self._b = b
+            ns = type("Batch", (), {})()
+            ns.idx, ns.slot, ns.act = dev_view(b.idx, B, torch.int64), dev_view(b.slot, B, torch.int32), dev_view(b.act, B, torch.int32)
+            ns.rew, ns.done, ns.weights = dev_view(b.rew, B, torch.float32), dev_view(b.done, B, torch.float32), dev_view(b.weights, B, torch.float32)
+            ns.prio = dev_view(b.prio, B, torch.float32) if b.prio else None
+            return ns
+        self._sample = _sample
+
+        def _train():
+            nl._update(self._b, self.st)
+            return peek(5), None
+        self._train = _train
+
+        def _update(ids, pr, state=None):
+            nl._priority(self.st)
+            self.rp._top_stale = True            # the handle leaves the tree's top levels to its next sample; ReplayDataset.tree brings them up to date for the comparison
+        self._update = _update
+        # the ReLU decisions come from the handle's own activations
+        self._ws = type("Ws", (), {})()
+        self._ws.R = B
+
+    def relu_masks(self, B):
+        ws = self._ws
+        ws.act1, ws.act2, ws.act3, ws.h = self._peek(1), self._peek(2), self._peek(3), self._peek(4)
+        return E.device_relu_masks(type("Dev", (), {"ws_o": ws})(), self.L, B)
+
+    def _frames_after_extend(self):
+        return self.tr.frame_count                                  # NativeLoop._commit has counted them already
+
+    def iteration(self):
+        """trainer.py:176-182 -> 74-119 through the handles; returns the rollout's (returns, per-step max-Q)."""
+        C, nl, tr = self.C, self.nl, self.tr
+        self.extend(None)
+        qs, rs, nret = (C.c_float * nl.T)(), (C.c_float * (nl.T * nl.E))(), C.c_int()
+        nl.ok(nl.lib.a0_actor_collect(nl.actor, qs, rs, nl.T * nl.E, C.addressof(nret), self.st), "a0_actor_collect")
+        n = int(tr.cfg.learner.learner_steps)
+        if int(nl.lib.a0_rbuf_len(nl.rbuf)) > tr.cfg.trainer.training_start_steps:
+            for i in range(n):
+                self._i, self._n = i, n
+                b = self.sample()
+                q, _ = self.train()
+                if self.ora.prioritize:
+                    self.update(b.idx, q)
+            tr.learner.updates_issued += n
+        return list(rs)[: nret.value], list(qs)
+
+
+def _noise_list(L, buf):
+    """A noise buffer in the device's layout (DeviceNet: per module noise_in | noise_out_weight | noise_out_bias, each padded to four floats, noise_in in kernel
+    column order) as the oracle takes it — what ``device_noise`` returns for a DeviceNet holding ``buf``."""
+    out, off = [], 0
+    for prefix, block, r0, r1, in_f in L.noise_modules:
+        for leaf, n in (("noise_in", in_f), ("noise_out_weight", r1 - r0), ("noise_out_bias", r1 - r0)):
+            v = buf[off:off + n]
+            out.append((L.noise_in_from_kernel(prefix, v) if leaf == "noise_in" else v).clone().cpu().numpy())
+            off += (n + 3) // 4 * 4
+    return out
+
+
+@pytest.mark.parametrize("algo,policy,sumtree,n_step,double_q,spec_name", [("dqn", "uniform", False, 1, False, None), ("dqn", "prioritize", True, 3, True, None),
+                                                                           ("c51", "prioritize", True, 3, True, "c51_duel_noisy")],
+                         ids=["dqn-configs1", "dqn-double-n3-sumtree", "rainbow-lite-configs2"])
+def test_library_handle_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_step, double_q, spec_name, monkeypatch):
+    """the path bench.py times — the native host loop's C calls — held to the oracle DIRECTLY instead of through its bit-identity with the
+    Python classes: seven iterations over a 200-slot ring (wraps twice), 18 updates, target sync every 4, for BASELINE configs[1] (dqn, uniform replay), dqn with
+    double-Q / 3-step returns / prioritized sum-tree replay and BASELINE configs[2] (rainbow-lite).  Same comparisons and tolerances as
+    test_trainer_loop_matches_the_oracle_link_by_link (reference trainer.py:74-119,171-184)."""
+    monkeypatch.setenv("A0_NATIVE_LOOP", "1")
+    E_, T_, B_, SIZE, LSTEPS, START, TFREQ = SMALL
+    tr, ora, spec = _build(algo, policy, sumtree, n_step, double_q, False, spec_name=spec_name)
+    actor_q = []
+    if spec.noisy:
+        ora.actor_noise = lambda: actor_q.pop(0)
+    ls = HandleLockStep(tr, ora, spec, tfreq=TFREQ, actor_q=actor_q)
+    Rs, Qs = [], []
+    for it in range(7):
+        rs, qs = ls.iteration()
+        want = ora.end_step()
+        Rs += rs
+        Qs += qs
+        assert Rs == [float(np.float32(x)) for x in ora.Rs], f"iteration {it}: episode returns"
+        assert_close(Qs, ora.Qs, 5e-5, 5e-6, f"iteration {it}: mean max-Q per step")
+        assert tr.frame_count == want["frames"] == (it + 1) * E_ * T_
+    n_train = sum(1 for it in range(7) if (it + 1) * E_ * T_ > START)
+    assert ls.n_ext == 7 and ls.n_upd == n_train * LSTEPS and int(ls.eng.state[1]) == n_train * LSTEPS and tr.replay.written == 7 * E_ * T_
+    tr._nl.close()
+    tr._nl = False

@@ -45,6 +45,18 @@ def assert_mostly_close(got, want, atol, max_bad_frac, max_rel_l2, what=""):
     assert frac <= max_bad_frac and rel <= max_rel_l2, f"{what}: {bad.sum()}/{bad.size} elements outside {atol} (allowed {max_bad_frac:.3%}), rel-L2 {rel:.3e} (allowed {max_rel_l2})"
 
 
+def record_stats(name, payload):
+    """Measured statistics of a GPU test, for profiles/ (gpurun merges gpurun_out/ back): one JSON file per statistic and case."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_stats")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(payload, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def pinned_oracle(case: str):
     """The oracle's FQF steps of G6 case ``case`` computed in a child process in the CPU-independent mode (tests/golden/pinned.py, tests/pinned_oracle.py)."""
     import os, sys, tempfile
