@@ -33,7 +33,9 @@ class DeviceSynthVecEnv:
     """obs (E,4,84,84) u8 on the GPU; ``step`` takes a device int32 action tensor and returns device tensors."""
 
     H = W = 84
-    TASKS = {"stream": 0, "block": 1}        # A0_ENV_TASK_* (include/agent0_hip.h): action-independent reward stream / the learnable block-quadrant task
+    # A0_ENV_TASK_* (include/agent0_hip.h): action-independent reward stream / the learnable block-quadrant task (a contextual bandit) / the chase task (temporal credit:
+    # the action moves the block, +1 on arrival at the target cell; served by the unmerged env step, the action being known when the kernel starts)
+    TASKS = {"stream": 0, "block": 1, "chase": 2}
 
     def __init__(self, env_id: str, num_envs: int, seed: int = 42, rank: int = 0, ops=None, task: str = "stream"):
         if task not in self.TASKS:
@@ -76,7 +78,7 @@ class DeviceSynthVecEnv:
     def reset(self, **kwargs):
         self.g = 0
         self._cur = 0
-        self.ops.env_reset(self.seed, self.rank, self.E, self._obs[0], self.ep_ret)
+        self.ops.env_reset(self.seed, self.rank, self.E, self._obs[0], self.ep_ret, task=self.task)
         return self._obs[0], {}
 
     def step(self, action: torch.Tensor, final_mask: Optional[torch.Tensor] = None, final_ret: Optional[torch.Tensor] = None, ctrl: Optional[torch.Tensor] = None):

@@ -30,12 +30,49 @@ A0_D float a0_env_reward(const a0_u4& x, int task, int A, uint32_t e, uint32_t g
     return rw < 50u ? -1.0f : (rw < 100u ? 1.0f : 0.0f);
 }
 
-A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix) {
+// `chase`: the background never reaches 255 under A0_ENV_TASK_CHASE (a lit pixel of value 255 becomes 254), so that 255 means "block" and the env can read its own
+// state — the block's cell — back from the newest frame of the observation
+A0_D uint8_t a0_env_pixel(uint32_t base, uint32_t by, uint32_t bx, uint32_t pix, bool chase = false) {
     const uint32_t y = pix / A0_ENV_W, x = pix - y * A0_ENV_W;
     const uint32_t h = a0_env_mix32(base ^ (pix * 0x85EBCA77u));
     uint8_t v = (((h >> 8) & 3u) == 0u) ? (uint8_t)(h & 255u) : (uint8_t)0;
+    if (chase && v == 255) v = 254;
     if (y >= by && y < by + 8 && x >= bx && x < bx + 8) v = 255;
     return v;
+}
+
+// ---- task 2 (A0_ENV_TASK_CHASE): a task with TEMPORAL credit.  The bright 8x8 block lives on a 4 x 4 lattice — cell c = 4 cy + cx, top-left pixel (4 + 22 cy, 4 + 22 cx) —
+// and the ACTION MOVES IT: a % 4 = 0 up, 1 down, 2 left, 3 right (clamped at the walls).  The env carries that state in its own output: the current cell is the one
+// whose probe pixel (7 + 22 cy, 7 + 22 cx) of the observation's newest frame is 255.  Reward +1 only on ARRIVAL at the target cell 15 (bottom right), after which the
+// block respawns at one of the ten cells at Manhattan distance >= 3 (the step's fourth Philox word picks it): a reward needs three to six correct moves, none of
+// which pays by itself — a learner without a bootstrap term, with a mis-indexed n-step window or without discounting cannot find the policy (tests/test_gpu_learning.py).
+// Optimum: one reward per 4.0 steps on average (the mean spawn distance).
+#define A0_CHASE_TARGET 15
+A0_D uint32_t a0_chase_start_cell(uint32_t e) { return (7u * e + 3u) % 15u; }
+A0_D void a0_chase_pos(int cell, uint32_t& by, uint32_t& bx) { by = 4u + 22u * (uint32_t)(cell >> 2); bx = 4u + 22u * (uint32_t)(cell & 3); }
+A0_D int a0_chase_cell(const uint8_t* __restrict__ newest /* one 84 x 84 frame */, uint32_t e) {
+    int found = -1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (newest[(7 + 22 * (c >> 2)) * A0_ENV_W + 7 + 22 * (c & 3)] == 255) found = found < 0 ? c : found;
+    return found < 0 ? (int)a0_chase_start_cell(e) : found;
+}
+A0_D int a0_chase_step(int cell, int a, uint32_t x3, float& reward) {
+    int cy = cell >> 2, cx = cell & 3;
+    const int m = a & 3;
+    if (m == 0) cy = cy > 0 ? cy - 1 : 0;
+    else if (m == 1) cy = cy < 3 ? cy + 1 : 3;
+    else if (m == 2) cx = cx > 0 ? cx - 1 : 0;
+    else cx = cx < 3 ? cx + 1 : 3;
+    int nc = 4 * cy + cx;
+    reward = 0.f;
+    if (nc == A0_CHASE_TARGET) {
+        reward = 1.f;
+        // the cells with cy + cx <= 3, in row-major order: 0 1 2 3 | 4 5 6 | 8 9 | 12
+        const uint32_t k = x3 % 10u;
+        nc = (int)(k < 4u ? k : (k < 7u ? k : (k < 9u ? k + 1u : 12u)));
+    }
+    return nc;
 }
 
 
@@ -117,10 +154,10 @@ A0_D void a0_env_nstep_row_pre(const a0_env_pre& Z, uint32_t e, int E, int n, lo
 A0_D void a0_env_commit_finish(const a0_env_pre& Z, const a0_u4& x, uint32_t e, uint32_t g, int task, int A, int E, int n, long long steps, double gamma, int a_now,
                                float* __restrict__ ep_ret, float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act,
                                float* __restrict__ ring_rew, float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew,
-                               float* __restrict__ r_done, long long slot) {
+                               float* __restrict__ r_done, long long slot, float r_chase = 0.f) {
 #pragma clang fp contract(off)
     const bool term = (x.y % 500u) == 0u;
-    const float r = a0_env_reward(x, task, A, e, g, a_now);
+    const float r = task == A0_ENV_TASK_CHASE ? r_chase : a0_env_reward(x, task, A, e, g, a_now);
     const bool life = (!term) && ((x.z % 200u) == 0u);
     const float ret = Z.ep_prev + r;
     final_mask[e] = term ? 1.f : 0.f;
@@ -131,18 +168,22 @@ A0_D void a0_env_commit_finish(const a0_env_pre& Z, const a0_u4& x, uint32_t e, 
 
 A0_D void a0_env_commit_scalars(const a0_u4& x, uint32_t e, uint32_t g, int task, int A, int E, int n, long long steps, double gamma, int a_now, float* __restrict__ ep_ret,
                                 float* __restrict__ final_mask, float* __restrict__ final_ret, int* __restrict__ ring_act, float* __restrict__ ring_rew,
-                                float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done, long long slot) {
+                                float* __restrict__ ring_done, int* __restrict__ r_act, float* __restrict__ r_rew, float* __restrict__ r_done, long long slot,
+                                float r_chase = 0.f) {
     a0_env_pre Z;
     a0_env_commit_prefetch(Z, e, E, n, steps, ep_ret, ring_act, ring_rew, ring_done);
-    a0_env_commit_finish(Z, x, e, g, task, A, E, n, steps, gamma, a_now, ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot);
+    a0_env_commit_finish(Z, x, e, g, task, A, E, n, steps, gamma, a_now, ep_ret, final_mask, final_ret, ring_act, ring_rew, ring_done, r_act, r_rew, r_done, slot, r_chase);
 }
 
 // the frame work of env e at step g for the 16-byte groups j = j0, j0 + jstride, ...: new frame, stack shift into obs_out, and the replay row
 // [st (obs0) | st_next] at `row`
+// (chase_cell >= 0: A0_ENV_TASK_CHASE — the block is drawn at that lattice cell, the background clamped below 255)
 A0_D void a0_env_commit_frames(unsigned long long seed, uint32_t e, uint32_t g, bool term, const uint8_t* __restrict__ obs_in, uint8_t* __restrict__ obs_out,
-                               const uint8_t* __restrict__ obs0, uint8_t* __restrict__ row, int j0, int jstride) {
+                               const uint8_t* __restrict__ obs0, uint8_t* __restrict__ row, int j0, int jstride, int chase_cell = -1) {
     const uint32_t base = (uint32_t)seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
-    const uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    uint32_t by = (3u * g + 11u * e) % 77u, bx = (5u * g + 7u * e) % 77u;
+    const bool chase = chase_cell >= 0;
+    if (chase) a0_chase_pos(chase_cell, by, bx);
     const int q = A0_ENV_PIX / 16;
     const uint4* in16 = (const uint4*)(obs_in + (size_t)e * 4 * A0_ENV_PIX);
     const uint4* o016 = (const uint4*)(obs0 + (size_t)e * 4 * A0_ENV_PIX);
@@ -154,8 +195,8 @@ A0_D void a0_env_commit_frames(unsigned long long seed, uint32_t e, uint32_t g, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t p = 16u * (uint32_t)j + 4u * (uint32_t)k;
-            w[k] = (uint32_t)a0_env_pixel(base, by, bx, p) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1) << 8) |
-                   ((uint32_t)a0_env_pixel(base, by, bx, p + 2) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3) << 24);
+            w[k] = (uint32_t)a0_env_pixel(base, by, bx, p, chase) | ((uint32_t)a0_env_pixel(base, by, bx, p + 1, chase) << 8) |
+                   ((uint32_t)a0_env_pixel(base, by, bx, p + 2, chase) << 16) | ((uint32_t)a0_env_pixel(base, by, bx, p + 3, chase) << 24);
         }
         const uint4 nw = uint4{w[0], w[1], w[2], w[3]};
         uint4 n0, n1, n2, n3;

@@ -12,7 +12,8 @@ Additions (all default to the reference's behaviour being available):
   learner.algo     accepts ``iqr`` (README spelling) as an alias of ``iqn`` (quirk Q10).
   env_task         reward task of the device-resident synthetic env (include/agent0_hip.h A0_ENV_TASK_*): ``stream`` (default; an action-independent reward
                    stream — the throughput workload) or ``block`` (learnable: +1 for naming the quadrant of the bright block in the newest frame,
-                   -1 for the next class; chance 0, optimum +1 per step) — what the learning tests train on.  Ignored by real Atari envs.
+                   -1 for the next class; chance 0, optimum +1 per step) or ``chase`` (temporal credit: the action moves the block on a 4 x 4 lattice, +1 only on
+                   arrival at the target cell three to six moves away; optimum 0.25 per step) — what the learning tests train on.  Ignored by real Atari envs.
   device           ``cuda`` is the only supported device: this build has no CPU path (it raises instead).
   checkpoint       path of a checkpoint written by ``Trainer.save_checkpoint``; read when ``mode`` is ``finetune`` (resume training)
                    or ``play`` (evaluate only) — the reference declares those modes (config.py:26-29) but never implements them.

@@ -87,6 +87,8 @@ def eligible(tr) -> Optional[str]:
         return f"no handle for {algo}"
     if tuple(cfg.obs_shape) != (4, 84, 84):
         return "observations other than 4 x 84 x 84"
+    if cfg.env_task not in ("stream", "block"):
+        return "the chase task's env step is a launch of its own (the handles issue the merged tail + env-step kernels)"
     actor = tr.actors[1]
     if not isinstance(actor.envs, DeviceSynthVecEnv) or actor.groups is not None:
         return "host environments"

@@ -706,11 +706,12 @@ class HipOps:
     def rng_normal(self, seed, stream_id, offset, std, out, n):
         check(self.lib.a0_rng_normal(seed, stream_id, offset, std, _req(out, torch.float32, n, "out"), n, _stream()), "a0_rng_normal")
 
-    def env_reset(self, seed, rank, E, obs, ep_ret):
-        check(self.lib.a0_env_synth_reset(seed, rank, E, _req(obs, torch.uint8, E * 4 * 84 * 84, "obs"), _req(ep_ret, torch.float32, E, "ep_ret"), _stream()), "a0_env_synth_reset")
+    def env_reset(self, seed, rank, E, obs, ep_ret, task=0):
+        check(self.lib.a0_env_synth_reset_task(seed, rank, E, _req(obs, torch.uint8, E * 4 * 84 * 84, "obs"), _req(ep_ret, torch.float32, E, "ep_ret"), int(task), _stream()),
+              "a0_env_synth_reset_task")
 
     def env_step(self, seed, rank, E, g, obs_in, obs_out, ep_ret, reward, terminal, truncated, life_loss, final_mask, final_ret, ctrl=None, action=None, A=1, task=0):
-        """``task`` 0: action-independent reward stream; 1: the learnable block task (needs ``action`` [E] int32 and the action count ``A``)."""
+        """``task`` 0: action-independent reward stream; 1: the learnable block task, 2: the chase task (both need ``action`` [E] int32 and the action count ``A``)."""
         n = E * 4 * 84 * 84
         check(self.lib.a0_env_synth_step(seed, rank, E, g, _req(obs_in, torch.uint8, n, "obs_in"), _req(obs_out, torch.uint8, n, "obs_out"),
                                          _req(ep_ret, torch.float32, E, "ep_ret"), _req(reward, torch.float32, E, "reward"), _req(terminal, torch.float32, E, "terminal"),

@@ -158,11 +158,11 @@ class SynthVecEnv:
 
     H = W = 84
 
-    TASKS = {"stream": 0, "block": 1}
+    TASKS = {"stream": 0, "block": 1, "chase": 2}
 
     def __init__(self, num_envs: int, seed: int = 42, rank: int = 0, action_dim: int = 4, env_offset: int = 0, task: str = "stream"):
         """``env_offset``: this object is envs [env_offset, env_offset + num_envs) of a larger vector env (a slice owned by one worker).
-        ``task``: "stream" = action-independent rewards, "block" = the learnable task (oracle/synth_env.c)."""
+        ``task``: "stream" = action-independent rewards, "block" = the learnable bandit task, "chase" = the task with temporal credit (oracle/synth_env.c)."""
         self.E, self.seed, self.rank, self.action_dim, self.e0 = num_envs, seed, rank, action_dim, env_offset
         self.task = self.TASKS[task]
         self.g = np.zeros(num_envs, dtype=np.uint32)
@@ -170,7 +170,8 @@ class SynthVecEnv:
         self.obs = np.zeros((num_envs, 4, 84, 84), dtype=np.uint8)
 
     def reset(self):
-        lib().a0o_env_reset_at(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.e0), C.c_int64(self.E), _p(self.g), _p(self.ep_ret), _p(self.obs))
+        lib().a0o_env_reset_task_at(C.c_uint64(self.seed), C.c_uint32(self.rank), C.c_int64(self.e0), C.c_int64(self.E), C.c_int32(self.task), _p(self.g), _p(self.ep_ret),
+                                    _p(self.obs))
         return self.obs.copy(), {}
 
     def step(self, action):
@@ -212,6 +213,12 @@ def env_block_target(e, g_prev, A: int):
     by = (np.uint32(3) * g_prev + np.uint32(11) * e) % np.uint32(77)
     bx = (np.uint32(5) * g_prev + np.uint32(7) * e) % np.uint32(77)
     return ((2 * (by >= 39).astype(np.int64) + (bx >= 39).astype(np.int64)) % A).astype(np.int64)
+
+
+def env_chase_cells(obs: np.ndarray, env_offset: int = 0) -> np.ndarray:
+    """The chase task's state of every env of an observation batch [E, 4, 84, 84]: the lattice cell of the block in the newest frame (oracle/synth_env.c)."""
+    obs = np.ascontiguousarray(obs, dtype=np.uint8).reshape(-1, 4, 84, 84)
+    return np.array([lib().a0o_env_chase_cell(_p(np.ascontiguousarray(obs[i, 3])), C.c_uint32(env_offset + i)) for i in range(obs.shape[0])], dtype=np.int64)
 
 
 def env_frame(seed: int, e: int, g: int) -> np.ndarray:

@@ -1,4 +1,4 @@
-"""Learning runs on the synthetic env's learnable task (``env_task=block``, oracle/synth_env.c) — TEST INFRASTRUCTURE.
+"""Learning runs on the synthetic env's learnable tasks (``env_task=chase`` — temporal credit — and ``env_task=block`` — a bandit; oracle/synth_env.c) — TEST INFRASTRUCTURE.
 
 The reference's only acceptance evidence is learning curves and a score table (README.md:62-112, imgs/*.png): its loop — epsilon schedule
 (trainer.py:46-50), replay, target sync every 500 updates (agent.py:160-161), priorities (trainer.py:103-104) — is validated by the fact
@@ -7,7 +7,7 @@ turns the episode returns it reports into REWARD PER STEP: episodes end independ
 step)), so the oracle's terminal map gives every reported episode its length, in the order the actor reports them (step-major, env-major:
 agent.py:85-88).  Chance level is 0, the optimum +1 per step (times 1 - eps * (1 - 1/A) under epsilon-greedy).
 
-``python tests/learning_runs.py [out.json]`` runs the set the GPU tests assert on and writes the curves (profiles/r04_learning.json).
+``python tests/learning_runs.py [out.json]`` runs the set the GPU tests assert on and writes the curves (profiles/r05_learning.json).
 """
 from __future__ import annotations
 
@@ -22,9 +22,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def make_cfg(algo: str, extra=None, E: int = 256, env_id: str = "Breakout"):
+def make_cfg(algo: str, extra=None, E: int = 256, env_id: str = "Breakout", task: str = "block"):
     from agent0_amd.deepq.config import parse_overrides
-    kv = {"learner.algo": algo, "actor.num_envs": E, "env_id": env_id, "env_task": "block", "wandb": "false", "tb": "false",
+    kv = {"learner.algo": algo, "actor.num_envs": E, "env_id": env_id, "env_task": task, "wandb": "false", "tb": "false",
           "logdir": "gpurun_out/learning_logs", "replay.size": 200000}
     kv.update(extra or {})
     return parse_overrides([f"{k}={v}" for k, v in kv.items()])
@@ -42,21 +42,41 @@ def episode_lengths(seed: int, rank: int, E: int, steps: int) -> np.ndarray:
     return np.asarray(out, dtype=np.int64)
 
 
-def run(algo: str, extra=None, frames: int = 4_000_000, launch: bool = False, E: int = 256, env_id: str = "Breakout", window: int = 25, sabotage=None):
+def run(algo: str, extra=None, frames: int = 4_000_000, launch: bool = False, E: int = 256, env_id: str = "Breakout", window: int = 25, sabotage=None, task: str = "block"):
     """Trains for ``frames`` agent steps; returns {"curve": [(frames, reward per step over the episodes that finished in the last ``window`` iterations)], ...}.
-    ``sabotage``: "no_target_sync" (target network never refreshed), "eps_one" (the actor never exploits), "lr_zero" (Adam does not move the weights) — runs
-    that must NOT pass the learning criterion."""
+    ``task``: "block" (a contextual bandit: optimum +1 per step) or "chase" (temporal credit: the action moves the block, +1 on arrival three to six moves later;
+    optimum 0.25 per step).  ``sabotage``: "no_target_sync" (target network never refreshed), "eps_one" (the actor never exploits), "lr_zero" (Adam does not move the
+    weights); and, for the chase task, the breakages only a task with temporal credit can see — "discount_zero" (no bootstrap term: gamma = 0), "nstep_shift" (the
+    n-step window mis-indexed by one: every transition of a rollout carries the action of the NEXT step, written over the ring right after ``replay.extend``) and
+    "stale_next_state" (st_next := st in every stored row: the target bootstraps from the state the action was taken in) — runs that must NOT pass the criterion."""
     from agent0_amd.deepq.trainer import Trainer
     extra = dict(extra or {})
+    if sabotage == "discount_zero":
+        extra["learner.discount"] = 1e-9              # (the config requires a positive discount)
     if sabotage == "no_target_sync":
         extra["learner.target_update_freq"] = 10 ** 9
     if sabotage == "eps_one":
         extra["actor.min_eps"] = 1.0
     if sabotage == "lr_zero":
         extra["learner.learning_rate"] = 0.0
-    cfg = make_cfg(algo, extra, E, env_id)
+    cfg = make_cfg(algo, extra, E, env_id, task)
     tr = Trainer(cfg, use_lp=launch)
     T = int(cfg.actor.sample_steps)
+    if sabotage in ("nstep_shift", "stale_next_state"):
+        rp = tr.replay
+        extend = rp.extend
+
+        def tampered(block):
+            start = rp.write_cursor()                 # the rollout's rows [start, start + T E) (mod the ring), step-major / env-major
+            extend(block)
+            idx = (start + np.arange(T * E)) % rp.size
+            rows = __import__("torch").as_tensor(idx, device=rp.act.device)
+            if sabotage == "nstep_shift":
+                rp.act[rows[: (T - 1) * E]] = rp.act[rows[E:]]
+            else:
+                fr = rp.frames.view(rp.size, 2, -1)
+                fr[rows, 1] = fr[rows, 0]
+        rp.extend = tampered
     iters = frames // (T * E)
     lengths = episode_lengths(cfg.seed, 0, E, (iters + 2) * T)
     curve, marks = [], [0]
@@ -92,31 +112,37 @@ FAMILIES = [("dqn", "dqn", {}, 4_000_000, "Breakout"),
 
 
 def main(out_path=None, only=None):
+    """The runs tests/test_gpu_learning.py asserts on, with their curves: the four families on the chase task (both schedules), prioritized replay, the six sabotaged
+    runs, and the bandit task under the library-handle loop."""
     runs = []
+
+    def keep(r, name):
+        r["name"] = name
+        print(json.dumps({k: v for k, v in r.items() if k != "curve"}), flush=True)
+        print("   curve:", r["curve"], flush=True)
+        runs.append(r)
+
+    small_q = {"learner.iqn.K": 16, "learner.iqn.N": 16, "learner.iqn.N_dash": 16, "learner.iqn.F": 16}
     for name, algo, extra, frames, env_id in FAMILIES:
         if only and name not in only:
             continue
         for launch in (False, True):
-            r = run(algo, extra, frames, launch, env_id=env_id)
-            r["name"] = name
-            print(json.dumps({k: v for k, v in r.items() if k != "curve"}), flush=True)
-            print("   curve:", r["curve"], flush=True)
-            runs.append(r)
+            x = {**extra, **small_q} if (launch and algo in ("iqn", "fqf")) else extra
+            keep(run(algo, x, 2_600_000 if algo == "c51" else 4_200_000, launch, env_id=env_id, task="chase"), name)
     if not only or "dqn_prio" in only:
-        r = run("dqn", {"replay.policy": "prioritize"}, 4_000_000)
-        r["name"] = "dqn_prioritized"
-        print(json.dumps({k: v for k, v in r.items() if k != "curve"}), flush=True)
-        runs.append(r)
+        keep(run("dqn", {"replay.policy": "prioritize"}, 4_200_000, task="chase"), "dqn_prioritized_sumtree")
+        keep(run("dqn", {"replay.policy": "prioritize", "replay.sumtree": "false"}, 4_200_000, task="chase"), "dqn_prioritized_flat_vector")
     if not only or "sabotage" in only:
-        for sab in ("no_target_sync", "eps_one", "lr_zero"):
-            r = run("dqn", {}, 4_000_000, sabotage=sab)
-            r["name"] = f"dqn_{sab}"
-            print(json.dumps({k: v for k, v in r.items() if k != "curve"}), flush=True)
-            print("   curve:", r["curve"], flush=True)
-            runs.append(r)
+        for sab in ("discount_zero", "nstep_shift", "stale_next_state", "no_target_sync", "eps_one", "lr_zero"):
+            keep(run("dqn", {}, 4_200_000, sabotage=sab, task="chase"), f"dqn_{sab}")
+    if not only or "block" in only:
+        os.environ["A0_NATIVE_LOOP"] = "1"
+        keep(run("dqn", {}, 2_600_000), "block_task_dqn_native_loop")
+        keep(run("c51", RAINBOW, 2_600_000), "block_task_c51_rainbow_lite_native_loop")
     if out_path:
         with open(out_path, "w") as f:
-            json.dump({"task": "env_task=block (oracle/synth_env.c): +1 for the block's quadrant, -1 for the next class; chance 0, optimum 1 per step",
+            json.dump({"task": "env_task=chase (oracle/synth_env.c): the action moves the block on a 4 x 4 lattice, +1 on arrival at the target cell, respawn three to six moves "
+                               "away; chance ~0.02, optimum 0.25 per step.  block_task_* runs: env_task=block (a contextual bandit, optimum 1 per step) under the library-handle loop",
                        "metric": "reward per env step over the episodes that finished in the last 25 iterations", "runs": runs}, f, indent=1)
     return runs
 

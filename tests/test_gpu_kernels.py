@@ -100,9 +100,10 @@ def test_rng_streams(hip):
     assert np.array_equal(ri.cpu().numpy(), (core.rng_u32(8, 2, 0, n) % 18).astype(np.int32))
 
 
-@pytest.mark.parametrize("task,A", [("stream", 4), ("block", 4), ("block", 9), ("block", 18)])
+@pytest.mark.parametrize("task,A", [("stream", 4), ("block", 4), ("block", 9), ("block", 18), ("chase", 4), ("chase", 9)])
 def test_synth_env_bytes(hip, task, A):
-    """a0_env_synth_step against oracle/synth_env.c, both reward tasks; on the block task the actions cycle through right / wrong / neutral classes."""
+    """a0_env_synth_step against oracle/synth_env.c, all three reward tasks; on the block task the actions cycle through right / wrong / neutral classes, on the chase task
+    two thirds of the moves follow the shortest path (so that arrivals, respawns and wall clamps all occur)."""
     E = 5
     env = core.SynthVecEnv(E, seed=42, rank=3, action_dim=A, task=task)
     tid = core.SynthVecEnv.TASKS[task]
@@ -112,16 +113,21 @@ def test_synth_env_bytes(hip, task, A):
     obs = [hip.zeros(E * 4 * 84 * 84, dtype=torch.uint8), hip.zeros(E * 4 * 84 * 84, dtype=torch.uint8)]
     ep = hip.zeros(E)
     f = [hip.zeros(E) for _ in range(6)]
-    hip.env_reset(42, 3, E, obs[0], ep)
+    hip.env_reset(42, 3, E, obs[0], ep, task=tid)
     assert np.array_equal(obs[0].cpu().numpy().reshape(E, 4, 84, 84), obs_c)
     n_term = 0
+    o = obs_c
     for t in range(1, 1200):
-        a = (core.env_block_target(np.arange(E), np.full(E, t - 1), A) + (np.arange(E) + t) % 3) % A        # target, target + 1 (wrong), target + 2
+        if task == "chase":
+            c = core.env_chase_cells(o)
+            a = np.where((np.arange(E) + t) % 3 == 0, (np.arange(E) * 7 + t) % A, np.where((c >> 2) < 3, 1, 3) + 4 * ((t % 2) if A > 4 else 0))
+        else:
+            a = (core.env_block_target(np.arange(E), np.full(E, t - 1), A) + (np.arange(E) + t) % 3) % A        # target, target + 1 (wrong), target + 2
         act.copy_(torch.from_numpy(a.astype(np.int32)))
         o, r, term, trunc, info = env.step(a)
         n_pos += int((r > 0).sum()); n_neg += int((r < 0).sum())
         hip.env_step(42, 3, E, t, obs[(t - 1) % 2], obs[t % 2], ep, *f, action=act, A=A, task=tid)
-        if t < 40 or term.any():
+        if t < 40 or term.any() or (task == "chase" and (t % 7 == 0 or (r > 0).any())):
             assert np.array_equal(obs[t % 2].cpu().numpy().reshape(E, 4, 84, 84), o), f"obs at step {t}"
         assert np.array_equal(f[0].cpu().numpy(), r.astype(np.float32))
         assert np.array_equal(f[1].cpu().numpy() != 0, term) and not f[2].cpu().numpy().any()
@@ -134,6 +140,8 @@ def test_synth_env_bytes(hip, task, A):
     assert np.array_equal(ep.cpu().numpy(), env.ep_ret)
     if task == "block":
         assert n_pos > 1500 and n_neg > 1500        # a third of the actions each (A = 4 ... 18: target + 2 is never rewarded)
+    if task == "chase":
+        assert n_pos > 400 and n_neg == 0           # arrivals at the target cell
 
 
 @pytest.mark.parametrize("n_step", [1, 3])

@@ -28,7 +28,8 @@ ROLLOUT_SPECS = dict(recipe.SPECS, fqf4=recipe.NetSpec("fqf", 4))
 @pytest.mark.parametrize("n_step,spec_name,task", [(1, "dqn", "stream"), (3, "dqn", "stream"), (1, "dqn_duel", "stream"), (3, "c51", "stream"), (1, "qr", "stream"),
                                                   (1, "iqn_duel", "stream"), (3, "iqn_duel", "stream"), (3, "fqf4", "stream"),
                                                   (3, "dqn", "block"), (1, "dqn_duel", "block"), (3, "c51", "block"), (1, "iqn_duel", "block"), (3, "fqf4", "block"),
-                                                  (3, "dqn", "block-unmerged")])
+                                                  (3, "dqn", "block-unmerged"),
+                                                  (1, "dqn", "chase"), (3, "dqn_duel", "chase"), (3, "c51", "chase"), (1, "iqn_duel", "chase"), (3, "fqf4", "chase")])
 def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the distributional tail, iqn / fqf the quantile tail (head GEMM slabs ->
     bias, dueling per quantile, mean / fraction-weighted sum, argmax, epsilon-greedy), each in one launch with the env step
@@ -53,7 +54,8 @@ def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     replay = ReplayDataset(cfg, ops=model.ops)
     actor = Actor(cfg, model, replay=replay, rank=0)
-    assert actor.fused_tail == (spec.algo == "dqn") and actor.quant_tail == (spec.algo in ("iqn", "fqf"))
+    # (the chase task — the action moves the block, so the new frame needs it — runs its env step as a launch of its own behind the tail)
+    assert actor.fused_tail == (spec.algo == "dqn") and actor.quant_tail == (spec.algo in ("iqn", "fqf") and task != "chase") and actor.tail_env == (task != "chase" and os.environ.get("A0_TAIL_ENV") != "0" and spec.algo in ("dqn", "c51", "qr"))
     # oracle twin: same env definition, same Philox draws (stream ids / offsets as DeviceRng assigns them)
     seed64 = (cfg.seed & 0xFFFFFFFF)
     step_no = [0]

@@ -170,3 +170,57 @@ def test_synth_env_block_task_is_readable_from_the_pixels(A):
         o2, r2, term2, _, info2 = ref.step(a)
         assert np.array_equal(obs, o2) and np.array_equal(term, term2) and np.array_equal(info["life_loss"], info2["life_loss"])
         assert np.array_equal(term, terms[t - 1])
+
+
+@pytest.mark.parametrize("A", [4, 9])
+def test_synth_env_chase_task_needs_a_sequence_of_moves(A):
+    """``task="chase"`` (round 5: the learnable task WITH temporal credit): the action moves the block on a 4 x 4 lattice (a % 4 = up, down, left, right, clamped at the
+    walls); +1 only on arrival at cell 15, then a respawn at Manhattan distance >= 3.  Checked from the pixels alone: exactly one 8 x 8 block of 255 per frame, on the
+    lattice, no other pixel at 255; the dynamics follow a plain-Python model of the rules; the shortest-path policy earns one reward per ~4 steps, a random one a tenth
+    of that, a constant action nothing; terminals / life losses are those of the stream task."""
+    E = 6
+    env = core.SynthVecEnv(E, seed=42, rank=0, action_dim=A, task="chase")
+    ref = core.SynthVecEnv(E, seed=42, rank=0, action_dim=A)
+    obs, _ = env.reset()
+    ref.reset()
+
+    def cells_from_pixels(o):
+        out = []
+        for e in range(E):
+            fr = o[e, 3]
+            ys, xs = np.nonzero(fr == 255)
+            assert len(ys) == 64 and ys.max() - ys.min() == 7 and xs.max() - xs.min() == 7, "exactly one 8 x 8 block of 255"
+            y, x = int(ys.min()), int(xs.min())
+            assert (y - 4) % 22 == 0 and (x - 4) % 22 == 0
+            out.append(4 * ((y - 4) // 22) + (x - 4) // 22)
+        return np.array(out)
+
+    cells = cells_from_pixels(obs)
+    assert np.array_equal(cells, (7 * np.arange(E) + 3) % 15) and np.array_equal(cells, core.env_chase_cells(obs))
+    g = recipe.gen(3) if False else np.random.default_rng(3)
+    total = {"greedy": 0.0, "random": 0.0}
+    n_arrivals = 0
+    for phase, steps in (("greedy", 240), ("random", 240)):
+        for t in range(steps):
+            if phase == "greedy":
+                a = np.where((cells >> 2) < 3, 1, 3) + 4 * (np.arange(E) % 2) * (A > 4)        # down until the last row, then right; a + 4 is the same move when A > 4
+            else:
+                a = g.integers(0, A, E)
+            obs, r, term, trunc, info = env.step(a.astype(np.int32))
+            _, _, term2, _, info2 = ref.step(np.zeros(E, np.int32))
+            assert np.array_equal(term, term2) and np.array_equal(info["life_loss"], info2["life_loss"])
+            new = cells_from_pixels(obs)
+            for e in range(E):
+                cy, cx, m = cells[e] >> 2, cells[e] & 3, a[e] % 4
+                cy, cx = (max(cy - 1, 0), cx) if m == 0 else (min(cy + 1, 3), cx) if m == 1 else (cy, max(cx - 1, 0)) if m == 2 else (cy, min(cx + 1, 3))
+                if 4 * cy + cx == 15:
+                    assert r[e] == 1.0 and (new[e] >> 2) + (new[e] & 3) <= 3, "arrival: reward and a respawn at distance >= 3"
+                    n_arrivals += 1
+                else:
+                    assert r[e] == 0.0 and new[e] == 4 * cy + cx
+                if term[e]:
+                    assert (obs[e] == obs[e, 3]).all(), "a terminal resets the frame stack to the new frame"
+            cells = new
+            total[phase] += float(r.sum())
+    assert n_arrivals > 300
+    assert 0.22 <= total["greedy"] / (240 * E) <= 0.28 and total["random"] / (240 * E) < 0.06
