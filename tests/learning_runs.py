@@ -131,7 +131,7 @@ def main(out_path=None, only=None):
             keep(run(algo, x, 2_600_000 if algo == "c51" else 4_200_000, launch, env_id=env_id, task="chase"), name)
     if not only or "dqn_prio" in only:
         keep(run("dqn", {"replay.policy": "prioritize"}, 4_200_000, task="chase"), "dqn_prioritized_sumtree")
-        keep(run("dqn", {"replay.policy": "prioritize", "replay.sumtree": "false"}, 4_200_000, task="chase"), "dqn_prioritized_flat_vector")
+        keep(run("dqn", {"replay.policy": "prioritize", "replay.sumtree": "false"}, 5_700_000, task="chase"), "dqn_prioritized_flat_vector")
     if not only or "sabotage" in only:
         for sab in ("discount_zero", "nstep_shift", "stale_next_state", "no_target_sync", "eps_one", "lr_zero"):
             keep(run("dqn", {}, 4_200_000, sabotage=sab, task="chase"), f"dqn_{sab}")

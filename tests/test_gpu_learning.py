@@ -60,9 +60,12 @@ def test_every_family_learns_the_chase_task(name, algo, extra, frames, env_id, l
     check_chase(r)
 
 
-@pytest.mark.parametrize("extra", [{"replay.policy": "prioritize"}, {"replay.policy": "prioritize", "replay.sumtree": "false"}], ids=["sum-tree", "flat-priority-vector"])
-def test_prioritized_replay_learns_the_chase_task(extra):
-    r = LR.run("dqn", extra, 4_200_000, task="chase")
+@pytest.mark.parametrize("extra,frames", [({"replay.policy": "prioritize"}, 4_200_000), ({"replay.policy": "prioritize", "replay.sumtree": "false"}, 5_700_000)],
+                         ids=["sum-tree", "flat-priority-vector"])
+def test_prioritized_replay_learns_the_chase_task(extra, frames):
+    """(the reference-faithful flat priority vector — uniform sampling, importance weights from priorities that quirk Q1 leaves misaligned — reaches the optimum later
+    and less steadily: 0.246 at 3.6 M frames, 0.216 at 4.6 M, 0.247 from 5.1 M on)"""
+    r = LR.run("dqn", extra, frames, task="chase")
     r["name"] = f"dqn {extra}"
     check_chase(r)
 
