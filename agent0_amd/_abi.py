@@ -45,7 +45,8 @@ class EncoderWeights(C.Structure):
 class LearnerDesc(C.Structure):
     _fields_ = [("A", C.c_int), ("dueling", C.c_int), ("double_q", C.c_int), ("B", C.c_int), ("n_step", C.c_int), ("discount", C.c_double), ("lr", C.c_double),
                 ("adam_eps", C.c_double), ("target_update_freq", C.c_int), ("algo", C.c_int), ("num_atoms", C.c_int), ("vmin", C.c_double), ("vmax", C.c_double),
-                ("noisy", C.c_int), ("seed", C.c_ulonglong), ("iqn_K", C.c_int), ("iqn_N", C.c_int), ("iqn_N_dash", C.c_int), ("fqf_F", C.c_int), ("mdqn_tau", C.c_double), ("mdqn_lo", C.c_double)]
+                ("noisy", C.c_int), ("seed", C.c_ulonglong), ("iqn_K", C.c_int), ("iqn_N", C.c_int), ("iqn_N_dash", C.c_int), ("fqf_F", C.c_int), ("mdqn_tau", C.c_double), ("mdqn_lo", C.c_double),
+                ("max_grad_norm", C.c_double)]
 
 
 class ReduceSeg(C.Structure):

@@ -31,12 +31,12 @@ extern "C" int a0_learner_create_on(const a0_learner_desc* d, const a0_learner_b
         return a0_fail(A0_EINVAL, "a0_learner_create: bad description");
     if (d->algo == A0_ALGO_QR && (d->num_atoms < 1 || d->num_atoms > 1024)) return a0_fail(A0_EINVAL, "a0_learner_create: qr needs 1 <= num_atoms <= 1024");
     if (d->algo == A0_ALGO_MDQN && !(d->mdqn_tau > 0.0)) return a0_fail(A0_EINVAL, "a0_learner_create: mdqn needs tau > 0");
-    if (d->algo == A0_ALGO_FQF && (d->noisy || d->fqf_F < 2 || d->fqf_F > 32 || d->A + (d->dueling ? 1 : 0) > 32))
-        return a0_fail(A0_EINVAL, "a0_learner_create: fqf needs 2 <= F <= 32, no NoisyNet, A + dueling <= 32");
-    if (d->algo == A0_ALGO_IQN && (d->noisy || d->iqn_K < 1 || d->iqn_N < 1 || d->iqn_N_dash < 1 || d->A + (d->dueling ? 1 : 0) > 32))
-        return a0_fail(A0_EINVAL, "a0_learner_create: iqn needs K, N, N' >= 1, no NoisyNet, A + dueling <= 32");
-    if (d->algo == A0_ALGO_DQN && (d->A + (d->dueling ? 1 : 0) > 24 || d->noisy))
-        return a0_fail(A0_EINVAL, "a0_learner_create: the dqn handle covers scalar heads with A + dueling <= 24 actions without NoisyNet");
+    if (d->algo == A0_ALGO_FQF && (d->fqf_F < 2 || d->fqf_F > 32 || d->A + (d->dueling ? 1 : 0) > 32))
+        return a0_fail(A0_EINVAL, "a0_learner_create: fqf needs 2 <= F <= 32, A + dueling <= 32");
+    if (d->algo == A0_ALGO_IQN && (d->iqn_K < 1 || d->iqn_N < 1 || d->iqn_N_dash < 1 || d->A + (d->dueling ? 1 : 0) > 32))
+        return a0_fail(A0_EINVAL, "a0_learner_create: iqn needs K, N, N' >= 1, A + dueling <= 32");
+    if (d->algo == A0_ALGO_DQN && d->A + (d->dueling ? 1 : 0) > 24)
+        return a0_fail(A0_EINVAL, "a0_learner_create: the dqn handle covers scalar heads with A + dueling <= 24 actions");
     if (d->algo == A0_ALGO_C51 && (d->num_atoms < 2 || d->num_atoms > 64 || !(d->vmax > d->vmin)))
         return a0_fail(A0_EINVAL, "a0_learner_create: c51 needs 2 <= num_atoms <= 64 and vmin < vmax");
     a0_learner* L = new a0_learner();
@@ -237,10 +237,12 @@ static int a0_dense_head(a0_learner* L, bool target, a0_learner::DWs& w, void* s
 
 // IQNHead.forward (model.py:235-251) for `n_tau` fractions per sample: cosine features, the embedding times the state features (in the embedding GEMM's epilogue where the
 // shape allows; kept for the backward pass when the pass is differentiated), fc1, the head, the dueling combine — DeviceNet.head of agent0_amd/deepq/engine.py
-static int a0_iqn_head(a0_learner* L, const float* flat, a0_learner::QWs& w, const float* taus, int n_tau, bool grads, void* stream) {
+static int a0_iqn_head(a0_learner* L, bool target, a0_learner::QWs& w, const float* taus, int n_tau, bool grads, void* stream) {
     const int B = L->d.B, A = L->d.A;
     const int R = B * n_tau;
-    const float *Wc = flat + L->cos.w(), *bc = flat + L->cos.b(), *Wf = flat + L->fc1.w(), *bf = flat + L->fc1.b(), *Wh = flat + L->head.w(), *bh = flat + L->head.b();
+    const float* flat = target ? L->target : L->online;
+    // (fc1 and the heads are NoisyLinear layers under NoisyNet — their composed weights; the cosine embedding is a plain Linear: model.py:204-217)
+    const float *Wc = flat + L->cos.w(), *bc = flat + L->cos.b(), *Wf = L->Wf(target), *bf = L->bf(target), *Wh = L->Wh(target), *bh = L->bh(target);
     A0_CHECK(a0_cos_features(taus, w.cosx, R, 64, stream));
     if (!grads && a0_dense_fwd_scratch(R, L->feat, 64) == 0) A0_CHECK(a0_dense_fwd_mul(w.cosx, 64, Wc, bc, w.act3, n_tau, w.x, R, L->feat, 64, 1, stream));
     else if (grads && a0_dense_fwd_mul_keep_ok(R, L->feat, 64, 64)) A0_CHECK(a0_dense_fwd_mul_keep(w.cosx, 64, Wc, bc, w.act3, n_tau, w.emb, w.x, R, L->feat, 64, 1, stream));
@@ -425,23 +427,23 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
             return a0_fqf_taus(w.logits, 32, w.tau_all, w.tau_hat, B, F, stream);
         };
         A0_CHECK(taus(on, L->act3_o, L->fo));
-        A0_CHECK(a0_iqn_head(L, on, L->qo, L->fo.tau_hat, F, true, stream));
+        A0_CHECK(a0_iqn_head(L, false, L->qo, L->fo.tau_hat, F, true, stream));
         if (dq) {
             A0_CHECK(taus(on, L->act3_s, L->fs));
-            A0_CHECK(a0_iqn_head(L, on, L->qs, L->fs.tau_hat, F, false, stream));
+            A0_CHECK(a0_iqn_head(L, false, L->qs, L->fs.tau_hat, F, false, stream));
             A0_CHECK(a0_select_action(L->qs.q, (long long)F * A, 1, A, B, A, F, 3, L->fs.tau_all, L->a_star, nullptr, nullptr, stream));
         } else {
             A0_CHECK(taus(tg, L->act3_t, L->ft));
-            A0_CHECK(a0_iqn_head(L, tg, L->qt, L->ft.tau_hat, F, false, stream));
+            A0_CHECK(a0_iqn_head(L, true, L->qt, L->ft.tau_hat, F, false, stream));
             A0_CHECK(a0_select_action(L->qt.q, (long long)F * A, 1, A, B, A, F, 3, L->ft.tau_all, L->a_star, nullptr, nullptr, stream));
         }
-        A0_CHECK(a0_iqn_head(L, tg, L->qt, L->fo.tau_hat, F, false, stream));                      // quirk Q16: the target evaluated at the ONLINE tau-hats
+        A0_CHECK(a0_iqn_head(L, true, L->qt, L->fo.tau_hat, F, false, stream));                      // quirk Q16: the target evaluated at the ONLINE tau-hats
         A0_CHECK(a0_quantile_target(L->qt.q, (long long)F * A, A, 1, L->a_star, rew, done, L->gamma_n, B, F, L->y, stream));
         A0_HIP_THROW(hipMemsetAsync(L->qo.dq, 0, (size_t)L->qo.R * A * 4, (hipStream_t)stream));
         A0_CHECK(a0_loss_quantile_huber(L->qo.q, (long long)F * A, A, 1, L->y, L->fo.tau_hat, F, act, wgt, B, F, F, L->loss, L->qo.dq, L->state, stream));
         // fraction loss: q at the interior taus (no grad), its gradient w.r.t. the fraction logits; the fraction net's RMSprop step follows the backward pass
         A0_CHECK(a0_fqf_inner_taus(L->fo.tau_all, L->inner_taus, B, F, stream));
-        A0_CHECK(a0_iqn_head(L, on, L->qf, L->inner_taus, F - 1, false, stream));
+        A0_CHECK(a0_iqn_head(L, false, L->qf, L->inner_taus, F - 1, false, stream));
         A0_CHECK(a0_fqf_fraction_loss(L->qf.q, L->qo.q, L->fo.tau_all, act, wgt, B, F, A, 32, L->frac_loss, L->dfrac, L->fo.logits, stream));
         A0_CHECK(a0_dense_wgrad(L->dfrac, L->act3_o, L->feat, L->grads + L->frac.off, B, 32, L->feat, L->slabs, stream));
     } else if (L->d.algo == A0_ALGO_IQN) {
@@ -458,15 +460,15 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         passes[np++] = a0_encoder_pass{L->wt_on, &w_on, &f_obs, B, L->act1, L->act2, L->act3_o};
         A0_CHECK(a0_net_encoder_fwd_fused_multi(L->C, L->H, L->W, np, passes, stream));
         if (dq) {        // greedy next action from the online network's K-sample mean (agent.py:303-306)
-            A0_CHECK(a0_iqn_head(L, on, L->qs, L->t_sel, K, false, stream));
+            A0_CHECK(a0_iqn_head(L, false, L->qs, L->t_sel, K, false, stream));
             A0_CHECK(a0_select_action(L->qs.q, (long long)K * A, 1, A, B, A, K, 1, nullptr, L->a_star, nullptr, nullptr, stream));
         } else {
-            A0_CHECK(a0_iqn_head(L, tg, L->qt, L->t_sel, K, false, stream));
+            A0_CHECK(a0_iqn_head(L, true, L->qt, L->t_sel, K, false, stream));
             A0_CHECK(a0_select_action(L->qt.q, (long long)K * A, 1, A, B, A, K, 1, nullptr, L->a_star, nullptr, nullptr, stream));
         }
-        A0_CHECK(a0_iqn_head(L, tg, L->qt, L->t_tgt, Nd, false, stream));
+        A0_CHECK(a0_iqn_head(L, true, L->qt, L->t_tgt, Nd, false, stream));
         A0_CHECK(a0_quantile_target(L->qt.q, (long long)Nd * A, A, 1, L->a_star, rew, done, L->gamma_n, B, Nd, L->y, stream));
-        A0_CHECK(a0_iqn_head(L, on, L->qo, L->t_on, N, true, stream));
+        A0_CHECK(a0_iqn_head(L, false, L->qo, L->t_on, N, true, stream));
         A0_HIP_THROW(hipMemsetAsync(L->qo.dq, 0, (size_t)L->qo.R * A * 4, (hipStream_t)stream));
         A0_CHECK(a0_loss_quantile_huber(L->qo.q, (long long)N * A, A, 1, L->y, L->t_on, N, act, wgt, B, N, Nd, L->loss, L->qo.dq, L->state, stream));
     } else if (L->d.algo == A0_ALGO_C51 || L->d.algo == A0_ALGO_QR) {
@@ -565,8 +567,8 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         // ---- dense backward over the B * n_tau rows of the differentiated pass (DeviceLearner._backward_dense, quantile branch)
         const int R = (int)L->qo.R;
         A0_CHECK(a0_dueling_bwd(L->qo.dq, L->draw, L->Npad, R, A, 1, L->d.dueling ? 1 : 0, stream));
-        A0_CHECK(a0_dense_dgrad(L->draw, on + L->head.w(), L->qo.h, L->dh, R, L->Npad, 512, stream));
-        A0_CHECK(a0_dense_dgrad(L->dh, on + L->fc1.w(), nullptr, L->qo.dx, R, 512, L->feat, stream));
+        A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->qo.h, L->dh, R, L->Npad, 512, stream));
+        A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), nullptr, L->qo.dx, R, 512, L->feat, stream));
         A0_CHECK(a0_hadamard_bwd(L->qo.dx, L->qo.emb, L->act3_o, L->qo.demb, L->d3, B, N, L->feat, stream));
         {
             const float* dY[3] = {L->draw, L->dh, L->qo.demb};
@@ -635,7 +637,7 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     }
     if (loss_out) A0_HIP_THROW(hipMemcpyAsync(loss_out, L->loss, (size_t)B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (L->d.algo == A0_ALGO_FQF)      // unconditional, like the reference's fqf_optimizer.step() in front of the NaN guard (agent.py:139-148); lr / 2e4, alpha 0.95, eps 1e-5
-        A0_CHECK(a0_rmsprop_step(on + L->frac.off, L->grads + L->frac.off, L->rms_sq, L->frac.size(), L->d.lr / 2e4, 0.95, 1e-5, -1.0, L->clip, stream));
+        A0_CHECK(a0_rmsprop_step(on + L->frac.off, L->grads + L->frac.off, L->rms_sq, L->frac.size(), L->d.lr / 2e4, 0.95, 1e-5, L->d.max_grad_norm > 0.0 ? L->d.max_grad_norm : -1.0, L->clip, stream));
     // ---- Adam (eps = 1e-2 / B unless given), NaN guard, update counter, target copy every target_update_freq updates, weight-copy refresh (agent.py:102-106,152-161)
     const double eps = L->d.adam_eps > 0.0 ? L->d.adam_eps : 1e-2 / (double)B;
     A0_CHECK(a0_adam_step_sync_wt(on, L->grads, L->m, L->v, L->n_adam, L->state, L->scalars, L->d.lr, 0.9, 0.999, eps, L->d.target_update_freq, tg, L->n_pad, dp ? L->grads + L->n_pad : nullptr, &w_on, L->C,

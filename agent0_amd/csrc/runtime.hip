@@ -79,6 +79,10 @@ extern "C" int a0_rbuf_create_on(const a0_rbuf_desc* d, uint8_t* frames, int* ac
         R->b_idx = R->mem.alloc<long long>(B); R->b_slot = R->mem.alloc<int>(B); R->b_act = R->mem.alloc<int>(B); R->b_rew = R->mem.alloc<float>(B);
         R->b_done = R->mem.alloc<float>(B); R->b_prio = R->mem.alloc<float>(B); R->b_w = R->mem.alloc<float>(B); R->ones = R->mem.alloc<float>(B);
         R->pstate = max_p ? max_p : R->mem.alloc<float>(1); R->val = R->mem.alloc<float>(4);
+        if (!R->prio) {      // a0_rbuf_sample_block's buffers (uniform replay only): allocated here, so that no call after create allocates or synchronises
+            R->m_idx = R->mem.alloc<long long>(32LL * B); R->m_slot = R->mem.alloc<int>(32LL * B); R->m_act = R->mem.alloc<int>(32LL * B); R->m_rew = R->mem.alloc<float>(32LL * B);
+            R->m_done = R->mem.alloc<float>(32LL * B); R->m_prio = R->mem.alloc<float>(32LL * B);
+        }
         hipLaunchKernelGGL(a0_fill_one_kernel, dim3((B + 255) / 256), dim3(256), 0, 0, R->ones, (long long)B, 1.0f);
         if (!max_p) hipLaunchKernelGGL(a0_fill_one_kernel, dim3(1), dim3(256), 0, 0, R->pstate, 1LL, 1.0f);           // max_p = 1 (replay.py:20)
         if (R->prio) {
@@ -152,6 +156,27 @@ extern "C" int a0_rbuf_commit(a0_rbuf* R, long long n, void* stream) {
     A0_CATCH
 }
 
+// ReplayDataset.extend for a rollout that landed in ANOTHER ring (round 5; the launch schedule, launch.py:47-62: the learner books a finished rollout while the next
+// one is in flight): rows [start_row, start_row + n) of `stage` — an a0_rbuf an asynchronous actor rolled out into — are copied to this ring's write cursor (at most two
+// pieces: the ring may wrap), then committed like a0_rbuf_commit.  Stream-ordered on `stream`; the caller has made sure the rollout is complete.
+extern "C" int a0_rbuf_extend_from(a0_rbuf* R, const a0_rbuf* S, long long start_row, long long n, void* stream) {
+    A0_TRY
+    if (!R || !S || n < 1 || start_row < 0 || start_row + n > S->size || n > R->size || S->row_bytes != R->row_bytes)
+        return a0_fail(A0_EINVAL, "a0_rbuf_extend_from: rows [start_row, start_row + n) of a stage ring with the same row format, n <= ring size");
+    hipStream_t st = (hipStream_t)stream;
+    long long done = 0;
+    while (done < n) {
+        const long long c = (R->written + done) % R->size, k = std::min(n - done, R->size - c), a = start_row + done;
+        A0_HIP_THROW(hipMemcpyAsync(R->frames + c * R->row_bytes, S->frames + a * S->row_bytes, (size_t)(k * R->row_bytes), hipMemcpyDeviceToDevice, st));
+        A0_HIP_THROW(hipMemcpyAsync(R->act + c, S->act + a, (size_t)k * 4, hipMemcpyDeviceToDevice, st));
+        A0_HIP_THROW(hipMemcpyAsync(R->rew + c, S->rew + a, (size_t)k * 4, hipMemcpyDeviceToDevice, st));
+        A0_HIP_THROW(hipMemcpyAsync(R->done + c, S->done + a, (size_t)k * 4, hipMemcpyDeviceToDevice, st));
+        done += k;
+    }
+    return a0_rbuf_commit(R, n, stream);
+    A0_CATCH
+}
+
 // One batch (trainer.py:63-72 / 91-96): uniform — element pos * B + b of the epoch's permutation of range(top) (an epoch is opened when the previous one has
 // no whole batch left BUT ONE: the reference's prefetcher never returns its last batch, utils.py:51-56) — or proportional from the sum-tree with importance
 // weights.  The pointers in `out` are the handle's persistent batch buffers (valid until the next sample).
@@ -185,10 +210,6 @@ extern "C" int a0_rbuf_sample_block(a0_rbuf* R, int n, a0_batch* out, void* stre
     if (!R || !out || n < 1 || n > 32) return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: 1..32 batches");
     if (R->prio) return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: prioritized batches depend on the update before them (a0_rbuf_sample)");
     const int B = R->B;
-    if (!R->m_idx) {
-        R->m_idx = R->mem.alloc<long long>(32LL * B); R->m_slot = R->mem.alloc<int>(32LL * B); R->m_act = R->mem.alloc<int>(32LL * B); R->m_rew = R->mem.alloc<float>(32LL * B);
-        R->m_done = R->mem.alloc<float>(32LL * B); R->m_prio = R->mem.alloc<float>(32LL * B);
-    }
     unsigned long long start[32], n_perm[32];
     unsigned int seed[32];
     for (int g = 0; g < n; ++g) {        // the epoch bookkeeping of n consecutive a0_rbuf_sample calls (the ring does not change inside an update block)
@@ -250,7 +271,82 @@ struct a0_actor {
     // quantile heads (iqn): E * K rows — tau draws, cosine features, embedding x features, fc1 output
     float *q_taus = nullptr, *q_cosx = nullptr, *q_x = nullptr;
     float *f_logits = nullptr, *f_tau_all = nullptr;        // fqf: fraction logits [E][32], taus [E][F + 1] (q_taus holds the tau-hats)
+    bool bound = false;
+    // round 5, the launch schedule (launch.py:34-36,58-62): the actor's OWN copy of the network — packed parameters, the fused kernels' weight copies, and under NoisyNet
+    // its own noise vectors and composed weights — refreshed by a0_actor_snapshot when a rollout is issued.  Without it (main schedule) the actor acts with the learner's
+    // online network, NoisyNet buffers included: the reference's train actor SHARES the learner's module there (trainer.py:41-44).
+    float *own_flat = nullptr, *own_wt = nullptr, *own_eff = nullptr, *own_noise = nullptr;
 };
+
+// the network an actor acts with: the learner's online network, or the actor's own snapshot of it
+struct a0_actor_net {
+    const float* flat; const float* wt; float* eff; float* noise;
+    const a0_learner* L;
+    const float* Wf() const { return L->d.noisy ? eff + L->eff_fc1.w() : flat + L->fc1.w(); }
+    const float* bf() const { return L->d.noisy ? eff + L->eff_fc1.b() : flat + L->fc1.b(); }
+    const float* Wh() const { return L->d.noisy ? eff + L->eff_head.w() : flat + L->head.w(); }
+    const float* bh() const { return L->d.noisy ? eff + L->eff_head.b() : flat + L->head.b(); }
+};
+static a0_actor_net a0_actor_view(const a0_actor* a, a0_learner* L) {
+    if (a->own_flat) return a0_actor_net{a->own_flat, a->own_wt, a->own_eff, a->own_noise, L};
+    return a0_actor_net{L->online, L->wt_on, L->eff_on, L->noise, L};
+}
+
+// Every workspace a rollout with `learner` needs — the distributional / quantile heads' buffers, sized by the learner's head — and, own_network != 0, the actor's own
+// copy of the network (a0_actor_snapshot fills it).  Call it once at set-up: a0_actor_rollout then neither allocates nor synchronises (an unbound actor is bound at its
+// first rollout, which does both).
+extern "C" int a0_actor_bind(a0_actor* a, const a0_learner* L, int own_network) {
+    A0_TRY
+    if (!a || !L) return a0_fail(A0_EINVAL, "a0_actor_bind: null argument");
+    if (L->d.A != a->d.A || (L->d.dueling != 0) != (a->d.dueling != 0)) return a0_fail(A0_EINVAL, "a0_actor_bind: actor and learner were created for different heads");
+    const int E = a->E;
+    const bool dist = L->d.algo == A0_ALGO_C51 || L->d.algo == A0_ALGO_QR, fqf = L->d.algo == A0_ALGO_FQF, quant = L->d.algo == A0_ALGO_IQN || fqf;
+    if (a->bound && a->dist_Npad != L->Npad) return a0_fail(A0_EINVAL, "a0_actor_bind: this actor was sized for another head");
+    if (!a->bound) {
+        const int nt = fqf ? L->F : (quant ? L->d.iqn_K : 1);
+        if (quant) {
+            const long long R = (long long)E * nt;
+            if (a0_dense_fwd_scratch((int)R, L->feat, 64) != 0) return a0_fail(A0_EINVAL, "a0_actor_bind: E * K rows too few for the embedding kernel this path takes");
+            a->h = a->mem.alloc<float>(R * 512);
+            a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs((int)R, L->Npad, 512) * R * L->Npad);
+            long long sc = a0_dense_fwd_scratch((int)R, 512, L->feat);
+            if (fqf && a0_dense_fwd_scratch(E, 32, L->feat) > sc) sc = a0_dense_fwd_scratch(E, 32, L->feat);
+            a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
+            a->q_taus = a->mem.alloc<float>(ceil_to(R, 4)); a->q_cosx = a->mem.alloc<float>(R * 64); a->q_x = a->mem.alloc<float>(R * L->feat);
+            if (fqf) { a->f_logits = a->mem.alloc<float>((long long)E * 32); a->f_tau_all = a->mem.alloc<float>((long long)E * (nt + 1)); }
+        } else if (dist) {
+            a->h = a->mem.alloc<float>((long long)E * 512);
+            a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs(E, L->Npad, 512) * E * L->Npad);
+            const long long sc = a0_dense_fwd_scratch(E, 512, L->feat);
+            a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
+        }
+        a->dist_Npad = L->Npad;
+        a->bound = true;
+    }
+    if (own_network && !a->own_flat) {
+        a->own_flat = a->mem.alloc<float>(L->n_pad); a->own_wt = a->mem.alloc<float>(L->wt_floats);
+        if (L->d.noisy) { a->own_eff = a->mem.alloc<float>(L->n_eff); a->own_noise = a->mem.alloc<float>(L->noise_len); }
+    }
+    A0_HIP_THROW(hipDeviceSynchronize());
+    return A0_OK;
+    A0_CATCH
+}
+
+// actor.futures.sample(eps, state_dict) (launch.py:34-36,58-62): the actor's own network := the learner's online network as it is at this point of `stream` — packed
+// parameters, weight copies, NoisyNet noise and composed weights (DeviceNet.copy_from).  Needs a0_actor_bind(actor, learner, 1).
+extern "C" int a0_actor_snapshot(a0_actor* a, const a0_learner* L, void* stream) {
+    A0_TRY
+    if (!a || !L || !a->own_flat) return a0_fail(A0_EINVAL, "a0_actor_snapshot: an actor bound with its own network (a0_actor_bind(actor, learner, 1))");
+    hipStream_t st = (hipStream_t)stream;
+    A0_HIP_THROW(hipMemcpyAsync(a->own_flat, L->online, (size_t)L->n_pad * 4, hipMemcpyDeviceToDevice, st));
+    A0_HIP_THROW(hipMemcpyAsync(a->own_wt, L->wt_on, (size_t)L->wt_floats * 4, hipMemcpyDeviceToDevice, st));
+    if (L->d.noisy) {
+        A0_HIP_THROW(hipMemcpyAsync(a->own_eff, L->eff_on, (size_t)L->n_eff * 4, hipMemcpyDeviceToDevice, st));
+        A0_HIP_THROW(hipMemcpyAsync(a->own_noise, L->noise, (size_t)L->noise_len * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return A0_OK;
+    A0_CATCH
+}
 
 extern "C" int a0_actor_create(const a0_actor_desc* d, a0_actor** out) {
     A0_TRY
@@ -289,15 +385,16 @@ extern "C" int a0_actor_destroy(a0_actor* a) { delete a; return A0_OK; }
 // rows written straight into the ring at its write cursor (call a0_rbuf_commit(replay, T * E) afterwards: ReplayDataset.extend), then the per-step mean max-Q.
 // Asynchronous like everything else; a0_actor_collect waits and returns the statistics.
 // the online network's effective weights from its parameters and the noise vectors it currently holds (DeviceNet.compose_noise)
-static int a0_actor_compose(const a0_learner* L, void* stream) {
+static int a0_actor_compose(const a0_actor_net& V, void* stream) {
+    const a0_learner* L = V.L;
     const float *mu[3], *sg[3], *nin[3], *nw[3], *nb[3];
     float* eff[3];
     int N[3], K[3], r0[3], r1[3];
     for (int k = 0; k < L->n_mods; ++k) {
         const a0_noise_mod& m = L->mods[k];
         const Blk &bm = m.block ? L->head : L->fc1, &bs = m.block ? L->head_sigma : L->fc1_sigma, &be = m.block ? L->eff_head : L->eff_fc1;
-        mu[k] = L->online + bm.off; sg[k] = L->online + bs.off; eff[k] = L->eff_on + be.off; N[k] = bm.N; K[k] = bm.K; r0[k] = m.r0; r1[k] = m.r1;
-        nin[k] = L->noise + m.off_in; nw[k] = L->noise + m.off_w; nb[k] = L->noise + m.off_b;
+        mu[k] = V.flat + bm.off; sg[k] = V.flat + bs.off; eff[k] = V.eff + be.off; N[k] = bm.N; K[k] = bm.K; r0[k] = m.r0; r1[k] = m.r1;
+        nin[k] = V.noise + m.off_in; nw[k] = V.noise + m.off_w; nb[k] = V.noise + m.off_b;
     }
     return a0_noisy_multi(0, L->n_mods, mu, sg, eff, N, K, r0, r1, nin, nw, nb, stream);
 }
@@ -311,39 +408,21 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     const bool dist = L->d.algo == A0_ALGO_C51 || L->d.algo == A0_ALGO_QR, fqf = L->d.algo == A0_ALGO_FQF, quant = L->d.algo == A0_ALGO_IQN || fqf;
     const int freq = a->d.reset_noise_freq > 0 ? a->d.reset_noise_freq : 4;
     const int nt = fqf ? L->F : (quant ? L->d.iqn_K : 1);  // fractions per env and step (agent.py:25-39 with IQNHead.qval / FQFHead.qval, model.py:253-257,280-284)
-    if (quant && a->h == nullptr) {
-        const long long R = (long long)E * nt;
-        if (a0_dense_fwd_scratch((int)R, L->feat, 64) != 0) return a0_fail(A0_EINVAL, "a0_actor_rollout: E * K rows too few for the embedding kernel this path takes");
-        a->h = a->mem.alloc<float>(R * 512);
-        a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs((int)R, L->Npad, 512) * R * L->Npad);
-        long long sc = a0_dense_fwd_scratch((int)R, 512, L->feat);
-        if (fqf && a0_dense_fwd_scratch(E, 32, L->feat) > sc) sc = a0_dense_fwd_scratch(E, 32, L->feat);
-        a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
-        a->q_taus = a->mem.alloc<float>(ceil_to(R, 4)); a->q_cosx = a->mem.alloc<float>(R * 64); a->q_x = a->mem.alloc<float>(R * L->feat);
-        if (fqf) { a->f_logits = a->mem.alloc<float>((long long)E * 32); a->f_tau_all = a->mem.alloc<float>((long long)E * (nt + 1)); }
-        a->dist_Npad = L->Npad;
-    }
-    if (dist && (a->h == nullptr || a->dist_Npad != L->Npad)) {
-        if (a->h != nullptr) return a0_fail(A0_EINVAL, "a0_actor_rollout: this actor was sized for another head");
-        a->h = a->mem.alloc<float>((long long)E * 512);
-        a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs(E, L->Npad, 512) * E * L->Npad);
-        const long long sc = a0_dense_fwd_scratch(E, 512, L->feat);
-        a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
-        a->dist_Npad = L->Npad;
-    }
+    if (!a->bound || a->dist_Npad != L->Npad) A0_CHECK(a0_actor_bind(a, L, 0));      // (a host that wants no allocation after set-up binds there)
+    const a0_actor_net V = a0_actor_view(a, L);
     const long long start = R->written % R->size;
-    a0_encoder_weights w = L->enc(L->online);
+    a0_encoder_weights w = L->enc(V.flat);
     // NoisyLinear.forward composes mu + sigma * eps with the parameters as they are NOW (model.py:54-62): a rollout that does not start on a noise reset
     // recomposes the copies once (agent0_amd/deepq/agent.py Actor._rollout)
-    if (L->d.noisy && a->steps % freq != 0) A0_CHECK(a0_actor_compose(L, stream));
+    if (L->d.noisy && a->steps % freq != 0) A0_CHECK(a0_actor_compose(V, stream));
     for (int t = 0; t < a->T; ++t) {
         if (L->d.noisy && a->steps % freq == 0) {      // agent.py:52-53: self.model.reset_noise() every reset_noise_freq steps, from the ACTOR's stream
-            A0_CHECK(a0_rng_normal(a->rng.seed, 4 /* STREAM_NOISE */, a->rng.reserve(4, L->noise_len), 0.1f, L->noise, L->noise_len, stream));
-            A0_CHECK(a0_actor_compose(L, stream));
+            A0_CHECK(a0_rng_normal(a->rng.seed, 4 /* STREAM_NOISE */, a->rng.reserve(4, L->noise_len), 0.1f, V.noise, L->noise_len, stream));
+            A0_CHECK(a0_actor_compose(V, stream));
         }
         const uint8_t* cur_obs = a->obs[a->cur];
         a0_frames_arg f{cur_obs, nullptr, (long long)a->obs_bytes, 0};
-        A0_CHECK(a0_net_encoder_fwd_fused(L->C, L->H, L->W, L->wt_on, &w, &f, E, nullptr, nullptr, a->act3, stream));
+        A0_CHECK(a0_net_encoder_fwd_fused(L->C, L->H, L->W, V.wt, &w, &f, E, nullptr, nullptr, a->act3, stream));
         const long long back = (a->steps + 1 < a->n ? a->steps + 1 : a->n) - 1;                 // first observation of the emitted n-step transition
         const uint8_t* obs0 = a->obs[((a->cur - back) % a->K + a->K) % a->K];
         if (quant) {
@@ -351,7 +430,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             // times the features in the embedding GEMM's epilogue, fc1, the head GEMM's slabs, then ONE launch for slab sum + bias, dueling, the mean over the fractions,
             // first-max argmax, epsilon-greedy, env step, n-step bookkeeping and the replay row
             const int rows = E * nt;
-            const float* on = L->online;
+            const float* on = V.flat;
             if (fqf) {      // FQFHead.prop_taus (model.py:268-278): the fraction net on the step's features; no draws
                 A0_CHECK(a0_dense_fwd(a->act3, L->feat, on + L->frac.w(), on + L->frac.b(), a->f_logits, E, 32, L->feat, 0, a->fwd_scratch, stream));
                 A0_CHECK(a0_fqf_taus(a->f_logits, 32, a->f_tau_all, a->q_taus, E, nt, stream));
@@ -360,13 +439,13 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             }
             A0_CHECK(a0_cos_features(a->q_taus, a->q_cosx, rows, 64, stream));
             A0_CHECK(a0_dense_fwd_mul(a->q_cosx, 64, on + L->cos.w(), on + L->cos.b(), a->act3, nt, a->q_x, rows, L->feat, 64, 1, stream));
-            A0_CHECK(a0_dense_fwd(a->q_x, L->feat, on + L->fc1.w(), on + L->fc1.b(), a->h, rows, 512, L->feat, 1, a->fwd_scratch, stream));
+            A0_CHECK(a0_dense_fwd(a->q_x, L->feat, V.Wf(), V.bf(), a->h, rows, 512, L->feat, 1, a->fwd_scratch, stream));
             const int ns = a0_dense_fwd_partial_slabs(rows, L->Npad, 512);
-            A0_CHECK(a0_dense_fwd_partial(a->h, 512, on + L->head.w(), rows, L->Npad, 512, a->head_slabs, stream));
+            A0_CHECK(a0_dense_fwd_partial(a->h, 512, V.Wh(), rows, L->Npad, 512, a->head_slabs, stream));
             const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);
             const int nx = (a->cur + 1) % a->K;
             a->g += 1;
-            A0_CHECK(a0_actor_quantile_tail_env_step(a->head_slabs, (long long)rows * L->Npad, ns, on + L->head.b(), L->Npad, A, nt, a->d.dueling ? 1 : 0, fqf ? 3 : 1, fqf ? a->f_tau_all : nullptr, E, a->rng.seed,
+            A0_CHECK(a0_actor_quantile_tail_env_step(a->head_slabs, (long long)rows * L->Npad, ns, V.bh(), L->Npad, A, nt, a->d.dueling ? 1 : 0, fqf ? 3 : 1, fqf ? a->f_tau_all : nullptr, E, a->rng.seed,
                                                      STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed,
                                                      a->d.rank, a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
                                                      a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act,
@@ -378,14 +457,14 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
         if (dist) {
             // fc1, the head GEMM's slabs, then ONE launch: slab sum + bias, dueling, expectation over the support, first-max argmax, epsilon-greedy, env step,
             // n-step bookkeeping and the replay row (Actor._dist_tail_args + act_step_commit(kind = "dist"))
-            A0_CHECK(a0_dense_fwd(a->act3, L->feat, L->Wf(false), L->bf(false), a->h, E, 512, L->feat, 1, a->fwd_scratch, stream));
+            A0_CHECK(a0_dense_fwd(a->act3, L->feat, V.Wf(), V.bf(), a->h, E, 512, L->feat, 1, a->fwd_scratch, stream));
             const int ns = a0_dense_fwd_partial_slabs(E, L->Npad, 512);
-            A0_CHECK(a0_dense_fwd_partial(a->h, 512, L->Wh(false), E, L->Npad, 512, a->head_slabs, stream));
+            A0_CHECK(a0_dense_fwd_partial(a->h, 512, V.Wh(), E, L->Npad, 512, a->head_slabs, stream));
             const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);
             const int nx = (a->cur + 1) % a->K;
             a->g += 1;
             if (4LL * ((long long)A * L->T + L->T) * 4 > 160 * 1024) return a0_fail(A0_EINVAL, "a0_actor_rollout: head too wide for the distributional tail kernel");
-            A0_CHECK(a0_actor_dist_tail_env_step(a->head_slabs, (long long)E * L->Npad, ns, L->bh(false), L->Npad, A, L->T, a->d.dueling ? 1 : 0, L->d.algo == A0_ALGO_C51 ? 2 : 1,
+            A0_CHECK(a0_actor_dist_tail_env_step(a->head_slabs, (long long)E * L->Npad, ns, V.bh(), L->Npad, A, L->T, a->d.dueling ? 1 : 0, L->d.algo == A0_ALGO_C51 ? 2 : 1,
                                                  L->d.algo == A0_ALGO_C51 ? L->atoms : nullptr, E, a->rng.seed,
                                                  STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed, a->d.rank,
                                                  a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps, a->d.discount,
@@ -399,7 +478,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
         const unsigned long long off_a = a->rng.reserve(STREAM_EGREEDY_A, E), off_u = a->rng.reserve(STREAM_EGREEDY_U, E);
         const int nxt = (a->cur + 1) % a->K;
         a->g += 1;
-        A0_CHECK(a0_actor_qhead_env_step(a->act3, E, a->feat, L->Wf(false), L->bf(false), L->Wh(false), L->bh(false), A, a->d.dueling ? 1 : 0,
+        A0_CHECK(a0_actor_qhead_env_step(a->act3, E, a->feat, V.Wf(), V.bf(), V.Wh(), V.bh(), A, a->d.dueling ? 1 : 0,
                                          a->scratch, a->rng.seed, STREAM_EGREEDY_A, STREAM_EGREEDY_U, off_a, off_u, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E,
                                          a->d.seed, a->d.rank, a->g, cur_obs, a->obs[nxt], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
                                          a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,

@@ -8,9 +8,11 @@ target, Adam moments, status words, loss ring, weight copies, NoisyNet buffers, 
 reader of ``trainer.replay`` keep seeing the live data, with no copies in either direction.  What the handles own themselves: the actor's env state and Philox
 offsets, the sampler's state (epochs / beta), the workspaces.
 
-Scope = what the handles cover (include/agent0_hip.h): all six learners (dqn without NoisyNet and with A + dueling <= 24; iqn / fqf without NoisyNet) on 4 x 84 x 84 observations, the device-resident env,
-uniform or sum-tree replay, one GPU, the ``main`` schedule.  Everything else — and any Trainer whose hot-loop methods a test harness has wrapped — stays on the Python
-classes.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
+Scope = what the handles cover (include/agent0_hip.h): all six learners (scalar heads with A + dueling <= 24), with or without NoisyNet, on 4 x 84 x 84 observations, the
+device-resident env's stream / block tasks, uniform or sum-tree replay, one GPU, the ``main`` AND (round 5) the ``launch`` schedule — there the actor handle owns a copy
+of the network (a0_actor_bind(.., 1) / a0_actor_snapshot) and rolls out into the Trainer's stage ring on the actor stream while the update block runs
+(``run_iteration_lp``).  Everything else — host environments, the chase task, the reference-faithful flat priority vector, data parallelism unless opted in — and any
+Trainer whose hot-loop methods a test harness has wrapped stays on the Python classes.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
 """
 from __future__ import annotations
 
@@ -68,15 +70,13 @@ def eligible(tr) -> Optional[str]:
     lc = cfg.learner
     if os.environ.get("A0_NATIVE_LOOP", "1") == "0":
         return "A0_NATIVE_LOOP=0"
-    if tr.use_lp:
-        return "the launch schedule keeps its second stream in Python"
     algo = lc.algo.name
     if algo == "dqn":
-        if lc.noisy_net or cfg.action_dim + (1 if lc.dueling_head else 0) > 24:
-            return "dqn handle: no NoisyNet, A + dueling <= 24"
+        if cfg.action_dim + (1 if lc.dueling_head else 0) > 24:
+            return "dqn handle: A + dueling <= 24"
     elif algo in ("iqn", "fqf"):
-        if lc.noisy_net or cfg.action_dim + (1 if lc.dueling_head else 0) > 32 or not getattr(tr.actors[1], "quant_tail", False):
-            return "quantile handles: no NoisyNet, A + dueling <= 32, the merged quantile tail"
+        if cfg.action_dim + (1 if lc.dueling_head else 0) > 32 or not getattr(tr.actors[1], "quant_tail", False):
+            return "quantile handles: A + dueling <= 32, the merged quantile tail"
     elif algo == "qr":
         if not getattr(tr.actors[1], "dist_tail", False):
             return "qr handle: the distributional tail kernel"
@@ -100,8 +100,10 @@ def eligible(tr) -> Optional[str]:
     eng = tr.learner.engine
     if not (eng.online.fused and eng.online.fused_dgrad) or tr.ops.gemm_mode() != 1 or not getattr(eng, "_defer_dense", False):
         return "a tuning mode of the Python composition"
-    if lc.learner_steps > eng.loss_ring.numel() or lc.max_grad_norm > 0:
-        return "block longer than the loss ring / gradient clipping"
+    if lc.learner_steps > eng.loss_ring.numel():
+        return "block longer than the loss ring"
+    if tr.use_lp and not tr.overlap:
+        return "the launch schedule on one stream (a test mode of the Python classes)"
     if algo == "c51" and not (2 <= lc.c51.num_atoms <= 64):
         return "support size"
     return None
@@ -129,7 +131,8 @@ class NativeLoop:
         # ---- learner over the engine's buffers
         desc = _abi.LearnerDesc(int(cfg.action_dim), int(bool(lc.dueling_head)), int(bool(lc.double_q)), self.B, int(lc.n_step_q), float(lc.discount), float(lc.learning_rate),
                                 float(eng.adam_eps), int(lc.target_update_freq), {"dqn": 0, "c51": 1, "iqn": 2, "fqf": 3, "qr": 4, "mdqn": 5}[lc.algo.name], int(lc.qr.num_atoms if lc.algo.name == "qr" else lc.c51.num_atoms), float(lc.c51.vmin), float(lc.c51.vmax),
-                                int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF, int(lc.iqn.K), int(lc.iqn.N), int(lc.iqn.N_dash), int(lc.iqn.F), float(lc.mdqn.tau), float(lc.mdqn.lo))
+                                int(bool(lc.noisy_net)), (int(cfg.seed) + 15485863) & 0xFFFFFFFFFFFFFFFF, int(lc.iqn.K), int(lc.iqn.N), int(lc.iqn.N_dash), int(lc.iqn.F), float(lc.mdqn.tau), float(lc.mdqn.lo),
+                                float(lc.max_grad_norm))
         p = lambda t: None if t is None else t.data_ptr()
         bufs = _LearnerBuffers(p(eng.online.flat), p(eng.target.flat), p(eng.grads), p(eng.adam_m), p(eng.adam_v), p(eng.state), p(eng.scalars), p(eng.loss_ring),
                                int(eng.loss_ring.numel()), p(eng.online.wt), p(eng.target.wt), p(eng.online.eff), p(eng.target.eff), p(eng.noise_joint), p(getattr(eng, "rms_sq", None)))
@@ -155,6 +158,18 @@ class NativeLoop:
                         {"stream": 0, "block": 1}[cfg.env_task], int(lc.reset_noise_freq))
         self.actor = C.c_void_p()
         ok(lib.a0_actor_create(C.addressof(ad), C.addressof(self.actor)), "a0_actor_create")
+        # every workspace now, so that no call of the loop allocates; on the launch schedule the actor gets its OWN copy of the network (launch.py:34-36,58-62) and rolls
+        # out into the Trainer's stage ring on the Trainer's actor stream
+        self.lp = bool(tr.use_lp)
+        ok(lib.a0_actor_bind(self.actor, self.learner, int(self.lp)), "a0_actor_bind")
+        self.stage = None
+        if self.lp:
+            sg = tr.stage
+            sd = _RbufDesc(int(sg.size), int(sg.obs_bytes), min(self.B, int(sg.size)), 0, float(rc.alpha), float(rc.eps), float(rc.beta0), int(cfg.trainer.total_steps), int(cfg.seed) + 7)
+            self._stage_pstate = ops.zeros(1)
+            self.stage = C.c_void_p()
+            ok(lib.a0_rbuf_create_on(C.addressof(sd), p(sg.frames), p(sg.act), p(sg.rew), p(sg.done), None, p(self._stage_pstate), C.addressof(self.stage)), "a0_rbuf_create_on (stage)")
+            self._lp_pending = None
         lp = C.c_void_p()
         ok(lib.a0_learner_loss_buffer(self.learner, C.addressof(lp)), "a0_learner_loss_buffer")
         self.loss_ptr = lp                                # the learner's own per-sample losses: update_priority reads them in place
@@ -249,6 +264,60 @@ class NativeLoop:
         result.update(fps=tr.num_transitions / (time.time() - tic))
         return result
 
+    # ------------------------------------------------------------------ the launch schedule (Trainer.run_iteration_lp; launch.py:30-63)
+    def _issue_lp(self):
+        """``actor.futures.sample(eps, state_dict)``: the weight snapshot on the learner's stream — behind every update enqueued so far, ahead of the next — then the
+        rollout into the free half of the stage on the actor stream, without waiting."""
+        tr, lib, ok = self.tr, self.lib, self.ok
+        eps = tr.epsilon_fn(tr.frame_count)
+        cur = torch.cuda.current_stream()
+        ast = tr.actor_stream
+        ok(lib.a0_actor_snapshot(self.actor, self.learner, cur.cuda_stream), "a0_actor_snapshot")
+        ast.wait_stream(cur)
+        start = int(lib.a0_rbuf_write_cursor(self.stage))
+        ok(lib.a0_actor_rollout(self.actor, self.learner, self.stage, C.c_float(eps), ast.cuda_stream), "a0_actor_rollout")
+        ok(lib.a0_rbuf_commit(self.stage, self.T * self.E, ast.cuda_stream), "a0_rbuf_commit (stage)")
+        tr.stage.written += self.T * self.E
+        return start
+
+    def run_iteration_lp(self):
+        tr, lib, ok = self.tr, self.lib, self.ok
+        st = torch.cuda.current_stream().cuda_stream
+        tic = time.time()
+        if self._lp_pending is None:
+            self._lp_pending = self._issue_lp()          # launch.py:32-37 primes the pipeline before the loop
+        # wait for the rollout in flight and take its statistics (a0_actor_collect synchronises the ACTOR stream)
+        ok(lib.a0_actor_collect(self.actor, self._qs, self._rs, self.T * self.E, C.addressof(self._nret), tr.actor_stream.cuda_stream), "a0_actor_collect")
+        start = self._lp_pending
+        qs, rs = np.ctypeslib.as_array(self._qs).tolist(), np.ctypeslib.as_array(self._rs)[: self._nret.value].tolist()
+        self._lp_pending = self._issue_lp()              # the next rollout, with the weights and the epsilon of NOW, before this one's update block
+        # Trainer.step: extend (the finished rollout's rows from the stage into the ring), then the update block beside the rollout in flight
+        n = self.T * self.E
+        ok(lib.a0_rbuf_extend_from(self.rbuf, self.stage, start, n, st), "a0_rbuf_extend_from")
+        rp = tr.replay
+        tr.frame_count += n
+        rp.written += n
+        rp.top = min(rp.top + n, rp.size)
+        if self.prio:
+            beta = C.c_double()
+            ok(lib.a0_rbuf_info(self.rbuf, None, None, C.addressof(beta)), "a0_rbuf_info")
+            rp.beta = beta.value
+        tr.Qs.extend(qs)
+        tr.Rs.extend(rs)
+        n_upd = self._block(st)
+        blk = tr._block_stats_async(n_upd, self.fqf and n_upd > 0)
+        tr._block_stats_finish(blk)
+        result = tr._result()
+        torch.cuda.synchronize()
+        result.update(fps=tr.num_transitions / (time.time() - tic))
+        return result
+
+    def drain_lp(self):
+        """The rollout still in flight when the run ends: waited for and dropped, like Trainer.final does for the Python actor's."""
+        if self.lp and self._lp_pending is not None:
+            self.ok(self.lib.a0_actor_collect(self.actor, self._qs, self._rs, self.T * self.E, C.addressof(self._nret), self.tr.actor_stream.cuda_stream), "a0_actor_collect")
+            self._lp_pending = None
+
     def detach_exchange(self):
         """The handle stops exchanging gradients (before the communicator's owner destroys it)."""
         if self.learner:
@@ -274,7 +343,8 @@ class NativeLoop:
         if getattr(self, "actor", None) is None and getattr(self, "rbuf", None) is None and getattr(self, "learner", None) is None:
             return
         torch.cuda.synchronize()
-        for h, fn in ((self.actor, self.lib.a0_actor_destroy), (self.rbuf, self.lib.a0_rbuf_destroy), (self.learner, self.lib.a0_learner_destroy)):
+        for h, fn in ((self.actor, self.lib.a0_actor_destroy), (self.rbuf, self.lib.a0_rbuf_destroy), (getattr(self, "stage", None), self.lib.a0_rbuf_destroy),
+                      (self.learner, self.lib.a0_learner_destroy)):
             if h is not None and h.value:
                 fn(h)
-        self.actor = self.rbuf = self.learner = None
+        self.actor = self.rbuf = self.learner = self.stage = None

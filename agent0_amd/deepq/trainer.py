@@ -446,7 +446,7 @@ class Trainer:
         ok_now = native_loop.hook_ok(self.learner.engine.grad_hook) and not any(native_loop._wrapped(o) for o in (self, self.replay, self.learner, self.actors[1]))
         if nl is None:
             why = native_loop.eligible(self)
-            if why is not None or not ok_now or getattr(self, "_prefetched", None) is not None or self.replay.written != 0 or self.actors[1].steps != 0:
+            if why is not None or not ok_now or getattr(self, "_prefetched", None) is not None or self.replay.written != 0 or self.actors[1].steps != 0 or getattr(self, "_pending", None) is not None:
                 self._nl = False
                 self.native_loop_reason = why or "hot-loop methods wrapped, a gradient hook, or a run already under way"
                 return None
@@ -472,11 +472,11 @@ class Trainer:
         arguments (the next epsilon depends on the frame count only), so every number is the one the unpipelined loop produces
         (tests/test_gpu_trainer.py::test_prefetched_rollouts_change_no_number), but the GPU does not idle while Python collects statistics, logs and builds the
         next launch.  A rollout issued ahead is consumed by the next call (whatever its ``prefetch``), or booked into the replay by ``final()``."""
-        if self.use_lp:
-            return self.run_iteration_lp()
         nl = self._native_loop()
         if nl is not None:
-            return nl.run_iteration(prefetch)
+            return nl.run_iteration_lp() if self.use_lp else nl.run_iteration(prefetch)
+        if self.use_lp:
+            return self.run_iteration_lp()
         tic = time.time()
         # Same work in the same stream order as ``step(*actor.sample(eps))`` — the update block's kernels are ordered behind the rollout's — but
         # the host does not stop between them: the rollout's statistics (episode returns, per-step max-Q: one small read-back) are collected
@@ -522,7 +522,7 @@ class Trainer:
             self.actors[1].sample_finish(self._pending)      # drain the rollout still in flight
             self._pending = None
         if getattr(self, "_nl", None):
-            self._nl.drain()
+            self._nl.drain_lp() if self.use_lp else self._nl.drain()
         if getattr(self, "_prefetched", None) is not None:   # a rollout issued ahead by run_iteration(prefetch=True) and never consumed: book it, so that replay and counters agree with the device
             pending, self._prefetched = self._prefetched, None
             transitions, returns, qmax = self.actors[1].sample_finish(pending)

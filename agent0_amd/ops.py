@@ -68,10 +68,11 @@ class NativeLearner:
     ALGOS = {"dqn": 0, "c51": 1, "iqn": 2, "fqf": 3, "qr": 4, "mdqn": 5}
 
     def __init__(self, lib, A, dueling, double_q, B, n_step=1, discount=0.99, lr=5e-4, adam_eps=0.0, target_update_freq=500, algo="dqn", num_atoms=51, vmin=-10.0,
-                 vmax=10.0, noisy=False, seed=0, K=32, N=64, N_dash=64, F=32, mdqn_tau=0.03, mdqn_lo=-1.0):
+                 vmax=10.0, noisy=False, seed=0, K=32, N=64, N_dash=64, F=32, mdqn_tau=0.03, mdqn_lo=-1.0, max_grad_norm=-1.0):
         self.lib, self.B, self.T = lib, B, int(num_atoms)
         desc = LearnerDesc(int(A), int(bool(dueling)), int(bool(double_q)), int(B), int(n_step), float(discount), float(lr), float(adam_eps), int(target_update_freq),
-                           self.ALGOS[algo], int(num_atoms), float(vmin), float(vmax), int(bool(noisy)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(K), int(N), int(N_dash), int(F), float(mdqn_tau), float(mdqn_lo))
+                           self.ALGOS[algo], int(num_atoms), float(vmin), float(vmax), int(bool(noisy)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(K), int(N), int(N_dash), int(F), float(mdqn_tau), float(mdqn_lo),
+                           float(max_grad_norm))
         h = C.c_void_p()
         check(lib.a0_learner_create(C.addressof(desc), C.addressof(h)), "a0_learner_create")
         self.h = h

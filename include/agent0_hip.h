@@ -327,6 +327,8 @@ typedef struct a0_learner_desc {
     int iqn_K, iqn_N, iqn_N_dash;     /* iqn: learner.iqn.K / N / N_dash (config.py:103-109); 64 cosines */
     int fqf_F;                        /* fqf: learner.iqn.F fractions (<= 32) */
     double mdqn_tau, mdqn_lo;         /* mdqn: learner.mdqn.tau / lo (config.py:88-92) */
+    double max_grad_norm;             /* (round 5) learner.max_grad_norm: > 0 clips the fqf fraction net's gradient to this L2 norm before its RMSprop step, the only
+                                       * place the reference clips (agent.py:143-147); <= 0 (and a zero-initialised trailing field): no clipping */
 } a0_learner_desc;
 int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
 /* BaseLearner.__init__ (agent.py:97-110) over HBM the CALLER already holds (each pointer may be NULL: the library allocates that buffer): what lets a host that keeps its own views of the
@@ -334,7 +336,8 @@ int a0_learner_create(const a0_learner_desc* desc, a0_learner** out);
  * online / target / adam_m / adam_v a0_learner_param_floats floats (known from a throw-away handle or deepq/layout.py), grads 4 more, state 8 ints, scalars 4,
  * loss_ring loss_ring_cap floats (the per-update batch-mean loss lands in slot state[6] % cap), wt_* a0_net_conv_wt_floats(4), eff_* the composed NoisyNet weights
  * [fc1 | head] and noise [online | target] the noise vectors (layout: a0_learner_desc above).  Borrowed buffers are used as they are: no initial noise is drawn into a
- * borrowed `noise` (a0_learner_set_rng tells the handle where the caller's stream stands). */
+ * borrowed `noise` (a0_learner_set_rng tells the handle where the caller's stream stands).  The library cannot measure a borrowed buffer: `grads` MUST hold
+ * a0_learner_param_floats + 4 floats (the NaN flag of a data-parallel update rides behind the parameters), every other size is exactly as listed, all 16-byte aligned. */
 typedef struct a0_learner_buffers {
     float *online, *target, *grads, *adam_m, *adam_v;
     int* state;
@@ -402,6 +405,10 @@ int a0_rbuf_buffers(a0_rbuf* replay, uint8_t** frames, int** act, float** rew, f
 int a0_rbuf_read(const a0_rbuf* replay, long long rows, uint8_t* frames_out, int* act_out, float* rew_out, float* done_out, float* tree_out, float* max_p_out, void* stream);
 /* ReplayDataset.extend for n transitions already written into the ring at the write cursor (a0_actor_rollout does that) */
 int a0_rbuf_commit(a0_rbuf* replay, long long n, void* stream);
+/* (round 5) ReplayDataset.extend for a rollout that an asynchronous actor wrote into ANOTHER ring (`stage`: an a0_rbuf of a few rollouts' rows; the launch schedule,
+ * launch.py:47-62): rows [start_row, start_row + n) of `stage` are copied to this ring's write cursor and committed like a0_rbuf_commit.  The caller orders the call
+ * behind the rollout's end. */
+int a0_rbuf_extend_from(a0_rbuf* replay, const a0_rbuf* stage, long long start_row, long long n, void* stream);
 /* one batch into the handle's persistent batch buffers (device pointers in *out, valid until the next sample) */
 int a0_rbuf_sample(a0_rbuf* replay, a0_batch* out, void* stream);
 /* uniform replay: the next n <= 32 batches — exactly the batches n consecutive a0_rbuf_sample calls would return (trainer.py:63-72: they do not depend on the updates
@@ -423,6 +430,12 @@ typedef struct a0_actor_desc {
 } a0_actor_desc;
 int a0_actor_create(const a0_actor_desc* desc, a0_actor** out);
 int a0_actor_destroy(a0_actor* actor);
+/* (round 5) every workspace a rollout with `learner` needs, allocated at set-up (a0_actor_rollout on an unbound actor binds it first — the one call after create that
+ * allocates); own_network != 0: the actor also gets its OWN copy of the network (parameters, weight copies, NoisyNet noise and composed weights), which
+ * a0_actor_snapshot refreshes from the learner — the launch schedule's actor.futures.sample(eps, state_dict) (launch.py:34-36,58-62).  Without it the actor acts with
+ * the learner's online network, NoisyNet buffers included, like the reference's train actor on the main schedule (trainer.py:41-44: the SAME module). */
+int a0_actor_bind(a0_actor* actor, const a0_learner* learner, int own_network);
+int a0_actor_snapshot(a0_actor* actor, const a0_learner* learner, void* stream);
 /* (the learner is not const: like the reference's single-process main, the actor acts with the learner's own network object — a NoisyNet actor redraws that
  * network's noise every reset_noise_freq steps from ITS Philox stream 4 and recomposes the effective weights, agent.py:52-53) */
 int a0_actor_rollout(a0_actor* actor, a0_learner* learner, a0_rbuf* replay, float epsilon, void* stream);

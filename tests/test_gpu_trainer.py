@@ -791,9 +791,18 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
                                         ("iqn", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
                                         ("fqf", {"env_id": "Asterix", "env_task": "block"}),
                                         ("fqf", {"env_id": "Asterix", "learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3, "replay.policy": "prioritize"}),
-                                        ("qr", {"learner.double_q": "true", "env_task": "block"}), ("mdqn", {"learner.n_step_q": 3, "replay.policy": "prioritize"})],
+                                        ("qr", {"learner.double_q": "true", "env_task": "block"}), ("mdqn", {"learner.n_step_q": 3, "replay.policy": "prioritize"}),
+                                        # round 5: NoisyNet on scalar and quantile heads; the fqf fraction net's gradient clipping (agent.py:143-147)
+                                        ("dqn", {"learner.noisy_net": "true", "learner.dueling_head": "true", "env_task": "block"}),
+                                        ("iqn", {"env_id": "Asterix", "learner.noisy_net": "true", "learner.double_q": "true", "learner.reset_noise_freq": 5}),
+                                        ("fqf", {"env_id": "Asterix", "learner.noisy_net": "true", "learner.dueling_head": "true", "learner.max_grad_norm": 0.05, "replay.policy": "prioritize"}),
+                                        # round 5: the launch schedule through the handles (the actor's own network snapshot, the stage ring, the second stream)
+                                        ("dqn", {"_launch": True}), ("c51", {**RAINBOW, "_launch": True, "env_task": "block"}),
+                                        ("c51", {**RAINBOW, "_launch": True, "learner.reset_noise_freq": 5}),
+                                        ("iqn", {"env_id": "Asterix", "learner.n_step_q": 3, "_launch": True}), ("qr", {"learner.double_q": "true", "replay.policy": "prioritize", "_launch": True})],
                          ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block", "iqn-block", "iqn-duel-double-n3-per", "fqf-block",
-                              "fqf-duel-double-n3-per", "qr-double-block", "mdqn-n3-per"])
+                              "fqf-duel-double-n3-per", "qr-double-block", "mdqn-n3-per", "dqn-noisy-duel-block", "iqn-noisy-double", "fqf-noisy-duel-clip-per",
+                              "launch-dqn", "launch-rainbow-lite-block", "launch-rainbow-lite-noise5", "launch-iqn-n3", "launch-qr-double-per"])
 def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
     """agent0_amd/deepq/native_loop.py: for the configurations the handles cover, ``Trainer.run_iteration`` hands the loop to a0_actor / a0_rbuf / a0_learner created
     OVER the Python classes' own buffers (a0_learner_create_on / a0_rbuf_create_on) — one C call per rollout, batch and update, eager launches from native code.
@@ -803,11 +812,14 @@ def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
     from agent0_amd.deepq.native_loop import NativeLoop
     from agent0_amd.deepq.trainer import Trainer
 
+    extra = dict(extra)
+    launch = bool(extra.pop("_launch", False))
+
     def run(native):
         monkeypatch.setenv("A0_NATIVE_LOOP", "1" if native else "0")
         cfg = make_cfg(algo, 8, **{"actor.sample_steps": 12, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 5, "trainer.training_start_steps": 100,
                                     "learner.target_update_freq": 7, "trainer.exploration_steps": 600, **extra})
-        tr = Trainer(cfg)
+        tr = Trainer(cfg, use_lp=launch)
         res = []
         for i in range(10):
             res.append({k: v for k, v in tr.run_iteration(prefetch=(i % 3 != 1)).items() if k != "fps"})
