@@ -306,9 +306,9 @@ class NativeLoop:
         tr.Rs.extend(rs)
         n_upd = self._block(st)
         blk = tr._block_stats_async(n_upd, self.fqf and n_upd > 0)
+        torch.cuda.current_stream().synchronize()        # the update block (and the statistics' copies behind it); the next rollout keeps running on the actor stream
         tr._block_stats_finish(blk)
         result = tr._result()
-        torch.cuda.synchronize()
         result.update(fps=tr.num_transitions / (time.time() - tic))
         return result
 
