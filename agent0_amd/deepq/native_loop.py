@@ -265,15 +265,22 @@ class NativeLoop:
         return result
 
     # ------------------------------------------------------------------ the launch schedule (Trainer.run_iteration_lp; launch.py:30-63)
-    def _issue_lp(self):
-        """``actor.futures.sample(eps, state_dict)``: the weight snapshot on the learner's stream — behind every update enqueued so far, ahead of the next — then the
-        rollout into the free half of the stage on the actor stream, without waiting."""
-        tr, lib, ok = self.tr, self.lib, self.ok
+    def _snapshot_lp(self):
+        """First half of ``actor.futures.sample(eps, state_dict)`` (launch.py:34-36,58-62): epsilon from the frame count as it is now, and the weight snapshot on the
+        learner's stream — behind every update enqueued so far, ahead of the next.  Returns (epsilon, event the rollout has to wait for)."""
+        tr = self.tr
         eps = tr.epsilon_fn(tr.frame_count)
         cur = torch.cuda.current_stream()
+        self.ok(self.lib.a0_actor_snapshot(self.actor, self.learner, cur.cuda_stream), "a0_actor_snapshot")
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        return eps, ev
+
+    def _rollout_lp(self, eps, ev):
+        """Second half: the rollout into the free half of the stage on the actor stream, behind the snapshot, without waiting.  Returns its first stage row."""
+        tr, lib, ok = self.tr, self.lib, self.ok
         ast = tr.actor_stream
-        ok(lib.a0_actor_snapshot(self.actor, self.learner, cur.cuda_stream), "a0_actor_snapshot")
-        ast.wait_stream(cur)
+        ast.wait_event(ev)
         start = int(lib.a0_rbuf_write_cursor(self.stage))
         ok(lib.a0_actor_rollout(self.actor, self.learner, self.stage, C.c_float(eps), ast.cuda_stream), "a0_actor_rollout")
         ok(lib.a0_rbuf_commit(self.stage, self.T * self.E, ast.cuda_stream), "a0_rbuf_commit (stage)")
@@ -281,17 +288,21 @@ class NativeLoop:
         return start
 
     def run_iteration_lp(self):
+        """One pass of launch.py:44-63: collect the finished rollout, issue the next one with the current weights, run the update block on the collected transitions
+        while that rollout is in flight.  The host enqueues the update block BEFORE the next rollout's 240 launches (the snapshot, which both depend on, first): the
+        learner stream — the critical path — never waits for the host to finish issuing the actor's work; stream order and dependencies are those of
+        Trainer.run_iteration_lp, so every number is too (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes[launch-*])."""
         tr, lib, ok = self.tr, self.lib, self.ok
         st = torch.cuda.current_stream().cuda_stream
         tic = time.time()
         if self._lp_pending is None:
-            self._lp_pending = self._issue_lp()          # launch.py:32-37 primes the pipeline before the loop
+            self._lp_pending = self._rollout_lp(*self._snapshot_lp())          # launch.py:32-37 primes the pipeline before the loop
         # wait for the rollout in flight and take its statistics (a0_actor_collect synchronises the ACTOR stream)
         ok(lib.a0_actor_collect(self.actor, self._qs, self._rs, self.T * self.E, C.addressof(self._nret), tr.actor_stream.cuda_stream), "a0_actor_collect")
         start = self._lp_pending
         qs, rs = np.ctypeslib.as_array(self._qs).tolist(), np.ctypeslib.as_array(self._rs)[: self._nret.value].tolist()
-        self._lp_pending = self._issue_lp()              # the next rollout, with the weights and the epsilon of NOW, before this one's update block
-        # Trainer.step: extend (the finished rollout's rows from the stage into the ring), then the update block beside the rollout in flight
+        eps, ev = self._snapshot_lp()                    # the next rollout acts with the weights and the epsilon of NOW
+        # Trainer.step: extend (the finished rollout's rows from the stage into the ring), then the update block
         n = self.T * self.E
         ok(lib.a0_rbuf_extend_from(self.rbuf, self.stage, start, n, st), "a0_rbuf_extend_from")
         rp = tr.replay
@@ -306,6 +317,7 @@ class NativeLoop:
         tr.Rs.extend(rs)
         n_upd = self._block(st)
         blk = tr._block_stats_async(n_upd, self.fqf and n_upd > 0)
+        self._lp_pending = self._rollout_lp(eps, ev)     # ... and runs beside the block
         torch.cuda.current_stream().synchronize()        # the update block (and the statistics' copies behind it); the next rollout keeps running on the actor stream
         tr._block_stats_finish(blk)
         result = tr._result()
