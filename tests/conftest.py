@@ -15,8 +15,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 os.environ.setdefault("A0_NATIVE_LOOP", "0")
 
 
+def _usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, further limited by a cgroup CPU quota (a GPU box reports the whole host in os.cpu_count() and grants
+    the container a share: torch's default of one intra-op thread per reported core oversubscribes that share and slows the CPU oracle several-fold)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    import torch
+
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), _usable_cores())))
 
 
 def pytest_collection_modifyitems(config, items):

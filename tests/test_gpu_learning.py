@@ -25,8 +25,8 @@ pytestmark = pytest.mark.gpu
 CHASE_OPTIMUM = 0.25 * (1.0 - 0.01 * 0.75)          # one reward per 4.0 steps (the mean spawn distance); min_eps = 0.01 of the moves are random, a quarter of them right anyway
 # the launch schedule runs the quantile networks with 16 fractions instead of 64 / 32 (a quarter of the update's rows): same code paths, a third of the wall-clock
 SMALL_Q = {"learner.iqn.K": 16, "learner.iqn.N": 16, "learner.iqn.N_dash": 16, "learner.iqn.F": 16}
-FAMILIES = [("dqn", "dqn", {}, 4_200_000, "Breakout"), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, "Breakout"), ("iqn", "iqn", {}, 4_200_000, "Asterix"),
-            ("fqf", "fqf", {}, 4_200_000, "Asterix")]
+FAMILIES = [("dqn", "dqn", {}, 4_200_000, "Breakout"), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, "Breakout"), ("iqn", "iqn", {}, 3_800_000, "Asterix"),
+            ("fqf", "fqf", {}, 3_800_000, "Asterix")]
 
 
 def check_chase(r):
