@@ -34,7 +34,7 @@ class DeviceSynthVecEnv:
 
     H = W = 84
     # A0_ENV_TASK_* (include/agent0_hip.h): action-independent reward stream / the learnable block-quadrant task (a contextual bandit) / the chase task (temporal credit:
-    # the action moves the block, +1 on arrival at the target cell; served by the unmerged env step, the action being known when the kernel starts)
+    # the action moves the block, +1 on arrival at the target cell)
     TASKS = {"stream": 0, "block": 1, "chase": 2}
 
     def __init__(self, env_id: str, num_envs: int, seed: int = 42, rank: int = 0, ops=None, task: str = "stream"):

@@ -251,8 +251,13 @@ __global__ __launch_bounds__(512) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
     asm volatile("" : "+v"(e_v));
     const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
     const bool term = (x.y % 500u) == 0u;
+    // A0_ENV_TASK_CHASE: the frame waves wait at a workgroup barrier for wave 0's action and read the block's new cell from LDS (a0_actor_qhead_env_kernel, net.hip)
+    __shared__ int s_chase_cell;
+    const bool chase = P.task == A0_ENV_TASK_CHASE;
     if (wave != 0) {
-        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448);
+        int cell = -1;
+        if (chase) { __syncthreads(); cell = s_chase_cell; }
+        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448, cell);
         return;
     }
     // everything the env's scalar work will need from memory is requested now, ahead of the slab loads: the control words, epsilon, the env's running
@@ -367,9 +372,12 @@ __global__ __launch_bounds__(512) void a0_actor_dist_tail_env_kernel(a0_dtenv_ar
             const float u = (float)(a0_philox_word(seed_v, su_v, off_u + (unsigned long long)e) >> 8) * 0x1.0p-24f;
             const int act = (u > eps) ? besta : ra;
             action_v[e] = act; qmax_v[e] = best;
+            float r_chase = 0.f;
+            if (chase) s_chase_cell = a0_chase_step(a0_chase_cell(P.obs_in + ((size_t)e * 4 + 3) * A0_ENV_PIX, e), act, x.w, r_chase);
             a0_env_commit_finish(Z, x, e, g, task_v, A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
-                                 O.r_done, slot);
+                                 O.r_done, slot, r_chase);
         }
+        if (chase) __syncthreads();
     }
 }
 
@@ -383,7 +391,7 @@ extern "C" int a0_actor_dist_tail_env_step(const float* slabs, long long slab_st
         (mode != 1 && mode != 2) || (mode == 2 && !atoms))
         return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad argument");
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
-        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || task < A0_ENV_TASK_STREAM || task > A0_ENV_TASK_CHASE || (task == A0_ENV_TASK_CHASE && A < 4))
         return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: bad env argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step: buffers must be 16-byte aligned");
     const bool vec4 = !(ld & 3) && !(slab_stride & 3) && !((((uintptr_t)slabs) | ((uintptr_t)bias)) & 15);
@@ -422,7 +430,7 @@ extern "C" int a0_actor_quantile_tail_env_step(const float* slabs, long long sla
         (mode != 1 && mode != 3) || (mode == 3 && !taus))
         return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: bad argument");
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
-        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || task < A0_ENV_TASK_STREAM || task > A0_ENV_TASK_CHASE || (task == A0_ENV_TASK_CHASE && A < 4))
         return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: bad env argument");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step: buffers must be 16-byte aligned");
     const size_t lds = (size_t)(A * T + T) * sizeof(float);

@@ -671,8 +671,14 @@ __global__ __launch_bounds__(512) void a0_actor_qhead_env_kernel(a0_qenv_args P)
     asm volatile("" : "+v"(e_v));
     const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
     const bool term = (x.y % 500u) == 0u;
+    // A0_ENV_TASK_CHASE: the action moves the block, so the new frame needs it — the frame waves wait at a workgroup barrier for wave 0's tail and read the block's new
+    // cell from LDS (the other tasks keep the barrier-free overlap: their frames do not depend on the action)
+    __shared__ int s_chase_cell;
+    const bool chase = P.task == A0_ENV_TASK_CHASE;
     if (wave != 0) {
-        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448);
+        int cell = -1;
+        if (chase) { __syncthreads(); cell = s_chase_cell; }
+        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448, cell);
         return;
     }
     {
@@ -694,9 +700,12 @@ __global__ __launch_bounds__(512) void a0_actor_qhead_env_kernel(a0_qenv_args P)
         a0_qhead_wave(P.slabs, P.slab_stride, P.nslab, P.b1, w2s, P.b2, P.A, P.dueling, (int)e, lane, raw, P.rng_seed, P.stream_a, P.stream_u, off_a, off_u, eps, act, best);
         if (lane == 0) {
             action_v[e] = act; qmax_v[e] = best;
+            float r_chase = 0.f;
+            if (chase) s_chase_cell = a0_chase_step(a0_chase_cell(P.obs_in + ((size_t)e * 4 + 3) * A0_ENV_PIX, e), act, x.w, r_chase);
             a0_env_commit_finish(Z, x, e, g, task_v, P.A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
-                                 O.r_done, slot);
+                                 O.r_done, slot, r_chase);
         }
+        if (chase) __syncthreads();
     }
 }
 
@@ -735,8 +744,8 @@ extern "C" int a0_actor_qhead_env_step(const float* feat, int E, int K, const fl
     if (!feat || !W1 || !b1 || !W2 || !b2 || !scratch || !action || !qmax || E < 1 || K < 4 || (K & 3) || A < 1 || A + (dueling ? 1 : 0) > 24)
         return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad argument (A + dueling <= 24: the head rows are staged in 48 KB of LDS)");
     if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
-        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || (task != A0_ENV_TASK_STREAM && task != A0_ENV_TASK_BLOCK))
-        return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad env argument");
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || task < A0_ENV_TASK_STREAM || task > A0_ENV_TASK_CHASE || (task == A0_ENV_TASK_CHASE && A < 4))
+        return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: bad env argument (the chase task needs at least four actions)");
     if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step: buffers must be 16-byte aligned");
     a0_hip_backend bk{(hipStream_t)stream};
     const int splits = a0_fc1_splits(E, 512, K);

@@ -351,7 +351,7 @@ extern "C" int a0_actor_snapshot(a0_actor* a, const a0_learner* L, void* stream)
 extern "C" int a0_actor_create(const a0_actor_desc* d, a0_actor** out) {
     A0_TRY
     if (!d || !out) return a0_fail(A0_EINVAL, "a0_actor_create: null argument");
-    if (d->E < 1 || d->T < 1 || d->A < 1 || d->n_step < 1 || d->reset_noise_freq < 0 || !(d->discount > 0.0) || (d->env_task != A0_ENV_TASK_STREAM && d->env_task != A0_ENV_TASK_BLOCK))
+    if (d->E < 1 || d->T < 1 || d->A < 1 || d->n_step < 1 || d->reset_noise_freq < 0 || !(d->discount > 0.0) || d->env_task < A0_ENV_TASK_STREAM || d->env_task > A0_ENV_TASK_CHASE || (d->env_task == A0_ENV_TASK_CHASE && d->A < 4))
         return a0_fail(A0_EINVAL, "a0_actor_create: bad description");
     a0_actor* a = new a0_actor();
     try {
@@ -371,7 +371,7 @@ extern "C" int a0_actor_create(const a0_actor_desc* d, a0_actor** out) {
         a->ring_act = a->mem.alloc<int>((long long)a->n * E); a->ring_rew = a->mem.alloc<float>((long long)a->n * E); a->ring_done = a->mem.alloc<float>((long long)a->n * E);
         a->act3 = a->mem.alloc<float>(E * a->feat); a->scratch = a->mem.alloc<float>(a0_actor_qhead_scratch(a->E, a->feat));
         a->h_mask.resize((size_t)(T * E)); a->h_ret.resize((size_t)(T * E));
-        if (a0_env_synth_reset(d->seed, d->rank, a->E, a->obs[0], a->ep_ret, nullptr) != A0_OK) { delete a; return A0_EINVAL; }      // Actor.__init__: self.obs = envs.reset()
+        if (a0_env_synth_reset_task(d->seed, d->rank, a->E, a->obs[0], a->ep_ret, d->env_task, nullptr) != A0_OK) { delete a; return A0_EINVAL; }      // Actor.__init__: self.obs = envs.reset()
         A0_HIP_THROW(hipDeviceSynchronize());
     } catch (...) { delete a; throw; }
     *out = a;

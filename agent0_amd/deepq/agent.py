@@ -65,9 +65,7 @@ class Actor:
         self.dist_tail = (not self.fused_tail) and self.L.algo in ("c51", "qr") and 4 * (self.L.A * self.L.T + self.L.T) * 4 <= 160 * 1024
         self._head_slabs = ops.empty(ops.dense_fwd_partial_slabs(E, self.L.Npad, 512) * E * self.L.Npad) if self.dist_tail else None
         # quantile heads (iqn, fqf) on the device env: head GEMM slabs -> one kernel for the tail AND the env step (a0_actor_quantile_tail_env_step)
-        # (the chase task's frame depends on the action just chosen: its env step runs as a launch of its own behind the tail, include/agent0_hip.h A0_ENV_TASK_CHASE)
-        chase = getattr(self.envs, "task", 0) == 2
-        self.quant_tail = (self.L.algo in ("iqn", "fqf") and hasattr(self.envs, "act_step_commit") and self.obs_bytes == 4 * 84 * 84 and not chase
+        self.quant_tail = (self.L.algo in ("iqn", "fqf") and hasattr(self.envs, "act_step_commit") and self.obs_bytes == 4 * 84 * 84
                            and ops.dense_fwd_scratch(E * n_tau, self.L.feat, self.L.num_cosines) == 0 and os.environ.get("A0_QUANT_TAIL", "1") != "0")     # 0: tuning aid (same bytes)
         if self.quant_tail:
             self._head_slabs = ops.empty(ops.dense_fwd_partial_slabs(E * n_tau, self.L.Npad, 512) * E * n_tau * self.L.Npad)
@@ -95,7 +93,7 @@ class Actor:
         self._stage = None
         self.fused_commit = hasattr(self.envs, "step_commit") and (self.obs_bytes == 4 * 84 * 84)
         # scalar heads on the synthetic env: the tail and the env step share one launch (a0_actor_qhead_env_step)
-        self.tail_env = (self.fused_tail or self.dist_tail) and self.fused_commit and hasattr(self.envs, "act_step_commit") and not chase and os.environ.get("A0_TAIL_ENV", "1") != "0"      # 0: tuning aid (same bytes)
+        self.tail_env = (self.fused_tail or self.dist_tail) and self.fused_commit and hasattr(self.envs, "act_step_commit") and os.environ.get("A0_TAIL_ENV", "1") != "0"      # 0: tuning aid (same bytes)
         # a host env split into groups (env_pool.HostEnvGroups): per-group workspaces and n-step state; the CPU steps one group while the GPU infers the other
         self.groups = None
         if hasattr(self.envs, "pools"):

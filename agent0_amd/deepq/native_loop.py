@@ -87,8 +87,6 @@ def eligible(tr) -> Optional[str]:
         return f"no handle for {algo}"
     if tuple(cfg.obs_shape) != (4, 84, 84):
         return "observations other than 4 x 84 x 84"
-    if cfg.env_task not in ("stream", "block"):
-        return "the chase task's env step is a launch of its own (the handles issue the merged tail + env-step kernels)"
     actor = tr.actors[1]
     if not isinstance(actor.envs, DeviceSynthVecEnv) or actor.groups is not None:
         return "host environments"
@@ -155,7 +153,7 @@ class NativeLoop:
            "a0_rbuf_create_on")
         # ---- actor (its own env state: the Python Actor's stays where the constructor left it)
         ad = _ActorDesc(self.E, self.T, int(cfg.action_dim), int(bool(lc.dueling_head)), int(lc.n_step_q), float(lc.discount), int(cfg.seed), int(tr.rank),
-                        {"stream": 0, "block": 1}[cfg.env_task], int(lc.reset_noise_freq))
+                        {"stream": 0, "block": 1, "chase": 2}[cfg.env_task], int(lc.reset_noise_freq))
         self.actor = C.c_void_p()
         ok(lib.a0_actor_create(C.addressof(ad), C.addressof(self.actor)), "a0_actor_create")
         # every workspace now, so that no call of the loop allocates; on the launch schedule the actor gets its OWN copy of the network (launch.py:34-36,58-62) and rolls

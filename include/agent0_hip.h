@@ -585,8 +585,9 @@ int a0_rng_normal_ctrl(unsigned long long seed, unsigned int stream_id, unsigned
 #define A0_ENV_TASK_STREAM 0
 #define A0_ENV_TASK_BLOCK 1
 /* (round 5) A0_ENV_TASK_CHASE = a task with TEMPORAL credit: the action MOVES the block on a 4 x 4 lattice (a % 4: up, down, left, right), +1 only on arrival at the
- * bottom-right cell, then a respawn three to six moves away; the env reads its state back from the newest frame of the observation (csrc/synth_env.h).  Served by
- * a0_env_synth_step / a0_env_synth_step_commit (the action is known when they start); the kernels that merge the actor's tail with the env step refuse it. */
+ * bottom-right cell, then a respawn three to six moves away; the env reads its state back from the newest frame of the observation (csrc/synth_env.h).  In the kernels
+ * that merge the actor's tail with the env step the frame waves wait at a workgroup barrier for the action under this task (the other tasks' frames do not depend on
+ * it and keep the barrier-free overlap). */
 #define A0_ENV_TASK_CHASE 2
 int a0_env_synth_reset(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, void* stream);
 int a0_env_synth_reset_task(unsigned long long seed, unsigned int rank, int E, uint8_t* obs, float* ep_ret, int task, void* stream);      /* (round 5) a0_env_synth_reset for `task`: the chase task's first frame shows the block at the env's start cell */

@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     a0_actor_desc ad = {E, T, A, rainbow, rainbow ? 3 : 1, 0.99, 42, 0, task, 4};
     a0_learner* L = NULL; a0_rbuf* R = NULL; a0_actor* ac = NULL;
     CHECK(a0_learner_create(&ld, &L)); CHECK(a0_rbuf_create(&rd, &R)); CHECK(a0_actor_create(&ad, &ac));
+    CHECK(a0_actor_bind(ac, L, 0));      /* the rollout's workspaces now: nothing below allocates or synchronises the device */
     long long comm = 0;
     if (exchange) {
         /* one process per GPU; rank 0 creates the 128-byte id and hands it to the other ranks over whatever transport the job has (MPI, a file, a socket), every rank

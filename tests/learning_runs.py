@@ -135,10 +135,12 @@ def main(out_path=None, only=None):
     if not only or "sabotage" in only:
         for sab in ("discount_zero", "nstep_shift", "stale_next_state", "no_target_sync", "eps_one", "lr_zero"):
             keep(run("dqn", {}, 4_200_000, sabotage=sab, task="chase"), f"dqn_{sab}")
-    if not only or "block" in only:
+    if not only or "native" in only:
         os.environ["A0_NATIVE_LOOP"] = "1"
+        keep(run("dqn", {}, 4_200_000, task="chase"), "dqn_native_loop")
+        keep(run("c51", RAINBOW, 2_600_000, task="chase"), "c51_rainbow_lite_native_loop")
+        keep(run("dqn", {}, 4_200_000, True, task="chase"), "dqn_native_loop_launch")
         keep(run("dqn", {}, 2_600_000), "block_task_dqn_native_loop")
-        keep(run("c51", RAINBOW, 2_600_000), "block_task_c51_rainbow_lite_native_loop")
     if out_path:
         with open(out_path, "w") as f:
             json.dump({"task": "env_task=chase (oracle/synth_env.c): the action moves the block on a 4 x 4 lattice, +1 on arrival at the target cell, respawn three to six moves "

@@ -11,8 +11,7 @@ they compose to.  Two learnable tasks of the synthetic env (oracle/synth_env.c, 
     schedule, with uniform, flat-priority and sum-tree replay; and runs with ONE link of the credit path cut must NOT: gamma = 0, the n-step window mis-indexed by
     one step, the bootstrap taken from s instead of s', a target network that is never refreshed — none of which the bandit task below can see — plus an actor
     that never exploits and an optimizer that does not move.
-  * ``env_task=block`` (round 4; a contextual bandit: +1 for naming the block's quadrant): kept for the library-handle host loop, whose merged tail + env-step
-    kernels serve it (the chase task's frame depends on the action, so its env step is a launch of its own and runs under the Python classes).
+  * ``env_task=block`` (round 4; a contextual bandit: +1 for naming the block's quadrant): kept as a second, independent task (one run).
 
 Curves: profiles/r05_learning.json (``python tests/learning_runs.py``).
 """
@@ -82,11 +81,22 @@ def test_runs_with_a_cut_credit_path_do_not_pass(sabotage):
     assert r["final_reward_per_step"] < 0.3 * CHASE_OPTIMUM
 
 
-@pytest.mark.parametrize("name,algo,extra,env_id", [("dqn", "dqn", {}, "Breakout"), ("c51_rainbow_lite", "c51", LR.RAINBOW, "Breakout")])
-def test_the_native_loop_learns_the_block_task(name, algo, extra, env_id, monkeypatch):
-    """The bandit task with the loop issued by the library's own handles (agent0_amd/deepq/native_loop.py: the production default for these configurations)."""
+@pytest.mark.parametrize("name,algo,extra,frames,launch", [("dqn", "dqn", {}, 4_200_000, False), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, False), ("dqn", "dqn", {}, 4_200_000, True)],
+                         ids=["dqn-main", "rainbow-lite-main", "dqn-launch"])
+def test_the_native_loop_learns_the_chase_task(name, algo, extra, frames, launch, monkeypatch):
+    """The same criterion with the loop issued by the library's own handles (agent0_amd/deepq/native_loop.py: the production default for these configurations) — under
+    the chase task the merged tail + env-step kernels hold their frame waves at a workgroup barrier until wave 0 has chosen the action."""
     monkeypatch.setenv("A0_NATIVE_LOOP", "1")
-    r = LR.run(algo, extra, 2_600_000, env_id=env_id)
+    r = LR.run(algo, extra, frames, launch, task="chase")
     r["name"] = name
+    assert r["host_loop"] == "native handles"
+    check_chase(r)
+
+
+def test_the_native_loop_learns_the_block_task(monkeypatch):
+    """The bandit task of round 4 (+1 for naming the block's quadrant) stays as a second, independent learnable task."""
+    monkeypatch.setenv("A0_NATIVE_LOOP", "1")
+    r = LR.run("dqn", {}, 2_600_000)
+    r["name"] = "dqn"
     assert r["host_loop"] == "native handles"
     check_block(r)

@@ -29,7 +29,8 @@ ROLLOUT_SPECS = dict(recipe.SPECS, fqf4=recipe.NetSpec("fqf", 4))
                                                   (1, "iqn_duel", "stream"), (3, "iqn_duel", "stream"), (3, "fqf4", "stream"),
                                                   (3, "dqn", "block"), (1, "dqn_duel", "block"), (3, "c51", "block"), (1, "iqn_duel", "block"), (3, "fqf4", "block"),
                                                   (3, "dqn", "block-unmerged"),
-                                                  (1, "dqn", "chase"), (3, "dqn_duel", "chase"), (3, "c51", "chase"), (1, "iqn_duel", "chase"), (3, "fqf4", "chase")])
+                                                  (1, "dqn", "chase"), (3, "dqn_duel", "chase"), (3, "c51", "chase"), (1, "iqn_duel", "chase"), (3, "fqf4", "chase"),
+                                                  (3, "dqn", "chase-unmerged")])
 def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the distributional tail, iqn / fqf the quantile tail (head GEMM slabs ->
     bias, dueling per quantile, mean / fraction-weighted sum, argmax, epsilon-greedy), each in one launch with the env step
@@ -44,9 +45,9 @@ def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
 
     E, T = 4, 12
     spec = ROLLOUT_SPECS[spec_name]
-    if task == "block-unmerged":
+    if task.endswith("-unmerged"):
         monkeypatch.setenv("A0_TAIL_ENV", "0")
-        task = "block"
+        task = task[: -len("-unmerged")]
     cfg = make_cfg(spec.algo, E, **{"env_task": task, "learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8,
                                      "learner.dueling_head": str(bool(spec.dueling)).lower(), **({"learner.qr.num_atoms": spec.num_atoms} if spec.algo == "qr" else {})})
     model = DeepQNet(cfg)
@@ -54,8 +55,7 @@ def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     replay = ReplayDataset(cfg, ops=model.ops)
     actor = Actor(cfg, model, replay=replay, rank=0)
-    # (the chase task — the action moves the block, so the new frame needs it — runs its env step as a launch of its own behind the tail)
-    assert actor.fused_tail == (spec.algo == "dqn") and actor.quant_tail == (spec.algo in ("iqn", "fqf") and task != "chase") and actor.tail_env == (task != "chase" and os.environ.get("A0_TAIL_ENV") != "0" and spec.algo in ("dqn", "c51", "qr"))
+    assert actor.fused_tail == (spec.algo == "dqn") and actor.quant_tail == (spec.algo in ("iqn", "fqf")) and actor.tail_env == (os.environ.get("A0_TAIL_ENV") != "0" and spec.algo in ("dqn", "c51", "qr"))
     # oracle twin: same env definition, same Philox draws (stream ids / offsets as DeviceRng assigns them)
     seed64 = (cfg.seed & 0xFFFFFFFF)
     step_no = [0]
