@@ -386,6 +386,13 @@ def main():
         other = {"entry": "agent0.deepq." + ("main" if args.entry == "launch" else "launch"), "value": round(per_iter / d2, 1), "unit": "env-frames/sec",
                  "ms_per_step": round(1e3 * d2, 3), "steps": args.steps}
         del tr2
+    # the CPU baseline is a property of the box, not of the rank count: rank 0 times it at every N, while the other ranks wait in the barrier below (so that every rank
+    # leaves the process group together)
+    cpu_base = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(args, cfg)
+        if world > 1:
+            cpu_base["note"] = f"timed on rank 0's share of the host cores while the other {world - 1} ranks wait in a barrier; compare with the N = 1 line's"
     if dp:
         barrier()
     exchange = None
@@ -471,11 +478,7 @@ def main():
                 "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off",
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
     out["roofline"] = roof
-    # the CPU baseline is a property of the box, not of the rank count: rank 0 times it at every N (the other ranks have left their last collective by now and
-    # only wait in destroy_process_group)
-    out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args, cfg)
-    if out["cpu_baseline"] is not None and world > 1:
-        out["cpu_baseline"]["note"] = f"timed on rank 0's share of the host cores while the other {world - 1} ranks idle; compare with the N = 1 line's"
+    out["cpu_baseline"] = cpu_base
     print(json.dumps(out))
     if dp:
         import torch.distributed as dist

@@ -50,9 +50,10 @@ traffic = {
                "a0_env_step_commit_kernel as the calibration kernel",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
               "--no-ratio320 --no-other-entry --replay-size 100000 (tools/refresh_profiles.sh)",
-    "corrections": "counter unit KB; FETCH_SIZE x2 on gfx950 (64 B counted per 128-B request on wide coalesced reads), WRITE_SIZE x1.  Calibration on "
-                   f"a0_env_step_commit_kernel, which reads 256 x 28 224 B = {E256 * OBS / 1e6:.2f} MB and writes 256 x (28 224 + 56 448) B = {E256 * 3 * OBS / 1e6:.2f} MB per launch: "
-                   + (f"FETCH_SIZE x2 = {2 * cal_r / 1e6:.2f} MB, WRITE_SIZE = {cal_w / 1e6:.2f} MB" if cal_r and cal_w else "not captured in this run"),
+    "corrections": "counter unit KB; FETCH_SIZE x2 on gfx950 (64 B counted per 128-B request on wide coalesced reads), WRITE_SIZE x1.  Calibrated IN THIS RUN on the kernels of "
+                   "known traffic listed under `calibration` (" + "; ".join(f"{k}: read x{v['read_correction_implied']}, write x{v['write_correction_implied']}" for k, v in calib.items()) + ")"
+                   + (f"; and on a0_env_step_commit_kernel ({E256 * OBS / 1e6:.2f} MB in, {E256 * 3 * OBS / 1e6:.2f} MB out per launch): FETCH_SIZE x2 = {2 * cal_r / 1e6:.2f} MB, WRITE_SIZE = {cal_w / 1e6:.2f} MB"
+                      if cal_r and cal_w else " (a0_env_step_commit_kernel, rounds 1-3's calibration kernel, no longer runs in the bench: the actor's tail performs the env step)"),
     "calibration": calib,
     "per_launch": {},
 }
@@ -93,11 +94,11 @@ for f, name in names.items():
 json.dump(other, open(os.path.join(DST, f"{tag}_other_configs.json"), "w"), indent=1)
 
 # ---- BASELINE configs[2..4] with their own kernel tables and roofline (tools/prof_configs.sh)
-cfg_lines = [f"# BASELINE configs[2..4] at full size ({tag}, MI355X gfx950, 1 GPU): bench line with the roofline of that configuration's dominant kernel + rocprofv3 kernel statistics", "",
+cfg_lines = [f"# BASELINE configs[2..4] (+ qr, mdqn) at full size ({tag}, MI355X gfx950, 1 GPU): bench line with the roofline of that configuration's dominant kernel + rocprofv3 kernel statistics", "",
              "`R=" + tag + " bash tools/prof_configs.sh`: per configuration `python3 bench.py --no-cpu-baseline --no-ratio320 --no-other-entry --steps 4 --warmup 2 --algo ...` once plain (the JSON line) "
              "and once under `rocprofv3 --kernel-trace --stats` (the table; it covers the untimed replay fill, warm-up, the timed and the probe iterations).", ""]
 for short, title in (("c51", "configs[2] Breakout c51 double-Q + dueling + NoisyNet, n_step = 3, prioritized sum-tree replay"), ("iqn", "configs[3] Asterix iqn (iqr)"),
-                     ("fqf", "configs[4] Asterix fqf, one rank")):
+                     ("fqf", "configs[4] Asterix fqf, one rank"), ("qr", "Breakout qr (quantile regression, 200 quantiles: named in north_star)"), ("mdqn", "Breakout mdqn (Munchausen dqn)")):
     bj, ks = os.path.join(SRC, f"{short}_bench.json"), os.path.join(SRC, f"{short}_kernel_stats.csv")
     if not (os.path.exists(bj) and os.path.exists(ks)):
         continue
@@ -128,7 +129,8 @@ for src, dst in (("bench_dpforce.json", f"{tag}_bench_dqn_dp_rehearsal.json"), (
         except Exception as e:      # noqa: BLE001
             print("skipped", src, e)
 
-for src, dst in (("suite8.json", f"{tag}_fqf_suite8.json"), ("pmc_encoder.txt", f"{tag}_pmc_encoder.txt")):
+for src, dst in (("suite8.json", f"{tag}_fqf_suite8.json"), ("pmc_encoder.txt", f"{tag}_pmc_encoder.txt"), ("qr_quantile_huber_ubench.json", f"{tag}_qr_quantile_huber_ubench.json"),
+                 ("c_host_loop.json", f"{tag}_c_host_loop.json"), ("learning.json", f"{tag}_learning.json")):
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_learning.json")):
@@ -188,4 +190,16 @@ lines += ["## Bench lines of this build", "",
           f"* `agent0.deepq.launch` schedule (rollout with a weight snapshot on a second stream while the update block runs): {oe.get('value')} env-frames/s in the same run ({oe.get('ms_per_step')} ms per "
           f"iteration); standalone `--entry launch` run: {launch['value']:.0f}.", ""]
 open(os.path.join(DST, f"{tag}_bench_dqn_rocprof_summary.md"), "w").write("\n".join(lines))
+# ---- the per-kernel floor tables (tools/budget.py) of the headline configuration and of configs[2], qr, mdqn
+import subprocess
+parts = ["# Per-kernel floor table (" + tag + ")\n", open(os.path.join(ROOT, "tools", "budget.py")).read().split('"""')[1].split("Bounds")[0].strip().splitlines()[0] + "\n",
+         "Bounds: MFMA issue (v_mfma_f32_16x16x32_bf16 every 16 cycles, v_mfma_f32_32x32x16_bf16 every 32 cycles per SIMD = 2.5 PFLOP/s; an exact fp32 product costs 9 bf16 products, 3 where "
+         "one operand is bytes), achievable HBM 6.3 TB/s, one vector wave-instruction per 2 cycles per SIMD, and a launch floor of 2.5 us (ramp-up, first loads, drain); the floor of a kernel is the "
+         "larger of its pipe bound and the launch floor.  `gap ms / iteration` = launches x (measured - floor).  Measured = rocprofv3 kernel statistics of the bench command.\n"]
+for cfgname, stats, bj in (("dqn", "kernel_stats.csv", "bench.json"), ("c51", "c51_kernel_stats.csv", "c51_bench.json"), ("qr", "qr_kernel_stats.csv", "qr_bench.json"),
+                           ("mdqn", "mdqn_kernel_stats.csv", "mdqn_bench.json")):
+    if os.path.exists(os.path.join(SRC, stats)):
+        ms = last_json(os.path.join(SRC, bj))["ms_per_step"] if os.path.exists(os.path.join(SRC, bj)) else ""
+        parts.append(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "budget.py"), os.path.join(SRC, stats), cfgname, str(ms)], capture_output=True, text=True).stdout)
+open(os.path.join(DST, f"{tag}_budget.md"), "w").write("\n".join(parts))
 print("profiles/ refreshed from", SRC)

@@ -1,6 +1,6 @@
 # rocprofv3 kernel statistics of BASELINE configs[2..4] at full size (c51 rainbow-lite, Asterix iqn, Asterix fqf): one bench line each (with the roofline of
 # that configuration's dominant kernel) and the per-kernel table of the same command.  Output: gpurun_out/<round>/{c51,iqn,fqf}_{bench.json,kernel_stats.csv}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; R=${R:-r03}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; R=${R:-r05}
 mkdir -p gpurun_out/$R
 run() {   # name, bench arguments...
   name=$1; shift
@@ -13,4 +13,6 @@ print('$name', d['value'], d['ms_per_step'], d['updates_per_sec'], r['kernel'][:
 }
 run c51 --algo c51 learner.double_q=true learner.dueling_head=true learner.noisy_net=true learner.n_step_q=3 replay.policy=prioritize &&
 run iqn --algo iqn --env Asterix &&
-run fqf --algo fqf --env Asterix
+run fqf --algo fqf --env Asterix &&
+run qr --algo qr &&
+run mdqn --algo mdqn
