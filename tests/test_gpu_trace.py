@@ -15,7 +15,7 @@ corresponding step and compares —
 — and then copies the oracle's floating-point state (parameters, Adam moments, priorities) over the device's, so that ulp-level drift
 cannot move a later comparison: an index that differs, a β off by one extend, a priority written to the wrong leaf or a rollout acting
 with the wrong weights shows up at the link where it happens.  Ring size 200 with 80 transitions per rollout: the ring wraps in the
-third rollout and again in the fifth; training starts in the second iteration; the target syncs every 4 updates; a walk is five iterations (WALK).
+third rollout and again in the fifth; training starts in the second iteration; the target syncs every 4 updates; a walk is seven iterations (WALK).
 """
 import numpy as np
 import pytest
@@ -33,8 +33,8 @@ import collections
 
 Dims = collections.namedtuple("Dims", "E T B size lsteps start tfreq")
 # iterations of a lock-step walk: with 80 transitions per rollout the 200-slot ring wraps in the third and in the fifth; training starts in the second iteration
-# (12 updates, three target syncs).  Round 5: five instead of seven — the sixth and seventh added no new event — because the suite has a time budget
-WALK = 5
+# (18 updates, four target syncs)
+WALK = 7
 SMALL = Dims(8, 10, 32, 200, 3, 100, 4)
 # BASELINE configs[0]'s actor / learner sizes (reference config.py:108-120 defaults: 16 envs x 80 steps per rollout, batch 512) on a ring that
 # wraps in the fourth rollout (the 100 k default would make every whole-ring comparison a 5.6 GB copy); two updates per block
@@ -525,7 +525,7 @@ def _noise_list(L, buf):
                          ids=["dqn-configs1", "dqn-double-n3-sumtree", "rainbow-lite-configs2"])
 def test_library_handle_loop_matches_the_oracle_link_by_link(algo, policy, sumtree, n_step, double_q, spec_name, monkeypatch):
     """the path bench.py times — the native host loop's C calls — held to the oracle DIRECTLY instead of through its bit-identity with the
-    Python classes: five iterations over a 200-slot ring (wraps twice), 12 updates, target sync every 4, for BASELINE configs[1] (dqn, uniform replay), dqn with
+    Python classes: seven iterations over a 200-slot ring (wraps twice), 18 updates, target sync every 4, for BASELINE configs[1] (dqn, uniform replay), dqn with
     double-Q / 3-step returns / prioritized sum-tree replay and BASELINE configs[2] (rainbow-lite).  Same comparisons and tolerances as
     test_trainer_loop_matches_the_oracle_link_by_link (reference trainer.py:74-119,171-184)."""
     monkeypatch.setenv("A0_NATIVE_LOOP", "1")
