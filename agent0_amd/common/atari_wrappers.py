@@ -104,14 +104,19 @@ class DeviceSynthVecEnv:
         self._cur = nxt
         return self._obs[nxt]
 
-    def act_step_commit(self, tail_args, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, replay, start_slot, kind: str = "qhead"):
+    def act_step_commit(self, tail_args, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, replay, start_slot, kind: str = "qhead", enc=None):
         """``step_commit`` with the actor's tail in the same launch: ``tail_args`` are the arguments of ``ops.actor_qhead`` (``kind="qhead"``: scalar heads,
         a0_actor_qhead_env_step), of ``ops.actor_dist_tail`` (``"dist"``: c51 / qr, a0_actor_dist_tail_env_step) or of the quantile tail (``"quantile"``:
         iqn / fqf, a0_actor_quantile_tail_env_step), all ending in action, qmax, ctrl, eps_ptr; the action chosen there is the one this step takes."""
         self.g += 1
         nxt = (self._cur + 1) % len(self._obs)
-        {"qhead": self.ops.actor_qhead_env_step, "dist": self.ops.actor_dist_tail_env_step, "quantile": self.ops.actor_quantile_tail_env_step}[kind](*tail_args, self.seed, self.rank, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps,
-                                      gamma, ring_act, ring_rew, ring_done, obs0, replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done, task=self.task)
+        common = (self.seed, self.rank, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0,
+                  replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done)
+        if enc is not None:      # (wt, encoder weights, act3): the same launch goes on to encode the new observation — the next step's features (a0_actor_qhead_env_step_enc)
+            assert kind == "qhead"
+            self.ops.actor_qhead_env_step_enc(*tail_args, *common, task=self.task, wt=enc[0], enc_w=enc[1], act3_next=enc[2])
+        else:
+            {"qhead": self.ops.actor_qhead_env_step, "dist": self.ops.actor_dist_tail_env_step, "quantile": self.ops.actor_quantile_tail_env_step}[kind](*tail_args, *common, task=self.task)
         self._cur = nxt
         return self._obs[nxt]
 

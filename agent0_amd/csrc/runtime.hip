@@ -415,6 +415,13 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     // NoisyLinear.forward composes mu + sigma * eps with the parameters as they are NOW (model.py:54-62): a rollout that does not start on a noise reset
     // recomposes the copies once (agent0_amd/deepq/agent.py Actor._rollout)
     if (L->d.noisy && a->steps % freq != 0) A0_CHECK(a0_actor_compose(V, stream));
+    // scalar heads (Actor._rollout): the tail + env-step launch of step t also encodes the env's new observation (a0_actor_qhead_env_step_enc), so that step t + 1
+    // starts with its features in place; the convolution weights do not change inside a rollout, the last step has no next one
+    static const bool step_enc_on = getenv("A0_NO_X9") == nullptr && (getenv("A0_STEP_ENC") == nullptr || atoi(getenv("A0_STEP_ENC")) != 0);
+    // (not for an actor with its own network — the launch schedule: its rollout runs beside the update block, the critical path there, and a workgroup that holds a CU's
+    // LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives: 9.43 -> 9.75 ms)
+    const bool step_enc = step_enc_on && !dist && !quant && !a->own_flat;
+    bool feat_ready = false;
     for (int t = 0; t < a->T; ++t) {
         if (L->d.noisy && a->steps % freq == 0) {      // agent.py:52-53: self.model.reset_noise() every reset_noise_freq steps, from the ACTOR's stream
             A0_CHECK(a0_rng_normal(a->rng.seed, 4 /* STREAM_NOISE */, a->rng.reserve(4, L->noise_len), 0.1f, V.noise, L->noise_len, stream));
@@ -422,7 +429,8 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
         }
         const uint8_t* cur_obs = a->obs[a->cur];
         a0_frames_arg f{cur_obs, nullptr, (long long)a->obs_bytes, 0};
-        A0_CHECK(a0_net_encoder_fwd_fused(L->C, L->H, L->W, V.wt, &w, &f, E, nullptr, nullptr, a->act3, stream));
+        if (!feat_ready) A0_CHECK(a0_net_encoder_fwd_fused(L->C, L->H, L->W, V.wt, &w, &f, E, nullptr, nullptr, a->act3, stream));
+        feat_ready = false;
         const long long back = (a->steps + 1 < a->n ? a->steps + 1 : a->n) - 1;                 // first observation of the emitted n-step transition
         const uint8_t* obs0 = a->obs[((a->cur - back) % a->K + a->K) % a->K];
         if (quant) {
@@ -478,6 +486,14 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
         const unsigned long long off_a = a->rng.reserve(STREAM_EGREEDY_A, E), off_u = a->rng.reserve(STREAM_EGREEDY_U, E);
         const int nxt = (a->cur + 1) % a->K;
         a->g += 1;
+        if (step_enc && t + 1 < a->T) {
+            A0_CHECK(a0_actor_qhead_env_step_enc(a->act3, E, a->feat, V.Wf(), V.bf(), V.Wh(), V.bh(), A, a->d.dueling ? 1 : 0,
+                                                 a->scratch, a->rng.seed, STREAM_EGREEDY_A, STREAM_EGREEDY_U, off_a, off_u, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E,
+                                                 a->d.seed, a->d.rank, a->g, cur_obs, a->obs[nxt], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
+                                                 a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,
+                                                 a->d.env_task, V.wt, &w, a->act3, stream));
+            feat_ready = true;
+        } else
         A0_CHECK(a0_actor_qhead_env_step(a->act3, E, a->feat, V.Wf(), V.bf(), V.Wh(), V.bh(), A, a->d.dueling ? 1 : 0,
                                          a->scratch, a->rng.seed, STREAM_EGREEDY_A, STREAM_EGREEDY_U, off_a, off_u, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E,
                                          a->d.seed, a->d.rank, a->g, cur_obs, a->obs[nxt], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,

@@ -188,11 +188,22 @@ class Actor:
             # composed copies the device keeps were last written before the learner's latest Adam step (or come from a weight snapshot).
             # A rollout that does not start on a noise reset recomposes them once (with the default sample_steps = 80 it always does).
             self.model._dev.compose_noise()
+        # round 5: on the scalar-head path the tail + env-step launch of step t also ENCODES the env's new observation (a0_actor_qhead_env_step_enc) — the next step
+        # starts with its features in place, and a step is two launches (fc1 GEMM | tail + env step + next encoder) instead of three.  The convolution weights do not
+        # change inside a rollout (NoisyNet touches the dense layers only), the last step has no next one.
+        dev = self.model._dev
+        step_enc = (self.tail_env and self.fused_tail and bound and not test and dev.fused and (self.L.C, self.L.H, self.L.W) == (4, 84, 84) and hasattr(ops, "actor_qhead_env_step_enc")
+                    and os.environ.get("A0_NO_X9") is None and os.environ.get("A0_STEP_ENC", "1") != "0"       # 0: tuning aid (same bytes, three launches per step)
+                    # not on the launch schedule (the rollout into a stage ring): there the rollout runs BESIDE the update block, which is the critical path, and a
+                    # workgroup that holds a CU's LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives (9.43 -> 9.75 ms)
+                    and not isinstance(self.replay, StageRing))
+        feat_ready = False
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
                 self.model.reset_noise(rng=self.rng)
             merged = bound and not test and (self.tail_env or (self.quant_tail and self.fused_commit))
-            self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t, tail=not merged)
+            if not feat_ready:
+                self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t, tail=not merged)
             cur_obs = self.obs
             if self.n > 1 and self.env_history:
                 obs0 = self.envs.history(min(self.steps + 1, self.n) - 1)         # first observation of the emitted n-step transition
@@ -209,9 +220,11 @@ class Actor:
                 rp = self.replay
                 kind = "qhead" if self.fused_tail else ("dist" if self.dist_tail else "quantile")
                 targs = {"qhead": self._qhead_args, "dist": self._dist_tail_args, "quantile": self._quant_tail_args}[kind](epsilon, ctrl, eps_ptr, t)
+                enc = (dev.wt, dev.encoder_weights(), self.ws.act3) if (step_enc and t + 1 < T) else None
                 self.obs = self.envs.act_step_commit(targs, self.stat_mask[t * E:(t + 1) * E], self.stat_ret[t * E:(t + 1) * E], self.n, self.steps,
                                                      float(cfg.learner.discount), self.ring_act, self.ring_rew, self.ring_done, obs0, rp, (start + t * E) % rp.size,
-                                                     kind=kind)
+                                                     kind=kind, enc=enc)
+                feat_ready = enc is not None
                 self.steps += 1
                 continue
             if bound and not test and self.fused_commit:

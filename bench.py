@@ -475,7 +475,9 @@ def main():
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
                 "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor launch) or x 1024 (learner launch: the update's target and online passes of 512 observations in one launch; 1536 with double-Q)"
                                                if pr["kernel"] == "encoder_fused" else f"2*M*N*K per launch; {pr['flop'] / max(pr['launches'], 1) / 1e9:.2f} GFLOP average over the launch mix",
-                "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off",
+                "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off"
+                            + ("; on the launch schedule the rollout's launches run on the actor stream BESIDE the update block's, so these durations include the contention for "
+                               "the chip — the `main` entry's line carries the kernel's own rate" if args.entry == "launch" else ""),
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
     out["roofline"] = roof
     out["cpu_baseline"] = cpu_base

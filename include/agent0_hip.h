@@ -542,6 +542,17 @@ int a0_actor_qhead_env_step(const float* feat, int E, int K, const float* W1, co
 int a0_mean_rows(const float* x, int T, int E, float* out, void* stream);
 
 /* the same with both draws generated in-kernel from Philox streams (bit-identical to a0_rng_randint + a0_rng_uniform + a0_actor_egreedy) */
+/* (round 5) a0_actor_qhead_env_step whose second launch goes on to ENCODE the env's new observation: fc1 GEMM over `feat`, then ONE launch per env for tail + env
+ * step + the fused encoder over obs_out into act3_next [E][3136] (may be `feat`) — the next actor step's features, so that a step is two launches instead of three
+ * (agent.py:25-39,52-81 and model.py:90-105 for the next observation).  wt / w: the acting network's weight copies and encoder weights as for
+ * a0_net_encoder_fwd_fused (4 x 84 x 84 observations only).  Same bytes and features as a0_actor_qhead_env_step + a0_net_encoder_fwd_fused. */
+int a0_actor_qhead_env_step_enc(const float* feat, int E, int K, const float* W1, const float* b1, const float* W2, const float* b2, int A, int dueling,
+                                float* scratch, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task,
+                                const float* wt, const a0_encoder_weights* w, float* act3_next, void* stream);
 int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
                          unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out,
                          const long long* ctrl, const float* eps_ptr, void* stream);

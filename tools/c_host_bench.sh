@@ -1,6 +1,6 @@
 # BASELINE configs[1] and configs[2] from the plain C host (tests/c_host_loop.c) next to the Python bench of the same box, ALTERNATING (consecutive runs on one box drift by
 # a per cent or two either way) -> gpurun_out/$R/c_host_loop.json
-cd $GRAFT_REPO_ROOT; R=${R:-r04}
+cd $GRAFT_REPO_ROOT; R=${R:-r05}
 mkdir -p gpurun_out/$R
 gcc -O2 -D__HIP_PLATFORM_AMD__ tests/c_host_loop.c -I/opt/rocm/include -Iinclude -Lagent0_amd/lib -lagent0_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$GRAFT_REPO_ROOT/agent0_amd/lib -Wl,-rpath,/opt/rocm/lib -lm -o /tmp/c_host_loop || exit 1
 C51="--algo c51 learner.double_q=true learner.dueling_head=true learner.noisy_net=true learner.n_step_q=3 replay.policy=prioritize"
@@ -19,7 +19,9 @@ done
 python3 - <<PY
 import json
 R = "$R"
-rd = lambda f: json.loads(open(f"gpurun_out/{R}/{f}").read().strip().splitlines()[-1])
+def rd(f):      # the bench line / the C host's summary line (it also prints a fingerprint line behind it)
+    rows = [json.loads(x) for x in open(f"gpurun_out/{R}/{f}").read().strip().splitlines() if x.startswith("{")]
+    return next((r for r in rows if "host" in r), rows[-1])
 out = {"note": "one box, alternating runs, ms per iteration: tests/c_host_loop.c (plain C over a0_actor / a0_rbuf / a0_learner, eager launches, no rollout prefetch, 1 M-slot ring, 40 timed "
                "iterations), bench.py with the library's handles over the Trainer's buffers (deepq/native_loop.py, the default), bench.py with A0_NATIVE_LOOP=0 (Python classes + hipGraphs)"}
 for c, key in ((1, "configs[1]"), (2, "configs[2]")):
