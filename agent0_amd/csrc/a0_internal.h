@@ -43,3 +43,4 @@ int a0_conv23_wgrad_fused_launch(const a0_net_core& n, int B, const float* act1,
 #endif
 #define A0_TAG_ENCODER_FUSED 12
 #define A0_TAG_ENCODER_DGRAD_FUSED 13
+#define A0_TAG_ACTOR_STEP_ENC 14      // the actor step's tail + env step + next observation's encoder in one kernel (its own family: the encoder's roofline keeps the pure launches)

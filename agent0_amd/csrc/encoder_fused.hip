@@ -928,7 +928,7 @@ int a0_actor_step_enc_launch(const a0_qenv_args& Q, const float* wt, const a0_en
             return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step_enc: LDS");
         configured = lds;
     }
-    const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, st);
+    const bool probed = a0_probe_start(A0_TAG_ACTOR_STEP_ENC, st);
     hipLaunchKernelGGL(a0_actor_step_enc_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
     if (probed) a0_probe_stop(st, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_qhead_env_step_enc");

@@ -782,7 +782,7 @@ class HipOps:
 
     # ------------------------------------------------------------------ measurement
     PROBE_TAGS = {"conv1_fwd": 1, "conv2_fwd": 2, "conv3_fwd": 3, "dense_fwd": 4, "dense_dgrad": 5, "dense_wgrad": 6, "conv3_wgrad": 7,
-                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13}
+                  "conv3_dgrad": 8, "conv2_wgrad": 9, "conv2_dgrad": 10, "conv1_wgrad": 11, "encoder_fused": 12, "encoder_dgrad_fused": 13, "actor_step_enc": 14}
 
     def dense_dgrad_wgrad_ok(self, R, N, K) -> bool:
         return bool(self.lib.a0_dense_dgrad_wgrad_ok(R, N, K))

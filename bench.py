@@ -331,6 +331,19 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             pr = tr.ops.probe_end()
+        # round 5: on the `main` schedule the actor's steps 1..T-1 encode inside the tail + env-step kernel (a0_actor_step_enc_kernel, its own probe family, so that
+        # the encoder's line above keeps the pure encoder launches rocprofv3 lists as a0_encoder_fused_*): one more repeat brackets that kernel
+        pr_step = None
+        if probe_kernel == "encoder_fused" and not dp:
+            if rank == 0:
+                tr.ops.probe_begin("actor_step_enc", 64 + args.steps * 2 * cfg.actor.sample_steps)
+            for _ in range(args.steps):
+                tr.run_iteration()
+            torch.cuda.synchronize()
+            if rank == 0:
+                pr_step = tr.ops.probe_end()
+                if not pr_step["launches"]:
+                    pr_step = None
     # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
     # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
     replay_gbps = None
@@ -435,7 +448,7 @@ def main():
         traffic_file = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # newest round
         pm = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["per_launch"]
         if "1024" in pm:      # round 4: the update's two forward passes (target on s', online on s: 2 x 512 observations) are ONE launch
-            n_act, n_lrn = cfg.actor.sample_steps, cfg.learner.learner_steps
+            n_act, n_lrn = (1 if pr_step else cfg.actor.sample_steps), cfg.learner.learner_steps      # (merged actor steps: only a rollout's first step launches the encoder alone)
             traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["1024"]["hbm_bytes"]) / (n_act + n_lrn))
         else:
             n_act, n_lrn = cfg.actor.sample_steps, 2 * cfg.learner.learner_steps
@@ -479,6 +492,14 @@ def main():
                             + ("; on the launch schedule the rollout's launches run on the actor stream BESIDE the update block's, so these durations include the contention for "
                                "the chip — the `main` entry's line carries the kernel's own rate" if args.entry == "launch" else ""),
                 "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
+    if roof is not None and pr_step is not None:
+        us = 1e3 * pr_step["ms"] / pr_step["launches"]
+        roof["actor_step_kernel"] = {
+            "kernel": "a0_actor_step_enc_kernel (a0_actor_qhead_env_step_enc: Q head + action + env step + frame commit of step t, then conv1+conv2+conv3 of the env's new "
+                      "observation, one workgroup per env)", "launches": pr_step["launches"], "avg_us": round(us, 2),
+            "encoder_flop_rate": {"achieved": round(pr_step["flop"] / (pr_step["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                  "note": "the encoder's 15.47 MFLOP per observation over the WHOLE kernel's duration (tail and env step included): a lower bound on its encoder phase"},
+            "replaces": "a0_actor_qhead_env_kernel + a0_encoder_fused_kernel<grid 256> of the three-launch step (A0_STEP_ENC=0); profiles/ carries both durations"}
     out["roofline"] = roof
     out["cpu_baseline"] = cpu_base
     print(json.dumps(out))

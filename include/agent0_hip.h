@@ -159,7 +159,8 @@ int a0_reduce_bias_act_multi(int n, const float* const* slabs, const long long* 
                              const int* rows, int N, int relu, void* stream);
 
 /* measurement hook for bench.py: HIP events around every launch of the GEMM tagged `tag` (1 conv1 fwd, 2 conv2 fwd, 3 conv3 fwd,
- * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad, 12 fused encoder), recorded on the
+ * 4 dense fwd, 5 dense dgrad, 6 dense wgrad, 7/8 conv3 wgrad/dgrad, 9/10 conv2 wgrad/dgrad, 11 conv1 wgrad, 12 fused encoder, 13 fused encoder dgrad,
+ * 14 the actor step's tail + env step + encoder kernel of a0_actor_qhead_env_step_enc), recorded on the
  * launch stream.  a0_probe_end writes host_out3 = {launches, total ms, total algorithmic FLOP (2*M*N*K)}. */
 int a0_probe_begin(int tag, int max_launches);
 int a0_probe_end(double* host_out3);

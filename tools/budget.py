@@ -61,6 +61,9 @@ def model(cfg):
                                                                        "Unsplit (bias + ReLU in the epilogue, no slabs) would be 32 workgroups x 98 k tiles = 23.5 us: split-K wins"),
         "a0_igemm_x9_kernel<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2, 2>": ("actor fc1 (c51 / qr: a0_dense_fwd, 16 slabs)", "mfma32 issue", mfma_us(gemm(E, 512, FEAT) * X9), "as above"),
         "a0_actor_qhead_env_kernel": ("actor tail + env step + replay row, 256 envs", "hbm", hbm_us(E * (OBS + 3 * OBS) + 8 * E * 512 * 4), "28 KB read + 85 KB written per env, + the fc1 slabs; wave 0's serial tail (slab sums, head, Philox, n-step) is the critical path"),
+        "a0_actor_step_enc_kernel": ("actor tail + env step + replay row, then the new observation's encoder (main schedule, scalar heads: steps 1..T-1)", "mfma16 issue + hbm",
+                                     ENC_TILE_CYC / GHZ * 1e6 + hbm_us(E * (OBS + 3 * OBS) + 8 * E * 512 * 4), "the two phases are serial per workgroup (one env per CU): the encoder's issue floor plus the tail's traffic; "
+                                     "saves the boundary between a0_actor_qhead_env_kernel and a0_encoder_fused_kernel (~4 us per step)"),
         "a0_actor_dist_tail_env_kernel": ("distributional actor tail + env step + replay row", "hbm", hbm_us(E * (OBS + 3 * OBS) + 8 * E * Npad * 4), "as above, head slabs instead of fc1 slabs"),
         "a0_reduce_bias_act_kernel": ("fc1 slab sum + bias + ReLU (dist actors)", "launch", LAUNCH, "16 x 0.5 MB of slabs: 1.3 us of traffic under a launch floor"),
         "a0_igemm_x9_group_kernel": (f"{npass} grouped fc1 GEMMs 512 x 512 x 3136 (and, c51 / qr, the grouped head GEMMs)", "mfma32 issue", mfma_us(gemm(B, 512, FEAT, npass) * X9), "fc1 group; the head group is smaller"),
@@ -92,6 +95,10 @@ def model(cfg):
 # launches per iteration (80 actor steps, 20 updates; NoisyNet: a reset every 4 actor steps and one per update)
 def per_iteration(cfg, name):
     noisy = cfg == "c51"
+    if name.startswith("a0_actor_step_enc_kernel"):
+        return 79
+    if name.startswith(("a0_encoder_fused_kernel", "a0_actor_qhead_env_kernel")) and cfg in ("dqn", "mdqn"):
+        return 1                     # a rollout's first encoder and last tail; the 79 steps between run a0_actor_step_enc_kernel
     if name.startswith(("a0_encoder_fused_kernel", "a0_actor_qhead_env_kernel", "a0_actor_dist_tail_env_kernel", "a0_reduce_bias_act_kernel")):
         return 80
     if name.startswith("a0_igemm_x9_kernel<OpMatKC, OpMatKC, EpiSlab"):
