@@ -912,7 +912,54 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     a0_encoder_fused_x9_body<7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// The distributional heads' step (c51 / qr): a0_actor_dist_tail_env_kernel's body (head slab sum, dueling, expectation or quantile mean, first maximum, epsilon-greedy,
+// env step, replay row), then the same encoder phase.
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_dist_step_enc_kernel(a0_dtenv_args Q, a0_step_enc_args N) {
+    __shared__ int s_chase_cell;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long v_wt = (unsigned long long)N.wt, v_b1 = (unsigned long long)N.b1, v_b2 = (unsigned long long)N.b2, v_b3 = (unsigned long long)N.b3,
+                       v_a3 = (unsigned long long)N.act3, v_obs = (unsigned long long)Q.obs_out;
+    A0_TO_VGPR(v_wt); A0_TO_VGPR(v_b1); A0_TO_VGPR(v_b2); A0_TO_VGPR(v_b3); A0_TO_VGPR(v_a3); A0_TO_VGPR(v_obs);
+    int v_E = Q.E;
+    A0_TO_VGPR(v_E);
+    a0_actor_dist_tail_env_body(Q, (float*)smem, &s_chase_cell);
+    __syncthreads();
+    auto uni = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull));
+    };
+    const float* wt = (const float*)uni(v_wt);
+    a0_fused_args P;
+    P.frames = (const uint8_t*)uni(v_obs); P.slot = nullptr; P.sample_stride = 4 * 84 * 84; P.chan_off = 0;
+    P.wt1 = wt; P.wt2 = wt + 48LL * 4 * 64; P.wt3 = P.wt2 + 64LL * 512;
+    P.wx2 = P.wt3 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; P.wx3 = P.wx2 + 96LL * 512;
+    P.b1 = (const float*)uni(v_b1); P.b2 = (const float*)uni(v_b2); P.b3 = (const float*)uni(v_b3);
+    P.act1 = nullptr; P.act2 = nullptr; P.act3 = (float*)uni(v_a3); P.B = __builtin_amdgcn_readfirstlane(v_E);
+    P.C = 4; P.H = 84; P.W = 84; P.H1 = 20; P.W1 = 20; P.H2 = 9; P.W2 = 9; P.H3 = 7; P.W3 = 7;
+    P.off_act1 = 0; P.off_act2 = 0; P.off_end = 0; P.rp1 = 0; P.rp2 = 0;
+    a0_encoder_fused_x9_body<7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
+}
+
 static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_bytes);
+int a0_actor_dist_step_enc_launch(const a0_dtenv_args& Q, size_t tail_lds, const float* wt, const a0_encoder_weights* w, float* act3, hipStream_t st) {
+    a0_fused_args P;
+    size_t lds = 0;
+    if (!wt || !w || !w->b1 || !w->b2 || !w->b3 || !act3 || !a0_fused_layout(4, 84, 84, P, lds)) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: bad encoder argument");
+    if (getenv("A0_NO_X9") != nullptr) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: the split-operand encoder only");
+    if (P.H1 != 20 || P.W1 != 20 || P.H2 != 9 || P.W2 != 9 || P.H3 != 7 || P.W3 != 7) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: geometry");
+    const a0_step_enc_args N{wt, w->b1, w->b2, w->b3, act3};
+    lds = A0_X9_LDS_BYTES > tail_lds ? (size_t)A0_X9_LDS_BYTES : tail_lds;
+    if (lds > 160 * 1024 - 64) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: head too wide for LDS");
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)a0_actor_dist_step_enc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: LDS");
+        configured = lds;
+    }
+    const bool probed = a0_probe_start(A0_TAG_ACTOR_STEP_ENC, st);
+    hipLaunchKernelGGL(a0_actor_dist_step_enc_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
+    if (probed) a0_probe_stop(st, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E);
+    return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail_env_step_enc");
+}
 int a0_actor_step_enc_launch(const a0_qenv_args& Q, const float* wt, const a0_encoder_weights* w, float* act3, hipStream_t st) {
     a0_fused_args P;
     size_t lds = 0;

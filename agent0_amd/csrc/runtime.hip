@@ -420,7 +420,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     static const bool step_enc_on = getenv("A0_NO_X9") == nullptr && (getenv("A0_STEP_ENC") == nullptr || atoi(getenv("A0_STEP_ENC")) != 0);
     // (not for an actor with its own network — the launch schedule: its rollout runs beside the update block, the critical path there, and a workgroup that holds a CU's
     // LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives: 9.43 -> 9.75 ms)
-    const bool step_enc = step_enc_on && !dist && !quant && !a->own_flat;
+    const bool step_enc = step_enc_on && !quant && !a->own_flat;
     bool feat_ready = false;
     for (int t = 0; t < a->T; ++t) {
         if (L->d.noisy && a->steps % freq == 0) {      // agent.py:52-53: self.model.reset_noise() every reset_noise_freq steps, from the ACTOR's stream
@@ -472,6 +472,15 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             const int nx = (a->cur + 1) % a->K;
             a->g += 1;
             if (4LL * ((long long)A * L->T + L->T) * 4 > 160 * 1024) return a0_fail(A0_EINVAL, "a0_actor_rollout: head too wide for the distributional tail kernel");
+            if (step_enc && t + 1 < a->T) {
+                A0_CHECK(a0_actor_dist_tail_env_step_enc(a->head_slabs, (long long)E * L->Npad, ns, V.bh(), L->Npad, A, L->T, a->d.dueling ? 1 : 0, L->d.algo == A0_ALGO_C51 ? 2 : 1,
+                                                         L->d.algo == A0_ALGO_C51 ? L->atoms : nullptr, E, a->rng.seed,
+                                                         STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed, a->d.rank,
+                                                         a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps, a->d.discount,
+                                                         a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act, R->rew, R->done,
+                                                         a->d.env_task, V.wt, &w, a->act3, stream));
+                feat_ready = true;
+            } else
             A0_CHECK(a0_actor_dist_tail_env_step(a->head_slabs, (long long)E * L->Npad, ns, V.bh(), L->Npad, A, L->T, a->d.dueling ? 1 : 0, L->d.algo == A0_ALGO_C51 ? 2 : 1,
                                                  L->d.algo == A0_ALGO_C51 ? L->atoms : nullptr, E, a->rng.seed,
                                                  STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed, a->d.rank,

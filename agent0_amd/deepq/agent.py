@@ -188,11 +188,11 @@ class Actor:
             # composed copies the device keeps were last written before the learner's latest Adam step (or come from a weight snapshot).
             # A rollout that does not start on a noise reset recomposes them once (with the default sample_steps = 80 it always does).
             self.model._dev.compose_noise()
-        # round 5: on the scalar-head path the tail + env-step launch of step t also ENCODES the env's new observation (a0_actor_qhead_env_step_enc) — the next step
-        # starts with its features in place, and a step is two launches (fc1 GEMM | tail + env step + next encoder) instead of three.  The convolution weights do not
-        # change inside a rollout (NoisyNet touches the dense layers only), the last step has no next one.
+        # round 5: for scalar and distributional heads the tail + env-step launch of step t also ENCODES the env's new observation (a0_actor_qhead_env_step_enc /
+        # a0_actor_dist_tail_env_step_enc) — the next step starts with its features in place, and a scalar-head step is two launches (fc1 GEMM | tail + env step + next
+        # encoder) instead of three.  The convolution weights do not change inside a rollout (NoisyNet touches the dense layers only), the last step has no next one.
         dev = self.model._dev
-        step_enc = (self.tail_env and self.fused_tail and bound and not test and dev.fused and (self.L.C, self.L.H, self.L.W) == (4, 84, 84) and hasattr(ops, "actor_qhead_env_step_enc")
+        step_enc = (self.tail_env and (self.fused_tail or self.dist_tail) and bound and not test and dev.fused and (self.L.C, self.L.H, self.L.W) == (4, 84, 84) and hasattr(ops, "actor_qhead_env_step_enc")
                     and os.environ.get("A0_NO_X9") is None and os.environ.get("A0_STEP_ENC", "1") != "0"       # 0: tuning aid (same bytes, three launches per step)
                     # not on the launch schedule (the rollout into a stage ring): there the rollout runs BESIDE the update block, which is the critical path, and a
                     # workgroup that holds a CU's LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives (9.43 -> 9.75 ms)

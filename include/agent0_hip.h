@@ -554,6 +554,15 @@ int a0_actor_qhead_env_step_enc(const float* feat, int E, int K, const float* W1
                                 float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
                                 const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task,
                                 const float* wt, const a0_encoder_weights* w, float* act3_next, void* stream);
+/* (round 5) a0_actor_dist_tail_env_step (c51 / qr) whose kernel goes on to encode the env's new observation into act3_next [E][3136], as a0_actor_qhead_env_step_enc
+ * does for scalar heads: the same bytes and features as a0_actor_dist_tail_env_step + a0_net_encoder_fwd_fused, one launch and one kernel boundary less per step. */
+int a0_actor_dist_tail_env_step_enc(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                    const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                    unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                    unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                    float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                    const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task,
+                                    const float* wt, const a0_encoder_weights* w, float* act3_next, void* stream);
 int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
                          unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out,
                          const long long* ctrl, const float* eps_ptr, void* stream);
