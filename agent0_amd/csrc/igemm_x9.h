@@ -367,8 +367,12 @@ template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int 
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_pair_kernel(typename OA1::Params pa1, typename OB1::Params pb1, typename EP1::Params pe1, int X1, int Y1, int K1, int kc1,
                                                                 int gx1, int gy1, typename OA2::Params pa2, typename OB2::Params pb2, typename EP2::Params pe2, int X2, int Y2,
                                                                 int K2, int kc2, int gx2, int gy2) {
-    if (blockIdx.y == 0) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1);
-    else a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    // (round 5: the two problems may have different numbers of tiles — the grid is as long as the longer one, and a workgroup whose logical tile, by the body's own
+    // id -> tile map, does not exist in its problem leaves at once)
+    const int n = gridDim.x, id = blockIdx.x, per = n >> 3;
+    const int L = (id < (per << 3)) ? (id & 7) * per + (id >> 3) : id;
+    if (blockIdx.y == 0) { if (L < gx1 * gy1) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1); }
+    else if (L < gx2 * gy2) a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
 }
 
 template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
@@ -387,8 +391,53 @@ static inline hipError_t a0_igemm_x9_pair_launch(hipStream_t st, const typename 
     constexpr int BK = 16 * KS;
     const int kc1 = ((K1 + BK - 1) / BK) * BK, kc2 = ((K2 + BK - 1) / BK) * BK;          // no reduction split
     const int gx1 = (X1 + G1::BX - 1) / G1::BX, gy1 = (Y1 + G1::BY - 1) / G1::BY, gx2 = (X2 + G2::BX - 1) / G2::BX, gy2 = (Y2 + G2::BY - 1) / G2::BY;
-    if (gx1 * gy1 != gx2 * gy2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(gx1 * gy1), 2), dim3(WM * WN * 64), LDS, st, pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1, pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    const int gmax = gx1 * gy1 > gx2 * gy2 ? gx1 * gy1 : gx2 * gy2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gmax, 2), dim3(WM * WN * 64), LDS, st, pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1, pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    return hipGetLastError();
+}
+
+// The pair above plus a SECOND instance of its second body on a smaller problem (round 5): fc1's data gradient, fc1's weight gradient and the HEAD's weight gradient all
+// depend on the loss kernel's outputs only, and the head's few tiles (8 for a scalar head, 56 for qr's 800 columns) fit into the slots the pair leaves empty — its launch
+// (6.5 - 10.9 us alone, 20 times per block) disappears.  blockIdx.y names the problem; the third problem's grid column is as long as the pair's, workgroups without a tile
+// of it leave at once.
+template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
+__global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_trio_kernel(typename OA1::Params pa1, typename OB1::Params pb1, typename EP1::Params pe1, int X1, int Y1, int K1, int kc1,
+                                                                int gx1, int gy1, typename OA2::Params pa2, typename OB2::Params pb2, typename EP2::Params pe2, int X2, int Y2,
+                                                                int K2, int kc2, int gx2, int gy2, typename OA2::Params pa3, typename OB2::Params pb3, typename EP2::Params pe3,
+                                                                int X3, int Y3, int K3, int kc3, int gx3, int gy3) {
+    // the small problem takes grid row 0: rows are dispatched in order, so its workgroups start with the launch instead of behind the pair's 784 (measured: in the last
+    // row they began when the pair's slots drained and added their whole duration to the launch's tail)
+    if (blockIdx.y == 1) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1);
+    else if (blockIdx.y == 2) a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    else {
+        const int n = gridDim.x, id = blockIdx.x, per = n >> 3;          // the body's own id -> logical tile map: only tiles [0, gx3 * gy3) exist
+        const int L = (id < (per << 3)) ? (id & 7) * per + (id >> 3) : id;
+        if (L >= gx3 * gy3) return;
+        a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa3, pb3, pe3, X3, Y3, K3, kc3, gx3, gy3);
+    }
+}
+
+template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
+static inline hipError_t a0_igemm_x9_trio_launch(hipStream_t st, const typename OA1::Params& pa1, const typename OB1::Params& pb1, const typename EP1::Params& pe1, int X1, int Y1, int K1,
+                                                 const typename OA2::Params& pa2, const typename OB2::Params& pb2, const typename EP2::Params& pe2, int X2, int Y2, int K2,
+                                                 const typename OA2::Params& pa3, const typename OB2::Params& pb3, const typename EP2::Params& pe3, int X3, int Y3, int K3) {
+    typedef a0_x9_geom<OA1, OB1, WM, WN, MT, NT, KS> G1;
+    typedef a0_x9_geom<OA2, OB2, WM, WN, MT, NT, KS> G2;
+    constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
+    auto kern = a0_igemm_x9_trio_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    constexpr int BK = 16 * KS;
+    const int kc1 = ((K1 + BK - 1) / BK) * BK, kc2 = ((K2 + BK - 1) / BK) * BK, kc3 = ((K3 + BK - 1) / BK) * BK;          // no reduction split
+    const int gx1 = (X1 + G1::BX - 1) / G1::BX, gy1 = (Y1 + G1::BY - 1) / G1::BY, gx2 = (X2 + G2::BX - 1) / G2::BX, gy2 = (Y2 + G2::BY - 1) / G2::BY;
+    const int gx3 = (X3 + G2::BX - 1) / G2::BX, gy3 = (Y3 + G2::BY - 1) / G2::BY;
+    if (gx1 * gy1 != gx2 * gy2 || gx3 * gy3 > gx1 * gy1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx1 * gy1), 3), dim3(WM * WN * 64), LDS, st, pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1, pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2,
+                       pa3, pb3, pe3, X3, Y3, K3, kc3, gx3, gy3);
     return hipGetLastError();
 }
 

@@ -374,6 +374,7 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     }
     a0_pending_reduce pend;
     pend.n = 0;
+    bool head_wgrad_done = false;      // a distributional head's weight gradient rode in its data gradient's launch (a0_dense_dgrad_wgrad, small class)
     // data parallelism: the dense range is exchanged right after the dense backward, so its slab reductions cannot wait for the encoder's launch (engine.py::_backward_dense)
     const bool dp = L->dp_comm != 0;
     // A0_DP_ONE_STREAM=1 (the same on every rank; a tuning aid): both all-reduces on the caller's stream — no overlap with the encoder backward, but none of the three
@@ -411,6 +412,10 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         }
         // DeviceLearner._backward_dense: the dueling combine's and the head's backward-data passes; fc1's and the weight gradients follow in the common block
         A0_CHECK(a0_dueling_bwd(L->g_dq, L->draw, L->Npad, B, A, T, L->d.dueling ? 1 : 0, stream));
+        if (a0_dense_dgrad_wgrad_ok2(B, L->Npad, 512)) {      // ... side by side with the head's weight gradient (DeviceLearner._backward_dense)
+            A0_CHECK(a0_dense_dgrad_wgrad(L->draw, L->Wh(false), L->h, 512, L->dh, L->grads + L->head.off, B, L->Npad, 512, stream));
+            head_wgrad_done = true;
+        } else
         A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->h, L->dh, B, L->Npad, 512, stream));
     } else if (L->d.algo == A0_ALGO_FQF) {
         // ---- FQFLearner.train_step (agent.py:334-388) in the order of agent0_amd/deepq/engine.py's fqf path
@@ -525,6 +530,10 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
                                         L->Npad, A, L->T, L->d.dueling ? 1 : 0, act, rew, done, wgt, L->atoms, L->gamma_n, (float)L->d.vmin, (float)L->d.vmax, B, L->loss, L->draw,
                                         L->q_o, L->q_t, L->m_proj, L->a_star, L->state, stream));
         // the head's data gradient (the scalar-head kernel above folds it in; the distributional one does not)
+        if (a0_dense_dgrad_wgrad_ok2(B, L->Npad, 512)) {      // ... side by side with the head's weight gradient (DeviceLearner._backward_dense)
+            A0_CHECK(a0_dense_dgrad_wgrad(L->draw, L->Wh(false), L->h, 512, L->dh, L->grads + L->head.off, B, L->Npad, 512, stream));
+            head_wgrad_done = true;
+        } else
         A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->h, L->dh, B, L->Npad, 512, stream));
     } else {
     // ---- forward: the target pass on s', the online pass on s' (double-Q) and the online pass on s as ONE encoder launch, then their fc1 GEMMs (split-K slabs)
@@ -584,7 +593,17 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         const float* X[2] = {L->h, L->act3_o};
         const int ldx[2] = {512, L->feat}, R[2] = {B, B}, N[2] = {L->Npad, 512}, K[2] = {512, L->feat};
         float* G[2] = {L->grads + L->head.off, L->grads + L->fc1.off};
-        if (a0_dense_dgrad_wgrad_ok(B, 512, L->feat)) {      // fc1's data gradient and weight gradient as one launch; the head's weight gradient alone
+        if (head_wgrad_done) {
+            if (a0_dense_dgrad_wgrad_ok(B, 512, L->feat)) {
+                A0_CHECK(a0_dense_dgrad_wgrad(L->dh, L->Wf(false), L->act3_o, L->feat, L->d3, G[1], B, 512, L->feat, stream));
+            } else {
+                A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), L->act3_o, L->d3, B, 512, L->feat, stream));
+                A0_CHECK(a0_dense_wgrad_multi(1, dY + 1, X + 1, ldx + 1, G + 1, R + 1, N + 1, K + 1, L->slabs, L->slab_off + 1, pp, stream));
+            }
+        } else if (a0_dense_dgrad_wgrad2_ok(B, 512, L->feat, L->Npad, 512)) {
+            // fc1's data gradient, fc1's weight gradient and the head's weight gradient — all three wait for the loss kernel only — as ONE launch (DeviceLearner._backward_dense)
+            A0_CHECK(a0_dense_dgrad_wgrad2(L->dh, L->Wf(false), L->act3_o, L->feat, L->d3, G[1], B, 512, L->feat, L->draw, L->h, 512, G[0], L->Npad, 512, stream));
+        } else if (a0_dense_dgrad_wgrad_ok(B, 512, L->feat)) {      // fc1's data gradient and weight gradient as one launch; the head's weight gradient alone
             A0_CHECK(a0_dense_dgrad_wgrad(L->dh, L->Wf(false), L->act3_o, L->feat, L->d3, G[1], B, 512, L->feat, stream));
             A0_CHECK(a0_dense_wgrad_multi(1, dY, X, ldx, G, R, N, K, L->slabs, L->slab_off, pp, stream));
         } else {

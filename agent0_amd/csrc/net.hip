@@ -693,18 +693,62 @@ extern "C" int a0_dense_dgrad_wgrad_ok(int R, int N, int K) {
     return (!off && g_gemm_x9 != 0 && g_probe.tag == 0 && R == N && R >= 1 && R <= 1024 && !(N & 3) && !(K & 3) && b128 < 256 && b64 >= 256 && N >= 512 &&
             (long long)((R + 127) / 128) * ((K + 127) / 128) < g_x9_big_min) ? 1 : 0;
 }
+// (round 5) a second class of shapes: SMALL layers whose two gradients together fit one round of 64 x 64 tiles — the head of a distributional learner at a 512-row batch
+// (c51: 64 + 32 tiles, qr: 64 + 104).  Alone, the data gradient occupies a quarter of the chip for its whole k loop and the weight gradient follows it; side by side
+// the launch lasts as long as the longer of the two.  The weight gradient is then an UNSPLIT sum on the bf16 pipe (a0_dense_wgrad: slabs on the fp32 pipe).
+static int a0_dense_dgrad_wgrad_small_ok(int R, int N, int K) {
+    static const bool off = getenv("A0_NO_HEAD_PAIR") != nullptr;      // tuning aid
+    const long long t1 = (long long)((R + 63) / 64) * ((K + 63) / 64), t2 = (long long)((N + 63) / 64) * ((K + 63) / 64);
+    return (!off && g_gemm_x9 != 0 && g_probe.tag == 0 && R >= 64 && R <= 1024 && N >= 64 && !(N & 3) && !(K & 3) && t1 + t2 <= 256 && t2 >= 16) ? 1 : 0;
+}
+extern "C" int a0_dense_dgrad_wgrad_ok2(int R, int N, int K) { return (a0_dense_dgrad_wgrad_ok(R, N, K) || a0_dense_dgrad_wgrad_small_ok(R, N, K)) ? 1 : 0; }
 extern "C" int a0_dense_dgrad_wgrad(const float* dY, const float* W, const float* X, int ldx, float* dX, float* grad, int R, int N, int K, void* stream) {
     A0_TRY
-    if (!dY || !W || !X || !dX || !grad || ldx < K || (ldx & 3) || !a0_dense_dgrad_wgrad_ok(R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_dgrad_wgrad: shapes a0_dense_dgrad_wgrad_ok accepts");
+    if (!dY || !W || !X || !dX || !grad || ldx < K || (ldx & 3) || !a0_dense_dgrad_wgrad_ok2(R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_dgrad_wgrad: shapes a0_dense_dgrad_wgrad_ok2 accepts");
     a0_mat_src a1{dY, N}, b1{W, K};                          // data gradient: rows r, reduction over n
     EpiMaskMat::Params e1{dX, X, K};
     a0_mat_src a2{dY, N}, b2{X, ldx};                        // weight gradient: rows n, reduction over r
     EpiWgradSlab::Params e2{grad, 0, K, (long long)N * K};
+    if (!a0_dense_dgrad_wgrad_ok(R, N, K)) {                 // the small class: 64 x 64 tiles, four waves, unequal tile counts
+        A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
+        return A0_OK;
+    }
     // 128 x 64 tiles on eight waves (196 + 196 workgroups, one per CU at a time): the same sums as the 64 x 64 tiles of the separate calls (every output element's k loop is the
     // same sequence of MFMAs), equal on the `main` schedule and ~2 % faster under `launch`, where the rollout's kernels share the chip (A0_PAIR_TILE=0: 64 x 64, tuning aid)
     static const int pv = getenv("A0_PAIR_TILE") ? atoi(getenv("A0_PAIR_TILE")) : 1;
     if (pv == 1) A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 4, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
     else A0_HIP_THROW((a0_igemm_x9_pair_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R)));
+    return A0_OK;
+    A0_CATCH
+}
+
+// a0_dense_dgrad_wgrad plus the NEXT layer's weight gradient in the same launch (round 5): with dY = d loss / d fc1's output and dY2 = d loss / d head's output both
+// final (the head / loss kernel writes them), fc1's data gradient, fc1's weight gradient and the head's weight gradient dW2 = dY2^T X2 (+ bias row sums) into grad2
+// [N2 x K2 | N2] are independent; the head's few tiles ride in the pair's launch (a0_igemm_x9_trio_kernel).  grad2 gets an UNSPLIT sum over the R rows on the bf16 pipe
+// (a0_dense_wgrad splits it into slabs on the fp32 pipe: the same sum up to the association order).  Shapes: a0_dense_dgrad_wgrad_ok(R, N, K), X2 rows of R, ldx2 >= K2.
+// where it pays: heads of at most one row of 128 x 64 tiles (scalar heads: 8 workgroups).  Measured with wider heads in the launch (same box, alternating): c51's 16 tiles
+// 14.47 - 14.50 -> 14.57 ms, qr's 56 tiles 12.13 -> 12.16 ms — there the fp32-pipe split launch of its own stays; dqn 9.97 -> 9.85 ms, mdqn 11.69 -> 11.60.
+extern "C" int a0_dense_dgrad_wgrad2_ok(int R, int N, int K, int N2, int K2) {
+    static const bool off = getenv("A0_NO_TRIO") != nullptr;      // tuning aid (the head's weight gradient as a launch of its own: the same sum in another order)
+    static const int max_tiles = getenv("A0_TRIO_MAX_TILES") ? atoi(getenv("A0_TRIO_MAX_TILES")) : 8;
+    return (!off && a0_dense_dgrad_wgrad_ok(R, N, K) && N2 >= 4 && !(N2 & 3) && K2 >= 4 && !(K2 & 3) &&
+            (long long)((N2 + 127) / 128) * ((K2 + 63) / 64) <= max_tiles) ? 1 : 0;
+}
+extern "C" int a0_dense_dgrad_wgrad2(const float* dY, const float* W, const float* X, int ldx, float* dX, float* grad, int R, int N, int K,
+                                     const float* dY2, const float* X2, int ldx2, float* grad2, int N2, int K2, void* stream) {
+    A0_TRY
+    if (!dY || !W || !X || !dX || !grad || ldx < K || (ldx & 3) || !a0_dense_dgrad_wgrad_ok(R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_dgrad_wgrad2: shapes a0_dense_dgrad_wgrad_ok accepts");
+    if (!dY2 || !X2 || !grad2 || N2 < 4 || (N2 & 3) || K2 < 4 || (K2 & 3) || ldx2 < K2 || (ldx2 & 3) ||
+        (long long)((N2 + 127) / 128) * ((K2 + 63) / 64) > (long long)((R + 127) / 128) * ((K + 63) / 64))
+        return a0_fail(A0_EINVAL, "a0_dense_dgrad_wgrad2: the second layer's weight gradient must have no more 128 x 64 tiles than the first layer's data gradient");
+    a0_mat_src a1{dY, N}, b1{W, K};
+    EpiMaskMat::Params e1{dX, X, K};
+    a0_mat_src a2{dY, N}, b2{X, ldx};
+    EpiWgradSlab::Params e2{grad, 0, K, (long long)N * K};
+    a0_mat_src a3{dY2, N2}, b3{X2, ldx2};
+    EpiWgradSlab::Params e3{grad2, 0, K2, (long long)N2 * K2};
+    A0_HIP_THROW((a0_igemm_x9_trio_launch<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 4, 2, 1, 1>((hipStream_t)stream, a1, b1, e1, R, K, N, a2, b2, e2, N, K, R,
+                                                                                                                  a3, b3, e3, N2, K2, R)));
     return A0_OK;
     A0_CATCH
 }

@@ -362,9 +362,18 @@ class DeviceLearner:
         # the data gradients first, then every dense weight gradient with ONE slab reduction
         wg = [(ws.draw, ws.h, 512, self._grad("head"), R, L.Npad, 512)]
         if not have_dh:
-            ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
+            if hasattr(ops, "dense_dgrad_wgrad_ok2") and ops.dense_dgrad_wgrad_ok2(R, L.Npad, 512):
+                # round 5: a distributional head's data gradient (64 tiles) and weight gradient (32 - 104 tiles) side by side in one launch
+                ops.dense_dgrad_wgrad(ws.draw, Wh, ws.h, 512, ws.dh, self._grad("head"), R, L.Npad, 512)
+                wg = []
+            else:
+                ops.dense_dgrad(ws.draw, Wh, ws.h, ws.dh, R, L.Npad, 512)
         if not L.quantile:
-            if hasattr(ops, "dense_dgrad_wgrad") and ops.dense_dgrad_wgrad_ok(R, 512, L.feat):
+            if wg and hasattr(ops, "dense_dgrad_wgrad2") and ops.dense_dgrad_wgrad2_ok(R, 512, L.feat, L.Npad, 512):
+                # round 5: ... and the head's weight gradient, which waits for the loss kernel only, in the same launch (its few tiles fill slots the pair leaves empty)
+                ops.dense_dgrad_wgrad2(ws.dh, Wf, ws.act3, L.feat, ws.d3, self._grad("fc1"), R, 512, L.feat, ws.draw, ws.h, 512, self._grad("head"), L.Npad, 512)
+                wg = []
+            elif hasattr(ops, "dense_dgrad_wgrad") and ops.dense_dgrad_wgrad_ok(R, 512, L.feat):
                 # fc1's data gradient and weight gradient — 392 tiles each at R = 512 — as ONE launch that keeps the chip's workgroup slots filled (bit-identical)
                 ops.dense_dgrad_wgrad(ws.dh, Wf, ws.act3, L.feat, ws.d3, self._grad("fc1"), R, 512, L.feat)
             else:
@@ -379,7 +388,8 @@ class DeviceLearner:
         # data parallelism exchanges the dense range right after this call: its reductions cannot wait for the encoder's launch then
         defer = self._defer_dense and self.grad_hook is None
         self._pend = ops.pending_reduce() if defer else None
-        ops.dense_wgrad_multi(wg, self.slabs, **({"pend": self._pend} if defer else {}))
+        if wg:
+            ops.dense_wgrad_multi(wg, self.slabs, **({"pend": self._pend} if defer else {}))
         if L.noisy and not defer:
             self._noisy_sigma_grads()
 

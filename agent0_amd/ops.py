@@ -805,10 +805,23 @@ class HipOps:
     def dense_dgrad_wgrad_ok(self, R, N, K) -> bool:
         return bool(self.lib.a0_dense_dgrad_wgrad_ok(R, N, K))
 
+    def dense_dgrad_wgrad_ok2(self, R, N, K) -> bool:
+        return bool(self.lib.a0_dense_dgrad_wgrad_ok2(R, N, K))
+
     def dense_dgrad_wgrad(self, dY, W, X, ldx, dX, grad, R, N, K):
         """One layer's masked data gradient and unsplit weight gradient in one launch (a0_dense_dgrad_wgrad)."""
         check(self.lib.a0_dense_dgrad_wgrad(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"), _req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx,
                                             _req(dX, torch.float32, R * K, "dX"), _req(grad, torch.float32, N * K + N, "grad"), R, N, K, _stream()), "a0_dense_dgrad_wgrad")
+
+    def dense_dgrad_wgrad2_ok(self, R, N, K, N2, K2) -> bool:
+        return bool(self.lib.a0_dense_dgrad_wgrad2_ok(R, N, K, N2, K2))
+
+    def dense_dgrad_wgrad2(self, dY, W, X, ldx, dX, grad, R, N, K, dY2, X2, ldx2, grad2, N2, K2):
+        """``dense_dgrad_wgrad`` plus the next layer's unsplit weight gradient (dY2^T X2 into grad2 [N2 x K2 | N2]) in the same launch (a0_dense_dgrad_wgrad2)."""
+        check(self.lib.a0_dense_dgrad_wgrad2(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"), _req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx,
+                                             _req(dX, torch.float32, R * K, "dX"), _req(grad, torch.float32, N * K + N, "grad"), R, N, K,
+                                             _req(dY2, torch.float32, R * N2, "dY2"), _req(X2, torch.float32, (R - 1) * ldx2 + K2, "X2"), ldx2,
+                                             _req(grad2, torch.float32, N2 * K2 + N2, "grad2"), N2, K2, _stream()), "a0_dense_dgrad_wgrad2")
 
     def dense_wgrad_multi(self, layers, slabs, pend=None):
         """layers: [(dY, X, ldx, grad, R, N, K)] (at most four); their slab reductions run as one launch — or, with ``pend``, in the next encoder_wgrad(pend=...)'s."""

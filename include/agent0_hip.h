@@ -120,7 +120,15 @@ int a0_dense_dgrad(const float* dY, const float* W, const float* act_mask, float
 /* (round 4) a0_dense_dgrad with the ReLU mask X and the unsplit a0_dense_wgrad of ONE layer (loss.backward() through first_dense, agent.py:153-155) as one launch: the two
  * GEMMs have the same number of 64 x 64 tiles (R == N) and together keep the chip's workgroup slots filled; bit-identical to the two calls.  Shapes: _ok (fc1 of a 512-row batch) */
 int a0_dense_dgrad_wgrad_ok(int R, int N, int K);
+int a0_dense_dgrad_wgrad_ok2(int R, int N, int K);      /* (round 5) _ok, or a SMALL layer whose two gradients together fit one round of 64 x 64 tiles (a distributional head at a
+                                                         * 512-row batch): side by side in one launch; the weight gradient is then an unsplit sum (a0_dense_wgrad's up to the association order) */
 int a0_dense_dgrad_wgrad(const float* dY, const float* W, const float* X, int ldx, float* dX, float* grad_w_b, int R, int N, int K, void* stream);
+/* (round 5) the same launch also carries the NEXT layer's weight gradient: dW2 = dY2^T X2 (+ bias row sums) into grad2 [N2 x K2 | N2], an unsplit sum over the R rows
+ * (what a0_dense_wgrad(dY2, X2, ldx2, grad2, R, N2, K2) computes, up to the association order of the fp32 additions).  fc1's two gradients and the head's weight gradient
+ * of a learner's backward pass (agent.py:153-155) are independent once the loss kernel has written dY and dY2.  N2 x K2 must have no more 128 x 64 tiles than R x K. */
+int a0_dense_dgrad_wgrad2_ok(int R, int N, int K, int N2, int K2);      /* where the library's own learners use it: heads of at most eight such tiles (scalar heads) */
+int a0_dense_dgrad_wgrad2(const float* dY, const float* W, const float* X, int ldx, float* dX, float* grad, int R, int N, int K,
+                          const float* dY2, const float* X2, int ldx2, float* grad2, int N2, int K2, void* stream);
 long long a0_dense_wgrad_scratch(int R, int N, int K);
 int a0_dense_wgrad(const float* dY, const float* X, int ldx, float* grad_w_b, int R, int N, int K, float* slabs, void* stream);
 /* n <= 4 dense weight gradients (the head's and fc1's, + the cosine embedding's) whose slab reductions share one launch; layer i reduces in

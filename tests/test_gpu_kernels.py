@@ -391,6 +391,7 @@ def test_fc1_data_and_weight_gradient_in_one_launch_equal_the_two_calls(hip):
     a0_dense_dgrad + a0_dense_wgrad."""
     R, N, K = 512, 512, 3136
     assert hip.dense_dgrad_wgrad_ok(R, N, K) and not hip.dense_dgrad_wgrad_ok(256, 512, K) and not hip.dense_dgrad_wgrad_ok(512, 256, K)
+    assert hip.dense_dgrad_wgrad2_ok(R, N, K, 32, 512) and not hip.dense_dgrad_wgrad2_ok(R, N, K, 256, 512), "the third problem rides along for scalar heads only"
     g = recipe.gen(5)
     dY = D(hip, g.standard_normal((R, N)).astype(np.float32))
     W = D(hip, (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
@@ -402,6 +403,57 @@ def test_fc1_data_and_weight_gradient_in_one_launch_equal_the_two_calls(hip):
     hip.dense_dgrad_wgrad(dY, W, X, K, dX1, g1, R, N, K)
     assert torch.equal(dX0, dX1) and torch.equal(g0, g1)
     assert float((dX1.view(R, K)[X.view(R, K) <= 0]).abs().max()) == 0.0, "the ReLU mask"
+
+
+@pytest.mark.parametrize("N2", [32, 256, 800, 52])
+def test_fc1_gradients_and_the_head_weight_gradient_in_one_launch(hip, N2):
+    """a0_dense_dgrad_wgrad2 (round 5): the pair launch above plus the HEAD's weight gradient as a third problem of the same launch (a0_igemm_x9_trio_kernel).  fc1's two
+    gradients stay bit-identical to the pair's; the head's [W | b] gradient is an unsplit sum on the bf16 pipe where a0_dense_wgrad splits it into slabs on the fp32
+    pipe — both within fp32 rounding of the fp64 product (head widths of dqn, c51, qr and a ragged one)."""
+    R, N, K, K2 = 512, 512, 3136, 512
+    g = recipe.gen(6)
+    dY = D(hip, g.standard_normal((R, N)).astype(np.float32))
+    W = D(hip, (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    X = D(hip, np.maximum(g.standard_normal((R, K)), 0).astype(np.float32))
+    dY2n = g.standard_normal((R, N2)).astype(np.float32)
+    X2n = np.maximum(g.standard_normal((R, K2)), 0).astype(np.float32)
+    dY2, X2 = D(hip, dY2n), D(hip, X2n)
+    dX0, dX1 = hip.empty(R * K), hip.empty(R * K).fill_(float("nan"))
+    g0, g1 = hip.empty(N * K + N), hip.empty(N * K + N).fill_(float("nan"))
+    h0, h1 = hip.empty(N2 * K2 + N2), hip.empty(N2 * K2 + N2).fill_(float("nan"))
+    hip.dense_dgrad_wgrad(dY, W, X, K, dX0, g0, R, N, K)
+    hip.dense_wgrad(dY2, X2, K2, h0, R, N2, K2, hip.empty(max(hip.dense_wgrad_scratch(R, N2, K2), 4)))
+    hip.dense_dgrad_wgrad2(dY, W, X, K, dX1, g1, R, N, K, dY2, X2, K2, h1, N2, K2)
+    assert torch.equal(dX0, dX1) and torch.equal(g0, g1)
+    ref = np.concatenate([(dY2n.astype(np.float64).T @ X2n.astype(np.float64)).reshape(-1), dY2n.astype(np.float64).sum(0)])
+    scale = np.abs(ref).max()
+    e0, e1 = np.abs(h0.cpu().numpy() - ref).max() / scale, np.abs(h1.cpu().numpy() - ref).max() / scale
+    assert e1 < 2e-6 and e1 < 4 * e0 + 2e-7, f"head weight gradient {e1} of the scale against fp64 (a0_dense_wgrad: {e0})"
+
+
+@pytest.mark.parametrize("R,N", [(512, 256), (512, 800), (64, 256), (200, 132)])
+def test_head_data_and_weight_gradient_side_by_side(hip, R, N):
+    """a0_dense_dgrad_wgrad's small class (round 5): a distributional head's masked data gradient (R x 512 out, k = N) and weight gradient (N x 512 out, k = R) — unequal
+    tile counts — in one launch.  The data gradient is the same body on the same tiles as a0_dense_dgrad (bit-identical); the weight gradient an unsplit sum on the bf16
+    pipe, within fp32 rounding of the fp64 product like a0_dense_wgrad's."""
+    K = 512
+    assert hip.dense_dgrad_wgrad_ok2(R, N, K) and not hip.dense_dgrad_wgrad_ok(R, N, K) and not hip.dense_dgrad_wgrad_ok2(32, N, K)
+    g = recipe.gen(8)
+    dYn = g.standard_normal((R, N)).astype(np.float32)
+    Xn = np.maximum(g.standard_normal((R, K)), 0).astype(np.float32)
+    dY, X = D(hip, dYn), D(hip, Xn)
+    W = D(hip, (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    dX0, dX1 = hip.empty(R * K), hip.empty(R * K).fill_(float("nan"))
+    g0, g1 = hip.empty(N * K + N), hip.empty(N * K + N).fill_(float("nan"))
+    hip.dense_dgrad(dY, W, X, dX0, R, N, K)
+    hip.dense_wgrad(dY, X, K, g0, R, N, K, hip.empty(max(hip.dense_wgrad_scratch(R, N, K), 4)))
+    hip.dense_dgrad_wgrad(dY, W, X, K, dX1, g1, R, N, K)
+    assert torch.equal(dX0, dX1)
+    ref = np.concatenate([(dYn.astype(np.float64).T @ Xn.astype(np.float64)).reshape(-1), dYn.astype(np.float64).sum(0)])
+    scale = np.abs(ref).max()
+    e0, e1 = np.abs(g0.cpu().numpy() - ref).max() / scale, np.abs(g1.cpu().numpy() - ref).max() / scale
+    # (one fp32 chain over the R rows against a0_dense_wgrad's sum of shorter chains: a few ulp of the scale either way; measured 8.8e-7 / 1.5e-7 at R = 512, N = 800)
+    assert e0 < 2e-6 and e1 < 2e-6, f"weight gradient {e1} of the scale against fp64 (a0_dense_wgrad: {e0})"
 
 
 def test_sumtree_sample_batch_equals_separate_kernels(hip):

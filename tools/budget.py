@@ -64,6 +64,8 @@ def model(cfg):
         "a0_actor_step_enc_kernel": ("actor tail + env step + replay row, then the new observation's encoder (main schedule, scalar heads: steps 1..T-1)", "mfma16 issue + hbm",
                                      ENC_TILE_CYC / GHZ * 1e6 + hbm_us(E * (OBS + 3 * OBS) + 8 * E * 512 * 4), "the two phases are serial per workgroup (one env per CU): the encoder's issue floor plus the tail's traffic; "
                                      "saves the boundary between a0_actor_qhead_env_kernel and a0_encoder_fused_kernel (~4 us per step)"),
+        "a0_actor_dist_step_enc_kernel": ("distributional actor tail + env step + replay row, then the new observation's encoder (main schedule, c51 / qr: steps 1..T-1)", "mfma16 issue + hbm",
+                                          ENC_TILE_CYC / GHZ * 1e6 + hbm_us(E * (OBS + 3 * OBS) + 8 * E * Npad * 4), "as a0_actor_step_enc_kernel, head slabs instead of fc1 slabs"),
         "a0_actor_dist_tail_env_kernel": ("distributional actor tail + env step + replay row", "hbm", hbm_us(E * (OBS + 3 * OBS) + 8 * E * Npad * 4), "as above, head slabs instead of fc1 slabs"),
         "a0_reduce_bias_act_kernel": ("fc1 slab sum + bias + ReLU (dist actors)", "launch", LAUNCH, "16 x 0.5 MB of slabs: 1.3 us of traffic under a launch floor"),
         "a0_igemm_x9_group_kernel": (f"{npass} grouped fc1 GEMMs 512 x 512 x 3136 (and, c51 / qr, the grouped head GEMMs)", "mfma32 issue", mfma_us(gemm(B, 512, FEAT, npass) * X9), "fc1 group; the head group is smaller"),
@@ -95,10 +97,10 @@ def model(cfg):
 # launches per iteration (80 actor steps, 20 updates; NoisyNet: a reset every 4 actor steps and one per update)
 def per_iteration(cfg, name):
     noisy = cfg == "c51"
-    if name.startswith("a0_actor_step_enc_kernel"):
+    if name.startswith(("a0_actor_step_enc_kernel", "a0_actor_dist_step_enc_kernel")):
         return 79
-    if name.startswith(("a0_encoder_fused_kernel", "a0_actor_qhead_env_kernel")) and cfg in ("dqn", "mdqn"):
-        return 1                     # a rollout's first encoder and last tail; the 79 steps between run a0_actor_step_enc_kernel
+    if name.startswith(("a0_encoder_fused_kernel", "a0_actor_qhead_env_kernel", "a0_actor_dist_tail_env_kernel")):
+        return 1                     # a rollout's first encoder and last tail; the 79 steps between run a0_actor_step_enc_kernel / a0_actor_dist_step_enc_kernel
     if name.startswith(("a0_encoder_fused_kernel", "a0_actor_qhead_env_kernel", "a0_actor_dist_tail_env_kernel", "a0_reduce_bias_act_kernel")):
         return 80
     if name.startswith("a0_igemm_x9_kernel<OpMatKC, OpMatKC, EpiSlab"):
@@ -130,6 +132,8 @@ def main():
         per_iter = per_iteration(cfg, name)
         hit = next((k for k in md if name.startswith(k)), None)
         if hit is None or per_iter == 0:
+            if hit is None and name.startswith("a0_") and calls > 20:
+                print(f"(no model row for {name.split('(')[0]}: {calls} calls x {avg:.1f} us)", file=sys.stderr)
             continue
         what, bound, floor, note = md[hit]
         floor = max(floor, LAUNCH)
