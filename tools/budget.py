@@ -69,6 +69,10 @@ def model(cfg):
         "a0_actor_dist_tail_env_kernel": ("distributional actor tail + env step + replay row", "hbm", hbm_us(E * (OBS + 3 * OBS) + 8 * E * Npad * 4), "as above, head slabs instead of fc1 slabs"),
         "a0_reduce_bias_act_kernel": ("fc1 slab sum + bias + ReLU (dist actors)", "launch", LAUNCH, "16 x 0.5 MB of slabs: 1.3 us of traffic under a launch floor"),
         "a0_igemm_x9_group_kernel": (f"{npass} grouped fc1 GEMMs 512 x 512 x 3136 (and, c51 / qr, the grouped head GEMMs)", "mfma32 issue", mfma_us(gemm(B, 512, FEAT, npass) * X9), "fc1 group; the head group is smaller"),
+        "a0_igemm_x9_trio_kernel": ("fc1 data gradient + fc1 weight gradient + the head's weight gradient, one launch (scalar heads)", "mfma32 issue", mfma_us((gemm(B, 512, FEAT, 2) + gemm(B, Npad, 512)) * X9),
+                                    "the pair below with the head's 8 tiles as a third problem in grid row 0"),
+        "a0_igemm_x9_pair_kernel<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2": ("the head's data gradient + weight gradient side by side (c51 / qr)", "mfma32 issue",
+                                    max(LAUNCH, mfma_us(gemm(B, 512, Npad, 2) * X9)), "64 + 32 (c51) / 104 (qr) tiles of 64 x 64 in one round; lasts as long as the longer k loop"),
         "a0_igemm_x9_pair_kernel": ("fc1 data gradient + weight gradient, one launch", "mfma32 issue", mfma_us(gemm(B, 512, FEAT, 2) * X9), "2 x 1.64 GFLOP x 9; 784 workgroups on 512 slots"),
         "a0_igemm_x9_kernel<OpMatKC, OpMatXC, EpiMaskMat": ("head / fc1 data gradient (unpaired launches)", "mfma32 issue", mfma_us(gemm(B, 512, max(Npad, 512)) * X9), ""),
         "a0_igemm_x9_kernel<OpMatXC, OpMatXC, EpiWgradSlab": ("fc1 weight gradient (unpaired launches: probe pass)", "mfma32 issue", mfma_us(gemm(B, 512, FEAT) * X9), ""),
@@ -111,10 +115,9 @@ def per_iteration(cfg, name):
         return 20 if cfg in ("dqn", "mdqn") else 40
     if name.startswith(("a0_mean_rows_kernel", "a0_sumtree_set_range_kernel", "a0_sample_slots_multi_kernel")):
         return 1
-    if name.startswith(("a0_sample_gather_kernel", "a0_igemm_x9_kernel<OpMatXC, OpMatXC, EpiWgradSlab")):
-        return 0                     # bench metric 2 / probe pass only
-    if name.startswith("a0_igemm_x9_kernel<OpMatKC, OpMatXC, EpiMaskMat"):
-        return 0 if cfg in ("dqn", "mdqn") else 20      # dqn: the head's data gradient comes from the loss kernel; c51 / qr: one GEMM per update
+    if name.startswith(("a0_sample_gather_kernel", "a0_igemm_x9_kernel<OpMatXC, OpMatXC, EpiWgradSlab", "a0_igemm_x9_kernel<OpMatKC, OpMatXC, EpiMaskMat",
+                        "a0_igemm_kernel<OpMatXC, OpMatXC, EpiWgradSlab")):
+        return 0                     # bench metric 2 / probe pass only (the unpaired gradient GEMMs: pair and trio launches are off while the probe brackets kernels)
     return 20
 
 
