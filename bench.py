@@ -485,6 +485,8 @@ def main():
                           f"a0_igemm_x9_kernel, every launch tagged {pr['kernel']} (the dense layers' GEMMs of this pass direction: fc1 512 x 3136 over B*N rows and the heads; "
                           "the cosine embedding 3136 x 64 runs in the store-bound a0_short_k_fwd_kernel and is not part of this family; both fp32 operands split exactly into three bf16 terms, nine v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation; "
                           "FLOPs = 2*M*N*K counted once, peak = fp32 MFMA)",
+                "frac_note": "`frac` prices every MAC once against the fp32 MFMA peak, the bound of an fp32-input kernel; this kernel reaches (and on a fast box exceeds) it because it "
+                             "issues exact bf16-term products on the 16x faster bf16 pipe — `issued_bf16.frac` is its utilisation of the pipe it actually runs on",
                 "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
                 "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor launch) or x 1024 (learner launch: the update's target and online passes of 512 observations in one launch; 1536 with double-Q)"
                                                if pr["kernel"] == "encoder_fused" else f"2*M*N*K per launch; {pr['flop'] / max(pr['launches'], 1) / 1e9:.2f} GFLOP average over the launch mix",
