@@ -766,6 +766,58 @@ constexpr int A0_X9_XCH1 = A0_X9_BIAS_OFF + 160 * 4;        // region 1: behind 
 static_assert(A0_X9_XCH0 + 4 * 3 * 1024 <= 2 * 4 * 84 * 84, "conv2 exchange region 0 fits into the image");
 constexpr int A0_X9_LDS_BYTES = A0_X9_XCH1 + (A0_KSPLIT ? 4 * (2 * 64 + 4) * 16 : 0);
 static_assert(A0_X9_LDS_BYTES <= 160 * 1024, "LDS");
+// conv2 + conv3 of the split-operand encoder for observation b, behind conv1's epilogue (act1 term planes in LDS): shared by a0_encoder_fused_x9_body and the actor-step
+// kernel that overlaps conv1 with the step's tail (a0_actor_step_enc2_kernel).
+#if A0_KSPLIT
+typedef a0_wring9<64, 4, A0_RK2, 2> a0_ring2_t;      // 8 own steps of conv2's 16
+typedef a0_wring9<64, 4, A0_RK3, 2> a0_ring3_t;      // 9 own steps of conv3's 18
+#else
+typedef a0_wring9<64, A0_WNX, A0_RX2> a0_ring2_t;
+typedef a0_wring9<64, A0_WNX, A0_RX3> a0_ring3_t;
+#endif
+template <int MBW2, int MBW3, bool LOOP>
+A0_D void a0_x9_conv23(const a0_fused_args& P, int b, unsigned char* smem, float* bias_lds, a0_wring1<A0_R1>& ring1, a0_ring2_t& ring2, a0_ring3_t& ring3) {
+    const int obs_bytes = P.C * P.H * P.W;
+    const int M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
+    uint16_t* a1p = (uint16_t*)(smem + 2 * obs_bytes);
+    constexpr int term1 = 20 * A0_RP1X, term2 = 9 * A0_RP2X;
+    uint16_t* a2p = (uint16_t*)smem;
+    typedef EpiFwdX<9, A0_P2X, A0_RP2X, term2> E2X;
+    constexpr int WNX = A0_WNX, WMGX = A0_FUSED_WAVES / WNX;
+    constexpr int MBW2X = (6 + WMGX - 1) / WMGX, MBW3X = (4 + WMGX - 1) / WMGX;
+    static_assert(MBW2X <= MBW2 * 2 && MBW3X <= MBW3 * 2, "84x84 geometry");
+#if !A0_KSPLIT
+    a0_pre<64, WNX, MBW2X, E2X> pre2;
+    a0_pre<64, WNX, MBW3X, EpiFwdT> pre3;
+#endif
+    (void)a1p; (void)term1;
+    {
+        const AF2X<term1> f2{a1p, A0_RP1X, P.W2, A0_P1X};
+        const E2X e2{bias_lds + 32, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
+#if A0_KSPLIT
+        // exchange buffers, all dead while their stage's k loops run: conv2's partial sums go behind the act2 planes-to-be (the top 12 KB of the
+        // image region) and into the tail of the LDS allocation, conv3's where act1 was
+        const AF3X<term2> f3k{a2p, A0_RP2X, P.W3, A0_P2X};
+        const EpiFwdT e3k{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
+        a0_conv_stage_x9k<64, 4, 6, A0_RK2, 1>(f2, M2, ring2, e2, (float*)(smem + A0_X9_XCH0), (float*)(smem + A0_X9_XCH1), [&] { ring3.prologue(); });
+        a0_conv_stage_x9k<64, 4, 4, A0_RK3, 16>(f3k, M3, ring3, e3k, (float*)a1p, (float*)a1p + 4 * 2 * 256, [&] { if (LOOP) ring1.prologue(); });
+#else
+        const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
+        constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
+        if (uneven2 && wmgx + (MBW2X - 1) * WMGX >= 6)
+            a0_conv_stage_x9<64, WNX, (MBW2X > 1 ? MBW2X - 1 : 1), A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+        else
+            a0_conv_stage_x9<64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+        const AF3X<term2> f3{a2p, A0_RP2X, P.W3, A0_P2X};
+        const EpiFwdT e3{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
+        if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
+            a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
+        else
+            a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
+#endif
+    }
+}
+
 // LOOP: the workgroup walks over several observations (b += gridDim.x; launches of more observations than CUs) and requests the next
 // observation's conv1 weights behind conv3; without it (the actor's launches: one observation per workgroup) that request is not made.
 // bid / nblk: this workgroup's index among the workgroups that serve P and their number (blockIdx.x / gridDim.x for a launch of one pass;
@@ -792,12 +844,9 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
     a0_wring1<A0_R1> ring1;
 #if A0_KSPLIT
     static_assert(WNX == 4 && A0_FUSED_WAVES == 8, "N-stationary stages: four waves along N, two along K");
-    a0_wring9<64, 4, A0_RK2, 2> ring2;      // 8 own steps of conv2's 16
-    a0_wring9<64, 4, A0_RK3, 2> ring3;      // 9 own steps of conv3's 18
-#else
-    a0_wring9<64, WNX, A0_RX2> ring2;
-    a0_wring9<64, WNX, A0_RX3> ring3;
 #endif
+    a0_ring2_t ring2;
+    a0_ring3_t ring3;
     ring1.init(P.wt1, P.C);
     ring2.init(P.wx2, 512);
     ring3.init(P.wx3, 576);
@@ -805,10 +854,6 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
     constexpr int MBW1X = (25 + A0_WMG1 - 1) / A0_WMG1;
     static_assert(A0_FUSED_WAVES != 8 || MBW1X == MBW1, "84x84 geometry");
     a0_pre<32, 2, MBW1X, E1X> pre1;           // (empty: these epilogues take nothing from global memory)
-#if !A0_KSPLIT
-    a0_pre<64, WNX, MBW2X, E2X> pre2;
-    a0_pre<64, WNX, MBW3X, EpiFwdT> pre3;
-#endif
     float* bias_lds = (float*)(smem + A0_X9_BIAS_OFF);      // b1 | b2 | b3 behind the activation planes; visible after the first barrier below
     if (threadIdx.x < 160) bias_lds[threadIdx.x] = threadIdx.x < 32 ? P.b1[threadIdx.x] : threadIdx.x < 96 ? P.b2[threadIdx.x - 32] : P.b3[threadIdx.x - 96];
     // the pad channels (32..39 / 64..71) of the term planes are never read; nothing to initialise
@@ -848,29 +893,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
             a0_conv1_stage<(MBW1X > 1 ? MBW1X - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
             a0_conv1_stage<MBW1X, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
-        const AF2X<term1> f2{a1p, A0_RP1X, P.W2, A0_P1X};
-        const E2X e2{bias_lds + 32, a2p, P.act2 ? P.act2 + (long long)b * M2 * 64 : nullptr, 64};
-#if A0_KSPLIT
-        // exchange buffers, all dead while their stage's k loops run: conv2's partial sums go behind the act2 planes-to-be (the top 12 KB of the
-        // image region) and into the tail of the LDS allocation, conv3's where act1 was
-        const AF3X<term2> f3k{a2p, A0_RP2X, P.W3, A0_P2X};
-        const EpiFwdT e3k{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
-        a0_conv_stage_x9k<64, 4, 6, A0_RK2, 1>(f2, M2, ring2, e2, (float*)(smem + A0_X9_XCH0), (float*)(smem + A0_X9_XCH1), [&] { ring3.prologue(); });
-        a0_conv_stage_x9k<64, 4, 4, A0_RK3, 16>(f3k, M3, ring3, e3k, (float*)a1p, (float*)a1p + 4 * 2 * 256, [&] { if (LOOP) ring1.prologue(); });
-#else
-        const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
-        constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
-        if (uneven2 && wmgx + (MBW2X - 1) * WMGX >= 6)
-            a0_conv_stage_x9<64, WNX, (MBW2X > 1 ? MBW2X - 1 : 1), A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
-        else
-            a0_conv_stage_x9<64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
-        const AF3X<term2> f3{a2p, A0_RP2X, P.W3, A0_P2X};
-        const EpiFwdT e3{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
-        if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
-            a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
-        else
-            a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
-#endif
+        a0_x9_conv23<MBW2, MBW3, LOOP>(P, b, smem, bias_lds, ring1, ring2, ring3);
         if constexpr (!LOOP) break;
     }
 }
@@ -939,6 +962,268 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     a0_encoder_fused_x9_body<7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ---- Round 5, second form: the step's tail BESIDE conv1 (scalar heads).  In a0_actor_step_enc_kernel seven waves copy frames and then wait for wave 0's latency chain
+// (slab sums, head, Philox, n-step bookkeeping) before anyone touches the matrix pipe.  But three of the new observation's four channels are the OLD stack's frames
+// 1..3 — known when the kernel starts — and conv1's reduction runs channel by channel (MFMA steps 2c, 2c + 1 = channel c): so the frame waves put those channels
+// into the LDS image themselves (from the registers they copy the stack with) and run conv1's steps 0..5 while wave 0 is in the tail; behind the barrier that
+// publishes the action the workgroup adds the newest frame's steps 6, 7.  Same MFMAs on the same operands in the same k order per accumulator: bit-identical features.
+//   barrier 0: start of the kernel (zeroes the counter below);
+//   "barrier 1": the seven frame waves meet through a counter in LDS — a workgroup barrier would hold wave 0's chain until their staging is done;
+//   barrier 2: wave 0's tail is done (action, chase cell);  barrier 3 (chase only): the action-dependent new frame is in LDS.
+// A terminal step of the chase task (all four channels = the new frame, which needs the action) runs the whole of conv1 behind barrier 3; wave 0 catches up on its own
+// row blocks' steps 0..5 behind barrier 2.  The frame waves issue their global stores BEHIND steps 0..5: loads and stores share vmcnt on this part and complete out of
+// order, so behind a pending store every wait for a weight fragment is a wait for the stores' acknowledgements.
+// Measured (profiles/r05_experiments.md): 32.3 -> 31.1 us per launch by the kernel trace.  Timing-only builds of this kernel: without the 21.7 MB of stores 29.9 us,
+// without the head's evaluation 30.7, without both and without wave 0's catch-up 28.7 — the floor of the structure; the stand-alone encoder is 25.7.
+A0_D void a0_bytes16_to_img(uint16_t* img, int idx16, const uint4 v) {      // 16 pixels -> 16 bf16 (exact) at element 16 * idx16 of the [4][84 * 84] image
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t f0 = __float_as_uint((float)(w[k] & 0xffu)), f1 = __float_as_uint((float)((w[k] >> 8) & 0xffu));
+        const uint32_t f2 = __float_as_uint((float)((w[k] >> 16) & 0xffu)), f3 = __float_as_uint((float)(w[k] >> 24));
+        o[2 * k] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+        o[2 * k + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+    }
+    ((uint4*)img)[2 * idx16] = uint4{o[0], o[1], o[2], o[3]};
+    ((uint4*)img)[2 * idx16 + 1] = uint4{o[4], o[5], o[6], o[7]};
+}
+
+// a0_conv1_stage for the 4 x 84 x 84 image with the k loop cut behind step 5: steps 0..5 (channels 0..2) run before `mid()` on waves with first_before_mid, behind it on
+// the others; steps 6, 7 behind it on all.  Same fetch / MFMA / ring-fill sequence per step as a0_conv1_stage.
+template <int MBW, class EPI, class Mid, class Between>
+A0_D void a0_conv1_stage_split(const uint16_t* img, a0_wring1<A0_R1>& ring, const EPI& epi, bool first_before_mid, Mid&& mid, Between&& between) {
+    static_assert(A0_R1 == 4 && EPI::TR, "ring of four steps, transposed accumulators");
+    constexpr int HW = 84 * 84, W = 84, W1 = 20, M = 400, MB = 25;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % 2, wmg = wave / 2;
+    const int q = lane >> 4, r16 = lane & 15;
+    int rows[MBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        int m = (wmg + i * A0_WMG1) * 16 + r16;
+        m = m < M ? m : 0;
+        const int oh = m / W1, ow = m - oh * W1;
+        rows[i] = (4 * oh + q) * W + 4 * ow;
+    }
+    a0_acc4 acc[MBW];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) acc[i] = a0_acc4{0.f, 0.f, 0.f, 0.f};
+    uint2 a[2][MBW][2];
+    auto fetch = [&](int slot, int off) {
+#pragma unroll
+        for (int i = 0; i < MBW; ++i) {
+            a[slot][i][0] = *(const uint2*)(img + rows[i] + off);
+            a[slot][i][1] = *(const uint2*)(img + rows[i] + off + 4);
+        }
+    };
+    auto off_of = [&](int st) { return (st >> 1) * HW + (st & 1) * 4 * W; };
+    auto step = [&](auto UC, int off_next) {      // ring slot u = step % 4, fragments in a[u & 1]; requests the next step's fragments first
+        constexpr int u = decltype(UC)::value;
+        fetch((u + 1) & 1, off_next);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int i = 0; i < MBW; ++i) {
+                const a0_u32x4 av = {a[u & 1][i][0].x, a[u & 1][i][0].y, a[u & 1][i][1].x, a[u & 1][i][1].y};
+                const a0_u32x4 bv = {ring.v[u][s3].x, ring.v[u][s3].y, ring.v[u][s3].z, ring.v[u][s3].w};
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[i], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        ring.fill(u);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> U0; typedef std::integral_constant<int, 1> U1; typedef std::integral_constant<int, 2> U2; typedef std::integral_constant<int, 3> U3;
+    auto steps05 = [&] {
+        fetch(0, off_of(0));
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see a0_conv_stage (here also the frame waves' stores)
+        step(U0{}, off_of(1)); step(U1{}, off_of(2)); step(U2{}, off_of(3)); step(U3{}, off_of(4));
+        step(U0{}, off_of(5)); step(U1{}, off_of(5));      // (the last request re-reads step 5: channel 3 may not be there yet)
+    };
+    if (first_before_mid) steps05();
+    mid();
+    if (!first_before_mid) steps05();
+    fetch(0, off_of(6));
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    step(U2{}, off_of(7)); step(U3{}, off_of(7));
+    between();
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+        const int mb = wmg + i * A0_WMG1;
+        if (mb < MB) {
+            const int m = mb * 16 + r16;
+            if (m < M) epi.emit_n4(m, wn * 16 + 4 * q, acc[i], nullptr);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_step_enc2_kernel(a0_qenv_args Q, a0_step_enc_args N) {
+    __shared__ float raw[64];
+    __shared__ int s_chase_cell;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HW = 84 * 84, G16 = HW / 16;      // 441 sixteen-byte groups per frame
+    uint16_t* img = (uint16_t*)smem;
+    uint16_t* a1p = (uint16_t*)(smem + 2 * 4 * HW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t e = blockIdx.x;
+    // ---- the encoder's set-up: weight rings, biases (a0_encoder_fused_x9_body)
+    a0_fused_args P;
+    P.frames = nullptr; P.slot = nullptr; P.sample_stride = 4 * HW; P.chan_off = 0;
+    P.wt1 = N.wt; P.wt2 = N.wt + 48LL * 4 * 64; P.wt3 = P.wt2 + 64LL * 512;
+    P.wx2 = P.wt3 + 64LL * 576 + 64LL * 576 + 4LL * 32 * 256; P.wx3 = P.wx2 + 96LL * 512;
+    P.b1 = N.b1; P.b2 = N.b2; P.b3 = N.b3;
+    P.act1 = nullptr; P.act2 = nullptr; P.act3 = N.act3; P.B = Q.E;
+    P.C = 4; P.H = 84; P.W = 84; P.H1 = 20; P.W1 = 20; P.H2 = 9; P.W2 = 9; P.H3 = 7; P.W3 = 7;
+    P.off_act1 = 0; P.off_act2 = 0; P.off_end = 0; P.rp1 = 0; P.rp2 = 0;
+    a0_wring1<A0_R1> ring1;
+    a0_ring2_t ring2;
+    a0_ring3_t ring3;
+    ring1.init(P.wt1, 4);
+    ring1.prologue();
+    float* bias_lds = (float*)(smem + A0_X9_BIAS_OFF);
+    if (tid < 160) bias_lds[tid] = tid < 32 ? P.b1[tid] : tid < 96 ? P.b2[tid - 32] : P.b3[tid - 96];
+    // (conv2's / conv3's rings are set up behind the step: their pointers wait in vector registers, the scalar file is the tail's until then)
+    unsigned long long v_wx2 = (unsigned long long)P.wx2, v_wx3 = (unsigned long long)P.wx3;
+    A0_TO_VGPR(v_wx2); A0_TO_VGPR(v_wx3);
+    // ---- the step (a0_actor_qhead_env_body)
+    const int NQ = Q.A + (Q.dueling ? 1 : 0);
+    uint32_t g = Q.g; long long steps = Q.steps, start = Q.start; unsigned long long off_a = Q.off_a, off_u = Q.off_u; float eps = Q.eps;
+    if (Q.ctrl) {
+        g += (uint32_t)Q.ctrl[A0_CTRL_ENV_STEP]; steps += Q.ctrl[A0_CTRL_ACTOR_STEPS]; start += Q.ctrl[A0_CTRL_REPLAY_SLOT];
+        off_a += (unsigned long long)Q.ctrl[A0_CTRL_RNG_ACTION]; off_u += (unsigned long long)Q.ctrl[A0_CTRL_RNG_UNIFORM];
+    }
+    if (Q.eps_ptr) eps = Q.eps_ptr[0];
+    const long long slot = (start + e) % Q.cap;
+    uint32_t e_v = e;
+    asm volatile("" : "+v"(e_v));
+    const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)Q.env_seed, (uint32_t)(Q.env_seed >> 32) ^ Q.rank);
+    const bool term = __builtin_amdgcn_readfirstlane((int)((x.y % 500u) == 0u)) != 0;
+    const bool chase = Q.task == A0_ENV_TASK_CHASE;
+    const bool early = !(chase && term);
+    // frame work of waves 1..7: lane j < 441 owns sixteen-byte group j of every frame
+    const int j = tid - 64;
+    // (recomputed at each use: kept, the lane mask would sit in a scalar register pair across the tail — one more than the file has)
+    auto has_group = [&] { int jj = j; asm volatile("" : "+v"(jj)); return wave != 0 && jj < G16; };
+    const uint32_t pbase = (uint32_t)Q.env_seed ^ a0_env_mix32(e * 0x9E3779B1u + g);
+    // (per-lane pointers: vector registers — the scalar file holds the tail's and the encoder's uniform values at the same time here)
+    uint4* out16 = (uint4*)(Q.obs_out + (size_t)e * 4 * HW) + j;
+    uint4* row16 = (uint4*)(Q.frames + slot * (8LL * HW)) + j;
+    A0_TO_VGPR(out16); A0_TO_VGPR(row16);
+    float* act3_v = N.act3;
+    A0_TO_VGPR(act3_v);
+    auto new_group = [&](uint32_t by, uint32_t bx) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = 16u * (uint32_t)j + 4u * (uint32_t)k;
+            w[k] = (uint32_t)a0_env_pixel(pbase, by, bx, p, chase) | ((uint32_t)a0_env_pixel(pbase, by, bx, p + 1, chase) << 8) |
+                   ((uint32_t)a0_env_pixel(pbase, by, bx, p + 2, chase) << 16) | ((uint32_t)a0_env_pixel(pbase, by, bx, p + 3, chase) << 24);
+        }
+        return uint4{w[0], w[1], w[2], w[3]};
+    };
+    auto put = [&](int c, const uint4 v) {      // channel c of the new observation: global stack, replay row's st_next half, LDS image
+        out16[c * G16] = v; row16[(4 + c) * G16] = v;
+        a0_bytes16_to_img(img, c * G16 + j, v);
+    };
+    // the frame waves meet each other WITHOUT wave 0 (a workgroup barrier would hold wave 0's latency chain until their staging is done): a counter in LDS
+    __shared__ int s_staged;
+    if (tid == 0) s_staged = 0;
+    __syncthreads();      // barrier 0: at the kernel's start, nobody waits
+    uint4 keep[9];        // the frame waves' global stores are issued BEHIND conv1's first steps (gfx9 counts stores and loads together: pending stores would make the
+                          // stage's first wait for its weights a wait for their acknowledgements)
+    if (wave == 0) {
+        a0_env_pre Z;
+        a0_env_commit_prefetch(Z, e, Q.E, Q.n, steps, Q.ep_ret, Q.ring_act, Q.ring_rew, Q.ring_done);
+        a0_env_pre_to_vgpr(Z);
+        const a0_env_out O = a0_env_out_vgpr(Q.ep_ret, Q.final_mask, Q.final_ret, Q.ring_act, Q.ring_rew, Q.ring_done, Q.r_act, Q.r_rew, Q.r_done);
+        A0_TO_VGPR(steps); A0_TO_VGPR(off_a); A0_TO_VGPR(off_u); A0_TO_VGPR(eps);
+        int n_v = Q.n, E_v = Q.E, task_v = Q.task; double gamma_v = Q.gamma; int* action_v = Q.action; float* qmax_v = Q.qmax;
+        A0_TO_VGPR(n_v); A0_TO_VGPR(E_v); A0_TO_VGPR(task_v); A0_TO_VGPR(gamma_v); A0_TO_VGPR(action_v); A0_TO_VGPR(qmax_v);
+        float* w2s = (float*)a1p;      // the head's rows, wave-private, where conv1's epilogue will write act1 (behind barrier 2)
+#pragma unroll 4
+        for (int i = lane; i < NQ * 128; i += 64) ((a0_f4*)w2s)[i] = ((const a0_f4*)Q.W2)[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int act = 0; float best = 0.f;
+        a0_qhead_wave(Q.slabs, Q.slab_stride, Q.nslab, Q.b1, w2s, Q.b2, Q.A, Q.dueling, (int)e, lane, raw, Q.rng_seed, Q.stream_a, Q.stream_u, off_a, off_u, eps, act, best);
+        if (lane == 0) {
+            action_v[e] = act; qmax_v[e] = best;
+            float r_chase = 0.f;
+            if (chase) s_chase_cell = a0_chase_step(a0_chase_cell(Q.obs_in + ((size_t)e * 4 + 3) * A0_ENV_PIX, e), act, x.w, r_chase);
+            a0_env_commit_finish(Z, x, e, g, task_v, Q.A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
+                                 O.r_done, slot, r_chase);
+        }
+    } else {
+        if (has_group()) {
+            const uint4* in16 = (const uint4*)(Q.obs_in + (size_t)e * 4 * HW) + j;
+            A0_TO_VGPR(in16);
+            const uint4 i0 = in16[0], i1 = in16[G16], i2 = in16[2 * G16], i3 = in16[3 * G16];
+            if (Q.obs0 == Q.obs_in) { keep[0] = i0; keep[1] = i1; keep[2] = i2; keep[3] = i3; }
+            else {
+                const uint4* o016 = (const uint4*)(Q.obs0 + (size_t)e * 4 * HW) + j;
+                A0_TO_VGPR(o016);
+                keep[0] = o016[0]; keep[1] = o016[G16]; keep[2] = o016[2 * G16]; keep[3] = o016[3 * G16];
+            }
+            if (!chase) {
+                const uint4 nw = new_group((3u * g + 11u * e) % 77u, (5u * g + 7u * e) % 77u);
+                if (term) { keep[4] = nw; keep[5] = nw; keep[6] = nw; } else { keep[4] = i1; keep[5] = i2; keep[6] = i3; }
+                keep[7] = nw;
+                for (int c = 0; c < 4; ++c) a0_bytes16_to_img(img, c * G16 + j, keep[4 + c]);
+            } else if (!term) {
+                keep[4] = i1; keep[5] = i2; keep[6] = i3;
+                for (int c = 0; c < 3; ++c) a0_bytes16_to_img(img, c * G16 + j, keep[4 + c]);
+            }
+        }
+        // "barrier 1" among the seven frame waves: their parts of the image are in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(&s_staged, 1);
+        while (__builtin_amdgcn_readfirstlane(*(volatile int*)&s_staged) < A0_FUSED_WAVES - 1) __builtin_amdgcn_s_sleep(1);
+    }
+    auto early_stores = [&] {      // everything of the step's frame traffic that does not wait for the action
+        if (has_group()) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) row16[c * G16] = keep[c];
+            const int nc = !chase ? 4 : (!term ? 3 : 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nc) { out16[c * G16] = keep[4 + c]; row16[(4 + c) * G16] = keep[4 + c]; }
+        }
+    };
+    auto mid = [&] {
+        if (wave != 0) early_stores();
+        __syncthreads();      // barrier 2
+        if (chase) {
+            if (has_group()) {
+                uint32_t by, bx;
+                a0_chase_pos(s_chase_cell, by, bx);
+                const uint4 nw = new_group(by, bx);
+                if (term) { put(0, nw); put(1, nw); put(2, nw); }
+                put(3, nw);
+            }
+            __syncthreads();      // barrier 3
+        }
+    };
+    auto uni = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull));
+    };
+    ring2.init((const float*)uni(v_wx2), 512);
+    ring3.init((const float*)uni(v_wx3), 576);
+    typedef EpiFwdX<20, A0_P1X, A0_RP1X, 20 * A0_RP1X> E1X;
+    const E1X e1{bias_lds, a1p, nullptr, 32};
+    constexpr int MBW1X = (25 + A0_WMG1 - 1) / A0_WMG1;
+    const bool before = early && wave != 0;
+    if (MBW1X > 1 && wave / 2 + (MBW1X - 1) * A0_WMG1 >= 25)
+        a0_conv1_stage_split<(MBW1X > 1 ? MBW1X - 1 : 1)>(img, ring1, e1, before, mid, [&] { ring2.prologue(); });
+    else
+        a0_conv1_stage_split<MBW1X>(img, ring1, e1, before, mid, [&] { ring2.prologue(); });
+    P.act3 = (float*)uni((unsigned long long)act3_v);
+    a0_x9_conv23<3, 2, false>(P, (int)e, smem, bias_lds, ring1, ring2, ring3);
+}
+
 static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_bytes);
 int a0_actor_dist_step_enc_launch(const a0_dtenv_args& Q, size_t tail_lds, const float* wt, const a0_encoder_weights* w, float* act3, hipStream_t st) {
     a0_fused_args P;
@@ -975,7 +1260,16 @@ int a0_actor_step_enc_launch(const a0_qenv_args& Q, const float* wt, const a0_en
             return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step_enc: LDS");
         configured = lds;
     }
+    static const int form = getenv("A0_STEP_ENC") ? atoi(getenv("A0_STEP_ENC")) : 2;      // tuning aid: 1 = tail, barrier, whole encoder (the first form); 2 = conv1's channels 0..2 beside the tail
+    static size_t configured2 = 0;
+    if (form != 1 && lds > configured2) {
+        if (hipFuncSetAttribute((const void*)a0_actor_step_enc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step_enc: LDS");
+        configured2 = lds;
+    }
     const bool probed = a0_probe_start(A0_TAG_ACTOR_STEP_ENC, st);
+    if (form != 1) hipLaunchKernelGGL(a0_actor_step_enc2_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
+    else
     hipLaunchKernelGGL(a0_actor_step_enc_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
     if (probed) a0_probe_stop(st, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_qhead_env_step_enc");
