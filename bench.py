@@ -331,7 +331,7 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             pr = tr.ops.probe_end()
-        # round 5: on the `main` schedule the actor's steps 1..T-1 encode inside the tail + env-step kernel (a0_actor_step_enc_kernel, its own probe family, so that
+        # round 5: on the `main` schedule the actor's steps 1..T-1 encode inside the tail + env-step kernel (a0_actor_step_enc2_kernel, its own probe family, so that
         # the encoder's line above keeps the pure encoder launches rocprofv3 lists as a0_encoder_fused_*): one more repeat brackets that kernel
         pr_step = None
         if probe_kernel == "encoder_fused" and not dp:
@@ -497,8 +497,8 @@ def main():
     if roof is not None and pr_step is not None:
         us = 1e3 * pr_step["ms"] / pr_step["launches"]
         roof["actor_step_kernel"] = {
-            "kernel": "a0_actor_step_enc_kernel (a0_actor_qhead_env_step_enc: Q head + action + env step + frame commit of step t, then conv1+conv2+conv3 of the env's new "
-                      "observation, one workgroup per env)", "launches": pr_step["launches"], "avg_us": round(us, 2),
+            "kernel": "a0_actor_step_enc2_kernel (a0_actor_qhead_env_step_enc: Q head + action + env step + frame commit of step t beside conv1's first three channels, then the rest of "
+                      "conv1 + conv2 + conv3 of the env's new observation, one workgroup per env)", "launches": pr_step["launches"], "avg_us": round(us, 2),
             "encoder_flop_rate": {"achieved": round(pr_step["flop"] / (pr_step["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                   "note": "the encoder's 15.47 MFLOP per observation over the WHOLE kernel's duration (tail and env step included): a lower bound on its encoder phase"},
             "replaces": "a0_actor_qhead_env_kernel + a0_encoder_fused_kernel<grid 256> of the three-launch step (A0_STEP_ENC=0); profiles/ carries both durations"}

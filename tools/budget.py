@@ -61,8 +61,8 @@ def model(cfg):
                                                                        "Unsplit (bias + ReLU in the epilogue, no slabs) would be 32 workgroups x 98 k tiles = 23.5 us: split-K wins"),
         "a0_igemm_x9_kernel<OpMatKC, OpMatKC, EpiSlab, 4, 1, 1, 2, 2>": ("actor fc1 (c51 / qr: a0_dense_fwd, 16 slabs)", "mfma32 issue", mfma_us(gemm(E, 512, FEAT) * X9), "as above"),
         "a0_actor_qhead_env_kernel": ("actor tail + env step + replay row, 256 envs", "hbm", hbm_us(E * (OBS + 3 * OBS) + 8 * E * 512 * 4), "28 KB read + 85 KB written per env, + the fc1 slabs; wave 0's serial tail (slab sums, head, Philox, n-step) is the critical path"),
-        "a0_actor_step_enc_kernel": ("actor tail + env step + replay row, then the new observation's encoder (main schedule, scalar heads: steps 1..T-1)", "mfma16 issue + hbm",
-                                     ENC_TILE_CYC / GHZ * 1e6 + hbm_us(E * (OBS + 3 * OBS) + 8 * E * 512 * 4), "the two phases are serial per workgroup (one env per CU): the encoder's issue floor plus the tail's traffic; "
+        "a0_actor_step_enc": ("actor tail + env step + replay row, then the new observation's encoder (main schedule, scalar heads: steps 1..T-1)", "mfma16 issue + hbm",
+                                     ENC_TILE_CYC / GHZ * 1e6 + hbm_us(E * (OBS + 3 * OBS) + 8 * E * 512 * 4), "the encoder's issue floor plus the tail's traffic (a0_actor_step_enc2_kernel runs conv1's channels 0..2 beside the tail; timing-only builds: 28.7 us without stores, tail and catch-up); "
                                      "saves the boundary between a0_actor_qhead_env_kernel and a0_encoder_fused_kernel (~4 us per step)"),
         "a0_actor_dist_step_enc_kernel": ("distributional actor tail + env step + replay row, then the new observation's encoder (main schedule, c51 / qr: steps 1..T-1)", "mfma16 issue + hbm",
                                           ENC_TILE_CYC / GHZ * 1e6 + hbm_us(E * (OBS + 3 * OBS) + 8 * E * Npad * 4), "as a0_actor_step_enc_kernel, head slabs instead of fc1 slabs"),
@@ -101,7 +101,7 @@ def model(cfg):
 # launches per iteration (80 actor steps, 20 updates; NoisyNet: a reset every 4 actor steps and one per update)
 def per_iteration(cfg, name):
     noisy = cfg == "c51"
-    if name.startswith(("a0_actor_step_enc_kernel", "a0_actor_dist_step_enc_kernel")):
+    if name.startswith(("a0_actor_step_enc", "a0_actor_dist_step_enc_kernel")):      # a0_actor_step_enc_kernel / a0_actor_step_enc2_kernel (the default: conv1 beside the tail)
         return 79
     if name.startswith(("a0_encoder_fused_kernel", "a0_actor_qhead_env_kernel", "a0_actor_dist_tail_env_kernel")):
         return 1                     # a rollout's first encoder and last tail; the 79 steps between run a0_actor_step_enc_kernel / a0_actor_dist_step_enc_kernel

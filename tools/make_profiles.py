@@ -38,7 +38,7 @@ calib = {}
 for name, rd, wr, what in (("gather", 512 * 2 * OBS, 512 * 2 * OBS, "a0_sample_gather_kernel: 512 rows x 56 448 B copied"),
                            ("qenv", E256 * OBS + 8 * E256 * 512 * 4, E256 * 3 * OBS, "a0_actor_qhead_env_kernel: 256 observations + the fc1 GEMM's eight split-K slabs (4.19 MB) read, "
                                     "new stacks + replay rows written"),
-                           ("stepenc", E256 * OBS + 8 * E256 * 512 * 4, E256 * 3 * OBS + E256 * 3136 * 4, "a0_actor_step_enc_kernel (round 5): the same tail traffic, then the encoder of the new observation "
+                           ("stepenc", E256 * OBS + 8 * E256 * 512 * 4, E256 * 3 * OBS + E256 * 3136 * 4, "a0_actor_step_enc2_kernel (round 5): the same tail traffic, then the encoder of the new observation "
                                        "(read back by the workgroup that wrote it: an L2 hit, not counted as algorithmic) + 3.2 MB of conv features written")):
     for k in list(pm):
         if k.startswith(name + ":") and k.endswith(":FETCH_SIZE"):

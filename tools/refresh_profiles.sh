@@ -19,7 +19,7 @@ for name in ("fetch", "write"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             key = ("enc" if ("a0_encoder_fused_kernel" in k or "a0_encoder_fused_multi_kernel" in k) else "dgrad" if "a0_encoder_dgrad_fused" in k else "envcommit" if "a0_env_step_commit" in k else
-                   "gather" if "a0_sample_gather_kernel" in k else "qenv" if "a0_actor_qhead_env_kernel" in k else "stepenc" if "a0_actor_step_enc_kernel" in k else None)
+                   "gather" if "a0_sample_gather_kernel" in k else "qenv" if "a0_actor_qhead_env_kernel" in k else "stepenc" if "a0_actor_step_enc" in k else None)
             gs = r["Grid_Size"]
             if key == "enc" and "a0_encoder_fused_multi_kernel" in k: gs = "multi"     # round 4: the learner's forward passes of one update in one launch (2 x 512 observations for dqn)
             elif key == "enc" and looping(k): gs = "loop"          # the looping instantiation (launches of more observations than CUs: the learner's 512)
@@ -33,7 +33,7 @@ per = collections.defaultdict(list)
 for f in glob.glob(f"gpurun_out/{R}/prof/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "a0_encoder_fused_kernel" in k or "a0_encoder_dgrad_fused" in k or "a0_encoder_fused_multi_kernel" in k or "a0_actor_step_enc_kernel" in k:
+        if "a0_encoder_fused_kernel" in k or "a0_encoder_dgrad_fused" in k or "a0_encoder_fused_multi_kernel" in k or "a0_actor_step_enc" in k:
             per[(k.split("(")[0][:48], "multi" if "a0_encoder_fused_multi_kernel" in k else "loop" if ("a0_encoder_fused_kernel" in k and looping(k)) else r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tr = {f"{k}|grid={g}": {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)} for (k, g), v in per.items()}
 json.dump(tr, open(f"gpurun_out/{R}/fused_by_grid.json", "w"), indent=1)
