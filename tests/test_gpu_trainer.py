@@ -30,7 +30,10 @@ ROLLOUT_SPECS = dict(recipe.SPECS, fqf4=recipe.NetSpec("fqf", 4))
                                                   (3, "dqn", "block"), (1, "dqn_duel", "block"), (3, "c51", "block"), (1, "iqn_duel", "block"), (3, "fqf4", "block"),
                                                   (3, "dqn", "block-unmerged"),
                                                   (1, "dqn", "chase"), (3, "dqn_duel", "chase"), (3, "c51", "chase"), (1, "iqn_duel", "chase"), (3, "fqf4", "chase"),
-                                                  (3, "dqn", "chase-unmerged")])
+                                                  (3, "dqn", "chase-unmerged"),
+                                                  # 96 envs: terminal steps occur (1 / 500 per env and step) — the merged kernels' terminal paths: all four channels of the
+                                                  # new observation are the new frame; on the chase task that frame waits for the action (the whole of conv1 behind it)
+                                                  (3, "dqn_duel", "chase@96"), (1, "dqn", "stream@96"), (3, "c51", "chase@96")])
 def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     """dqn / dqn_duel take the fused actor tail (a0_actor_qhead), c51 / qr the distributional tail, iqn / fqf the quantile tail (head GEMM slabs ->
     bias, dueling per quantile, mean / fraction-weighted sum, argmax, epsilon-greedy), each in one launch with the env step
@@ -44,11 +47,14 @@ def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
     from agent0_amd.common.utils import DeviceRng
 
     E, T = 4, 12
+    if "@" in task:
+        task, big = task.split("@")
+        E = int(big)
     spec = ROLLOUT_SPECS[spec_name]
     if task.endswith("-unmerged"):
         monkeypatch.setenv("A0_TAIL_ENV", "0")
         task = task[: -len("-unmerged")]
-    cfg = make_cfg(spec.algo, E, **{"env_task": task, "learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": 256, "learner.batch_size": 8,
+    cfg = make_cfg(spec.algo, E, **{"env_task": task, "learner.n_step_q": n_step, "actor.sample_steps": 6, "replay.size": max(256, 36 * E), "learner.batch_size": 8,
                                      "learner.dueling_head": str(bool(spec.dueling)).lower(), **({"learner.qr.num_atoms": spec.num_atoms} if spec.algo == "qr" else {})})
     model = DeepQNet(cfg)
     sd = recipe.make_state_dict(spec, 11)
@@ -93,7 +99,9 @@ def test_actor_rollout_matches_oracle(n_step, spec_name, task, monkeypatch):
             assert np.array_equal(rows[i], fr.reshape(-1)), f"transition {base + i}: packed st||st_next bytes"
             assert int(replay.act[base + i]) == int(at) and float(replay.rew[base + i]) == np.float32(rt) and bool(replay.done[base + i] != 0) == bool(dt)
     assert actor._graph is not None, "the rollout should have been captured"
-    assert len(replay) == 6 * 6 * E and replay.top == 144
+    assert len(replay) == min(6 * 6 * E, replay.size) and replay.top == min(36 * E, replay.size)
+    if E > 4:
+        assert core.env_terminals(cfg.seed, 0, E, 36).any(), "the larger case exists for the terminal steps"
 
 
 ALGOS = [("dqn", {}), ("dqn", {"learner.double_q": "true", "learner.dueling_head": "true", "learner.n_step_q": 3}),
