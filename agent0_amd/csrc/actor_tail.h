@@ -188,32 +188,14 @@ struct a0_dtenv_args {
     int vec4;                // kt == 0 and rows / slabs / bias 16-byte aligned: the slab sum runs 16 bytes wide over the padded row
     const float* taus;       // mode 3 (fqf): [E][T + 1] fraction boundaries, value(a) = sum_t (tau[t + 1] - tau[t]) q(t, a)  (== a0_select_action_kernel mode 3)
 };
-// Round 4: EIGHT waves, no workgroup barrier.  Wave 0 is the tail alone (it sums the head's slabs for itself: for row-per-env heads 16 bytes per lane and slab
-// over the padded row, all slabs requested before any is added), waves 1-7 are 448 lanes for the 441 sixteen-byte groups of a frame, each issuing its four
-// loads and twelve stores once and at once (was: 256 lanes, two or three trips, wave 0 joining after the tail; 16.4 us -> profiles/r04_experiments.md).
-// The body of a0_actor_dist_tail_env_kernel for env blockIdx.x (512 threads).  xs: max(A*T + T, ld) floats of LDS, s_chase_cell: one int of LDS.  Every wave returns (no
-// barrier at the end): a caller that goes on to read what the workgroup wrote synchronises first.
-A0_D void a0_actor_dist_tail_env_body(const a0_dtenv_args& P, float* __restrict__ xs, int* __restrict__ s_chase_cell_p) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// Wave 0's part of the body below: head slab sum, dueling, expectation / quantile mean, first maximum, epsilon-greedy draw, the env's scalar work with the action
+// (and, chase task, the block's new cell into *s_chase_cell_p).  No workgroup barrier inside.  g / slot / x: the step's counter, the replay slot and the env's Philox
+// draw as the body derives them.
+A0_D void a0_actor_dist_tail_wave0(const a0_dtenv_args& P, float* __restrict__ xs, int* __restrict__ s_chase_cell_p, uint32_t g, long long slot, const a0_u4& x) {
+    const int lane = threadIdx.x & 63;
     const uint32_t e = blockIdx.x;
     const int A = P.A, T = P.T, NC = A * T + (P.dueling ? T : 0);
-    uint32_t g = P.g; long long start = P.start;
-    if (P.ctrl) { g += (uint32_t)P.ctrl[A0_CTRL_ENV_STEP]; start += P.ctrl[A0_CTRL_REPLAY_SLOT]; }
-    const long long slot = (start + e) % P.cap;
-    // the env's Philox draws on the VECTOR unit (every lane the same): on uniform inputs the compiler runs the ten rounds on the scalar unit and keeps their
-    // partial products in scalar registers for the rest of the kernel (the source of its scalar-register spills)
-    uint32_t e_v = e;
-    asm volatile("" : "+v"(e_v));
-    const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
-    const bool term = (x.y % 500u) == 0u;
-    // A0_ENV_TASK_CHASE: the frame waves wait at a workgroup barrier for wave 0's action and read the block's new cell from LDS (a0_actor_qhead_env_kernel, net.hip)
     const bool chase = P.task == A0_ENV_TASK_CHASE;
-    if (wave != 0) {
-        int cell = -1;
-        if (chase) { __syncthreads(); cell = *s_chase_cell_p; }
-        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448, cell);
-        return;
-    }
     // everything the env's scalar work will need from memory is requested now, ahead of the slab loads: the control words, epsilon, the env's running
     // return and the n-step ring's previous entries (a0_env_commit_prefetch) — the arithmetic behind the action then never waits for memory again
     long long steps = P.steps; unsigned long long off_a = P.off_a, off_u = P.off_u; float eps = P.eps;
@@ -331,8 +313,36 @@ A0_D void a0_actor_dist_tail_env_body(const a0_dtenv_args& P, float* __restrict_
             a0_env_commit_finish(Z, x, e, g, task_v, A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
                                  O.r_done, slot, r_chase);
         }
-        if (chase) __syncthreads();
     }
+}
+
+// Round 4: EIGHT waves, no workgroup barrier.  Wave 0 is the tail alone (it sums the head's slabs for itself: for row-per-env heads 16 bytes per lane and slab
+// over the padded row, all slabs requested before any is added), waves 1-7 are 448 lanes for the 441 sixteen-byte groups of a frame, each issuing its four
+// loads and twelve stores once and at once (was: 256 lanes, two or three trips, wave 0 joining after the tail; 16.4 us -> profiles/r04_experiments.md).
+// The body of a0_actor_dist_tail_env_kernel for env blockIdx.x (512 threads).  xs: max(A*T + T, ld) floats of LDS, s_chase_cell: one int of LDS.  Every wave returns (no
+// barrier at the end): a caller that goes on to read what the workgroup wrote synchronises first.
+A0_D void a0_actor_dist_tail_env_body(const a0_dtenv_args& P, float* __restrict__ xs, int* __restrict__ s_chase_cell_p) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t e = blockIdx.x;
+    uint32_t g = P.g; long long start = P.start;
+    if (P.ctrl) { g += (uint32_t)P.ctrl[A0_CTRL_ENV_STEP]; start += P.ctrl[A0_CTRL_REPLAY_SLOT]; }
+    const long long slot = (start + e) % P.cap;
+    // the env's Philox draws on the VECTOR unit (every lane the same): on uniform inputs the compiler runs the ten rounds on the scalar unit and keeps their
+    // partial products in scalar registers for the rest of the kernel (the source of its scalar-register spills)
+    uint32_t e_v = e;
+    asm volatile("" : "+v"(e_v));
+    const a0_u4 x = a0_philox4x32_10(e_v, g, 0u, 0x454E56u, (uint32_t)P.env_seed, (uint32_t)(P.env_seed >> 32) ^ P.rank);
+    const bool term = (x.y % 500u) == 0u;
+    // A0_ENV_TASK_CHASE: the frame waves wait at a workgroup barrier for wave 0's action and read the block's new cell from LDS (a0_actor_qhead_env_kernel, net.hip)
+    const bool chase = P.task == A0_ENV_TASK_CHASE;
+    if (wave != 0) {
+        int cell = -1;
+        if (chase) { __syncthreads(); cell = *s_chase_cell_p; }
+        a0_env_commit_frames(P.env_seed, e, g, term, P.obs_in, P.obs_out, P.obs0, P.frames + slot * (8LL * A0_ENV_PIX), (int)threadIdx.x - 64, 448, cell);
+        return;
+    }
+    a0_actor_dist_tail_wave0(P, xs, s_chase_cell_p, g, slot, x);
+    if (chase) __syncthreads();
 }
 
 

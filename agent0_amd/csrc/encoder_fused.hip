@@ -827,12 +827,10 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* img = (uint16_t*)smem;
     const int obs_bytes = P.C * P.H * P.W;
-    const int M1 = P.H1 * P.W1, M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
+    const int M1 = P.H1 * P.W1;
     uint16_t* a1p = (uint16_t*)(smem + 2 * obs_bytes);
-    constexpr int term1 = 20 * A0_RP1X, term2 = 9 * A0_RP2X;
-    uint16_t* a2p = (uint16_t*)smem;
+    constexpr int term1 = 20 * A0_RP1X;
     typedef EpiFwdX<20, A0_P1X, A0_RP1X, term1> E1X;
-    typedef EpiFwdX<9, A0_P2X, A0_RP2X, term2> E2X;
     // conv2 / conv3 wave tiling: WNX waves along N (each owns 64 / 16 / WNX column blocks), 8 / WNX groups along M.  An A fragment read
     // from LDS feeds 9 * NBW MFMAs, and the waves along N re-read the same fragments: with four waves along N (NBW = 1) the two stages
     // moved 72 / 48 KB of LDS per 32-k step against 864 / 576 matrix-pipe cycles — LDS-bound at 128 B/clk.  Two waves along N halve that.
@@ -1060,7 +1058,38 @@ A0_D void a0_conv1_stage_split(const uint16_t* img, a0_wring1<A0_R1>& ring, cons
     __syncthreads();
 }
 
-__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_step_enc2_kernel(a0_qenv_args Q, a0_step_enc_args N) {
+struct TailScalar {
+    typedef a0_qenv_args Args;
+    static A0_D void run(const a0_qenv_args& Q, uint32_t e, uint32_t g, long long steps, unsigned long long off_a, unsigned long long off_u, float eps, long long slot, const a0_u4& x,
+                         bool chase, int lane, float* w2s /* wave-private LDS: where conv1's epilogue will write act1 (behind barrier 2) */, float* raw, int* s_chase_cell_p) {
+        const int NQ = Q.A + (Q.dueling ? 1 : 0);
+        a0_env_pre Z;
+        a0_env_commit_prefetch(Z, e, Q.E, Q.n, steps, Q.ep_ret, Q.ring_act, Q.ring_rew, Q.ring_done);
+        a0_env_pre_to_vgpr(Z);
+        const a0_env_out O = a0_env_out_vgpr(Q.ep_ret, Q.final_mask, Q.final_ret, Q.ring_act, Q.ring_rew, Q.ring_done, Q.r_act, Q.r_rew, Q.r_done);
+        A0_TO_VGPR(steps); A0_TO_VGPR(off_a); A0_TO_VGPR(off_u); A0_TO_VGPR(eps);
+        int n_v = Q.n, E_v = Q.E, task_v = Q.task; double gamma_v = Q.gamma; int* action_v = Q.action; float* qmax_v = Q.qmax;
+        A0_TO_VGPR(n_v); A0_TO_VGPR(E_v); A0_TO_VGPR(task_v); A0_TO_VGPR(gamma_v); A0_TO_VGPR(action_v); A0_TO_VGPR(qmax_v);
+#pragma unroll 4
+        for (int i = lane; i < NQ * 128; i += 64) ((a0_f4*)w2s)[i] = ((const a0_f4*)Q.W2)[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int act = 0; float best = 0.f;
+        a0_qhead_wave(Q.slabs, Q.slab_stride, Q.nslab, Q.b1, w2s, Q.b2, Q.A, Q.dueling, (int)e, lane, raw, Q.rng_seed, Q.stream_a, Q.stream_u, off_a, off_u, eps, act, best);
+        if (lane == 0) {
+            action_v[e] = act; qmax_v[e] = best;
+            float r_chase = 0.f;
+            if (chase) *s_chase_cell_p = a0_chase_step(a0_chase_cell(Q.obs_in + ((size_t)e * 4 + 3) * A0_ENV_PIX, e), act, x.w, r_chase);
+            a0_env_commit_finish(Z, x, e, g, task_v, Q.A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
+                                 O.r_done, slot, r_chase);
+        }
+    }
+};
+// TAIL: the step's wave-0 part — TailScalar (a0_qenv_args: fc1 slabs -> head -> action, a0_actor_qhead_env_body); a TailDist over a0_actor_dist_tail_wave0 (a0_dtenv_args names
+// the env's fields alike) was measured and not kept, see a0_actor_dist_step_enc_launch.
+template <class TAIL>
+A0_D void a0_actor_step_enc2_body(const typename TAIL::Args& Q, const a0_step_enc_args& N) {
     __shared__ float raw[64];
     __shared__ int s_chase_cell;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1089,7 +1118,6 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     unsigned long long v_wx2 = (unsigned long long)P.wx2, v_wx3 = (unsigned long long)P.wx3;
     A0_TO_VGPR(v_wx2); A0_TO_VGPR(v_wx3);
     // ---- the step (a0_actor_qhead_env_body)
-    const int NQ = Q.A + (Q.dueling ? 1 : 0);
     uint32_t g = Q.g; long long steps = Q.steps, start = Q.start; unsigned long long off_a = Q.off_a, off_u = Q.off_u; float eps = Q.eps;
     if (Q.ctrl) {
         g += (uint32_t)Q.ctrl[A0_CTRL_ENV_STEP]; steps += Q.ctrl[A0_CTRL_ACTOR_STEPS]; start += Q.ctrl[A0_CTRL_REPLAY_SLOT];
@@ -1135,28 +1163,7 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     uint4 keep[9];        // the frame waves' global stores are issued BEHIND conv1's first steps (gfx9 counts stores and loads together: pending stores would make the
                           // stage's first wait for its weights a wait for their acknowledgements)
     if (wave == 0) {
-        a0_env_pre Z;
-        a0_env_commit_prefetch(Z, e, Q.E, Q.n, steps, Q.ep_ret, Q.ring_act, Q.ring_rew, Q.ring_done);
-        a0_env_pre_to_vgpr(Z);
-        const a0_env_out O = a0_env_out_vgpr(Q.ep_ret, Q.final_mask, Q.final_ret, Q.ring_act, Q.ring_rew, Q.ring_done, Q.r_act, Q.r_rew, Q.r_done);
-        A0_TO_VGPR(steps); A0_TO_VGPR(off_a); A0_TO_VGPR(off_u); A0_TO_VGPR(eps);
-        int n_v = Q.n, E_v = Q.E, task_v = Q.task; double gamma_v = Q.gamma; int* action_v = Q.action; float* qmax_v = Q.qmax;
-        A0_TO_VGPR(n_v); A0_TO_VGPR(E_v); A0_TO_VGPR(task_v); A0_TO_VGPR(gamma_v); A0_TO_VGPR(action_v); A0_TO_VGPR(qmax_v);
-        float* w2s = (float*)a1p;      // the head's rows, wave-private, where conv1's epilogue will write act1 (behind barrier 2)
-#pragma unroll 4
-        for (int i = lane; i < NQ * 128; i += 64) ((a0_f4*)w2s)[i] = ((const a0_f4*)Q.W2)[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int act = 0; float best = 0.f;
-        a0_qhead_wave(Q.slabs, Q.slab_stride, Q.nslab, Q.b1, w2s, Q.b2, Q.A, Q.dueling, (int)e, lane, raw, Q.rng_seed, Q.stream_a, Q.stream_u, off_a, off_u, eps, act, best);
-        if (lane == 0) {
-            action_v[e] = act; qmax_v[e] = best;
-            float r_chase = 0.f;
-            if (chase) s_chase_cell = a0_chase_step(a0_chase_cell(Q.obs_in + ((size_t)e * 4 + 3) * A0_ENV_PIX, e), act, x.w, r_chase);
-            a0_env_commit_finish(Z, x, e, g, task_v, Q.A, E_v, n_v, steps, gamma_v, act, O.ep_ret, O.final_mask, O.final_ret, O.ring_act, O.ring_rew, O.ring_done, O.r_act, O.r_rew,
-                                 O.r_done, slot, r_chase);
-        }
+        TAIL::run(Q, e, g, steps, off_a, off_u, eps, slot, x, chase, lane, (float*)a1p, raw, &s_chase_cell);
     } else {
         if (has_group()) {
             const uint4* in16 = (const uint4*)(Q.obs_in + (size_t)e * 4 * HW) + j;
@@ -1224,6 +1231,8 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     a0_x9_conv23<3, 2, false>(P, (int)e, smem, bias_lds, ring1, ring2, ring3);
 }
 
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_step_enc2_kernel(a0_qenv_args Q, a0_step_enc_args N) { a0_actor_step_enc2_body<TailScalar>(Q, N); }
+
 static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_bytes);
 int a0_actor_dist_step_enc_launch(const a0_dtenv_args& Q, size_t tail_lds, const float* wt, const a0_encoder_weights* w, float* act3, hipStream_t st) {
     a0_fused_args P;
@@ -1240,6 +1249,8 @@ int a0_actor_dist_step_enc_launch(const a0_dtenv_args& Q, size_t tail_lds, const
             return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: LDS");
         configured = lds;
     }
+    // (the second form — conv1's channels 0..2 beside the tail, a0_actor_step_enc2_body<TailDist> — was built for these heads too: bit-identical, and c51 14.21 - 14.24 ->
+    // 14.32 - 14.34 ms, qr 11.75 - 11.86 -> 11.74 - 11.77 with the same kernel durations: not kept, profiles/r05_experiments.md)
     const bool probed = a0_probe_start(A0_TAG_ACTOR_STEP_ENC, st);
     hipLaunchKernelGGL(a0_actor_dist_step_enc_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
     if (probed) a0_probe_stop(st, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E);
