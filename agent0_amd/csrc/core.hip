@@ -1,7 +1,11 @@
 // Error plumbing and device queries for the C-ABI.
 #include "a0_internal.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 #include <string>
 
 static thread_local std::string a0_tls_error;
@@ -38,3 +42,56 @@ extern "C" int a0_device_info(int* cu_count, long long* hbm_bytes, char* arch_na
     if (arch_name64) { std::strncpy(arch_name64, p.gcnArchName, 63); arch_name64[63] = 0; }
     return A0_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ roctx ranges (SURVEY.md §5 tracing; the reference times wall clock only, trainer.py:176-180)
+// Named host-side ranges for rocprofv3 --marker-trace: `rollout`, `update_block`, `update`, `exchange` ..., prefixed with the rank ("r3:exchange").  Off unless
+// A0_ROCTX=1 (one getenv + a branch otherwise); the marker library is resolved at run time (dlopen "librocprofiler-sdk-roctx.so", no link-time dependency).  A range
+// brackets the ENQUEUE of its launches on the host — the kernels themselves are in the kernel trace of the same run, on the streams named there.
+namespace {
+struct roctx_api {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    void (*mark)(const char*) = nullptr;
+    bool on = false;
+    char prefix[16] = "";
+};
+roctx_api& roctx() {
+    static roctx_api a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("A0_ROCTX");
+        if (!e || e[0] != '1') return;
+        void* lib = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        a.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        a.pop = (int (*)())dlsym(lib, "roctxRangePop");
+        a.mark = (void (*)(const char*))dlsym(lib, "roctxMarkA");
+        a.on = a.push && a.pop;
+    });
+    return a;
+}
+}  // namespace
+
+void a0_trace_push_internal(const char* name) {
+    roctx_api& a = roctx();
+    if (!a.on) return;
+    char buf[96];
+    snprintf(buf, sizeof buf, "%s%s", a.prefix, name ? name : "?");
+    a.push(buf);
+}
+void a0_trace_pop_internal() {
+    roctx_api& a = roctx();
+    if (a.on) a.pop();
+}
+extern "C" int a0_trace_enabled(void) { return roctx().on ? 1 : 0; }
+extern "C" int a0_trace_rank(int rank) {
+    roctx_api& a = roctx();
+    if (rank >= 0) snprintf(a.prefix, sizeof a.prefix, "r%d:", rank); else a.prefix[0] = 0;
+    return A0_OK;
+}
+extern "C" int a0_trace_push(const char* name) { a0_trace_push_internal(name); return A0_OK; }
+extern "C" int a0_trace_pop(void) { a0_trace_pop_internal(); return A0_OK; }

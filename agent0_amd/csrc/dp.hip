@@ -98,6 +98,7 @@ extern "C" int a0_dp_allreduce(long long comm, float* buf, long long n, void* st
     rccl_api& a = api();
     if (!a.error.empty()) return a0_fail(A0_EINVAL, a.error.c_str());
     if (!comm || !buf || n < 1) return a0_fail(A0_EINVAL, "a0_dp_allreduce: bad argument");
+    a0_trace_scope range("exchange");
     ncclResult_t r = a.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)(intptr_t)comm, (hipStream_t)stream);
     return r == ncclSuccess ? A0_OK : fail_rccl(r, "ncclAllReduce");
 }

@@ -513,7 +513,7 @@ struct EpiFwdT {            // y = relu(acc + bias[n]) -> fp32 global [m][N] (co
     }
 };
 
-template <int N, int WN, int MBW, int R, int MBWP, class AFX, class EPI, class Between>
+template <int ORD, int N, int WN, int MBW, int R, int MBWP, class AFX, class EPI, class Between>
 A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, const EPI& epi, const a0_pre<N, WN, MBWP, EPI>& pre, Between&& between) {
     constexpr int NB = N / 16, NBW = NB / WN, WMG = A0_FUSED_WAVES / WN;
     static_assert(NBW >= 1 && (R % 2) == 0 && MBWP >= MBW, "tile shape");
@@ -557,7 +557,7 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
                     for (int i = 0; i < MBW; ++i)
 #pragma unroll
                         for (int jn = 0; jn < NBW; ++jn) {
-                            if (ta + tw > A0_X9_MAXORD) continue;      // see A0_X9_MAXORD
+                            if (ta + tw > ORD) continue;      // see A0_X9_MAXORD
                             const a0_u32x4 av = {a[u & 1][i][ta].x, a[u & 1][i][ta].y, a[u & 1][i][ta].z, a[u & 1][i][ta].w};
                             const a0_u32x4 bv = {ring.v[u][jn][tw].x, ring.v[u][jn][tw].y, ring.v[u][jn][tw].z, ring.v[u][jn][tw].w};
                             if constexpr (EPI::TR) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[i][jn], 0, 0, 0);
@@ -602,7 +602,7 @@ A0_D void a0_conv_stage_x9(const AFX& af, int M, a0_wring9<N, WN, R>& ring, cons
 // flight while this one's MFMAs issue: same register ring as above).  At the end the two waves of a column block exchange partial sums
 // through LDS — wave wk finishes row-block half wk, so each sends the other's half — which costs one barrier and 2 x 4 KB x MBT of LDS traffic.
 // `xch`: 8 * MBT / 2 KB of LDS nobody reads any more when the first wave leaves its k loop.  Association of the k sum: (even steps) + (odd steps).
-template <int N, int WN, int MBT, int R, int LR, class AFX, class EPI, class Between>
+template <int ORD, int N, int WN, int MBT, int R, int LR, class AFX, class EPI, class Between>
 A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_WAVES / WN>& ring, const EPI& epi, float* xch0, float* xch1, Between&& between) {
     constexpr int WK = A0_FUSED_WAVES / WN, HB0 = (MBT + 1) / 2, HB1 = MBT / 2;       // row blocks of the two halves of a k step: [0, HB0) and [HB0, MBT)
     static_assert(WK == 2 && N == 16 * WN && HB1 >= 1 && EPI::TR && LR >= 1 && LR <= 16, "tile shape");
@@ -648,7 +648,7 @@ A0_D void a0_conv_stage_x9k(const AFX& af, int M, a0_wring9<N, WN, R, A0_FUSED_W
                     for (int tw = 0; tw < 3; ++tw)
 #pragma unroll
                         for (int i = 0; i < HB0; ++i) {
-                            if (ta + tw > A0_X9_MAXORD || h * HB0 + i >= MBT) continue;      // see A0_X9_MAXORD
+                            if (ta + tw > ORD || h * HB0 + i >= MBT) continue;      // see A0_X9_MAXORD
                             const a0_u32x4 av = {a[h][i][ta].x, a[h][i][ta].y, a[h][i][ta].z, a[h][i][ta].w};
                             const a0_u32x4 bv = {ring.v[u][0][tw].x, ring.v[u][0][tw].y, ring.v[u][0][tw].z, ring.v[u][0][tw].w};
                             acc[h * HB0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(a0_bf16x8, bv), __builtin_bit_cast(a0_bf16x8, av), acc[h * HB0 + i], 0, 0, 0);
@@ -748,7 +748,7 @@ constexpr int A0_R1 = 4, A0_R2 = 4, A0_R3 = 6;     // conv1: 32-k steps (three 1
 #ifndef A0_FUSED_MINWAVES
 #define A0_FUSED_MINWAVES 1
 #endif
-template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP = false>
+template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP = false, int ORD = 4>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P);
 
 // Split-operand variant (84 x 84 geometry): all three layers on the bf16 pipe.  LDS: bf16 image [0, 56 448), act1 term planes behind it;
@@ -775,7 +775,7 @@ typedef a0_wring9<64, 4, A0_RK3, 2> a0_ring3_t;      // 9 own steps of conv3's 1
 typedef a0_wring9<64, A0_WNX, A0_RX2> a0_ring2_t;
 typedef a0_wring9<64, A0_WNX, A0_RX3> a0_ring3_t;
 #endif
-template <int MBW2, int MBW3, bool LOOP>
+template <int ORD, int MBW2, int MBW3, bool LOOP>
 A0_D void a0_x9_conv23(const a0_fused_args& P, int b, unsigned char* smem, float* bias_lds, a0_wring1<A0_R1>& ring1, a0_ring2_t& ring2, a0_ring3_t& ring3) {
     const int obs_bytes = P.C * P.H * P.W;
     const int M2 = P.H2 * P.W2, M3 = P.H3 * P.W3;
@@ -799,21 +799,21 @@ A0_D void a0_x9_conv23(const a0_fused_args& P, int b, unsigned char* smem, float
         // image region) and into the tail of the LDS allocation, conv3's where act1 was
         const AF3X<term2> f3k{a2p, A0_RP2X, P.W3, A0_P2X};
         const EpiFwdT e3k{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
-        a0_conv_stage_x9k<64, 4, 6, A0_RK2, 1>(f2, M2, ring2, e2, (float*)(smem + A0_X9_XCH0), (float*)(smem + A0_X9_XCH1), [&] { ring3.prologue(); });
-        a0_conv_stage_x9k<64, 4, 4, A0_RK3, 16>(f3k, M3, ring3, e3k, (float*)a1p, (float*)a1p + 4 * 2 * 256, [&] { if (LOOP) ring1.prologue(); });
+        a0_conv_stage_x9k<ORD, 64, 4, 6, A0_RK2, 1>(f2, M2, ring2, e2, (float*)(smem + A0_X9_XCH0), (float*)(smem + A0_X9_XCH1), [&] { ring3.prologue(); });
+        a0_conv_stage_x9k<ORD, 64, 4, 4, A0_RK3, 16>(f3k, M3, ring3, e3k, (float*)a1p, (float*)a1p + 4 * 2 * 256, [&] { if (LOOP) ring1.prologue(); });
 #else
         const int wmgx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WNX;
         constexpr bool uneven2 = MBW2X > 1 && MBW2X * WMGX > 6, uneven3 = MBW3X > 1 && MBW3X * WMGX > 4;      // some M groups own one block less
         if (uneven2 && wmgx + (MBW2X - 1) * WMGX >= 6)
-            a0_conv_stage_x9<64, WNX, (MBW2X > 1 ? MBW2X - 1 : 1), A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+            a0_conv_stage_x9<ORD, 64, WNX, (MBW2X > 1 ? MBW2X - 1 : 1), A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
         else
-            a0_conv_stage_x9<64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
+            a0_conv_stage_x9<ORD, 64, WNX, MBW2X, A0_RX2>(f2, M2, ring2, e2, pre2, [&] { ring3.prologue(); });
         const AF3X<term2> f3{a2p, A0_RP2X, P.W3, A0_P2X};
         const EpiFwdT e3{bias_lds + 96, P.act3 + (long long)b * M3 * 64, 64};
         if (uneven3 && wmgx + (MBW3X - 1) * WMGX >= 4)
-            a0_conv_stage_x9<64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
+            a0_conv_stage_x9<ORD, 64, WNX, (MBW3X > 1 ? MBW3X - 1 : 1), A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
         else
-            a0_conv_stage_x9<64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
+            a0_conv_stage_x9<ORD, 64, WNX, MBW3X, A0_RX3>(f3, M3, ring3, e3, pre3, [&] { if (LOOP) ring1.prologue(); });
 #endif
     }
 }
@@ -822,7 +822,7 @@ A0_D void a0_x9_conv23(const a0_fused_args& P, int b, unsigned char* smem, float
 // observation's conv1 weights behind conv3; without it (the actor's launches: one observation per workgroup) that request is not made.
 // bid / nblk: this workgroup's index among the workgroups that serve P and their number (blockIdx.x / gridDim.x for a launch of one pass;
 // a0_encoder_fused_multi_kernel hands every pass a share of the grid).
-template <int MBW1, int MBW2, int MBW3, bool LOOP>
+template <int ORD, int MBW1, int MBW2, int MBW3, bool LOOP>
 A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* img = (uint16_t*)smem;
@@ -891,7 +891,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
             a0_conv1_stage<(MBW1X > 1 ? MBW1X - 1 : 1), A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
         else
             a0_conv1_stage<MBW1X, A0_R1, 84>(img, P.H * P.W, P.W, P.W1, M1, ring1, e1, pre1, [&] { ring2.prologue(); });
-        a0_x9_conv23<MBW2, MBW3, LOOP>(P, b, smem, bias_lds, ring1, ring2, ring3);
+        a0_x9_conv23<ORD, MBW2, MBW3, LOOP>(P, b, smem, bias_lds, ring1, ring2, ring3);
         if constexpr (!LOOP) break;
     }
 }
@@ -906,6 +906,7 @@ A0_D void a0_encoder_fused_x9_body(const a0_fused_args& P, int bid, int nblk) {
 // (the encoder's arguments travel as five pointers: the 4 x 84 x 84 geometry is a compile-time constant here, and the two full argument structs together do not fit
 // the scalar registers)
 struct a0_step_enc_args { const float *wt, *b1, *b2, *b3; float* act3; };
+template <int ORD>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_step_enc_kernel(a0_qenv_args Q, a0_step_enc_args N) {
     __shared__ float raw[64];
     __shared__ int s_chase_cell;
@@ -930,11 +931,12 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     P.act1 = nullptr; P.act2 = nullptr; P.act3 = (float*)uni(v_a3); P.B = __builtin_amdgcn_readfirstlane(v_E);
     P.C = 4; P.H = 84; P.W = 84; P.H1 = 20; P.W1 = 20; P.H2 = 9; P.W2 = 9; P.H3 = 7; P.W3 = 7;
     P.off_act1 = 0; P.off_act2 = 0; P.off_end = 0; P.rp1 = 0; P.rp2 = 0;      // (the fp32-chain variants' LDS layout: not used by the split-operand body)
-    a0_encoder_fused_x9_body<7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
+    a0_encoder_fused_x9_body<ORD, 7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The distributional heads' step (c51 / qr): a0_actor_dist_tail_env_kernel's body (head slab sum, dueling, expectation or quantile mean, first maximum, epsilon-greedy,
 // env step, replay row), then the same encoder phase.
+template <int ORD>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_dist_step_enc_kernel(a0_dtenv_args Q, a0_step_enc_args N) {
     __shared__ int s_chase_cell;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_
     P.act1 = nullptr; P.act2 = nullptr; P.act3 = (float*)uni(v_a3); P.B = __builtin_amdgcn_readfirstlane(v_E);
     P.C = 4; P.H = 84; P.W = 84; P.H1 = 20; P.W1 = 20; P.H2 = 9; P.W2 = 9; P.H3 = 7; P.W3 = 7;
     P.off_act1 = 0; P.off_act2 = 0; P.off_end = 0; P.rp1 = 0; P.rp2 = 0;
-    a0_encoder_fused_x9_body<7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
+    a0_encoder_fused_x9_body<ORD, 7, 3, 2, false>(P, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- Round 5, second form: the step's tail BESIDE conv1 (scalar heads).  In a0_actor_step_enc_kernel seven waves copy frames and then wait for wave 0's latency chain
@@ -1088,7 +1090,7 @@ struct TailScalar {
 };
 // TAIL: the step's wave-0 part — TailScalar (a0_qenv_args: fc1 slabs -> head -> action, a0_actor_qhead_env_body); a TailDist over a0_actor_dist_tail_wave0 (a0_dtenv_args names
 // the env's fields alike) was measured and not kept, see a0_actor_dist_step_enc_launch.
-template <class TAIL>
+template <int ORD, class TAIL>
 A0_D void a0_actor_step_enc2_body(const typename TAIL::Args& Q, const a0_step_enc_args& N) {
     __shared__ float raw[64];
     __shared__ int s_chase_cell;
@@ -1228,10 +1230,11 @@ A0_D void a0_actor_step_enc2_body(const typename TAIL::Args& Q, const a0_step_en
     else
         a0_conv1_stage_split<MBW1X>(img, ring1, e1, before, mid, [&] { ring2.prologue(); });
     P.act3 = (float*)uni((unsigned long long)act3_v);
-    a0_x9_conv23<3, 2, false>(P, (int)e, smem, bias_lds, ring1, ring2, ring3);
+    a0_x9_conv23<ORD, 3, 2, false>(P, (int)e, smem, bias_lds, ring1, ring2, ring3);
 }
 
-__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_step_enc2_kernel(a0_qenv_args Q, a0_step_enc_args N) { a0_actor_step_enc2_body<TailScalar>(Q, N); }
+template <int ORD>
+__global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_actor_step_enc2_kernel(a0_qenv_args Q, a0_step_enc_args N) { a0_actor_step_enc2_body<ORD, TailScalar>(Q, N); }
 
 static bool a0_fused_layout(int C, int H, int W, a0_fused_args& P, size_t& lds_bytes);
 int a0_actor_dist_step_enc_launch(const a0_dtenv_args& Q, size_t tail_lds, const float* wt, const a0_encoder_weights* w, float* act3, hipStream_t st) {
@@ -1243,17 +1246,17 @@ int a0_actor_dist_step_enc_launch(const a0_dtenv_args& Q, size_t tail_lds, const
     const a0_step_enc_args N{wt, w->b1, w->b2, w->b3, act3};
     lds = A0_X9_LDS_BYTES > tail_lds ? (size_t)A0_X9_LDS_BYTES : tail_lds;
     if (lds > 160 * 1024 - 64) return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: head too wide for LDS");
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)a0_actor_dist_step_enc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_actor_dist_step_enc_kernel<2> : a0_actor_dist_step_enc_kernel<4>;
+    static size_t configured[2] = {0, 0};
+    if (lds > configured[six]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return a0_fail(A0_EINVAL, "a0_actor_dist_tail_env_step_enc: LDS");
-        configured = lds;
+        configured[six] = lds;
     }
     // (the second form — conv1's channels 0..2 beside the tail, a0_actor_step_enc2_body<TailDist> — was built for these heads too: bit-identical, and c51 14.21 - 14.24 ->
     // 14.32 - 14.34 ms, qr 11.75 - 11.86 -> 11.74 - 11.77 with the same kernel durations: not kept, profiles/r05_experiments.md)
-    const bool probed = a0_probe_start(A0_TAG_ACTOR_STEP_ENC, st);
-    hipLaunchKernelGGL(a0_actor_dist_step_enc_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
-    if (probed) a0_probe_stop(st, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E);
+    A0_LAUNCH_PROBED(A0_TAG_ACTOR_STEP_ENC, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E, kern, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_dist_tail_env_step_enc");
 }
 int a0_actor_step_enc_launch(const a0_qenv_args& Q, const float* wt, const a0_encoder_weights* w, float* act3, hipStream_t st) {
@@ -1265,24 +1268,16 @@ int a0_actor_step_enc_launch(const a0_qenv_args& Q, const float* wt, const a0_en
     const a0_step_enc_args N{wt, w->b1, w->b2, w->b3, act3};
     const size_t tail_lds = (size_t)(Q.A + (Q.dueling ? 1 : 0)) * 512 * sizeof(float);
     lds = A0_X9_LDS_BYTES > tail_lds ? (size_t)A0_X9_LDS_BYTES : tail_lds;
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)a0_actor_step_enc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step_enc: LDS");
-        configured = lds;
-    }
     static const int form = getenv("A0_STEP_ENC") ? atoi(getenv("A0_STEP_ENC")) : 2;      // tuning aid: 1 = tail, barrier, whole encoder (the first form); 2 = conv1's channels 0..2 beside the tail
-    static size_t configured2 = 0;
-    if (form != 1 && lds > configured2) {
-        if (hipFuncSetAttribute((const void*)a0_actor_step_enc2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const int six = a0_x9_products_now() == 6;
+    auto kern = form != 1 ? (six ? a0_actor_step_enc2_kernel<2> : a0_actor_step_enc2_kernel<4>) : (six ? a0_actor_step_enc_kernel<2> : a0_actor_step_enc_kernel<4>);
+    static size_t configured[2] = {0, 0};
+    if (lds > configured[six]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return a0_fail(A0_EINVAL, "a0_actor_qhead_env_step_enc: LDS");
-        configured2 = lds;
+        configured[six] = lds;
     }
-    const bool probed = a0_probe_start(A0_TAG_ACTOR_STEP_ENC, st);
-    if (form != 1) hipLaunchKernelGGL(a0_actor_step_enc2_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
-    else
-    hipLaunchKernelGGL(a0_actor_step_enc_kernel, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
-    if (probed) a0_probe_stop(st, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E);
+    A0_LAUNCH_PROBED(A0_TAG_ACTOR_STEP_ENC, 2.0 * (400.0 * 32 * 256 + 81.0 * 64 * 512 + 49.0 * 64 * 576) * Q.E, kern, dim3(Q.E), dim3(A0_FUSED_THREADS), lds, st, Q, N);
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_qhead_env_step_enc");
 }
 
@@ -1291,16 +1286,17 @@ int a0_actor_step_enc_launch(const a0_qenv_args& Q, const float* wt, const a0_en
 // than over 512 (ring set-up and the first weights per workgroup, the tail of the last wave of workgroups: tools/ubench_encoder_fwd.py).  Every pass gets a share
 // of the grid proportional to its observations; its workgroups run the unchanged per-pass body with their own weights, frames and outputs.
 struct a0_fused_multi_args { a0_fused_args p[3]; int first[4]; };
+template <int ORD>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_multi_kernel(a0_fused_multi_args M) {
     const int bid = (int)blockIdx.x;
     const int k = bid >= M.first[2] ? 2 : (bid >= M.first[1] ? 1 : 0);
-    a0_encoder_fused_x9_body<7, 3, 2, true>(M.p[k], bid - M.first[k], M.first[k + 1] - M.first[k]);
+    a0_encoder_fused_x9_body<ORD, 7, 3, 2, true>(M.p[k], bid - M.first[k], M.first[k + 1] - M.first[k]);
 }
 
-template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP>
+template <int MBW1, int MBW2, int MBW3, int WC, bool X9, bool LOOP, int ORD>
 __global__ __launch_bounds__(A0_FUSED_THREADS, A0_FUSED_MINWAVES) void a0_encoder_fused_kernel(a0_fused_args P) {
     if constexpr (X9) {
-        a0_encoder_fused_x9_body<MBW1, MBW2, MBW3, LOOP>(P, (int)blockIdx.x, (int)gridDim.x);
+        a0_encoder_fused_x9_body<ORD, MBW1, MBW2, MBW3, LOOP>(P, (int)blockIdx.x, (int)gridDim.x);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1515,6 +1511,7 @@ struct EpiBwdPair {             // two stride phases of conv2's data gradient si
 };
 constexpr int A0_RXD3 = 6, A0_RXD2 = 4;               // 32-k steps of split weights in flight (18 and 8 steps per stage)
 
+template <int ORD>
 __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_kernel(a0_dgrad_args P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* plA = (uint16_t*)smem;                  // d3, padded by 2: three term planes
@@ -1553,9 +1550,9 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
             const EpiBwd3X e3{P.act2 + (long long)b * 81 * 64, P.d2 + (long long)b * 81 * 64, plB};
             const EpiBwdPair e2a{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, 0};
             const EpiBwdPair e2b{P.act1 + (long long)b * 400 * 32, P.d1 + (long long)b * 400 * 32, 2};
-            a0_conv_stage_x9k<64, 4, 6, 3, 1>(f3, 81, ring3, e3, xch0, xch1, [&] { ringq[0].init_at(wq, 4, 768); ringq[0].prologue(); });
-            a0_conv_stage_x9k<64, 4, 7, 2, 4>(f2, 100, ringq[0], e2a, xch0, xch1, [&] { ringq[1].init_at(wq + 2 * 3072, 4, 768); ringq[1].prologue(); });
-            a0_conv_stage_x9k<64, 4, 7, 2, 4>(f2, 100, ringq[1], e2b, xch0, xch1, [&] { ring3.prologue(); });
+            a0_conv_stage_x9k<ORD, 64, 4, 6, 3, 1>(f3, 81, ring3, e3, xch0, xch1, [&] { ringq[0].init_at(wq, 4, 768); ringq[0].prologue(); });
+            a0_conv_stage_x9k<ORD, 64, 4, 7, 2, 4>(f2, 100, ringq[0], e2a, xch0, xch1, [&] { ringq[1].init_at(wq + 2 * 3072, 4, 768); ringq[1].prologue(); });
+            a0_conv_stage_x9k<ORD, 64, 4, 7, 2, 4>(f2, 100, ringq[1], e2b, xch0, xch1, [&] { ring3.prologue(); });
         }
         return;
     }
@@ -1596,11 +1593,11 @@ __global__ __launch_bounds__(A0_FUSED_THREADS) void a0_encoder_dgrad_fused_x9_ke
         const AFD2X f2{plB};
         const int bn = b + gridDim.x < P.B ? b + gridDim.x : b;       // next observation of this workgroup (its masks are prefetched in the last slot)
         // each `between` slot requests the NEXT stage's weights and ReLU masks before this stage's epilogue runs
-        a0_conv_stage_x9<64, 4, 3, A0_RXD3>(f3, 81, ring3, epi3(b), pre3, [&] { ringp[0].init(P.wd2, 256); ringp[0].prologue(); prep[0].load(epi2(b, 0, 0), 100); });
-        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[0], epi2(b, 0, 0), prep[0], [&] { ringp[1].init(P.wd2 + 1 * 12288, 256); ringp[1].prologue(); prep[1].load(epi2(b, 0, 1), 100); });
-        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[1], epi2(b, 0, 1), prep[1], [&] { ringp[0].init(P.wd2 + 2 * 12288, 256); ringp[0].prologue(); prep[0].load(epi2(b, 1, 0), 100); });
-        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[0], epi2(b, 1, 0), prep[0], [&] { ringp[1].init(P.wd2 + 3 * 12288, 256); ringp[1].prologue(); prep[1].load(epi2(b, 1, 1), 100); });
-        a0_conv_stage_x9<32, 2, 2, A0_RXD2>(f2, 100, ringp[1], epi2(b, 1, 1), prep[1], [&] { ring3.prologue(); pre3.load(epi3(bn), 81); });
+        a0_conv_stage_x9<ORD, 64, 4, 3, A0_RXD3>(f3, 81, ring3, epi3(b), pre3, [&] { ringp[0].init(P.wd2, 256); ringp[0].prologue(); prep[0].load(epi2(b, 0, 0), 100); });
+        a0_conv_stage_x9<ORD, 32, 2, 2, A0_RXD2>(f2, 100, ringp[0], epi2(b, 0, 0), prep[0], [&] { ringp[1].init(P.wd2 + 1 * 12288, 256); ringp[1].prologue(); prep[1].load(epi2(b, 0, 1), 100); });
+        a0_conv_stage_x9<ORD, 32, 2, 2, A0_RXD2>(f2, 100, ringp[1], epi2(b, 0, 1), prep[1], [&] { ringp[0].init(P.wd2 + 2 * 12288, 256); ringp[0].prologue(); prep[0].load(epi2(b, 1, 0), 100); });
+        a0_conv_stage_x9<ORD, 32, 2, 2, A0_RXD2>(f2, 100, ringp[0], epi2(b, 1, 0), prep[0], [&] { ringp[1].init(P.wd2 + 3 * 12288, 256); ringp[1].prologue(); prep[1].load(epi2(b, 1, 1), 100); });
+        a0_conv_stage_x9<ORD, 32, 2, 2, A0_RXD2>(f2, 100, ringp[1], epi2(b, 1, 1), prep[1], [&] { ring3.prologue(); pre3.load(epi3(bn), 81); });
     }
 }
 
@@ -1785,25 +1782,23 @@ extern "C" int a0_net_encoder_fwd_fused(int C, int H, int W, const float* wt, co
     static const int grid_cap = getenv("A0_ENC_GRID") ? atoi(getenv("A0_ENC_GRID")) : 256;
     const int gridx = (which == 2 && grid_cap > 0 && B > grid_cap) ? grid_cap : B;
     if (which == 2 && gridx < B) which = 3;                  // the looping instantiation of the split-operand kernel
-    static size_t configured[4] = {0, 0, 0, 0};
-    const void* fn = which == 3 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true, true> : which == 2 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, true>
-                   : which == 1 ? (const void*)a0_encoder_fused_kernel<7, 3, 2, 84, false> : (const void*)a0_encoder_fused_kernel<7, 4, 2, 0, false>;
+    static size_t configured[6] = {0, 0, 0, 0, 0, 0};
+    const int six = a0_x9_products_now() == 6;
+    if (six && which >= 2) which += 2;       // 4 / 5: the six-product forms of 2 / 3
+    typedef void (*a0_enc_kern)(a0_fused_args);
+    const a0_enc_kern fn = which == 5 ? a0_encoder_fused_kernel<7, 3, 2, 84, true, true, 2> : which == 4 ? a0_encoder_fused_kernel<7, 3, 2, 84, true, false, 2>
+                         : which == 3 ? a0_encoder_fused_kernel<7, 3, 2, 84, true, true> : which == 2 ? a0_encoder_fused_kernel<7, 3, 2, 84, true>
+                         : which == 1 ? a0_encoder_fused_kernel<7, 3, 2, 84, false> : a0_encoder_fused_kernel<7, 4, 2, 0, false>;
     if (lds > configured[which]) {
-        A0_HIP_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        A0_HIP_THROW(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured[which] = lds;
     }
-    const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
     // split-operand kernel: at most one workgroup per CU (152 KB of LDS each), looping over its observations (b += gridDim.x) when there are more
     // observations than that: ring set-up is paid once and the next observation's conv1 weights are requested behind conv3 (-4 % per 512
     // observations, tools/ubench_encoder_fwd.py).  A0_ENC_GRID: tuning aid (0 = one workgroup per observation)
-    if (which == 3) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true, true>), dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    else if (which == 2) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, true>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    else if (which == 1) hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 3, 2, 84, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL((a0_encoder_fused_kernel<7, 4, 2, 0, false>), dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    if (probed) {   // algorithmic FLOP of the three convolutions: 2 * (M1*32*K1 + M2*64*512 + M3*64*576) per observation
-        const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
-        a0_probe_stop((hipStream_t)stream, per_obs * B);
-    }
+    // algorithmic FLOP of the three convolutions: 2 * (M1*32*K1 + M2*64*512 + M3*64*576) per observation
+    const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
+    A0_LAUNCH_PROBED(A0_TAG_ENCODER_FUSED, per_obs * B, fn, dim3((which == 3 || which == 5) ? gridx : B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
     A0_CATCH
@@ -1847,18 +1842,16 @@ extern "C" int a0_net_encoder_fwd_fused_multi(int C, int H, int W, int n, const 
     for (int i = n; i <= 3; ++i) M.first[i] = 0x7fffffff;
     M.first[n] = used;
     lds = A0_X9_LDS_BYTES;
-    static bool configured = false;
-    if (!configured) {
-        A0_HIP_THROW(hipFuncSetAttribute((const void*)a0_encoder_fused_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_encoder_fused_multi_kernel<2> : a0_encoder_fused_multi_kernel<4>;
+    static bool configured[2] = {false, false};
+    if (!configured[six]) {
+        A0_HIP_THROW(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[six] = true;
     }
-    const bool probed = a0_probe_start(A0_TAG_ENCODER_FUSED, (hipStream_t)stream);
-    hipLaunchKernelGGL(a0_encoder_fused_multi_kernel, dim3(used), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, M);
-    if (probed) {
-        const a0_fused_args& P = M.p[0];
-        const double per_obs = 2.0 * ((double)P.H1 * P.W1 * 32 * (P.C * 64) + (double)P.H2 * P.W2 * 64 * 512 + (double)P.H3 * P.W3 * 64 * 576);
-        a0_probe_stop((hipStream_t)stream, per_obs * (double)total);
-    }
+    const a0_fused_args& P0 = M.p[0];
+    const double per_obs = 2.0 * ((double)P0.H1 * P0.W1 * 32 * (P0.C * 64) + (double)P0.H2 * P0.W2 * 64 * 512 + (double)P0.H3 * P0.W3 * 64 * 576);
+    A0_LAUNCH_PROBED(A0_TAG_ENCODER_FUSED, per_obs * (double)total, kern, dim3(used), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, M);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
     A0_CATCH
@@ -1885,20 +1878,19 @@ extern "C" int a0_net_encoder_dgrad_fused(int C, int H, int W, const float* wt, 
         P.wd2 = P.wd3 + 96LL * 576;
     }
     const size_t lds = x9 ? (size_t)3 * (A0_DTERMA + A0_DTERMB) * 2 + (A0_KSPLIT_D ? (4 * 4 + 4 * 3) * 1024 : 0) : (size_t)11 * (P.rpa + P.rpb) * 4;      // + the exchange regions of the N-stationary stages
-    static bool configured[2] = {false, false};
-    const void* fn = x9 ? (const void*)a0_encoder_dgrad_fused_x9_kernel : (const void*)a0_encoder_dgrad_fused_kernel;
-    if (!configured[x9]) {
-        A0_HIP_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[x9] = true;
+    static bool configured[3] = {false, false, false};
+    const int kv = x9 ? (a0_x9_products_now() == 6 ? 2 : 1) : 0;
+    typedef void (*a0_dg_kern)(a0_dgrad_args);
+    const a0_dg_kern fn = kv == 2 ? a0_encoder_dgrad_fused_x9_kernel<2> : kv == 1 ? a0_encoder_dgrad_fused_x9_kernel<4> : a0_encoder_dgrad_fused_kernel;
+    if (!configured[kv]) {
+        A0_HIP_THROW(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[kv] = true;
     }
-    const bool probed = a0_probe_start(A0_TAG_ENCODER_DGRAD_FUSED, (hipStream_t)stream);
     // at most one workgroup per CU, each looping over its observations (b += gridDim.x): the next observation's masks and the first
     // stage's weights are prefetched in the last stage's `between` slot instead of at workgroup start (-5 us per 512 observations)
     static const int grid_cap = getenv("A0_DGRAD_GRID") ? atoi(getenv("A0_DGRAD_GRID")) : 256;
     const int gridx = (grid_cap > 0 && B > grid_cap) ? grid_cap : B;
-    if (x9) hipLaunchKernelGGL(a0_encoder_dgrad_fused_x9_kernel, dim3(gridx), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(a0_encoder_dgrad_fused_kernel, dim3(B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
-    if (probed) a0_probe_stop((hipStream_t)stream, 2.0 * (81.0 * 64 * 576 + 400.0 * 32 * 256) * B);
+    A0_LAUNCH_PROBED(A0_TAG_ENCODER_DGRAD_FUSED, 2.0 * (81.0 * 64 * 576 + 400.0 * 32 * 256) * B, fn, dim3(x9 ? gridx : B), dim3(A0_FUSED_THREADS), lds, (hipStream_t)stream, P);
     A0_HIP_THROW(hipGetLastError());
     return A0_OK;
     A0_CATCH

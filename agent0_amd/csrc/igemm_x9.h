@@ -159,7 +159,12 @@ template <class OA, class OB, int WM, int WN, int MT, int NT, int KS = 2> struct
     static constexpr int LDS_BYTES = 2 * (ABYTES + BBYTES);                 // double-buffered
 };
 
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
+// Cross products of the three-term splits that are formed (NPR): 9 = all of them (every partial product of the fp32 fmaf chain, exactly: the strict mode), 6 = those
+// with term orders i + j <= 2 — a1*b2, a2*b1 and a2*b2 are left out, each below 2^-24 of a*b, i.e. below the rounding the fp32 chain itself applies to every partial SUM
+// (tools/check_bf16x9.hip, profiles/r06_x6_accuracy.txt: against fp64 the six-product sum is at least as close as the fmaf chain at every K of the path).  Chosen at run
+// time (a0_x9_products(), A0_X9_PRODUCTS=9|6); both forms of every instantiation are in the library.
+int a0_x9_products_now();
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
 __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, const typename OB::Params& pb,
                                                  const typename EP::Params& pe, int X, int Y, int K, int kchunk, int gx, int gy) {
     static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
@@ -170,7 +175,8 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
     typedef a0_x9_stager<OB, BY, NTH, KS> SB;
     constexpr int APL = a0_x9_image<OA::MODE, BX, KS>::PLANE, BPL = a0_x9_image<OB::MODE, BY, KS>::PLANE;
     constexpr int RA = SA::R, RB = SB::R, NP = RA + RB;      // commit / fetch pieces per tile
-    constexpr int NG = 9 * KS;                               // product groups per tile: KS k-steps x 9 term pairs, MT*NT MFMAs each
+    static_assert(NPR == 9 || NPR == 6, "nine or six cross products");
+    constexpr int NG = NPR * KS;                             // product groups per tile: KS k-steps x NPR term pairs, MT*NT MFMAs each
     static_assert(!EP::ROWSUM_A || OA::MODE == A0_XC, "row sums need an x-contiguous A operand");
     extern __shared__ __attribute__((aligned(16))) char a0_x9_lds[];
     char* const As = a0_x9_lds;                       // [2 buffers][3 planes]
@@ -254,8 +260,9 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
             for (int t = 2; t >= 0; --t) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a[s][i][t] = SA::frag(ap + t * APL, abase, i, s);
+                const int tq = NPR == 6 ? 2 - t : t;         // six products start with lo x hi: B's planes arrive in the opposite order
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[s][j][t] = SB::frag(bp + t * BPL, bbase, j, s);
+                for (int j = 0; j < NT; ++j) b[s][j][tq] = SB::frag(bp + tq * BPL, bbase, j, s);
             }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NM = NG * MT * NT, NU = 6 * NP;
@@ -263,7 +270,7 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
         for (int n = 0; n < NM; ++n) {
             // MFMA n: product group g = n / (MT*NT) -> k-step g / 9 and term pair g % 9 in the order of increasing magnitude (lo*lo first, hi*hi last)
             const int g = n / (MT * NT), i = (n / NT) % MT, j = n % NT;
-            const int s = g / 9, q = g % 9;
+            const int s = g / NPR, q = g % NPR + (9 - NPR);            // six products: the three smallest (lo*lo, lo*mid, mid*lo) are not formed
             constexpr int TA[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
             constexpr int TB[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0};
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0_bf16x8g, a[s][i][TA[q]]),
@@ -324,10 +331,10 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
         }
 }
 
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::Params pa, typename OB::Params pb,
                                                            typename EP::Params pe, int X, int Y, int K, int kchunk, int gx, int gy) {
-    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS>(pa, pb, pe, X, Y, K, kchunk, gx, gy);
+    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS, NPR>(pa, pb, pe, X, Y, K, kchunk, gx, gy);
 }
 
 // Up to three GEMMs of ONE shape (own operands and outputs each) in one launch: blockIdx.y names the problem.  The point is not the launch it saves but the split: a
@@ -335,21 +342,22 @@ __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::
 // passes side by side fill the chip with half or a third of the splits — each workgroup's k loop is two or three times as long, the fixed part is paid once
 // (the learner's target / online fc1 passes of one update: 2 x 17.1 us -> one launch; and the consumer sums half as many slabs).
 template <class OA, class OB, class EP> struct a0_x9_group { typename OA::Params pa[3]; typename OB::Params pb[3]; typename EP::Params pe[3]; };
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_group_kernel(a0_x9_group<OA, OB, EP> G, int X, int Y, int K, int kchunk, int gx, int gy) {
     const int g = blockIdx.y;
-    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS>(G.pa[g], G.pb[g], G.pe[g], X, Y, K, kchunk, gx, gy);
+    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS, NPR>(G.pa[g], G.pb[g], G.pe[g], X, Y, K, kchunk, gx, gy);
 }
 
 template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2>
 static inline hipError_t a0_igemm_x9_group_launch(hipStream_t st, int n, const a0_x9_group<OA, OB, EP>& grp, int X, int Y, int K, int splits) {
     typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
-    auto kern = a0_igemm_x9_group_kernel<OA, OB, EP, WM, WN, MT, NT, KS>;
-    static bool configured = false;
-    if (!configured) {
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_igemm_x9_group_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 6> : a0_igemm_x9_group_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 9>;
+    static bool configured[2] = {false, false};
+    if (!configured[six]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[six] = true;
     }
     if (splits < 1) splits = 1;
     constexpr int BK = 16 * KS;
@@ -363,7 +371,7 @@ static inline hipError_t a0_igemm_x9_group_launch(hipStream_t st, int n, const a
 // Two DIFFERENT GEMMs with the same tile shape and the same number of workgroups in one launch (blockIdx.y picks the body): fc1's data gradient and fc1's weight gradient of
 // a 512-row batch are 392 tiles each on a chip with 512 workgroup slots — alone each leaves a quarter of the slots empty and ends on the CUs that hold two workgroups; together
 // their 784 workgroups keep the slots filled (1.5 rounds instead of 2 x 1).  Same bodies, same tiles: bit-identical results.
-template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
+template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_pair_kernel(typename OA1::Params pa1, typename OB1::Params pb1, typename EP1::Params pe1, int X1, int Y1, int K1, int kc1,
                                                                 int gx1, int gy1, typename OA2::Params pa2, typename OB2::Params pb2, typename EP2::Params pe2, int X2, int Y2,
                                                                 int K2, int kc2, int gx2, int gy2) {
@@ -371,8 +379,8 @@ __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_pair_kernel(typename
     // id -> tile map, does not exist in its problem leaves at once)
     const int n = gridDim.x, id = blockIdx.x, per = n >> 3;
     const int L = (id < (per << 3)) ? (id & 7) * per + (id >> 3) : id;
-    if (blockIdx.y == 0) { if (L < gx1 * gy1) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1); }
-    else if (L < gx2 * gy2) a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    if (blockIdx.y == 0) { if (L < gx1 * gy1) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS, NPR>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1); }
+    else if (L < gx2 * gy2) a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS, NPR>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
 }
 
 template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
@@ -381,12 +389,13 @@ static inline hipError_t a0_igemm_x9_pair_launch(hipStream_t st, const typename 
     typedef a0_x9_geom<OA1, OB1, WM, WN, MT, NT, KS> G1;
     typedef a0_x9_geom<OA2, OB2, WM, WN, MT, NT, KS> G2;
     constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
-    auto kern = a0_igemm_x9_pair_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS>;
-    static bool configured = false;
-    if (!configured) {
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_igemm_x9_pair_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS, 6> : a0_igemm_x9_pair_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS, 9>;
+    static bool configured[2] = {false, false};
+    if (!configured[six]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[six] = true;
     }
     constexpr int BK = 16 * KS;
     const int kc1 = ((K1 + BK - 1) / BK) * BK, kc2 = ((K2 + BK - 1) / BK) * BK;          // no reduction split
@@ -400,20 +409,20 @@ static inline hipError_t a0_igemm_x9_pair_launch(hipStream_t st, const typename 
 // depend on the loss kernel's outputs only, and the head's few tiles (8 for a scalar head, 56 for qr's 800 columns) fit into the slots the pair leaves empty — its launch
 // (6.5 - 10.9 us alone, 20 times per block) disappears.  blockIdx.y names the problem; the third problem's grid column is as long as the pair's, workgroups without a tile
 // of it leave at once.
-template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2>
+template <class OA1, class OB1, class EP1, class OA2, class OB2, class EP2, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_trio_kernel(typename OA1::Params pa1, typename OB1::Params pb1, typename EP1::Params pe1, int X1, int Y1, int K1, int kc1,
                                                                 int gx1, int gy1, typename OA2::Params pa2, typename OB2::Params pb2, typename EP2::Params pe2, int X2, int Y2,
                                                                 int K2, int kc2, int gx2, int gy2, typename OA2::Params pa3, typename OB2::Params pb3, typename EP2::Params pe3,
                                                                 int X3, int Y3, int K3, int kc3, int gx3, int gy3) {
     // the small problem takes grid row 0: rows are dispatched in order, so its workgroups start with the launch instead of behind the pair's 784 (measured: in the last
     // row they began when the pair's slots drained and added their whole duration to the launch's tail)
-    if (blockIdx.y == 1) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1);
-    else if (blockIdx.y == 2) a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
+    if (blockIdx.y == 1) a0_igemm_x9_body<OA1, OB1, EP1, WM, WN, MT, NT, KS, NPR>(pa1, pb1, pe1, X1, Y1, K1, kc1, gx1, gy1);
+    else if (blockIdx.y == 2) a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS, NPR>(pa2, pb2, pe2, X2, Y2, K2, kc2, gx2, gy2);
     else {
         const int n = gridDim.x, id = blockIdx.x, per = n >> 3;          // the body's own id -> logical tile map: only tiles [0, gx3 * gy3) exist
         const int L = (id < (per << 3)) ? (id & 7) * per + (id >> 3) : id;
         if (L >= gx3 * gy3) return;
-        a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS>(pa3, pb3, pe3, X3, Y3, K3, kc3, gx3, gy3);
+        a0_igemm_x9_body<OA2, OB2, EP2, WM, WN, MT, NT, KS, NPR>(pa3, pb3, pe3, X3, Y3, K3, kc3, gx3, gy3);
     }
 }
 
@@ -424,12 +433,13 @@ static inline hipError_t a0_igemm_x9_trio_launch(hipStream_t st, const typename 
     typedef a0_x9_geom<OA1, OB1, WM, WN, MT, NT, KS> G1;
     typedef a0_x9_geom<OA2, OB2, WM, WN, MT, NT, KS> G2;
     constexpr int LDS = G1::LDS_BYTES > G2::LDS_BYTES ? G1::LDS_BYTES : G2::LDS_BYTES;
-    auto kern = a0_igemm_x9_trio_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS>;
-    static bool configured = false;
-    if (!configured) {
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_igemm_x9_trio_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS, 6> : a0_igemm_x9_trio_kernel<OA1, OB1, EP1, OA2, OB2, EP2, WM, WN, MT, NT, KS, 9>;
+    static bool configured[2] = {false, false};
+    if (!configured[six]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[six] = true;
     }
     constexpr int BK = 16 * KS;
     const int kc1 = ((K1 + BK - 1) / BK) * BK, kc2 = ((K2 + BK - 1) / BK) * BK, kc3 = ((K3 + BK - 1) / BK) * BK;          // no reduction split
@@ -445,12 +455,13 @@ template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS =
 static inline hipError_t a0_igemm_x9_launch(hipStream_t st, const typename OA::Params& pa, const typename OB::Params& pb,
                                             const typename EP::Params& pe, int X, int Y, int K, int splits) {
     typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
-    auto kern = a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS>;
-    static bool configured = false;                       // per instantiation: more than 64 KB of dynamic LDS needs the attribute
-    if (!configured) {
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 6> : a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 9>;
+    static bool configured[2] = {false, false};           // per instantiation: more than 64 KB of dynamic LDS needs the attribute
+    if (!configured[six]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[six] = true;
     }
     if (splits < 1) splits = 1;
     constexpr int BK = 16 * KS;

@@ -270,6 +270,11 @@ extern "C" int a0_learner_set_exchange(a0_learner* L, long long comm) {
         for (hipEvent_t& e : L->dp_ev) A0_HIP_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     L->dp_comm = comm;
+    L->dp_one_rank = false;
+    if (comm) {       // a one-rank group (a rehearsal, or a job of one GPU): nothing to overlap, so both all-reduces go on the update's own stream
+        int info[3] = {0, 0, 0};
+        if (a0_dp_info(comm, info) == A0_OK) L->dp_one_rank = info[0] == 1;
+    }
     return A0_OK;
     A0_CATCH
 }
@@ -346,6 +351,7 @@ extern "C" int a0_learner_get(const a0_learner* L, float* online_out, float* tar
 extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int* slot, long long row_bytes, const int* act, const float* rew, const float* done,
                                  const float* wgt, float* loss_out, void* stream) {
     A0_TRY
+    a0_trace_scope range("update");
     if (!L || !frames || !act || !rew || !done || !wgt) return a0_fail(A0_EINVAL, "a0_learner_update: null argument");
     const int B = L->d.B, A = L->d.A, dq = L->d.double_q ? 1 : 0, obs = L->C * L->H * L->W;
     if (row_bytes < 2LL * obs) return a0_fail(A0_EINVAL, "a0_learner_update: a replay row holds st || st_next (2 x C x H x W bytes)");
@@ -379,7 +385,10 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
     const bool dp = L->dp_comm != 0;
     // A0_DP_ONE_STREAM=1 (the same on every rank; a tuning aid): both all-reduces on the caller's stream — no overlap with the encoder backward, but none of the three
     // cross-stream hand-offs either, which cost an eager host ~10 us each (profiles/r04_experiments.md)
-    static const bool dp_inline = getenv("A0_DP_ONE_STREAM") != nullptr && atoi(getenv("A0_DP_ONE_STREAM")) != 0;
+    // Default (round 6): the side stream when the group has more than one rank (the dense bucket, 95 % of the bytes, travels beside the encoder backward — what the
+    // captured form does), the caller's stream in a one-rank group (+0.1 ms per iteration instead of +0.65, profiles/r04_native_dp_one_rank_ab.txt); A0_DP_ONE_STREAM=0 / 1 forces either.
+    static const int dp_force = getenv("A0_DP_ONE_STREAM") != nullptr ? (atoi(getenv("A0_DP_ONE_STREAM")) != 0 ? 1 : 0) : -1;
+    const bool dp_inline = dp_force >= 0 ? dp_force == 1 : L->dp_one_rank;
     a0_pending_reduce* const pp = dp ? nullptr : &pend;
     a0_frames_arg f_next{frames, slot, row_bytes, obs}, f_obs{frames, slot, row_bytes, 0};
     if ((L->d.algo == A0_ALGO_QR && !L->qr_fused) || (L->d.algo == A0_ALGO_MDQN && !L->mdqn_fused)) {

@@ -76,6 +76,7 @@ struct a0_learner {
     // ---- data parallelism: a communicator of a0_dp_init; the dense bucket's all-reduce runs on `dp_side` beside the encoder backward
     long long dp_comm = 0;
     hipStream_t dp_side = nullptr;
+    bool dp_one_rank = false;         // the communicator has one rank: the exchange runs on the update's own stream (a0_learner_set_exchange)
     hipEvent_t dp_ev[3] = {nullptr, nullptr, nullptr};
 
     template <class T> T* alloc(long long n, bool zero = false) {

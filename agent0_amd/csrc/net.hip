@@ -162,6 +162,13 @@ void a0_probe_stop(hipStream_t st, double flops) {
     g_probe.flops += flops;
 }
 
+bool a0_probe_events(int tag, hipEvent_t* start, hipEvent_t* stop) {
+    if (g_probe.tag == 0 || g_probe.tag != tag || g_probe.used + 2 > g_probe.ev.size()) return false;
+    *start = g_probe.ev[g_probe.used]; *stop = g_probe.ev[g_probe.used + 1];
+    return true;
+}
+void a0_probe_commit(double flops) { g_probe.used += 2; g_probe.flops += flops; }
+
 extern "C" int a0_probe_begin(int tag, int max_launches) {
     A0_TRY
     for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);
@@ -197,6 +204,15 @@ static const long long g_x9_big_min = getenv("A0_X9_BIG_MIN") ? atoll(getenv("A0
 extern "C" int a0_gemm_mode(int mode) {
     const int prev = g_gemm_x9;
     if (mode >= 0) g_gemm_x9 = mode ? 1 : 0;
+    return prev;
+}
+
+// Cross products of the split-operand kernels (igemm_x9.h, encoder_fused.hip): 6 (default) or 9 (strict: every partial product of the fp32 chain)
+static int g_x9_products = (getenv("A0_X9_PRODUCTS") && atoi(getenv("A0_X9_PRODUCTS")) == 9) ? 9 : 6;
+int a0_x9_products_now() { return g_x9_products; }
+extern "C" int a0_x9_products(int n) {
+    const int prev = g_x9_products;
+    if (n == 6 || n == 9) g_x9_products = n;
     return prev;
 }
 

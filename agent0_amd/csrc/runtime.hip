@@ -47,7 +47,9 @@ struct a0_rbuf {
     long long size = 0, top = 0, written = 0, cap2 = 1;
     int obs_bytes = 0, B = 0;
     long long row_bytes = 0;
-    bool prio = false;
+    bool prio = false;             // prioritized replay: sum-tree (prioritize == 1) or the reference's flat priority vector (prioritize == 2, `flat`)
+    bool flat = false;             // replay.py:45-59 / trainer.py:91-104 to the letter: uniform permutation batches, priority[-n:] = max_p^alpha on extend, whole-capacity sum
+    float *prio_vec = nullptr, *psum = nullptr, *sum_scratch = nullptr;
     double beta_use = 0.0, sched_cur = 0.0, beta_inc = 0.0;      // importance exponent in use / LinearSchedule(beta0, 1, total_steps).current / its increment per transition
     struct { bool open = false; long long top = 0, nb = 0, pos = 0; unsigned seed = 0; } ep;
     Rng rng;
@@ -67,11 +69,12 @@ extern "C" int a0_rbuf_create(const a0_rbuf_desc* d, a0_rbuf** out) { return a0_
 extern "C" int a0_rbuf_create_on(const a0_rbuf_desc* d, uint8_t* frames, int* act, float* rew, float* done, float* tree, float* max_p, a0_rbuf** out) {
     A0_TRY
     if (!d || !out) return a0_fail(A0_EINVAL, "a0_rbuf_create: null argument");
-    if (d->size < 2 || d->obs_bytes < 16 || (d->obs_bytes % 16) || d->B < 1 || d->B > d->size || (d->prioritize && (d->B > 1024 || !(d->alpha > 0.0) || d->total_steps < 1)))
-        return a0_fail(A0_EINVAL, "a0_rbuf_create: bad description (observation bytes a multiple of 16; prioritized batches of at most 1024)");
+    if (d->size < 2 || d->obs_bytes < 16 || (d->obs_bytes % 16) || d->B < 1 || d->B > d->size || d->prioritize < 0 || d->prioritize > 2 ||
+        (d->prioritize && (!(d->alpha > 0.0) || d->total_steps < 1)) || (d->prioritize == 1 && d->B > 1024))
+        return a0_fail(A0_EINVAL, "a0_rbuf_create: bad description (observation bytes a multiple of 16; prioritize 0 / 1 / 2; sum-tree batches of at most 1024)");
     a0_rbuf* R = new a0_rbuf();
     try {
-        R->d = *d; R->size = d->size; R->obs_bytes = d->obs_bytes; R->row_bytes = 2LL * d->obs_bytes; R->B = d->B; R->prio = d->prioritize != 0;
+        R->d = *d; R->size = d->size; R->obs_bytes = d->obs_bytes; R->row_bytes = 2LL * d->obs_bytes; R->B = d->B; R->prio = d->prioritize != 0; R->flat = d->prioritize == 2;
         R->rng.init(d->seed, 0);
         R->frames = frames ? frames : R->mem.alloc<uint8_t>(R->size * R->row_bytes, false);
         R->act = act ? act : R->mem.alloc<int>(R->size); R->rew = rew ? rew : R->mem.alloc<float>(R->size); R->done = done ? done : R->mem.alloc<float>(R->size);
@@ -85,7 +88,13 @@ extern "C" int a0_rbuf_create_on(const a0_rbuf_desc* d, uint8_t* frames, int* ac
         }
         hipLaunchKernelGGL(a0_fill_one_kernel, dim3((B + 255) / 256), dim3(256), 0, 0, R->ones, (long long)B, 1.0f);
         if (!max_p) hipLaunchKernelGGL(a0_fill_one_kernel, dim3(1), dim3(256), 0, 0, R->pstate, 1LL, 1.0f);           // max_p = 1 (replay.py:20)
-        if (R->prio) {
+        if (R->flat) {       // `tree` names the caller's priority vector [size] here (torch.ones(size), replay.py:19)
+            R->prio_vec = tree ? tree : R->mem.alloc<float>(R->size, false);
+            if (!tree) hipLaunchKernelGGL(a0_fill_one_kernel, dim3((unsigned)((R->size + 255) / 256)), dim3(256), 0, 0, R->prio_vec, R->size, 1.0f);
+            R->psum = R->mem.alloc<float>(4); R->sum_scratch = R->mem.alloc<float>(256);
+            R->beta_use = R->sched_cur = d->beta0;
+            R->beta_inc = (1.0 - d->beta0) / (double)d->total_steps;
+        } else if (R->prio) {
             while (R->cap2 < R->size) R->cap2 <<= 1;
             R->tree = tree ? tree : R->mem.alloc<float>(2 * R->cap2);
             R->beta_use = R->sched_cur = d->beta0;                                                         // LinearSchedule(beta0, 1, total_steps), utils.py:12-28
@@ -115,7 +124,7 @@ extern "C" int a0_rbuf_buffers(a0_rbuf* R, uint8_t** frames, int** act, float** 
     if (act) *act = R->act;
     if (rew) *rew = R->rew;
     if (done) *done = R->done;
-    if (tree) *tree = R->tree;       // (levels with < 2048 nodes may be stale after a0_rbuf_update_priority until the next a0_rbuf_sample / a0_rbuf_commit: use a0_rbuf_read for a consistent copy)
+    if (tree) *tree = R->flat ? R->prio_vec : R->tree;       // flat mode: the priority vector [size]. (levels with < 2048 nodes may be stale after a0_rbuf_update_priority until the next a0_rbuf_sample / a0_rbuf_commit: use a0_rbuf_read for a consistent copy)
     if (max_p) *max_p = R->pstate;
     return A0_OK;
 }
@@ -131,6 +140,7 @@ extern "C" int a0_rbuf_read(const a0_rbuf* R, long long rows, uint8_t* frames_ou
     if (done_out) A0_HIP_THROW(hipMemcpyAsync(done_out, R->done, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
     if (tree_out && R->tree && R->top_stale) A0_CHECK(a0_sumtree_top_rebuild(R->tree, R->cap2, stream));      // (the flag stays: idempotent, and R is const here)
     if (tree_out && R->tree) A0_HIP_THROW(hipMemcpyAsync(tree_out, R->tree, (size_t)(2 * R->cap2) * 4, hipMemcpyDeviceToDevice, st));
+    if (tree_out && R->flat) A0_HIP_THROW(hipMemcpyAsync(tree_out, R->prio_vec, (size_t)R->size * 4, hipMemcpyDeviceToDevice, st));      // flat mode: the priority vector [size]
     if (max_p_out) A0_HIP_THROW(hipMemcpyAsync(max_p_out, R->pstate, 4, hipMemcpyDeviceToDevice, st));
     return A0_OK;
     A0_CATCH
@@ -143,7 +153,13 @@ extern "C" int a0_rbuf_commit(a0_rbuf* R, long long n, void* stream) {
     if (!R || n < 1) return a0_fail(A0_EINVAL, "a0_rbuf_commit: bad argument");
     R->written += n;
     R->top = R->top + n < R->size ? R->top + n : R->size;
-    if (R->prio) {
+    if (R->flat) {
+        // replay.py:51-52 as written: the roll's result is discarded and the n new priorities max_p^alpha land in the TAIL of the vector (quirk Q1)
+        A0_CHECK(a0_priority_tail(R->prio_vec, R->size, n < R->size ? n : R->size, R->pstate, (float)R->d.alpha, stream));
+        R->beta_use = R->sched_cur;
+        const double nxt = R->sched_cur + R->beta_inc * (double)n;
+        R->sched_cur = nxt < 1.0 ? nxt : 1.0;
+    } else if (R->prio) {
         hipLaunchKernelGGL(a0_pow_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, R->pstate, R->d.alpha, R->val);
         const long long k = n < R->size ? n : R->size;
         A0_CHECK(a0_sumtree_set_range(R->tree, R->cap2, (R->written - k) % R->size, k, R->size, R->val, stream));
@@ -182,9 +198,10 @@ extern "C" int a0_rbuf_extend_from(a0_rbuf* R, const a0_rbuf* S, long long start
 // weights.  The pointers in `out` are the handle's persistent batch buffers (valid until the next sample).
 extern "C" int a0_rbuf_sample(a0_rbuf* R, a0_batch* out, void* stream) {
     A0_TRY
+    a0_trace_scope range("sample");
     if (!R || !out) return a0_fail(A0_EINVAL, "a0_rbuf_sample: null argument");
     const int B = R->B;
-    if (R->prio) {
+    if (R->prio && !R->flat) {
         const unsigned long long off = R->rng.reserve(STREAM_SUMTREE, B);
         A0_CHECK(a0_sumtree_sample_batch(R->rng.seed, STREAM_SUMTREE, off, R->tree, R->cap2, B, R->top, R->size, (float)R->beta_use, R->act, R->rew, R->done, R->b_idx, R->b_slot,
                                          R->b_act, R->b_rew, R->b_done, R->b_prio, R->b_w, R->top_stale ? 1 : 0, stream));
@@ -198,15 +215,20 @@ extern "C" int a0_rbuf_sample(a0_rbuf* R, a0_batch* out, void* stream) {
     }
     const long long start = R->ep.pos * B;
     R->ep.pos += 1;
-    A0_CHECK(a0_replay_sample_slots((unsigned long long)start, (unsigned long long)R->ep.top, R->ep.seed, R->top, R->head(), R->size, R->act, R->rew, R->done, nullptr, B,
+    A0_CHECK(a0_replay_sample_slots((unsigned long long)start, (unsigned long long)R->ep.top, R->ep.seed, R->top, R->head(), R->size, R->act, R->rew, R->done, R->flat ? R->prio_vec : nullptr, B,
                                     R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, stream));
-    *out = a0_batch{R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, R->ones};
+    if (R->flat) {       // trainer.py:91-94: probs = p / priority.sum() over the WHOLE capacity (quirk Q7), w = (top * probs)^-beta / max
+        A0_CHECK(a0_sum_f32(R->prio_vec, R->size, R->sum_scratch, R->psum, stream));
+        A0_CHECK(a0_is_weights(R->b_prio, B, R->psum, R->top, (float)R->beta_use, R->b_w, stream));
+    }
+    *out = a0_batch{R->b_idx, R->b_slot, R->b_act, R->b_rew, R->b_done, R->b_prio, R->flat ? R->b_w : R->ones};
     return A0_OK;
     A0_CATCH
 }
 
 extern "C" int a0_rbuf_sample_block(a0_rbuf* R, int n, a0_batch* out, void* stream) {
     A0_TRY
+    a0_trace_scope range("sample");
     if (!R || !out || n < 1 || n > 32) return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: 1..32 batches");
     if (R->prio) return a0_fail(A0_EINVAL, "a0_rbuf_sample_block: prioritized batches depend on the update before them (a0_rbuf_sample)");
     const int B = R->B;
@@ -236,6 +258,7 @@ extern "C" int a0_rbuf_update_priority(a0_rbuf* R, const float* loss, const int*
     A0_TRY
     if (!R || !loss) return a0_fail(A0_EINVAL, "a0_rbuf_update_priority: null argument");
     if (!R->prio) return A0_OK;
+    if (R->flat) return a0_priority_update(R->prio_vec, R->b_idx, loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->pstate, learner_state, stream);      // priority[ids] = (loss + eps)^alpha
     if (a0_sumtree_set_from_loss_ok(R->cap2)) {
         R->top_stale = true;
         return a0_sumtree_set_from_loss(R->tree, R->cap2, R->b_idx, loss, R->B, (float)R->d.eps, (float)R->d.alpha, R->pstate, learner_state, 1, stream);
@@ -401,6 +424,7 @@ static int a0_actor_compose(const a0_actor_net& V, void* stream) {
 
 extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float epsilon, void* stream) {
     A0_TRY
+    a0_trace_scope range("rollout");
     if (!a || !L || !R) return a0_fail(A0_EINVAL, "a0_actor_rollout: null argument");
     if (L->d.A != a->d.A || (L->d.dueling != 0) != (a->d.dueling != 0) || R->obs_bytes != a->obs_bytes || R->size < a->E)
         return a0_fail(A0_EINVAL, "a0_actor_rollout: actor, learner and replay were created for different shapes");

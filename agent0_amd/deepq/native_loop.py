@@ -9,10 +9,10 @@ reader of ``trainer.replay`` keep seeing the live data, with no copies in either
 offsets, the sampler's state (epochs / beta), the workspaces.
 
 Scope = what the handles cover (include/agent0_hip.h): all six learners (scalar heads with A + dueling <= 24), with or without NoisyNet, on 4 x 84 x 84 observations, the
-device-resident env's stream / block tasks, uniform or sum-tree replay, one GPU, the ``main`` AND (round 5) the ``launch`` schedule — there the actor handle owns a copy
-of the network (a0_actor_bind(.., 1) / a0_actor_snapshot) and rolls out into the Trainer's stage ring on the actor stream while the update block runs
-(``run_iteration_lp``).  Everything else — host environments, the chase task, the reference-faithful flat priority vector, data parallelism unless opted in — and any
-Trainer whose hot-loop methods a test harness has wrapped stays on the Python classes.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
+device-resident env's stream / block / chase tasks, uniform, sum-tree or (round 6) the reference-faithful flat-priority replay, one GPU or — round 6, the default — data
+parallelism over RCCL (the learner handle issues the two all-reduces itself: ``a0_learner_set_exchange``), the ``main`` AND the ``launch`` schedule — there the actor
+handle owns a copy of the network (a0_actor_bind(.., 1) / a0_actor_snapshot) and rolls out into the Trainer's stage ring on the actor stream while the update block runs
+(``run_iteration_lp``).  What stays on the Python classes: host environments (the worker pool is Python) and any Trainer whose hot-loop methods a test harness has wrapped.  Same launches, same order, same arguments: a run is BIT-identical either way (tests/test_gpu_trainer.py::test_native_loop_equals_the_python_classes).
 """
 from __future__ import annotations
 
@@ -54,13 +54,14 @@ def _wrapped(obj) -> bool:
 
 
 def hook_ok(hook) -> bool:
-    """No gradient hook, or — opt-in, A0_NATIVE_LOOP_DP=1 (the same on every rank) — the RCCL exchange of dist.RcclGradAllReduce, which the learner handle issues itself
-    (``a0_learner_set_exchange``: same communicator, buckets, side stream and order, eager instead of captured).  Off by default: the multi-rank form has only been rehearsed
-    with a one-rank group (one-GPU boxes), so N > 1 jobs stay on the path whose collective start-up and failure handling the gloo tests cover."""
+    """No gradient hook, or the RCCL exchange of dist.RcclGradAllReduce, which the learner handle issues itself (``a0_learner_set_exchange``: same communicator, buckets and
+    order as the captured form — the dense bucket beside the encoder backward on a side stream when the group has more than one rank, on the update's own stream in a
+    one-rank group, where there is nothing to overlap).  The default since round 6, so that an N > 1 job runs the host loop every one-GPU number was measured with;
+    A0_NATIVE_LOOP_DP=0 (the same on every rank) keeps data parallelism on the Python classes + hipGraphs.  Any other hook (the gloo test exchange) stays there too."""
     if hook is None:
         return True
     from .dist import RcclGradAllReduce
-    return os.environ.get("A0_NATIVE_LOOP_DP", "0") == "1" and isinstance(hook, RcclGradAllReduce)
+    return os.environ.get("A0_NATIVE_LOOP_DP", "1") != "0" and isinstance(hook, RcclGradAllReduce)
 
 
 def eligible(tr) -> Optional[str]:
@@ -91,9 +92,7 @@ def eligible(tr) -> Optional[str]:
     if not isinstance(actor.envs, DeviceSynthVecEnv) or actor.groups is not None:
         return "host environments"
     rp = tr.replay
-    if rp.prioritize and not rp.use_sumtree:
-        return "the reference-faithful flat priority vector"
-    if rp.prioritize and lc.batch_size > 1024:
+    if rp.use_sumtree and lc.batch_size > 1024:
         return "prioritized batches above 1024"
     eng = tr.learner.engine
     if not (eng.online.fused and eng.online.fused_dgrad) or tr.ops.gemm_mode() != 1 or not getattr(eng, "_defer_dense", False):
@@ -147,9 +146,10 @@ class NativeLoop:
             rng = tr.learner.rng
             ok(lib.a0_learner_set_rng(self.learner, rng.STREAM_NOISE, C.c_ulonglong(rng.offsets.get(rng.STREAM_NOISE, 0))), "a0_learner_set_rng")
         # ---- replay over the ReplayDataset's ring
-        rd = _RbufDesc(int(rp.size), int(rp.obs_bytes), self.B, int(self.prio), float(rc.alpha), float(rc.eps), float(rc.beta0), int(cfg.trainer.total_steps), int(cfg.seed) + 104729)
+        self.flat = self.prio and not rp.use_sumtree      # replay.sumtree=false: the reference's flat priority vector (a0_rbuf_desc.prioritize == 2; its `tree` argument is the vector)
+        rd = _RbufDesc(int(rp.size), int(rp.obs_bytes), self.B, 2 if self.flat else int(self.prio), float(rc.alpha), float(rc.eps), float(rc.beta0), int(cfg.trainer.total_steps), int(cfg.seed) + 104729)
         self.rbuf = C.c_void_p()
-        ok(lib.a0_rbuf_create_on(C.addressof(rd), p(rp.frames), p(rp.act), p(rp.rew), p(rp.done), p(rp._tree) if self.prio else None, p(rp._pstate), C.addressof(self.rbuf)),
+        ok(lib.a0_rbuf_create_on(C.addressof(rd), p(rp.frames), p(rp.act), p(rp.rew), p(rp.done), p(rp.priority) if self.flat else p(rp._tree) if self.prio else None, p(rp._pstate), C.addressof(self.rbuf)),
            "a0_rbuf_create_on")
         # ---- actor (its own env state: the Python Actor's stays where the constructor left it)
         ad = _ActorDesc(self.E, self.T, int(cfg.action_dim), int(bool(lc.dueling_head)), int(lc.n_step_q), float(lc.discount), int(cfg.seed), int(tr.rank),
@@ -223,17 +223,18 @@ class NativeLoop:
         n = int(cfg.learner.learner_steps)
         if self.fqf and tr._floss_means.numel() < n:
             tr._loss_means, tr._floss_means = tr.ops.zeros(n), tr.ops.zeros(n)
-        for i in range(n):
-            b = self._sample(i, n, st)
-            self._update(b, st)
-            if self.prio:
-                self._priority(st)
-            if self.fqf:                                  # the `fraction_loss` statistic (trainer.py:99-101): batch mean of the update's fraction losses
-                ok(lib.a0_learner_get_frac_loss(self.learner, self._floss.data_ptr(), st), "a0_learner_get_frac_loss")
-                tr.ops.mean_rows(self._floss, 1, self.B, tr._floss_means[i:i + 1])
+        with tr.ops.range("update_block"):
+            for i in range(n):
+                b = self._sample(i, n, st)
+                self._update(b, st)
+                if self.prio:
+                    self._priority(st)
+                if self.fqf:                              # the `fraction_loss` statistic (trainer.py:99-101): batch mean of the update's fraction losses
+                    ok(lib.a0_learner_get_frac_loss(self.learner, self._floss.data_ptr(), st), "a0_learner_get_frac_loss")
+                    tr.ops.mean_rows(self._floss, 1, self.B, tr._floss_means[i:i + 1])
         tr._ring0 = ln.updates_issued                     # the Adam launch wrote the block's batch-mean losses to ring slots ring0 .. ring0 + n - 1
         ln.updates_issued += n
-        if self.prio:
+        if self.prio and not self.flat:
             tr.replay._top_stale = True                   # the handle defers the tree's top levels to its next sample; ReplayDataset.tree brings them up to date for other readers
         return n
 

@@ -52,6 +52,8 @@ class Trainer:
             from agent0_amd.ops import HipOps
             ops = HipOps()
         self.ops = ops
+        if ops.trace_enabled() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            ops.trace_rank(rank)                          # roctx ranges carry the rank ("r3:exchange") in a data-parallel job
         dummy_env = make_atari(cfg.env_id, 1, ops=ops)
         self.obs_shape = tuple(dummy_env.observation_space.shape[1:])
         self.act_dim = int(dummy_env.action_space[0].n)
@@ -167,7 +169,8 @@ class Trainer:
         has_frac = False
         self._ring0 = None
         if len(self.replay) > cfg.trainer.training_start_steps and self._pipeline_ok():
-            n_upd = self._update_block_pipelined()
+            with self.ops.range("update_block"):
+                n_upd = self._update_block_pipelined()
         elif len(self.replay) > cfg.trainer.training_start_steps:
             rp = self.replay
             if self._loss_means.numel() < cfg.learner.learner_steps:       # learner_steps changed after construction
@@ -474,9 +477,15 @@ class Trainer:
         next launch.  A rollout issued ahead is consumed by the next call (whatever its ``prefetch``), or booked into the replay by ``final()``."""
         nl = self._native_loop()
         if nl is not None:
-            return nl.run_iteration_lp() if self.use_lp else nl.run_iteration(prefetch)
+            with self.ops.range("iteration"):             # roctx (A0_ROCTX=1): the handles open `rollout`, `sample`, `update`, `exchange` inside it
+                return nl.run_iteration_lp() if self.use_lp else nl.run_iteration(prefetch)
         if self.use_lp:
-            return self.run_iteration_lp()
+            with self.ops.range("iteration"):
+                return self.run_iteration_lp()
+        with self.ops.range("iteration"):
+            return self._run_iteration_py(prefetch)
+
+    def _run_iteration_py(self, prefetch: bool):
         tic = time.time()
         # Same work in the same stream order as ``step(*actor.sample(eps))`` — the update block's kernels are ordered behind the rollout's — but
         # the host does not stop between them: the rollout's statistics (episode returns, per-step max-Q: one small read-back) are collected

@@ -116,6 +116,29 @@ class NativeLearner:
             pass
 
 
+class _TraceRange:
+    def __init__(self, lib, name: bytes):
+        self.lib, self.name = lib, name
+
+    def __enter__(self):
+        self.lib.a0_trace_push(self.name)
+
+    def __exit__(self, *exc):
+        self.lib.a0_trace_pop()
+        return False
+
+
+class _NoRange:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_RANGE = _NoRange()
+
+
 class HipOps:
     name = "hip"
 
@@ -853,6 +876,23 @@ class HipOps:
     def gemm_mode(self, mode: int = -1) -> int:
         """1 = split-operand bf16 MFMA GEMMs (default), 0 = fp32 MFMA fmaf chain; returns the previous mode (mode < 0: query only)."""
         return int(self.lib.a0_gemm_mode(int(mode)))
+
+    # ------------------------------------------------------------------ roctx ranges (A0_ROCTX=1; rocprofv3 --marker-trace)
+    def trace_enabled(self) -> bool:
+        if getattr(self, "_trace_on", None) is None:
+            self._trace_on = bool(self.lib.a0_trace_enabled())
+        return self._trace_on
+
+    def trace_rank(self, rank: int):
+        self.lib.a0_trace_rank(int(rank))
+
+    def range(self, name: str):
+        """Context manager: a named host-side range around the enqueue of whatever runs inside (a shared no-op object unless A0_ROCTX=1)."""
+        return _TraceRange(self.lib, name.encode()) if self.trace_enabled() else _NO_RANGE
+
+    def x9_products(self, n: int = -1) -> int:
+        """Cross products of the split-operand kernels: 6 (default) or 9 (strict); returns the previous value (other n: query only).  Not during graph capture."""
+        return int(self.lib.a0_x9_products(int(n)))
 
     def device_info(self):
         cu = C.c_int()

@@ -240,6 +240,129 @@ def throughput_fields(world: int, per_iter: int, learner_steps: int, steps: int,
             "updates_per_sec": round(world * learner_steps * steps / dt, 2)}
 
 
+# ------------------------------------------------------------------------------------------------ roofline
+PEAK_BF16, PEAK_FP32 = 2500.0, 157.3          # TFLOP/s dense MFMA, MI355X_MICROARCH.md
+ENC_F1, ENC_F2, ENC_F3 = 2.0 * 400 * 32 * 256, 2.0 * 81 * 64 * 512, 2.0 * 49 * 64 * 576       # conv1 / conv2 / conv3 FLOP per observation (model.py:93-105)
+# candidate kernel families of the probe (agent0_amd/ops.py PROBE_TAGS), tried in this order; the one with the largest share of the iteration is the roofline kernel
+PROBE_FAMILIES = ("actor_step_enc", "encoder_fused", "encoder_dgrad_fused", "dense_fwd")
+
+
+def issued_per_mac(family: str, products: int) -> float:
+    """bf16 products the family's kernels issue on the matrix pipe per algorithmic fp32 multiply-add: every fp32 operand is an exact sum of three bf16 terms, so a
+    product of two costs `products` (9, or 6 with the cross terms below 2^-24 of the product left out: a0_x9_products) bf16 MFMA products; conv1 multiplies bytes
+    (exact in bf16) by three weight terms."""
+    if family in ("encoder_fused", "actor_step_enc"):
+        return (3 * ENC_F1 + products * (ENC_F2 + ENC_F3)) / (ENC_F1 + ENC_F2 + ENC_F3)
+    return float(products)
+
+
+def family_kernel(family: str, algo: str) -> str:
+    scalar = algo in ("dqn", "mdqn")
+    return {"actor_step_enc": ("a0_actor_step_enc2_kernel" if scalar else "a0_actor_dist_step_enc_kernel") +
+                              " (per env: head + action + env step + replay row of step t, then conv1 + conv2 + conv3 of the env's new observation; one workgroup per env)",
+            "encoder_fused": "a0_encoder_fused_multi_kernel / a0_encoder_fused_kernel (conv1 + conv2 + conv3 per observation: the update's forward passes in one launch of 256 looping "
+                             "workgroups, and the rollout's first encoder)",
+            "encoder_dgrad_fused": "a0_encoder_dgrad_fused_x9_kernel (conv3 + conv2 data gradients per observation)",
+            "dense_fwd": "a0_igemm_x9_kernel / a0_igemm_x9_group_kernel, the dense layers' forward GEMMs (fc1 512 x 3136 over the pass's rows, the heads)"}.get(family, family)
+
+
+def algorithmic_flop_per_iteration(cfg) -> dict:
+    """forward FLOP per observation from the layer shapes (model.py:93-105,110-123,203-257); an update = the forward passes of the learner
+    (online on s, target on s', + online on s' with double-Q / the third pass of mdqn) + the backward pass (2 x forward - conv1's data gradient).  Quantile networks
+    count their rows per observation (iqn: N online rows differentiated, N' target rows, K selection rows; fqf: F differentiated, F target, F selection, F - 1 for the
+    fraction loss)."""
+    lc, A = cfg.learner, cfg.action_dim
+    algo = lc.algo.name
+    enc, conv1, fc1 = ENC_F1 + ENC_F2 + ENC_F3, ENC_F1, 2.0 * 3136 * 512
+    duel = 1 if lc.dueling_head else 0
+    if algo in ("dqn", "mdqn", "c51", "qr"):
+        atoms = {"dqn": 1, "mdqn": 1, "c51": lc.c51.num_atoms, "qr": lc.qr.num_atoms}[algo]
+        fwd = enc + fc1 + 2.0 * 512 * (A + duel) * atoms
+        actor = fwd
+        update = (3 if (lc.double_q or algo == "mdqn") else 2) * fwd + 2 * fwd - conv1
+    else:
+        row = 2.0 * lc.iqn.num_cosines * 3136 + fc1 + 2.0 * 512 * (A + duel)
+        if algo == "iqn":
+            actor = enc + lc.iqn.K * row
+            rows = 3 * lc.iqn.N + lc.iqn.N_dash + lc.iqn.K
+        else:
+            actor = enc + lc.iqn.F * row + 2.0 * 3136 * lc.iqn.F
+            rows = 3 * lc.iqn.F + lc.iqn.F + lc.iqn.F + (lc.iqn.F - 1)
+        update = (3 if lc.double_q else 2) * enc + 2 * enc - conv1 + rows * row
+    n_obs = cfg.actor.sample_steps * cfg.actor.num_envs
+    total = n_obs * actor + lc.learner_steps * lc.batch_size * update
+    return {"actor_mflop_per_obs": round(actor / 1e6, 2), "update_mflop_per_sample": round(update / 1e6, 1), "total": total}
+
+
+def newest_profile(suffix: str):
+    try:
+        name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))[-1]
+        return name, json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None, None
+
+
+def roofline_object(probes, cfg, args, products: int, iter_s: float):
+    """The bench line's `roofline`: the probed kernel family with the largest measured time per iteration, priced on the pipe it issues on — bf16 MFMA products
+    issued / 2.5 PFLOP/s (a fraction that cannot exceed 1) — with the fp32-equivalent rate (every MAC counted once against the fp32 MFMA peak, a bound this family
+    can exceed) as a secondary field, the other candidates beside it, and the whole iteration's algorithmic rate."""
+    algo = cfg.learner.algo.name
+    flop_it = algorithmic_flop_per_iteration(cfg)
+    tfl = flop_it["total"] / iter_s / 1e12
+    iteration = {"algorithmic_flop": flop_it["total"], "actor_mflop_per_obs": flop_it["actor_mflop_per_obs"], "update_mflop_per_sample": flop_it["update_mflop_per_sample"],
+                 "tflops": round(tfl, 1), "frac_fp32_basis": round(tfl / PEAK_FP32, 3), "kernel_floor_ms": None, "kernel_sum_ms": None}
+    bname, budget = newest_profile("_budget.json")
+    if budget and algo in budget:
+        iteration.update(kernel_floor_ms=budget[algo].get("kernel_floor_ms"), kernel_sum_ms=budget[algo].get("kernel_sum_ms"),
+                         kernel_floor_note=f"NOT measured in this run: per-kernel floors (MFMA issue of the products actually issued / 6.3 TB/s HBM / 2.5 us launch floor) and the "
+                                           f"rocprofv3 kernel-time sum of the same command, profiles/{bname} (tools/budget.py)")
+    if not probes:
+        return {"bound": "mfma", "achieved": None, "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": None, "traffic": None, "iteration": iteration, "note": "probe switched off (A0_PROBE=none)"}
+    cands = []
+    for pr in probes:
+        per = issued_per_mac(pr["kernel"], products)
+        eq = pr["flop"] / (pr["ms"] * 1e-3) / 1e12
+        cands.append({"family": pr["kernel"], "kernel": family_kernel(pr["kernel"], algo), "launches_per_iteration": round(pr["launches"] / args.steps, 1),
+                      "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2), "ms_per_iteration": round(pr["ms"] / args.steps, 3), "share_of_iteration": round(pr["ms"] / args.steps / (iter_s * 1e3), 3),
+                      "algorithmic_gflop_per_launch": round(pr["flop"] / pr["launches"] / 1e9, 3), "bf16_products_per_mac": round(per, 3),
+                      "achieved": round(eq * per, 1), "frac": round(eq * per / PEAK_BF16, 4), "fp32_equivalent_tflops": round(eq, 2)})
+    cands.sort(key=lambda c: -c["ms_per_iteration"])
+    top = cands[0]
+    tname, tjson = newest_profile("_pmc_traffic.json")
+    traffic, tnote = None, "not measured for this kernel (traffic is null)"
+    try:
+        if top["family"] == "actor_step_enc":
+            c = tjson["calibration"]["stepenc"]
+            traffic = round(2 * c["FETCH_SIZE_bytes_raw"] + c["WRITE_SIZE_bytes_raw"])
+            tnote = (f"NOT measured in this run: HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes, tools/refresh_profiles.sh), profiles/{tname}; "
+                     f"algorithmic {c['algorithmic_read_bytes'] + c['algorithmic_write_bytes']} B (observations + fc1 slabs in, new stacks + replay rows + conv features out)")
+        elif top["family"] == "encoder_fused":
+            pm = tjson["per_launch"]
+            traffic = round(pm["1024"]["hbm_bytes"])
+            tnote = f"NOT measured in this run: the learner launch's (1024 observations) 2 x FETCH_SIZE + WRITE_SIZE, profiles/{tname}; algorithmic minimum {pm['1024']['algorithmic_bytes_min']} B"
+        elif top["family"] == "dense_fwd":
+            traffic = round(tjson["dense_fwd"][algo]["dense_fwd_gemm"]["hbm_bytes"])
+            tnote = f"NOT measured in this run: per-launch mean of the family's 2 x FETCH_SIZE + WRITE_SIZE (tools/pmc_quantile.sh), profiles/{tname}"
+    except Exception:
+        pass
+    return {"bound": "mfma", "achieved": top["achieved"], "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": top["frac"], "traffic": traffic, "traffic_note": tnote,
+            "kernel": top["kernel"], "family": top["family"], "launches_per_iteration": top["launches_per_iteration"], "avg_us": top["avg_us"],
+            "share_of_iteration": top["share_of_iteration"], "algorithmic_gflop_per_launch": top["algorithmic_gflop_per_launch"], "bf16_products_per_mac": top["bf16_products_per_mac"],
+            "basis": f"`achieved` = bf16 MFMA FLOPs the kernel ISSUES (algorithmic FLOPs x {top['bf16_products_per_mac']} bf16 products per multiply-add: fp32 operands as exact sums of three bf16 "
+                     f"terms, {products} cross products per fp32 x fp32 product (a0_x9_products), 3 per byte x fp32 product in conv1) / the kernel's average duration; `peak` = dense bf16 MFMA, "
+                     "the pipe it issues on, so `frac` cannot exceed 1",
+            "fp32_equivalent": {"achieved": top["fp32_equivalent_tflops"], "peak": PEAK_FP32, "unit": "TFLOP/s", "frac": round(top["fp32_equivalent_tflops"] / PEAK_FP32, 4),
+                                "note": "every multiply-add counted once against the fp32 MFMA peak — the bound of an fp32-input kernel, which this family may exceed because it issues "
+                                        "exact bf16-term products on the faster pipe; secondary, not a utilisation"},
+            "chosen_by": "largest measured time per iteration among the probed families (`candidates`, sorted); agrees with the top a0_* row of the rocprofv3 kernel statistics of the "
+                         "same command under profiles/",
+            "measured": "HIP events on the launch stream over a repeat of the timed iterations with hipGraph replay off: single-kernel families carry the event pair in the launch "
+                        "(hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), dense_fwd brackets each launch with recorded events"
+                        + ("; on the launch schedule the probe runs without the overlapped rollout stream" if args.entry == "launch" else ""),
+            "peak_source": "MI355X_MICROARCH.md: dense bf16 MFMA 2.5 PFLOP/s, fp32 MFMA 157.3 TFLOP/s",
+            "candidates": cands, "iteration": iteration}
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
@@ -313,37 +436,28 @@ def main():
     if dp:
         import torch.distributed as dist
         dt, per_rank = rank_clock(dist, dt, dt_local, rank, world, args.steps, "cuda")
-    # ---- roofline of the dominant kernel: the same iterations once more with the hipGraphs switched off, so that HIP events can
-    # bracket every launch of that kernel on its stream (events cannot be read out of a replayed graph).  Not part of `value`.
-    # the quantile networks (iqn / fqf) spend their time in the fc1-family GEMMs over B * N rows ("IQN/FQF fc1 + cosine-embed GEMMs:
-    # MFMA-bound"), every other configuration in the fused encoder
-    probe_kernel = os.environ.get("A0_PROBE", "dense_fwd" if cfg.learner.algo.name in ("iqn", "fqf") else "encoder_fused")
-    pr = None
-    if probe_kernel != "none":           # every rank repeats the iterations (they contain the gradient all-reduce); rank 0 records
+    # ---- roofline of the dominant kernel: the same iterations once more per candidate kernel family with the hipGraphs switched off, every launch of
+    # the family carrying a HIP event pair on its stream (events cannot be read out of a replayed graph; single-kernel families take the dispatch's own begin / end
+    # timestamps through hipExtLaunchKernelGGL — what rocprofv3's kernel trace reports).  The family with the largest share of the iteration is THE roofline kernel; the
+    # others are listed beside it.  Not part of `value`.
+    probes = []
+    pick = os.environ.get("A0_PROBE", "auto")
+    families = [] if pick == "none" else list(PROBE_FAMILIES) if pick == "auto" else [pick]
+    if families:           # every rank repeats the iterations (they contain the gradient all-reduce); rank 0 records
         tr.learner.use_graph = False
         tr.actors[1].use_graph = False
         if args.entry == "launch":
             tr.overlap = False               # kernel timing without a second stream competing for the CUs
-        if rank == 0:
-            tr.ops.probe_begin(probe_kernel, 64 + args.steps * (4 * cfg.actor.sample_steps + 16 * cfg.learner.learner_steps))
-        for _ in range(args.steps):
-            tr.run_iteration()
-        torch.cuda.synchronize()
-        if rank == 0:
-            pr = tr.ops.probe_end()
-        # round 5: on the `main` schedule the actor's steps 1..T-1 encode inside the tail + env-step kernel (a0_actor_step_enc2_kernel, its own probe family, so that
-        # the encoder's line above keeps the pure encoder launches rocprofv3 lists as a0_encoder_fused_*): one more repeat brackets that kernel
-        pr_step = None
-        if probe_kernel == "encoder_fused" and not dp:
+        for fam in families:
             if rank == 0:
-                tr.ops.probe_begin("actor_step_enc", 64 + args.steps * 2 * cfg.actor.sample_steps)
+                tr.ops.probe_begin(fam, 64 + args.steps * (4 * cfg.actor.sample_steps + 16 * cfg.learner.learner_steps))
             for _ in range(args.steps):
                 tr.run_iteration()
             torch.cuda.synchronize()
             if rank == 0:
-                pr_step = tr.ops.probe_end()
-                if not pr_step["launches"]:
-                    pr_step = None
+                pr = tr.ops.probe_end()
+                if pr["launches"] and pr["ms"] > 0:
+                    probes.append(pr)
     # ---- metric 2 of BASELINE.json: replay sample GB/s = B * 56 448 B / t(sample + gather); the update itself never gathers
     # (conv1 reads ring rows through the slot index), so the gather kernel is timed on its own here
     replay_gbps = None
@@ -441,68 +555,7 @@ def main():
         "at_reference_update_ratio": ratio320, "other_entry": other,
         "replay_sample_GBps": None if replay_gbps is None else round(replay_gbps, 1), "last_loss": None if last is None or last.get("loss") is None else float(last["loss"]),
     }
-    roof = None
-    traffic = None
-    traffic_file = None
-    try:      # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside this process)
-        traffic_file = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # newest round
-        pm = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["per_launch"]
-        if "1024" in pm:      # round 4: the update's two forward passes (target on s', online on s: 2 x 512 observations) are ONE launch
-            n_act, n_lrn = (1 if pr_step else cfg.actor.sample_steps), cfg.learner.learner_steps      # (merged actor steps: only a rollout's first step launches the encoder alone)
-            traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["1024"]["hbm_bytes"]) / (n_act + n_lrn))
-        else:
-            n_act, n_lrn = cfg.actor.sample_steps, 2 * cfg.learner.learner_steps
-            traffic = round((n_act * pm["256"]["hbm_bytes"] + n_lrn * pm["512"]["hbm_bytes"]) / (n_act + n_lrn))
-    except Exception:
-        pass
-    if pr is not None and pr["launches"] and pr["ms"] > 0:
-        achieved = pr["flop"] / (pr["ms"] * 1e-3) / 1e12
-        # the same launches priced as what the kernel actually issues: every layer runs on v_mfma_f32_16x16x32_bf16 with operands split exactly
-        # into bf16 terms — 3 products per conv1 MAC (bytes x three weight terms), 9 per conv2 / conv3 MAC — against the dense bf16 MFMA peak
-        issued_ratio = 1.0
-        if pr["kernel"] == "encoder_fused":
-            f1, f2, f3 = 2.0 * 400 * 32 * 256, 2.0 * 81 * 64 * 512, 2.0 * 49 * 64 * 576
-            issued_ratio = (3 * f1 + 9 * (f2 + f3)) / (f1 + f2 + f3)
-        enc = pr["kernel"] == "encoder_fused"
-        if not enc:
-            issued_ratio, traffic = 9.0, None             # nine bf16 products per MAC
-            try:      # per-launch mean of the family's HBM bytes from the committed PMC passes of this configuration (tools/pmc_quantile.sh)
-                traffic = round(json.load(open(os.path.join(ROOT, "profiles", traffic_file)))["dense_fwd"][cfg.learner.algo.name]["dense_fwd_gemm"]["hbm_bytes"])
-            except Exception:
-                pass
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4), "traffic": traffic,
-                "issued_bf16": {"achieved": round(achieved * issued_ratio, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved * issued_ratio / 2500.0, 4),
-                                "note": ("bf16 MFMA FLOPs the kernel issues (3 products per conv1 MAC, 9 per conv2 / conv3 MAC: 99.96 MFLOP per observation) against the dense "
-                                         "bf16 MFMA peak" if enc else "bf16 MFMA FLOPs the kernel issues (9 cross products per MAC) against the dense bf16 MFMA peak") +
-                                        "; `frac` above counts every MAC once against the fp32 MFMA peak"},
-                "traffic_note": ("not measured for this kernel (traffic is null)" if traffic is None else f"NOT measured in this run: mean HBM bytes per launch of the family (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/pmc_quantile.sh), read from profiles/{traffic_file}") if not enc else f"NOT measured in this run: HBM bytes per launch (launch-mix average), FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
-                                f"at --replay-size 100000 --steps 2 (tools/refresh_profiles.sh), read from profiles/{traffic_file}; "
-                                "algorithmic minimum 10.9 MB (256 obs) / 21.3 MB per 512 obs (the learner's two passes of an update share one launch of 1024); the learner's online pass also stores act1/act2 for the backward pass",
-                "kernel": "a0_encoder_fused_kernel (conv1+conv2+conv3 of the Nature CNN per observation; u8 input, activations in LDS, weights streamed through registers; "
-                          "all layers on v_mfma_f32_16x16x32_bf16 with operands split exactly into bf16 terms (bytes x 3 weight terms; 3 activation x 3 weight terms), fp32 accumulation; "
-                          "FLOPs counted once, peak = fp32 MFMA, the bound of the fp32-chain variant A0_NO_X9=1)"
-                          if pr["kernel"] == "encoder_fused" else
-                          f"a0_igemm_x9_kernel, every launch tagged {pr['kernel']} (the dense layers' GEMMs of this pass direction: fc1 512 x 3136 over B*N rows and the heads; "
-                          "the cosine embedding 3136 x 64 runs in the store-bound a0_short_k_fwd_kernel and is not part of this family; both fp32 operands split exactly into three bf16 terms, nine v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation; "
-                          "FLOPs = 2*M*N*K counted once, peak = fp32 MFMA)",
-                "frac_note": "`frac` prices every MAC once against the fp32 MFMA peak, the bound of an fp32-input kernel; this kernel reaches (and on a fast box exceeds) it because it "
-                             "issues exact bf16-term products on the 16x faster bf16 pipe — `issued_bf16.frac` is its utilisation of the pipe it actually runs on",
-                "launches": pr["launches"], "avg_us": round(1e3 * pr["ms"] / pr["launches"], 2),
-                "algorithmic_flop_per_launch": "15.47 MFLOP per observation (2*(400*32*256 + 81*64*512 + 49*64*576)) x 256 (actor launch) or x 1024 (learner launch: the update's target and online passes of 512 observations in one launch; 1536 with double-Q)"
-                                               if pr["kernel"] == "encoder_fused" else f"2*M*N*K per launch; {pr['flop'] / max(pr['launches'], 1) / 1e9:.2f} GFLOP average over the launch mix",
-                "measured": "HIP events on the launch stream around every launch of the kernel, over a repeat of the timed iterations with hipGraph replay off"
-                            + ("; on the launch schedule the rollout's launches run on the actor stream BESIDE the update block's, so these durations include the contention for "
-                               "the chip — the `main` entry's line carries the kernel's own rate" if args.entry == "launch" else ""),
-                "peak_source": "MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s dense (a register-only 16x16x4 loop sustains 126-137 TFLOP/s on this part, tools/ubench_mfma.hip)"}
-    if roof is not None and pr_step is not None:
-        us = 1e3 * pr_step["ms"] / pr_step["launches"]
-        roof["actor_step_kernel"] = {
-            "kernel": "a0_actor_step_enc2_kernel (a0_actor_qhead_env_step_enc: Q head + action + env step + frame commit of step t beside conv1's first three channels, then the rest of "
-                      "conv1 + conv2 + conv3 of the env's new observation, one workgroup per env)", "launches": pr_step["launches"], "avg_us": round(us, 2),
-            "encoder_flop_rate": {"achieved": round(pr_step["flop"] / (pr_step["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                                  "note": "the encoder's 15.47 MFLOP per observation over the WHOLE kernel's duration (tail and env step included): a lower bound on its encoder phase"},
-            "replaces": "a0_actor_qhead_env_kernel + a0_encoder_fused_kernel<grid 256> of the three-launch step (A0_STEP_ENC=0); profiles/ carries both durations"}
-    out["roofline"] = roof
+    out["roofline"] = roofline_object(probes, cfg, args, tr.ops.x9_products(), dt / args.steps)
     out["cpu_baseline"] = cpu_base
     print(json.dumps(out))
     if dp:

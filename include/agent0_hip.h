@@ -173,11 +173,30 @@ int a0_reduce_bias_act_multi(int n, const float* const* slabs, const long long* 
 int a0_probe_begin(int tag, int max_launches);
 int a0_probe_end(double* host_out3);
 
+/* Named host-side ranges for rocprofv3 --marker-trace (roctx; SURVEY.md §5 — the reference has wall-clock timing only, trainer.py:176-180).  Active only when the
+ * process was started with A0_ROCTX=1 and librocprofiler-sdk-roctx.so can be loaded (a0_trace_enabled); otherwise every call is a branch.  The library's own
+ * handles open ranges `rollout` (a0_actor_rollout), `update` (a0_learner_update), `exchange` (the gradient all-reduce's enqueue), `sample` (a0_rbuf_sample*);
+ * a host adds its own around them (the Python Trainer: `iteration`, `update_block`).  a0_trace_rank(r) prefixes every name with "r<r>:" (r < 0: no prefix).
+ * A range brackets the ENQUEUE on the host; the kernels it launched are in the kernel trace of the same run. */
+int a0_trace_enabled(void);
+int a0_trace_rank(int rank);
+int a0_trace_push(const char* name);
+int a0_trace_pop(void);
+
 /* Matrix pipe used by every fp32-operand GEMM above (dense layers, conv2/conv3 weight gradients, unfused conv layers):
  * 1 (default) = bf16 MFMA with both operands split exactly into three bf16 terms, nine products, fp32 accumulation (igemm_x9.h);
  * 0 = fp32 MFMA fmaf chain (igemm.h).  Same results up to the association order of the fp32 additions.  Returns the previous mode;
  * mode < 0 only queries.  Process-wide, not a per-stream setting: change it between launches, never during graph capture. */
 int a0_gemm_mode(int mode);
+
+/* Cross products the split-operand kernels form per multiply (the x9 GEMM family, the fused encoder's conv2 / conv3 and their data gradients, the fused conv2 / conv3
+ * weight gradient): with a = a0 + a1 + a2, b = b0 + b1 + b2 (exact bf16 terms, |a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|)
+ *   9 = all of them: every partial product of the fp32 fmaf chain, exactly (the strict mode);
+ *   6 = those with i + j <= 2 (default): a1*b2, a2*b1, a2*b2 — each below 2^-24 of a*b, below the rounding the fp32 chain applies to every partial sum — are not
+ *       formed; against fp64 the result is at least as close as the fp32 fmaf chain's at every reduction length of the path (profiles/r06_x6_accuracy.txt).
+ * n = 6 or 9 sets it, anything else only queries; returns the previous value.  Environment: A0_X9_PRODUCTS=9.  Process-wide: change it between launches, never
+ * during graph capture (captured graphs keep the kernels they were captured with).  conv1 (bytes x three weight terms) always forms all three. */
+int a0_x9_products(int n);
 
 /* ---------------------------------------------------------------- heads and losses */
 /* dueling combine (model.py:127-130,168-172,228-231): raw [R][ld] = [A*T advantages | T values | pad] -> q [R][A][T] */
@@ -391,18 +410,21 @@ int a0_learner_update(a0_learner* learner, const uint8_t* frames, const int* slo
 /* ---------------------------------------------------------------- the rest of the loop behind handles: replay ring and actor (csrc/runtime.hip)
  * a0_rbuf = ReplayDataset (replay.py:14-59) + the sampling of trainer.py:63-72,91-96: the HBM ring of st || st_next rows (2 * obs_bytes each) with its metadata,
  * uniform sampling (the DataLoader's shuffled epochs as a Feistel permutation, last batch of an epoch never returned: utils.py:51-56) or, prioritize != 0,
- * proportional sampling from the sum-tree with importance weights and the beta schedule; `seed` is the sampler's Philox seed (the Python classes use cfg.seed + 104729).
- * The reference-faithful flat priority vector (replay.sumtree=false: quirks Q1 / Q2 / Q7) exists in the Python classes only. */
+ * prioritize == 1, proportional sampling from the sum-tree with importance weights and the beta schedule, or, prioritize == 2 (round 6), the reference's prioritized
+ * mode TO THE LETTER (replay.sumtree=false; replay.py:45-59, trainer.py:91-104, quirks Q1 / Q2 / Q7): uniform permutation batches, a flat priority vector [size]
+ * whose TAIL takes max_p^alpha on every extend, importance weights from priority[idx] / the sum over the WHOLE capacity, priority[ids] = (loss + eps)^alpha.
+ * `seed` is the sampler's Philox seed (the Python classes use cfg.seed + 104729). */
 typedef struct a0_rbuf a0_rbuf;
 typedef struct a0_rbuf_desc {
-    long long size; int obs_bytes, B, prioritize;      /* replay.size, C*H*W, learner.batch_size, replay.policy == prioritize (sum-tree) */
+    long long size; int obs_bytes, B, prioritize;      /* replay.size, C*H*W, learner.batch_size, 0 = uniform / 1 = prioritized, sum-tree / 2 = prioritized, the reference's flat vector */
     double alpha, eps, beta0; long long total_steps;   /* replay.alpha / eps / beta0 (config.py:118-124), trainer.total_steps (the beta schedule's length) */
     unsigned long long seed;
 } a0_rbuf_desc;
 typedef struct a0_batch { const long long* idx; const int* slot; const int* act; const float* rew; const float* done; const float* prio; const float* weights; } a0_batch;
 int a0_rbuf_create(const a0_rbuf_desc* desc, a0_rbuf** out);
 /* ReplayDataset.__init__ (replay.py:14-30) over ring buffers the caller already holds (each may be NULL: library-owned): frames [size * 2 * obs_bytes] u8, act i32 / rew / done f32 [size], tree f32
- * [2 * 2^ceil(log2 size)] (prioritized), max_p f32 [1] (must hold the caller's current max priority: 1 for an empty ring) */
+ * [2 * 2^ceil(log2 size)] (prioritize == 1; with prioritize == 2 this argument is the flat priority vector f32 [size], all ones for an empty ring), max_p f32 [1] (must hold the
+ * caller's current max priority: 1 for an empty ring) */
 int a0_rbuf_create_on(const a0_rbuf_desc* desc, uint8_t* frames, int* act, float* rew, float* done, float* tree, float* max_p, a0_rbuf** out);
 int a0_rbuf_destroy(a0_rbuf* replay);
 long long a0_rbuf_len(const a0_rbuf* replay);

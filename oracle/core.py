@@ -12,13 +12,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liba0oracle.so")
+_SAN = os.environ.get("A0_SANITIZE") == "1"          # tools/asan.sh: the ASan + UBSan build of the same sources (make -C oracle asan)
+_SO = os.path.join(_HERE, "_build", *(("asan",) if _SAN else ()), "liba0oracle.so")
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("sumtree.c", "philox.c", "synth_env.c")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "asan" if _SAN else "all"])
     return _SO
 
 

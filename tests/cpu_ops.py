@@ -20,7 +20,8 @@ from agent0_amd._abi import EncoderWeights, FramesArg
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SO = os.path.join(_HERE, "_build", "libhost_emul.so")
+_SAN = os.environ.get("A0_SANITIZE") == "1"          # tools/asan.sh: ASan + UBSan build of the host emulation
+_SO = os.path.join(_HERE, "_build", *(("asan",) if _SAN else ()), "libhost_emul.so")
 
 
 def build_emul() -> str:
@@ -29,7 +30,8 @@ def build_emul() -> str:
     deps.append(os.path.join(_ROOT, "include", "agent0_hip.h"))
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SO, src])
+        opt = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if _SAN else ["-O2"]
+        subprocess.check_call(["g++", *opt, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SO, src])
     return _SO
 
 

@@ -71,8 +71,37 @@ def _install_stubs():
         def __init__(self, env=None, *a, **k):
             self.env = env
 
-    gym.RewardWrapper = _W
-    gym.Wrapper = _W
+    class Wrapper:
+        """gymnasium.Wrapper as far as the reference's wrappers use it (gymnasium 0.28.1 core.py): holds ``env``, forwards step / reset / unwrapped and unknown
+        attributes.  FUNCTIONAL since fixture group G12: the reference's FireResetEnv / EpisodicLifeEnv / ClipRewardEnv run on it."""
+
+        def __init__(self, env):
+            self.env = env
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
+
+        def __getattr__(self, name):
+            if name.startswith("_"):
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+        def step(self, action):
+            return self.env.step(action)
+
+        def reset(self, **kwargs):
+            return self.env.reset(**kwargs)
+
+    class RewardWrapper(Wrapper):
+        """gymnasium.RewardWrapper: step() passes the reward through ``self.reward`` (gymnasium 0.28.1 core.py)."""
+
+        def step(self, action):
+            obs, reward, terminated, truncated, info = self.env.step(action)
+            return obs, self.reward(reward), terminated, truncated, info
+
+    gym.RewardWrapper = RewardWrapper
+    gym.Wrapper = Wrapper
     gym.Env = object
     gym.make_vec = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no gymnasium here"))
     core = types.ModuleType("gymnasium.core")
@@ -98,7 +127,9 @@ def import_reference():
     import agent0.deepq.agent as ragent
     import agent0.deepq.replay as rreplay
     import agent0.common.utils as rutils
+    import agent0.common.atari_wrappers as rwrap
 
+    globals()["rwrap"] = rwrap
     assert os.path.realpath(rcfg.__file__).startswith(os.path.realpath(REF)), rcfg.__file__
     return rcfg, rmodel, ragent, rreplay, rutils
 
@@ -659,14 +690,41 @@ def g10_noisy():
          noisy_sigma_w=np.array(float(fresh.weight_sigma[0, 0])), noisy_sigma_b=np.array(float(fresh.bias_sigma[0])))
 
 
+# --------------------------------------------------------------------------- G12 Atari wrapper semantics
+def g12_wrappers():
+    """The reference's single-env wrappers (atari_wrappers.py:11-56) in make_atari's order — EpisodicLifeEnv, FireResetEnv, [RecordEpisodeStatistics: gymnasium's, absent],
+    ClipRewardEnv — over the scripted emulator of fake_ale.py, driven under the vector env's autoreset rule.  Stored per case: what every agent step returned (obs id,
+    clipped and raw reward, terminated, truncated, life_loss, the info's emulator counter), the observation of every reset, and the emulator's complete action log."""
+    import fake_ale
+    print("G12 atari wrappers (ClipRewardEnv, FireResetEnv, EpisodicLifeEnv) on a scripted emulator")
+    for name, (kw, needs_fire, n) in fake_ale.CASES.items():
+        actions = fake_ale.actions_for(name, n)
+        arrays = {"actions": actions}
+        for tag, clip in (("clip", True), ("raw", False)):
+            ale = fake_ale.ScriptedAle(fake_ale.make_script(**kw), needs_fire=needs_fire)
+            env = rwrap.EpisodicLifeEnv(ale)
+            if needs_fire:                       # FireResetEnv asserts a FIRE action (atari_wrappers.py:23): games without one cannot take it
+                env = rwrap.FireResetEnv(env)
+            if clip:
+                env = rwrap.ClipRewardEnv(env)
+            got = fake_ale.drive(env, actions)
+            if clip:
+                arrays.update({k: v for k, v in got.items()})
+                arrays["emulator_log"] = np.array(ale.log, dtype=np.int64)
+            else:
+                arrays["raw_reward"] = got["reward"]
+                assert np.array_equal(np.array(ale.log, dtype=np.int64), arrays["emulator_log"]), "clipping changes no emulator call"
+        save(f"g12_wrappers_{name}", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(1 if PINNED else 8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g12"]
     if PINNED and which != ["g6p"]:
         raise SystemExit("pinned mode generates group g6p only")
     table = dict(g1=g1_forward, g2=g2_layers, g3=g3_losses, g4=g4_c51_projection, g5=g5_huber, g6=g6_train,
-                 g7=g7_actor, g8=g8_replay, g9=g9_schedules, g10=g10_noisy, g6p=lambda: g6_train(pinned_fqf=True))
+                 g7=g7_actor, g8=g8_replay, g9=g9_schedules, g10=g10_noisy, g12=g12_wrappers, g6p=lambda: g6_train(pinned_fqf=True))
     for w in which:
         table[w]()
     print("done; total payload bytes:", sum(OUT.values()))

@@ -59,3 +59,54 @@ class ScriptedStack:
 
 def scripted_slice(seed=5):
     return functools.partial(ScriptedStack, seed)
+
+
+# ------------------------------------------------------------------------------------------------ fixture group G12 behind the env pool
+class _AsFrames:
+    """Turns the scripted emulator's (counter, base step) observation into a (4, 84, 84) uint8 stack that names it: every byte is counter % 251, bytes 0..3 of
+    frame 0 spell the counter itself (little endian)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def _frames(self, obs):
+        import numpy as np
+        c = int(obs[0])
+        f = np.full((4, 84, 84), c % 251, dtype=np.uint8)
+        f[0, 0, :4] = np.frombuffer(np.uint32(c).tobytes(), np.uint8)
+        return f
+
+    def reset(self, **kw):
+        o, info = self.env.reset(**kw)
+        return self._frames(o), info
+
+    def step(self, a):
+        o, r, te, tr, info = self.env.step(a)
+        return self._frames(o), r, te, tr, info
+
+    def close(self):
+        pass
+
+
+G12_NAMES = ("fire_lives", "fire_busy", "fire_ends_in_presses", "nofire")
+
+
+def _g12(e0, k):
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fake_ale
+    from agent0_amd.common.host_envs import FireOnReset, LifeLossInfo, VectorizedSingles
+    envs = []
+    for i in range(e0, e0 + k):
+        kw, needs_fire, _ = fake_ale.CASES[G12_NAMES[i % len(G12_NAMES)]]
+        env = LifeLossInfo(fake_ale.ScriptedAle(fake_ale.make_script(**kw), needs_fire=needs_fire))
+        envs.append(_AsFrames(FireOnReset(env) if needs_fire else env))
+    return VectorizedSingles(envs, clip_reward=True)
+
+
+def g12_slice():
+    """env i of the vector = the product's wrapper chain (what AtariSlice builds, minus gymnasium's preprocessing) over G12 case i % 4's scripted emulator."""
+    return _g12

@@ -278,3 +278,80 @@ def test_worker_accepts_only_the_next_sequence_number():
     assert accept_word(ctl_word(CMD_RESET, 8), 7) == (CMD_RESET, 8)
     src = inspect.getsource(env_pool.HostEnvPool.reset)
     assert src.index("self._wait_workers()") < src.index('self._np["ctl"][CTL_WORD] = ctl_word(CMD_STEP, self.seq)'), "reset() re-arms the word as CMD_STEP after the acknowledgement"
+
+
+# ------------------------------------------------------------------------------------------------ fixture group G12: the reference's own wrappers
+import pytest
+
+import fake_ale
+from util import golden
+
+
+def _product_chain(name):
+    kw, needs_fire, n = fake_ale.CASES[name]
+    ale = fake_ale.ScriptedAle(fake_ale.make_script(**kw), needs_fire=needs_fire)
+    env = LifeLossInfo(ale)
+    if needs_fire:
+        env = FireOnReset(env)
+    return ale, env, n
+
+
+@pytest.mark.parametrize("name", list(fake_ale.CASES))
+def test_g12_single_env_wrappers_equal_the_reference(name):
+    """FireOnReset / LifeLossInfo against what the reference's FireResetEnv / EpisodicLifeEnv (atari_wrappers.py:20-56) returned on the same scripted emulator
+    (tests/golden/gen_golden.py g12): every emulator call (action log, resets included), every returned observation, the life_loss flags — including the frames
+    with lives == 0 before the game ends, games that end during the start presses (reset again after a reset, ignored after a lost life) and games without FIRE."""
+    g = golden(f"g12_wrappers_{name}")
+    ale, env, n = _product_chain(name)
+    got = fake_ale.drive(env, g["actions"])
+    assert np.array_equal(np.array(ale.log), g["emulator_log"]), "the same emulator calls in the same order"
+    for k in ("obs_c", "obs_t", "terminated", "truncated", "life_loss", "info_c", "reset_obs_c"):
+        assert np.array_equal(got[k], g[k]), k
+    assert np.array_equal(got["reward"], g["raw_reward"]), "rewards reach the vectorisation layer unclipped (statistics first, clipping last: atari_wrappers.py:66-67)"
+    assert np.array_equal(np.sign(got["reward"]), g["reward"]), "ClipRewardEnv: the sign (atari_wrappers.py:15-17)"
+
+
+@pytest.mark.parametrize("name", list(fake_ale.CASES))
+def test_g12_vectorised_singles_equal_the_reference(name):
+    """The vectorisation layer over the product chain (autoreset, sign clipping, life_loss vector, final_info with the UNCLIPPED episode return) against the same
+    fixture: two copies of the case side by side, the second one step behind, so that the per-env bookkeeping cannot leak between envs."""
+    g = golden(f"g12_wrappers_{name}")
+    (ale0, e0, n), (ale1, e1, _) = _product_chain(name), _product_chain(name)
+    v = VectorizedSingles([e0, e1])
+    obs, _ = v.reset()
+    assert obs[:, 0].tolist() == [int(g["reset_obs_c"][0])] * 2
+    acts = g["actions"]
+    resets = [1, 1]                                         # index of the next reset observation per env
+    ret = [0.0, 0.0]
+    for t in range(n + 1):
+        a = np.array([acts[t] if t < n else 0, acts[t - 1] if t >= 1 else 0])
+        if t == 0:                                          # env 1 starts one step later: step env 0 alone through a one-env view
+            o, r, te, tr, info = VectorizedSingles.step(_OneOf(v, 0), a[:1])
+            idx = [(0, 0)]
+        elif t == n:
+            o, r, te, tr, info = VectorizedSingles.step(_OneOf(v, 1), a[1:])
+            idx = [(1, 0)]
+        else:
+            o, r, te, tr, info = v.step(a)
+            idx = [(0, 0), (1, 1)]
+        for env_i, col in idx:
+            s = t if env_i == 0 else t - 1
+            assert float(r[col]) == float(g["reward"][s]) and bool(te[col]) == bool(g["terminated"][s]) and bool(tr[col]) == bool(g["truncated"][s]), (t, env_i)
+            assert bool(info["life_loss"][col]) == bool(g["life_loss"][s])
+            ret[env_i] += float(g["raw_reward"][s])
+            if g["terminated"][s] or g["truncated"][s]:
+                assert int(o[col, 0]) == int(g["reset_obs_c"][resets[env_i]]), "autoreset: the next episode's first observation (after the start presses) is returned"
+                resets[env_i] += 1
+                assert bool(info["_final_info"][col]) and float(info["final_info"][col]["episode"]["r"][0]) == np.float32(ret[env_i]), "episode return over the unclipped rewards"
+                ret[env_i] = 0.0
+            else:
+                assert int(o[col, 0]) == int(g["obs_c"][s])
+                assert "_final_info" not in info or not bool(info["_final_info"][col])
+    assert np.array_equal(np.array(ale0.log), g["emulator_log"]) and np.array_equal(np.array(ale1.log), g["emulator_log"])
+
+
+class _OneOf:
+    """A one-env view of a VectorizedSingles (shares its envs and return accumulators)."""
+
+    def __init__(self, v, i):
+        self.envs, self.clip, self.returns = v.envs[i:i + 1], v.clip, v.returns[i:i + 1]

@@ -318,6 +318,62 @@ def test_host_env_pool_matches_device_env(workers, newest, algo, knobs, monkeypa
     assert float(outs[0][3].sum()) > 0, "the run contains done flags (life losses), so the flag path is exercised"
 
 
+@pytest.mark.parametrize("workers", [0, 2])
+def test_g12_host_env_pool_rows_equal_the_reference_wrappers(workers):
+    """N1 pinned to the reference: the product's wrapper chain over the scripted emulators of fixture group G12, behind HostEnvPool (in-process and
+    two worker processes), through Actor.sample into the replay ring.  Every row must hold what the REFERENCE's wrappers returned on the same emulator
+    (tests/golden/g12_wrappers_*.npz, generated by importing atari_wrappers.py:11-56): st = the observation before the step, st_next = the one after it (the next
+    episode's first observation on an autoreset), the sign-clipped reward, done = (terminated | life_loss) & ~truncated (agent.py:57-62), and the finished episodes'
+    unclipped returns in env order.  The emulator's outcomes do not depend on the action, so the actor's own epsilon-greedy choices are free."""
+    import host_slices
+    from agent0_amd.common.env_pool import HostEnvPool
+    from agent0_amd.deepq.agent import Actor
+    from agent0_amd.deepq.model import DeepQNet
+    from agent0_amd.deepq.replay import ReplayDataset
+    from util import golden
+    E, T, R = 4, 8, 18                                    # 144 agent steps per env (the shortest case drives 160)
+    cfg = make_cfg("dqn", E, **{"learner.n_step_q": 1, "actor.sample_steps": T, "replay.size": E * T * R, "learner.batch_size": 8})
+    model = DeepQNet(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(recipe.NetSpec("dqn", 4), 11).items()})
+    replay = ReplayDataset(cfg, ops=model.ops)
+    envs = HostEnvPool(host_slices.g12_slice(), E, obs_shape=(4, 84, 84), action_dim=4, num_workers=workers, ops=model.ops)
+    actor = Actor(cfg, model, replay=replay, rank=0, envs=envs)
+    rs_all = []
+    try:
+        for _ in range(R):
+            data, rs, qs = actor.sample(0.5)
+            replay.extend(data)
+            rs_all += [float(x) for x in rs]
+    finally:
+        actor.close()
+    n = E * T * R
+    rows = replay.frames[: n * replay.row_bytes].view(n, 2, 4, 84, 84).cpu().numpy()
+    rew, done = replay.rew[:n].cpu().numpy(), replay.done[:n].cpu().numpy()
+    counter = lambda stack: int(np.frombuffer(stack[0, 0, :4].tobytes(), np.uint32)[0])
+    G = [golden(f"g12_wrappers_{name}") for name in host_slices.G12_NAMES]
+    want_rs = []
+    prev = [int(g["reset_obs_c"][0]) for g in G]
+    nreset = [1] * E
+    ret = [0.0] * E
+    for s in range(T * R):
+        for e in range(E):
+            g, row = G[e], s * E + e                     # env-major within a step, step-major overall (agent.py:78-81)
+            over = bool(g["terminated"][s] or g["truncated"][s])
+            nxt = int(g["reset_obs_c"][nreset[e]]) if over else int(g["obs_c"][s])
+            assert counter(rows[row, 0]) == prev[e] and counter(rows[row, 1]) == nxt, (s, e)
+            assert (rows[row, 1, 1:] == nxt % 251).all() and (rows[row, 0, 1:] == prev[e] % 251).all()
+            assert float(rew[row]) == float(g["reward"][s]), (s, e)
+            assert bool(done[row]) == bool((g["terminated"][s] or g["life_loss"][s]) and not g["truncated"][s]), (s, e)
+            ret[e] += float(g["raw_reward"][s])
+            if over:
+                want_rs.append(float(np.float32(ret[e])))
+                ret[e] = 0.0
+                nreset[e] += 1
+            prev[e] = nxt
+    assert rs_all == want_rs, "episode returns over the unclipped rewards, in step and env order (agent.py:85-88)"
+    assert float(done.sum()) > 20 and len(want_rs) > 20
+
+
 @pytest.mark.parametrize("algo,n_step,workers,groups", [("dqn", 3, 4, 2), ("dqn", 1, 0, 2), ("c51", 1, 6, 3), ("dqn", 3, 2, 2)])
 def test_grouped_host_env_rollouts_match_the_device_env(algo, n_step, workers, groups):
     """Round 4 (N1): env_pool.HostEnvGroups splits the host vector env into groups with their own worker processes; the actor steps one group on the CPU while the
