@@ -113,7 +113,8 @@ class DeviceSynthVecEnv:
         common = (self.seed, self.rank, self.g, self._obs[self._cur], self._obs[nxt], self.ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0,
                   replay.frames, replay.size, start_slot, replay.act, replay.rew, replay.done)
         if enc is not None:      # (wt, encoder weights, act3): the same launch goes on to encode the new observation — the next step's features (a0_actor_*_env_step_enc)
-            {"qhead": self.ops.actor_qhead_env_step_enc, "dist": self.ops.actor_dist_tail_env_step_enc}[kind](*tail_args, *common, task=self.task, wt=enc[0], enc_w=enc[1], act3_next=enc[2])
+            {"qhead": self.ops.actor_qhead_env_step_enc, "dist": self.ops.actor_dist_tail_env_step_enc, "quantile": self.ops.actor_quantile_tail_env_step_enc}[kind](
+                *tail_args, *common, task=self.task, wt=enc[0], enc_w=enc[1], act3_next=enc[2])
         else:
             {"qhead": self.ops.actor_qhead_env_step, "dist": self.ops.actor_dist_tail_env_step, "quantile": self.ops.actor_quantile_tail_env_step}[kind](*tail_args, *common, task=self.task)
         self._cur = nxt

@@ -60,6 +60,11 @@ class DeviceRng:
         else:
             self.ops.rng_uniform(self.seed, stream, self._advance(stream, n), out, n)
 
+    def uniform_cos(self, stream: int, out: torch.Tensor, cos_out: torch.Tensor, n: int, D: int):
+        """``uniform`` plus the cosine features cos(pi (d + 1) out[r]), d < D, of the draws in the same launch (a0_tau_cos_features: the actor's IQN step)."""
+        ctrl = self.ctrl if (self.ctrl is not None and stream in self.CTRL_INDEX) else None
+        self.ops.tau_cos_features(self.seed, stream, self._advance(stream, n), out, cos_out, n, D, ctrl=ctrl, ctrl_idx=self.CTRL_INDEX.get(stream, 0))
+
     def randint(self, stream: int, hi: int, out: torch.Tensor, n: int):
         self.ops.rng_randint(self.seed, stream, self._advance(stream, n), hi, out, n)
 

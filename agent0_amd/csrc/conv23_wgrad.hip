@@ -94,7 +94,7 @@ A0_D a0q_u32x4 a0q_frag(const unsigned char* plane, int off0, int off1) {
 
 // One observation's k-steps for NT tiles of one wave (NT is wave-uniform: conv3 has waves with two tiles and with one).  The fragments are
 // not double-buffered: four waves per SIMD (two workgroups per CU) cover the LDS latency, and the registers buy the second workgroup.
-template <int LAYER, int NT>
+template <int NPR, int LAYER, int NT>
 A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, int aoff, const int (&boff)[a0q_geom<LAYER>::STEPS][2],
                         int a_blk, const int (&b_blk)[2], a0_acc16 (&acc)[2]) {
     typedef a0q_geom<LAYER> G;
@@ -112,7 +112,7 @@ A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, int 
             for (int j = 0; j < NT; ++j) b[j][t] = a0q_frag(act + t * G::ACT_PLANE + b_blk[j], boff[s][0], boff[s][1]);
         }
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
+        for (int q = 9 - NPR; q < 9; ++q)       // six products (a0_x9_products): lo*lo, lo*mid, mid*lo are not formed
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0q_bf16x8, a[TA[q]]), __builtin_bit_cast(a0q_bf16x8, b[j][TB[q]]), acc[j], 0, 0, 0);
@@ -138,7 +138,7 @@ A0_D void a0q_mma_steps(const unsigned char* act, const unsigned char* dpl, int 
     }
 }
 
-template <int LAYER>
+template <int NPR, int LAYER>
 A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned char* smem) {
     typedef a0q_geom<LAYER> G;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -237,8 +237,8 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
         }
         __syncthreads();
         if (b + ngroups < P.B) load_raw(b + ngroups);
-        if (nt == 2) a0q_mma_steps<LAYER, 2>(act, dpl, aoff, boff, a_blk, b_blk, acc);
-        else a0q_mma_steps<LAYER, 1>(act, dpl, aoff, boff, a_blk, b_blk, acc);
+        if (nt == 2) a0q_mma_steps<NPR, LAYER, 2>(act, dpl, aoff, boff, a_blk, b_blk, acc);
+        else a0q_mma_steps<NPR, LAYER, 1>(act, dpl, aoff, boff, a_blk, b_blk, acc);
         __syncthreads();          // the planes are rebuilt for the next observation
     }
 
@@ -271,6 +271,7 @@ A0_D void a0q_body(const a0_c23w_args& P, int part, int g, int ngroups, unsigned
     }
 }
 
+template <int NPR>
 __global__ __launch_bounds__(A0Q_THREADS, 4) void a0_conv23_wgrad_fused_kernel(a0_c23w_args P) {      // four waves per SIMD: two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char a0q_smem[];
     // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  The seven parts of a group read the
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(A0Q_THREADS, 4) void a0_conv23_wgrad_fused_kernel(a
     // inside an XCD the workgroups run group by group, part by part (parts 0-3: conv2 classes, 4-6: conv3 kernel rows).
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, g = xcd + 8 * (k / 7), part = k % 7;
     if (g >= P.G2) return;                                   // G2 == G3 (a0_c23w_plan); the grid is rounded up to whole XCD rows
-    if (part < 4) a0q_body<2>(P, part, g, P.G2, a0q_smem);
-    else a0q_body<3>(P, part - 4, g, P.G3, a0q_smem);
+    if (part < 4) a0q_body<NPR, 2>(P, part, g, P.G2, a0q_smem);
+    else a0q_body<NPR, 3>(P, part - 4, g, P.G3, a0q_smem);
 }
 
 // returns 1 when the kernel ran (slab2: G2 slabs of 64*512 + 64 floats, slab3: G3 slabs of 64*576 + 64; a0_c23w_plan), 0 = shape not
@@ -290,13 +291,15 @@ int a0_conv23_wgrad_fused_launch(const a0_net_core& n, int B, const float* act1,
     if (!a0_c23w_plan(n, B, &G2, &G3) || !slab2 || !slab3) return 0;
     a0_c23w_args P;
     P.act1 = act1; P.act2 = act2; P.d2 = d2; P.d3 = d3; P.slab2 = slab2; P.slab3 = slab3; P.B = B; P.G2 = G2; P.G3 = G3;
-    static bool configured = false;
-    if (!configured) {
-        A0_HIP_THROW(hipFuncSetAttribute((const void*)a0_conv23_wgrad_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A0Q_LDS_BYTES));
-        configured = true;
+    const int six = a0_x9_products_now() == 6;
+    auto kern = six ? a0_conv23_wgrad_fused_kernel<6> : a0_conv23_wgrad_fused_kernel<9>;
+    static bool configured[2] = {false, false};
+    if (!configured[six]) {
+        A0_HIP_THROW(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, A0Q_LDS_BYTES));
+        configured[six] = true;
     }
     if (G2 != G3) return 0;
-    hipLaunchKernelGGL(a0_conv23_wgrad_fused_kernel, dim3(8 * 7 * ((G2 + 7) / 8)), dim3(A0Q_THREADS), A0Q_LDS_BYTES, st, P);
+    hipLaunchKernelGGL(kern, dim3(8 * 7 * ((G2 + 7) / 8)), dim3(A0Q_THREADS), A0Q_LDS_BYTES, st, P);
     A0_HIP_THROW(hipGetLastError());
     return 1;
 }

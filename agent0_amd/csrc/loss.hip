@@ -314,6 +314,36 @@ extern "C" int a0_actor_quantile_tail_env_step(const float* slabs, long long sla
     return a0_fail_hip((int)hipGetLastError(), "a0_actor_quantile_tail_env_step");
 }
 
+// a0_actor_quantile_tail_env_step whose workgroups go on to encode their env's new observation into act3_next [E][3136] (round 6; a0_actor_dist_tail_env_step_enc's kernel
+// with the quantile layout of the head's slabs): the NEXT step's features in the same launch
+extern "C" int a0_actor_quantile_tail_env_step_enc(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                                   const float* taus, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                                   unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                                   unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                                   float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                                   const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task,
+                                                   const float* wt, const a0_encoder_weights* w, float* act3_next, void* stream) {
+    if (!slabs || !bias || !action || !qmax || E < 1 || A < 1 || T < 1 || nslab < 1 || ld < A + (dueling ? 1 : 0) || slab_stride < (long long)E * T * ld ||
+        (mode != 1 && mode != 3) || (mode == 3 && !taus))
+        return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step_enc: bad argument");
+    if (!obs_in || !obs_out || obs_in == obs_out || !ep_ret || !final_mask || !final_ret || !ring_act || !ring_rew || !ring_done || !obs0 || !frames || !r_act ||
+        !r_rew || !r_done || n < 1 || steps < 0 || cap < E || start_slot < 0 || task < A0_ENV_TASK_STREAM || task > A0_ENV_TASK_CHASE || (task == A0_ENV_TASK_CHASE && A < 4))
+        return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step_enc: bad env argument");
+    if ((((uintptr_t)obs_in) | ((uintptr_t)obs_out) | ((uintptr_t)obs0) | ((uintptr_t)frames)) & 15) return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step_enc: buffers must be 16-byte aligned");
+    const size_t lds = (size_t)(A * T + T) * sizeof(float);
+    if (lds > 64 * 1024) return a0_fail(A0_EINVAL, "a0_actor_quantile_tail_env_step_enc: head too wide for LDS");
+    a0_dtenv_args P;
+    P.slabs = slabs; P.slab_stride = slab_stride; P.nslab = nslab; P.bias = bias; P.ld = ld; P.A = A; P.T = T; P.dueling = dueling; P.mode = mode; P.atoms = nullptr; P.E = E;
+    P.rng_seed = seed; P.stream_a = stream_a; P.stream_u = stream_u; P.off_a = off_a; P.off_u = off_u; P.eps = eps; P.ctrl = ctrl; P.eps_ptr = eps_ptr;
+    P.action = action; P.qmax = qmax;
+    P.env_seed = env_seed; P.rank = rank; P.g = g; P.obs_in = obs_in; P.obs_out = obs_out; P.ep_ret = ep_ret; P.final_mask = final_mask; P.final_ret = final_ret;
+    P.n = n; P.steps = steps; P.gamma = gamma; P.ring_act = ring_act; P.ring_rew = ring_rew; P.ring_done = ring_done; P.obs0 = obs0; P.frames = frames;
+    P.cap = cap; P.start = start_slot % cap; P.r_act = r_act; P.r_rew = r_rew; P.r_done = r_done; P.task = task;
+    P.kt = 1; P.taus = taus;
+    P.vec4 = (!(ld & 3) && !(slab_stride & 3) && !((((uintptr_t)slabs) | ((uintptr_t)bias)) & 15)) ? 1 : 0;
+    return a0_actor_dist_step_enc_launch(P, lds, wt, w, act3_next, (hipStream_t)stream);
+}
+
 // mode 1: mean over the T quantiles (qr); mode 2: C51 expectation with `atoms` [T]
 extern "C" int a0_actor_dist_tail(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
                                   const float* atoms, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,

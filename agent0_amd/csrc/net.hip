@@ -262,6 +262,8 @@ struct a0_hip_backend {
                     return;
                 }
             }
+            // (round 6, six products: the same 128 x 128 tile on FOUR waves of 64 x 64 — a third fewer LDS fragment reads per MFMA, one wave per SIMD — measured 139.9 vs
+            // 137.7 us on the actor's 8 192-row fc1, iqn 86.4 vs 85.9 ms: not kept, profiles/r06_experiments.md)
             if (x9 && large) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
             else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
             else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));

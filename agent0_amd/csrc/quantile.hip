@@ -3,6 +3,7 @@
 // Restates reference agent0/deepq/model.py:235-251 (IQNHead.feature_emb), model.py:268-278 (FQFHead.prop_taus) and
 // agent0/deepq/agent.py:371-387 (fraction loss).
 #include "a0_internal.h"
+#include "philox.h"
 
 // cosx[r][i] = cos((pi * (i+1)) * tau_r), i < D   — pi*(i+1) rounded to fp32 first, as `np.pi * torch.arange(1, D+1)` is
 __global__ void a0_cos_features_kernel(const float* __restrict__ taus, float* __restrict__ out, long long R, int D) {
@@ -19,6 +20,29 @@ extern "C" int a0_cos_features(const float* taus, float* out, long long R, int D
     long long n = R * D;
     hipLaunchKernelGGL(a0_cos_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, taus, out, R, D);
     return a0_fail_hip((int)hipGetLastError(), "a0_cos_features");
+}
+
+// The actor's IQN step (round 6): the step's R = E * K fractions drawn from the Philox stream (element r of a0_rng_uniform: word (r & 3) of block (offset + r) >> 2) AND
+// their cosine features in one launch — the same two formulas as a0_rng_uniform_kernel and a0_cos_features_kernel, hence the same bits.
+__global__ void a0_tau_cos_features_kernel(unsigned long long seed, uint32_t stream, unsigned long long offset, const long long* __restrict__ ctrl, int ctrl_idx,
+                                           float* __restrict__ taus, float* __restrict__ out, long long R, int D) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * D) return;
+    if (ctrl) offset += (unsigned long long)ctrl[ctrl_idx];
+    const long long r = i / D;
+    const int d = (int)(i % D);
+    const float tau = (float)(a0_philox_word(seed, stream, offset + (unsigned long long)r) >> 8) * 0x1.0p-24f;
+    if (d == 0) taus[r] = tau;
+    const float ipi = 3.14159274101257324f * (float)(d + 1);
+    out[i] = cosf(ipi * tau);
+}
+
+extern "C" int a0_tau_cos_features(unsigned long long seed, unsigned int stream, unsigned long long offset, const long long* ctrl, int ctrl_idx, float* taus, float* out,
+                                   long long R, int D, void* stream_h) {
+    if (!taus || !out || R < 1 || D < 1 || (ctrl && (ctrl_idx < 0 || ctrl_idx >= A0_CTRL_WORDS))) return a0_fail(A0_EINVAL, "a0_tau_cos_features: bad argument");
+    const long long n = R * D;
+    hipLaunchKernelGGL(a0_tau_cos_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_h, seed, stream, offset, ctrl, ctrl_idx, taus, out, R, D);
+    return a0_fail_hip((int)hipGetLastError(), "a0_tau_cos_features");
 }
 
 // x[(b,n)][d] = emb[(b,n)][d] * feat[b][d]       (16 B per lane; D % 4 == 0)
@@ -69,8 +93,11 @@ extern "C" int a0_hadamard_bwd(const float* dx, const float* emb, const float* f
 }
 
 // taus[b][0] = 0, taus[b][i+1] = cumsum_i softmax(logits[b]);  tau_hat[b][i] = (taus[i] + taus[i+1]) / 2     (F <= 64)
-__global__ __launch_bounds__(64) void a0_fqf_taus_kernel(const float* __restrict__ logits, int ld, float* __restrict__ taus, float* __restrict__ tau_hat, int B, int F) {
+// cos_out (optional, round 6: the actor's step): the cosine features [B * F][D] of the tau_hats in the same launch (== a0_cos_features on tau_hat)
+__global__ __launch_bounds__(64) void a0_fqf_taus_kernel(const float* __restrict__ logits, int ld, float* __restrict__ taus, float* __restrict__ tau_hat, int B, int F,
+                                                          float* __restrict__ cos_out, int D) {
     __shared__ float p[64];
+    __shared__ float th[64];
     const int b = blockIdx.x, t = threadIdx.x;
     const float x = (t < F) ? logits[(long long)b * ld + t] : -INFINITY;
     float mx = x;
@@ -88,15 +115,31 @@ __global__ __launch_bounds__(64) void a0_fqf_taus_kernel(const float* __restrict
             const float prev = c;
             c += p[i];
             taus[(long long)b * (F + 1) + i + 1] = c;
-            tau_hat[(long long)b * F + i] = (prev + c) / 2.0f;
+            const float h = (prev + c) / 2.0f;
+            tau_hat[(long long)b * F + i] = h;
+            th[i] = h;
+        }
+    }
+    if (cos_out) {
+        __syncthreads();
+        for (int k = t; k < F * D; k += 64) {
+            const int i = k / D, d = k - i * D;
+            const float ipi = 3.14159274101257324f * (float)(d + 1);
+            cos_out[(long long)b * F * D + k] = cosf(ipi * th[i]);
         }
     }
 }
 
 extern "C" int a0_fqf_taus(const float* logits, int ld, float* taus, float* tau_hat, int B, int F, void* stream) {
     if (!logits || !taus || !tau_hat || B < 1 || F < 2 || F > 64 || ld < F) return a0_fail(A0_EINVAL, "a0_fqf_taus: bad argument");
-    hipLaunchKernelGGL(a0_fqf_taus_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ld, taus, tau_hat, B, F);
+    hipLaunchKernelGGL(a0_fqf_taus_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ld, taus, tau_hat, B, F, (float*)nullptr, 0);
     return a0_fail_hip((int)hipGetLastError(), "a0_fqf_taus");
+}
+
+extern "C" int a0_fqf_taus_cos(const float* logits, int ld, float* taus, float* tau_hat, float* cos_out, int D, int B, int F, void* stream) {
+    if (!logits || !taus || !tau_hat || !cos_out || D < 1 || B < 1 || F < 2 || F > 64 || ld < F) return a0_fail(A0_EINVAL, "a0_fqf_taus_cos: bad argument");
+    hipLaunchKernelGGL(a0_fqf_taus_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ld, taus, tau_hat, B, F, cos_out, D);
+    return a0_fail_hip((int)hipGetLastError(), "a0_fqf_taus_cos");
 }
 
 // out[b][i] = taus[b][i+1], i < F-1     (taus[:, 1:-1])

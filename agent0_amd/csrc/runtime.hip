@@ -444,7 +444,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     static const bool step_enc_on = getenv("A0_NO_X9") == nullptr && (getenv("A0_STEP_ENC") == nullptr || atoi(getenv("A0_STEP_ENC")) != 0);
     // (not for an actor with its own network — the launch schedule: its rollout runs beside the update block, the critical path there, and a workgroup that holds a CU's
     // LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives: 9.43 -> 9.75 ms)
-    const bool step_enc = step_enc_on && !quant && !a->own_flat;
+    const bool step_enc = step_enc_on && !a->own_flat;
     bool feat_ready = false;
     for (int t = 0; t < a->T; ++t) {
         if (L->d.noisy && a->steps % freq == 0) {      // agent.py:52-53: self.model.reset_noise() every reset_noise_freq steps, from the ACTOR's stream
@@ -465,11 +465,10 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             const float* on = V.flat;
             if (fqf) {      // FQFHead.prop_taus (model.py:268-278): the fraction net on the step's features; no draws
                 A0_CHECK(a0_dense_fwd(a->act3, L->feat, on + L->frac.w(), on + L->frac.b(), a->f_logits, E, 32, L->feat, 0, a->fwd_scratch, stream));
-                A0_CHECK(a0_fqf_taus(a->f_logits, 32, a->f_tau_all, a->q_taus, E, nt, stream));
-            } else {
-                A0_CHECK(a0_rng_uniform(a->rng.seed, 3 /* STREAM_TAUS */, a->rng.reserve(3, rows), a->q_taus, rows, stream));
+                A0_CHECK(a0_fqf_taus_cos(a->f_logits, 32, a->f_tau_all, a->q_taus, a->q_cosx, 64, E, nt, stream));       // (round 6) + the cosine features of the tau_hats
+            } else {       // (round 6) the draw and its cosine features in one launch
+                A0_CHECK(a0_tau_cos_features(a->rng.seed, 3 /* STREAM_TAUS */, a->rng.reserve(3, rows), nullptr, 0, a->q_taus, a->q_cosx, rows, 64, stream));
             }
-            A0_CHECK(a0_cos_features(a->q_taus, a->q_cosx, rows, 64, stream));
             A0_CHECK(a0_dense_fwd_mul(a->q_cosx, 64, on + L->cos.w(), on + L->cos.b(), a->act3, nt, a->q_x, rows, L->feat, 64, 1, stream));
             A0_CHECK(a0_dense_fwd(a->q_x, L->feat, V.Wf(), V.bf(), a->h, rows, 512, L->feat, 1, a->fwd_scratch, stream));
             const int ns = a0_dense_fwd_partial_slabs(rows, L->Npad, 512);
@@ -477,6 +476,14 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
             const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);
             const int nx = (a->cur + 1) % a->K;
             a->g += 1;
+            if (step_enc && t + 1 < a->T) {      // (round 6) the tail's workgroups go on to encode their env's new observation: the next step starts with its features
+                A0_CHECK(a0_actor_quantile_tail_env_step_enc(a->head_slabs, (long long)rows * L->Npad, ns, V.bh(), L->Npad, A, nt, a->d.dueling ? 1 : 0, fqf ? 3 : 1, fqf ? a->f_tau_all : nullptr, E, a->rng.seed,
+                                                             STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed,
+                                                             a->d.rank, a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,
+                                                             a->d.discount, a->ring_act, a->ring_rew, a->ring_done, obs0, R->frames, R->size, (start + (long long)t * E) % R->size, R->act,
+                                                             R->rew, R->done, a->d.env_task, V.wt, &w, a->act3, stream));
+                feat_ready = true;
+            } else
             A0_CHECK(a0_actor_quantile_tail_env_step(a->head_slabs, (long long)rows * L->Npad, ns, V.bh(), L->Npad, A, nt, a->d.dueling ? 1 : 0, fqf ? 3 : 1, fqf ? a->f_tau_all : nullptr, E, a->rng.seed,
                                                      STREAM_EGREEDY_A, STREAM_EGREEDY_U, oa, ou, epsilon, nullptr, nullptr, a->action, a->qmax_all + (long long)t * E, a->d.seed,
                                                      a->d.rank, a->g, cur_obs, a->obs[nx], a->ep_ret, a->stat_mask + (long long)t * E, a->stat_ret + (long long)t * E, a->n, a->steps,

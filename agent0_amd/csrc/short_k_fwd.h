@@ -51,7 +51,7 @@ A0_D void a0_short_k_split8(const a0_f4& v0, const a0_f4& v1, a0_u32x4g& hi, a0_
 // stores that follow the loads and waits for ALL of them to be acknowledged before every unit (46 instead of 38 us at 8 192 rows); the same
 // happens for any load still pending at the loop's entry (the strip's bias) and for loads issued after the previous unit's stores (the M
 // row of a unit is therefore requested one unit ahead, with the rows).
-template <int MODE, bool GUARD>
+template <int MODE, bool GUARD, int NPR = 9>
 __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void a0_short_k_fwd_kernel(a0_short_k_args 
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int q = 0; q < 9; ++q)
+            for (int q = 9 - NPR; q < 9; ++q)      // six products (a0_x9_products): lo*lo, lo*mid, mid*lo are not formed
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(a0_bf16x8g, a[s][TA[q]]),
@@ -216,15 +216,15 @@ static inline hipError_t a0_short_k_fwd_launch(hipStream_t st, const float* X, i
     const int mode = !M ? 0 : (Y2 ? 2 : 1);
     const bool guard = (R & 31) != 0 || (N & 63) != 0 || (mode != 0 && P.group < 31);       // groups of >= 31 rows: a 32-row block touches at most two of them
     const dim3 grid((unsigned)wg), block(256);
-    if (guard) {
-        if (mode == 0) hipLaunchKernelGGL((a0_short_k_fwd_kernel<0, true>), grid, block, 0, st, P);
-        else if (mode == 1) hipLaunchKernelGGL((a0_short_k_fwd_kernel<1, true>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((a0_short_k_fwd_kernel<2, true>), grid, block, 0, st, P);
-    } else {
-        if (mode == 0) hipLaunchKernelGGL((a0_short_k_fwd_kernel<0, false>), grid, block, 0, st, P);
-        else if (mode == 1) hipLaunchKernelGGL((a0_short_k_fwd_kernel<1, false>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((a0_short_k_fwd_kernel<2, false>), grid, block, 0, st, P);
-    }
+    typedef void (*a0_sk_kern)(a0_short_k_args);
+    const bool six = a0_x9_products_now() == 6;
+    const a0_sk_kern kern = guard ? (mode == 0 ? (six ? a0_short_k_fwd_kernel<0, true, 6> : a0_short_k_fwd_kernel<0, true, 9>)
+                                  : mode == 1 ? (six ? a0_short_k_fwd_kernel<1, true, 6> : a0_short_k_fwd_kernel<1, true, 9>)
+                                              : (six ? a0_short_k_fwd_kernel<2, true, 6> : a0_short_k_fwd_kernel<2, true, 9>))
+                                  : (mode == 0 ? (six ? a0_short_k_fwd_kernel<0, false, 6> : a0_short_k_fwd_kernel<0, false, 9>)
+                                  : mode == 1 ? (six ? a0_short_k_fwd_kernel<1, false, 6> : a0_short_k_fwd_kernel<1, false, 9>)
+                                              : (six ? a0_short_k_fwd_kernel<2, false, 6> : a0_short_k_fwd_kernel<2, false, 9>));
+    hipLaunchKernelGGL(kern, grid, block, 0, st, P);
     return hipGetLastError();
 }
 

@@ -130,13 +130,17 @@ class Actor:
     def _quant_tail_args(self, epsilon, ctrl, eps_ptr, t):
         """The quantile head up to the head GEMM's slabs (enqueued here), then the arguments of ``ops.actor_quantile_tail_env_step``."""
         L, ops, E, dev, rng = self.L, self.ops, self.E, self.model._dev, self.rng
+        fused_cos = hasattr(ops, "tau_cos_features") and os.environ.get("A0_TAU_COS", "1") != "0"      # round 6: the fractions and their cosine features in one launch (0: tuning aid, same bits)
         if L.algo == "fqf":
-            dev.fqf_taus(self.ws, E)
+            dev.fqf_taus(self.ws, E, with_cos=fused_cos)
             taus, aux, mode = self.ws.tau_hat, self.ws.tau_all, 3
         else:
-            rng.uniform(rng.STREAM_TAUS, self.taus, E * self.n_tau)
+            if fused_cos:
+                rng.uniform_cos(rng.STREAM_TAUS, self.taus, self.ws.cosx, E * self.n_tau, L.num_cosines)
+            else:
+                rng.uniform(rng.STREAM_TAUS, self.taus, E * self.n_tau)
             taus, aux, mode = self.taus, None, 1
-        ns = dev.head_slabs(self.ws, E, taus, self.n_tau, self._head_slabs)
+        ns = dev.head_slabs(self.ws, E, taus, self.n_tau, self._head_slabs, cos_ready=fused_cos)
         _, bh = dev.wb("head")
         return (self._head_slabs, ns, bh, L.Npad, L.A, self.n_tau, L.dueling, mode, aux, E, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
                 rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
@@ -192,7 +196,8 @@ class Actor:
         # a0_actor_dist_tail_env_step_enc) — the next step starts with its features in place, and a scalar-head step is two launches (fc1 GEMM | tail + env step + next
         # encoder) instead of three.  The convolution weights do not change inside a rollout (NoisyNet touches the dense layers only), the last step has no next one.
         dev = self.model._dev
-        step_enc = (self.tail_env and (self.fused_tail or self.dist_tail) and bound and not test and dev.fused and (self.L.C, self.L.H, self.L.W) == (4, 84, 84) and hasattr(ops, "actor_qhead_env_step_enc")
+        step_enc = ((self.tail_env and (self.fused_tail or self.dist_tail) or (self.quant_tail and self.fused_commit and hasattr(ops, "actor_quantile_tail_env_step_enc")))
+                    and bound and not test and dev.fused and (self.L.C, self.L.H, self.L.W) == (4, 84, 84) and hasattr(ops, "actor_qhead_env_step_enc")
                     and os.environ.get("A0_NO_X9") is None and os.environ.get("A0_STEP_ENC", "1") != "0"       # 0: tuning aid (same bytes, three launches per step)
                     # not on the launch schedule (the rollout into a stage ring): there the rollout runs BESIDE the update block, which is the critical path, and a
                     # workgroup that holds a CU's LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives (9.43 -> 9.75 ms)

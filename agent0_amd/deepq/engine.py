@@ -223,12 +223,14 @@ class DeviceNet:
         ops.dueling_fwd(ws.raw, L.Npad, ws.q, R, L.A, 1, L.dueling)
         return ws.q
 
-    def head_slabs(self, ws: Workspace, B, taus: torch.Tensor, n_tau: int, slabs: torch.Tensor) -> int:
+    def head_slabs(self, ws: Workspace, B, taus: torch.Tensor, n_tau: int, slabs: torch.Tensor, cos_ready: bool = False) -> int:
         """Quantile heads of a pass that is not differentiated, up to the head GEMM's split-K slabs [ns][B * n_tau][Npad] (the consumer kernel finishes
-        the layer: a0_actor_quantile_tail_env_step).  Returns the slab count."""
+        the layer: a0_actor_quantile_tail_env_step).  Returns the slab count.  ``cos_ready``: ``ws.cosx`` already holds the fractions' cosine features (the launch that
+        produced the fractions wrote them: a0_tau_cos_features / a0_fqf_taus_cos)."""
         L, ops = self.L, self.ops
         R = B * n_tau
-        ops.cos_features(taus, ws.cosx, R, L.num_cosines)
+        if not cos_ready:
+            ops.cos_features(taus, ws.cosx, R, L.num_cosines)
         Wc, bc = self.wb("cos")
         ops.dense_fwd_mul(ws.cosx, L.num_cosines, Wc, bc, ws.act3, n_tau, ws.x, R, L.feat, L.num_cosines, True)
         self._dense(ws.x, L.feat, "fc1", ws.h, R, True)
@@ -239,11 +241,14 @@ class DeviceNet:
         """features -> relu(fc1) only (the fused DQN head kernel takes it from there)."""
         self._dense(ws.act3, self.L.feat, "fc1", ws.h, B, True)
 
-    def fqf_taus(self, ws: Workspace, B):
-        """FQFHead.prop_taus (model.py:268-278): fraction net on (detached) features -> taus, tau_hats."""
+    def fqf_taus(self, ws: Workspace, B, with_cos: bool = False):
+        """FQFHead.prop_taus (model.py:268-278): fraction net on (detached) features -> taus, tau_hats (``with_cos``: and the tau_hats' cosine features into ``ws.cosx``)."""
         L = self.L
         self._dense(ws.act3, L.feat, "frac", ws.frac_logits, B, False)
-        self.ops.fqf_taus(ws.frac_logits, L.Fpad, ws.tau_all, ws.tau_hat, B, L.F)
+        if with_cos:
+            self.ops.fqf_taus_cos(ws.frac_logits, L.Fpad, ws.tau_all, ws.tau_hat, ws.cosx, L.num_cosines, B, L.F)
+        else:
+            self.ops.fqf_taus(ws.frac_logits, L.Fpad, ws.tau_all, ws.tau_hat, B, L.F)
 
     def select(self, ws: Workspace, B, n_tau, a_star, qsel=None, qmax=None, atoms=None):
         """argmax_a head.qval (greedy action) from the activations in ``ws``."""

@@ -348,6 +348,15 @@ class HipOps:
     def cos_features(self, taus, out, R, D):
         check(self.lib.a0_cos_features(_req(taus, torch.float32, R, "taus"), _req(out, torch.float32, R * D, "out"), R, D, _stream()), "a0_cos_features")
 
+    def tau_cos_features(self, seed, stream_id, offset, taus, out, R, D, ctrl=None, ctrl_idx=0):
+        """taus = the Philox uniform draws [offset, offset + R) of the stream (== rng_uniform / rng_uniform_ctrl) and out = cos_features(taus), one launch (a0_tau_cos_features)."""
+        check(self.lib.a0_tau_cos_features(seed, stream_id, offset, _req(ctrl, torch.int64, 8, "ctrl", optional=True), int(ctrl_idx), _req(taus, torch.float32, R, "taus"),
+                                           _req(out, torch.float32, R * D, "out"), R, D, _stream()), "a0_tau_cos_features")
+
+    def fqf_taus_cos(self, logits, ld, taus, tau_hat, cos_out, D, B, F):
+        check(self.lib.a0_fqf_taus_cos(_req(logits, torch.float32, B * ld, "logits"), ld, _req(taus, torch.float32, B * (F + 1), "taus"), _req(tau_hat, torch.float32, B * F, "tau_hat"),
+                                       _req(cos_out, torch.float32, B * F * D, "cos_out"), D, B, F, _stream()), "a0_fqf_taus_cos")
+
     def hadamard_fwd(self, emb, feat, x, B, n, D):
         check(self.lib.a0_hadamard_fwd(_req(emb, torch.float32, B * n * D, "emb"), _req(feat, torch.float32, B * D, "feat"), _req(x, torch.float32, B * n * D, "x"), B, n, D, _stream()), "a0_hadamard_fwd")
 
@@ -616,6 +625,24 @@ class HipOps:
             _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
             _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
             _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), int(task), _stream()), "a0_actor_quantile_tail_env_step")
+
+    def actor_quantile_tail_env_step_enc(self, slabs, nslab, bias, ld, A, T, dueling, mode, taus, E, seed, stream_a, stream_u, off_a, off_u, eps, action, qmax, ctrl, eps_ptr,
+                                         env_seed, rank, g, obs_in, obs_out, ep_ret, final_mask, final_ret, n, steps, gamma, ring_act, ring_rew, ring_done, obs0, frames, cap,
+                                         start_slot, r_act, r_rew, r_done, task=0, wt=None, enc_w=None, act3_next=None):
+        """``actor_quantile_tail_env_step`` whose kernel goes on to encode the env's new observation into ``act3_next`` [E][3136] (a0_actor_quantile_tail_env_step_enc)."""
+        nb = E * 4 * 84 * 84
+        ew = self._enc_w(enc_w)
+        check(self.lib.a0_actor_quantile_tail_env_step_enc(
+            _req(slabs, torch.float32, nslab * E * T * ld, "slabs"), E * T * ld, nslab, _req(bias, torch.float32, A + (1 if dueling else 0), "bias"), ld, A, T, int(dueling),
+            mode, _req(taus, torch.float32, E * (T + 1), "taus", optional=(mode != 3)), E, seed, stream_a, stream_u, off_a, off_u, float(eps),
+            _req(ctrl, torch.int64, 8, "ctrl", optional=True), _req(eps_ptr, torch.float32, 1, "eps_ptr", optional=True),
+            _req(action, torch.int32, E, "action"), _req(qmax, torch.float32, E, "qmax"),
+            env_seed, rank, g, _req(obs_in, torch.uint8, nb, "obs_in"), _req(obs_out, torch.uint8, nb, "obs_out"), _req(ep_ret, torch.float32, E, "ep_ret"),
+            _req(final_mask, torch.float32, E, "final_mask"), _req(final_ret, torch.float32, E, "final_ret"), n, steps, float(gamma),
+            _req(ring_act, torch.int32, n * E, "ring_act"), _req(ring_rew, torch.float32, n * E, "ring_rew"), _req(ring_done, torch.float32, n * E, "ring_done"),
+            _req(obs0, torch.uint8, nb, "obs0"), _req(frames, torch.uint8, cap * 8 * 84 * 84, "frames"), cap, start_slot, _req(r_act, torch.int32, cap, "r_act"),
+            _req(r_rew, torch.float32, cap, "r_rew"), _req(r_done, torch.float32, cap, "r_done"), int(task),
+            _req(wt, torch.float32, self.conv_wt_floats(4), "wt"), C.addressof(ew), _req(act3_next, torch.float32, E * 3136, "act3_next"), _stream()), "a0_actor_quantile_tail_env_step_enc")
 
     def actor_qhead_scratch(self, E, K) -> int:
         return int(self.lib.a0_actor_qhead_scratch(E, K))

@@ -298,9 +298,15 @@ int a0_loss_quantile_huber(const float* q, long long sb, long long si, long long
 
 /* IQN / FQF head pieces (model.py:235-251, 268-278; agent.py:371-387) */
 int a0_cos_features(const float* taus, float* out, long long R, int D, void* stream);
+/* (round 6) the actor's IQN step: taus[r] = element offset + r of the Philox uniform stream (== a0_rng_uniform / a0_rng_uniform_ctrl: ctrl, when given, adds
+ * ctrl[ctrl_idx] to the offset) and out = a0_cos_features(taus) in ONE launch; the same bits as the two calls (model.py:238-241) */
+int a0_tau_cos_features(unsigned long long seed, unsigned int stream, unsigned long long offset, const long long* ctrl, int ctrl_idx, float* taus, float* out,
+                        long long R, int D, void* stream_h);
 int a0_hadamard_fwd(const float* emb, const float* feat, float* x, int B, int n, int D, void* stream);
 int a0_hadamard_bwd(const float* dx, const float* emb, const float* feat, float* demb, float* d3, int B, int n, int D, void* stream);
 int a0_fqf_taus(const float* logits, int ld, float* taus, float* tau_hat, int B, int F, void* stream);
+/* (round 6) a0_fqf_taus + a0_cos_features(tau_hat) -> cos_out [B * F][D] in one launch (the actor's FQF step); the same bits as the two calls */
+int a0_fqf_taus_cos(const float* logits, int ld, float* taus, float* tau_hat, float* cos_out, int D, int B, int F, void* stream);
 int a0_fqf_inner_taus(const float* taus, float* out, int B, int F, void* stream);
 int a0_fqf_fraction_loss(const float* q, const float* qh, const float* taus, const int* act, const float* wgt, int B, int F, int A,
                          int ldl, float* loss, float* dlogits, const float* logits, void* stream);
@@ -593,6 +599,15 @@ int a0_actor_dist_tail_env_step_enc(const float* slabs, long long slab_stride, i
                                     float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
                                     const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task,
                                     const float* wt, const a0_encoder_weights* w, float* act3_next, void* stream);
+/* (round 6) the same for the quantile networks' tail (a0_actor_quantile_tail_env_step: iqn mode 1, fqf mode 3 with `taus` [E][T + 1]): tail + env step + replay row +
+ * the new observation's encoder in one launch — an iqn actor step is then a0_tau_cos_features | embedding GEMM | fc1 GEMM | head GEMM | this. */
+int a0_actor_quantile_tail_env_step_enc(const float* slabs, long long slab_stride, int nslab, const float* bias, int ld, int A, int T, int dueling, int mode,
+                                        const float* taus, int E, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
+                                        unsigned long long off_u, float eps, const long long* ctrl, const float* eps_ptr, int* action, float* qmax,
+                                        unsigned long long env_seed, unsigned int rank, unsigned int g, const uint8_t* obs_in, uint8_t* obs_out, float* ep_ret,
+                                        float* final_mask, float* final_ret, int n, long long steps, double gamma, int* ring_act, float* ring_rew, float* ring_done,
+                                        const uint8_t* obs0, uint8_t* frames, long long cap, long long start_slot, int* r_act, float* r_rew, float* r_done, int task,
+                                        const float* wt, const a0_encoder_weights* w, float* act3_next, void* stream);
 int a0_actor_egreedy_rng(const int* greedy, unsigned long long seed, unsigned int stream_a, unsigned int stream_u, unsigned long long off_a,
                          unsigned long long off_u, int A, float eps, int E, int* action, const float* qmax, float* qs_out,
                          const long long* ctrl, const float* eps_ptr, void* stream);

@@ -156,3 +156,65 @@ def test_dense_wgrad_multi_equals_single_calls(hip):
         hip.dense_wgrad(dY, X, ldx, G2, r, N, K, hip.empty(max(hip.dense_wgrad_scratch(r, N, K), 4)))
     for a, b in zip(layers, singles):
         assert torch.equal(a[3], b[3])
+
+
+# ------------------------------------------------------------------------------------------------ six vs nine cross products (a0_x9_products)
+@pytest.mark.parametrize("R,N,K", [(256, 512, 3136), (513, 132, 96), (8192, 512, 3136), (32768, 512, 3136)])
+def test_six_and_nine_product_forms_agree_to_fp32_rounding(hip, R, N, K):
+    """The split-operand GEMMs form six (default) or nine (strict, A0_X9_PRODUCTS=9) of the cross products of the three-term splits.  The three that the default leaves
+    out are each below 2^-24 of the product they belong to: both forms must meet the same bound against fp64 (2e-6 of sum |a||b|, this file's tolerance for either
+    pipe) and agree with each other to a tenth of it; the switch must really select different kernels (the results differ somewhere) and restore."""
+    g = recipe.gen(R + N + K)
+    X = np.maximum(g.standard_normal((R, K)), 0).astype(np.float32)          # post-ReLU activations, as fc1 sees them
+    W = (g.standard_normal((N, K)) * 0.03).astype(np.float32)
+    b = np.zeros(N, np.float32)
+    Xd, Wd, bd = D(hip, X), D(hip, W), D(hip, b)
+    rows = slice(0, min(R, 2048))                                           # fp64 reference on the first rows (the whole product on the device for the cross-check)
+    want = X[rows].astype(np.float64) @ W.astype(np.float64).T
+    scale = np.abs(X[rows]).astype(np.float64) @ np.abs(W).astype(np.float64).T
+    prev = hip.x9_products()
+    assert prev in (6, 9)
+    outs = {}
+    try:
+        for n in (9, 6):
+            assert hip.x9_products(n) in (6, 9) and hip.x9_products() == n
+            Y = hip.empty(R * N)
+            need = hip.dense_fwd_scratch(R, N, K)
+            hip.dense_fwd(Xd, K, Wd, bd, Y, R, N, K, 0, hip.empty(max(need, 1)))
+            outs[n] = Y.view(R, N).clone()
+            _scale_close(outs[n][rows].cpu().numpy(), want, scale, f"{n}-product dense_fwd {R}x{N}x{K}")
+    finally:
+        hip.x9_products(prev)
+    assert hip.x9_products() == prev
+    full_scale = (Xd.abs().double() @ Wd.abs().double().T).clamp_min(1e-30)
+    rel = ((outs[6].double() - outs[9].double()).abs() / full_scale).max().item()
+    assert rel < 2e-7, f"six- vs nine-product results differ by {rel:.3e} of the accumulated magnitude"
+    assert not torch.equal(outs[6], outs[9]), "the switch selects a different kernel"
+
+
+def test_six_and_nine_product_encoders_agree_to_fp32_rounding(hip):
+    """The fused encoder (conv2 / conv3 forward) and its data gradient under a0_x9_products 6 and 9: features within 2e-6 relative to the largest feature, gradients
+    within 2e-6 of the largest gradient; conv1 (bytes x three weight terms: always all three products) is bit-identical."""
+    from agent0_amd.deepq.engine import DeviceNet, Workspace
+    from agent0_amd.deepq.layout import NetLayout
+    spec = recipe.NetSpec("dqn", 4)
+    L = NetLayout.from_spec(spec)
+    net = DeviceNet(hip, L, hip.net(4, 84, 84))
+    net.load_state_dict(recipe.make_state_dict(spec, 11))
+    B = 300
+    frames = D(hip, recipe.make_frames(B, 5, (4, 84, 84)).reshape(-1))
+    prev = hip.x9_products()
+    got = {}
+    try:
+        for n in (9, 6):
+            hip.x9_products(n)
+            ws = Workspace(hip, L, B, 1)
+            net.encode(ws, frames, None, 2 * 4 * 84 * 84, 0, B)
+            got[n] = (ws.act1.clone(), ws.act2.clone(), ws.act3.clone())
+    finally:
+        hip.x9_products(prev)
+    assert torch.equal(got[6][0], got[9][0]), "conv1 does not depend on the mode"
+    for k, name in ((1, "conv2"), (2, "conv3")):
+        a, b = got[6][k], got[9][k]
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name
+        assert not torch.equal(a, b), f"{name}: the switch selects a different kernel"

@@ -562,8 +562,8 @@ def test_data_parallel_path_with_one_rank_rccl_group_matches_plain_run(tmp_path)
                          ids=["dqn", "c51-rainbow-lite"])
 def test_learner_handle_exchanges_gradients_itself_one_rank_group(extra):
     """Round 4, (e) through the boundary: ``a0_learner_set_exchange`` puts the RCCL gradient exchange (dense bucket + NaN flag on a side stream beside the encoder backward,
-    convolution bucket behind it, join before Adam — dist.RcclGradAllReduce's buckets and order) into ``a0_learner_update``, so the native host loop (opt-in,
-    A0_NATIVE_LOOP_DP=1) and a plain C host can run data-parallel.  Rehearsed with a one-rank RCCL group (the identity): the losses must equal, bit for bit, the plain
+    convolution bucket behind it, join before Adam — dist.RcclGradAllReduce's buckets and order) into ``a0_learner_update``, so the native host loop (the default since
+    round 6; A0_NATIVE_LOOP_DP=0 opts out) and a plain C host can run data-parallel.  Rehearsed with a one-rank RCCL group (the identity): the losses must equal, bit for bit, the plain
     native run, the Python classes' plain run and the Python classes' data-parallel run; the line must say who issued the exchange."""
     import json
     import socket
@@ -578,7 +578,7 @@ def test_learner_handle_exchanges_gradients_itself_one_rank_group(extra):
     base = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
     lines = {}
     runs = (("python plain", dict(A0_NATIVE_LOOP="0", A0_DP_FORCE="0")), ("native plain", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="0")),
-            ("python dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1")), ("native dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1", A0_NATIVE_LOOP_DP="1")))
+            ("python dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1", A0_NATIVE_LOOP_DP="0")), ("native dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1")))
     if extra:      # the second configuration: the handle's exchange against the plain handle run only (the Python classes' two runs are the first configuration's)
         runs = (runs[1], runs[3])
     for name, env in runs:
@@ -588,7 +588,7 @@ def test_learner_handle_exchanges_gradients_itself_one_rank_group(extra):
     handles = "library handles"
     assert handles in lines["native plain"]["config"]["host_loop"] and handles in lines["native dp"]["config"]["host_loop"]
     if not extra:
-        assert handles not in lines["python plain"]["config"]["host_loop"] and handles not in lines["python dp"]["config"]["host_loop"]      # without the opt-in a hook keeps the Python classes
+        assert handles not in lines["python plain"]["config"]["host_loop"] and handles not in lines["python dp"]["config"]["host_loop"]      # A0_NATIVE_LOOP_DP=0 keeps a data-parallel run on the Python classes
         assert "captured" in lines["python dp"]["gradient_exchange"]
     assert "a0_learner_set_exchange" in lines["native dp"]["gradient_exchange"]
     losses = {k: v["last_loss"] for k, v in lines.items()}
@@ -868,10 +868,16 @@ def test_native_handles_run_the_loop_like_the_python_trainer(algo, extra):
                                         # round 5: the launch schedule through the handles (the actor's own network snapshot, the stage ring, the second stream)
                                         ("dqn", {"_launch": True}), ("c51", {**RAINBOW, "_launch": True, "env_task": "block"}),
                                         ("c51", {**RAINBOW, "_launch": True, "learner.reset_noise_freq": 5}),
-                                        ("iqn", {"env_id": "Asterix", "learner.n_step_q": 3, "_launch": True}), ("qr", {"learner.double_q": "true", "replay.policy": "prioritize", "_launch": True})],
+                                        ("iqn", {"env_id": "Asterix", "learner.n_step_q": 3, "_launch": True}), ("qr", {"learner.double_q": "true", "replay.policy": "prioritize", "_launch": True}),
+                                        # round 6: the reference-faithful flat priority vector (replay.sumtree=false: a0_rbuf_desc.prioritize == 2) ...
+                                        ("dqn", {"replay.policy": "prioritize", "replay.sumtree": "false", "learner.n_step_q": 3}), ("c51", {**RAINBOW, "replay.sumtree": "false", "env_task": "chase"}),
+                                        ("qr", {"replay.policy": "prioritize", "replay.sumtree": "false", "_launch": True}),
+                                        # ... and data parallelism through the learner handle (a one-rank RCCL group: the exchange is the identity, every launch of it is issued)
+                                        ("dqn", {"_dp": True}), ("c51", {**RAINBOW, "_dp": True}), ("fqf", {"env_id": "Asterix", "replay.policy": "prioritize", "_dp": True})],
                          ids=["dqn", "dqn-duel-double-n3-per", "c51-block", "rainbow-lite", "rainbow-lite-noise3-block", "iqn-block", "iqn-duel-double-n3-per", "fqf-block",
                               "fqf-duel-double-n3-per", "qr-double-block", "mdqn-n3-per", "dqn-noisy-duel-block", "iqn-noisy-double", "fqf-noisy-duel-clip-per",
-                              "launch-dqn", "launch-rainbow-lite-block", "launch-rainbow-lite-noise5", "launch-iqn-n3", "launch-qr-double-per"])
+                              "launch-dqn", "launch-rainbow-lite-block", "launch-rainbow-lite-noise5", "launch-iqn-n3", "launch-qr-double-per",
+                              "dqn-n3-flat-per", "rainbow-lite-flat-per-chase", "launch-qr-flat-per", "dp-dqn", "dp-rainbow-lite", "dp-fqf-per"])
 def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
     """agent0_amd/deepq/native_loop.py: for the configurations the handles cover, ``Trainer.run_iteration`` hands the loop to a0_actor / a0_rbuf / a0_learner created
     OVER the Python classes' own buffers (a0_learner_create_on / a0_rbuf_create_on) — one C call per rollout, batch and update, eager launches from native code.
@@ -883,12 +889,28 @@ def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
 
     extra = dict(extra)
     launch = bool(extra.pop("_launch", False))
+    dp = bool(extra.pop("_dp", False))
+    if dp:                                         # A0_DP_FORCE=1: a one-rank RCCL process group in this process (127.0.0.1), closed again at the end of the test
+        import socket
+        import torch.distributed as dist
+        from agent0_amd.deepq.dist import init_process_group, make_grad_hook
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+        for k, v in (("A0_DP_FORCE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", port)):
+            monkeypatch.setenv(k, v)
+        init_process_group()
 
     def run(native):
         monkeypatch.setenv("A0_NATIVE_LOOP", "1" if native else "0")
         cfg = make_cfg(algo, 8, **{"actor.sample_steps": 12, "replay.size": 400, "learner.batch_size": 32, "learner.learner_steps": 5, "trainer.training_start_steps": 100,
                                     "learner.target_update_freq": 7, "trainer.exploration_steps": 600, **extra})
         tr = Trainer(cfg, use_lp=launch)
+        hook = None
+        if dp:                                     # what bench.py / launch.py do for N > 1
+            eng0 = tr.learner.engine
+            hook = eng0.grad_hook = make_grad_hook(tr.ops, eng0.L.n_adam)
+            assert type(hook).__name__ == "RcclGradAllReduce" and hook.active
         res = []
         for i in range(10):
             res.append({k: v for k, v in tr.run_iteration(prefetch=(i % 3 != 1)).items() if k != "fps"})
@@ -896,16 +918,27 @@ def test_native_loop_equals_the_python_classes(algo, extra, monkeypatch):
         sd = {k: v.clone() for k, v in tr.learner.model.state_dict().items()}
         eng, rp = tr.learner.engine, tr.replay
         n_len = len(rp)
-        tree = rp.tree.clone() if rp.prioritize else torch.zeros(1)
+        tree = (rp.tree if rp.use_sumtree else rp.priority).clone() if rp.prioritize else torch.zeros(1)      # (flat mode: the priority vector)
         out = (res, list(tr.Ls) + list(tr.FLs), list(tr.Qs), list(tr.Rs), tr.frame_count, n_len, rp.written, float(rp.beta) if rp.prioritize else 0.0, rp.max_p if rp.prioritize else 1.0,
                eng.online.flat.clone(), eng.target.flat.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.state.clone(), rp.frames.clone(), rp.act.clone(), rp.rew.clone(),
                rp.done.clone(), tree, sd)
+        if dp:
+            calls = hook.report()                  # collective; the exchange really ran: two all-reduce launches per update through this communicator
+            assert calls["nranks"] == 1 and calls["allreduce_of_ones"] == 1.0
+            if native:
+                tr._nl.detach_exchange()
         tr.test = lambda: None
         tr.final(save=False)                       # books the rollout issued ahead, closes the handles
+        if hook is not None:
+            hook.close()
         return out + (tr.frame_count, list(tr.Qs), len(rp))
 
-    a = run(False)
-    b = run(True)
+    try:
+        a = run(False)
+        b = run(True)
+    finally:
+        if dp:
+            dist.destroy_process_group()
     assert len(a[1]) == 9 * 5 * (2 if algo == "fqf" else 1) and a[4] == 10 * 96
     for i, (x, y) in enumerate(zip(a, b)):
         if isinstance(x, torch.Tensor):

@@ -1,7 +1,10 @@
 """Per-kernel floor table of one bench configuration: for every kernel of an iteration — launches, measured average duration (rocprofv3
 kernel stats of the bench command), algorithmic FLOPs / bytes, the bound that applies to ITS pipe, the floor that bound gives, and the gap.
 
-    python tools/budget.py <kernel_stats.csv> <config: dqn|c51|qr|mdqn> [ms_per_step] >> profiles/r05_budget.md
+    python tools/budget.py <kernel_stats.csv> <config: dqn|c51|qr|mdqn> [ms_per_step] [--json profiles/r06_budget.json] >> profiles/r06_budget.md
+
+A0_BUDGET_PRODUCTS=9 prices the strict nine-product mode (a0_x9_products); the default is the shipped six.  --json merges {config: {kernel_sum_ms, kernel_floor_ms,
+ms_per_iteration}} into the named file (what bench.py's roofline.iteration cites).
 
 Bounds (MI355X_MICROARCH.md constants table):
   mfma16   v_mfma_f32_16x16x32_bf16 issues every 16 cycles per SIMD            -> 16 384 bf16 FLOP / 16 cyc / SIMD = 2.5 PFLOP/s over 1024 SIMDs at 2.4 GHz
@@ -13,6 +16,9 @@ Bounds (MI355X_MICROARCH.md constants table):
 The floor is the LARGER of the pipe bound and the launch floor.
 """
 import csv
+import json
+import os
+import re
 import sys
 
 PF = 2.5e15
@@ -31,11 +37,11 @@ def hbm_us(nbytes):
 
 
 B, E, OBS, FEAT = 512, 256, 4 * 84 * 84, 3136
-ENC_ISSUED = 3 * 2 * 400 * 32 * 256 + 9 * (2 * 81 * 64 * 512 + 2 * 49 * 64 * 576)          # bf16 FLOP per observation as issued without tile padding
-# MFMAs per observation with the tiles the kernel uses (16-row blocks: 400 -> 25, 81 -> 6, 49 -> 4 blocks): (25*2*8*3 + 6*4*16*9 + 4*4*18*9) * 16 cycles over 4 SIMDs
-ENC_TILE_CYC = (25 * 2 * 8 * 3 + 6 * 4 * 16 * 9 + 4 * 4 * 18 * 9) * 16 / 4
+X9 = int(os.environ.get("A0_BUDGET_PRODUCTS", "6"))          # cross products per fp32 x fp32 multiply (a0_x9_products): 6 shipped, 9 strict
+ENC_ISSUED = 3 * 2 * 400 * 32 * 256 + X9 * (2 * 81 * 64 * 512 + 2 * 49 * 64 * 576)          # bf16 FLOP per observation as issued without tile padding
+# MFMAs per observation with the tiles the kernel uses (16-row blocks: 400 -> 25, 81 -> 6, 49 -> 4 blocks): (25*2*8*3 + 6*4*16*X9 + 4*4*18*X9) * 16 cycles over 4 SIMDs
+ENC_TILE_CYC = (25 * 2 * 8 * 3 + 6 * 4 * 16 * X9 + 4 * 4 * 18 * X9) * 16 / 4
 DGRAD_FLOP = 12.5e6
-X9 = 9
 
 
 def gemm(M, N, K, n=1):
@@ -52,8 +58,8 @@ def model(cfg):
         "a0_encoder_fused_kernel": ("actor encoder, 256 obs (1 per CU)", "mfma16 issue", max(ENC_TILE_CYC / GHZ * 1e6, 0), f"{ENC_ISSUED / 1e6:.1f} MFLOP bf16 issued per obs; one obs per CU, so the launch lasts as long as ONE observation: "
                                     f"{ENC_TILE_CYC:.0f} cyc of MFMA issue per SIMD with the kernel's tiles (unpadded: {ENC_ISSUED / 4096 / 4:.0f}); matrix pipe busy 55 % of a wave's lifetime (r04_pmc_encoder.txt): LDS fragment reads + the bf16 term split of act1 / act2 + three layer barriers on 8 waves"),
         "a0_encoder_fused_multi_kernel": (f"learner encoder, {npass} x 512 obs", "mfma16 issue", npass * 512 / 256 * ENC_TILE_CYC / GHZ * 1e6, "the same body looping over 2 (3) x 2 observations per CU"),
-        "a0_encoder_dgrad_fused_x9_kernel": ("conv3 + conv2 data gradients, 512 obs", "mfma16 issue", mfma_us(512 * DGRAD_FLOP * X9), "12.5 MFLOP fp32 per obs x 9 products; one workgroup per CU (123 KB LDS)"),
-        "a0_conv23_wgrad_fused_kernel": ("conv2 + conv3 weight gradients", "mfma32 issue", mfma_us(512 * 8.92e6 * X9), "8.92 MFLOP per obs x 9"),
+        "a0_encoder_dgrad_fused_x9_kernel": ("conv3 + conv2 data gradients, 512 obs", "mfma16 issue", mfma_us(512 * DGRAD_FLOP * X9), f"12.5 MFLOP fp32 per obs x {X9} products; one workgroup per CU (123 KB LDS)"),
+        "a0_conv23_wgrad_fused_kernel": ("conv2 + conv3 weight gradients", "mfma32 issue", mfma_us(512 * 8.92e6 * X9), f"8.92 MFLOP per obs x {X9}"),
         "a0_conv1_wgrad_fused_kernel": ("conv1 weight gradient", "mfma issue (x3)", mfma_us(512 * 6.55e6 * 3), "6.55 MFLOP per obs, bytes x three terms of d1"),
         "a0_igemm_x9_kernel<OpMatKC, OpMatKC, EpiSlab, 2, 2, 1, 1, 2>": ("actor fc1 256 x 512 x 3136 (dqn / mdqn: 8 split-K slabs) or actor head GEMM (c51 / qr)", "mfma32 issue",
                                                                        max(mfma_us(gemm(E, 512, FEAT) * X9), LAUNCH) if cfg in ("dqn", "mdqn") else max(mfma_us(gemm(E, Npad, 512) * X9), LAUNCH),
@@ -73,7 +79,7 @@ def model(cfg):
                                     "the pair below with the head's 8 tiles as a third problem in grid row 0"),
         "a0_igemm_x9_pair_kernel<OpMatKC, OpMatXC, EpiMaskMat, OpMatXC, OpMatXC, EpiWgradSlab, 2, 2": ("the head's data gradient + weight gradient side by side (c51 / qr)", "mfma32 issue",
                                     max(LAUNCH, mfma_us(gemm(B, 512, Npad, 2) * X9)), "64 + 32 (c51) / 104 (qr) tiles of 64 x 64 in one round; lasts as long as the longer k loop"),
-        "a0_igemm_x9_pair_kernel": ("fc1 data gradient + weight gradient, one launch", "mfma32 issue", mfma_us(gemm(B, 512, FEAT, 2) * X9), "2 x 1.64 GFLOP x 9; 784 workgroups on 512 slots"),
+        "a0_igemm_x9_pair_kernel": ("fc1 data gradient + weight gradient, one launch", "mfma32 issue", mfma_us(gemm(B, 512, FEAT, 2) * X9), f"2 x 1.64 GFLOP x {X9}; 784 workgroups on 512 slots"),
         "a0_igemm_x9_kernel<OpMatKC, OpMatXC, EpiMaskMat": ("head / fc1 data gradient (unpaired launches)", "mfma32 issue", mfma_us(gemm(B, 512, max(Npad, 512)) * X9), ""),
         "a0_igemm_x9_kernel<OpMatXC, OpMatXC, EpiWgradSlab": ("fc1 weight gradient (unpaired launches: probe pass)", "mfma32 issue", mfma_us(gemm(B, 512, FEAT) * X9), ""),
         "a0_igemm_kernel<OpMatXC, OpMatXC, EpiWgradSlab": ("head weight gradient", "launch", max(LAUNCH, mfma_us(gemm(B, Npad, 512) * 16)), "fp32 MFMA chain"),
@@ -122,8 +128,14 @@ def per_iteration(cfg, name):
 
 
 def main():
-    path, cfg = sys.argv[1], sys.argv[2]
-    ms = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    argv = list(sys.argv[1:])
+    jpath = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        jpath = argv[i + 1]
+        del argv[i:i + 2]
+    path, cfg = argv[0], argv[1]
+    ms = float(argv[2]) if len(argv) > 2 else None
     rows = list(csv.DictReader(open(path)))
     md = model(cfg)
     tot = tot_floor = 0.0
@@ -132,6 +144,8 @@ def main():
         name, calls, avg = r["Name"], int(r["Calls"]), float(r["AverageNs"]) / 1e3
         if name.startswith("void "):
             name = name[5:]
+        if name.startswith("a0_igemm_x9"):          # the trailing template argument is the product count (round 6): the model rows are keyed without it
+            name = re.sub(r", [69]>", ">", name, count=1)
         per_iter = per_iteration(cfg, name)
         hit = next((k for k in md if name.startswith(k)), None)
         if hit is None or per_iter == 0:
@@ -149,6 +163,13 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|")
     for _, line in sorted(out, key=lambda x: -x[0]):
         print(line)
+    if jpath:
+        try:
+            acc = json.load(open(jpath))
+        except (OSError, ValueError):
+            acc = {}
+        acc[cfg] = {"kernel_sum_ms": round(tot / 1e3, 3), "kernel_floor_ms": round(tot_floor / 1e3, 3), "ms_per_iteration": ms, "products": X9, "source": os.path.basename(path)}
+        json.dump(acc, open(jpath, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
