@@ -229,8 +229,10 @@ struct a0_hip_backend {
     int tag = 0;
     template <class OA, class OB, class EP, int WM, int WN, int MT, int NT>
     void igemm(const typename OA::Params& pa, const typename OB::Params& pb, const typename EP::Params& pe, int X, int Y, int K, int splits) {
-        const bool probe = g_probe.tag != 0 && g_probe.tag == tag && g_probe.used + 2 <= g_probe.ev.size();
-        if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], st));
+        // the probe's event pair travels IN the split-operand launches (the dispatch's own timestamps, as for the fused kernels); the fp32-chain kernel is bracketed
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool probe = a0_probe_events(tag, &e0, &e1);
+        bool carried = false;
         // fp32 operands: the split-operand kernel on the bf16 matrix pipe (igemm_x9.h); A0_GEMM=fp32 keeps the fmaf-chain kernel
         const bool x9 = g_gemm_x9 != 0;
         // the fmaf-chain kernel has four waves: an eight-wave tile shape falls back to the same tile on four (twice the blocks per wave along N)
@@ -257,23 +259,26 @@ struct a0_hip_backend {
             const double fill_huge = (double)huge / (256.0 * (double)((huge + 255) / 256)), fill_big = (double)big / (256.0 * (double)((big + 255) / 256));
             if constexpr (mats) {
                 if (x9 && X >= 256 && Y >= 128 && huge >= g_x9_huge_min && fill_huge >= 0.93 * fill_big && (deep || !wgrad_family)) {
-                    A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 2, 2, 1>(st, pa, pb, pe, X, Y, K, splits)));
-                    if (probe) { A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st)); g_probe.used += 2; g_probe.flops += 2.0 * (double)X * (double)Y * (double)K; }
+                    A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 2, 2, 1>(st, pa, pb, pe, X, Y, K, splits, e0, e1)));
+                    if (probe) a0_probe_commit(2.0 * (double)X * (double)Y * (double)K);
                     return;
                 }
             }
             // (round 6, six products: the same 128 x 128 tile on FOUR waves of 64 x 64 — a third fewer LDS fragment reads per MFMA, one wave per SIMD — measured 139.9 vs
             // 137.7 us on the actor's 8 192-row fc1, iqn 86.4 vs 85.9 ms: not kept, profiles/r06_experiments.md)
-            if (x9 && large) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits)));
-            else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits)));
-            else A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));
+            if (x9 && large) { A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits, e0, e1))); carried = true; }
+            else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) { A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits, e0, e1))); carried = true; }
+            else {
+                if (probe) A0_HIP_THROW(hipEventRecord(e0, st));
+                A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));
+            }
         } else {
+            if (probe) A0_HIP_THROW(hipEventRecord(e0, st));
             A0_HIP_THROW((a0_igemm_launch<OA, OB, EP, FWM, FWN, FMT, FNT>(st, pa, pb, pe, X, Y, K, splits)));
         }
         if (probe) {
-            A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], st));
-            g_probe.used += 2;
-            g_probe.flops += 2.0 * (double)X * (double)Y * (double)K;
+            if (!carried) A0_HIP_THROW(hipEventRecord(e1, st));
+            a0_probe_commit(2.0 * (double)X * (double)Y * (double)K);
         }
     }
     // (not part of the timing probe's dense_fwd family: bound by its output stream, not by the matrix pipe)
@@ -541,10 +546,10 @@ extern "C" int a0_dense_fwd_partial_multi(int n, const float* const* X, int ldx,
         grp.pe[i] = EpiSlab::Params{slabs[j], stride, N};
     }
     const int splits = a0_fwd_multi_splits(n, R, N, K);
-    const bool probe = g_probe.tag != 0 && g_probe.tag == A0_TAG_DENSE_FWD && g_probe.used + 2 <= g_probe.ev.size();
-    if (probe) A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used], (hipStream_t)stream));
-    A0_HIP_THROW((a0_igemm_x9_group_launch<OpMatKC, OpMatKC, EpiSlab, 4, 2, 1, 1>((hipStream_t)stream, n, grp, R, N, K, splits)));      // 128 x 64 tiles, eight waves
-    if (probe) { A0_HIP_THROW(hipEventRecord(g_probe.ev[g_probe.used + 1], (hipStream_t)stream)); g_probe.used += 2; g_probe.flops += 2.0 * n * (double)R * (double)N * (double)K; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool probe = a0_probe_events(A0_TAG_DENSE_FWD, &e0, &e1);
+    A0_HIP_THROW((a0_igemm_x9_group_launch<OpMatKC, OpMatKC, EpiSlab, 4, 2, 1, 1>((hipStream_t)stream, n, grp, R, N, K, splits, e0, e1)));      // 128 x 64 tiles, eight waves
+    if (probe) a0_probe_commit(2.0 * n * (double)R * (double)N * (double)K);
     return A0_OK;
     A0_CATCH
 }

@@ -356,8 +356,8 @@ def roofline_object(probes, cfg, args, products: int, iter_s: float):
                                         "exact bf16-term products on the faster pipe; secondary, not a utilisation"},
             "chosen_by": "largest measured time per iteration among the probed families (`candidates`, sorted); agrees with the top a0_* row of the rocprofv3 kernel statistics of the "
                          "same command under profiles/",
-            "measured": "HIP events on the launch stream over a repeat of the timed iterations with hipGraph replay off: single-kernel families carry the event pair in the launch "
-                        "(hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), dense_fwd brackets each launch with recorded events"
+            "measured": "HIP events on the launch stream over a repeat of the timed iterations with hipGraph replay off; every probed launch carries its event pair "
+                        "(hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports)"
                         + ("; on the launch schedule the probe runs without the overlapped rollout stream" if args.entry == "launch" else ""),
             "peak_source": "MI355X_MICROARCH.md: dense bf16 MFMA 2.5 PFLOP/s, fp32 MFMA 157.3 TFLOP/s",
             "candidates": cands, "iteration": iteration}
@@ -448,6 +448,8 @@ def main():
         tr.actors[1].use_graph = False
         if args.entry == "launch":
             tr.overlap = False               # kernel timing without a second stream competing for the CUs
+        tr.run_iteration()                   # consumes the rollout the timed loop issued ahead: every probed iteration below launches its own 80 steps
+        torch.cuda.synchronize()
         for fam in families:
             if rank == 0:
                 tr.ops.probe_begin(fam, 64 + args.steps * (4 * cfg.actor.sample_steps + 16 * cfg.learner.learner_steps))
@@ -541,6 +543,13 @@ def main():
         "metric": "env-frames/sec (learner FPS: transitions collected and saved to replay per second with the learner running, pre-frameskip)",
         **throughput_fields(world, per_iter, cfg.learner.learner_steps, args.steps, args.warmup, dt),
         "dtype": "f32", "data": "synthetic",
+        "arithmetic": {"x9_products": tr.ops.x9_products(),
+                       "what": "fp32 results on the bf16 matrix pipe: every fp32 operand is an exact sum of three bf16 terms and the kernels accumulate, in fp32, six of the nine cross products "
+                               "of two such sums (the three left out are each below 2^-24 of the product; A0_X9_PRODUCTS=9 / a0_x9_products(9) forms all nine); conv1 multiplies bytes by three "
+                               "weight terms, all formed",
+                       "record": "profiles/r06_x6_accuracy.txt (tools/check_x6_accuracy.hip): against fp64, six- and nine-product dot products differ by < 1 % in rms error at every "
+                                 "reduction length of the path; both are 0.9 - 1.4 x the sequential fp32 fmaf chain's rms error (the excess is the matrix instruction's accumulate rounding, "
+                                 "present in both forms); every GPU parity test runs on the six-product default at unchanged tolerances"},
         "config": {"workload": f"{cfg.env_id} {cfg.learner.algo.name}, {cfg.actor.num_envs} vectorized envs x {cfg.actor.sample_steps} steps + "
                                f"{cfg.learner.learner_steps} updates of batch {cfg.learner.batch_size} per iteration, {cfg.replay.size}-transition HBM replay "
                                f"(full), obs 4x84x84 u8, per-rank shards, " + ("independent replicas: one game per rank, no gradient exchange" if args.replicas else

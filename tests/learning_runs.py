@@ -7,7 +7,7 @@ turns the episode returns it reports into REWARD PER STEP: episodes end independ
 step)), so the oracle's terminal map gives every reported episode its length, in the order the actor reports them (step-major, env-major:
 agent.py:85-88).  Chance level is 0, the optimum +1 per step (times 1 - eps * (1 - 1/A) under epsilon-greedy).
 
-``python tests/learning_runs.py [out.json]`` runs the set the GPU tests assert on and writes the curves (profiles/r05_learning.json).
+``python tests/learning_runs.py [out.json]`` runs the set the GPU tests assert on and writes the curves (profiles/r06_learning.json).
 """
 from __future__ import annotations
 
@@ -128,18 +128,18 @@ def main(out_path=None, only=None):
             continue
         for launch in (False, True):
             x = {**extra, **small_q} if (launch and algo in ("iqn", "fqf")) else extra
-            keep(run(algo, x, 2_600_000 if algo == "c51" else 4_200_000, launch, env_id=env_id, task="chase"), name)
+            keep(run(algo, x, 2_600_000 if algo == "c51" else 4_700_000 if algo == "dqn" else 4_200_000, launch, env_id=env_id, task="chase"), name)
     if not only or "dqn_prio" in only:
-        keep(run("dqn", {"replay.policy": "prioritize"}, 4_200_000, task="chase"), "dqn_prioritized_sumtree")
+        keep(run("dqn", {"replay.policy": "prioritize"}, 4_700_000, task="chase"), "dqn_prioritized_sumtree")
         keep(run("dqn", {"replay.policy": "prioritize", "replay.sumtree": "false"}, 5_700_000, task="chase"), "dqn_prioritized_flat_vector")
     if not only or "sabotage" in only:
         for sab in ("discount_zero", "nstep_shift", "stale_next_state", "no_target_sync", "eps_one", "lr_zero"):
             keep(run("dqn", {}, 4_200_000, sabotage=sab, task="chase"), f"dqn_{sab}")
     if not only or "native" in only:
         os.environ["A0_NATIVE_LOOP"] = "1"
-        keep(run("dqn", {}, 4_200_000, task="chase"), "dqn_native_loop")
+        keep(run("dqn", {}, 4_700_000, task="chase"), "dqn_native_loop")
         keep(run("c51", RAINBOW, 2_600_000, task="chase"), "c51_rainbow_lite_native_loop")
-        keep(run("dqn", {}, 4_200_000, True, task="chase"), "dqn_native_loop_launch")
+        keep(run("dqn", {}, 4_700_000, True, task="chase"), "dqn_native_loop_launch")
         keep(run("dqn", {}, 2_600_000), "block_task_dqn_native_loop")
     if out_path:
         with open(out_path, "w") as f:

@@ -13,7 +13,7 @@ they compose to.  Two learnable tasks of the synthetic env (oracle/synth_env.c, 
     that never exploits and an optimizer that does not move.
   * ``env_task=block`` (round 4; a contextual bandit: +1 for naming the block's quadrant): kept as a second, independent task (one run).
 
-Curves: profiles/r05_learning.json (``python tests/learning_runs.py``).
+Curves: profiles/r06_learning.json (``python tests/learning_runs.py``).
 """
 import pytest
 
@@ -24,7 +24,10 @@ pytestmark = pytest.mark.gpu
 CHASE_OPTIMUM = 0.25 * (1.0 - 0.01 * 0.75)          # one reward per 4.0 steps (the mean spawn distance); min_eps = 0.01 of the moves are random, a quarter of them right anyway
 # the launch schedule runs the quantile networks with 16 fractions instead of 64 / 32 (a quarter of the update's rows): same code paths, a third of the wall-clock
 SMALL_Q = {"learner.iqn.K": 16, "learner.iqn.N": 16, "learner.iqn.N_dash": 16, "learner.iqn.F": 16}
-FAMILIES = [("dqn", "dqn", {}, 4_200_000, "Breakout"), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, "Breakout"), ("iqn", "iqn", {}, 3_800_000, "Asterix"),
+# (round 6: 4.7 M frames for the dqn runs, one 25-iteration window more than round 5's 4.2 M.  The curves are chaotic in the low bits — the knee between 3 M and 4.2 M frames
+# moves by a window with anything that changes a rounding: the six-product kernels, even the BLAS thread count behind the orthogonal initialisation — and at 4.2 M one of
+# eleven runs ended its last window at 0.221, under the 0.223 bar, on its way to the same 0.247 plateau: gpurun_out/r06/learn_*.log)
+FAMILIES = [("dqn", "dqn", {}, 4_700_000, "Breakout"), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, "Breakout"), ("iqn", "iqn", {}, 3_800_000, "Asterix"),
             ("fqf", "fqf", {}, 3_800_000, "Asterix")]
 
 
@@ -59,7 +62,7 @@ def test_every_family_learns_the_chase_task(name, algo, extra, frames, env_id, l
     check_chase(r)
 
 
-@pytest.mark.parametrize("extra,frames", [({"replay.policy": "prioritize"}, 4_200_000), ({"replay.policy": "prioritize", "replay.sumtree": "false"}, 5_700_000)],
+@pytest.mark.parametrize("extra,frames", [({"replay.policy": "prioritize"}, 4_700_000), ({"replay.policy": "prioritize", "replay.sumtree": "false"}, 5_700_000)],
                          ids=["sum-tree", "flat-priority-vector"])
 def test_prioritized_replay_learns_the_chase_task(extra, frames):
     """(the reference-faithful flat priority vector — uniform sampling, importance weights from priorities that quirk Q1 leaves misaligned — reaches the optimum later
@@ -81,7 +84,7 @@ def test_runs_with_a_cut_credit_path_do_not_pass(sabotage):
     assert r["final_reward_per_step"] < 0.3 * CHASE_OPTIMUM
 
 
-@pytest.mark.parametrize("name,algo,extra,frames,launch", [("dqn", "dqn", {}, 4_200_000, False), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, False), ("dqn", "dqn", {}, 4_200_000, True)],
+@pytest.mark.parametrize("name,algo,extra,frames,launch", [("dqn", "dqn", {}, 4_700_000, False), ("c51_rainbow_lite", "c51", LR.RAINBOW, 2_600_000, False), ("dqn", "dqn", {}, 4_700_000, True)],
                          ids=["dqn-main", "rainbow-lite-main", "dqn-launch"])
 def test_the_native_loop_learns_the_chase_task(name, algo, extra, frames, launch, monkeypatch):
     """The same criterion with the loop issued by the library's own handles (agent0_amd/deepq/native_loop.py: the production default for these configurations) — under

@@ -110,8 +110,11 @@ for short, title in (("c51", "configs[2] Breakout c51 double-Q + dueling + Noisy
     r = d.get("roofline") or {}
     cfg_lines += [f"## {title}", "",
                   f"* {d['value']:.0f} env-frames/s, {d['ms_per_step']} ms per iteration, {d['updates_per_sec']} updates/s (`{tag}_{short}_bench.json`).",
-                  f"* roofline of the dominant kernel family: {r.get('achieved')} {r.get('unit')} = {r.get('frac')} of the {r.get('peak')} fp32 MFMA peak over {r.get('launches')} launches "
-                  f"({r.get('avg_us')} us each; {str(r.get('kernel'))[:120]}...).", "",
+                  f"* roofline of the kernel family with the largest measured share ({r.get('share_of_iteration')} of the iteration: {r.get('launches_per_iteration')} launches x {r.get('avg_us')} us): "
+                  f"{r.get('achieved')} {r.get('unit')} of bf16 MFMA products issued = **{r.get('frac')}** of the {r.get('peak')} dense bf16 peak ({r.get('bf16_products_per_mac')} products per multiply-add); "
+                  f"fp32-equivalent {(r.get('fp32_equivalent') or {}).get('achieved')} TFLOP/s.  {str(r.get('kernel'))[:160]}...",
+                  "* other probed families: " + "; ".join(f"{c['family']} {c['launches_per_iteration']} x {c['avg_us']} us = {c['ms_per_iteration']} ms, frac {c['frac']}" for c in (r.get('candidates') or [])[1:]) + ".",
+                  f"* whole iteration: {(r.get('iteration') or {}).get('tflops')} TFLOP/s algorithmic = {(r.get('iteration') or {}).get('frac_fp32_basis')} of the fp32 MFMA peak.", "",
                   "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
     rows_c = list(csv.DictReader(open(ks)))
     for rr in rows_c[:14]:
@@ -155,27 +158,42 @@ for r in rows[:26]:
     lines.append(f"| `{nm}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
 lines += ["", f"Total GPU kernel time: {tot_ns / 1e6:.1f} ms over {tot_calls} launches.", ""]
 enc = {k.split("grid=")[1]: v for k, v in by_grid.items() if "a0_encoder_fused_kernel" in k}
+multi = [v for k, v in by_grid.items() if "a0_encoder_fused_multi_kernel" in k]
+stepk = [(k, v) for k, v in by_grid.items() if "a0_actor_step_enc" in k or "a0_actor_dist_step_enc" in k]
 dg = [v for k, v in by_grid.items() if "dgrad" in k]
 FLOP = 15.47e6
 roof = bench.get("roofline") or {}
-lines += ["## Dominant kernel: `a0_encoder_fused_kernel<7,3,2,84,true[,true]>` (conv1 + conv2 + conv3 of the Nature CNN per observation; one workgroup per observation for the actor's "
-          "256-observation launches, 256 looping workgroups for the learner's 512)", ""]
-if "131072" in enc and "loop" in enc:
-    a, l = enc["131072"], enc["loop"]
-    mix = (80 * a["avg_us"] + 40 * l["avg_us"]) / 120
-    lines += [f"* kernel trace, by launch size: 256 observations (actor) {a['avg_us']:.2f} us average over {a['launches']} launches = {256 * FLOP / a['avg_us'] / 1e6:.1f} TFLOP/s; "
-              f"512 observations (learner) {l['avg_us']:.2f} us over {l['launches']} launches = {512 * FLOP / l['avg_us'] / 1e6:.1f} TFLOP/s (15.47 MFLOP per observation, counted once).",
-              f"* bench.py's in-run probe (HIP events on the launch stream around every launch of the timed mix, 80 actor + 40 learner launches per iteration): {roof.get('avg_us')} us average over "
-              f"{roof.get('launches')} launches = {roof.get('achieved')} TFLOP/s = {100 * (roof.get('frac') or 0):.1f} % of the 157.3 TFLOP/s fp32 MFMA peak.  The kernel trace gives {mix:.2f} us for the same mix "
-              f"(80 x {a['avg_us']:.2f} + 40 x {l['avg_us']:.2f}) / 120; the difference is the event pair around each un-graphed launch, so the probe figure is the conservative one."]
+PROD = roof.get("bf16_products_per_mac")
+lines += [f"## Dominant kernel by measured time: {str(roof.get('kernel'))[:60]}", "",
+          f"* bench.py's in-run probe (HIP events carried by the launch: the dispatch's own begin / end timestamps): {roof.get('avg_us')} us average, {roof.get('launches_per_iteration')} launches per iteration = "
+          f"{roof.get('share_of_iteration')} of the iteration; {roof.get('algorithmic_gflop_per_launch')} GFLOP algorithmic per launch x {PROD} bf16 products per multiply-add = {roof.get('achieved')} TFLOP/s issued = "
+          f"**{roof.get('frac')} of the 2.5 PFLOP/s dense bf16 MFMA peak** (`roofline.frac`); fp32-equivalent {(roof.get('fp32_equivalent') or {}).get('achieved')} TFLOP/s "
+          f"({(roof.get('fp32_equivalent') or {}).get('frac')} of the fp32 MFMA peak, secondary)."]
+for k, v in stepk:
+    lines += [f"* kernel trace of the same command: `{k.split('|')[0]}` {v['avg_us']:.2f} us average over {v['launches']} launches (min {v['min_us']:.2f}, max {v['max_us']:.2f}): the probe's figure and the trace's agree "
+              f"to {abs(v['avg_us'] - (roof.get('avg_us') or 0)) / v['avg_us'] * 100:.1f} %."]
+st = traffic.get("calibration", {}).get("stepenc")
+if st:
+    lines += [f"* HBM traffic per launch (PMC, separate passes): read {2 * st['FETCH_SIZE_bytes_raw'] / 1e6:.1f} MB (FETCH_SIZE x 2), write {st['WRITE_SIZE_bytes_raw'] / 1e6:.1f} MB; algorithmic "
+              f"{st['algorithmic_read_bytes'] / 1e6:.1f} / {st['algorithmic_write_bytes'] / 1e6:.1f} MB.  At ~28 us that is ~1.5 TB/s: matrix-pipe / issue bound, not HBM bound."]
+lines += ["* other probed families of the same run (`roofline.candidates`): " + "; ".join(f"{c['family']} {c['launches_per_iteration']} x {c['avg_us']} us = {c['ms_per_iteration']} ms per iteration, "
+                                                                                           f"{c['achieved']} TFLOP/s issued = {c['frac']}" for c in (roof.get('candidates') or [])[1:]) + ".",
+          f"* whole iteration (`roofline.iteration`): {(roof.get('iteration') or {}).get('algorithmic_flop', 0) / 1e12:.3f} TFLOP algorithmic in {bench['ms_per_step']} ms = {(roof.get('iteration') or {}).get('tflops')} TFLOP/s = "
+          f"{(roof.get('iteration') or {}).get('frac_fp32_basis')} of the fp32 MFMA peak; kernels sum to {(roof.get('iteration') or {}).get('kernel_sum_ms')} ms, their floors to {(roof.get('iteration') or {}).get('kernel_floor_ms')} ms.", ""]
+lines += ["## `a0_encoder_fused_multi_kernel` / `a0_encoder_fused_kernel` (conv1 + conv2 + conv3 per observation: the learner's forward passes in one launch of 256 looping workgroups; the rollout's first encoder)", ""]
+if multi:
+    m = multi[0]
+    lines += [f"* kernel trace: learner launch (2 x 512 observations) {m['avg_us']:.2f} us over {m['launches']} launches = {1024 * FLOP / m['avg_us'] / 1e6:.1f} TFLOP/s algorithmic"
+              + (f" x {PROD} = {1024 * FLOP * PROD / m['avg_us'] / 1e6:.0f} TFLOP/s issued = {1024 * FLOP * PROD / m['avg_us'] / 1e6 / 2500:.3f} of the bf16 peak" if PROD else "") + "."]
+if "131072" in enc:
+    a = enc["131072"]
+    lines += [f"* kernel trace: 256 observations (a rollout's first step) {a['avg_us']:.2f} us over {a['launches']} launches."]
 pl = traffic["per_launch"]
-if "256" in pl and "512" in pl:
-    lines += [f"* HBM traffic per launch (PMC): 256 observations {pl['256']['hbm_bytes'] / 1e6:.1f} MB (read {pl['256']['hbm_read_bytes'] / 1e6:.1f}, write {pl['256']['hbm_write_bytes'] / 1e6:.2f}; "
-              f"algorithmic minimum {pl['256']['algorithmic_bytes_min'] / 1e6:.1f} MB); 512 observations {pl['512']['hbm_bytes'] / 1e6:.1f} MB on average (the online pass also stores act1/act2 for the "
-              f"backward pass).  At ~30 us that is ~0.5 TB/s: the kernel is matrix-pipe / issue bound, not HBM bound."]
-lines += ["* all three layers run on `v_mfma_f32_16x16x32_bf16` with operands split EXACTLY into bf16 terms (conv1: bytes x three weight terms, 3 MFMAs per 32 k; conv2/conv3: three activation terms x "
-          "three weight terms, 9 MFMAs per 32 k), fp32 accumulation; FLOPs are counted once (algorithmic) and the peak quoted is the fp32 MFMA one, which the fp32-chain version of this kernel "
-          "(`A0_NO_X9=1`) is bound by.", ""]
+if "1024" in pl:
+    lines += [f"* HBM traffic per learner launch (PMC): {pl['1024']['hbm_bytes'] / 1e6:.1f} MB (read {pl['1024']['hbm_read_bytes'] / 1e6:.1f}, write {pl['1024']['hbm_write_bytes'] / 1e6:.1f}; algorithmic minimum "
+              f"{pl['1024']['algorithmic_bytes_min'] / 1e6:.1f} MB + 36.8 MB of act1 / act2 kept for the backward pass)."]
+lines += ["* all three layers run on `v_mfma_f32_16x16x32_bf16` with fp32 operands as exact sums of three bf16 terms (conv1: bytes x three weight terms, 3 MFMAs per 32 k; conv2 / conv3: six of the nine cross "
+          "products of three activation terms x three weight terms by default — `a0_x9_products`, nine in the strict mode), fp32 accumulation.", ""]
 if dg:
     d = dg[0]
     lines += ["## `a0_encoder_dgrad_fused_x9_kernel` (conv3 + conv2 data gradients per observation, split operands on the bf16 pipe)", "",
@@ -195,13 +213,14 @@ open(os.path.join(DST, f"{tag}_bench_dqn_rocprof_summary.md"), "w").write("\n".j
 # ---- the per-kernel floor tables (tools/budget.py) of the headline configuration and of configs[2], qr, mdqn
 import subprocess
 parts = ["# Per-kernel floor table (" + tag + ")\n", open(os.path.join(ROOT, "tools", "budget.py")).read().split('"""')[1].split("Bounds")[0].strip().splitlines()[0] + "\n",
-         "Bounds: MFMA issue (v_mfma_f32_16x16x32_bf16 every 16 cycles, v_mfma_f32_32x32x16_bf16 every 32 cycles per SIMD = 2.5 PFLOP/s; an exact fp32 product costs 9 bf16 products, 3 where "
+         "Bounds: MFMA issue (v_mfma_f32_16x16x32_bf16 every 16 cycles, v_mfma_f32_32x32x16_bf16 every 32 cycles per SIMD = 2.5 PFLOP/s; an exact fp32 product costs 9 bf16 products — 6 as shipped, a0_x9_products — 3 where "
          "one operand is bytes), achievable HBM 6.3 TB/s, one vector wave-instruction per 2 cycles per SIMD, and a launch floor of 2.5 us (ramp-up, first loads, drain); the floor of a kernel is the "
          "larger of its pipe bound and the launch floor.  `gap ms / iteration` = launches x (measured - floor).  Measured = rocprofv3 kernel statistics of the bench command.\n"]
 for cfgname, stats, bj in (("dqn", "kernel_stats.csv", "bench.json"), ("c51", "c51_kernel_stats.csv", "c51_bench.json"), ("qr", "qr_kernel_stats.csv", "qr_bench.json"),
                            ("mdqn", "mdqn_kernel_stats.csv", "mdqn_bench.json")):
     if os.path.exists(os.path.join(SRC, stats)):
         ms = last_json(os.path.join(SRC, bj))["ms_per_step"] if os.path.exists(os.path.join(SRC, bj)) else ""
-        parts.append(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "budget.py"), os.path.join(SRC, stats), cfgname, str(ms)], capture_output=True, text=True).stdout)
+        parts.append(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "budget.py"), os.path.join(SRC, stats), cfgname, str(ms), "--json", os.path.join(DST, f"{tag}_budget.json")],
+                                    capture_output=True, text=True).stdout)
 open(os.path.join(DST, f"{tag}_budget.md"), "w").write("\n".join(parts))
 print("profiles/ refreshed from", SRC)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; R=${R:-r04}
 mkdir -p gpurun_out/$R
 for algo in ${ALGOS:-iqn fqf}; do
   i=0
-  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_WAVES"; do
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
     i=$((i+1))
     A0_PROBE=none rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/$R/pmcq_${algo}_g$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ratio320 --no-other-entry --replay-size 100000 --algo $algo --env Asterix > gpurun_out/$R/pmcq_${algo}_g$i.log 2>&1
   done
