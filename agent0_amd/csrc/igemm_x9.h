@@ -69,6 +69,7 @@ template <int BX, int KS> struct a0_x9_image<A0_XC, BX, KS> {
 template <class OP, int BX, int NTH, int KS = 2, int MODE = OP::MODE> struct a0_x9_stager;
 
 template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS, A0_KC> {
+    static constexpr bool PRESPLIT = false;
     static constexpr int TPR = 4 * KS;       // threads per row: eight (four) threads cover the 32 (16) k of one row
     static constexpr int RPP = NTH / TPR;    // rows per pass
     static constexpr int R = BX / RPP;
@@ -110,6 +111,7 @@ template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS
 };
 
 template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS, A0_XC> {
+    static constexpr bool PRESPLIT = false;
     static constexpr int R = 4 * KS * BX / NTH;
     static constexpr int Q = BX / 4;   // 16-byte groups per k row
     static_assert((4 * KS * BX) % NTH == 0 && NTH % Q == 0, "tile columns per pass");
@@ -152,6 +154,64 @@ template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS
         const a0_u32x2g a = __builtin_bit_cast(a0_u32x2g, k03), b = __builtin_bit_cast(a0_u32x2g, k47);
         a0_u32x4g r; r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y;
         return r;
+    }
+};
+
+// ---- an operand that is ALREADY split (round 6): the three bf16 term planes of a weight matrix W [N][K], written once per optimizer step by a0_split_planes_kernel
+// (net.hip) and reused by every GEMM until the weights change — the actor's fc1 runs 80 steps on one W, a learner pass has rows in the tens of thousands — so that
+// this operand's tiles go from global memory to the LDS term planes without a vector instruction.  Layout: per row n and group g of four consecutive k six dwords
+// { hi(k0,k1) hi(k2,k3) | mid .. | lo .. } = the three 8-byte LDS stores of a piece, 24 bytes apart.  K % 4 == 0; rows beyond Y and the k range past the split's end
+// are NOT zero-filled (callers guarantee whole k tiles; rows past the edge only feed outputs that are never stored).
+struct a0_planes_src { const uint32_t* p; int kgroups; };      // kgroups = K / 4
+struct OpPlanesKC {
+    static constexpr int MODE = A0_KC;
+    typedef a0_planes_src Params;
+    struct Row { const uint32_t* p; };
+    struct KInfo { int g; };
+    struct Raw { a0_u32x4g a; a0_u32x2g b; };
+    A0_HD static Row row(const Params& P, int r, int R) { Row o; o.p = P.p + (long long)(r < R ? r : R - 1) * P.kgroups * 6; return o; }
+    A0_HD static KInfo kinfo(const Params& P, int k, int Kend) { KInfo ki; ki.g = (k < Kend ? k : 0) >> 2; return ki; }
+    A0_HD static Raw load(const Params&, const Row& r, const KInfo& ki) {
+        Raw v;
+        const uint32_t* q = r.p + (long long)ki.g * 6;
+        v.a = *(const a0_u32x4g*)q;
+        v.b = *(const a0_u32x2g*)(q + 4);
+        return v;
+    }
+};
+template <int BX, int NTH, int KS> struct a0_x9_stager<OpPlanesKC, BX, NTH, KS, A0_KC> {
+    static constexpr bool PRESPLIT = true;
+    static constexpr int TPR = 4 * KS;
+    static constexpr int RPP = NTH / TPR;
+    static constexpr int R = BX / RPP;
+    static_assert(BX % RPP == 0, "tile rows per pass");
+    typedef a0_x9_image<A0_KC, BX, KS> IM;
+    typedef OpPlanesKC OP;
+    OP::Row rows[R];
+    OP::KInfo ki;
+    struct Slot { OP::Raw raw[R]; unsigned okmask; };
+    A0_D void init(const OP::Params& P, int x0, int X, int kb, int ke, int tid) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + tid / TPR + RPP * j, X);
+        ki = OP::kinfo(P, kb + 4 * (tid % TPR), ke);
+    }
+    A0_D void fetch_piece(const OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
+        s.raw[j] = OP::load(P, rows[j], ki);
+        if (j == R - 1) ki = OP::kinfo(P, k0 + 16 * KS + 4 * (tid % TPR), ke);
+    }
+    template <bool RS> A0_D a0_f4 value(const Slot&, int, a0_f4&) const { return a0_zero4(); }      // (never called: PRESPLIT pieces skip the split micro-steps)
+    A0_D void store(const a0_x9_piece&, int, char*, int) const {}
+    A0_D void store_raw(const Slot& s, int j, char* lds, int tid) const {
+        const int r = tid / TPR + RPP * j;
+        char* p = lds + r * IM::PITCH + 8 * (tid % TPR);
+        a0_u32x2g hi, mid; hi.x = s.raw[j].a.x; hi.y = s.raw[j].a.y; mid.x = s.raw[j].a.z; mid.y = s.raw[j].a.w;
+        *(a0_u32x2g*)(p) = hi;
+        *(a0_u32x2g*)(p + IM::PLANE) = mid;
+        *(a0_u32x2g*)(p + 2 * IM::PLANE) = s.raw[j].b;
+    }
+    A0_D static int frag_base(int lane, int woff) { return (woff + (lane & 31)) * IM::PITCH + (lane >> 5) * 16; }
+    A0_D static a0_u32x4g frag(const char* plane, int base, int blk, int s) {
+        return *(const a0_u32x4g*)(plane + base + blk * 32 * IM::PITCH + s * 32);
     }
 };
 
@@ -229,6 +289,12 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
     auto micro = [&](int u, const typename SA::Slot& s_a_c, const typename SB::Slot& s_b_c, typename SA::Slot& s_a, typename SB::Slot& s_b,
                      char* a_dst, char* b_dst, int k_fetch) {
         const int p = u / 6, st = u % 6;
+        if constexpr (SB::PRESPLIT) {
+            if (p >= RA) {      // an operand that arrives as term planes: no split, one micro-step (planes to LDS, refetch)
+                if (st == 5) { sb.store_raw(s_b_c, p - RA, b_dst, tid); fetch_piece(s_a, s_b, p, k_fetch); }
+                return;
+            }
+        }
         if (st == 0) {
             if (p < RA) pc.v = sa.template value<EP::ROWSUM_A>(s_a_c, p, rowsum);
             else pc.v = sb.template value<false>(s_b_c, p - RA, rowsum);

@@ -403,6 +403,49 @@ extern "C" int a0_dense_fwd(const float* X, int ldx, const float* W, const float
     A0_CATCH
 }
 
+// ---- weights as term planes (round 6): W [N][K] fp32 -> the three bf16 term planes in OpPlanesKC's layout (igemm_x9.h), once per change of W; a0_dense_fwd_wplanes
+// is a0_dense_fwd for unsplit shapes (a0_dense_fwd_scratch == 0) with whole k tiles (K % 32 == 0) reading them: the same exact terms, so the same result bit for bit.
+__global__ void a0_split_planes_kernel(const a0_f4* __restrict__ W, uint32_t* __restrict__ planes, long long groups) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups) return;
+    a0_x9_piece pc;
+    pc.v = W[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pc.split(e);
+    a0_u32x2g hi, mid, lo;
+    pc.pack(hi, mid, lo);
+    a0_u32x2g* o = (a0_u32x2g*)(planes + i * 6);
+    o[0] = hi; o[1] = mid; o[2] = lo;
+}
+extern "C" long long a0_weight_planes_words(int N, int K) { return (long long)N * (K / 4) * 6; }
+extern "C" int a0_split_planes(const float* W, unsigned int* planes, int N, int K, void* stream) {
+    if (!W || !planes || N < 1 || K < 4 || (K & 3)) return a0_fail(A0_EINVAL, "a0_split_planes: bad argument (K a multiple of 4)");
+    const long long groups = (long long)N * (K / 4);
+    hipLaunchKernelGGL(a0_split_planes_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const a0_f4*)W, planes, groups);
+    return a0_fail_hip((int)hipGetLastError(), "a0_split_planes");
+}
+extern "C" int a0_dense_fwd_wplanes_ok(int R, int N, int K) {
+    return (R >= 2048 && N >= 128 && !(N & 3) && !(K & 31) && a0_fwd_splits((R + 127) / 128, (N + 63) / 64, K) == 1 && g_gemm_x9 != 0) ? 1 : 0;
+}
+extern "C" int a0_dense_fwd_wplanes(const float* X, int ldx, const unsigned int* Wplanes, const float* b, float* Y, int R, int N, int K, int relu, void* stream) {
+    A0_TRY
+    if (!X || !Wplanes || !b || !Y || (ldx & 3) || !a0_dense_fwd_wplanes_ok(R, N, K)) return a0_fail(A0_EINVAL, "a0_dense_fwd_wplanes: shapes a0_dense_fwd_wplanes_ok accepts");
+    hipStream_t st = (hipStream_t)stream;
+    const a0_mat_src a{X, ldx};
+    const a0_planes_src bw{Wplanes, K / 4};
+    const EpiBiasAct::Params e{Y, b, N, relu};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool probe = a0_probe_events(A0_TAG_DENSE_FWD, &e0, &e1);
+    // the tile choice of a0_hip_backend::igemm for unsplit matrix operands
+    const long long huge = (long long)((R + 255) / 256) * ((N + 127) / 128), big = (long long)((R + 127) / 128) * ((N + 127) / 128);
+    const double fill_huge = (double)huge / (256.0 * (double)((huge + 255) / 256)), fill_big = (double)big / (256.0 * (double)((big + 255) / 256));
+    if (R >= 256 && huge >= g_x9_huge_min && fill_huge >= 0.93 * fill_big) A0_HIP_THROW((a0_igemm_x9_launch<OpMatKC, OpPlanesKC, EpiBiasAct, 4, 2, 2, 2, 1>(st, a, bw, e, R, N, K, 1, e0, e1)));
+    else A0_HIP_THROW((a0_igemm_x9_launch<OpMatKC, OpPlanesKC, EpiBiasAct, 4, 2, 1, 2>(st, a, bw, e, R, N, K, 1, e0, e1)));
+    if (probe) a0_probe_commit(2.0 * (double)R * (double)N * (double)K);
+    return A0_OK;
+    A0_CATCH
+}
+
 // Y[r][:] = act(X[r] W^T + b) * M[r / group][:] — the quantile networks' embedding times the state features in the GEMM's epilogue
 // (reference model.py:244-247: relu(cosine_emb(cos(pi i tau))) * features), for passes that are not differentiated: the embedding never
 // goes to HBM and the Hadamard pass disappears.  Only for shapes whose forward GEMM is not split (a0_dense_fwd_scratch == 0).

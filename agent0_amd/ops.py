@@ -276,6 +276,20 @@ class HipOps:
                                     _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu),
                                     _req(scratch, torch.float32, need, "scratch", optional=(need == 0)), _stream()), "a0_dense_fwd")
 
+    def weight_planes_words(self, N, K) -> int:
+        return int(self.lib.a0_weight_planes_words(N, K))
+
+    def split_planes(self, W, planes, N, K):
+        """The three bf16 term planes of W [N][K] for ``dense_fwd_wplanes`` (a0_split_planes)."""
+        check(self.lib.a0_split_planes(_req(W, torch.float32, N * K, "W"), _req(planes, torch.int32, self.weight_planes_words(N, K), "planes"), N, K, _stream()), "a0_split_planes")
+
+    def dense_fwd_wplanes_ok(self, R, N, K) -> bool:
+        return bool(self.lib.a0_dense_fwd_wplanes_ok(R, N, K))
+
+    def dense_fwd_wplanes(self, X, ldx, planes, b, Y, R, N, K, relu):
+        check(self.lib.a0_dense_fwd_wplanes(_req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx, _req(planes, torch.int32, self.weight_planes_words(N, K), "planes"),
+                                            _req(b, torch.float32, N, "b"), _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu), _stream()), "a0_dense_fwd_wplanes")
+
     def dense_fwd_mul(self, X, ldx, W, b, M, group, Y, R, N, K, relu):
         check(self.lib.a0_dense_fwd_mul(_req(X, torch.float32, (R - 1) * ldx + K, "X"), ldx, _req(W, torch.float32, N * K, "W"), _req(b, torch.float32, N, "b"),
                                         _req(M, torch.float32, ((R - 1) // group + 1) * N, "M"), group, _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu), _stream()),

@@ -183,6 +183,14 @@ int a0_trace_rank(int rank);
 int a0_trace_push(const char* name);
 int a0_trace_pop(void);
 
+/* Weights as term planes (round 6): a0_split_planes writes the three exact bf16 terms of W [N][K] (K % 4 == 0) into `planes` (a0_weight_planes_words(N, K) 32-bit words) once
+ * per change of W; a0_dense_fwd_wplanes is a0_dense_fwd (model.py:112-114) for the shapes a0_dense_fwd_wplanes_ok accepts (unsplit, K % 32 == 0, R >= 2048, N >= 128) reading them —
+ * the same products, the same result bit for bit, without the weight operand's split instructions in the GEMM. */
+long long a0_weight_planes_words(int N, int K);
+int a0_split_planes(const float* W, unsigned int* planes, int N, int K, void* stream);
+int a0_dense_fwd_wplanes_ok(int R, int N, int K);
+int a0_dense_fwd_wplanes(const float* X, int ldx, const unsigned int* Wplanes, const float* b, float* Y, int R, int N, int K, int relu, void* stream);
+
 /* Matrix pipe used by every fp32-operand GEMM above (dense layers, conv2/conv3 weight gradients, unfused conv layers):
  * 1 (default) = bf16 MFMA with both operands split exactly into three bf16 terms, nine products, fp32 accumulation (igemm_x9.h);
  * 0 = fp32 MFMA fmaf chain (igemm.h).  Same results up to the association order of the fp32 additions.  Returns the previous mode;
