@@ -299,6 +299,7 @@ struct a0_actor {
     // its own noise vectors and composed weights — refreshed by a0_actor_snapshot when a rollout is issued.  Without it (main schedule) the actor acts with the learner's
     // online network, NoisyNet buffers included: the reference's train actor SHARES the learner's module there (trainer.py:41-44).
     float *own_flat = nullptr, *own_wt = nullptr, *own_eff = nullptr, *own_noise = nullptr;
+    unsigned int* w_planes = nullptr;     // quantile actors (round 6): fc1's weights as bf16 term planes (a0_split_planes), refreshed when a rollout starts and after every NoisyNet compose
 };
 
 // the network an actor acts with: the learner's online network, or the actor's own snapshot of it
@@ -337,6 +338,8 @@ extern "C" int a0_actor_bind(a0_actor* a, const a0_learner* L, int own_network) 
             a->fwd_scratch = a->mem.alloc<float>(sc > 4 ? sc : 4);
             a->q_taus = a->mem.alloc<float>(ceil_to(R, 4)); a->q_cosx = a->mem.alloc<float>(R * 64); a->q_x = a->mem.alloc<float>(R * L->feat);
             if (fqf) { a->f_logits = a->mem.alloc<float>((long long)E * 32); a->f_tau_all = a->mem.alloc<float>((long long)E * (nt + 1)); }
+            static const bool no_planes = getenv("A0_NO_WPLANES") != nullptr;      // tuning aid (same bits)
+            if (!no_planes && a0_dense_fwd_wplanes_ok((int)R, 512, L->feat)) a->w_planes = a->mem.alloc<unsigned int>(a0_weight_planes_words(512, L->feat), false);
         } else if (dist) {
             a->h = a->mem.alloc<float>((long long)E * 512);
             a->head_slabs = a->mem.alloc<float>((long long)a0_dense_fwd_partial_slabs(E, L->Npad, 512) * E * L->Npad);
@@ -439,6 +442,10 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
     // NoisyLinear.forward composes mu + sigma * eps with the parameters as they are NOW (model.py:54-62): a rollout that does not start on a noise reset
     // recomposes the copies once (agent0_amd/deepq/agent.py Actor._rollout)
     if (L->d.noisy && a->steps % freq != 0) A0_CHECK(a0_actor_compose(V, stream));
+    // quantile actors (round 6): fc1's weight operand as term planes for the rollout's 80 GEMMs of E * K rows — split once here (and after every noise reset below)
+    // instead of in every tile of every GEMM; the same exact terms, the same bits
+    const bool planes = quant && a->w_planes && a0_dense_fwd_wplanes_ok(E * nt, 512, L->feat);
+    if (planes && !(L->d.noisy && a->steps % freq == 0)) A0_CHECK(a0_split_planes(V.Wf(), a->w_planes, 512, L->feat, stream));
     // scalar heads (Actor._rollout): the tail + env-step launch of step t also encodes the env's new observation (a0_actor_qhead_env_step_enc), so that step t + 1
     // starts with its features in place; the convolution weights do not change inside a rollout, the last step has no next one
     static const bool step_enc_on = getenv("A0_NO_X9") == nullptr && (getenv("A0_STEP_ENC") == nullptr || atoi(getenv("A0_STEP_ENC")) != 0);
@@ -450,6 +457,7 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
         if (L->d.noisy && a->steps % freq == 0) {      // agent.py:52-53: self.model.reset_noise() every reset_noise_freq steps, from the ACTOR's stream
             A0_CHECK(a0_rng_normal(a->rng.seed, 4 /* STREAM_NOISE */, a->rng.reserve(4, L->noise_len), 0.1f, V.noise, L->noise_len, stream));
             A0_CHECK(a0_actor_compose(V, stream));
+            if (planes) A0_CHECK(a0_split_planes(V.Wf(), a->w_planes, 512, L->feat, stream));
         }
         const uint8_t* cur_obs = a->obs[a->cur];
         a0_frames_arg f{cur_obs, nullptr, (long long)a->obs_bytes, 0};
@@ -470,7 +478,8 @@ extern "C" int a0_actor_rollout(a0_actor* a, a0_learner* L, a0_rbuf* R, float ep
                 A0_CHECK(a0_tau_cos_features(a->rng.seed, 3 /* STREAM_TAUS */, a->rng.reserve(3, rows), nullptr, 0, a->q_taus, a->q_cosx, rows, 64, stream));
             }
             A0_CHECK(a0_dense_fwd_mul(a->q_cosx, 64, on + L->cos.w(), on + L->cos.b(), a->act3, nt, a->q_x, rows, L->feat, 64, 1, stream));
-            A0_CHECK(a0_dense_fwd(a->q_x, L->feat, V.Wf(), V.bf(), a->h, rows, 512, L->feat, 1, a->fwd_scratch, stream));
+            if (planes) A0_CHECK(a0_dense_fwd_wplanes(a->q_x, L->feat, a->w_planes, V.bf(), a->h, rows, 512, L->feat, 1, stream));
+            else A0_CHECK(a0_dense_fwd(a->q_x, L->feat, V.Wf(), V.bf(), a->h, rows, 512, L->feat, 1, a->fwd_scratch, stream));
             const int ns = a0_dense_fwd_partial_slabs(rows, L->Npad, 512);
             A0_CHECK(a0_dense_fwd_partial(a->h, 512, V.Wh(), rows, L->Npad, 512, a->head_slabs, stream));
             const unsigned long long oa = a->rng.reserve(STREAM_EGREEDY_A, E), ou = a->rng.reserve(STREAM_EGREEDY_U, E);

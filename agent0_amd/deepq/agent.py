@@ -140,7 +140,7 @@ class Actor:
             else:
                 rng.uniform(rng.STREAM_TAUS, self.taus, E * self.n_tau)
             taus, aux, mode = self.taus, None, 1
-        ns = dev.head_slabs(self.ws, E, taus, self.n_tau, self._head_slabs, cos_ready=fused_cos)
+        ns = dev.head_slabs(self.ws, E, taus, self.n_tau, self._head_slabs, cos_ready=fused_cos, w_planes=getattr(self, "_planes_on", False))
         _, bh = dev.wb("head")
         return (self._head_slabs, ns, bh, L.Npad, L.A, self.n_tau, L.dueling, mode, aux, E, rng.seed, rng.STREAM_EGREEDY_A, rng.STREAM_EGREEDY_U,
                 rng.reserve(rng.STREAM_EGREEDY_A, E), rng.reserve(rng.STREAM_EGREEDY_U, E), float(epsilon), self.action, self.qmax_all[t * E:(t + 1) * E], ctrl, eps_ptr)
@@ -202,10 +202,18 @@ class Actor:
                     # not on the launch schedule (the rollout into a stage ring): there the rollout runs BESIDE the update block, which is the critical path, and a
                     # workgroup that holds a CU's LDS from the tail to the end of the encoder takes more from the block than the saved boundary gives (9.43 -> 9.75 ms)
                     and not isinstance(self.replay, StageRing))
+        # quantile actors (round 6): fc1's weight operand as bf16 term planes for the rollout's T GEMMs of E * K rows, split once here and after every noise reset
+        # (a0_split_planes; the same exact terms the GEMM forms per tile, hence the same bits — A0_NO_WPLANES: tuning aid)
+        self._planes_on = bool(self.quant_tail and bound and not test and self.fused_commit and hasattr(ops, "dense_fwd_wplanes") and os.environ.get("A0_NO_WPLANES") is None
+                               and ops.dense_fwd_wplanes_ok(E * self.n_tau, 512, self.L.feat))
+        if self._planes_on and not (cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0):
+            dev.refresh_fc1_planes()
         feat_ready = False
         for t in range(T):
             if cfg.learner.noisy_net and self.steps % cfg.learner.reset_noise_freq == 0:
                 self.model.reset_noise(rng=self.rng)
+                if self._planes_on:
+                    dev.refresh_fc1_planes()
             merged = bound and not test and (self.tail_env or (self.quant_tail and self.fused_commit))
             if not feat_ready:
                 self._act_device(epsilon, self.qs[t:t + 1], ctrl, eps_ptr, t, tail=not merged)

@@ -223,7 +223,15 @@ class DeviceNet:
         ops.dueling_fwd(ws.raw, L.Npad, ws.q, R, L.A, 1, L.dueling)
         return ws.q
 
-    def head_slabs(self, ws: Workspace, B, taus: torch.Tensor, n_tau: int, slabs: torch.Tensor, cos_ready: bool = False) -> int:
+    def refresh_fc1_planes(self):
+        """fc1's EFFECTIVE weights as bf16 term planes (a0_split_planes) for ``head_slabs(.., w_planes=True)``: the actor refreshes them when a rollout starts and after
+        every NoisyNet compose, and reuses them for the rollout's GEMMs of E * K rows (same exact terms as the GEMM would form per tile: same bits)."""
+        W, _ = self.wb("fc1")
+        if getattr(self, "fc1_planes", None) is None:
+            self.fc1_planes = torch.empty(self.ops.weight_planes_words(512, self.L.feat), dtype=torch.int32, device=self.flat.device)
+        self.ops.split_planes(W, self.fc1_planes, 512, self.L.feat)
+
+    def head_slabs(self, ws: Workspace, B, taus: torch.Tensor, n_tau: int, slabs: torch.Tensor, cos_ready: bool = False, w_planes: bool = False) -> int:
         """Quantile heads of a pass that is not differentiated, up to the head GEMM's split-K slabs [ns][B * n_tau][Npad] (the consumer kernel finishes
         the layer: a0_actor_quantile_tail_env_step).  Returns the slab count.  ``cos_ready``: ``ws.cosx`` already holds the fractions' cosine features (the launch that
         produced the fractions wrote them: a0_tau_cos_features / a0_fqf_taus_cos)."""
@@ -233,7 +241,10 @@ class DeviceNet:
             ops.cos_features(taus, ws.cosx, R, L.num_cosines)
         Wc, bc = self.wb("cos")
         ops.dense_fwd_mul(ws.cosx, L.num_cosines, Wc, bc, ws.act3, n_tau, ws.x, R, L.feat, L.num_cosines, True)
-        self._dense(ws.x, L.feat, "fc1", ws.h, R, True)
+        if w_planes:      # ``refresh_fc1_planes`` has run since fc1's effective weights last changed
+            ops.dense_fwd_wplanes(ws.x, L.feat, self.fc1_planes, self.wb("fc1")[1], ws.h, R, 512, L.feat, True)
+        else:
+            self._dense(ws.x, L.feat, "fc1", ws.h, R, True)
         Wh, _ = self.wb("head")
         return ops.dense_fwd_partial(ws.h, 512, Wh, R, L.Npad, 512, slabs)
 

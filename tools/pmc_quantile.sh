@@ -22,7 +22,7 @@ for algo in ("iqn", "fqf"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             key = None
-            if "a0_igemm_x9_kernel<OpMatKC, OpMatKC, Epi" in k:
+            if "a0_igemm_x9_kernel<OpMatKC, OpMatKC, Epi" in k or "a0_igemm_x9_kernel<OpMatKC, OpPlanesKC, Epi" in k:      # (the actor's fc1 reads W as term planes since round 6)
                 key = "dense_fwd_gemm"
             elif "a0_short_k_fwd_kernel" in k:
                 key = "short_k_fwd"
