@@ -222,6 +222,9 @@ template <class OA, class OB, int WM, int WN, int MT, int NT, int KS = 2> struct
     static constexpr int LDS_BYTES = 2 * (ABYTES + BBYTES);                 // double-buffered
 };
 
+template <class EP> struct a0_is_hadamard { static constexpr bool value = false; };
+template <> struct a0_is_hadamard<EpiHadamard> { static constexpr bool value = true; };
+
 // Cross products of the three-term splits that are formed (NPR): 9 = all of them (every partial product of the fp32 fmaf chain, exactly: the strict mode), 6 = those
 // with term orders i + j <= 2 — a1*b2, a2*b1 and a2*b2 are left out, each below 2^-24 of a*b, i.e. below the rounding the fp32 chain itself applies to every partial SUM
 // (tools/check_bf16x9.hip, profiles/r06_x6_accuracy.txt: against fp64 the six-product sum is at least as close as the fmaf chain at every K of the path).  Chosen at run
@@ -386,6 +389,42 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
     }
 
     // C/D layout of v_mfma_f32_32x32x16_bf16 == that of 32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if constexpr (a0_is_hadamard<EP>::value) {
+        // EpiHadamard: a wave holds MT * 32 consecutive rows = whole samples (n = 32: one per 32-row block; n = 64 with MT = 2: one per wave; the launcher checks), so the
+        // sum over a sample's rows is 16 values per lane and block plus the partner lane that holds the other 16 rows of the block — no atomics, a fixed order
+        static_assert(MT == 2, "EpiHadamard: waves of 64 rows");
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int y = y0 + wn * (NT * 32) + j * 32 + (lane & 31);
+            const bool yok = y < Y;
+            const int yy = yok ? y : 0;
+            float s64 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int xb = x0 + wm * (MT * 32) + i * 32;                  // first row of the block (a multiple of 32)
+                const int bsmp = xb / pe.n;                                   // the sample these rows belong to
+                const float f = pe.feat[(long long)bsmp * pe.ld + yy];
+                float sacc = 0.f;
+                float ev[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ev[r] = pe.emb[(long long)(xb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * pe.ld + yy];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long idx = (long long)(xb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * pe.ld + yy;
+                    const float g = acc[i][j][r];
+                    if (yok) pe.demb[idx] = (ev[r] > 0.f) ? g * f : 0.f;
+                    sacc += g * ev[r];
+                }
+                sacc += __shfl_xor(sacc, 32, 64);
+                if (pe.n == 32) { if (yok && lane < 32) pe.d3[(long long)bsmp * pe.ld + y] = (f > 0.f) ? sacc : 0.f; }
+                else {
+                    s64 += sacc;
+                    if (i == MT - 1 && yok && lane < 32) pe.d3[(long long)bsmp * pe.ld + y] = (f > 0.f) ? s64 : 0.f;
+                }
+            }
+        }
+        return;
+    }
     const int z = bz;
 #pragma unroll
     for (int i = 0; i < MT; ++i)

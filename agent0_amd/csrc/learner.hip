@@ -586,8 +586,12 @@ extern "C" int a0_learner_update(a0_learner* L, const uint8_t* frames, const int
         const int R = (int)L->qo.R;
         A0_CHECK(a0_dueling_bwd(L->qo.dq, L->draw, L->Npad, R, A, 1, L->d.dueling ? 1 : 0, stream));
         A0_CHECK(a0_dense_dgrad(L->draw, L->Wh(false), L->qo.h, L->dh, R, L->Npad, 512, stream));
-        A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), nullptr, L->qo.dx, R, 512, L->feat, stream));
-        A0_CHECK(a0_hadamard_bwd(L->qo.dx, L->qo.emb, L->act3_o, L->qo.demb, L->d3, B, N, L->feat, stream));
+        if (a0_dense_dgrad_hadamard_ok(R, 512, L->feat, N)) {      // round 6: dx = dh W never reaches HBM (DeviceLearner._backward_dense takes the same branch)
+            A0_CHECK(a0_dense_dgrad_hadamard(L->dh, L->Wf(false), L->qo.emb, L->act3_o, L->qo.demb, L->d3, R, 512, L->feat, N, stream));
+        } else {
+            A0_CHECK(a0_dense_dgrad(L->dh, L->Wf(false), nullptr, L->qo.dx, R, 512, L->feat, stream));
+            A0_CHECK(a0_hadamard_bwd(L->qo.dx, L->qo.emb, L->act3_o, L->qo.demb, L->d3, B, N, L->feat, stream));
+        }
         {
             const float* dY[3] = {L->draw, L->dh, L->qo.demb};
             const float* X[3] = {L->qo.h, L->qo.x, L->qo.cosx};

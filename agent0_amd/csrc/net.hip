@@ -750,6 +750,28 @@ extern "C" int a0_dense_dgrad(const float* dY, const float* W, const float* act_
     A0_CATCH
 }
 
+// a0_dense_dgrad(dY, W, no mask) + a0_hadamard_bwd in ONE launch (round 6): dx = dY W [R][K] is consumed in the GEMM's epilogue (EpiHadamard) and never written — R = B * n rows,
+// n = 32 or 64 fractions per sample, R a multiple of 256 (whole 256 x 128 tiles along the rows: a wave's 64 rows are whole samples), N (the reduction, fc1's 512) a multiple of 16.
+// demb is bit-identical to the two calls' (the same accumulators times the same features); d3 sums the sample's rows in the tile's register order instead of row by row
+// (fp32 rounding: 1e-7 of the accumulated magnitude).
+extern "C" int a0_dense_dgrad_hadamard_ok(int R, int N, int K, int n) {
+    static const bool off = getenv("A0_NO_DGRAD_HADAMARD") != nullptr;      // tuning aid
+    return (!off && g_gemm_x9 != 0 && (n == 32 || n == 64) && R >= 4096 && !(R & 255) && !(R % n) && !(N & 15) && N >= 64 && !(K & 3) && K >= 128) ? 1 : 0;
+}
+extern "C" int a0_dense_dgrad_hadamard(const float* dY, const float* W, const float* emb, const float* feat, float* demb, float* d3, int R, int N, int K, int n, void* stream) {
+    A0_TRY
+    if (!dY || !W || !emb || !feat || !demb || !d3 || !a0_dense_dgrad_hadamard_ok(R, N, K, n)) return a0_fail(A0_EINVAL, "a0_dense_dgrad_hadamard: shapes a0_dense_dgrad_hadamard_ok accepts");
+    const a0_mat_src a{dY, N};
+    const a0_mat_src bw{W, K};
+    const EpiHadamard::Params e{emb, feat, demb, d3, K, n};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool probe = a0_probe_events(A0_TAG_DENSE_DGRAD, &e0, &e1);
+    A0_HIP_THROW((a0_igemm_x9_launch<OpMatKC, OpMatXC, EpiHadamard, 4, 2, 2, 2, 1>((hipStream_t)stream, a, bw, e, R, K, N, 1, e0, e1)));
+    if (probe) a0_probe_commit(2.0 * (double)R * (double)N * (double)K);
+    return A0_OK;
+    A0_CATCH
+}
+
 // a0_dense_dgrad (with the ReLU mask) and the unsplit a0_dense_wgrad of ONE layer — same dY, R x N x K with as many 64 x 64 tiles in the data gradient (R x K) as in the
 // weight gradient (N x K): N == R — as one launch (a0_igemm_x9_pair_kernel).  fc1 of a 512-row batch: dX = (dY W) * (X > 0) into dX, dW = dY^T X (+ bias row sums) into grad.
 // Bit-identical to the two calls.  Shapes: a0_dense_dgrad_wgrad_ok.

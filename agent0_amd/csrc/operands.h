@@ -265,6 +265,17 @@ struct EpiDgrad {              // scatter-free data gradient: row x = (b, h2, w2
     }
 };
 
+// The quantile networks' dx = dh W_fc1 [B * n][feat] consumed where it is produced (round 6; == a0_dense_dgrad + a0_hadamard_bwd, model.py:244-247 backwards):
+//   demb[x][y] = emb[x][y] > 0 ? dx * feat[x / n][y] : 0        (gradient w.r.t. the cosine layer's pre-activation)
+//   d3[b][y]   = feat[b][y] > 0 ? sum over the sample's n rows of dx * emb : 0
+// dx never goes to HBM (411 MB written and read back at B * n = 32 768).  Not a per-element store: the GEMM body reduces over the n rows of a sample inside the wave
+// that holds them (igemm_x9.h, a0_is_hadamard).
+struct EpiHadamard {
+    static constexpr bool ROWSUM_A = false;
+    struct Params { const float* emb; const float* feat; float* demb; float* d3; int ld; int n; };
+    A0_HD static void store(const Params&, int, int, float, int) {}
+};
+
 struct EpiMaskMat {            // dX[x][y] = act[x][y] > 0 ? v : 0   (dense layers)
     static constexpr bool ROWSUM_A = false;
     struct Params { float* dx; const float* act; int ld; };

@@ -398,8 +398,12 @@ class DeviceLearner:
         else:
             n = ws.n_tau
             wg.append((ws.dh, ws.x, L.feat, self._grad("fc1"), R, 512, L.feat))
-            ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
-            ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
+            if hasattr(ops, "dense_dgrad_hadamard") and ops.dense_dgrad_hadamard_ok(R, 512, L.feat, n):
+                # round 6: dx = dh W never reaches HBM — the embedding product's backward runs in the data-gradient GEMM's epilogue
+                ops.dense_dgrad_hadamard(ws.dh, Wf, ws.emb, ws.act3, ws.demb, ws.d3, R, 512, L.feat, n)
+            else:
+                ops.dense_dgrad(ws.dh, Wf, None, ws.dx, R, 512, L.feat)
+                ops.hadamard_bwd(ws.dx, ws.emb, ws.act3, ws.demb, ws.d3, B, n, L.feat)
             wg.append((ws.demb, ws.cosx, L.num_cosines, self._grad("cos"), R, L.feat, L.num_cosines))
         # data parallelism exchanges the dense range right after this call: its reductions cannot wait for the encoder's launch then
         defer = self._defer_dense and self.grad_hook is None

@@ -276,6 +276,15 @@ class HipOps:
                                     _req(Y, torch.float32, R * N, "Y"), R, N, K, int(relu),
                                     _req(scratch, torch.float32, need, "scratch", optional=(need == 0)), _stream()), "a0_dense_fwd")
 
+    def dense_dgrad_hadamard_ok(self, R, N, K, n) -> bool:
+        return bool(self.lib.a0_dense_dgrad_hadamard_ok(R, N, K, n))
+
+    def dense_dgrad_hadamard(self, dY, W, emb, feat, demb, d3, R, N, K, n):
+        """dense_dgrad(dY, W, no mask) + hadamard_bwd in one launch: dx = dY W is consumed in the GEMM's epilogue (a0_dense_dgrad_hadamard)."""
+        check(self.lib.a0_dense_dgrad_hadamard(_req(dY, torch.float32, R * N, "dY"), _req(W, torch.float32, N * K, "W"), _req(emb, torch.float32, R * K, "emb"),
+                                               _req(feat, torch.float32, (R // n) * K, "feat"), _req(demb, torch.float32, R * K, "demb"), _req(d3, torch.float32, (R // n) * K, "d3"),
+                                               R, N, K, n, _stream()), "a0_dense_dgrad_hadamard")
+
     def weight_planes_words(self, N, K) -> int:
         return int(self.lib.a0_weight_planes_words(N, K))
 

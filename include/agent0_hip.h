@@ -312,6 +312,10 @@ int a0_tau_cos_features(unsigned long long seed, unsigned int stream, unsigned l
                         long long R, int D, void* stream_h);
 int a0_hadamard_fwd(const float* emb, const float* feat, float* x, int B, int n, int D, void* stream);
 int a0_hadamard_bwd(const float* dx, const float* emb, const float* feat, float* demb, float* d3, int B, int n, int D, void* stream);
+/* (round 6) a0_dense_dgrad(dY [R][N], W [N][K], no mask) + a0_hadamard_bwd in one launch for R = B * n rows, n = 32 or 64: dx = dY W is consumed in the GEMM's epilogue and never
+ * reaches HBM.  demb [R][K] is bit-identical to the two calls'; d3 [R / n][K] sums a sample's n rows in another order (fp32 rounding).  Shapes: a0_dense_dgrad_hadamard_ok. */
+int a0_dense_dgrad_hadamard_ok(int R, int N, int K, int n);
+int a0_dense_dgrad_hadamard(const float* dY, const float* W, const float* emb, const float* feat, float* demb, float* d3, int R, int N, int K, int n, void* stream);
 int a0_fqf_taus(const float* logits, int ld, float* taus, float* tau_hat, int B, int F, void* stream);
 /* (round 6) a0_fqf_taus + a0_cos_features(tau_hat) -> cos_out [B * F][D] in one launch (the actor's FQF step); the same bits as the two calls */
 int a0_fqf_taus_cos(const float* logits, int ld, float* taus, float* tau_hat, float* cos_out, int D, int B, int F, void* stream);

@@ -218,3 +218,33 @@ def test_six_and_nine_product_encoders_agree_to_fp32_rounding(hip):
         a, b = got[6][k], got[9][k]
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name
         assert not torch.equal(a, b), f"{name}: the switch selects a different kernel"
+
+
+@pytest.mark.parametrize("B,n", [(512, 64), (512, 32), (64, 64), (128, 32)])
+def test_data_gradient_with_the_embedding_product_in_its_epilogue(hip, B, n):
+    """a0_dense_dgrad_hadamard (round 6; reference model.py:244-247 backwards: x = relu(cosine_emb) * features): dx = dh W_fc1 consumed in the GEMM's epilogue.  demb must be
+    bit-identical to a0_dense_dgrad + a0_hadamard_bwd (the same accumulators times the same features); d3 sums a sample's n rows in the tile's register order instead of row by
+    row: equal to 2e-6 of sum_n |dx| |emb|, and within this file's fp64 bound."""
+    R, N, K = B * n, 512, 3136
+    assert hip.dense_dgrad_hadamard_ok(R, N, K, n)
+    g = recipe.gen(B + n)
+    dh = (g.standard_normal((R, N)) * 1e-3).astype(np.float32)
+    W = (g.standard_normal((N, K)) * 0.03).astype(np.float32)
+    emb = np.maximum(g.standard_normal((R, K)), 0).astype(np.float32)
+    feat = np.maximum(g.standard_normal((B, K)), 0).astype(np.float32)
+    dhd, Wd, embd, featd = D(hip, dh), D(hip, W), D(hip, emb), D(hip, feat)
+    dx, demb0, d30 = hip.empty(R * K), hip.empty(R * K), hip.empty(B * K)
+    hip.dense_dgrad(dhd, Wd, None, dx, R, N, K)
+    hip.hadamard_bwd(dx, embd, featd, demb0, d30, B, n, K)
+    demb1, d31 = hip.empty(R * K).fill_(float("nan")), hip.empty(B * K).fill_(float("nan"))
+    hip.dense_dgrad_hadamard(dhd, Wd, embd, featd, demb1, d31, R, N, K, n)
+    assert torch.equal(demb0, demb1), "demb"
+    scale = (dx.view(B, n, K).abs().double() * embd.view(B, n, K).abs().double()).sum(1).clamp_min(1e-30)
+    err = ((d30.view(B, K).double() - d31.view(B, K).double()).abs() / scale).max().item()
+    assert err < 2e-6, f"d3 differs by {err:.3e} of the accumulated magnitude"
+    assert torch.equal(d30 == 0, d31 == 0) or float(((d30 == 0) != (d31 == 0)).float().mean()) < 1e-5, "the feature mask"
+    rows = slice(0, 4 * n)                          # fp64 reference on the first four samples
+    dx64 = dh[rows].astype(np.float64) @ W.astype(np.float64)
+    want = np.where(feat[:4] > 0, (dx64 * emb[rows]).reshape(4, n, K).sum(1), 0.0)
+    sc = (np.abs(dh[rows]).astype(np.float64) @ np.abs(W).astype(np.float64) * np.abs(emb[rows])).reshape(4, n, K).sum(1)
+    _scale_close(d31.view(B, K)[:4].cpu().numpy(), want, sc, "d3 against fp64")
