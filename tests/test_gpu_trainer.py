@@ -578,9 +578,11 @@ def test_learner_handle_exchanges_gradients_itself_one_rank_group(extra):
     base = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, A0_PROBE="none", HSA_ENABLE_IPC_MODE_LEGACY="0")
     lines = {}
     runs = (("python plain", dict(A0_NATIVE_LOOP="0", A0_DP_FORCE="0")), ("native plain", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="0")),
-            ("python dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1", A0_NATIVE_LOOP_DP="0")), ("native dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1")))
+            ("python dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1", A0_NATIVE_LOOP_DP="0")), ("native dp", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1")),
+            # the form a group of MORE than one rank takes (dense bucket on the side stream beside the encoder backward, three cross-stream hand-offs), forced at one rank
+            ("native dp side stream", dict(A0_NATIVE_LOOP="1", A0_DP_FORCE="1", A0_DP_ONE_STREAM="0")))
     if extra:      # the second configuration: the handle's exchange against the plain handle run only (the Python classes' two runs are the first configuration's)
-        runs = (runs[1], runs[3])
+        runs = (runs[1], runs[3], runs[4])
     for name, env in runs:
         r = subprocess.run(cmd, env=dict(base, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
@@ -590,7 +592,7 @@ def test_learner_handle_exchanges_gradients_itself_one_rank_group(extra):
     if not extra:
         assert handles not in lines["python plain"]["config"]["host_loop"] and handles not in lines["python dp"]["config"]["host_loop"]      # A0_NATIVE_LOOP_DP=0 keeps a data-parallel run on the Python classes
         assert "captured" in lines["python dp"]["gradient_exchange"]
-    assert "a0_learner_set_exchange" in lines["native dp"]["gradient_exchange"]
+    assert "a0_learner_set_exchange" in lines["native dp"]["gradient_exchange"] and "a0_learner_set_exchange" in lines["native dp side stream"]["gradient_exchange"]
     losses = {k: v["last_loss"] for k, v in lines.items()}
     assert len(set(losses.values())) == 1 and losses["native dp"] is not None, losses
     assert lines["native dp"]["rccl"]["nranks"] == 1 and lines["native dp"]["rccl"]["allreduce_of_ones"] == 1.0
