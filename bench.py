@@ -99,8 +99,9 @@ def cpu_baseline(args, cfg):
       (ii)  the actor's Q-forward + argmax at E = 16 and E = 256;
       (iii) the reference's replay (oracle.replay.ReferenceReplay): extend, uniform permutation sample of B = 512 rows, importance weights — bytes/s of 56 448-byte rows;
       (iv)  one whole Trainer iteration at BASELINE configs[0]'s sizes (16 envs x 80 steps + 20 updates of B = 512, synthetic env on the CPU).
-    ``value`` = the bench workload's iteration composed from (i) and (ii): sample_steps x act(E) + learner_steps x update(algo); env stepping, lz4 and the
-    data-loader processes the reference also pays are NOT included, so this flatters the CPU."""
+      (v)   round 6: one whole Trainer iteration at the BENCH workload's sizes (E envs x sample_steps + learner_steps updates of B), measured end to end.
+    ``value`` = (v) for scalar / distributional heads; for the quantile networks (an iteration would take minutes) the iteration composed from (i) and (ii): sample_steps x
+    act(E) + learner_steps x update(algo), which leaves out env stepping and replay.  lz4 and the data-loader processes the reference also pays are never included."""
     import numpy as np
     import torch
 
@@ -197,13 +198,31 @@ def cpu_baseline(args, cfg):
     items["iv_config0_iteration"] = {"ms": round(1e3 * t_c0, 1), "env_frames_per_sec": round(16 * 80 / t_c0, 1),
                                      "what": "oracle Trainer iteration: 80 steps x 16 synthetic envs (actor forward, eps-greedy, n-step, extend) + 20 updates of B=512, "
                                              "100 000-slot replay, first iteration (training_start_steps lowered to 0)"}
-    torch.set_num_threads(keep_threads)
     t_upd, t_act = upd[algo0]["ms"] * 1e-3, act[E]
     t_iter = args.sample_steps * t_act + args.learner_steps * t_upd
-    return {"value": round(args.sample_steps * E / t_iter, 1), "unit": "env-frames/sec", "cores": cores["used"], "kind": "port", "host_cores": cores,
-            "sample": f"{upd[algo0]['runs']} oracle {algo0} updates at B={B} ({upd[algo0]['ms']:.1f} ms each) + oracle actor forwards at E={E} ({t_act*1e3:.2f} ms each), "
-                      f"extrapolated to one iteration of {args.sample_steps} actor steps + {args.learner_steps} updates; torch threads = {cores['used']}",
-            "items": items}
+    composed = round(args.sample_steps * E / t_iter, 1)
+    items["composed_from_i_and_ii"] = {"env_frames_per_sec": composed,
+                                       "what": f"{upd[algo0]['runs']} oracle {algo0} updates at B={B} ({upd[algo0]['ms']:.1f} ms each) + oracle actor forwards at E={E} ({t_act*1e3:.2f} ms each), "
+                                               f"extrapolated to one iteration of {args.sample_steps} actor steps + {args.learner_steps} updates: env stepping, n-step bookkeeping and replay are NOT "
+                                               "included (round 5's `value`)"}
+    # (v) round 6: ONE whole iteration of the bench workload itself, measured end to end on the oracle — actor forwards, epsilon-greedy, the synthetic env on the CPU, n-step
+    # bookkeeping, replay extend, sampling and `learner_steps` updates of batch B (a 100 000-slot replay: the rows of one rollout are 1.2 GB) — for the scalar / distributional heads
+    # (a quantile network's iteration would take minutes: its `value` stays the composed figure)
+    value, sample = composed, items["composed_from_i_and_ii"]["what"]
+    if algo0 in ("dqn", "mdqn", "c51", "qr") and not cfg.learner.noisy_net:
+        ot = OracleTrainer(spec0, recipe.make_state_dict(spec0, 1), num_envs=E, sample_steps=args.sample_steps, batch_size=B, replay_size=100_000, learner_steps=args.learner_steps,
+                           training_start_steps=0, policy=cfg.replay.policy.name, n_step=cfg.learner.n_step_q, double_q=cfg.learner.double_q)
+        t0 = time.time()
+        ot.iteration()
+        t_it = time.time() - t0
+        value = round(args.sample_steps * E / t_it, 1)
+        items["v_bench_workload_iteration"] = {"ms": round(1e3 * t_it, 1), "env_frames_per_sec": value}
+        sample = (f"one whole oracle Trainer iteration at the bench workload's sizes, measured end to end ({t_it:.1f} s): {args.sample_steps} steps x {E} synthetic envs on the CPU (actor forward, "
+                  f"eps-greedy, n-step, replay extend) + {args.learner_steps} {algo0} updates of B={B}, 100 000-slot replay, first iteration; torch threads = {cores['used']}.  "
+                  f"(Composed from the update and forward timings alone, without env stepping and replay: {composed} env-frames/s, items.composed_from_i_and_ii)")
+        del ot
+    torch.set_num_threads(keep_threads)
+    return {"value": value, "unit": "env-frames/sec", "cores": cores["used"], "kind": "port", "host_cores": cores, "sample": sample, "items": items}
 
 
 def rank_clock(dist, dt: float, dt_local: float, rank: int, world: int, steps: int, device):
