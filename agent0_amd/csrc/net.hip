@@ -266,6 +266,8 @@ struct a0_hip_backend {
             }
             // (round 6, six products: the same 128 x 128 tile on FOUR waves of 64 x 64 — a third fewer LDS fragment reads per MFMA, one wave per SIMD — measured 139.9 vs
             // 137.7 us on the actor's 8 192-row fc1, iqn 86.4 vs 85.9 ms: not kept, profiles/r06_experiments.md)
+            // (round 6: TWO four-wave workgroups per CU on 128 x 64 x 16 tiles — independent barriers, so the SIMD partners are not in lockstep — measured 211 vs 177 us at
+            // 8 192 rows, 319 vs 322 at 16 384: not kept, profiles/r06_experiments.md)
             if (x9 && large) { A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, 4, 2, 1, 2>(st, pa, pb, pe, X, Y, K, splits, e0, e1))); carried = true; }
             else if (x9 && (!wgrad_family || (deep && !a0_is_gather<OB>::value))) { A0_HIP_THROW((a0_igemm_x9_launch<OA, OB, EP, WM, WN, MT, NT>(st, pa, pb, pe, X, Y, K, splits, e0, e1))); carried = true; }
             else {
