@@ -84,15 +84,18 @@ template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS
         ki = OP::kinfo(P, kb + 4 * (tid % TPR), ke);
     }
     // pieces of one tile are fetched in the order j = 0 .. R-1; the last one moves the k state on to the next tile
-    A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
+    // FULL (the body's launch-time choice: no partial k tile anywhere in the launch): nothing is zero-filled — rows past the edge read valid memory and feed only outputs
+    // that are never stored, tiles past the k range are staged and never multiplied — so the ok bits are neither kept nor applied
+    template <bool FULL = false> A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
         bool ok;
         s.raw[j] = OP::load(P, rows[j], ki, ok);
-        s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
+        if constexpr (!FULL) s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
         if (j == R - 1) ki = OP::kinfo(P, k0 + 16 * KS + 4 * (tid % TPR), ke);
     }
-    template <bool RS> A0_D a0_f4 value(const Slot& s, int j, a0_f4&) const {
+    template <bool RS, bool FULL = false> A0_D a0_f4 value(const Slot& s, int j, a0_f4&) const {
         static_assert(!RS, "row sums are taken from x-contiguous A operands");
-        return OP::finish(s.raw[j], (s.okmask >> j) & 1u);
+        if constexpr (FULL) return OP::finish(s.raw[j], true);
+        else return OP::finish(s.raw[j], (s.okmask >> j) & 1u);
     }
     A0_D void store(const a0_x9_piece& pc, int j, char* lds, int tid) const {
         const int r = tid / TPR + RPP * j;
@@ -122,13 +125,13 @@ template <class OP, int BX, int NTH, int KS> struct a0_x9_stager<OP, BX, NTH, KS
 #pragma unroll
         for (int j = 0; j < R; ++j) xi[j] = OP::xinfo(P, x0 + 4 * ((tid + NTH * j) % Q), X);
     }
-    A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
+    template <bool FULL = false> A0_D void fetch_piece(const typename OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
         bool ok;
         s.raw[j] = OP::load(P, k0 + (tid + NTH * j) / Q, ke, xi[j], ok);
-        s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
+        if constexpr (!FULL) s.okmask = (s.okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
     }
-    template <bool RS> A0_D a0_f4 value(const Slot& s, int j, a0_f4& rowsum) const {
-        const a0_f4 v = OP::finish(s.raw[j], (s.okmask >> j) & 1u);
+    template <bool RS, bool FULL = false> A0_D a0_f4 value(const Slot& s, int j, a0_f4& rowsum) const {
+        const a0_f4 v = FULL ? OP::finish(s.raw[j], true) : OP::finish(s.raw[j], (s.okmask >> j) & 1u);
         if constexpr (RS) { rowsum.x += v.x; rowsum.y += v.y; rowsum.z += v.z; rowsum.w += v.w; }
         return v;
     }
@@ -195,11 +198,11 @@ template <int BX, int NTH, int KS> struct a0_x9_stager<OpPlanesKC, BX, NTH, KS, 
         for (int j = 0; j < R; ++j) rows[j] = OP::row(P, x0 + tid / TPR + RPP * j, X);
         ki = OP::kinfo(P, kb + 4 * (tid % TPR), ke);
     }
-    A0_D void fetch_piece(const OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
+    template <bool FULL = false> A0_D void fetch_piece(const OP::Params& P, Slot& s, int j, int k0, int ke, int tid) {
         s.raw[j] = OP::load(P, rows[j], ki);
         if (j == R - 1) ki = OP::kinfo(P, k0 + 16 * KS + 4 * (tid % TPR), ke);
     }
-    template <bool RS> A0_D a0_f4 value(const Slot&, int, a0_f4&) const { return a0_zero4(); }      // (never called: PRESPLIT pieces skip the split micro-steps)
+    template <bool RS, bool FULL = false> A0_D a0_f4 value(const Slot&, int, a0_f4&) const { return a0_zero4(); }      // (never called: PRESPLIT pieces skip the split micro-steps)
     A0_D void store(const a0_x9_piece&, int, char*, int) const {}
     A0_D void store_raw(const Slot& s, int j, char* lds, int tid) const {
         const int r = tid / TPR + RPP * j;
@@ -222,6 +225,12 @@ template <class OA, class OB, int WM, int WN, int MT, int NT, int KS = 2> struct
     static constexpr int LDS_BYTES = 2 * (ABYTES + BBYTES);                 // double-buffered
 };
 
+// plain matrix operands (no gather tables, no padding semantics): eligible for the unmasked staging of FULL launches
+template <class OP> struct a0_x9_plain { static constexpr bool value = false; };
+template <> struct a0_x9_plain<OpMatKC> { static constexpr bool value = true; };
+template <> struct a0_x9_plain<OpMatXC> { static constexpr bool value = true; };
+struct OpPlanesKC;
+template <> struct a0_x9_plain<OpPlanesKC> { static constexpr bool value = true; };
 template <class EP> struct a0_is_hadamard { static constexpr bool value = false; };
 template <> struct a0_is_hadamard<EpiHadamard> { static constexpr bool value = true; };
 
@@ -230,7 +239,7 @@ template <> struct a0_is_hadamard<EpiHadamard> { static constexpr bool value = t
 // (tools/check_bf16x9.hip, profiles/r06_x6_accuracy.txt: against fp64 the six-product sum is at least as close as the fmaf chain at every K of the path).  Chosen at run
 // time (a0_x9_products(), A0_X9_PRODUCTS=9|6); both forms of every instantiation are in the library.
 int a0_x9_products_now();
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9, bool FULL = false>
 __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, const typename OB::Params& pb,
                                                  const typename EP::Params& pe, int X, int Y, int K, int kchunk, int gx, int gy) {
     static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
@@ -284,8 +293,8 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
 
     // piece p of a tile: p < RA -> A slot row-group p, else B slot row-group p - RA
     auto fetch_piece = [&](typename SA::Slot& s_a, typename SB::Slot& s_b, int p, int k0) {
-        if (p < RA) sa.fetch_piece(pa, s_a, p, k0, ke, tid);
-        else sb.fetch_piece(pb, s_b, p - RA, k0, ke, tid);
+        if (p < RA) sa.template fetch_piece<FULL>(pa, s_a, p, k0, ke, tid);
+        else sb.template fetch_piece<FULL>(pb, s_b, p - RA, k0, ke, tid);
     };
     // micro-step u of a tile's staging work: piece u / 6 (A row-groups first, then B), step u % 6 = finish | split e0..e3 | pack + store + refetch
     a0_x9_piece pc;
@@ -299,8 +308,8 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
             }
         }
         if (st == 0) {
-            if (p < RA) pc.v = sa.template value<EP::ROWSUM_A>(s_a_c, p, rowsum);
-            else pc.v = sb.template value<false>(s_b_c, p - RA, rowsum);
+            if (p < RA) pc.v = sa.template value<EP::ROWSUM_A, FULL>(s_a_c, p, rowsum);
+            else pc.v = sb.template value<false, FULL>(s_b_c, p - RA, rowsum);
         } else if (st <= 4) {
             pc.split(st - 1);
         } else {
@@ -439,10 +448,10 @@ __device__ __forceinline__ void a0_igemm_x9_body(const typename OA::Params& pa, 
         }
 }
 
-template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9>
+template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS = 2, int NPR = 9, bool FULL = false>
 __global__ __launch_bounds__(WM * WN * 64) void a0_igemm_x9_kernel(typename OA::Params pa, typename OB::Params pb,
                                                            typename EP::Params pe, int X, int Y, int K, int kchunk, int gx, int gy) {
-    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS, NPR>(pa, pb, pe, X, Y, K, kchunk, gx, gy);
+    a0_igemm_x9_body<OA, OB, EP, WM, WN, MT, NT, KS, NPR, FULL>(pa, pb, pe, X, Y, K, kchunk, gx, gy);
 }
 
 // Up to three GEMMs of ONE shape (own operands and outputs each) in one launch: blockIdx.y names the problem.  The point is not the launch it saves but the split: a
@@ -565,16 +574,25 @@ template <class OA, class OB, class EP, int WM, int WN, int MT, int NT, int KS =
 static inline hipError_t a0_igemm_x9_launch(hipStream_t st, const typename OA::Params& pa, const typename OB::Params& pb,
                                             const typename EP::Params& pe, int X, int Y, int K, int splits, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     typedef a0_x9_geom<OA, OB, WM, WN, MT, NT, KS> G;
-    const int six = a0_x9_products_now() == 6;
-    auto kern = six ? a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 6> : a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 9>;
-    static bool configured[2] = {false, false};           // per instantiation: more than 64 KB of dynamic LDS needs the attribute
-    if (!configured[six]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        configured[six] = true;
-    }
     if (splits < 1) splits = 1;
     constexpr int BK = 16 * KS;
+    // FULL (round 6): no partial k tile anywhere in the launch (K a multiple of the tile depth) and plain matrix operands without the row-sum by-product: the staging
+    // keeps and applies no validity masks (a fifth of its vector instructions; the vector issue port, not the matrix pipe, paces this kernel: profiles/r06_pmc_gemm.md)
+    constexpr bool can_full = a0_x9_plain<OA>::value && a0_x9_plain<OB>::value && !EP::ROWSUM_A;
+    static const bool full_off = getenv("A0_X9_NO_FULL") != nullptr;      // tuning aid (same bits)
+    const int six = a0_x9_products_now() == 6;
+    const int full = (can_full && !full_off && (K % BK) == 0) ? 1 : 0;
+    typedef void (*a0_kern_t)(typename OA::Params, typename OB::Params, typename EP::Params, int, int, int, int, int, int);
+    a0_kern_t kern;
+    if constexpr (can_full) kern = full ? (six ? (a0_kern_t)a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 6, true> : (a0_kern_t)a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 9, true>)
+                                        : (six ? (a0_kern_t)a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 6> : (a0_kern_t)a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 9>);
+    else kern = six ? (a0_kern_t)a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 6> : (a0_kern_t)a0_igemm_x9_kernel<OA, OB, EP, WM, WN, MT, NT, KS, 9>;
+    static bool configured[4] = {false, false, false, false};           // per instantiation: more than 64 KB of dynamic LDS needs the attribute
+    if (!configured[2 * full + six]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured[2 * full + six] = true;
+    }
     const int ktiles = (K + BK - 1) / BK;
     const int kchunk = ((ktiles + splits - 1) / splits) * BK;
     const int gx = (X + G::BX - 1) / G::BX, gy = (Y + G::BY - 1) / G::BY;
