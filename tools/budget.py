@@ -145,7 +145,7 @@ def main():
         if name.startswith("void "):
             name = name[5:]
         if name.startswith("a0_igemm_x9"):          # the trailing template argument is the product count (round 6): the model rows are keyed without it
-            name = re.sub(r", [69]>", ">", name, count=1)
+            name = re.sub(r", [69](, (true|false))?>", ">", name, count=1)      # (and, for the plain GEMM, whether the launch runs without staging masks)
         per_iter = per_iteration(cfg, name)
         hit = next((k for k in md if name.startswith(k)), None)
         if hit is None or per_iter == 0:
